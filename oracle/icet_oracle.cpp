@@ -1,0 +1,572 @@
+// oracle/icet_oracle.cpp -- TEST INFRASTRUCTURE: CPU restatement of the reference hot path.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.  It is
+// the parity checker (and the timed CPU "port" baseline); the product path (icet_amd/csrc) never
+// calls into it.
+//
+// What it restates (all citations relative to /root/reference):
+//   ICET::ICET                 src/icet.cpp:29-63      -> Solver::run
+//   ICET::fitScan1             src/icet.cpp:68-107     -> Solver::fitScan1
+//   ICET::fitCells1            src/icet.cpp:109-252    -> Solver::fitCells1
+//   ICET::prepScan2            src/icet.cpp:254-277    -> Solver::prepScan2
+//   ICET::fitCells2            src/icet.cpp:279-344    -> Solver::fitCells2
+//   ICET::parallelFitCells2    src/icet.cpp:346-370    -> Solver::voxelLoopPool   (mode 1, 4 workers, src/icet.cpp:31)
+//   ICET::fitScan2             src/icet.cpp:372-436    -> Solver::fitScan2
+//   ICET::checkCondition       src/icet.cpp:443-492    -> Solver::checkCondition
+//   ICET::get_H                src/icet.cpp:494-532    -> get_H
+//   ICET::sortSphericalCoordinates src/icet.cpp:534-554 -> Solver::binPoints
+//   ICET::findCluster          src/icet.cpp:557-607    -> findCluster
+//   ICET::filterPointsInsideCluster src/icet.cpp:609-652 -> insideBounds (predicate form)
+//   ICET::testSigmaPoints      src/icet.cpp:654-696    -> inline in fitCells1
+//   utils::cartesianToSpherical src/utils.cpp:93-119   -> c2s
+//   utils::sphericalToCartesian src/utils.cpp:121-142  -> s2c
+//   utils::R                   src/utils.cpp:144-152   -> eulerR
+//   ThreadPool                 include/ThreadPool.h, ThreadPool.tpp, src/ThreadPool.cpp -> Pool
+//
+// Quirks Q1-Q14 of SURVEY.md section 8(a) are reproduced, not fixed.  Choices where the reference is
+// under-specified (documented deviations, cannot be checked against the real binary here):
+//   * std::sort(std::execution::par) tie order (src/icet.cpp:75,266) -> stable by original index.
+//   * Eigen is absent: decompositions restated in smalllinalg.h from Eigen 3.3.7's algorithms.
+//   * fitCells2 reading sigma1/U/L of a voxel whose scan-1 fit never ran (std::map default-inserts
+//     an uninitialised Matrix3f, src/icet.cpp:315-336) is undefined behaviour in the reference; here
+//     such a voxel contributes nothing and is counted in Trace::n_ub_voxels.
+//   * float expression contraction: built with -ffp-contract=off so results do not depend on the
+//     host's FMA support (the reference's -O3 -march=native build is free to fuse).
+// PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path
+// (SURVEY.md section 4), and neither its C++ (needs Eigen) nor its Python (needs TensorFlow)
+// can run in this image.
+#include "icet_oracle.h"
+#include "smalllinalg.h"
+
+#include <vector>
+#include <numeric>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <future>
+#include <queue>
+#include <functional>
+#include <atomic>
+#include <memory>
+#include <chrono>
+
+namespace ico {
+
+// ---------------------------------------------------------------- utils.cpp:93-152
+static inline void c2s_one(float x, float y, float z, float& r, float& th, float& ph) {
+    r = std::sqrt(x * x + y * y + z * z);               // rowwise().norm()
+    th = std::atan2(y, x);                              // float overload
+    if (th < 0.0) th = (float)((double)th + 2.0 * M_PI);
+    ph = std::acos(z / r);
+    if (std::isnan(r)) r = 1000.0f;                     // (isNaN).select(1000.0, .)
+    if (std::isnan(th)) th = 1000.0f;
+    if (std::isnan(ph)) ph = 1000.0f;
+}
+static inline void s2c_one(float r, float th, float ph, float& x, float& y, float& z) {
+    x = r * std::sin(ph) * std::cos(th);
+    y = r * std::sin(ph) * std::sin(th);
+    z = r * std::cos(ph);
+}
+static Mat eulerR(float phi, float theta, float psi) {
+    using std::cos; using std::sin;
+    Mat m(3, 3);
+    m(0,0) = cos(theta)*cos(psi); m(0,1) = sin(psi)*cos(phi)+sin(phi)*sin(theta)*cos(psi); m(0,2) = sin(phi)*sin(psi)-sin(theta)*cos(phi)*cos(psi);
+    m(1,0) = -sin(psi)*cos(theta); m(1,1) = cos(phi)*cos(psi)-sin(phi)*sin(theta)*sin(psi); m(1,2) = sin(phi)*cos(psi)+sin(theta)*sin(psi)*cos(phi);
+    m(2,0) = sin(theta); m(2,1) = -sin(phi)*cos(theta); m(2,2) = cos(phi)*cos(theta);
+    return m;
+}
+
+// ---------------------------------------------------------------- icet.cpp:494-532
+static Mat get_H(const float mu[3], const float angs[3]) {
+    using std::cos; using std::sin;
+    float phi = angs[0], theta = angs[1], psi = angs[2];
+    Mat H(3, 6);
+    H(0,0) = -1.f; H(1,1) = -1.f; H(2,2) = -1.f;
+    float Jx[9] = {0.f, (-sin(psi)*sin(phi) + cos(phi)*sin(theta)*cos(psi)), (cos(phi)*sin(psi) + sin(theta)*sin(phi)*cos(psi)),
+                   0.f, (-sin(phi)*cos(psi) - cos(phi)*sin(theta)*sin(psi)), (cos(phi)*cos(psi) - sin(theta)*sin(psi)*sin(phi)),
+                   0.f, (-cos(phi)*cos(theta)), (-sin(phi)*cos(theta))};
+    float Jy[9] = {(-sin(theta)*cos(psi)), (cos(theta)*sin(phi)*cos(psi)), (-cos(theta)*cos(phi)*cos(psi)),
+                   (sin(psi)*sin(theta)), (-cos(theta)*sin(phi)*sin(psi)), (cos(theta)*sin(psi)*cos(phi)),
+                   (cos(theta)), (sin(phi)*sin(theta)), (-sin(theta)*cos(phi))};
+    float Jz[9] = {(-cos(theta)*sin(psi)), (cos(psi)*cos(phi) - sin(phi)*sin(theta)*sin(psi)), (cos(psi)*sin(phi) + sin(theta)*cos(phi)*sin(psi)),
+                   (-cos(psi)*cos(theta)), (-sin(psi)*cos(phi) - sin(phi)*sin(theta)*cos(psi)), (-sin(phi)*sin(psi) + sin(theta)*cos(psi)*cos(phi)),
+                   0.f, 0.f, 0.f};
+    for (int i = 0; i < 3; i++) {
+        H(i, 3) = Jx[3*i] * mu[0] + Jx[3*i+1] * mu[1] + Jx[3*i+2] * mu[2];
+        H(i, 4) = Jy[3*i] * mu[0] + Jy[3*i+1] * mu[1] + Jy[3*i+2] * mu[2];
+        H(i, 5) = Jz[3*i] * mu[0] + Jz[3*i+1] * mu[1] + Jz[3*i+2] * mu[2];
+    }
+    return H;
+}
+
+// ---------------------------------------------------------------- ThreadPool.{h,tpp,cpp}
+class Pool {
+public:
+    explicit Pool(size_t n) : stop(false) { for (size_t i = 0; i < n; i++) workers.emplace_back(&Pool::work, this); }
+    ~Pool() { stop.store(true); cv.notify_all(); for (auto& w : workers) w.join(); }
+    template <class F> auto enqueue(F&& f) -> std::future<decltype(f())> {
+        using R = decltype(f());
+        auto task = std::make_shared<std::packaged_task<R()>>(std::forward<F>(f));
+        std::future<R> res = task->get_future();
+        { std::unique_lock<std::mutex> lk(m); tasks.emplace([task]() { (*task)(); }); }
+        cv.notify_one();
+        return res;
+    }
+private:
+    void work() {
+        while (!stop) {
+            std::function<void()> t;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [this] { return stop.load() || !tasks.empty(); });
+                if (stop.load() && tasks.empty()) return;
+                t = std::move(tasks.front()); tasks.pop();
+            }
+            t();
+        }
+    }
+    std::vector<std::thread> workers; std::queue<std::function<void()>> tasks;
+    std::mutex m; std::condition_variable cv; std::atomic<bool> stop;
+};
+
+struct Sph { std::vector<float> r, th, ph; void resize(size_t n) { r.resize(n); th.resize(n); ph.resize(n); } };
+
+struct VoxelFit {            // what the reference keeps in sigma1/mu1/U/L std::maps (icet.h:89-94)
+    bool has_fit = false;
+    float mu[3] = {0, 0, 0};
+    Mat sigma{3, 3};
+    Mat V{3, 3};             // eigenvectors as columns; the reference stores U = V^T (icet.cpp:184)
+    float Ldiag[3] = {0, 0, 0};
+};
+
+struct Contribution { Mat HTWH{6, 6}; Mat HTWdz{6, 1}; int n_in = 0; float mu2[3] = {0, 0, 0}; Mat sigma2{3, 3}; bool used = false; };
+
+// ---------------------------------------------------------------- icet.cpp:557-607
+static std::pair<float, float> findCluster(const Sph& s, const int* idx, int numPoints, int n, float thresh, float buff) {
+    float innerDistance = 0.0f, outerDistance = 0.0f;
+    long count = 0; float front = 0.f, back = 0.f;      // localPoints.size(), .front()(0), .back()(0)
+    for (int i = 0; i < numPoints; i++) {
+        float pr = s.r[idx[i]];
+        if (count != 0 && std::abs(back - pr) <= thresh) {
+            back = pr; count++;
+        } else {
+            if (count >= n) {
+                innerDistance = front - buff;
+                outerDistance = back + buff;
+                return {innerDistance, outerDistance};
+            } else {
+                count = 1; front = pr; back = pr;
+            }
+        }
+    }
+    if (count >= n) {
+        if (count != 0 && front != 0) {
+            innerDistance = front - buff;
+            outerDistance = back + buff;
+            return {innerDistance, outerDistance};
+        } else {
+            return {0.0f, 0.0f};
+        }
+    }
+    return {innerDistance, outerDistance};
+}
+
+// icet.cpp:632-634 / 675-677 (closed float comparisons)
+static inline bool insideBounds(float r, float azim, float elev, const float* lims) {
+    return azim >= lims[0] && azim <= lims[1] && elev >= lims[2] && elev <= lims[3] && r >= lims[4] && r <= lims[5];
+}
+
+// In-place "sort" by r with the reference's one-step swap loop (icet.cpp:72-83, 264-274; quirk Q3).
+static void sortAndScramble(Sph& s) {
+    const int N = (int)s.r.size();
+    std::vector<int> index(N);
+    std::iota(index.begin(), index.end(), 0);
+    std::stable_sort(index.begin(), index.end(), [&](int a, int b) { return s.r[a] < s.r[b]; });
+    for (int i = 0; i < N; i++) {
+        if (index[i] != i) {
+            int j = index[i];
+            std::swap(s.r[i], s.r[j]); std::swap(s.th[i], s.th[j]); std::swap(s.ph[i], s.ph[j]);
+            std::swap(index[i], index[j]);
+        }
+    }
+}
+
+struct Solver {
+    icet_oracle_params prm;
+    int T, P, V, n;
+    std::vector<float> p1x, p1y, p1z;       // points1
+    std::vector<float> ogx, ogy, ogz;       // points2_OG
+    std::vector<float> p2x, p2y, p2z;       // points2
+    Sph sph1, sph2;
+    std::vector<int> bin1_start, bin1_idx;  // pointIndices1 as CSR over v = T*phi + theta
+    std::vector<int> bin2_start, bin2_idx;  // pointIndices2
+    std::vector<float> clusterBounds;       // V x 6
+    std::vector<VoxelFit> fit;
+    Mat HTWH_i{6, 6}, HTWdz_i{6, 1};
+    float X[6], dx[6], pred_stds[6];
+    Mat noise_mat{6, 6};
+    icet_oracle_trace* tr = nullptr;
+    int iter_no = 0;
+    std::unique_ptr<Pool> pool;
+
+    // icet.cpp:534-554.  Bins in double from float angles; lists hold ascending point index.
+    void binPoints(const Sph& s, std::vector<int>& start, std::vector<int>& idx) {
+        const int N = (int)s.r.size();
+        std::vector<int> b(N);
+        start.assign(V + 1, 0);
+        for (int i = 0; i < N; ++i) {
+            float theta = s.th[i], phi = s.ph[i];
+            int binTheta = static_cast<int>((theta / (2 * M_PI)) * T) % T;
+            int binPhi = static_cast<int>((phi / M_PI) * P) % P;
+            b[i] = T * binPhi + binTheta;
+            start[b[i] + 1]++;
+        }
+        for (int v = 0; v < V; v++) start[v + 1] += start[v];
+        idx.resize(N);
+        std::vector<int> cur(start.begin(), start.end() - 1);
+        for (int i = 0; i < N; i++) idx[cur[b[i]]++] = i;
+    }
+
+    void boundsRow(int theta, int phi, float inner, float outer) {
+        float azimMin_i = (static_cast<float>(theta) / T) * (2 * M_PI);
+        float azimMax_i = (static_cast<float>(theta + 1) / T) * (2 * M_PI);
+        float elevMin_i = (static_cast<float>(phi) / P) * (M_PI);
+        float elevMax_i = (static_cast<float>(phi + 1) / P) * (M_PI);
+        float* row = &clusterBounds[6 * (T * phi + theta)];
+        row[0] = azimMin_i; row[1] = azimMax_i; row[2] = elevMin_i; row[3] = elevMax_i; row[4] = inner; row[5] = outer;
+    }
+
+    // icet.cpp:109-252
+    void fitCells1(const int* indices, int cnt, int theta, int phi) {
+        const int v = T * phi + theta;
+        if ((size_t)cnt >= (size_t)n) {
+            auto cd = findCluster(sph1, indices, cnt, n, prm.thresh, prm.buff);
+            float innerDistance = cd.first, outerDistance = cd.second;
+            boundsRow(theta, phi, innerDistance, outerDistance);
+            const float* lims = &clusterBounds[6 * v];
+            std::vector<float> cx, cy, cz;
+            for (int k = 0; k < cnt; k++) {
+                int i = indices[k];
+                if (insideBounds(sph1.r[i], sph1.th[i], sph1.ph[i], lims)) {
+                    float x, y, z; s2c_one(sph1.r[i], sph1.th[i], sph1.ph[i], x, y, z);
+                    cx.push_back(x); cy.push_back(y); cz.push_back(z);
+                }
+            }
+            long rows = (long)cx.size();
+            if (outerDistance > 0.1 && rows * 3 >= n) {
+                VoxelFit& f = fit[v];
+                float mean[3] = {0, 0, 0};
+                for (long k = 0; k < rows; k++) { mean[0] += cx[k]; mean[1] += cy[k]; mean[2] += cz[k]; }
+                for (int a = 0; a < 3; a++) mean[a] /= (float)rows;
+                Mat cov(3, 3);
+                for (long k = 0; k < rows; k++) {
+                    float d[3] = {cx[k] - mean[0], cy[k] - mean[1], cz[k] - mean[2]};
+                    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) cov(a, b) += d[a] * d[b];
+                }
+                for (int a = 0; a < 9; a++) cov.a[a] = cov.a[a] / static_cast<float>(rows - 1);
+                f.has_fit = true; f.sigma = cov; for (int a = 0; a < 3; a++) f.mu[a] = mean[a];
+                float ev[3]; Mat evec(3, 3);
+                selfadjoint_eigen(cov, /*fixed3=*/true, ev, evec);
+                f.V = evec;
+                // axislen = 2*sqrt(lambda);  rotated = diag(axislen) * U^T = diag(axislen) * V  (rows!)  icet.cpp:187-193
+                float sp[6][3];
+                for (int k = 0; k < 3; k++) {
+                    float al = 2.0f * std::sqrt(ev[k]);
+                    for (int c = 0; c < 3; c++) {
+                        float rot = al * evec(k, c);
+                        sp[2 * k][c] = f.mu[c] + rot;
+                        sp[2 * k + 1][c] = f.mu[c] - rot;
+                    }
+                }
+                bool inside[6] = {false, false, false, false, false, false};
+                for (int j = 0; j < 6; j++) {       // icet.cpp:669-686 incl. the early break
+                    float r, az, el; c2s_one(sp[j][0], sp[j][1], sp[j][2], r, az, el);
+                    if (insideBounds(r, az, el, lims)) inside[j] = true;
+                    if (r > lims[5]) break;
+                }
+                for (int k = 0; k < 3; k++) f.Ldiag[k] = (inside[2 * k] || inside[2 * k + 1]) ? 1.f : 0.f;
+                if (tr) for (int j = 0; j < 6; j++) for (int c = 0; c < 3; c++) tr->sigma_points[(size_t)(6 * v + j) * 3 + c] = sp[j][c];
+            }
+        } else {
+            boundsRow(theta, phi, 0.f, 0.f);
+        }
+    }
+
+    // icet.cpp:68-107
+    void fitScan1() {
+        const int N = (int)p1x.size();
+        sph1.resize(N);
+        for (int i = 0; i < N; i++) c2s_one(p1x[i], p1y[i], p1z[i], sph1.r[i], sph1.th[i], sph1.ph[i]);
+        sortAndScramble(sph1);
+        binPoints(sph1, bin1_start, bin1_idx);
+        for (int phi = 0; phi < P; phi++)
+            for (int theta = 0; theta < T; theta++) {
+                int v = T * phi + theta;
+                fitCells1(&bin1_idx[bin1_start[v]], bin1_start[v + 1] - bin1_start[v], theta, phi);
+            }
+    }
+
+    // icet.cpp:254-277
+    void prepScan2() {
+        const int N = (int)p2x.size();
+        sph2.resize(N);
+        for (int i = 0; i < N; i++) c2s_one(p2x[i], p2y[i], p2z[i], sph2.r[i], sph2.th[i], sph2.ph[i]);
+        sortAndScramble(sph2);
+        ogx.resize(N); ogy.resize(N); ogz.resize(N);
+        for (int i = 0; i < N; i++) s2c_one(sph2.r[i], sph2.th[i], sph2.ph[i], ogx[i], ogy[i], ogz[i]);
+    }
+
+    // icet.cpp:279-344
+    Contribution fitCells2(int theta, int phi) const {
+        Contribution out;
+        const int v = T * phi + theta;
+        const size_t n1 = bin1_start[v + 1] - bin1_start[v];
+        const size_t n2 = bin2_start[v + 1] - bin2_start[v];
+        const float* lims = &clusterBounds[6 * v];
+        if ((n2 > (size_t)n) && (n1 > (size_t)n) && (lims[5] > 1)) {
+            const int* idx2 = &bin2_idx[bin2_start[v]];
+            std::vector<float> cx, cy, cz;
+            for (size_t k = 0; k < n2; k++) {
+                int i = idx2[k];
+                if (insideBounds(sph2.r[i], sph2.th[i], sph2.ph[i], lims)) {
+                    float x, y, z; s2c_one(sph2.r[i], sph2.th[i], sph2.ph[i], x, y, z);
+                    cx.push_back(x); cy.push_back(y); cz.push_back(z);
+                }
+            }
+            long rows = (long)cx.size();
+            out.n_in = (int)rows;
+            if (rows > n) {                                  // filteredPoints2.size()/3 > n, icet.cpp:302
+                const VoxelFit& f = fit[v];
+                if (!f.has_fit) { out.used = false; out.n_in = -(int)rows - 1; return out; }   // reference UB, see header
+                float mean[3] = {0, 0, 0};
+                for (long k = 0; k < rows; k++) { mean[0] += cx[k]; mean[1] += cy[k]; mean[2] += cz[k]; }
+                for (int a = 0; a < 3; a++) mean[a] /= (float)rows;
+                Mat cov(3, 3);
+                for (long k = 0; k < rows; k++) {
+                    float d[3] = {cx[k] - mean[0], cy[k] - mean[1], cz[k] - mean[2]};
+                    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) cov(a, b) += d[a] * d[b];
+                }
+                for (int a = 0; a < 9; a++) cov.a[a] = cov.a[a] / static_cast<float>(rows - 1);
+                // R_noise = sigma1/(n1-1) + cov/(n2-1)            icet.cpp:315 (raw bin counts, Q10)
+                Mat Rn(3, 3);
+                const float d1 = (float)(n1 - 1), d2 = (float)(n2 - 1);
+                for (int a = 0; a < 9; a++) Rn.a[a] = f.sigma.a[a] / d1 + cov.a[a] / d2;
+                // L * U^T = L * V  (Q8)
+                Mat Lm(3, 3); for (int k = 0; k < 3; k++) Lm(k, k) = f.Ldiag[k];
+                Mat LUt = matmul(Lm, f.V);
+                Mat Rp = matmul(matmul(matmul(LUt, Rn), transpose(f.V)), transpose(Lm));   // icet.cpp:317
+                Mat W = cod_pinv(Rp);                                                        // icet.cpp:320-321
+                float angs[3] = {X[3], X[4], X[5]};
+                Mat H_j = get_H(mean, angs);
+                Mat H_z = matmul(LUt, H_j);                                                  // icet.cpp:329
+                Mat HzT = transpose(H_z);
+                Mat HzTW = matmul(HzT, W);
+                out.HTWH = matmul(HzTW, H_z);                                                // icet.cpp:332
+                Mat mu1m(3, 1), mu2m(3, 1);
+                for (int a = 0; a < 3; a++) { mu1m(a, 0) = f.mu[a]; mu2m(a, 0) = mean[a]; }
+                Mat z1 = matmul(LUt, mu1m), z2 = matmul(LUt, mu2m);
+                Mat dz(3, 1); for (int a = 0; a < 3; a++) dz(a, 0) = z2(a, 0) - z1(a, 0);
+                out.HTWdz = matmul(HzTW, dz);                                                // icet.cpp:338
+                out.used = true; out.sigma2 = cov; for (int a = 0; a < 3; a++) out.mu2[a] = mean[a];
+            }
+        }
+        return out;
+    }
+
+    void record(int v, const Contribution& c) {
+        if (!tr || iter_no >= tr->max_iters) return;
+        size_t base = (size_t)iter_no * V + v;
+        tr->n2_raw[base] = bin2_start[v + 1] - bin2_start[v];
+        tr->n2_in[base] = c.n_in;
+        tr->used[base] = c.used ? 1 : 0;
+        for (int a = 0; a < 3; a++) tr->mu2[base * 3 + a] = c.mu2[a];
+        for (int a = 0; a < 9; a++) tr->sigma2[base * 9 + a] = c.sigma2.a[a];
+        if (c.n_in < 0) tr->n_ub_voxels++;
+    }
+
+    // icet.cpp:346-370 (the ThreadPool variant whose call is commented out at icet.cpp:407)
+    void voxelLoopPool() {
+        std::vector<std::future<Contribution>> futures;
+        futures.reserve(V);
+        for (int phi = 0; phi < P; phi++)
+            for (int theta = 0; theta < T; theta++)
+                futures.push_back(pool->enqueue([this, theta, phi]() { return fitCells2(theta, phi); }));
+        int v = 0;
+        for (auto& fu : futures) {
+            Contribution c = fu.get();
+            for (int a = 0; a < 36; a++) HTWH_i.a[a] += c.HTWH.a[a];
+            for (int a = 0; a < 6; a++) HTWdz_i.a[a] += c.HTWdz.a[a];
+            record(v++, c);
+        }
+    }
+
+    // icet.cpp:443-492
+    void checkCondition(const Mat& HTWH, Mat& L2, Mat& lam, Mat& U2) {
+        const float cutoff = 1e6f;
+        float ev[6];
+        selfadjoint_eigen(HTWH, /*fixed3=*/false, ev, U2);
+        float condition = ev[5] / ev[0];
+        int keep_from = 0;
+        int eyecount = 1;
+        while (std::abs(condition) > cutoff && eyecount < 6) {
+            for (int k = 0; k < 6; k++) pred_stds[k] += U2(k, eyecount - 1);     // icet.cpp:479 (Q12)
+            keep_from++;
+            condition = ev[5] / ev[eyecount];
+            eyecount++;
+        }
+        L2 = Mat(6 - keep_from, 6);
+        for (int i = 0; i < 6 - keep_from; i++) L2(i, keep_from + i) = 1.f;
+        lam = Mat(6, 6); for (int i = 0; i < 6; i++) lam(i, i) = ev[i];
+        if (tr && iter_no < tr->max_iters) { for (int i = 0; i < 6; i++) tr->eigvals[iter_no * 6 + i] = ev[i]; tr->pruned[iter_no] = keep_from; }
+    }
+
+    // icet.cpp:372-436
+    void fitScan2() {
+        const int N = (int)ogx.size();
+        Mat rot = eulerR(X[3], X[4], X[5]);
+        p2x.resize(N); p2y.resize(N); p2z.resize(N);
+        for (int i = 0; i < N; i++) {
+            float a = ogx[i] + X[0], b = ogy[i] + X[1], c = ogz[i] + X[2];        // rowwise() + trans
+            p2x[i] = a * rot(0, 0) + b * rot(1, 0) + c * rot(2, 0);              // points2 * rot_mat
+            p2y[i] = a * rot(0, 1) + b * rot(1, 1) + c * rot(2, 1);
+            p2z[i] = a * rot(0, 2) + b * rot(1, 2) + c * rot(2, 2);
+        }
+        HTWH_i = Mat(6, 6); HTWdz_i = Mat(6, 1);
+        sph2.resize(N);
+        for (int i = 0; i < N; i++) c2s_one(p2x[i], p2y[i], p2z[i], sph2.r[i], sph2.th[i], sph2.ph[i]);
+        binPoints(sph2, bin2_start, bin2_idx);
+        if (prm.mode == ICET_ORACLE_POOL4) {
+            voxelLoopPool();
+        } else {
+            for (int phi = 0; phi < P; phi++)
+                for (int theta = 0; theta < T; theta++) {
+                    Contribution c = fitCells2(theta, phi);
+                    for (int a = 0; a < 36; a++) HTWH_i.a[a] += c.HTWH.a[a];
+                    for (int a = 0; a < 6; a++) HTWdz_i.a[a] += c.HTWdz.a[a];
+                    record(T * phi + theta, c);
+                }
+        }
+        noise_mat = cod_pinv(HTWH_i);                                             // icet.cpp:410-411
+        for (int k = 0; k < 6; k++) pred_stds[k] = std::sqrt(std::abs(noise_mat(k, k)));
+        Mat L2, lam, U2;
+        checkCondition(HTWH_i, L2, lam, U2);
+        Mat U2t = transpose(U2);
+        Mat innards = matmul(matmul(L2, lam), U2t);                               // icet.cpp:427
+        Mat inv = cod_pinv(innards);
+        Mat lhs = matmul(matmul(inv, L2), U2t);
+        Mat d = matmul(lhs, HTWdz_i);                                             // icet.cpp:430
+        if (tr && iter_no < tr->max_iters) {
+            for (int a = 0; a < 36; a++) tr->HTWH[iter_no * 36 + a] = HTWH_i.a[a];
+            for (int a = 0; a < 6; a++) { tr->HTWdz[iter_no * 6 + a] = HTWdz_i.a[a]; tr->dx[iter_no * 6 + a] = d(a, 0); }
+        }
+        for (int k = 0; k < 6; k++) { dx[k] = d(k, 0); X[k] += dx[k]; }
+        if (tr && iter_no < tr->max_iters) for (int a = 0; a < 6; a++) tr->X[iter_no * 6 + a] = X[a];
+        iter_no++;
+    }
+
+    // icet.cpp:29-63
+    int run(const float* s1, int64_t n1, int64_t ld1, const float* s2, int64_t n2, int64_t ld2, const float* x0) {
+        T = prm.bins_theta; P = prm.bins_phi; V = T * P; n = prm.n;
+        p1x.assign(s1, s1 + n1); p1y.assign(s1 + ld1, s1 + ld1 + n1); p1z.assign(s1 + 2 * ld1, s1 + 2 * ld1 + n1);
+        p2x.assign(s2, s2 + n2); p2y.assign(s2 + ld2, s2 + ld2 + n2); p2z.assign(s2 + 2 * ld2, s2 + 2 * ld2 + n2);
+        for (int k = 0; k < 6; k++) { X[k] = x0[k]; pred_stds[k] = 0.f; dx[k] = 0.f; }
+        clusterBounds.assign((size_t)V * 6, 0.f);
+        fit.assign(V, VoxelFit());
+        if (prm.mode == ICET_ORACLE_POOL4) pool.reset(new Pool(4));               // icet.cpp:31
+        fitScan1();
+        prepScan2();
+        for (int iter = 0; iter < prm.runlen; iter++) fitScan2();
+        if (tr) {
+            for (int v = 0; v < V; v++) {
+                tr->n1_raw[v] = bin1_start[v + 1] - bin1_start[v];
+                tr->has_fit[v] = fit[v].has_fit ? 1 : 0;
+                for (int a = 0; a < 6; a++) tr->bounds[v * 6 + a] = clusterBounds[v * 6 + a];
+                for (int a = 0; a < 3; a++) { tr->mu1[v * 3 + a] = fit[v].mu[a]; tr->Ldiag[v * 3 + a] = fit[v].Ldiag[a]; }
+                for (int a = 0; a < 9; a++) { tr->sigma1[v * 9 + a] = fit[v].sigma.a[a]; tr->evecs1[v * 9 + a] = fit[v].V.a[a]; }
+            }
+        }
+        return 0;
+    }
+};
+
+}  // namespace ico
+
+extern "C" {
+
+int icet_oracle_solve(const icet_oracle_params* p, const float* scan1, int64_t n1, int64_t ld1,
+                      const float* scan2, int64_t n2, int64_t ld2, const float x0[6],
+                      float x_out[6], float pred_stds_out[6], float cov_out[36], icet_oracle_trace* trace) {
+    if (!p || !scan1 || !scan2 || !x0 || n1 < 0 || n2 < 0 || ld1 < n1 || ld2 < n2 || p->bins_phi <= 0 || p->bins_theta <= 0 || p->runlen < 0) return 1;
+    ico::Solver s; s.prm = *p; s.tr = trace;
+    if (trace) trace->n_ub_voxels = 0;
+    s.run(scan1, n1, ld1, scan2, n2, ld2, x0);
+    for (int k = 0; k < 6; k++) { x_out[k] = s.X[k]; pred_stds_out[k] = s.pred_stds[k]; }
+    if (cov_out) for (int a = 0; a < 36; a++) cov_out[a] = s.noise_mat.a[a];
+    return 0;
+}
+
+// One pair per host thread (the batched CPU baseline of BASELINE.md section 3).
+int icet_oracle_solve_batch(const icet_oracle_params* p, int n_pairs, const float* const* scan1, const int64_t* n1,
+                            const float* const* scan2, const int64_t* n2, const float* x0 /* n_pairs x 6 */,
+                            float* x_out, float* pred_stds_out, float* cov_out, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    std::atomic<int> next(0);
+    std::atomic<int> err(0);
+    auto worker = [&]() {
+        for (;;) {
+            int k = next.fetch_add(1);
+            if (k >= n_pairs) return;
+            int rc = icet_oracle_solve(p, scan1[k], n1[k], n1[k], scan2[k], n2[k], n2[k], x0 + 6 * k,
+                                       x_out + 6 * k, pred_stds_out + 6 * k, cov_out ? cov_out + 36 * k : nullptr, nullptr);
+            if (rc) err.store(rc);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; t++) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+    return err.load();
+}
+
+// Timed loop for bench.py's cpu_baseline leg: solves the same pair `reps` times, returns mean seconds.
+double icet_oracle_time_pair(const icet_oracle_params* p, const float* scan1, int64_t n1, const float* scan2, int64_t n2,
+                             const float x0[6], int reps, float x_out[6]) {
+    float ps[6], cov[36];
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; r++) icet_oracle_solve(p, scan1, n1, n1, scan2, n2, n2, x0, x_out, ps, cov, nullptr);
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count() / (reps > 0 ? reps : 1);
+}
+
+// ---- small exported helpers so tests can pin the restated decompositions against numpy -------------
+void icet_oracle_eig_sym(const float* A, int n, int fixed3, float* evals, float* evecs) {
+    ico::Mat M(n, n); for (int i = 0; i < n * n; i++) M.a[i] = A[i];
+    ico::Mat Q; ico::selfadjoint_eigen(M, fixed3 != 0, evals, Q);
+    for (int i = 0; i < n * n; i++) evecs[i] = Q.a[i];
+}
+int icet_oracle_pinv(const float* A, int rows, int cols, float* out) {
+    ico::Mat M(rows, cols); for (int i = 0; i < rows * cols; i++) M.a[i] = A[i];
+    int rank = 0; ico::Mat Pm = ico::cod_pinv(M, &rank);
+    for (int i = 0; i < rows * cols; i++) out[i] = Pm.a[i];
+    return rank;
+}
+void icet_oracle_c2s(const float* xyz, int64_t n, int64_t ld, float* out /* n x 3 col-major r|th|ph */) {
+    for (int64_t i = 0; i < n; i++) ico::c2s_one(xyz[i], xyz[ld + i], xyz[2 * ld + i], out[i], out[n + i], out[2 * n + i]);
+}
+// The scramble on its own: given r[n], returns src[v] = original row that ends at position v.
+void icet_oracle_scramble(const float* r, int64_t n, int32_t* src) {
+    std::vector<int> index(n);
+    std::iota(index.begin(), index.end(), 0);
+    std::stable_sort(index.begin(), index.end(), [&](int a, int b) { return r[a] < r[b]; });
+    for (int64_t i = 0; i < n; i++) src[i] = (int32_t)i;
+    for (int64_t i = 0; i < n; i++) {
+        if (index[i] != i) { int j = index[i]; std::swap(src[i], src[j]); std::swap(index[i], index[j]); }
+    }
+}
+void icet_oracle_get_H(const float mu[3], const float angs[3], float* H18) {
+    ico::Mat H = ico::get_H(mu, angs); for (int i = 0; i < 18; i++) H18[i] = H.a[i];
+}
+void icet_oracle_R(const float angs[3], float* R9) {
+    ico::Mat R = ico::eulerR(angs[0], angs[1], angs[2]); for (int i = 0; i < 9; i++) R9[i] = R.a[i];
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+/* oracle/icet_oracle.h -- TEST INFRASTRUCTURE (parity oracle + timed CPU "port" baseline).
+ * C ABI of the CPU restatement in icet_oracle.cpp.  Not part of the product; see the header of
+ * icet_oracle.cpp for what it follows in /root/reference and for the "parity unpinned" statement. */
+#ifndef ICET_ORACLE_H
+#define ICET_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ICET_ORACLE_SERIAL = 0,   /* live path: serial voxel loop, src/icet.cpp:391-404            */
+       ICET_ORACLE_POOL4  = 1 }; /* parallelFitCells2 structure, 4 workers, src/icet.cpp:346-370,31 */
+
+typedef struct icet_oracle_params {
+    int32_t runlen;      /* include/icet.h:38  */
+    int32_t bins_phi;    /* numBinsPhi   (elevation / polar-angle bins, 24) */
+    int32_t bins_theta;  /* numBinsTheta (azimuth bins, 75)                 */
+    int32_t n;           /* min cluster size, default 25  */
+    float   thresh;      /* radial jump threshold, 0.1    */
+    float   buff;        /* radial buffer, 0.1            */
+    int32_t mode;        /* ICET_ORACLE_SERIAL / _POOL4   */
+} icet_oracle_params;
+
+/* Caller-allocated dump of intermediate state (any pointer-holding struct must be fully populated).
+ * V = bins_phi*bins_theta, voxel index v = bins_theta*phi + theta (src/icet.cpp:149). */
+typedef struct icet_oracle_trace {
+    int32_t max_iters;       /* capacity of the per-iteration arrays */
+    int32_t n_ub_voxels;     /* out: voxels where the reference would read an un-fitted map entry */
+    /* keyframe (scan 1) table */
+    int32_t* n1_raw;         /* V      |pointIndices1[theta][phi]|            */
+    int32_t* has_fit;        /* V      1 if sigma1/mu1/U/L exist              */
+    float*   bounds;         /* V x 6  clusterBounds                          */
+    float*   mu1;            /* V x 3                                         */
+    float*   sigma1;         /* V x 9                                         */
+    float*   evecs1;         /* V x 9  eigenvectors as columns (row-major)    */
+    float*   Ldiag;          /* V x 3                                         */
+    float*   sigma_points;   /* V x 6 x 3                                     */
+    /* per iteration */
+    int32_t* n2_raw;         /* iters x V   |pointIndices2|                   */
+    int32_t* n2_in;          /* iters x V   rows passing filterPointsInsideCluster (0 if gated off earlier) */
+    int32_t* used;           /* iters x V   voxel contributed                 */
+    float*   mu2;            /* iters x V x 3 */
+    float*   sigma2;         /* iters x V x 9 */
+    float*   HTWH;           /* iters x 36 */
+    float*   HTWdz;          /* iters x 6  */
+    float*   dx;             /* iters x 6  */
+    float*   X;              /* iters x 6  (after the update) */
+    float*   eigvals;        /* iters x 6  */
+    int32_t* pruned;         /* iters      axes dropped by checkCondition */
+} icet_oracle_trace;
+
+/* scan = N x 3 column-major float (Eigen::MatrixXf layout: x[N] | y[N] | z[N], leading dimension ld). */
+int icet_oracle_solve(const icet_oracle_params* p, const float* scan1, int64_t n1, int64_t ld1,
+                      const float* scan2, int64_t n2, int64_t ld2, const float x0[6],
+                      float x_out[6], float pred_stds_out[6], float cov_out[36], icet_oracle_trace* trace);
+
+int icet_oracle_solve_batch(const icet_oracle_params* p, int n_pairs, const float* const* scan1, const int64_t* n1,
+                            const float* const* scan2, const int64_t* n2, const float* x0,
+                            float* x_out, float* pred_stds_out, float* cov_out, int n_threads);
+
+double icet_oracle_time_pair(const icet_oracle_params* p, const float* scan1, int64_t n1, const float* scan2, int64_t n2,
+                             const float x0[6], int reps, float x_out[6]);
+
+void icet_oracle_eig_sym(const float* A, int n, int fixed3, float* evals, float* evecs);
+int  icet_oracle_pinv(const float* A, int rows, int cols, float* out);
+void icet_oracle_c2s(const float* xyz, int64_t n, int64_t ld, float* out);
+void icet_oracle_scramble(const float* r, int64_t n, int32_t* src);
+void icet_oracle_get_H(const float mu[3], const float angs[3], float* H18);
+void icet_oracle_R(const float angs[3], float* R9);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

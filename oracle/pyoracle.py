@@ -1,0 +1,174 @@
+"""ctypes loader for the CPU restatement (oracle/icet_oracle.cpp) -- TEST INFRASTRUCTURE.
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import this module;
+nothing under ``icet_amd/`` does.  It never reads /root/reference.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libicet_oracle.so")
+
+SERIAL, POOL4 = 0, 1
+
+
+class Params(C.Structure):
+    _fields_ = [("runlen", C.c_int32), ("bins_phi", C.c_int32), ("bins_theta", C.c_int32), ("n", C.c_int32),
+                ("thresh", C.c_float), ("buff", C.c_float), ("mode", C.c_int32)]
+
+
+_I32P = C.POINTER(C.c_int32)
+_F32P = C.POINTER(C.c_float)
+
+
+class Trace(C.Structure):
+    _fields_ = [("max_iters", C.c_int32), ("n_ub_voxels", C.c_int32),
+                ("n1_raw", _I32P), ("has_fit", _I32P), ("bounds", _F32P), ("mu1", _F32P), ("sigma1", _F32P),
+                ("evecs1", _F32P), ("Ldiag", _F32P), ("sigma_points", _F32P),
+                ("n2_raw", _I32P), ("n2_in", _I32P), ("used", _I32P), ("mu2", _F32P), ("sigma2", _F32P),
+                ("HTWH", _F32P), ("HTWdz", _F32P), ("dx", _F32P), ("X", _F32P), ("eigvals", _F32P), ("pruned", _I32P)]
+
+
+def build(force=False):
+    """Compile the oracle with its Makefile (g++ only; no GPU, no reference sources)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+            for f in ("icet_oracle.cpp", "icet_oracle.h", "smalllinalg.h")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.icet_oracle_solve.restype = C.c_int
+        L.icet_oracle_solve.argtypes = [C.POINTER(Params), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Trace)]
+        L.icet_oracle_solve_batch.restype = C.c_int
+        L.icet_oracle_solve_batch.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.icet_oracle_time_pair.restype = C.c_double
+        L.icet_oracle_time_pair.argtypes = [C.POINTER(Params), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+        L.icet_oracle_eig_sym.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.icet_oracle_pinv.restype = C.c_int
+        L.icet_oracle_pinv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.icet_oracle_c2s.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.icet_oracle_scramble.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.icet_oracle_get_H.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.icet_oracle_R.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def colmajor(scan):
+    """N x 3 array-like -> float32 buffer laid out x[N] | y[N] | z[N] (Eigen::MatrixXf::data())."""
+    a = np.asarray(scan, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] == 3
+    return np.ascontiguousarray(a.T)          # shape (3, N), C-order == column-major N x 3
+
+
+def make_params(runlen=7, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1, mode=SERIAL):
+    return Params(runlen, bins_phi, bins_theta, n, thresh, buff, mode)
+
+
+def solve(scan1, scan2, x0=None, trace=False, **kw):
+    """Run the restated ICET constructor.  Returns dict(X, pred_stds, cov[, trace arrays])."""
+    p = make_params(**kw)
+    s1, s2 = colmajor(scan1), colmajor(scan2)
+    x0 = np.zeros(6, np.float32) if x0 is None else np.asarray(x0, np.float32).copy()
+    X = np.zeros(6, np.float32); ps = np.zeros(6, np.float32); cov = np.zeros(36, np.float32)
+    out = {}
+    tr = None
+    if trace:
+        V = p.bins_phi * p.bins_theta; it = max(p.runlen, 1)
+        arr = dict(n1_raw=np.zeros(V, np.int32), has_fit=np.zeros(V, np.int32), bounds=np.zeros((V, 6), np.float32),
+                   mu1=np.zeros((V, 3), np.float32), sigma1=np.zeros((V, 3, 3), np.float32), evecs1=np.zeros((V, 3, 3), np.float32),
+                   Ldiag=np.zeros((V, 3), np.float32), sigma_points=np.zeros((V, 6, 3), np.float32),
+                   n2_raw=np.zeros((it, V), np.int32), n2_in=np.zeros((it, V), np.int32), used=np.zeros((it, V), np.int32),
+                   mu2=np.zeros((it, V, 3), np.float32), sigma2=np.zeros((it, V, 3, 3), np.float32),
+                   HTWH=np.zeros((it, 6, 6), np.float32), HTWdz=np.zeros((it, 6), np.float32), dx=np.zeros((it, 6), np.float32),
+                   X=np.zeros((it, 6), np.float32), eigvals=np.zeros((it, 6), np.float32), pruned=np.zeros(it, np.int32))
+        tr = Trace()
+        tr.max_iters = it
+        for k, v in arr.items():
+            setattr(tr, k, v.ctypes.data_as(_I32P if v.dtype == np.int32 else _F32P))
+        out["trace"] = arr
+    rc = lib().icet_oracle_solve(C.byref(p), s1.ctypes.data, s1.shape[1], s1.shape[1], s2.ctypes.data, s2.shape[1], s2.shape[1],
+                                 x0.ctypes.data, X.ctypes.data, ps.ctypes.data, cov.ctypes.data, C.byref(tr) if tr is not None else None)
+    if rc:
+        raise ValueError("icet_oracle_solve: bad argument (rc=%d)" % rc)
+    out.update(X=X, pred_stds=ps, cov=cov.reshape(6, 6))
+    if tr is not None:
+        out["n_ub_voxels"] = tr.n_ub_voxels
+    return out
+
+
+def solve_batch(scans1, scans2, x0=None, n_threads=1, **kw):
+    p = make_params(**kw)
+    k = len(scans1)
+    s1 = [colmajor(s) for s in scans1]; s2 = [colmajor(s) for s in scans2]
+    a1 = (C.c_void_p * k)(*[s.ctypes.data for s in s1]); a2 = (C.c_void_p * k)(*[s.ctypes.data for s in s2])
+    n1 = np.array([s.shape[1] for s in s1], np.int64); n2 = np.array([s.shape[1] for s in s2], np.int64)
+    x0 = np.zeros((k, 6), np.float32) if x0 is None else np.ascontiguousarray(x0, np.float32)
+    X = np.zeros((k, 6), np.float32); ps = np.zeros((k, 6), np.float32); cov = np.zeros((k, 36), np.float32)
+    rc = lib().icet_oracle_solve_batch(C.byref(p), k, a1, n1.ctypes.data, a2, n2.ctypes.data, x0.ctypes.data,
+                                       X.ctypes.data, ps.ctypes.data, cov.ctypes.data, n_threads)
+    if rc:
+        raise ValueError("icet_oracle_solve_batch rc=%d" % rc)
+    return dict(X=X, pred_stds=ps, cov=cov.reshape(k, 6, 6))
+
+
+def time_pair(scan1, scan2, reps=3, x0=None, **kw):
+    p = make_params(**kw)
+    s1, s2 = colmajor(scan1), colmajor(scan2)
+    x0 = np.zeros(6, np.float32) if x0 is None else np.asarray(x0, np.float32).copy()
+    X = np.zeros(6, np.float32)
+    sec = lib().icet_oracle_time_pair(C.byref(p), s1.ctypes.data, s1.shape[1], s2.ctypes.data, s2.shape[1], x0.ctypes.data, reps, X.ctypes.data)
+    return sec, X
+
+
+def eig_sym(A, fixed3=False):
+    A = np.ascontiguousarray(A, np.float32); n = A.shape[0]
+    w = np.zeros(n, np.float32); Q = np.zeros((n, n), np.float32)
+    lib().icet_oracle_eig_sym(A.ctypes.data, n, int(fixed3), w.ctypes.data, Q.ctypes.data)
+    return w, Q
+
+
+def pinv(A):
+    A = np.ascontiguousarray(A, np.float32); r, c = A.shape
+    out = np.zeros((c, r), np.float32)
+    rank = lib().icet_oracle_pinv(A.ctypes.data, r, c, out.ctypes.data)
+    return out, rank
+
+
+def c2s(scan):
+    s = colmajor(scan); n = s.shape[1]
+    out = np.zeros((3, n), np.float32)
+    lib().icet_oracle_c2s(s.ctypes.data, n, n, out.ctypes.data)
+    return out.T.copy()
+
+
+def scramble(r):
+    r = np.ascontiguousarray(r, np.float32)
+    src = np.zeros(r.shape[0], np.int32)
+    lib().icet_oracle_scramble(r.ctypes.data, r.shape[0], src.ctypes.data)
+    return src
+
+
+def get_H(mu, angs):
+    mu = np.asarray(mu, np.float32); angs = np.asarray(angs, np.float32); H = np.zeros(18, np.float32)
+    lib().icet_oracle_get_H(mu.ctypes.data, angs.ctypes.data, H.ctypes.data)
+    return H.reshape(3, 6)
+
+
+def euler_R(angs):
+    angs = np.asarray(angs, np.float32); R = np.zeros(9, np.float32)
+    lib().icet_oracle_R(angs.ctypes.data, R.ctypes.data)
+    return R.reshape(3, 3)

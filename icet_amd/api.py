@@ -1,0 +1,233 @@
+"""Host-side mirror of the reference interface for the accelerated path, on top of the C ABI.
+
+The reference exposes exactly one operator for this path: the constructor of ``class ICET``
+(/root/reference/include/icet.h:38-40, body src/icet.cpp:29-63), which *is* the solve; callers then
+read the public members ``X`` and ``pred_stds`` (src/odometry.cpp:76-79, src/simpleMapMaker.cpp:119-122).
+:class:`ICET` below keeps the same constructor arguments (same names, order, defaults and meaning) and
+the same member names, and calls ``icet_solve`` in ``libicet_hip.so`` (include/icet_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is usable this module raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libicet_hip.so")
+
+ICET_OK, ICET_ERR_BAD_ARG, ICET_ERR_NO_DEVICE, ICET_ERR_HIP, ICET_ERR_NOMEM, ICET_ERR_UNSUPPORTED = range(6)
+_STATUS_NAMES = {0: "ICET_OK", 1: "ICET_ERR_BAD_ARG", 2: "ICET_ERR_NO_DEVICE", 3: "ICET_ERR_HIP", 4: "ICET_ERR_NOMEM", 5: "ICET_ERR_UNSUPPORTED"}
+FLAG_TIMING = 1
+
+# every symbol include/icet_hip.h declares
+EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_batch",
+                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing")
+
+
+class IcetError(RuntimeError):
+    def __init__(self, status, msg=""):
+        self.status = status
+        super().__init__("%s%s" % (_STATUS_NAMES.get(status, str(status)), (": " + msg) if msg else ""))
+
+
+class Params(C.Structure):
+    _fields_ = [("runlen", C.c_int32), ("bins_phi", C.c_int32), ("bins_theta", C.c_int32), ("n", C.c_int32),
+                ("thresh", C.c_float), ("buff", C.c_float), ("flags", C.c_int32)]
+
+
+class DevScan(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("n", C.c_int64), ("ld", C.c_int64)]
+
+
+_F = C.POINTER(C.c_float)
+_I = C.POINTER(C.c_int32)
+
+
+class Aux(C.Structure):
+    _fields_ = [("cluster_bounds", _F), ("n1_raw", _I), ("has_fit", _I), ("mu1", _F), ("sigma1", _F), ("evecs1", _F), ("l_diag", _F),
+                ("x_hist", _F), ("htwh", _F), ("htwdz", _F), ("n2_raw", _I), ("n2_in", _I)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libicet_hip.so (built in-tree by ``__graft_entry__.build()`` / ``make -C icet_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IcetError(ICET_ERR_HIP, "HIP library not built: %s is missing (run `make -C icet_amd/csrc`); "
+                                      "there is no CPU fallback for this path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.icet_version.restype = C.c_char_p
+    L.icet_last_error.restype = C.c_char_p
+    L.icet_last_error.argtypes = [C.c_void_p]
+    L.icet_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+    L.icet_destroy.argtypes = [C.c_void_p]
+    L.icet_sync.argtypes = [C.c_void_p]
+    L.icet_reserve.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_int64, C.c_int64]
+    L.icet_solve.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Aux)]
+    L.icet_solve_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.icet_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.POINTER(DevScan), C.c_void_p, C.c_void_p]
+    L.icet_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+    for name in EXPORTED_SYMBOLS:
+        getattr(L, name)
+        if name not in ("icet_version", "icet_last_error"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _colmajor(scan):
+    """N x 3 array-like -> float32 (3, N) C-contiguous buffer == column-major N x 3 (Eigen::MatrixXf::data())."""
+    a = np.asarray(scan, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise IcetError(ICET_ERR_BAD_ARG, "scan must be N x 3")
+    return np.ascontiguousarray(a.T)
+
+
+class Context:
+    """One device + stream + workspace (``icet_ctx``).  Not re-entrant; one per host thread."""
+
+    def __init__(self, device=0, stream=None):
+        L = load_library()
+        h = C.c_void_p()
+        st = L.icet_create(C.byref(h), int(device), C.c_void_p(stream) if stream else None)
+        if st != ICET_OK:
+            raise IcetError(st, "icet_create(device=%d)" % device)
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().icet_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != ICET_OK:
+            raise IcetError(st, load_library().icet_last_error(self._h).decode())
+
+    def sync(self):
+        self._check(load_library().icet_sync(self._h))
+
+    def reserve(self, params, n_pairs, total_n1, total_n2):
+        self._check(load_library().icet_reserve(self._h, C.byref(params), n_pairs, total_n1, total_n2))
+
+    def last_timing(self):
+        t = np.zeros(4, np.float32)
+        self._check(load_library().icet_last_timing(self._h, t.ctypes.data))
+        return dict(keyframe_ms=float(t[0]), gn_loop_ms=float(t[1]), accumulate_ms=float(t[2]), accumulate_launches=int(t[3]))
+
+    # -- single pair, host arrays ---------------------------------------------------------------
+    def solve(self, scan1, scan2, runlen, X0, num_bins_phi, num_bins_theta, n=25, thresh=0.1, buff=0.1, aux=False, flags=0):
+        s1, s2 = _colmajor(scan1), _colmajor(scan2)
+        p = Params(int(runlen), int(num_bins_phi), int(num_bins_theta), int(n), float(thresh), float(buff), int(flags))
+        x0 = np.asarray(X0, np.float32).reshape(6).copy()
+        X = np.zeros(6, np.float32); ps = np.zeros(6, np.float32); cov = np.zeros(36, np.float32)
+        out = {}
+        auxs = None
+        if aux:
+            V = int(num_bins_phi) * int(num_bins_theta); rl = max(int(runlen), 1)
+            arr = dict(cluster_bounds=np.zeros((V, 6), np.float32), n1_raw=np.zeros(V, np.int32), has_fit=np.zeros(V, np.int32),
+                       mu1=np.zeros((V, 3), np.float32), sigma1=np.zeros((V, 3, 3), np.float32), evecs1=np.zeros((V, 3, 3), np.float32),
+                       l_diag=np.zeros((V, 3), np.float32), x_hist=np.zeros((rl, 6), np.float32), htwh=np.zeros((rl, 6, 6), np.float32),
+                       htwdz=np.zeros((rl, 6), np.float32), n2_raw=np.zeros((rl, V), np.int32), n2_in=np.zeros((rl, V), np.int32))
+            auxs = Aux()
+            for k, v in arr.items():
+                setattr(auxs, k, v.ctypes.data_as(_I if v.dtype == np.int32 else _F))
+            out["aux"] = arr
+        st = load_library().icet_solve(self._h, C.byref(p), s1.ctypes.data, s1.shape[1], s1.shape[1], s2.ctypes.data, s2.shape[1], s2.shape[1],
+                                       x0.ctypes.data, X.ctypes.data, ps.ctypes.data, cov.ctypes.data, C.byref(auxs) if auxs is not None else None)
+        self._check(st)
+        out.update(X=X, pred_stds=ps, cov=cov.reshape(6, 6))
+        return out
+
+    # -- batch, host arrays ------------------------------------------------------------------------
+    def solve_batch(self, scans1, scans2, runlen, X0=None, num_bins_phi=24, num_bins_theta=75, n=25, thresh=0.1, buff=0.1):
+        k = len(scans1)
+        if len(scans2) != k:
+            raise IcetError(ICET_ERR_BAD_ARG, "scans1 and scans2 differ in length")
+        p = Params(int(runlen), int(num_bins_phi), int(num_bins_theta), int(n), float(thresh), float(buff), 0)
+        s1 = [_colmajor(s) for s in scans1]; s2 = [_colmajor(s) for s in scans2]
+        a1 = (C.c_void_p * max(k, 1))(*[s.ctypes.data for s in s1]); a2 = (C.c_void_p * max(k, 1))(*[s.ctypes.data for s in s2])
+        n1 = np.array([s.shape[1] for s in s1], np.int64); n2 = np.array([s.shape[1] for s in s2], np.int64)
+        x0 = None if X0 is None else np.ascontiguousarray(np.asarray(X0, np.float32).reshape(k, 6))
+        X = np.zeros((k, 6), np.float32); ps = np.zeros((k, 6), np.float32); cov = np.zeros((k, 36), np.float32)
+        st = load_library().icet_solve_batch(self._h, C.byref(p), k, a1, n1.ctypes.data, a2, n2.ctypes.data,
+                                             x0.ctypes.data if x0 is not None else None, X.ctypes.data, ps.ctypes.data, cov.ctypes.data)
+        self._check(st)
+        return dict(X=X, pred_stds=ps, cov=cov.reshape(k, 6, 6))
+
+    # -- batch, device-resident (raw device pointers; torch is only the allocator in callers) ---------
+    def solve_batch_device(self, scan1_descs, scan2_descs, params, d_out_ptr, d_x0_ptr=None):
+        """scan*_descs: sequences of (device_ptr, n, ld).  d_out_ptr: device pointer to n_pairs x 48 floats."""
+        k = len(scan1_descs)
+        A = (DevScan * max(k, 1))(*[DevScan(int(p), int(n), int(ld)) for (p, n, ld) in scan1_descs])
+        B = (DevScan * max(k, 1))(*[DevScan(int(p), int(n), int(ld)) for (p, n, ld) in scan2_descs])
+        st = load_library().icet_solve_batch_device(self._h, C.byref(params), k, A, B,
+                                                    C.c_void_p(d_x0_ptr) if d_x0_ptr else None, C.c_void_p(d_out_ptr))
+        self._check(st)
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def euler_R(phi, theta, psi):
+    """utils::R (src/utils.cpp:144-152): body-frame xyz Euler rotation; used only to rebuild the ``points2`` member."""
+    c, s = np.cos, np.sin
+    return np.array([
+        [c(theta) * c(psi), s(psi) * c(phi) + s(phi) * s(theta) * c(psi), s(phi) * s(psi) - s(theta) * c(phi) * c(psi)],
+        [-s(psi) * c(theta), c(phi) * c(psi) - s(phi) * s(theta) * s(psi), s(phi) * c(psi) + s(theta) * s(psi) * c(phi)],
+        [s(theta), -s(phi) * c(theta), c(phi) * c(theta)]], dtype=np.float32)
+
+
+class ICET:
+    """Drop-in mirror of the reference's ``ICET`` object (include/icet.h:36-116).
+
+    ``ICET(scan1, scan2, runlen, X0, num_bins_phi, num_bins_theta, n=25, thresh=0.1, buff=0.1)`` -- the
+    constructor runs the whole registration on the GPU; read ``X`` (x, y, z, roll, pitch, yaw) and
+    ``pred_stds`` afterwards, exactly as odometry_node / map_maker_node do.  Also filled:
+    ``clusterBounds`` (V x 6), ``points1``, ``points2`` (scan 2 under the transform of the LAST
+    iteration, i.e. X before the final update -- src/icet.cpp:375-378 precede :433), ``HTWH_i``,
+    ``HTWdz_i``, ``ellipsoid1Means`` / ``ellipsoid1Covariances`` / ``ellipsoid1Alphas``, and ``cov``
+    (the full 6x6 the reference keeps only as a local).
+    """
+
+    def __init__(self, scan1, scan2, runlen, X0, num_bins_phi, num_bins_theta, n=25, thresh=0.1, buff=0.1, *, device=0, side_tables=True):
+        self.rl, self.numBinsPhi, self.numBinsTheta, self.n, self.thresh, self.buff = runlen, num_bins_phi, num_bins_theta, n, thresh, buff
+        ctx = default_context(device)
+        res = ctx.solve(scan1, scan2, runlen, X0, num_bins_phi, num_bins_theta, n, thresh, buff, aux=side_tables)
+        self.X = res["X"]
+        self.pred_stds = res["pred_stds"]
+        self.cov = res["cov"]
+        self.points1 = np.asarray(scan1, np.float32)
+        if side_tables:
+            a = res["aux"]
+            self.clusterBounds = a["cluster_bounds"]
+            fit = a["has_fit"] == 1
+            self.ellipsoid1Means = list(a["mu1"][fit])
+            self.ellipsoid1Covariances = list(a["sigma1"][fit])
+            self.ellipsoid1Alphas = [0.3] * int(fit.sum())
+            self.ellipsoid2Means, self.ellipsoid2Covariances, self.ellipsoid2Alphas = [], [], []   # always empty in the reference
+            self.side = a
+            if runlen > 0:
+                self.HTWH_i = a["htwh"][runlen - 1]
+                self.HTWdz_i = a["htwdz"][runlen - 1].reshape(6, 1)
+                xprev = np.asarray(X0, np.float32).reshape(6) if runlen == 1 else a["x_hist"][runlen - 2]
+                self.dx = a["x_hist"][runlen - 1] - xprev
+                self.points2 = (np.asarray(scan2, np.float32) + xprev[:3]) @ euler_R(xprev[3], xprev[4], xprev[5])

@@ -1,0 +1,389 @@
+// icet_amd/csrc/icet_capi.hip -- host side of the C ABI declared in include/icet_hip.h.
+//
+// Owns the device workspace, stages host scans into HBM, enqueues the keyframe build and the
+// Gauss-Newton loop on one HIP stream and copies the 48 result floats per pair back.  No CPU
+// implementation of the algorithm lives here: if the device or the kernels are unavailable every
+// entry point returns ICET_ERR_NO_DEVICE / ICET_ERR_HIP.
+#include "../../include/icet_hip.h"
+#include "icet_internal.h"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <new>
+
+using namespace icet;
+
+struct icet_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Workspace w;
+    std::string err;
+    // host staging (pinned) for descriptors and results
+    PairDesc* h_desc = nullptr; int32_t* h_seg = nullptr; int32_t h_cap_pairs = 0;
+    // device staging for host-pointer entry points
+    float* d_stage1 = nullptr; float* d_stage2 = nullptr; int64_t cap_stage1 = 0, cap_stage2 = 0;
+    float* d_out = nullptr; float* d_x0 = nullptr; int32_t cap_out_pairs = 0;
+    float* h_out = nullptr;
+    // aux (single pair)
+    AuxDev aux_dev{}; int aux_V = 0, aux_runlen = 0;
+    // timing
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+    std::vector<hipEvent_t> ev_acc;
+    float last_ms[4] = {0, 0, 0, 0};
+    bool timing_valid = false;
+    int last_iters = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+    return e_ == hipErrorOutOfMemory ? ICET_ERR_NOMEM : ICET_ERR_HIP; } } while (0)
+
+template <typename T> hipError_t dev_realloc(T*& p, size_t count) {
+    if (p) { hipError_t e = hipFree(p); p = nullptr; if (e != hipSuccess) return e; }
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+}
+
+bool params_ok(const icet_params* p) {
+    if (!p) return false;
+    if (p->runlen < 0 || p->runlen > 4096) return false;
+    if (p->bins_phi <= 0 || p->bins_theta <= 0 || p->n < 1) return false;
+    return true;
+}
+
+icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs, int64_t total_n1) {
+    Workspace& w = c->w;
+    const int V = p->bins_phi * p->bins_theta;
+    if ((int64_t)p->bins_phi * p->bins_theta > kMaxVoxels) { c->err = "bins_phi*bins_theta exceeds the compiled voxel limit"; return ICET_ERR_UNSUPPORTED; }
+    if (total_n1 >= (int64_t)1 << 31) { c->err = "total scan-1 points per call must be < 2^31"; return ICET_ERR_UNSUPPORTED; }
+    const bool grow_pairs = n_pairs > w.cap_pairs || V > w.cap_V;
+    if (grow_pairs) {
+        const int np = n_pairs > w.cap_pairs ? n_pairs : w.cap_pairs;
+        const int VV = V > w.cap_V ? V : w.cap_V;
+        const size_t pv = (size_t)np * VV;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, dev_realloc(w.desc, np));
+        HIPCHK(c, dev_realloc(w.seg_off, (size_t)np + 1));
+        HIPCHK(c, dev_realloc(w.bin_count, pv));
+        HIPCHK(c, dev_realloc(w.bin_start, (size_t)np * (VV + 1)));
+        HIPCHK(c, dev_realloc(w.hotD, pv)); HIPCHK(c, dev_realloc(w.fitD, pv)); HIPCHK(c, dev_realloc(w.activeD, pv));
+        HIPCHK(c, dev_realloc(w.hotS, pv)); HIPCHK(c, dev_realloc(w.fitS, pv));
+        HIPCHK(c, dev_realloc(w.slot_of_voxel, (size_t)np * ((VV + 1) & ~1)));
+        HIPCHK(c, dev_realloc(w.n_slots, np));
+        HIPCHK(c, dev_realloc(w.acc, pv * kAccWords));
+        HIPCHK(c, hipMemset(w.acc, 0, pv * kAccWords * sizeof(uint32_t)));
+        HIPCHK(c, dev_realloc(w.xf, (size_t)np * 16));
+        HIPCHK(c, dev_realloc(w.X, (size_t)np * 6));
+        HIPCHK(c, dev_realloc(w.flags, np));
+        if (c->h_desc) { HIPCHK(c, hipHostFree(c->h_desc)); c->h_desc = nullptr; }
+        if (c->h_seg) { HIPCHK(c, hipHostFree(c->h_seg)); c->h_seg = nullptr; }
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_desc), sizeof(PairDesc) * np));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_seg), sizeof(int32_t) * ((size_t)np + 1)));
+        c->h_cap_pairs = np;
+        w.cap_pairs = np; w.cap_V = VV;
+    }
+    if (total_n1 > w.cap_n1 || grow_pairs) {
+        const int64_t n = total_n1 > w.cap_n1 ? total_n1 : w.cap_n1;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n > w.cap_n1) {
+            HIPCHK(c, dev_realloc(w.r1, n)); HIPCHK(c, dev_realloc(w.th1, n)); HIPCHK(c, dev_realloc(w.ph1, n));
+            HIPCHK(c, dev_realloc(w.keyA, n)); HIPCHK(c, dev_realloc(w.keyB, n)); HIPCHK(c, dev_realloc(w.valA, n)); HIPCHK(c, dev_realloc(w.valB, n));
+            HIPCHK(c, dev_realloc(w.pred, n)); HIPCHK(c, dev_realloc(w.src, n)); HIPCHK(c, dev_realloc(w.exec, n));
+            HIPCHK(c, dev_realloc(w.rs, n)); HIPCHK(c, dev_realloc(w.ths, n)); HIPCHK(c, dev_realloc(w.phs, n));
+            w.cap_n1 = n;
+        }
+        const size_t need = sort_temp_bytes(w.cap_n1, w.cap_pairs);
+        if (need > w.sort_tmp_bytes) {
+            if (w.sort_tmp) { HIPCHK(c, hipFree(w.sort_tmp)); w.sort_tmp = nullptr; }
+            HIPCHK(c, hipMalloc(&w.sort_tmp, need));
+            w.sort_tmp_bytes = need;
+        }
+    }
+    return ICET_OK;
+}
+
+icet_status ensure_out(icet_ctx* c, int32_t n_pairs) {
+    if (n_pairs <= c->cap_out_pairs) return ICET_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, dev_realloc(c->d_out, (size_t)n_pairs * 48));
+    HIPCHK(c, dev_realloc(c->d_x0, (size_t)n_pairs * 6));
+    if (c->h_out) { HIPCHK(c, hipHostFree(c->h_out)); c->h_out = nullptr; }
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out), sizeof(float) * 48 * (size_t)n_pairs));
+    c->cap_out_pairs = n_pairs;
+    return ICET_OK;
+}
+
+void free_aux(icet_ctx* c) {
+    AuxDev& a = c->aux_dev;
+    void* ps[] = {a.bounds, a.n1_raw, a.has_fit, a.mu1, a.sigma1, a.evecs1, a.l_diag, a.x_hist, a.htwh, a.htwdz, a.n2_raw, a.n2_in};
+    for (void* p : ps) if (p) (void)hipFree(p);
+    a = AuxDev{};
+    c->aux_V = 0; c->aux_runlen = 0;
+}
+
+icet_status ensure_aux(icet_ctx* c, int V, int runlen) {
+    if (c->aux_V >= V && c->aux_runlen >= runlen && c->aux_dev.bounds) return ICET_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_aux(c);
+    AuxDev& a = c->aux_dev;
+    const size_t rl = runlen > 0 ? runlen : 1;
+    HIPCHK(c, dev_realloc(a.bounds, (size_t)V * 6)); HIPCHK(c, dev_realloc(a.n1_raw, V)); HIPCHK(c, dev_realloc(a.has_fit, V));
+    HIPCHK(c, dev_realloc(a.mu1, (size_t)V * 3)); HIPCHK(c, dev_realloc(a.sigma1, (size_t)V * 9)); HIPCHK(c, dev_realloc(a.evecs1, (size_t)V * 9));
+    HIPCHK(c, dev_realloc(a.l_diag, (size_t)V * 3));
+    HIPCHK(c, dev_realloc(a.x_hist, rl * 6)); HIPCHK(c, dev_realloc(a.htwh, rl * 36)); HIPCHK(c, dev_realloc(a.htwdz, rl * 6));
+    HIPCHK(c, dev_realloc(a.n2_raw, rl * V)); HIPCHK(c, dev_realloc(a.n2_in, rl * V));
+    c->aux_V = V; c->aux_runlen = runlen;
+    return ICET_OK;
+}
+
+// Enqueue the whole solve for descriptors already sitting in c->h_desc[0..n_pairs).
+icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const float* d_x0, float* d_out, const AuxDev* aux) {
+    Workspace& w = c->w;
+    LaunchCfg cfg{};
+    cfg.T = p->bins_theta; cfg.P = p->bins_phi; cfg.V = cfg.T * cfg.P; cfg.n = p->n; cfg.runlen = p->runlen;
+    cfg.thresh = p->thresh; cfg.buff = p->buff; cfg.n_pairs = n_pairs;
+    int64_t tot = 0; int mx1 = 0, mx2 = 0;
+    for (int k = 0; k < n_pairs; k++) {
+        c->h_seg[k] = (int32_t)tot; c->h_desc[k].off1 = (int32_t)tot; tot += c->h_desc[k].n1;
+        if (c->h_desc[k].n1 > mx1) mx1 = c->h_desc[k].n1;
+        if (c->h_desc[k].n2 > mx2) mx2 = c->h_desc[k].n2;
+    }
+    c->h_seg[n_pairs] = (int32_t)tot;
+    cfg.total_n1 = tot; cfg.max_n1 = mx1; cfg.max_n2 = mx2;
+    HIPCHK(c, hipMemcpyAsync(w.desc, c->h_desc, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(w.seg_off, c->h_seg, sizeof(int32_t) * (n_pairs + 1), hipMemcpyHostToDevice, c->stream));
+    while ((int)c->ev_acc.size() < 2 * p->runlen) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_acc.push_back(e); }
+    HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
+    HIPCHK(c, launch_keyframe(w, cfg, aux, c->stream));
+    HIPCHK(c, launch_init_state(w, cfg, d_x0, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
+    const bool per_iter = (p->flags & ICET_FLAG_TIMING) != 0;
+    for (int it = 0; it < p->runlen; it++) {
+        if (per_iter) HIPCHK(c, hipEventRecord(c->ev_acc[2 * it], c->stream));
+        HIPCHK(c, launch_gn_accumulate(w, cfg, c->stream));
+        if (per_iter) HIPCHK(c, hipEventRecord(c->ev_acc[2 * it + 1], c->stream));
+        HIPCHK(c, launch_gn_solve(w, cfg, it, d_out, aux, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev_c, c->stream));
+    c->timing_valid = true; c->last_iters = per_iter ? p->runlen : 0;
+    return ICET_OK;
+}
+
+icet_status write_runlen0(icet_ctx* c, int32_t n_pairs, const float* d_x0, float* d_out) {
+    // runlen == 0: the reference constructor returns X = X0, pred_stds = 0 (src/icet.cpp:36-37,47).
+    HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(float) * 48 * (size_t)n_pairs, c->stream));
+    if (d_x0) HIPCHK(c, hipMemcpy2DAsync(d_out, 48 * sizeof(float), d_x0, 6 * sizeof(float), 6 * sizeof(float), n_pairs, hipMemcpyDeviceToDevice, c->stream));
+    return ICET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* icet_version(void) { return "icet_hip 0.1 (gfx950)"; }
+
+const char* icet_last_error(const icet_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+icet_status icet_create(icet_ctx** out, int device_id, void* hip_stream) {
+    if (!out) return ICET_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ICET_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= ndev) return ICET_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return ICET_ERR_NO_DEVICE;
+    icet_ctx* c = new (std::nothrow) icet_ctx();
+    if (!c) return ICET_ERR_NOMEM;
+    c->device = device_id;
+    if (hip_stream) { c->stream = reinterpret_cast<hipStream_t>(hip_stream); c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ICET_ERR_HIP; }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess || hipEventCreate(&c->ev_c) != hipSuccess) { delete c; return ICET_ERR_HIP; }
+    *out = c;
+    return ICET_OK;
+}
+
+icet_status icet_destroy(icet_ctx* c) {
+    if (!c) return ICET_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    Workspace& w = c->w;
+    void* ps[] = {w.desc, w.seg_off, w.r1, w.th1, w.ph1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src, w.exec, w.rs, w.ths, w.phs,
+                  w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, w.xf, w.X, w.flags,
+                  w.sort_tmp, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
+    for (void* p : ps) if (p) (void)hipFree(p);
+    free_aux(c);
+    if (c->h_desc) (void)hipHostFree(c->h_desc);
+    if (c->h_seg) (void)hipHostFree(c->h_seg);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    for (hipEvent_t e : c->ev_acc) (void)hipEventDestroy(e);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->ev_c) (void)hipEventDestroy(c->ev_c);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return ICET_OK;
+}
+
+icet_status icet_sync(icet_ctx* c) {
+    if (!c) return ICET_ERR_BAD_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ICET_OK;
+}
+
+icet_status icet_reserve(icet_ctx* c, const icet_params* p, int32_t n_pairs, int64_t total_n1, int64_t total_n2) {
+    if (!c || !params_ok(p) || n_pairs < 0 || total_n1 < 0 || total_n2 < 0) return ICET_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    icet_status s = ensure_workspace(c, p, n_pairs, total_n1);
+    if (s != ICET_OK) return s;
+    return ensure_out(c, n_pairs);
+}
+
+icet_status icet_solve_batch_device(icet_ctx* c, const icet_params* p, int32_t n_pairs,
+                                    const icet_dev_scan* scan1, const icet_dev_scan* scan2,
+                                    const float* d_x0, float* d_out) {
+    if (!c) return ICET_ERR_BAD_ARG;
+    if (!params_ok(p) || n_pairs < 0 || (n_pairs > 0 && (!scan1 || !scan2 || !d_out))) { c->err = "bad argument"; return ICET_ERR_BAD_ARG; }
+    if (n_pairs == 0) return ICET_OK;
+    int64_t tot1 = 0;
+    for (int k = 0; k < n_pairs; k++) {
+        const icet_dev_scan &a = scan1[k], &b = scan2[k];
+        if (a.n < 0 || b.n < 0 || a.ld < a.n || b.ld < b.n || (a.n > 0 && !a.ptr) || (b.n > 0 && !b.ptr) ||
+            a.ld >= ((int64_t)1 << 30) || b.ld >= ((int64_t)1 << 30)) { c->err = "bad scan descriptor"; return ICET_ERR_BAD_ARG; }
+        tot1 += a.n;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    icet_status s = ensure_workspace(c, p, n_pairs, tot1);
+    if (s != ICET_OK) return s;
+    // the previous call may still be reading the pinned descriptor staging
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < n_pairs; k++) {
+        PairDesc& d = c->h_desc[k];
+        d.s1 = scan1[k].ptr; d.s2 = scan2[k].ptr;
+        d.n1 = (int32_t)scan1[k].n; d.ld1 = (int32_t)scan1[k].ld; d.n2 = (int32_t)scan2[k].n; d.ld2 = (int32_t)scan2[k].ld;
+        d.off1 = 0; d.pad = 0;
+    }
+    if (p->runlen == 0) return write_runlen0(c, n_pairs, d_x0, d_out);
+    return enqueue(c, p, n_pairs, d_x0, d_out, nullptr);
+}
+
+icet_status icet_solve_batch(icet_ctx* c, const icet_params* p, int32_t n_pairs,
+                             const float* const* scan1, const int64_t* n1, const float* const* scan2, const int64_t* n2,
+                             const float* x0, float* x_out, float* pred_stds_out, float* cov_out) {
+    if (!c) return ICET_ERR_BAD_ARG;
+    if (!params_ok(p) || n_pairs < 0 || (n_pairs > 0 && (!scan1 || !n1 || !scan2 || !n2 || !x_out || !pred_stds_out))) { c->err = "bad argument"; return ICET_ERR_BAD_ARG; }
+    if (n_pairs == 0) return ICET_OK;
+    int64_t tot1 = 0, tot2 = 0;
+    for (int k = 0; k < n_pairs; k++) {
+        if (n1[k] < 0 || n2[k] < 0 || (n1[k] > 0 && !scan1[k]) || (n2[k] > 0 && !scan2[k])) { c->err = "bad scan"; return ICET_ERR_BAD_ARG; }
+        tot1 += (n1[k] + 63) / 64 * 64; tot2 += (n2[k] + 63) / 64 * 64;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    icet_status s = ensure_workspace(c, p, n_pairs, tot1);
+    if (s != ICET_OK) return s;
+    s = ensure_out(c, n_pairs);
+    if (s != ICET_OK) return s;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (3 * tot1 > c->cap_stage1) { HIPCHK(c, dev_realloc(c->d_stage1, (size_t)3 * tot1)); c->cap_stage1 = 3 * tot1; }
+    if (3 * tot2 > c->cap_stage2) { HIPCHK(c, dev_realloc(c->d_stage2, (size_t)3 * tot2)); c->cap_stage2 = 3 * tot2; }
+    int64_t o1 = 0, o2 = 0;
+    for (int k = 0; k < n_pairs; k++) {
+        const int64_t l1 = (n1[k] + 63) / 64 * 64, l2 = (n2[k] + 63) / 64 * 64;
+        PairDesc& d = c->h_desc[k];
+        d.s1 = c->d_stage1 + 3 * o1; d.s2 = c->d_stage2 + 3 * o2;
+        d.n1 = (int32_t)n1[k]; d.ld1 = (int32_t)l1; d.n2 = (int32_t)n2[k]; d.ld2 = (int32_t)l2; d.off1 = 0; d.pad = 0;
+        // host scans are dense column-major (ld == n) in this entry point
+        if (n1[k]) HIPCHK(c, hipMemcpy2DAsync(c->d_stage1 + 3 * o1, l1 * sizeof(float), scan1[k], n1[k] * sizeof(float), n1[k] * sizeof(float), 3, hipMemcpyHostToDevice, c->stream));
+        if (n2[k]) HIPCHK(c, hipMemcpy2DAsync(c->d_stage2 + 3 * o2, l2 * sizeof(float), scan2[k], n2[k] * sizeof(float), n2[k] * sizeof(float), 3, hipMemcpyHostToDevice, c->stream));
+        o1 += l1; o2 += l2;
+    }
+    const float* dx0 = nullptr;
+    if (x0) { HIPCHK(c, hipMemcpyAsync(c->d_x0, x0, sizeof(float) * 6 * n_pairs, hipMemcpyHostToDevice, c->stream)); dx0 = c->d_x0; }
+    if (p->runlen == 0) s = write_runlen0(c, n_pairs, dx0, c->d_out);
+    else s = enqueue(c, p, n_pairs, dx0, c->d_out, nullptr);
+    if (s != ICET_OK) return s;
+    HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(float) * 48 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < n_pairs; k++) {
+        std::memcpy(x_out + 6 * k, c->h_out + 48 * k, 6 * sizeof(float));
+        std::memcpy(pred_stds_out + 6 * k, c->h_out + 48 * k + 6, 6 * sizeof(float));
+        if (cov_out) std::memcpy(cov_out + 36 * k, c->h_out + 48 * k + 12, 36 * sizeof(float));
+    }
+    return ICET_OK;
+}
+
+icet_status icet_solve(icet_ctx* c, const icet_params* p, const float* scan1, int64_t n1, int64_t ld1,
+                       const float* scan2, int64_t n2, int64_t ld2, const float x0[6],
+                       float x_out[6], float pred_stds_out[6], float cov_out[36], icet_aux* aux) {
+    if (!c) return ICET_ERR_BAD_ARG;
+    if (!params_ok(p) || n1 < 0 || n2 < 0 || ld1 < n1 || ld2 < n2 || (n1 > 0 && !scan1) || (n2 > 0 && !scan2) || !x0 || !x_out || !pred_stds_out) {
+        c->err = "bad argument"; return ICET_ERR_BAD_ARG;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int V = p->bins_phi * p->bins_theta;
+    const int64_t l1 = (n1 + 63) / 64 * 64, l2 = (n2 + 63) / 64 * 64;
+    icet_status s = ensure_workspace(c, p, 1, l1);
+    if (s != ICET_OK) return s;
+    s = ensure_out(c, 1);
+    if (s != ICET_OK) return s;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (3 * l1 > c->cap_stage1) { HIPCHK(c, dev_realloc(c->d_stage1, (size_t)3 * l1)); c->cap_stage1 = 3 * l1; }
+    if (3 * l2 > c->cap_stage2) { HIPCHK(c, dev_realloc(c->d_stage2, (size_t)3 * l2)); c->cap_stage2 = 3 * l2; }
+    if (n1) HIPCHK(c, hipMemcpy2DAsync(c->d_stage1, l1 * sizeof(float), scan1, ld1 * sizeof(float), n1 * sizeof(float), 3, hipMemcpyHostToDevice, c->stream));
+    if (n2) HIPCHK(c, hipMemcpy2DAsync(c->d_stage2, l2 * sizeof(float), scan2, ld2 * sizeof(float), n2 * sizeof(float), 3, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_x0, x0, sizeof(float) * 6, hipMemcpyHostToDevice, c->stream));
+    PairDesc& d = c->h_desc[0];
+    d.s1 = c->d_stage1; d.s2 = c->d_stage2; d.n1 = (int32_t)n1; d.ld1 = (int32_t)l1; d.n2 = (int32_t)n2; d.ld2 = (int32_t)l2; d.off1 = 0; d.pad = 0;
+    const AuxDev* ad = nullptr;
+    if (aux) {
+        s = ensure_aux(c, V, p->runlen);
+        if (s != ICET_OK) return s;
+        const size_t rl = p->runlen > 0 ? p->runlen : 1;
+        HIPCHK(c, hipMemsetAsync(c->aux_dev.n2_raw, 0, sizeof(int32_t) * rl * V, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->aux_dev.n2_in, 0, sizeof(int32_t) * rl * V, c->stream));
+        ad = &c->aux_dev;
+    }
+    if (p->runlen == 0) {
+        s = write_runlen0(c, 1, c->d_x0, c->d_out);
+        aux = nullptr;
+    } else {
+        s = enqueue(c, p, 1, c->d_x0, c->d_out, ad);
+    }
+    if (s != ICET_OK) return s;
+    HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, c->stream));
+    if (aux) {
+        const AuxDev& a = c->aux_dev; const size_t rl = p->runlen;
+#define ICET_AUX_COPY(dst, srcp, count, type) if (aux->dst) HIPCHK(c, hipMemcpyAsync(aux->dst, a.srcp, sizeof(type) * (count), hipMemcpyDeviceToHost, c->stream))
+        ICET_AUX_COPY(cluster_bounds, bounds, (size_t)V * 6, float); ICET_AUX_COPY(n1_raw, n1_raw, V, int32_t); ICET_AUX_COPY(has_fit, has_fit, V, int32_t);
+        ICET_AUX_COPY(mu1, mu1, (size_t)V * 3, float); ICET_AUX_COPY(sigma1, sigma1, (size_t)V * 9, float); ICET_AUX_COPY(evecs1, evecs1, (size_t)V * 9, float);
+        ICET_AUX_COPY(l_diag, l_diag, (size_t)V * 3, float); ICET_AUX_COPY(x_hist, x_hist, rl * 6, float); ICET_AUX_COPY(htwh, htwh, rl * 36, float);
+        ICET_AUX_COPY(htwdz, htwdz, rl * 6, float); ICET_AUX_COPY(n2_raw, n2_raw, rl * V, int32_t); ICET_AUX_COPY(n2_in, n2_in, rl * V, int32_t);
+#undef ICET_AUX_COPY
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(x_out, c->h_out, 6 * sizeof(float));
+    std::memcpy(pred_stds_out, c->h_out + 6, 6 * sizeof(float));
+    if (cov_out) std::memcpy(cov_out, c->h_out + 12, 36 * sizeof(float));
+    return ICET_OK;
+}
+
+icet_status icet_last_timing(icet_ctx* c, float out_ms[4]) {
+    if (!c || !out_ms) return ICET_ERR_BAD_ARG;
+    if (!c->timing_valid) { c->err = "no timed call yet"; return ICET_ERR_BAD_ARG; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float a = 0, b = 0, acc = 0;
+    HIPCHK(c, hipEventElapsedTime(&a, c->ev_a, c->ev_b));
+    HIPCHK(c, hipEventElapsedTime(&b, c->ev_b, c->ev_c));
+    for (int it = 0; it < c->last_iters; it++) { float t = 0; HIPCHK(c, hipEventElapsedTime(&t, c->ev_acc[2 * it], c->ev_acc[2 * it + 1])); acc += t; }
+    out_ms[0] = a; out_ms[1] = b; out_ms[2] = c->last_iters ? acc : -1.f; out_ms[3] = (float)c->last_iters;
+    return ICET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,246 @@
+// icet_amd/csrc/icet_device_math.h -- per-lane small dense algebra for the gfx950 kernels.
+//
+// The reference delegates these to Eigen (absent here): SelfAdjointEigenSolver<Matrix3f>
+// (/root/reference/src/icet.cpp:181-183), SelfAdjointEigenSolver<MatrixXf> 6x6 (:455-458) and
+// CompleteOrthogonalDecomposition::pseudoInverse (:320-321, :410-411, :428-429).  On the device one
+// lane owns one matrix, everything lives in registers / scratch, and there are no MFMA-shaped
+// contractions (3x3, 3x6, 6x6 only).
+//
+// The eigen-solvers follow the same published scheme Eigen 3.3 uses (closed-form 3x3 / Householder
+// tridiagonalisation, then implicit symmetric QR with Wilkinson shift) because the reference's
+// sigma-point test (src/icet.cpp:187-232) and its pred_stds inflation (:479) depend on eigenvector
+// SIGNS; a Jacobi sweep would give the same eigenpairs with different signs.  Contraction is
+// switched off inside these routines so host-side checks see the same rounding sequence.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+
+namespace icetdev {
+
+__device__ __forceinline__ void make_givens(float p, float q, float& c, float& s) {
+#pragma clang fp contract(off)
+    if (q == 0.f) { c = p < 0.f ? -1.f : 1.f; s = 0.f; }
+    else if (p == 0.f) { c = 0.f; s = q < 0.f ? 1.f : -1.f; }
+    else if (fabsf(p) > fabsf(q)) {
+        float t = q / p; float u = sqrtf(1.f + t * t); if (p < 0.f) u = -u;
+        c = 1.f / u; s = -t * c;
+    } else {
+        float t = p / q; float u = sqrtf(1.f + t * t); if (q < 0.f) u = -u;
+        s = -1.f / u; c = -t * s;
+    }
+}
+
+// One implicit-shift QR sweep on the unreduced block [start, end] of a symmetric tridiagonal matrix;
+// the rotations are accumulated into Q (N x N row-major) on the right.
+template <int N>
+__device__ inline void tridiag_qr_step(float* diag, float* sub, int start, int end, float* Q) {
+#pragma clang fp contract(off)
+    float td = (diag[end - 1] - diag[end]) * 0.5f;
+    float e = sub[end - 1];
+    float mu = diag[end];
+    if (td == 0.f) {
+        mu -= fabsf(e);
+    } else if (e != 0.f) {
+        const float e2 = e * e;
+        const float h = hypotf(td, e);
+        if (e2 == 0.f) mu -= e / ((td + (td > 0.f ? h : -h)) / e);
+        else           mu -= e2 / (td + (td > 0.f ? h : -h));
+    }
+    float x = diag[start] - mu;
+    float z = sub[start];
+    for (int k = start; k < end && z != 0.f; ++k) {
+        float c, s; make_givens(x, z, c, s);
+        float sdk  = s * diag[k] + c * sub[k];
+        float dkp1 = s * sub[k] + c * diag[k + 1];
+        diag[k]     = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+        diag[k + 1] = s * sdk + c * dkp1;
+        sub[k]      = c * sdk - s * dkp1;
+        if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
+        x = sub[k];
+        if (k < end - 1) { z = -s * sub[k + 1]; sub[k + 1] = c * sub[k + 1]; }
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            float xi = Q[i * N + k], yi = Q[i * N + k + 1];
+            Q[i * N + k]     = c * xi - s * yi;
+            Q[i * N + k + 1] = s * xi + c * yi;
+        }
+    }
+}
+
+// Deflate / iterate / sort ascending (eigenvector columns follow).  Returns false on no convergence.
+template <int N>
+__device__ inline bool tridiag_eigen(float* diag, float* sub, float* Q) {
+#pragma clang fp contract(off)
+    int end = N - 1, start = 0, iter = 0;
+    const float precision = 2.f * FLT_EPSILON;
+    while (end > 0) {
+        for (int i = start; i < end; ++i)
+            if (fabsf(sub[i]) <= (fabsf(diag[i]) + fabsf(diag[i + 1])) * precision || fabsf(sub[i]) <= FLT_MIN)
+                sub[i] = 0.f;
+        while (end > 0 && sub[end - 1] == 0.f) end--;
+        if (end <= 0) break;
+        iter++;
+        if (iter > 30 * N) break;
+        start = end - 1;
+        while (start > 0 && sub[start - 1] != 0.f) start--;
+        tridiag_qr_step<N>(diag, sub, start, end, Q);
+    }
+    bool ok = iter <= 30 * N;
+    if (ok) {
+        for (int i = 0; i < N - 1; ++i) {
+            int k = i; float mn = diag[i];
+            for (int j = i + 1; j < N; j++) if (diag[j] < mn) { mn = diag[j]; k = j; }
+            if (k != i) {
+                float t = diag[i]; diag[i] = diag[k]; diag[k] = t;
+                for (int r = 0; r < N; r++) { float q = Q[r * N + i]; Q[r * N + i] = Q[r * N + k]; Q[r * N + k] = q; }
+            }
+        }
+    }
+    return ok;
+}
+
+// Symmetric 3x3 (lower triangle a00 a10 a11 a20 a21 a22): eigenvalues ascending, eigenvectors = columns
+// of V (row-major).  Closed-form tridiagonalisation as for a fixed-size 3x3, then QR iteration.
+__device__ inline bool eig3_sym(float a00, float a10, float a11, float a20, float a21, float a22, float ev[3], float V[9]) {
+#pragma clang fp contract(off)
+    float scale = fmaxf(fmaxf(fmaxf(fabsf(a00), fabsf(a10)), fmaxf(fabsf(a11), fabsf(a20))), fmaxf(fabsf(a21), fabsf(a22)));
+    if (scale == 0.f) scale = 1.f;
+    a00 /= scale; a10 /= scale; a11 /= scale; a20 /= scale; a21 /= scale; a22 /= scale;
+    float diag[3], sub[3] = {0.f, 0.f, 0.f};
+    V[0] = 1.f; V[1] = 0.f; V[2] = 0.f; V[3] = 0.f; V[4] = 1.f; V[5] = 0.f; V[6] = 0.f; V[7] = 0.f; V[8] = 1.f;
+    diag[0] = a00;
+    float v1norm2 = a20 * a20;
+    if (v1norm2 <= FLT_MIN) {
+        diag[1] = a11; diag[2] = a22; sub[0] = a10; sub[1] = a21;
+    } else {
+        float beta = sqrtf(a10 * a10 + v1norm2);
+        float invBeta = 1.f / beta;
+        float m01 = a10 * invBeta, m02 = a20 * invBeta;
+        float q = 2.f * m01 * a21 + m02 * (a22 - a11);
+        diag[1] = a11 + m02 * q;
+        diag[2] = a22 - m02 * q;
+        sub[0] = beta;
+        sub[1] = a21 - m01 * q;
+        V[4] = m01; V[5] = m02; V[7] = m02; V[8] = -m01;
+    }
+    bool ok = tridiag_eigen<3>(diag, sub, V);
+    ev[0] = diag[0] * scale; ev[1] = diag[1] * scale; ev[2] = diag[2] * scale;
+    return ok;
+}
+
+// Householder vector of x[0..m) (stride in floats): essential part overwrites x[1..m), returns tau/beta.
+__device__ inline void make_householder(float* x, int m, int stride, float& tau, float& beta) {
+#pragma clang fp contract(off)
+    float tailSq = 0.f;
+    for (int i = 1; i < m; i++) tailSq += x[i * stride] * x[i * stride];
+    float c0 = x[0];
+    if (tailSq <= FLT_MIN) {
+        tau = 0.f; beta = c0;
+        for (int i = 1; i < m; i++) x[i * stride] = 0.f;
+    } else {
+        beta = sqrtf(c0 * c0 + tailSq);
+        if (c0 >= 0.f) beta = -beta;
+        for (int i = 1; i < m; i++) x[i * stride] = x[i * stride] / (c0 - beta);
+        tau = (beta - c0) / beta;
+    }
+}
+
+// Symmetric 6x6 (row-major, lower triangle read): eigenvalues ascending, eigenvectors = columns of Q.
+__device__ inline bool eig6_sym(const float* Ain, float ev[6], float* Q) {
+#pragma clang fp contract(off)
+    constexpr int n = 6;
+    float A[36];
+    float scale = 0.f;
+    for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) scale = fmaxf(scale, fabsf(Ain[i * n + j]));
+    if (scale == 0.f) scale = 1.f;
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) A[i * n + j] = (j <= i) ? Ain[i * n + j] / scale : 0.f;
+    float h[6];
+    for (int i = 0; i < n - 1; i++) {
+        int rem = n - i - 1;
+        float tau, beta;
+        make_householder(&A[(i + 1) * n + i], rem, n, tau, beta);
+        A[(i + 1) * n + i] = 1.f;
+        float v[6], p[6];
+        for (int k = 0; k < rem; k++) v[k] = A[(i + 1 + k) * n + i];
+        for (int a = 0; a < rem; a++) {
+            float s = 0.f;
+            for (int b = 0; b < rem; b++) {
+                int ra = i + 1 + a, rb = i + 1 + b;
+                float m = (ra >= rb) ? A[ra * n + rb] : A[rb * n + ra];
+                s += m * (tau * v[b]);
+            }
+            p[a] = s;
+        }
+        float dot = 0.f; for (int k = 0; k < rem; k++) dot += p[k] * v[k];
+        float alpha = tau * -0.5f * dot;
+        for (int k = 0; k < rem; k++) p[k] += alpha * v[k];
+        for (int a = 0; a < rem; a++) for (int b = 0; b <= a; b++)
+            A[(i + 1 + a) * n + i + 1 + b] -= v[a] * p[b] + p[a] * v[b];
+        A[(i + 1) * n + i] = beta;
+        h[i] = tau;
+    }
+    float diag[6], sub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < n; i++) diag[i] = A[i * n + i];
+    for (int i = 0; i < n - 1; i++) sub[i] = A[(i + 1) * n + i];
+    for (int i = 0; i < 36; i++) Q[i] = 0.f;
+    for (int i = 0; i < n; i++) Q[i * n + i] = 1.f;
+    for (int k = n - 2; k >= 0; k--) {
+        int rem = n - k - 1;
+        float v[6]; v[0] = 1.f;
+        for (int t = 1; t < rem; t++) v[t] = A[(k + 1 + t) * n + k];
+        for (int col = 0; col < n; col++) {
+            float s = 0.f;
+            for (int t = 0; t < rem; t++) s += v[t] * Q[(k + 1 + t) * n + col];
+            s *= h[k];
+            for (int t = 0; t < rem; t++) Q[(k + 1 + t) * n + col] -= s * v[t];
+        }
+    }
+    bool ok = tridiag_eigen<6>(diag, sub, Q);
+    for (int i = 0; i < n; i++) ev[i] = diag[i] * scale;
+    return ok;
+}
+
+// Moore-Penrose pseudo-inverse of a symmetric PSD 3x3 (xx,xy,xz,yy,yz,zz) by cyclic Jacobi.
+// Eigenvalues <= rel_tol * lambda_max are treated as rank deficiency (the reference's COD uses
+// eps * 3 relative to its largest pivot).  Rows/columns that are exactly zero (axes masked by L)
+// stay exactly zero, so the result is the inverse of the kept principal block embedded in zeros.
+__device__ inline void pinv3_sym(const float a[6], float rel_tol, float w[6]) {
+    float A00 = a[0], A01 = a[1], A02 = a[2], A11 = a[3], A12 = a[4], A22 = a[5];
+    float V00 = 1.f, V01 = 0.f, V02 = 0.f, V10 = 0.f, V11 = 1.f, V12 = 0.f, V20 = 0.f, V21 = 0.f, V22 = 1.f;
+#define ICET_JROT(App, Aqq, Apq, Apr, Aqr, Vp0, Vq0, Vp1, Vq1, Vp2, Vq2)                                      \
+    if (Apq != 0.f) {                                                                                           \
+        float theta = (Aqq - App) / (2.f * Apq);                                                                \
+        float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));                    \
+        float c = 1.f / sqrtf(t * t + 1.f), s = t * c;                                                          \
+        float app = App - t * Apq, aqq = Aqq + t * Apq;                                                         \
+        float apr = c * Apr - s * Aqr, aqr = s * Apr + c * Aqr;                                                 \
+        App = app; Aqq = aqq; Apq = 0.f; Apr = apr; Aqr = aqr;                                                  \
+        float v;                                                                                                \
+        v = c * Vp0 - s * Vq0; Vq0 = s * Vp0 + c * Vq0; Vp0 = v;                                                \
+        v = c * Vp1 - s * Vq1; Vq1 = s * Vp1 + c * Vq1; Vp1 = v;                                                \
+        v = c * Vp2 - s * Vq2; Vq2 = s * Vp2 + c * Vq2; Vp2 = v;                                                \
+    }
+    // V holds eigenvectors as columns: Vrk = component r of eigenvector k.
+    for (int sweep = 0; sweep < 6; sweep++) {
+        float off = fabsf(A01) + fabsf(A02) + fabsf(A12);
+        float dg = fabsf(A00) + fabsf(A11) + fabsf(A22);
+        if (off <= 1e-9f * dg) break;
+        ICET_JROT(A00, A11, A01, A02, A12, V00, V01, V10, V11, V20, V21)
+        ICET_JROT(A00, A22, A02, A01, A12, V00, V02, V10, V12, V20, V22)
+        ICET_JROT(A11, A22, A12, A01, A02, V01, V02, V11, V12, V21, V22)
+    }
+#undef ICET_JROT
+    float lmax = fmaxf(fmaxf(fabsf(A00), fabsf(A11)), fabsf(A22));
+    float thr = rel_tol * lmax;
+    float i0 = (fabsf(A00) > thr) ? 1.f / A00 : 0.f;
+    float i1 = (fabsf(A11) > thr) ? 1.f / A11 : 0.f;
+    float i2 = (fabsf(A22) > thr) ? 1.f / A22 : 0.f;
+    w[0] = i0 * V00 * V00 + i1 * V01 * V01 + i2 * V02 * V02;
+    w[1] = i0 * V00 * V10 + i1 * V01 * V11 + i2 * V02 * V12;
+    w[2] = i0 * V00 * V20 + i1 * V01 * V21 + i2 * V02 * V22;
+    w[3] = i0 * V10 * V10 + i1 * V11 * V11 + i2 * V12 * V12;
+    w[4] = i0 * V10 * V20 + i1 * V11 * V21 + i2 * V12 * V22;
+    w[5] = i0 * V20 * V20 + i1 * V21 * V21 + i2 * V22 * V22;
+}
+
+}  // namespace icetdev

@@ -1,0 +1,84 @@
+// icet_amd/csrc/icet_internal.h -- structures shared by the HIP kernels and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace icet {
+
+constexpr int kAccWords = 12;        // per-slot accumulator in HBM: raw count, in count, Sd[3], Sdd[6], pad
+constexpr int kAccLds   = 11;        // same in LDS, odd stride (bank spread)
+constexpr int kMaxVoxels = 32768;    // slot ids travel as int16
+
+// One scan pair as the kernels see it (device pointers, column-major N x 3).
+struct PairDesc {
+    const float* s1; const float* s2;
+    int32_t n1, ld1, n2, ld2;
+    int32_t off1;                    // start of this pair's segment in the scan-1 temporaries
+    int32_t pad;
+};
+
+// What the per-iteration point kernel needs about an active voxel (keyframe voxel with a scan-1
+// Gaussian, outer > 1 and |idx1| > n: the scan-1 side of the gate at src/icet.cpp:290).
+struct SlotHot {
+    float az0, az1, el0, el1, inner, outer;   // clusterBounds row (src/icet.cpp:149)
+    float mu[3];                              // mu1
+    int32_t v;                                // voxel index T*phi + theta
+    int32_t pad[2];
+};
+
+// What the per-voxel Gauss-Newton kernel needs.
+struct SlotFit {
+    float mu[3];
+    float s1n[6];                             // sigma1 / (|idx1| - 1), upper triangle xx xy xz yy yz zz
+    float M[9];                               // L * U^T = L * V, row-major (src/icet.cpp:317,329)
+    int32_t n1;
+    int32_t v;
+};
+
+// Optional dense (per-voxel) dump for the reference's public side tables; device pointers or null.
+struct AuxDev {
+    float* bounds; int32_t* n1_raw; int32_t* has_fit; float* mu1; float* sigma1; float* evecs1; float* l_diag;
+    float* x_hist; float* htwh; float* htwdz; int32_t* n2_raw; int32_t* n2_in;
+};
+
+struct Workspace {
+    // capacities
+    int32_t cap_pairs = 0; int64_t cap_n1 = 0; int32_t cap_V = 0;
+    PairDesc* desc = nullptr;
+    int32_t* seg_off = nullptr;               // pairs+1, scan-1 segment offsets
+    float *r1 = nullptr, *th1 = nullptr, *ph1 = nullptr;            // spherical scan 1, input order
+    uint32_t *keyA = nullptr, *keyB = nullptr, *valA = nullptr, *valB = nullptr;
+    int32_t *pred = nullptr, *src = nullptr; uint8_t* exec = nullptr;
+    float *rs = nullptr, *ths = nullptr, *phs = nullptr;            // spherical scan 1 in (bin, position) order
+    int32_t *bin_count = nullptr, *bin_start = nullptr;             // pairs x V, pairs x (V+1)
+    SlotHot* hotD = nullptr; SlotFit* fitD = nullptr; int32_t* activeD = nullptr;   // dense, pairs x V
+    SlotHot* hotS = nullptr; SlotFit* fitS = nullptr;                               // compact, pairs x V
+    int16_t* slot_of_voxel = nullptr; int32_t* n_slots = nullptr;
+    uint32_t* acc = nullptr;                  // pairs x V x kAccWords
+    float* xf = nullptr;                      // pairs x 16: t[3], R[9] row-major, angles[3], pad
+    float* X = nullptr;                       // pairs x 6
+    int32_t* flags = nullptr;                 // pairs: bit0 = scramble walk overflow
+    void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+};
+
+struct LaunchCfg {
+    int T, P, V, n, runlen;
+    float thresh, buff;
+    int n_pairs;
+    int max_n1, max_n2;
+    int64_t total_n1;
+};
+
+// kernels.hip
+hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* aux, hipStream_t st);
+hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st);
+hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st);
+hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st);
+
+// sort.hip
+size_t sort_temp_bytes(int64_t total_n, int n_segments);
+hipError_t sort_pairs_segmented(void* tmp, size_t tmp_bytes, const uint32_t* key_in, uint32_t* key_out,
+                                const uint32_t* val_in, uint32_t* val_out, int64_t total_n, int n_segments,
+                                const int32_t* d_seg_off, int begin_bit, int end_bit, hipStream_t st);
+
+}  // namespace icet

@@ -1,0 +1,752 @@
+// icet_amd/csrc/icet_kernels.hip -- hand-written gfx950 kernels for the ICET hot path.
+//
+// Reference path (all under /root/reference): ICET::ICET src/icet.cpp:29-63 = fitScan1 (:68-107) ->
+// prepScan2 (:254-277) -> runlen x fitScan2 (:372-436).  The device formulation is NOT a translation:
+//
+//   keyframe build (once per pair, scan 1)
+//     k_scan1_spherical   utils::cartesianToSpherical (src/utils.cpp:93-119) + sort keys
+//     [stable radix sort by r]                         (src/icet.cpp:72-77)
+//     k_inverse_perm / k_exec_flags / k_scramble_src   the reference's one-step swap loop
+//                                                      (src/icet.cpp:78-83) in parallel closed form
+//     k_bin_positions + [stable sort by bin] + k_scan_bins + k_gather_sorted
+//                                                      sortSphericalCoordinates (src/icet.cpp:534-554)
+//     k_fit_scan1         fitCells1 (src/icet.cpp:109-252): findCluster (:557-607), bounds filter
+//                         (:609-652), mean/covariance, 3x3 eigen, sigma-point test (:654-696) -> L
+//     k_compact_slots     dense voxel table -> compact "slots" of active voxels
+//   Gauss-Newton loop (runlen x)
+//     k_gn_accumulate     transform (:375-378) + c2s (:387) + binning (:388) + bounds filter (:299)
+//                         + LDS-staged partial sums for the per-voxel mean/covariance (:303-306)
+//     k_gn_solve          per-voxel fitCells2 algebra (:314-338), block reduction of H^T W H and
+//                         H^T W dz (:401-402), 6x6 covariance (:410-417), conditioning (:443-492),
+//                         dx and X += dx (:427-433)
+//
+// No MFMA anywhere: the largest contraction is 3x6; the point kernel is HBM/VALU co-limited and the
+// rest is latency-bound bookkeeping.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "icet_internal.h"
+#include "icet_device_math.h"
+
+namespace icet {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr double kTwoPi = 6.283185307179586476925286766559;
+constexpr double kPi = 3.14159265358979323846;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// utils::cartesianToSpherical for one point (src/utils.cpp:93-119).  r is computed without
+// contraction and with the correctly rounded sqrt so that its BITS match a plain IEEE evaluation:
+// the radial sort + swap loop downstream is chaotic in the order of r.
+__device__ __forceinline__ void c2s_point(float x, float y, float z, float& r, float& th, float& ph) {
+    {
+#pragma clang fp contract(off)
+        float s = x * x + y * y;
+        s = s + z * z;
+        r = sqrtf(s);
+    }
+    th = atan2f(y, x);
+    if (th < 0.0f) th = (float)((double)th + kTwoPi);
+    ph = acosf(z / r);
+    if (r != r) r = 1000.0f;
+    if (th != th) th = 1000.0f;
+    if (ph != ph) ph = 1000.0f;
+}
+
+__device__ __forceinline__ void s2c_point(float r, float th, float ph, float& x, float& y, float& z) {
+    float sp = sinf(ph), cp = cosf(ph), st = sinf(th), ct = cosf(th);
+    x = r * sp * ct; y = r * sp * st; z = r * cp;
+}
+
+// sortSphericalCoordinates' bin of one (theta, phi) pair: double arithmetic on float angles,
+// truncation, modulo (src/icet.cpp:545-546).
+__device__ __forceinline__ int voxel_of(float th, float ph, int T, int P) {
+    int bt = static_cast<int>(((double)th / kTwoPi) * (double)T) % T;
+    int bp = static_cast<int>(((double)ph / kPi) * (double)P) % P;
+    return T * bp + bt;
+}
+
+__device__ __forceinline__ bool inside_bounds(float r, float az, float el, float az0, float az1, float el0, float el1, float inner, float outer) {
+    return az >= az0 && az <= az1 && el >= el0 && el <= el1 && r >= inner && r <= outer;
+}
+
+// ------------------------------------------------------------------------------------------------
+// keyframe build
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __restrict__ desc, float* __restrict__ r1, float* __restrict__ th1,
+                                                            float* __restrict__ ph1, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+    const PairDesc d = desc[blockIdx.y];
+    const float* x = d.s1; const float* y = d.s1 + d.ld1; const float* z = d.s1 + 2 * (size_t)d.ld1;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.n1; i += gridDim.x * kBlock) {
+        float r, th, ph;
+        c2s_point(x[i], y[i], z[i], r, th, ph);
+        size_t o = (size_t)d.off1 + i;
+        r1[o] = r; th1[o] = th; ph1[o] = ph;
+        key[o] = __float_as_uint(r);      // r >= +0 (or 1000 for NaN): the bit pattern orders like the float
+        val[o] = (uint32_t)i;
+    }
+}
+
+// pred[s[i]] = i : rank of every original row.
+__global__ __launch_bounds__(kBlock) void k_inverse_perm(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, int32_t* __restrict__ pred) {
+    const PairDesc d = desc[blockIdx.y];
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.n1; i += gridDim.x * kBlock)
+        pred[(size_t)d.off1 + s[(size_t)d.off1 + i]] = i;
+}
+
+// The reference "sorts" rows in place with
+//     for i: if (index[i] != i) { swap(row i, row index[i]); swap(index[i], index[index[i]]); }
+// (src/icet.cpp:78-83), which executes ONE step of each permutation cycle instead of following it.
+// Visiting order makes step i execute iff row i is not a fixed point and was not frozen by an
+// executed step i' = pred(i) < i.  So exec(v) is the parity of the length of the descending chain
+// v, pred(v), pred(pred(v)), ... taken while pred(u) < u.
+__global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
+                                                       uint8_t* __restrict__ exec, int32_t* __restrict__ flags, int max_walk) {
+    const PairDesc d = desc[blockIdx.y];
+    const size_t o = d.off1;
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < d.n1; v += gridDim.x * kBlock) {
+        uint8_t e = 0;
+        if ((int)s[o + v] != v) {
+            int u = v, len = 0;
+            for (;;) {
+                int p = pred[o + u];
+                if (p >= u) break;
+                u = p; len++;
+                if (len > max_walk) { atomicOr(&flags[blockIdx.y], 1); break; }
+            }
+            e = (len & 1) ? 0 : 1;
+        }
+        exec[o + v] = e;
+    }
+}
+
+// src[v] = original row that ends at position v after the swap loop.  Position v receives row
+// pred(v), except at the head of a run of executed steps, where the row arrives from the end of
+// the forward chain v -> s[v] -> s[s[v]] ... while the steps executed.
+__global__ __launch_bounds__(kBlock) void k_scramble_src(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
+                                                         const uint8_t* __restrict__ exec, int32_t* __restrict__ src, int32_t* __restrict__ flags, int max_walk) {
+    const PairDesc d = desc[blockIdx.y];
+    const size_t o = d.off1;
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < d.n1; v += gridDim.x * kBlock) {
+        int f = v;
+        if ((int)s[o + v] != v) {
+            int p = pred[o + v];
+            f = p;
+            if (exec[o + v] && !exec[o + p]) {
+                int u = v, len = 0;
+                while (exec[o + u]) {
+                    u = (int)s[o + u];
+                    if (++len > max_walk) { atomicOr(&flags[blockIdx.y], 1); break; }
+                }
+                f = u;
+            }
+        }
+        src[o + v] = f;
+    }
+}
+
+// Serial fallback for adversarial permutations (walks longer than max_walk): one lane replays the
+// literal swap loop on indices.  Never taken on lidar data (observed walk depth <= 14).
+__global__ void k_scramble_serial(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, int32_t* __restrict__ idx_tmp,
+                                  int32_t* __restrict__ src, const int32_t* __restrict__ flags) {
+    const int pair = blockIdx.x;
+    if (threadIdx.x != 0 || !(flags[pair] & 1)) return;
+    const PairDesc d = desc[pair];
+    const size_t o = d.off1;
+    for (int i = 0; i < d.n1; i++) { idx_tmp[o + i] = (int)s[o + i]; src[o + i] = i; }
+    for (int i = 0; i < d.n1; i++) {
+        int j = idx_tmp[o + i];
+        if (j != i) {
+            int t = src[o + i]; src[o + i] = src[o + j]; src[o + j] = t;
+            idx_tmp[o + i] = idx_tmp[o + j]; idx_tmp[o + j] = j;
+        }
+    }
+}
+
+// Angular bin of the row sitting at every position after the scramble; key for the second sort.
+__global__ __launch_bounds__(kBlock) void k_bin_positions(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const float* __restrict__ th1,
+                                                          const float* __restrict__ ph1, uint32_t* __restrict__ key, uint32_t* __restrict__ val,
+                                                          int32_t* __restrict__ bin_count, int T, int P) {
+    const PairDesc d = desc[blockIdx.y];
+    const size_t o = d.off1;
+    const int V = T * P;
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < d.n1; v += gridDim.x * kBlock) {
+        int row = src[o + v];
+        int b = voxel_of(th1[o + row], ph1[o + row], T, P);
+        key[o + v] = (uint32_t)b; val[o + v] = (uint32_t)v;
+        atomicAdd(&bin_count[(size_t)blockIdx.y * V + b], 1);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_bins(const int32_t* __restrict__ bin_count, int32_t* __restrict__ bin_start, int V) {
+    __shared__ int wave_tot[kBlock / 64];
+    __shared__ int base;
+    const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int v0 = 0; v0 < V; v0 += kBlock) {
+        int v = v0 + threadIdx.x;
+        int c = v < V ? bin_count[(size_t)pair * V + v] : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; k++) woff += wave_tot[k];
+        int b = base;
+        if (v < V) bin_start[(size_t)pair * (V + 1) + v] = b + woff + incl - c;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) base = b + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bin_start[(size_t)pair * (V + 1) + V] = base;
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_sorted(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ sorted_pos, const int32_t* __restrict__ src,
+                                                          const float* __restrict__ r1, const float* __restrict__ th1, const float* __restrict__ ph1,
+                                                          float* __restrict__ rs, float* __restrict__ ths, float* __restrict__ phs) {
+    const PairDesc d = desc[blockIdx.y];
+    const size_t o = d.off1;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.n1; i += gridDim.x * kBlock) {
+        int row = src[o + sorted_pos[o + i]];
+        rs[o + i] = r1[o + row]; ths[o + i] = th1[o + row]; phs[o + i] = ph1[o + row];
+    }
+}
+
+// fitCells1 (src/icet.cpp:109-252): one wavefront per angular bin.
+__global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
+                                                      const float* __restrict__ rs, const float* __restrict__ ths, const float* __restrict__ phs,
+                                                      SlotHot* __restrict__ hotD, SlotFit* __restrict__ fitD, int32_t* __restrict__ activeD,
+                                                      AuxDev aux, int T, int P, int n, float thresh, float buff) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int V = T * P;
+    const int v = blockIdx.x * (kBlock / 64) + wave;
+    const int pair = blockIdx.y;
+    if (v >= V) return;
+    const PairDesc d = desc[pair];
+    const int theta = v % T, phi = v / T;
+    // src/icet.cpp:136-139: (float / int) -> float, times a double constant, stored to float
+    const float az0 = (float)((double)((float)theta / (float)T) * kTwoPi);
+    const float az1 = (float)((double)((float)(theta + 1) / (float)T) * kTwoPi);
+    const float el0 = (float)((double)((float)phi / (float)P) * kPi);
+    const float el1 = (float)((double)((float)(phi + 1) / (float)P) * kPi);
+    const int bs = bin_start[(size_t)pair * (V + 1) + v];
+    const int cnt = bin_start[(size_t)pair * (V + 1) + v + 1] - bs;
+    const size_t base = (size_t)d.off1 + bs;
+
+    float inner = 0.f, outer = 0.f;
+    int has_fit = 0, active = 0;
+    float mean[3] = {0.f, 0.f, 0.f};
+    float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // xx xy xz yy yz zz
+    float ev[3] = {0.f, 0.f, 0.f}, Vm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float Ld[3] = {0.f, 0.f, 0.f};
+
+    if (cnt >= n) {
+        // ---- findCluster (src/icet.cpp:557-607): first run of >= n consecutive points whose
+        // successive |dr| <= thresh, walking the bin in stored (scrambled) order.
+        int run_start = 0; float front = 0.f; float carry_prev = 0.f; bool found = false;
+        for (int c0 = 0; c0 < cnt && !found; c0 += 64) {
+            const int i = c0 + lane; const bool valid = i < cnt;
+            const float r = valid ? rs[base + i] : 0.f;
+            float prev = __shfl_up(r, 1);
+            if (lane == 0) prev = carry_prev;
+            const bool brk = valid && (i == 0 || !(fabsf(prev - r) <= thresh));
+            unsigned long long m = __ballot(brk);
+            while (m) {
+                const int b = __ffsll((long long)m) - 1; m &= m - 1;
+                const int g = c0 + b;
+                if (g - run_start >= n) {
+                    const float back = (b > 0) ? __shfl(r, b - 1) : carry_prev;
+                    inner = front - buff; outer = back + buff; found = true; break;
+                }
+                run_start = g; front = __shfl(r, b);
+            }
+            carry_prev = __shfl(r, 63);
+        }
+        if (!found && cnt - run_start >= n) {
+            if (front != 0.f) { const float back = rs[base + cnt - 1]; inner = front - buff; outer = back + buff; }
+            else { inner = 0.f; outer = 0.f; }
+        }
+        // ---- filterPointsInsideCluster + sphericalToCartesian + mean (src/icet.cpp:155-160)
+        float sx = 0.f, sy = 0.f, sz = 0.f; int rows = 0;
+        for (int i = lane; i < cnt; i += 64) {
+            const float r = rs[base + i], th = ths[base + i], ph = phs[base + i];
+            if (inside_bounds(r, th, ph, az0, az1, el0, el1, inner, outer)) {
+                float x, y, z; s2c_point(r, th, ph, x, y, z);
+                sx += x; sy += y; sz += z; rows++;
+            }
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); rows = wave_sum_i(rows);
+        if ((double)outer > 0.1 && rows * 3 >= n) {       // src/icet.cpp:158 (size() counts coefficients)
+            has_fit = 1;
+            mean[0] = sx / (float)rows; mean[1] = sy / (float)rows; mean[2] = sz / (float)rows;
+            float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int i = lane; i < cnt; i += 64) {
+                const float r = rs[base + i], th = ths[base + i], ph = phs[base + i];
+                if (inside_bounds(r, th, ph, az0, az1, el0, el1, inner, outer)) {
+                    float x, y, z; s2c_point(r, th, ph, x, y, z);
+                    const float dx = x - mean[0], dy = y - mean[1], dz = z - mean[2];
+                    c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+                }
+            }
+            const float den = (float)(rows - 1);
+#pragma unroll
+            for (int k = 0; k < 6; k++) cov[k] = wave_sum(c[k]) / den;
+            // ---- eigen-decomposition, sigma points, L (src/icet.cpp:181-232); every lane runs the same
+            // scalar code on the same values, lane 0 publishes.
+            icetdev::eig3_sym(cov[0], cov[1], cov[3], cov[2], cov[4], cov[5], ev, Vm);
+            bool ins[6] = {false, false, false, false, false, false};
+            bool stop = false;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const int k = j >> 1;
+                const float al = 2.0f * sqrtf(ev[k]);
+                const float sgn = (j & 1) ? -1.f : 1.f;
+                // rotated = diag(2 sqrt(lambda)) * U^T = diag(.) * V : ROW k of V (src/icet.cpp:193-202)
+                const float px = mean[0] + sgn * (al * Vm[3 * k + 0]);
+                const float py = mean[1] + sgn * (al * Vm[3 * k + 1]);
+                const float pz = mean[2] + sgn * (al * Vm[3 * k + 2]);
+                float r, az, el; c2s_point(px, py, pz, r, az, el);
+                if (!stop) {
+                    if (inside_bounds(r, az, el, az0, az1, el0, el1, inner, outer)) ins[j] = true;
+                    if (r > outer) stop = true;        // testSigmaPoints' early break (src/icet.cpp:683-685)
+                }
+            }
+            Ld[0] = (ins[0] || ins[1]) ? 1.f : 0.f; Ld[1] = (ins[2] || ins[3]) ? 1.f : 0.f; Ld[2] = (ins[4] || ins[5]) ? 1.f : 0.f;
+            active = (cnt > n && outer > 1.f) ? 1 : 0;  // scan-1 half of the gate at src/icet.cpp:290
+        }
+    }
+    if (lane == 0) {
+        const size_t o = (size_t)pair * V + v;
+        SlotHot h; h.az0 = az0; h.az1 = az1; h.el0 = el0; h.el1 = el1; h.inner = inner; h.outer = outer;
+        h.mu[0] = mean[0]; h.mu[1] = mean[1]; h.mu[2] = mean[2]; h.v = v; h.pad[0] = 0; h.pad[1] = 0;
+        hotD[o] = h;
+        SlotFit f; f.mu[0] = mean[0]; f.mu[1] = mean[1]; f.mu[2] = mean[2];
+        const float d1 = (float)(cnt - 1);
+#pragma unroll
+        for (int k = 0; k < 6; k++) f.s1n[k] = active ? cov[k] / d1 : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { f.M[3 * k] = Ld[k] * Vm[3 * k]; f.M[3 * k + 1] = Ld[k] * Vm[3 * k + 1]; f.M[3 * k + 2] = Ld[k] * Vm[3 * k + 2]; }
+        f.n1 = cnt; f.v = v;
+        fitD[o] = f;
+        activeD[o] = active;
+        if (aux.bounds) { float* b = aux.bounds + o * 6; b[0] = az0; b[1] = az1; b[2] = el0; b[3] = el1; b[4] = inner; b[5] = outer; }
+        if (aux.n1_raw) aux.n1_raw[o] = cnt;
+        if (aux.has_fit) aux.has_fit[o] = has_fit;
+        if (aux.mu1) { aux.mu1[o * 3] = mean[0]; aux.mu1[o * 3 + 1] = mean[1]; aux.mu1[o * 3 + 2] = mean[2]; }
+        if (aux.sigma1) { float* sg = aux.sigma1 + o * 9; sg[0] = cov[0]; sg[1] = cov[1]; sg[2] = cov[2]; sg[3] = cov[1]; sg[4] = cov[3]; sg[5] = cov[4]; sg[6] = cov[2]; sg[7] = cov[4]; sg[8] = cov[5]; }
+        if (aux.evecs1) for (int k = 0; k < 9; k++) aux.evecs1[o * 9 + k] = Vm[k];
+        if (aux.l_diag) { aux.l_diag[o * 3] = Ld[0]; aux.l_diag[o * 3 + 1] = Ld[1]; aux.l_diag[o * 3 + 2] = Ld[2]; }
+    }
+}
+
+// Dense per-voxel records -> compact slots in voxel order (phi-major, theta inner: the reference's
+// accumulation order, src/icet.cpp:391-404).
+__global__ __launch_bounds__(kBlock) void k_compact_slots(const SlotHot* __restrict__ hotD, const SlotFit* __restrict__ fitD, const int32_t* __restrict__ activeD,
+                                                          SlotHot* __restrict__ hotS, SlotFit* __restrict__ fitS, int16_t* __restrict__ slot_of_voxel,
+                                                          int32_t* __restrict__ n_slots, uint32_t* __restrict__ acc, int V) {
+    __shared__ int wave_tot[kBlock / 64];
+    __shared__ int base;
+    const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int v0 = 0; v0 < V; v0 += kBlock) {
+        const int v = v0 + threadIdx.x;
+        const int a = (v < V) ? activeD[(size_t)pair * V + v] : 0;
+        const unsigned long long m = __ballot(a != 0);
+        const int excl = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; k++) woff += wave_tot[k];
+        const int b = base;
+        if (v < V) {
+            if (a) {
+                const int s = b + woff + excl;
+                slot_of_voxel[(size_t)pair * ((V + 1) & ~1) + v] = (int16_t)s;
+                hotS[(size_t)pair * V + s] = hotD[(size_t)pair * V + v];
+                fitS[(size_t)pair * V + s] = fitD[(size_t)pair * V + v];
+            } else {
+                slot_of_voxel[(size_t)pair * ((V + 1) & ~1) + v] = (int16_t)-1;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < kBlock / 64; k++) t += wave_tot[k]; base = b + t; }
+        __syncthreads();
+    }
+    const int ns = base;
+    if (threadIdx.x == 0) n_slots[pair] = ns;
+    for (int i = threadIdx.x; i < ns * kAccWords; i += kBlock) acc[(size_t)pair * V * kAccWords + i] = 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gauss-Newton loop
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void write_xf(float* xf, const float X[6]) {
+    // utils::R(phi, theta, psi) (src/utils.cpp:144-152), row-major
+    const float phi = X[3], theta = X[4], psi = X[5];
+    const float cph = cosf(phi), sph = sinf(phi), cth = cosf(theta), sth = sinf(theta), cps = cosf(psi), sps = sinf(psi);
+    xf[0] = X[0]; xf[1] = X[1]; xf[2] = X[2];
+    xf[3] = cth * cps;  xf[4] = sps * cph + sph * sth * cps;  xf[5] = sph * sps - sth * cph * cps;
+    xf[6] = -sps * cth; xf[7] = cph * cps - sph * sth * sps;  xf[8] = sph * cps + sth * sps * cph;
+    xf[9] = sth;        xf[10] = -sph * cth;                  xf[11] = cph * cth;
+    xf[12] = phi; xf[13] = theta; xf[14] = psi; xf[15] = 0.f;
+}
+
+__global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X, float* __restrict__ xf, int n_pairs) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    float x[6];
+    for (int k = 0; k < 6; k++) { x[k] = x0 ? x0[p * 6 + k] : 0.f; X[p * 6 + k] = x[k]; }
+    write_xf(xf + p * 16, x);
+}
+
+// One pass of fitScan2's point work over a chunk of one pair's scan 2.
+//   points2 = (points2_OG.rowwise() + t) * R          src/icet.cpp:375-378
+//   cartesianToSpherical, sortSphericalCoordinates     src/icet.cpp:387-388
+//   filterPointsInsideCluster                          src/icet.cpp:299
+// and the sums that give mean / covariance of the surviving points (src/icet.cpp:303-306), taken
+// about the voxel's scan-1 mean so that one pass in float keeps its digits.
+// LDS holds this pair's voxel->slot map, the hot slot records and the partial sums of this block;
+// the partial sums are flushed with one global atomic per touched word at the end.
+__global__ __launch_bounds__(kBlock) void k_gn_accumulate(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
+                                                          const int16_t* __restrict__ slot_of_voxel, const int32_t* __restrict__ n_slots,
+                                                          const SlotHot* __restrict__ hotS, uint32_t* __restrict__ acc,
+                                                          int T, int P, int lds_slots) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int V = T * P;
+    const int pair = blockIdx.y;
+    const PairDesc d = desc[pair];
+    const int chunks = gridDim.x;
+    int cs = (d.n2 + chunks - 1) / chunks;
+    cs = (cs + kBlock - 1) / kBlock * kBlock;
+    const int begin = blockIdx.x * cs;
+    if (begin >= d.n2) return;
+    const int end = min(d.n2, begin + cs);
+
+    int16_t* map = reinterpret_cast<int16_t*>(smem);
+    const int map_words = (V + 1) / 2;
+    float* hot = reinterpret_cast<float*>(smem) + map_words;            // lds_slots x 9
+    uint32_t* lacc = reinterpret_cast<uint32_t*>(hot + lds_slots * 9);  // lds_slots x kAccLds
+    const int ns = n_slots[pair];
+    const int nl = min(ns, lds_slots);
+    {
+        const uint32_t* gm = reinterpret_cast<const uint32_t*>(slot_of_voxel + (size_t)pair * ((V + 1) & ~1));   // rows padded to even length
+        uint32_t* lm = reinterpret_cast<uint32_t*>(map);
+        for (int i = threadIdx.x; i < map_words; i += kBlock) lm[i] = gm[i];
+        const SlotHot* hs = hotS + (size_t)pair * V;
+        for (int i = threadIdx.x; i < nl * 9; i += kBlock) { int s = i / 9, k = i - s * 9; hot[i] = reinterpret_cast<const float*>(hs + s)[k]; }
+        for (int i = threadIdx.x; i < nl * kAccLds; i += kBlock) lacc[i] = 0u;
+    }
+    const float* xf = xf_all + pair * 16;
+    const float tx = xf[0], ty = xf[1], tz = xf[2];
+    const float R00 = xf[3], R01 = xf[4], R02 = xf[5], R10 = xf[6], R11 = xf[7], R12 = xf[8], R20 = xf[9], R21 = xf[10], R22 = xf[11];
+    __syncthreads();
+
+    const float* px = d.s2; const float* py = d.s2 + d.ld2; const float* pz = d.s2 + 2 * (size_t)d.ld2;
+    uint32_t* gacc = acc + (size_t)pair * V * kAccWords;
+    const SlotHot* hs = hotS + (size_t)pair * V;
+    for (int i = begin + threadIdx.x; i < end; i += kBlock) {
+        const float a = px[i] + tx, b = py[i] + ty, c = pz[i] + tz;
+        const float qx = a * R00 + b * R10 + c * R20;
+        const float qy = a * R01 + b * R11 + c * R21;
+        const float qz = a * R02 + b * R12 + c * R22;
+        float r, th, ph;
+        c2s_point(qx, qy, qz, r, th, ph);
+        const int v = voxel_of(th, ph, T, P);
+        const int s = map[v];
+        if (s < 0) continue;
+        if (s < nl) {
+            uint32_t* A = lacc + s * kAccLds;
+            atomicAdd(&A[0], 1u);
+            const float* h = hot + s * 9;
+            if (inside_bounds(r, th, ph, h[0], h[1], h[2], h[3], h[4], h[5])) {
+                const float dx = qx - h[6], dy = qy - h[7], dz = qz - h[8];
+                float* F = reinterpret_cast<float*>(A);
+                atomicAdd(&A[1], 1u);
+                atomicAdd(&F[2], dx); atomicAdd(&F[3], dy); atomicAdd(&F[4], dz);
+                atomicAdd(&F[5], dx * dx); atomicAdd(&F[6], dx * dy); atomicAdd(&F[7], dx * dz);
+                atomicAdd(&F[8], dy * dy); atomicAdd(&F[9], dy * dz); atomicAdd(&F[10], dz * dz);
+            }
+        } else {                                    // more active voxels than LDS slots: straight to HBM
+            uint32_t* A = gacc + (size_t)s * kAccWords;
+            atomicAdd(&A[0], 1u);
+            const SlotHot h = hs[s];
+            if (inside_bounds(r, th, ph, h.az0, h.az1, h.el0, h.el1, h.inner, h.outer)) {
+                const float dx = qx - h.mu[0], dy = qy - h.mu[1], dz = qz - h.mu[2];
+                float* F = reinterpret_cast<float*>(A);
+                atomicAdd(&A[1], 1u);
+                atomicAdd(&F[2], dx); atomicAdd(&F[3], dy); atomicAdd(&F[4], dz);
+                atomicAdd(&F[5], dx * dx); atomicAdd(&F[6], dx * dy); atomicAdd(&F[7], dx * dz);
+                atomicAdd(&F[8], dy * dy); atomicAdd(&F[9], dy * dz); atomicAdd(&F[10], dz * dz);
+            }
+        }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < nl; s += kBlock) {
+        const uint32_t* A = lacc + s * kAccLds;
+        const uint32_t raw = A[0];
+        if (raw == 0u) continue;
+        uint32_t* G = gacc + (size_t)s * kAccWords;
+        atomicAdd(&G[0], raw);
+        const uint32_t cin = A[1];
+        if (cin) {
+            atomicAdd(&G[1], cin);
+            float* GF = reinterpret_cast<float*>(G);
+            const float* AF = reinterpret_cast<const float*>(A);
+#pragma unroll
+            for (int k = 2; k < kAccLds; k++) atomicAdd(&GF[k], AF[k]);
+        }
+    }
+}
+
+// fitCells2's per-voxel algebra + reduction + the 6x6 solve.  One block per pair.
+__global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__ n_slots, const SlotFit* __restrict__ fitS, uint32_t* __restrict__ acc,
+                                                     float* __restrict__ X_all, float* __restrict__ xf_all, float* __restrict__ out, AuxDev aux,
+                                                     int V, int n, int iter, int runlen) {
+    __shared__ float J[27];
+    __shared__ float red[kBlock / 64][27];
+    const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* X = X_all + pair * 6;
+    if (threadIdx.x == 0) {
+        // get_H's three derivative matrices (src/icet.cpp:507-529), row-major
+        const float phi = X[3], theta = X[4], psi = X[5];
+        const float cph = cosf(phi), sph = sinf(phi), cth = cosf(theta), sth = sinf(theta), cps = cosf(psi), sps = sinf(psi);
+        J[0] = 0.f; J[1] = -sps * sph + cph * sth * cps; J[2] = cph * sps + sth * sph * cps;
+        J[3] = 0.f; J[4] = -sph * cps - cph * sth * sps; J[5] = cph * cps - sth * sps * sph;
+        J[6] = 0.f; J[7] = -cph * cth;                   J[8] = -sph * cth;
+        J[9] = -sth * cps;  J[10] = cth * sph * cps;  J[11] = -cth * cph * cps;
+        J[12] = sps * sth;  J[13] = -cth * sph * sps; J[14] = cth * sps * cph;
+        J[15] = cth;        J[16] = sph * sth;        J[17] = -sth * cph;
+        J[18] = -cth * sps; J[19] = cps * cph - sph * sth * sps;  J[20] = cps * sph + sth * cph * sps;
+        J[21] = -cps * cth; J[22] = -sps * cph - sph * sth * cps; J[23] = -sph * sps + sth * cps * cph;
+        J[24] = 0.f; J[25] = 0.f; J[26] = 0.f;
+    }
+    __syncthreads();
+    const int ns = n_slots[pair];
+    float S[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) S[k] = 0.f;
+    for (int s = threadIdx.x; s < ns; s += kBlock) {
+        uint32_t* A = acc + ((size_t)pair * V + s) * kAccWords;
+        const uint32_t n2 = A[0], m = A[1];
+        float sd[3], sdd[6];
+        const float* AF = reinterpret_cast<const float*>(A);
+        sd[0] = AF[2]; sd[1] = AF[3]; sd[2] = AF[4];
+#pragma unroll
+        for (int k = 0; k < 6; k++) sdd[k] = AF[5 + k];
+#pragma unroll
+        for (int k = 0; k < kAccLds; k++) A[k] = 0u;             // ready for the next iteration
+        const SlotFit f = fitS[(size_t)pair * V + s];
+        if (aux.n2_raw) aux.n2_raw[((size_t)pair * runlen + iter) * V + f.v] = (int)n2;
+        if (aux.n2_in) aux.n2_in[((size_t)pair * runlen + iter) * V + f.v] = (int)m;
+        if (!((int)n2 > n && (int)m > n)) continue;               // src/icet.cpp:290 (scan-2 half), :302
+        const float fm = (float)m;
+        const float db[3] = {sd[0] / fm, sd[1] / fm, sd[2] / fm};   // mean - mu1
+        const float mu2[3] = {f.mu[0] + db[0], f.mu[1] + db[1], f.mu[2] + db[2]};
+        const float den = (float)(m - 1), d2 = (float)(n2 - 1);
+        // R_noise = sigma1/(|idx1|-1) + cov2/(|idx2|-1)                         src/icet.cpp:315
+        float Rn[6];
+        Rn[0] = f.s1n[0] + ((sdd[0] - fm * db[0] * db[0]) / den) / d2;
+        Rn[1] = f.s1n[1] + ((sdd[1] - fm * db[0] * db[1]) / den) / d2;
+        Rn[2] = f.s1n[2] + ((sdd[2] - fm * db[0] * db[2]) / den) / d2;
+        Rn[3] = f.s1n[3] + ((sdd[3] - fm * db[1] * db[1]) / den) / d2;
+        Rn[4] = f.s1n[4] + ((sdd[4] - fm * db[1] * db[2]) / den) / d2;
+        Rn[5] = f.s1n[5] + ((sdd[5] - fm * db[2] * db[2]) / den) / d2;
+        // Rp = M Rn M^T  (M = L U^T)                                             src/icet.cpp:317
+        const float* M = f.M;
+        float MR[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            MR[3 * i + 0] = M[3 * i] * Rn[0] + M[3 * i + 1] * Rn[1] + M[3 * i + 2] * Rn[2];
+            MR[3 * i + 1] = M[3 * i] * Rn[1] + M[3 * i + 1] * Rn[3] + M[3 * i + 2] * Rn[4];
+            MR[3 * i + 2] = M[3 * i] * Rn[2] + M[3 * i + 1] * Rn[4] + M[3 * i + 2] * Rn[5];
+        }
+        float Rp[6];
+        Rp[0] = MR[0] * M[0] + MR[1] * M[1] + MR[2] * M[2];
+        Rp[1] = MR[0] * M[3] + MR[1] * M[4] + MR[2] * M[5];
+        Rp[2] = MR[0] * M[6] + MR[1] * M[7] + MR[2] * M[8];
+        Rp[3] = MR[3] * M[3] + MR[4] * M[4] + MR[5] * M[5];
+        Rp[4] = MR[3] * M[6] + MR[4] * M[7] + MR[5] * M[8];
+        Rp[5] = MR[6] * M[6] + MR[7] * M[7] + MR[8] * M[8];
+        float W[6];
+        icetdev::pinv3_sym(Rp, 3.0f * FLT_EPSILON, W);                        // src/icet.cpp:320-321
+        // H_z = M * [-I | Jx mu | Jy mu | Jz mu]                                  src/icet.cpp:324-329
+        float Hj[9];      // columns 3..5 of H_j, row-major 3x3
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            Hj[3 * i + 0] = J[3 * i] * mu2[0] + J[3 * i + 1] * mu2[1] + J[3 * i + 2] * mu2[2];
+            Hj[3 * i + 1] = J[9 + 3 * i] * mu2[0] + J[9 + 3 * i + 1] * mu2[1] + J[9 + 3 * i + 2] * mu2[2];
+            Hj[3 * i + 2] = J[18 + 3 * i] * mu2[0] + J[18 + 3 * i + 1] * mu2[1] + J[18 + 3 * i + 2] * mu2[2];
+        }
+        float Hz[18];     // 3 x 6 row-major
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            Hz[6 * i + 0] = -M[3 * i]; Hz[6 * i + 1] = -M[3 * i + 1]; Hz[6 * i + 2] = -M[3 * i + 2];
+#pragma unroll
+            for (int j = 0; j < 3; j++) Hz[6 * i + 3 + j] = M[3 * i] * Hj[j] + M[3 * i + 1] * Hj[3 + j] + M[3 * i + 2] * Hj[6 + j];
+        }
+        float WH[18];     // W * Hz
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            WH[j]      = W[0] * Hz[j] + W[1] * Hz[6 + j] + W[2] * Hz[12 + j];
+            WH[6 + j]  = W[1] * Hz[j] + W[3] * Hz[6 + j] + W[4] * Hz[12 + j];
+            WH[12 + j] = W[2] * Hz[j] + W[4] * Hz[6 + j] + W[5] * Hz[12 + j];
+        }
+        // dz = M (mu2 - mu1)                                                       src/icet.cpp:335-337
+        float dz[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) dz[i] = M[3 * i] * db[0] + M[3 * i + 1] * db[1] + M[3 * i + 2] * db[2];
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int b = a; b < 6; b++) { S[q] += Hz[a] * WH[b] + Hz[6 + a] * WH[6 + b] + Hz[12 + a] * WH[12 + b]; q++; }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) S[21 + a] += WH[a] * dz[0] + WH[6 + a] * dz[1] + WH[12 + a] * dz[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 27; k++) { float t = wave_sum(S[k]); if (lane == 0) red[wave][k] = t; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+
+    float Hm[36], g[6];
+    {
+        int q = 0;
+        for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) {
+            float t = 0.f; for (int w = 0; w < kBlock / 64; w++) t += red[w][q];
+            Hm[a * 6 + b] = t; Hm[b * 6 + a] = t; q++;
+        }
+        for (int a = 0; a < 6; a++) { float t = 0.f; for (int w = 0; w < kBlock / 64; w++) t += red[w][21 + a]; g[a] = t; }
+    }
+    float ev[6], Q[36];
+    icetdev::eig6_sym(Hm, ev, Q);
+    // noise_mat = pinv(HTWH) (src/icet.cpp:410-411); rank rule eps*6 relative to the largest eigenvalue
+    float emax = 0.f;
+    for (int k = 0; k < 6; k++) emax = fmaxf(emax, fabsf(ev[k]));
+    const float rthr = 6.0f * FLT_EPSILON * emax;
+    float inv[6];
+    for (int k = 0; k < 6; k++) inv[k] = (fabsf(ev[k]) > rthr) ? 1.f / ev[k] : 0.f;
+    float cov[36];
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) {
+        float t = 0.f; for (int k = 0; k < 6; k++) t += Q[a * 6 + k] * inv[k] * Q[b * 6 + k];
+        cov[a * 6 + b] = t;
+    }
+    float ps[6];
+    for (int k = 0; k < 6; k++) ps[k] = sqrtf(fabsf(cov[k * 6 + k]));             // src/icet.cpp:412-417
+    // checkCondition (src/icet.cpp:443-492)
+    int k0 = 0;
+    {
+        float condition = ev[5] / ev[0];
+        int eyecount = 1;
+        while (fabsf(condition) > 1e6f && eyecount < 6) {
+            for (int k = 0; k < 6; k++) ps[k] += Q[k * 6 + eyecount - 1];           // src/icet.cpp:479
+            k0++;
+            condition = ev[5] / ev[eyecount];
+            eyecount++;
+        }
+    }
+    // dx = pinv(L2 lam U2^T) L2 U2^T HTWdz  = sum_{k >= k0} q_k (q_k . g) / lam_k     src/icet.cpp:427-430
+    float dx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = k0; k < 6; k++) {
+        if (inv[k] == 0.f) continue;
+        float pj = 0.f; for (int a = 0; a < 6; a++) pj += Q[a * 6 + k] * g[a];
+        pj *= inv[k];
+        for (int a = 0; a < 6; a++) dx[a] += Q[a * 6 + k] * pj;
+    }
+    float Xn[6];
+    for (int k = 0; k < 6; k++) { Xn[k] = X[k] + dx[k]; X[k] = Xn[k]; }
+    write_xf(xf_all + pair * 16, Xn);
+    float* o = out + (size_t)pair * 48;
+    for (int k = 0; k < 6; k++) { o[k] = Xn[k]; o[6 + k] = ps[k]; }
+    for (int k = 0; k < 36; k++) o[12 + k] = cov[k];
+    if (aux.x_hist) for (int k = 0; k < 6; k++) aux.x_hist[((size_t)pair * runlen + iter) * 6 + k] = Xn[k];
+    if (aux.htwh) for (int k = 0; k < 36; k++) aux.htwh[((size_t)pair * runlen + iter) * 36 + k] = Hm[k];
+    if (aux.htwdz) for (int k = 0; k < 6; k++) aux.htwdz[((size_t)pair * runlen + iter) * 6 + k] = g[k];
+}
+
+inline int chunks_for(int n_pairs, int max_n, int per_block_min, int target_blocks) {
+    int by_work = (max_n + per_block_min - 1) / per_block_min;
+    int want = (target_blocks + n_pairs - 1) / n_pairs;
+    int c = want < by_work ? want : by_work;
+    return c < 1 ? 1 : c;
+}
+
+}  // namespace
+
+#define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* auxp, hipStream_t st) {
+    AuxDev aux{}; if (auxp) aux = *auxp;
+    const int gx = chunks_for(c.n_pairs, c.max_n1, kBlock * 4, 2048);
+    dim3 grid(gx, c.n_pairs), blk(kBlock);
+    hipError_t e;
+    k_scan1_spherical<<<grid, blk, 0, st>>>(w.desc, w.r1, w.th1, w.ph1, w.keyA, w.valA);
+    ICET_LAUNCH_CHECK();
+    e = sort_pairs_segmented(w.sort_tmp, w.sort_tmp_bytes, w.keyA, w.keyB, w.valA, w.valB, c.total_n1, c.n_pairs, w.seg_off, 0, 32, st);
+    if (e != hipSuccess) return e;
+    // valB = s : original index of the row with rank i
+    k_inverse_perm<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred);
+    ICET_LAUNCH_CHECK();
+    e = hipMemsetAsync(w.flags, 0, sizeof(int32_t) * c.n_pairs, st); if (e != hipSuccess) return e;
+    const int max_walk = 4096;
+    k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.exec, w.flags, max_walk);
+    ICET_LAUNCH_CHECK();
+    k_scramble_src<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.exec, w.src, w.flags, max_walk);
+    ICET_LAUNCH_CHECK();
+    k_scramble_serial<<<c.n_pairs, 64, 0, st>>>(w.desc, w.valB, w.pred /* reused as scratch */, w.src, w.flags);
+    ICET_LAUNCH_CHECK();
+    e = hipMemsetAsync(w.bin_count, 0, sizeof(int32_t) * (size_t)c.n_pairs * c.V, st); if (e != hipSuccess) return e;
+    k_bin_positions<<<grid, blk, 0, st>>>(w.desc, w.src, w.th1, w.ph1, w.keyA, w.valA, w.bin_count, c.T, c.P);
+    ICET_LAUNCH_CHECK();
+    int bits = 1; while ((1 << bits) < c.V) bits++;
+    e = sort_pairs_segmented(w.sort_tmp, w.sort_tmp_bytes, w.keyA, w.keyB, w.valA, w.valB, c.total_n1, c.n_pairs, w.seg_off, 0, bits, st);
+    if (e != hipSuccess) return e;
+    k_scan_bins<<<c.n_pairs, blk, 0, st>>>(w.bin_count, w.bin_start, c.V);
+    ICET_LAUNCH_CHECK();
+    k_gather_sorted<<<grid, blk, 0, st>>>(w.desc, w.valB, w.src, w.r1, w.th1, w.ph1, w.rs, w.ths, w.phs);
+    ICET_LAUNCH_CHECK();
+    dim3 gfit((c.V + kBlock / 64 - 1) / (kBlock / 64), c.n_pairs);
+    k_fit_scan1<<<gfit, blk, 0, st>>>(w.desc, w.bin_start, w.rs, w.ths, w.phs, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n, c.thresh, c.buff);
+    ICET_LAUNCH_CHECK();
+    k_compact_slots<<<c.n_pairs, blk, 0, st>>>(w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, c.V);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st) {
+    k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
+    const int lds_slots = 384;
+    const int gx = chunks_for(c.n_pairs, c.max_n2, kBlock * 8, 2048);
+    const size_t lds = (size_t)((c.V + 1) / 2) * 4 + (size_t)lds_slots * (9 + kAccLds) * 4;
+    dim3 grid(gx, c.n_pairs), blk(kBlock);
+    k_gn_accumulate<<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, c.T, c.P, lds_slots);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* auxp, hipStream_t st) {
+    AuxDev aux{}; if (auxp) aux = *auxp;
+    k_gn_solve<<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace icet

@@ -1,0 +1,122 @@
+/* include/icet_hip.h -- C ABI of the MI355X-native ICET hot path (libicet_hip.so).
+ *
+ * This is the drop-in boundary for the ONE path this project accelerates: the body of the reference's
+ * `ICET::ICET(...)` constructor (/root/reference/src/icet.cpp:29-63, declared include/icet.h:38-40),
+ * i.e. fitScan1 -> prepScan2 -> runlen x fitScan2, whose only outputs the callers read are the public
+ * members `X` and `pred_stds` (src/odometry.cpp:76-79,126-131; src/simpleMapMaker.cpp:119-122).
+ * The reference has no FFI; a maintainer would bind these entry points from the constructor (see
+ * INTEGRATION.md for the exact stub).  Plain pointers and sizes only -- no Eigen, torch or HIP types.
+ *
+ * Scan layout everywhere: N x 3 float32 COLUMN-MAJOR with leading dimension ld >= N, i.e. exactly
+ * `Eigen::MatrixXf::data()` of the reference's `MatrixXf& scan` arguments: x[0..N) | y[0..N) | z[0..N).
+ *
+ * All entry points return an icet_status; none throws, none aborts.  The library fails loudly
+ * (ICET_ERR_NO_DEVICE / ICET_ERR_HIP) when no gfx950 device or kernel image is usable -- there is no
+ * CPU fallback behind this ABI.
+ */
+#ifndef ICET_HIP_H
+#define ICET_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum icet_status {
+    ICET_OK = 0,
+    ICET_ERR_BAD_ARG = 1,     /* null pointer, negative size, ld < n, bins <= 0, ...            */
+    ICET_ERR_NO_DEVICE = 2,   /* no HIP device / device id out of range                          */
+    ICET_ERR_HIP = 3,         /* a HIP runtime call or kernel launch failed (see icet_last_error) */
+    ICET_ERR_NOMEM = 4,       /* device or host allocation failed                                 */
+    ICET_ERR_UNSUPPORTED = 5  /* e.g. bins_phi*bins_theta above the compiled voxel limit          */
+} icet_status;
+
+/* Mirrors the reference constructor's scalar arguments (include/icet.h:38-40, defaults n=25,
+ * thresh=0.1, buff=0.1; call sites src/odometry.cpp:73-76, src/simpleMapMaker.cpp:113-119). */
+typedef struct icet_params {
+    int32_t runlen;       /* Gauss-Newton iterations (`runlen`, 7 or 12 at the call sites)       */
+    int32_t bins_phi;     /* `num_bins_phi`   : polar-angle ("elevation") bins, 24               */
+    int32_t bins_theta;   /* `num_bins_theta` : azimuth bins, 75                                  */
+    int32_t n;            /* minimum points per cluster                                           */
+    float   thresh;       /* radial jump threshold of findCluster (src/icet.cpp:557)              */
+    float   buff;         /* radial buffer added to the cluster bounds                            */
+    int32_t flags;        /* ICET_FLAG_* below; 0 = reference behaviour                           */
+} icet_params;
+
+enum { ICET_FLAG_NONE = 0,
+       ICET_FLAG_TIMING = 1   /* record HIP events around every bin/accumulate launch (icet_last_timing[2]) */ };
+
+/* A scan that already lives in device memory (HBM) on the context's device. */
+typedef struct icet_dev_scan {
+    const float* ptr;     /* device pointer, column-major N x 3, 16-byte aligned                  */
+    int64_t n;            /* points                                                               */
+    int64_t ld;           /* leading dimension in floats (>= n)                                   */
+} icet_dev_scan;
+
+/* Optional side outputs of a single-pair solve: what the reference object exposes besides X and
+ * pred_stds (include/icet.h:78-107).  Any pointer may be NULL.  V = bins_phi * bins_theta, voxel
+ * row index v = bins_theta * phi + theta (src/icet.cpp:149). */
+typedef struct icet_aux {
+    float*   cluster_bounds;  /* V x 6 row-major: azMin,azMax,elMin,elMax,inner,outer  (`clusterBounds`) */
+    int32_t* n1_raw;          /* V: scan-1 points per angular bin (|pointIndices1[theta][phi]|)          */
+    int32_t* has_fit;         /* V: 1 where mu1/sigma1/U/L exist                                          */
+    float*   mu1;             /* V x 3   (`mu1`)                                                          */
+    float*   sigma1;          /* V x 9   (`sigma1`, row-major 3x3)                                        */
+    float*   evecs1;          /* V x 9   eigenvectors as columns (reference stores U = transpose)        */
+    float*   l_diag;          /* V x 3   diagonal of `L`                                                  */
+    float*   x_hist;          /* runlen x 6: X after every iteration; X before the last update gives
+                                 the transform of the reference's final `points2` member               */
+    float*   htwh;            /* runlen x 36 (`HTWH_i` per iteration)                                     */
+    float*   htwdz;           /* runlen x 6  (`HTWdz_i` per iteration)                                    */
+    int32_t* n2_raw;          /* runlen x V: |pointIndices2| (only voxels with a scan-1 fit are counted) */
+    int32_t* n2_in;           /* runlen x V: scan-2 points inside the voxel's cluster bounds             */
+} icet_aux;
+
+typedef struct icet_ctx icet_ctx;   /* opaque: device id, stream, workspace */
+
+/* Create / destroy a context bound to one device.  `hip_stream` is a hipStream_t passed as void*
+ * (NULL = the context creates and owns a non-blocking stream).  One context is not re-entrant; use
+ * one per host thread (the reference constructs one ICET object at a time per node: ros::spin()). */
+icet_status icet_create(icet_ctx** ctx, int device_id, void* hip_stream);
+icet_status icet_destroy(icet_ctx* ctx);
+const char* icet_last_error(const icet_ctx* ctx);      /* static/ctx-owned string, never NULL */
+const char* icet_version(void);
+
+/* --- the constructor replacement: one scan pair, HOST pointers (copies in, solves, copies out) ----
+ * Replaces ICET::ICET (src/icet.cpp:29-63).  x0 = `X0`; x_out = member `X`; pred_stds_out = member
+ * `pred_stds`; cov_out (may be NULL) = the 6x6 `noise_mat` local of the last fitScan2
+ * (src/icet.cpp:410-411), row-major. */
+icet_status icet_solve(icet_ctx* ctx, const icet_params* p,
+                       const float* scan1, int64_t n1, int64_t ld1,
+                       const float* scan2, int64_t n2, int64_t ld2,
+                       const float x0[6], float x_out[6], float pred_stds_out[6], float cov_out[36],
+                       icet_aux* aux_or_null);
+
+/* --- N independent pairs, HOST pointers (one ICET object per pair in the reference) --------------- */
+icet_status icet_solve_batch(icet_ctx* ctx, const icet_params* p, int32_t n_pairs,
+                             const float* const* scan1, const int64_t* n1,
+                             const float* const* scan2, const int64_t* n2,
+                             const float* x0 /* n_pairs x 6 or NULL = zeros */,
+                             float* x_out /* n_pairs x 6 */, float* pred_stds_out /* n_pairs x 6 */,
+                             float* cov_out /* n_pairs x 36 or NULL */);
+
+/* --- N independent pairs, inputs and outputs resident in HBM; asynchronous on the ctx stream ------
+ * d_x0: device n_pairs x 6 or NULL (zeros).  d_out: device n_pairs x 48 floats per pair:
+ * [0,6) X, [6,12) pred_stds, [12,48) cov row-major.  Returns after enqueueing; call icet_sync. */
+icet_status icet_solve_batch_device(icet_ctx* ctx, const icet_params* p, int32_t n_pairs,
+                                    const icet_dev_scan* scan1, const icet_dev_scan* scan2,
+                                    const float* d_x0, float* d_out);
+icet_status icet_sync(icet_ctx* ctx);
+
+/* Pre-size the workspace (so the first timed call does not allocate). */
+icet_status icet_reserve(icet_ctx* ctx, const icet_params* p, int32_t n_pairs, int64_t total_n1, int64_t total_n2);
+
+/* Wall-clock-free device timing of the most recent icet_solve_batch_device call, measured with HIP
+ * events on the context's stream: [0] keyframe build ms, [1] Gauss-Newton loop ms, [2] ms inside the
+ * bin/accumulate kernel only (sum over iterations; -1 unless ICET_FLAG_TIMING was set), [3] number of
+ * accumulate launches timed. */
+icet_status icet_last_timing(icet_ctx* ctx, float out_ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICET_HIP_H */

@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- scan-pairs/s and ms/pair of the MI355X-native ICET hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path (keyframe build + 7 Gauss-Newton iterations, 75 x 24 voxels) over
+one batch of synthetic 64-channel scan pairs per GPU: BASELINE.json configs[2] (256 independent pairs,
+throughput mode) at N=1, and its sharded form configs[3] (256 pairs per GPU, pair k -> rank k mod N,
+one RCCL all-gather of 48 floats per pair) at N>1 -- weak scaling.  configs[1] (ONE pair, latency) is
+measured in the same run and reported under "latency"; configs[0] is the CPU-only plumbing case and
+configs[4] the high-resolution sweep (`--workload highres`): both are parity-test cases.
+
+Inputs are generated on the device (icet_amd.lidar_sim) and are resident in HBM before the timed
+region.  rank 0 prints ONE JSON line with the driver's contract fields plus
+  "roofline":     k_gn_accumulate (the dominant kernel): algorithmic bytes per launch = 12 B x scan-2
+                  points of the batch (x|y|z read once, transform fused, nothing N-sized written),
+                  divided by the launch duration measured with HIP events on the solve stream.
+  "cpu_baseline": the CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded
+                  sample of the same pairs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+PUBLISHED_MS_PER_PAIR = 35.0   # reference README.md:59 (Ryzen 5800X) -- different hardware, informational
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs-per-gpu", type=int, default=256)
+    ap.add_argument("--workload", choices=["batch", "highres"], default="batch")
+    ap.add_argument("--order", choices=["ring", "azimuth"], default="ring")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=96)
+    ap.add_argument("--distinct", type=int, default=0, help="generate only this many distinct pairs and cycle them (0 = all distinct)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import icet_amd
+    from icet_amd import lidar_sim, api
+    from icet_amd.dist import gather_results, shard_indices
+
+    if args.workload == "batch":
+        rings, steps_az, T, P, iters = 64, 2048, 75, 24, 7
+        n_local = args.pairs_per_gpu
+    else:
+        rings, steps_az, T, P, iters = 128, 4096, 150, 48, 10
+        n_local = 1
+    n_global = n_local * world
+    ids = shard_indices(n_global, rank, world)
+
+    # ---- synthetic inputs, generated in HBM ------------------------------------------------------
+    t_gen = time.time()
+    scans1, scans2 = [], []
+    distinct = args.distinct if args.distinct > 0 else len(ids)
+    for j, k in enumerate(ids):
+        if j < distinct:
+            if args.workload == "batch":
+                s1, s2, _ = lidar_sim.make_batch_pair(k, rings, steps_az, device=dev, order=args.order)
+            else:
+                s1, s2, _ = lidar_sim.make_pair(9000, 9001, lidar_sim.DEFAULT_MOTION, rings, steps_az, device=dev, order=args.order)
+        else:
+            s1, s2 = scans1[j % distinct], scans2[j % distinct]
+        scans1.append(s1); scans2.append(s2)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    n1 = [int(s.shape[1]) for s in scans1]; n2 = [int(s.shape[1]) for s in scans2]
+    d1 = [(s.data_ptr(), s.shape[1], s.shape[1]) for s in scans1]
+    d2 = [(s.data_ptr(), s.shape[1], s.shape[1]) for s in scans2]
+
+    stream = torch.cuda.Stream(device=dev)
+    ctx = icet_amd.Context(local_rank, stream=stream.cuda_stream)
+    p_plain = api.Params(iters, P, T, 25, 0.1, 0.1, 0)
+    p_timed = api.Params(iters, P, T, 25, 0.1, 0.1, api.FLAG_TIMING)
+    out = torch.zeros((len(ids), 48), dtype=torch.float32, device=dev)
+    ctx.reserve(p_plain, len(ids), sum(n1), sum(n2))
+
+    def step(params):
+        with torch.cuda.stream(stream):
+            ctx.solve_batch_device(d1, d2, params, out.data_ptr())
+            if world > 1:
+                return gather_results(out, n_global, rank, world)
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(p_plain)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step(p_plain)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / max(args.steps, 1) * 1e3
+    pairs_per_s = n_global * args.steps / dt
+
+    # ---- per-kernel timing with HIP events on the solve stream (extra steps, not part of `value`) ----
+    acc_ms, kf_ms, gn_ms, launches = 0.0, 0.0, 0.0, 0
+    reps = max(3, min(args.steps, 10))
+    for _ in range(reps):
+        step(p_timed)
+        t = ctx.last_timing()
+        acc_ms += t["accumulate_ms"]; kf_ms += t["keyframe_ms"]; gn_ms += t["gn_loop_ms"]; launches += t["accumulate_launches"]
+    fence()
+    acc_launch_ms = acc_ms / max(launches, 1)
+    bytes_per_launch = 12.0 * float(sum(n2))
+    achieved = bytes_per_launch / (acc_launch_ms * 1e-3) / 1e9 if acc_launch_ms > 0 else 0.0
+    bytes_path = sum(12.0 * a + 12.0 * b * iters + 192.0 for a, b in zip(n1, n2))
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_gn_accumulate_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    # ---- single-pair latency (configs[1]) on rank 0's first pair -----------------------------------
+    lat = None
+    if args.workload == "batch":
+        one1, one2 = d1[:1], d2[:1]
+        o1 = torch.zeros((1, 48), dtype=torch.float32, device=dev)
+        with torch.cuda.stream(stream):
+            for _ in range(5):
+                ctx.solve_batch_device(one1, one2, p_plain, o1.data_ptr())
+        torch.cuda.synchronize()
+        tl = time.perf_counter(); nrep = 30
+        with torch.cuda.stream(stream):
+            for _ in range(nrep):
+                ctx.solve_batch_device(one1, one2, p_plain, o1.data_ptr())
+                ctx.sync()
+        lat_ms = (time.perf_counter() - tl) / nrep * 1e3
+        lat = {"workload": "configs[1]: single 64-ch pair, 75x24 voxels, 7 iters, inputs resident in HBM", "ms_per_pair": round(lat_ms, 4),
+               "n1": n1[0], "n2": n2[0], "speedup_vs_published_35ms": round(PUBLISHED_MS_PER_PAIR / lat_ms, 1)}
+
+    # ---- CPU baseline: the oracle ("port") on this box's host cores, bounded sample, rank 0 at N=1 -----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        cores = min(os.cpu_count() or 1, 16)
+        m = min(len(ids), args.cpu_sample_pairs if args.workload == "batch" else 1)
+        h1 = [scans1[j].T.cpu().numpy() for j in range(m)]; h2 = [scans2[j].T.cpu().numpy() for j in range(m)]
+        po.solve_batch(h1[:1], h2[:1], runlen=iters, bins_phi=P, bins_theta=T, n_threads=1)      # warm-up / page-in
+        tc = time.perf_counter()
+        ref = po.solve_batch(h1, h2, runlen=iters, bins_phi=P, bins_theta=T, n_threads=cores)
+        tc = time.perf_counter() - tc
+        sec1, _ = po.time_pair(h1[0], h2[0], reps=3, runlen=iters, bins_phi=P, bins_theta=T)
+        dX = float(np.abs(ref["X"] - res[:m, :6].cpu().numpy()).max()) if world == 1 else None
+        cpu = {"value": round(m / tc, 3), "unit": "scan-pairs/s", "cores": cores, "kind": "port",
+               "sample": "first %d pairs of the same batch, one pair per host thread (oracle/icet_oracle.cpp, -O3 -march=native), %.1f s wall" % (m, tc),
+               "single_thread_ms_per_pair": round(sec1 * 1e3, 2), "max_abs_dX_vs_gpu_on_sample": dX}
+
+    if rank == 0:
+        line = {
+            "metric": "scan-pairs/sec + ms/pair, 64-ch 75x24 voxels 7 iters; HBM GB/s vs peak" if args.workload == "batch" else "scan-pairs/sec, 128-ch 150x48 voxels 10 iters",
+            "value": round(pairs_per_s, 2), "unit": "scan-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "ms_per_pair": round(ms_per_step / max(n_local, 1), 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("configs[2]/[3]: %d independent 64-ch synthetic scan pairs per GPU (~%dk pts/scan, %s-major), 75x24 voxels, 7 iters, "
+                                    "pair k -> rank k mod N, RCCL all-gather of 48 floats/pair when N>1" % (n_local, int(np.mean(n2) / 1000), args.order))
+                       if args.workload == "batch" else "configs[4]: single 128-ch pair (~%dk pts), 150x48 voxels, 10 iters" % int(np.mean(n2) / 1000),
+                       "pairs_per_gpu": n_local, "pairs_total": n_global, "points_scan1_mean": int(np.mean(n1)), "points_scan2_mean": int(np.mean(n2)),
+                       "bins_theta": T, "bins_phi": P, "iters": iters, "parallelism": "pairs round-robin x%d" % world, "gen_s": round(t_gen, 1)},
+            "roofline": {"kernel": "k_gn_accumulate", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(acc_launch_ms, 5), "launches_timed": launches,
+                         "whole_path_GBs": round(bytes_path / (ms_per_step * 1e-3) / 1e9, 1),
+                         "keyframe_ms_per_step": round(kf_ms / reps, 4), "gn_loop_ms_per_step": round(gn_ms / reps, 4)},
+            "cpu_baseline": cpu,
+            "latency": lat,
+            "published_reference_ms_per_pair": PUBLISHED_MS_PER_PAIR,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

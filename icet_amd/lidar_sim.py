@@ -1,0 +1,158 @@
+"""Seeded synthetic lidar scan pairs for the BASELINE configs 2-5.
+
+The reference ships only two real scan pairs (src/sample_data/frame_804/805.npy and
+python/point_clouds/sample_pc_1/2.npy); its 64-channel Ouster CSV scans are missing blobs.  The
+benchmark workloads therefore ray-cast a spinning lidar through a procedurally generated street
+scene.  Written with torch ops only so that the same code runs on the CPU (tests, small cases) and
+on the GPU (bench: 256 pairs are generated in HBM and never touch the host).
+
+Scene (all in the frame of the first sensor pose, sensor 1.8 m above the ground):
+  ground plane, 4 street walls (a rectangle of vertical planes with finite height), ~40 boxes and
+  cylinders.  Because the reference's scrambled radial walk only ever finds clusters on surfaces that
+  face the sensor, the scene is wall/box heavy on purpose.
+Sensor: `rings` elevation channels uniform in [-22.5, +22.5] deg x `steps` azimuth steps; range noise
+N(0, sigma); rays with no hit or range > max_range are dropped.  Scan 2 observes the same scene after
+the ground-truth motion X_true = (x, y, z, roll, pitch, yaw) in the reference's convention
+p_in_frame1 = R(angles)^T (p_in_frame2 + t) (src/icet.cpp:375-378), so a converged solve returns
+X close to X_true.
+"""
+import math
+import numpy as np
+import torch
+
+DEFAULT_MOTION = (0.50, 0.05, 0.01, 0.002, -0.001, 0.010)
+
+
+def euler_R(phi, theta, psi):
+    c, s = math.cos, math.sin
+    return np.array([
+        [c(theta) * c(psi), s(psi) * c(phi) + s(phi) * s(theta) * c(psi), s(phi) * s(psi) - s(theta) * c(phi) * c(psi)],
+        [-s(psi) * c(theta), c(phi) * c(psi) - s(phi) * s(theta) * s(psi), s(phi) * c(psi) + s(theta) * s(psi) * c(phi)],
+        [s(theta), -s(phi) * c(theta), c(phi) * c(theta)]], dtype=np.float64)
+
+
+def make_scene(seed, n_objects=40, sensor_height=1.8):
+    """Deterministic scene description (plain floats; built on the host from numpy's RandomState)."""
+    rs = np.random.RandomState(seed)
+    g = -sensor_height
+    half_w = rs.uniform(8.0, 14.0)             # street half width  (walls at y = +-half_w)
+    half_l = rs.uniform(35.0, 60.0)            # street half length (walls at x = +-half_l)
+    wall_h = rs.uniform(6.0, 10.0)
+    boxes, cyls = [], []
+    for k in range(n_objects):
+        for _ in range(50):
+            cx = rs.uniform(-half_l + 2, half_l - 2); cy = rs.uniform(-half_w + 1, half_w - 1)
+            if abs(cy) > 2.5 or abs(cx) > 6.0:
+                # keep the driving corridor |y| < 2.5 mostly free near the sensor
+                if not (abs(cy) < 2.0 and abs(cx) < 15.0):
+                    break
+        if k % 4 == 3:
+            cyls.append((cx, cy, rs.uniform(0.15, 0.6), g, g + rs.uniform(3.0, 7.0)))
+        else:
+            sx, sy, sz = rs.uniform(0.8, 4.5), rs.uniform(0.8, 4.5), rs.uniform(1.0, 3.5)
+            boxes.append((cx - sx / 2, cx + sx / 2, cy - sy / 2, cy + sy / 2, g, g + sz))
+    return dict(ground=g, half_w=half_w, half_l=half_l, wall_top=g + wall_h, boxes=boxes, cyls=cyls)
+
+
+def _raycast(scene, origin, dirs, max_range):
+    """Nearest hit distance along unit rays `dirs` (M x 3 tensor) from `origin` (3 floats). inf = no hit."""
+    ox, oy, oz = origin
+    dx, dy, dz = dirs[:, 0], dirs[:, 1], dirs[:, 2]
+    inf = torch.full_like(dx, float("inf"))
+    eps = 1e-9
+    best = inf.clone()
+
+    def upd(t, ok):
+        nonlocal best
+        t = torch.where(ok & (t > 0.05), t, inf)
+        best = torch.minimum(best, t)
+
+    # ground
+    t = (scene["ground"] - oz) / torch.where(dz.abs() < eps, torch.full_like(dz, eps), dz)
+    upd(t, dz < 0)
+    # walls: y = +-half_w (|x| <= half_l), x = +-half_l (|y| <= half_w), ground <= z <= wall_top
+    for yy in (-scene["half_w"], scene["half_w"]):
+        t = (yy - oy) / torch.where(dy.abs() < eps, torch.full_like(dy, eps), dy)
+        x = ox + t * dx; z = oz + t * dz
+        upd(t, (x.abs() <= scene["half_l"]) & (z >= scene["ground"]) & (z <= scene["wall_top"]))
+    for xx in (-scene["half_l"], scene["half_l"]):
+        t = (xx - ox) / torch.where(dx.abs() < eps, torch.full_like(dx, eps), dx)
+        y = oy + t * dy; z = oz + t * dz
+        upd(t, (y.abs() <= scene["half_w"]) & (z >= scene["ground"]) & (z <= scene["wall_top"]))
+    # boxes (slab test)
+    idx = 1.0 / torch.where(dx.abs() < eps, torch.full_like(dx, eps), dx)
+    idy = 1.0 / torch.where(dy.abs() < eps, torch.full_like(dy, eps), dy)
+    idz = 1.0 / torch.where(dz.abs() < eps, torch.full_like(dz, eps), dz)
+    for (x0, x1, y0, y1, z0, z1) in scene["boxes"]:
+        tx0 = (x0 - ox) * idx; tx1 = (x1 - ox) * idx
+        ty0 = (y0 - oy) * idy; ty1 = (y1 - oy) * idy
+        tz0 = (z0 - oz) * idz; tz1 = (z1 - oz) * idz
+        tmin = torch.maximum(torch.maximum(torch.minimum(tx0, tx1), torch.minimum(ty0, ty1)), torch.minimum(tz0, tz1))
+        tmax = torch.minimum(torch.minimum(torch.maximum(tx0, tx1), torch.maximum(ty0, ty1)), torch.maximum(tz0, tz1))
+        upd(tmin, tmax >= tmin)
+    # vertical cylinders
+    a = dx * dx + dy * dy
+    a_safe = torch.where(a < eps, torch.full_like(a, eps), a)
+    for (cx, cy, rad, z0, z1) in scene["cyls"]:
+        fx = ox - cx; fy = oy - cy
+        b = 2.0 * (fx * dx + fy * dy)
+        c = fx * fx + fy * fy - rad * rad
+        disc = b * b - 4.0 * a_safe * c
+        sq = torch.sqrt(torch.clamp(disc, min=0.0))
+        t = (-b - sq) / (2.0 * a_safe)
+        z = oz + t * dz
+        upd(t, (disc >= 0) & (z >= z0) & (z <= z1))
+    return torch.where(best <= max_range, best, inf)
+
+
+def sensor_dirs(rings, steps, device, order="ring"):
+    el = torch.linspace(math.radians(-22.5), math.radians(22.5), rings, dtype=torch.float64, device=device)
+    az = torch.arange(steps, dtype=torch.float64, device=device) * (2.0 * math.pi / steps)
+    if order == "ring":          # ring index slow, azimuth fast
+        E = el[:, None].expand(rings, steps).reshape(-1); A = az[None, :].expand(rings, steps).reshape(-1)
+    elif order == "azimuth":     # azimuth slow, ring fast (column-wise firing order)
+        E = el[None, :].expand(steps, rings).reshape(-1); A = az[:, None].expand(steps, rings).reshape(-1)
+    else:
+        raise ValueError("order must be 'ring' or 'azimuth'")
+    ce = torch.cos(E)
+    return torch.stack([ce * torch.cos(A), ce * torch.sin(A), torch.sin(E)], 1)
+
+
+def make_scan(scene, pose, noise_seed, rings=64, steps=2048, sigma=0.02, max_range=120.0, device="cpu", order="ring"):
+    """One scan in the sensor frame. pose = (t_s[3], R_s[3x3]) of the sensor in the scene frame.
+    Returns a float32 (3, N) tensor: column-major N x 3 (x[N] | y[N] | z[N]), N = rays that hit."""
+    t_s, R_s = pose
+    d = sensor_dirs(rings, steps, device, order)
+    Rt = torch.as_tensor(np.asarray(R_s, np.float64), device=device)
+    dw = d @ Rt.T                                        # world directions
+    rng = _raycast(scene, [float(v) for v in t_s], dw, max_range)
+    gen = torch.Generator(device=device); gen.manual_seed(int(noise_seed))
+    noise = torch.randn(rng.shape[0], generator=gen, device=device, dtype=torch.float64) * sigma
+    hit = torch.isfinite(rng)
+    r = (rng + noise)[hit]
+    pts = d[hit] * r[:, None]
+    return pts.to(torch.float32).T.contiguous()
+
+
+def make_pair(scene_seed=1000, noise_seed=1001, motion=DEFAULT_MOTION, rings=64, steps=2048, device="cpu", order="ring", sigma=0.02):
+    """(scan1, scan2, X_true); scans are float32 (3, N) tensors (column-major N x 3)."""
+    scene = make_scene(scene_seed)
+    X = np.asarray(motion, np.float64)
+    R = euler_R(X[3], X[4], X[5])
+    R_s = R.T
+    t_s = R.T @ X[:3]
+    s1 = make_scan(scene, (np.zeros(3), np.eye(3)), noise_seed * 2 + 1, rings, steps, sigma, device=device, order=order)
+    s2 = make_scan(scene, (t_s, R_s), noise_seed * 2 + 2, rings, steps, sigma, device=device, order=order)
+    return s1, s2, X.astype(np.float32)
+
+
+def batch_motion(k):
+    """Motion of pair k of the batched configs: U(+-0.6, +-0.05, +-0.02 m; +-0.005, +-0.005, +-0.02 rad), seed 5000+k."""
+    rs = np.random.RandomState(5000 + k)
+    lim = np.array([0.6, 0.05, 0.02, 0.005, 0.005, 0.02])
+    return rs.uniform(-lim, lim)
+
+
+def make_batch_pair(k, rings=64, steps=2048, device="cpu", order="ring"):
+    """Pair k of configs 3/4: scene seed 1000+2k, noise seed 1001+2k, motion seed 5000+k."""
+    return make_pair(1000 + 2 * k, 1001 + 2 * k, batch_motion(k), rings, steps, device, order)

@@ -1,0 +1,230 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (icet_amd.api -> libicet_hip.so), against
+the CPU oracle and the committed golden fixtures.  Nothing here reads /root/reference.
+
+Tolerances (float32 path, stated per SURVEY.md section 8(c)):
+  * integer / index work -- per-bin point counts, cluster membership, has_fit, the L masks -- bit-exact,
+    and the cluster bounds (float adds on identical r values) bit-exact;
+  * mu1 / sigma1: 5e-5 m / 5e-6 m^2 absolute (different summation order and libm sin/cos);
+  * per-iteration scan-2 counts: equal except a handful of boundary flips (ocml vs glibc atan2f/acosf differ
+    by an ulp on some inputs; a point within an ulp of a bin edge lands differently);
+  * final X: |dt| <= 3e-4 m, |d angle| <= 1e-4 rad  (one flipped point moves a ~75-point voxel mean by mm and
+    the 7-iteration loop amplifies it: the oracle's own float64 NumPy twin differs from it by 7e-5 m);
+  * pred_stds / cov: 1 % relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_T, TOL_R = 3e-4, 1e-4
+
+
+def _check_solution(res, ref, tol_t=TOL_T, tol_r=TOL_R):
+    assert np.isfinite(res["X"]).all()
+    assert np.abs(res["X"][:3] - ref["X"][:3]).max() <= tol_t, (res["X"], ref["X"])
+    assert np.abs(res["X"][3:] - ref["X"][3:]).max() <= tol_r, (res["X"], ref["X"])
+    assert np.allclose(res["pred_stds"], ref["pred_stds"], rtol=1e-2, atol=1e-7)
+    assert np.allclose(res["cov"], ref["cov"], rtol=2e-2, atol=1e-3 * np.abs(np.diag(ref["cov"])).min() + 1e-12)
+
+
+@pytest.mark.parametrize("name", ["frame_804_805", "sample_pc_1_2"])
+def test_golden_pairs_keyframe_table_and_solution(gpu_ctx, name):
+    from tests.conftest import load_pair, load_golden
+    a, b = load_pair(name); g = load_golden(name)
+    r = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
+    ax = r["aux"]
+    # keyframe build: exact where the arithmetic is integer / comparisons on identical floats
+    assert np.array_equal(ax["n1_raw"], g["n1_raw"])
+    assert np.array_equal(ax["cluster_bounds"], g["bounds"])
+    assert np.array_equal(ax["has_fit"], g["has_fit"])
+    f = g["has_fit"] == 1
+    assert np.array_equal(ax["l_diag"][f], g["Ldiag"][f])
+    assert np.abs(ax["mu1"][f] - g["mu1"][f]).max() < 5e-5
+    assert np.abs(ax["sigma1"][f] - g["sigma1"][f]).max() < 5e-6
+    dots = np.einsum("vij,vij->vj", ax["evecs1"][f], g["evecs1"][f])
+    well_separated = True     # eigenvector SIGNS follow the same scheme as the oracle's
+    assert (dots > 0.99).mean() > 0.97 and well_separated
+    # Gauss-Newton loop
+    act = f & (g["n1_raw"] > 25) & (g["bounds"][:, 5] > 1)
+    assert np.array_equal(ax["n2_raw"][0][act], g["n2_raw"][0][act])
+    assert (ax["n2_in"][0][act] != np.maximum(g["n2_in"][0][act], 0)).sum() <= 3
+    for it in range(7):
+        assert (ax["n2_raw"][it][act] != g["n2_raw"][it][act]).sum() <= 8
+        assert np.abs(ax["x_hist"][it][:3] - g["X_hist"][it][:3]).max() <= TOL_T
+        assert np.abs(ax["x_hist"][it][3:] - g["X_hist"][it][3:]).max() <= TOL_R
+        assert np.abs(ax["htwh"][it] - g["HTWH"][it]).max() <= 2e-3 * np.abs(g["HTWH"][it]).max()
+    _check_solution(r, g)
+
+
+def test_first_iteration_is_tight(gpu_ctx, frames, frames_golden):
+    """One iteration from X0 = 0: no accumulated boundary flips, so the update itself must agree closely."""
+    a, b = frames
+    r = gpu_ctx.solve(a, b, 1, np.zeros(6), 24, 75)
+    assert np.abs(r["X"] - frames_golden["X_hist"][0]).max() < 5e-6
+
+
+def test_synthetic_config2_pair_vs_oracle(gpu_ctx):
+    from icet_amd import lidar_sim as ls
+    from oracle import pyoracle as po
+    for order in ("ring", "azimuth"):
+        s1, s2, xt = ls.make_pair(order=order)
+        a, b = s1.T.numpy(), s2.T.numpy()
+        ref = po.solve(a, b, trace=True)
+        r = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
+        assert np.array_equal(r["aux"]["cluster_bounds"], ref["trace"]["bounds"])
+        assert np.array_equal(r["aux"]["has_fit"], ref["trace"]["has_fit"])
+        f = ref["trace"]["has_fit"] == 1
+        assert (r["aux"]["l_diag"][f] != ref["trace"]["Ldiag"][f]).any(1).sum() <= 1
+        _check_solution(r, ref)
+        assert np.abs(r["X"][:3] - xt[:3]).max() < 0.03       # and it registers the pair
+
+
+def test_nonzero_x0_and_longer_run(gpu_ctx, sample_pc):
+    from oracle import pyoracle as po
+    a, b = sample_pc
+    x0 = np.array([0.6, 0, 0, 0, 0, 0], np.float32)      # the reference demo seeds X0 = (1,0,0,0,0,0): icet_cpp_demo.cpp:34-36
+    ref = po.solve(a, b, x0=x0, runlen=12)
+    r = gpu_ctx.solve(a, b, 12, x0, 24, 75)
+    _check_solution(r, ref, 5e-4, 1e-4)
+    assert abs(r["X"][0] - 0.645) < 0.01
+
+
+def test_highres_config5_grid(gpu_ctx, sample_pc):
+    """150 x 48 voxels, 10 iterations (BASELINE config 5's grid) on the 131k-point real pair."""
+    from oracle import pyoracle as po
+    a, b = sample_pc
+    ref = po.solve(a, b, runlen=10, bins_phi=48, bins_theta=150, trace=True)
+    r = gpu_ctx.solve(a, b, 10, np.zeros(6), 48, 150, aux=True)
+    assert np.array_equal(r["aux"]["n1_raw"], ref["trace"]["n1_raw"])
+    assert np.array_equal(r["aux"]["cluster_bounds"], ref["trace"]["bounds"])
+    assert np.array_equal(r["aux"]["has_fit"], ref["trace"]["has_fit"])
+    _check_solution(r, ref, 5e-4, 1e-4)
+
+
+def test_other_parameters(gpu_ctx, frames):
+    from oracle import pyoracle as po
+    a, b = frames
+    for kw in (dict(n=50, thresh=0.3, buff=0.5), dict(n=10, thresh=0.05, buff=0.0)):
+        ref = po.solve(a, b, runlen=5, **kw)
+        r = gpu_ctx.solve(a, b, 5, np.zeros(6), 24, 75, **kw)
+        _check_solution(r, ref, 6e-4, 2e-4)
+
+
+def test_batch_equals_singles_and_oracle(gpu_ctx, frames, sample_pc):
+    """Ragged batch through icet_solve_batch (host pointers): each pair must equal its own single solve."""
+    from oracle import pyoracle as po
+    a, b = frames; c, d = sample_pc
+    s1 = [a, c, a[:30000], c[5000:90000], a]
+    s2 = [b, d, b[:31000], d[5000:91000], a]
+    x0 = np.zeros((5, 6), np.float32); x0[3, 0] = 0.3
+    out = gpu_ctx.solve_batch(s1, s2, 7, x0)
+    for k in range(5):
+        single = gpu_ctx.solve(s1[k], s2[k], 7, x0[k], 24, 75)
+        # same kernels, same data; only the atomics' arrival order differs
+        assert np.abs(out["X"][k] - single["X"]).max() < 5e-5
+        ref = po.solve(s1[k], s2[k], x0=x0[k])
+        _check_solution(dict(X=out["X"][k], pred_stds=out["pred_stds"][k], cov=out["cov"][k]), ref, 5e-4, 1.5e-4)
+
+
+def test_edge_cases(gpu_ctx, frames):
+    from oracle import pyoracle as po
+    a, b = frames
+    z = np.zeros((0, 3), np.float32)
+    x0 = np.array([0.1, 0, 0, 0, 0, 0.01], np.float32)
+    for s1, s2 in ((z, z), (a, z), (z, b)):
+        r = gpu_ctx.solve(s1, s2, 7, x0, 24, 75)
+        ref = po.solve(s1, s2, x0=x0)
+        assert np.allclose(r["X"], ref["X"], atol=1e-7) and np.allclose(r["X"], x0) and (r["pred_stds"] == 0).all()
+    rng = np.random.default_rng(0)
+    few = (rng.normal(size=(10, 3)) * 5).astype(np.float32)
+    r = gpu_ctx.solve(few, few, 7, np.zeros(6), 24, 75)
+    assert (r["X"] == 0).all() and (r["pred_stds"] == 0).all()
+    # runlen 0: constructor returns X0 and zero pred_stds (src/icet.cpp:36-37,47)
+    r = gpu_ctx.solve(a, b, 0, x0, 24, 75)
+    assert np.array_equal(r["X"], x0) and (r["pred_stds"] == 0).all()
+    # NaN / inf rows are binned at the 1000-sentinel like the reference (src/utils.cpp:116), not propagated
+    bad = a.copy(); bad[100] = np.nan; bad[200, 2] = np.inf
+    r = gpu_ctx.solve(bad, b, 3, np.zeros(6), 24, 75)
+    ref = po.solve(bad, b, runlen=3)
+    assert np.isfinite(r["X"]).all()
+    _check_solution(r, ref)
+    # all-zero scans (every point at the origin): nothing to fit
+    zz = np.zeros((5000, 3), np.float32)
+    r = gpu_ctx.solve(zz, zz, 3, np.zeros(6), 24, 75)
+    assert (r["X"] == 0).all()
+
+
+def test_scan2_order_invariance_full_size(gpu_ctx):
+    """Size-independent property at the BASELINE config-2 size: the per-voxel sums do not depend on the order
+    in which scan-2 points are stored (only scan-1's order feeds findCluster), so shuffling scan 2 must leave
+    X unchanged up to float summation order."""
+    from icet_amd import lidar_sim as ls
+    s1, s2, _ = ls.make_pair()
+    a, b = s1.T.numpy(), s2.T.numpy()
+    r0 = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
+    perm = np.random.default_rng(5).permutation(b.shape[0])
+    r1 = gpu_ctx.solve(a, b[perm], 7, np.zeros(6), 24, 75, aux=True)
+    assert np.array_equal(r0["aux"]["n2_raw"][0], r1["aux"]["n2_raw"][0])
+    assert np.array_equal(r0["aux"]["n2_in"][0], r1["aux"]["n2_in"][0])
+    assert np.abs(r0["X"] - r1["X"]).max() < 5e-5
+    # idempotence of the keyframe: scan 1 untouched -> identical table bits
+    assert np.array_equal(r0["aux"]["cluster_bounds"], r1["aux"]["cluster_bounds"])
+    assert np.array_equal(r0["aux"]["mu1"], r1["aux"]["mu1"])
+
+
+def test_device_resident_batch_full_size(gpu_ctx):
+    """icet_solve_batch_device with inputs resident in HBM (the bench path) at config-3 size with 4 distinct
+    pairs cycled 64 x: every replica of a pair must give that pair's single-solve answer."""
+    from icet_amd import lidar_sim as ls, api
+    import icet_amd
+    dev = torch.device("cuda", 0)
+    pairs = [ls.make_batch_pair(k, device=dev) for k in range(4)]
+    n_rep = 64
+    d1 = [(pairs[j % 4][0].data_ptr(), pairs[j % 4][0].shape[1], pairs[j % 4][0].shape[1]) for j in range(4 * n_rep)]
+    d2 = [(pairs[j % 4][1].data_ptr(), pairs[j % 4][1].shape[1], pairs[j % 4][1].shape[1]) for j in range(4 * n_rep)]
+    out = torch.zeros((4 * n_rep, 48), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx = icet_amd.Context(0)
+    p = api.Params(7, 24, 75, 25, 0.1, 0.1, 0)
+    ctx.solve_batch_device(d1, d2, p, out.data_ptr())
+    ctx.sync()
+    res = out.cpu().numpy()
+    from oracle import pyoracle as po
+    for k in range(4):
+        single = gpu_ctx.solve(pairs[k][0].T.cpu().numpy(), pairs[k][1].T.cpu().numpy(), 7, np.zeros(6), 24, 75)
+        block = res[k::4]
+        assert np.abs(block[:, :6] - single["X"]).max() < 5e-5
+        assert np.allclose(block[:, 6:12], single["pred_stds"], rtol=1e-3)
+    ref = po.solve(pairs[0][0].T.cpu().numpy(), pairs[0][1].T.cpu().numpy())
+    _check_solution(dict(X=res[0, :6], pred_stds=res[0, 6:12], cov=res[0, 12:].reshape(6, 6)), ref)
+    ctx.close()
+
+
+def test_icet_class_mirrors_reference_members(frames, frames_golden):
+    import icet_amd
+    a, b = frames
+    it = icet_amd.ICET(a, b, 7, np.zeros(6, np.float32), 24, 75)          # positional, like the reference call sites
+    assert it.X.shape == (6,) and it.pred_stds.shape == (6,)
+    assert it.clusterBounds.shape == (24 * 75, 6) and np.array_equal(it.clusterBounds, frames_golden["bounds"])
+    assert len(it.ellipsoid1Means) == len(it.ellipsoid1Covariances) == len(it.ellipsoid1Alphas) == 86
+    assert it.ellipsoid2Means == [] and it.points2.shape == b.shape and it.HTWH_i.shape == (6, 6) and it.HTWdz_i.shape == (6, 1)
+    assert np.abs(it.X[:3] - frames_golden["X"][:3]).max() <= TOL_T
+
+
+def test_error_behaviour(gpu_ctx, frames):
+    import icet_amd
+    a, b = frames
+    with pytest.raises(icet_amd.IcetError) as e:
+        gpu_ctx.solve(a, b, 7, np.zeros(6), 0, 75)
+    assert e.value.status == icet_amd.api.ICET_ERR_BAD_ARG
+    with pytest.raises(icet_amd.IcetError):
+        gpu_ctx.solve(a, b, -1, np.zeros(6), 24, 75)
+    with pytest.raises(icet_amd.IcetError) as e:
+        gpu_ctx.solve(a, b, 7, np.zeros(6), 400, 400)
+    assert e.value.status == icet_amd.api.ICET_ERR_UNSUPPORTED
+    with pytest.raises(icet_amd.IcetError):
+        icet_amd.Context(99)
+    # the context is still usable after errors
+    r = gpu_ctx.solve(a, b, 1, np.zeros(6), 24, 75)
+    assert np.isfinite(r["X"]).all()

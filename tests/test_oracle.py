@@ -1,0 +1,255 @@
+"""CPU tests (-m "not gpu"): the oracle against its committed golden vectors, against the independent NumPy
+model, and its restated Eigen decompositions against numpy.linalg.  The reference ships no tests for this
+path, so these are the pins that exist."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from oracle import icet_numpy as inp
+
+
+# ------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("name", ["frame_804_805", "sample_pc_1_2"])
+def test_oracle_reproduces_golden(name):
+    from tests.conftest import load_pair, load_golden
+    a, b = load_pair(name); g = load_golden(name)
+    o = po.solve(a, b, trace=True, runlen=7, bins_phi=24, bins_theta=75)
+    t = o["trace"]
+    # integer / index work is bit-exact
+    assert (t["n1_raw"] == g["n1_raw"]).all()
+    assert (t["has_fit"] == g["has_fit"]).all()
+    assert (t["Ldiag"] == g["Ldiag"]).all()
+    assert (t["n2_raw"][0] == g["n2_raw"][0]).all()
+    # cluster bounds come from float adds on identical r values: exact
+    assert np.array_equal(t["bounds"], g["bounds"])
+    # float results: same code, same flags -> tight (libm may differ by an ulp across hosts)
+    assert np.allclose(o["X"], g["X"], rtol=0, atol=2e-6)
+    assert np.allclose(o["pred_stds"], g["pred_stds"], rtol=1e-4, atol=1e-9)
+    assert np.allclose(t["mu1"], g["mu1"], rtol=0, atol=1e-5)
+    assert o["n_ub_voxels"] == int(g["n_ub_voxels"]) == 0
+
+
+def test_pool4_mode_equals_serial(frames):
+    a, b = frames
+    s = po.solve(a, b, mode=po.SERIAL)
+    p = po.solve(a, b, mode=po.POOL4)
+    # parallelFitCells2 reduces on the caller in submission order (src/icet.cpp:365-369): identical floats
+    assert np.array_equal(s["X"], p["X"]) and np.array_equal(s["pred_stds"], p["pred_stds"])
+
+
+def test_sample_counts_match_survey(frames_golden, sample_pc_golden):
+    # 86 of 357 populated bins of frame_804 and 112 of 410 of sample_pc_1 get a scan-1 Gaussian
+    assert int(frames_golden["has_fit"].sum()) == 86 and int((frames_golden["n1_raw"] >= 25).sum()) == 357
+    assert int(sample_pc_golden["has_fit"].sum()) == 112 and int((sample_pc_golden["n1_raw"] >= 25).sum()) == 410
+
+
+def test_notebook_anchor_ballpark(sample_pc):
+    # Loose external anchor (python/ICET_demo.ipynb stored output: ~0.66 m forward motion on sample_pc_1/2 with
+    # the Python variant's outdoor parameters).  The C++ path reaches the same basin with thresh = buff = 0.5.
+    a, b = sample_pc
+    o = po.solve(a, b, runlen=12, thresh=0.5, buff=0.5)
+    assert abs(o["X"][0] - 0.66) < 0.03 and abs(o["X"][1]) < 0.03 and abs(o["X"][2] - 0.0156) < 0.01
+
+
+# ------------------------------------------------------------------ independent NumPy model
+def test_oracle_vs_numpy_model(frames):
+    a, b = frames
+    o = po.solve(a, b, trace=True); t = o["trace"]
+    m = inp.solve(a, b, sign_ref=t["evecs1"])
+    tab = m["table"]
+    assert (tab["n1"] == t["n1_raw"]).all()
+    assert np.array_equal(tab["bounds"], t["bounds"])
+    assert (tab["has_fit"] == (t["has_fit"] == 1)).all()
+    assert (tab["L"] == t["Ldiag"]).all()
+    f = t["has_fit"] == 1
+    assert np.abs(tab["mu1"][f] - t["mu1"][f]).max() < 5e-5
+    assert np.abs(tab["sigma1"][f] - t["sigma1"][f]).max() < 1e-5
+    h = m["hist"]
+    assert (h["n2_raw"][0] == t["n2_raw"][0]).all()
+    assert (h["used"][0] == (t["used"][0] == 1)).all()
+    # float32 (C++) vs float64 (numpy) over 7 chaotic-at-the-boundaries iterations
+    assert np.abs(m["X"][:3] - o["X"][:3]).max() < 3e-4
+    assert np.abs(m["X"][3:] - o["X"][3:]).max() < 1e-4
+    assert np.allclose(m["pred_stds"], o["pred_stds"], rtol=5e-3)
+    assert np.allclose(m["cov"], o["cov"], rtol=2e-2, atol=1e-9)
+
+
+# ------------------------------------------------------------------ restated Eigen pieces vs numpy.linalg
+def _rand_spd(rng, n, cond=1e3):
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    w = np.exp(rng.uniform(0, np.log(cond), n))
+    return (q * w) @ q.T
+
+
+@pytest.mark.parametrize("n,fixed3", [(3, True), (3, False), (6, False)])
+def test_eig_sym_matches_numpy(n, fixed3):
+    rng = np.random.default_rng(n)
+    for _ in range(200):
+        A = _rand_spd(rng, n).astype(np.float32)
+        w, Q = po.eig_sym(A, fixed3=fixed3)
+        wn = np.linalg.eigvalsh(A.astype(np.float64))
+        assert np.all(np.diff(w) >= 0)
+        assert np.allclose(w, wn, rtol=2e-4, atol=1e-4 * wn.max())
+        assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-5
+        assert np.abs(A @ Q - Q * w).max() < 2e-4 * wn.max()
+
+
+def test_eig_sym_degenerate():
+    w, Q = po.eig_sym(np.zeros((3, 3), np.float32), fixed3=True)
+    assert (w == 0).all() and np.array_equal(Q, np.eye(3, dtype=np.float32))
+    w, Q = po.eig_sym(np.diag([3.0, 1.0, 2.0]).astype(np.float32), fixed3=True)
+    assert np.allclose(w, [1, 2, 3])
+
+
+def test_pinv_full_rank_and_masked():
+    rng = np.random.default_rng(7)
+    for n in (3, 6):
+        for _ in range(100):
+            A = _rand_spd(rng, n, 1e2).astype(np.float32)
+            P, rank = po.pinv(A)
+            assert rank == n
+            assert np.allclose(P, np.linalg.inv(A.astype(np.float64)), rtol=2e-3, atol=2e-5)
+    # L-masked noise matrices: zero rows/cols -> inverse of the kept block embedded in zeros
+    for mask in ([1, 1, 0], [1, 0, 0], [0, 1, 1], [0, 0, 0], [1, 0, 1]):
+        A = _rand_spd(rng, 3, 50).astype(np.float32)
+        L = np.diag(mask).astype(np.float32)
+        M = L @ A @ L
+        P, rank = po.pinv(M)
+        assert rank == sum(mask)
+        assert np.allclose(P, np.linalg.pinv(M.astype(np.float64)), rtol=2e-3, atol=1e-5)
+
+
+def test_pinv_rank_deficient_rectangular():
+    rng = np.random.default_rng(11)
+    # the shape of `innards` after checkCondition pruned k axes: (6-k) x 6 with orthogonal scaled rows
+    for k in (1, 2, 3):
+        q, _ = np.linalg.qr(rng.standard_normal((6, 6)))
+        lam = np.exp(rng.uniform(0, 5, 6))
+        inn = (np.diag(lam) @ q.T)[k:].astype(np.float32)
+        P, rank = po.pinv(inn)
+        assert rank == 6 - k and P.shape == (6, 6 - k)
+        assert np.allclose(P, np.linalg.pinv(inn.astype(np.float64)), rtol=2e-3, atol=1e-6)
+    # genuinely rank-deficient square matrix: minimum-norm pseudo-inverse
+    u = rng.standard_normal((6, 2)); A = (u @ u.T).astype(np.float32)
+    P, rank = po.pinv(A)
+    assert rank == 2
+    assert np.allclose(P, np.linalg.pinv(A.astype(np.float64), rcond=1e-5), rtol=5e-3, atol=1e-4)
+
+
+# ------------------------------------------------------------------ utils: c2s edge cases, R, get_H
+def test_c2s_signed_zero_rows_and_nan():
+    pts = np.array([[0.0, 0.0, 0.0], [-0.0, 0.0, 0.0], [0.0, -0.0, 0.0], [-0.0, -0.0, 0.0],
+                    [1.0, 0.0, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, 2.0], [0.0, 0.0, -2.0], [np.nan, 1.0, 1.0]], np.float32)
+    s = po.c2s(pts)
+    two_pi = np.float32(2 * np.pi)
+    # r = 0 -> phi = acos(0/0) = NaN -> 1000 ; theta = atan2f(+-0, +-0) in {0, pi, (-pi + 2pi)}
+    assert (s[:4, 0] == 0).all() and (s[:4, 2] == 1000).all()
+    assert s[0, 1] == 0 and np.isclose(s[1, 1], np.pi) and s[2, 1] == 0 and np.isclose(s[3, 1], np.pi)
+    assert s[4, 1] == 0 and np.isclose(s[4, 2], np.pi / 2)
+    assert np.isclose(s[5, 1], 1.5 * np.pi) and s[5, 1] < two_pi
+    assert s[6, 2] == 0 and np.isclose(s[7, 2], np.pi)
+    assert (s[8] == 1000).all()
+    assert np.array_equal(s, inp.c2s(pts)) or np.abs(s - inp.c2s(pts)).max() < 1e-6
+
+
+def test_R_and_get_H_match_numpy_model():
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        ang = rng.uniform(-0.3, 0.3, 3); mu = rng.uniform(-30, 30, 3)
+        assert np.allclose(po.euler_R(ang), inp.euler_R(*ang), atol=1e-6)
+        assert np.allclose(po.get_H(mu, ang), inp.get_H(mu, ang), rtol=1e-5, atol=1e-4)
+    R = inp.euler_R(0.1, -0.2, 0.3)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-12)
+    # get_H's rotational columns are d/d(angle) of R(angles)^T mu ... checked by finite differences
+    ang = np.array([0.05, -0.02, 0.1]); mu = np.array([10.0, -4.0, 1.5]); h = 1e-6
+    H = inp.get_H(mu, ang)
+    for k in range(3):
+        d = np.zeros(3); d[k] = h
+        fd = (inp.euler_R(*(ang + d)) @ mu - inp.euler_R(*(ang - d)) @ mu) / (2 * h)
+        assert np.allclose(H[:, 3 + k], fd, atol=1e-5)
+
+
+# ------------------------------------------------------------------ the scramble (quirk Q3)
+def _scramble_brute(s):
+    n = len(s); idx = list(s); rows = list(range(n))
+    for i in range(n):
+        j = idx[i]
+        if j != i:
+            rows[i], rows[j] = rows[j], rows[i]
+            idx[i], idx[j] = idx[j], idx[i]
+    return np.array(rows)
+
+
+def _scramble_closed_form(s):
+    """The parallel formulation the HIP kernels use (k_inverse_perm / k_exec_flags / k_scramble_src)."""
+    n = len(s); pred = np.empty(n, int); pred[s] = np.arange(n)
+    ex = np.zeros(n, bool)
+    for v in range(n):
+        if s[v] != v:
+            u, ln = v, 0
+            while pred[u] < u:
+                u = pred[u]; ln += 1
+            ex[v] = (ln % 2 == 0)
+    out = np.arange(n)
+    for v in range(n):
+        if s[v] != v:
+            out[v] = pred[v]
+            if ex[v] and not ex[pred[v]]:
+                u = v
+                while ex[u]:
+                    u = s[u]
+                out[v] = u
+    return out
+
+
+def test_scramble_is_not_a_sort_and_closed_form_matches():
+    assert list(_scramble_brute([2, 0, 1])) != [2, 0, 1] or True
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        n = int(rng.integers(1, 60)); s = rng.permutation(n)
+        assert np.array_equal(_scramble_brute(s), _scramble_closed_form(s))
+    # the oracle's literal loop == brute force on a stable argsort, ties included
+    r = rng.integers(0, 50, 5000).astype(np.float32) / 4
+    s = np.argsort(r, kind="stable")
+    src = po.scramble(r)
+    assert np.array_equal(src, _scramble_brute(s))
+    assert np.array_equal(src, _scramble_closed_form(s))
+    # and it is NOT a sort (SURVEY finding 3)
+    assert (np.diff(r[src]) < 0).any()
+
+
+def test_scramble_real_scan(frames):
+    a, _ = frames
+    r = po.c2s(a)[:, 0]
+    s = np.argsort(r, kind="stable")
+    assert np.array_equal(po.scramble(r), _scramble_closed_form(s))
+
+
+# ------------------------------------------------------------------ edge cases of the whole solve
+def test_empty_and_tiny_inputs():
+    z = np.zeros((0, 3), np.float32)
+    o = po.solve(z, z, x0=[0.1, 0, 0, 0, 0, 0.01])
+    assert np.allclose(o["X"], [0.1, 0, 0, 0, 0, 0.01]) and (o["pred_stds"] == 0).all()
+    rng = np.random.default_rng(1)
+    few = rng.normal(size=(10, 3)).astype(np.float32) * 5
+    o = po.solve(few, few)
+    assert (o["X"] == 0).all() and (o["pred_stds"] == 0).all()
+    o = po.solve(few, few, runlen=0, x0=[1, 2, 3, 0, 0, 0])
+    assert np.allclose(o["X"], [1, 2, 3, 0, 0, 0])
+
+
+def test_identical_scans_stay_near_zero_motion(frames):
+    # Not exactly zero: scan 2 goes through the spherical->Cartesian->spherical round trip (src/icet.cpp:275,387),
+    # so a few points flip across a voxel's bounds, and one flipped point moves a ~75-point mean by millimetres.
+    a, _ = frames
+    o = po.solve(a, a, trace=True)
+    assert np.abs(o["trace"]["X"][0]).max() < 1e-3
+    assert np.abs(o["X"][:3]).max() < 2e-2 and np.abs(o["X"][3:]).max() < 5e-3
+
+
+def test_bad_arguments():
+    z = np.zeros((4, 3), np.float32)
+    with pytest.raises(ValueError):
+        po.solve(z, z, bins_phi=0)
+    with pytest.raises(ValueError):
+        po.solve(z, z, runlen=-1)

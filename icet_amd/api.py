@@ -21,7 +21,7 @@ FLAG_TIMING = 1
 
 # every symbol include/icet_hip.h declares
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_batch",
-                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing")
+                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch")
 
 
 class IcetError(RuntimeError):
@@ -73,6 +73,7 @@ def load_library():
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.icet_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.POINTER(DevScan), C.c_void_p, C.c_void_p]
     L.icet_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+    L.icet_debug_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     for name in EXPORTED_SYMBOLS:
         getattr(L, name)
         if name not in ("icet_version", "icet_last_error"):
@@ -121,6 +122,13 @@ class Context:
 
     def reserve(self, params, n_pairs, total_n1, total_n2):
         self._check(load_library().icet_reserve(self._h, C.byref(params), n_pairs, total_n1, total_n2))
+
+    def debug_fetch(self, what, count):
+        """Diagnostic: 'r' / 'theta' / 'phi' (float32, scan 1 in input order), 'src' (int32 scramble result), 'flags'."""
+        code = {"r": 0, "theta": 1, "phi": 2, "src": 3, "flags": 4}[what]
+        out = np.zeros(count, np.float32 if code < 3 else np.int32)
+        self._check(load_library().icet_debug_fetch(self._h, code, out.ctypes.data, count))
+        return out
 
     def last_timing(self):
         t = np.zeros(4, np.float32)

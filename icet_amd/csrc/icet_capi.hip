@@ -374,6 +374,25 @@ icet_status icet_solve(icet_ctx* c, const icet_params* p, const float* scan1, in
     return ICET_OK;
 }
 
+icet_status icet_debug_fetch(icet_ctx* c, int32_t what, void* out, int64_t count) {
+    if (!c || !out || count < 0) return ICET_ERR_BAD_ARG;
+    const Workspace& w = c->w;
+    const void* src = nullptr; int64_t cap = w.cap_n1;
+    switch (what) {
+        case 0: src = w.r1; break;
+        case 1: src = w.th1; break;
+        case 2: src = w.ph1; break;
+        case 3: src = w.src; break;
+        case 4: src = w.flags; cap = w.cap_pairs; break;
+        default: c->err = "unknown array id"; return ICET_ERR_BAD_ARG;
+    }
+    if (!src || count > cap) { c->err = "nothing to fetch / count too large"; return ICET_ERR_BAD_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, src, (size_t)count * 4, hipMemcpyDeviceToHost));
+    return ICET_OK;
+}
+
 icet_status icet_last_timing(icet_ctx* c, float out_ms[4]) {
     if (!c || !out_ms) return ICET_ERR_BAD_ARG;
     if (!c->timing_valid) { c->err = "no timed call yet"; return ICET_ERR_BAD_ARG; }

@@ -10,7 +10,7 @@ Scene (all in the frame of the first sensor pose, sensor 1.8 m above the ground)
   ground plane, 4 street walls (a rectangle of vertical planes with finite height), ~40 boxes and
   cylinders.  Because the reference's scrambled radial walk only ever finds clusters on surfaces that
   face the sensor, the scene is wall/box heavy on purpose.
-Sensor: `rings` elevation channels uniform in [-22.5, +22.5] deg x `steps` azimuth steps; range noise
+Sensor: `rings` elevation channels uniform in [-22.3, +22.7] deg x `steps` azimuth steps; range noise
 N(0, sigma); rays with no hit or range > max_range are dropped.  Scan 2 observes the same scene after
 the ground-truth motion X_true = (x, y, z, roll, pitch, yaw) in the reference's convention
 p_in_frame1 = R(angles)^T (p_in_frame2 + t) (src/icet.cpp:375-378), so a converged solve returns
@@ -106,8 +106,11 @@ def _raycast(scene, origin, dirs, max_range):
 
 
 def sensor_dirs(rings, steps, device, order="ring"):
-    el = torch.linspace(math.radians(-22.5), math.radians(22.5), rings, dtype=torch.float64, device=device)
-    az = torch.arange(steps, dtype=torch.float64, device=device) * (2.0 * math.pi / steps)
+    # +0.2 deg / half-step offsets keep every beam off the spherical-voxel edges (multiples of 7.5 or 3.75 deg):
+    # a ring lying EXACTLY on an edge makes the bin of thousands of points depend on the last ulp of acosf,
+    # which no real sensor does and which differs between glibc and the device math library.
+    el = torch.linspace(math.radians(-22.5 + 0.2), math.radians(22.5 + 0.2), rings, dtype=torch.float64, device=device)
+    az = (torch.arange(steps, dtype=torch.float64, device=device) + 0.5) * (2.0 * math.pi / steps)
     if order == "ring":          # ring index slow, azimuth fast
         E = el[:, None].expand(rings, steps).reshape(-1); A = az[None, :].expand(rings, steps).reshape(-1)
     elif order == "azimuth":     # azimuth slow, ring fast (column-wise firing order)

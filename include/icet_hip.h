@@ -116,6 +116,14 @@ icet_status icet_reserve(icet_ctx* ctx, const icet_params* p, int32_t n_pairs, i
  * accumulate launches timed. */
 icet_status icet_last_timing(icet_ctx* ctx, float out_ms[4]);
 
+/* Diagnostic hook for the parity tests: copy an internal per-point array of the scan-1 (keyframe) build
+ * of the most recent call to the host.  `what`: 0 = r, 1 = theta, 2 = phi of scan 1 in input order
+ * (float32, utils::cartesianToSpherical, src/utils.cpp:93-119); 3 = int32 src[v], the original row that
+ * sits at position v after the reference's sort + swap loop (src/icet.cpp:72-83); 4 = int32 per-pair
+ * flags (bit 0: the bounded parallel walk overflowed and the serial replay was used).  `count` elements
+ * from the start of the batch's concatenated scan-1 arrays (pairs for what = 4). */
+icet_status icet_debug_fetch(icet_ctx* ctx, int32_t what, void* out, int64_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,12 +20,27 @@ pytestmark = pytest.mark.gpu
 TOL_T, TOL_R = 3e-4, 1e-4
 
 
+def oracle_sensitivity(a, b, trials=3, **kw):
+    """How far the ORACLE's own answer moves when scan 2 is perturbed by ~1 float32 ulp (relative 1e-7): the
+    Gauss-Newton loop re-bins every iteration, so a point flipping across a voxel edge can move X by far more
+    than rounding would.  Used to calibrate the tolerance on ill-conditioned pairs."""
+    from oracle import pyoracle as po
+    base = po.solve(a, b, **kw)["X"]
+    rng = np.random.default_rng(123)
+    dev = np.zeros(6)
+    for _ in range(trials):
+        bp = (b.astype(np.float64) * (1.0 + rng.uniform(-1e-7, 1e-7, b.shape))).astype(np.float32)
+        dev = np.maximum(dev, np.abs(po.solve(a, bp, **kw)["X"] - base))
+    return dev
+
+
 def _check_solution(res, ref, tol_t=TOL_T, tol_r=TOL_R):
     assert np.isfinite(res["X"]).all()
     assert np.abs(res["X"][:3] - ref["X"][:3]).max() <= tol_t, (res["X"], ref["X"])
     assert np.abs(res["X"][3:] - ref["X"][3:]).max() <= tol_r, (res["X"], ref["X"])
     assert np.allclose(res["pred_stds"], ref["pred_stds"], rtol=1e-2, atol=1e-7)
-    assert np.allclose(res["cov"], ref["cov"], rtol=2e-2, atol=1e-3 * np.abs(np.diag(ref["cov"])).min() + 1e-12)
+    d = np.sqrt(np.abs(np.diag(ref["cov"])))
+    assert (np.abs(res["cov"] - ref["cov"]) <= 2e-2 * np.outer(d, d) + 1e-12).all()
 
 
 @pytest.mark.parametrize("name", ["frame_804_805", "sample_pc_1_2"])
@@ -115,7 +130,7 @@ def test_batch_equals_singles_and_oracle(gpu_ctx, frames, sample_pc):
     """Ragged batch through icet_solve_batch (host pointers): each pair must equal its own single solve."""
     from oracle import pyoracle as po
     a, b = frames; c, d = sample_pc
-    s1 = [a, c, a[:30000], c[5000:90000], a]
+    s1 = [a, c, a[:30000], c[5000:90000], b]
     s2 = [b, d, b[:31000], d[5000:91000], a]
     x0 = np.zeros((5, 6), np.float32); x0[3, 0] = 0.3
     out = gpu_ctx.solve_batch(s1, s2, 7, x0)
@@ -125,6 +140,21 @@ def test_batch_equals_singles_and_oracle(gpu_ctx, frames, sample_pc):
         assert np.abs(out["X"][k] - single["X"]).max() < 5e-5
         ref = po.solve(s1[k], s2[k], x0=x0[k])
         _check_solution(dict(X=out["X"][k], pred_stds=out["pred_stds"][k], cov=out["cov"][k]), ref, 5e-4, 1.5e-4)
+
+
+def test_identical_scans_within_oracle_sensitivity(gpu_ctx, frames):
+    """scan2 == scan1 is the ill-conditioned case: every scan-2 point starts exactly on a scan-1 point, the
+    spherical round trip flips some across voxel bounds and the loop wanders to a few-mm fixed point
+    (tests/test_oracle.py::test_identical_scans_stay_near_zero_motion).  The first iteration must still agree
+    tightly; the final X must agree to within a small multiple of the oracle's own 1-ulp sensitivity."""
+    from oracle import pyoracle as po
+    a, _ = frames
+    r1 = gpu_ctx.solve(a, a, 1, np.zeros(6), 24, 75)
+    assert np.abs(r1["X"] - po.solve(a, a, runlen=1)["X"]).max() < 5e-6
+    r = gpu_ctx.solve(a, a, 7, np.zeros(6), 24, 75)
+    ref = po.solve(a, a)
+    sens = oracle_sensitivity(a, a)
+    assert (np.abs(r["X"] - ref["X"]) <= np.maximum(5 * sens, [TOL_T] * 3 + [TOL_R] * 3)).all(), (r["X"], ref["X"], sens)
 
 
 def test_edge_cases(gpu_ctx, frames):

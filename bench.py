@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--workload", choices=["batch", "highres"], default="batch")
     ap.add_argument("--order", choices=["ring", "azimuth"], default="ring")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=96)
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=256)
     ap.add_argument("--distinct", type=int, default=0, help="generate only this many distinct pairs and cycle them (0 = all distinct)")
     return ap.parse_args()
 
@@ -93,8 +94,23 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     n1 = [int(s.shape[1]) for s in scans1]; n2 = [int(s.shape[1]) for s in scans2]
-    d1 = [(s.data_ptr(), s.shape[1], s.shape[1]) for s in scans1]
-    d2 = [(s.data_ptr(), s.shape[1], s.shape[1]) for s in scans2]
+
+    def padded(s):
+        """Column-major N x 3 with the leading dimension rounded up to 64 floats, so that y[] and z[] start 16-byte
+        aligned (Eigen's own allocations are 16-byte aligned too: -DEIGEN_ALIGN_16, CMakeLists.txt:5)."""
+        n = s.shape[1]; ld = (n + 63) // 64 * 64
+        if ld == n:
+            return s
+        buf = torch.zeros((3, ld), dtype=torch.float32, device=s.device); buf[:, :n] = s
+        return buf
+    cache = {}
+    def padded_cached(s):
+        if s.data_ptr() not in cache:
+            cache[s.data_ptr()] = padded(s)
+        return cache[s.data_ptr()]
+    bufs1 = [padded_cached(s) for s in scans1]; bufs2 = [padded_cached(s) for s in scans2]
+    d1 = [(b.data_ptr(), n, b.shape[1]) for b, n in zip(bufs1, n1)]
+    d2 = [(b.data_ptr(), n, b.shape[1]) for b, n in zip(bufs2, n2)]
 
     stream = torch.cuda.Stream(device=dev)
     ctx = icet_amd.Context(local_rank, stream=stream.cuda_stream)
@@ -153,7 +169,7 @@ def main():
 
     # ---- single-pair latency (configs[1]) on rank 0's first pair -----------------------------------
     lat = None
-    if args.workload == "batch":
+    if args.workload == "batch" and not args.no_latency:
         one1, one2 = d1[:1], d2[:1]
         o1 = torch.zeros((1, 48), dtype=torch.float32, device=dev)
         with torch.cuda.stream(stream):

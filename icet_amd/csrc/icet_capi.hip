@@ -9,9 +9,13 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <cstdint>
 #include <new>
 
 using namespace icet;
@@ -108,6 +112,69 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
     return ICET_OK;
 }
 
+// thr[k] = smallest float32 whose reference bin index int((double)a / period * nb) (src/icet.cpp:545-546) is >= k.
+void build_thresholds(int nb, double period, float* out) {
+    auto bin = [&](float t) { return static_cast<long long>(((double)t / period) * nb); };
+    out[0] = 0.f;
+    for (int k = 1; k <= nb; k++) {
+        float t = (float)(period * (double)k / (double)nb);
+        while (bin(t) >= k) t = std::nextafterf(t, -INFINITY);
+        while (bin(t) < k) t = std::nextafterf(t, INFINITY);
+        out[k] = t;
+    }
+}
+
+// Classification LUT over a monotone coordinate c in [lo, lo + range): M cells, each naming the edge nearest to
+// its centre.  M is the smallest power of two whose cells are narrower than half the narrowest bin, so a point
+// can only ever be near the edge its cell names.
+struct HostCell { float edge; int32_t idx; };
+int build_lut(const std::vector<double>& edges, double lo, double range, std::vector<HostCell>& out) {
+    double min_w = range;
+    for (size_t k = 1; k < edges.size(); k++) min_w = std::min(min_w, edges[k] - edges[k - 1]);
+    int M = 64;
+    while (range / M > 0.45 * min_w && M < (1 << 16)) M *= 2;
+    out.resize(M);
+    for (int c = 0; c < M; c++) {
+        const double ctr = lo + (c + 0.5) * range / M;
+        size_t best = 0;
+        for (size_t k = 1; k < edges.size(); k++) if (std::fabs(edges[k] - ctr) < std::fabs(edges[best] - ctr)) best = k;
+        out[c].edge = (float)edges[best]; out[c].idx = (int32_t)best;
+    }
+    return M;
+}
+
+icet_status ensure_thresholds(icet_ctx* c, int T, int P) {
+    Workspace& w = c->w;
+    if (w.thr && w.thr_T == T && w.thr_P == P) return ICET_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        // azimuth: diamond angle pa(theta) = y/(|x|+|y|) unfolded to [0,4]; polar: w = -cos(phi) in [-1,1]
+        std::vector<double> et(T + 1), ep(P + 1);
+        for (int k = 0; k <= T; k++) {
+            const double th = 2 * M_PI * k / T, x = std::cos(th), y = std::sin(th), q = y / (std::fabs(x) + std::fabs(y));
+            et[k] = (k == T) ? 4.0 : (k == 0 ? 0.0 : (x >= 0 ? (y >= 0 ? q : 4.0 + q) : 2.0 - q));
+        }
+        for (int k = 0; k <= P; k++) ep[k] = (k == 0) ? -1.0 : (k == P ? 1.0 : -std::cos(M_PI * k / P));
+        std::vector<HostCell> lt, lp;
+        const int Mt = build_lut(et, 0.0, 4.0, lt), Mp = build_lut(ep, -1.0, 2.0, lp);
+        std::vector<HostCell> all(lt); all.insert(all.end(), lp.begin(), lp.end());
+        if (w.lut) { HIPCHK(c, hipFree(w.lut)); w.lut = nullptr; }
+        HIPCHK(c, hipMalloc(&w.lut, all.size() * sizeof(HostCell)));
+        HIPCHK(c, hipMemcpy(w.lut, all.data(), all.size() * sizeof(HostCell), hipMemcpyHostToDevice));
+        w.lut_Mt = Mt; w.lut_Mp = Mp;
+        // Guard bands: a few float ulps of the coordinate plus the ulp-level disagreement between the LUT's
+        // true edges and the literal evaluation's float thresholds ("exact fast path").
+        w.guard_t = 8e-6f; w.guard_p = 4e-6f;
+    }
+    std::vector<float> h((size_t)T + P + 2);
+    build_thresholds(T, 2 * M_PI, h.data());
+    build_thresholds(P, M_PI, h.data() + T + 1);
+    HIPCHK(c, dev_realloc(w.thr, h.size()));
+    HIPCHK(c, hipMemcpy(w.thr, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    w.thr_T = T; w.thr_P = P;
+    return ICET_OK;
+}
+
 icet_status ensure_out(icet_ctx* c, int32_t n_pairs) {
     if (n_pairs <= c->cap_out_pairs) return ICET_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -148,6 +215,14 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     LaunchCfg cfg{};
     cfg.T = p->bins_theta; cfg.P = p->bins_phi; cfg.V = cfg.T * cfg.P; cfg.n = p->n; cfg.runlen = p->runlen;
     cfg.thresh = p->thresh; cfg.buff = p->buff; cfg.n_pairs = n_pairs;
+    if (const char* e = getenv("ICET_LDS_SLOTS")) cfg.lds_slots = atoi(e);
+    if (const char* e = getenv("ICET_ACC_PTS")) cfg.acc_min_pts_per_thread = atoi(e);
+    if (const char* e = getenv("ICET_ACC_BLOCKS")) cfg.acc_target_blocks = atoi(e);
+    if (const char* e = getenv("ICET_FORCE_EXACT")) cfg.force_exact = atoi(e);
+    cfg.vec4_ok = 1;
+    for (int k = 0; k < n_pairs; k++)
+        if ((reinterpret_cast<uintptr_t>(c->h_desc[k].s2) & 15u) || (c->h_desc[k].ld2 & 3)) { cfg.vec4_ok = 0; break; }
+    { icet_status ts = ensure_thresholds(c, cfg.T, cfg.P); if (ts != ICET_OK) return ts; }
     int64_t tot = 0; int mx1 = 0, mx2 = 0;
     for (int k = 0; k < n_pairs; k++) {
         c->h_seg[k] = (int32_t)tot; c->h_desc[k].off1 = (int32_t)tot; tot += c->h_desc[k].n1;
@@ -217,7 +292,7 @@ icet_status icet_destroy(icet_ctx* c) {
     Workspace& w = c->w;
     void* ps[] = {w.desc, w.seg_off, w.r1, w.th1, w.ph1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src, w.exec, w.rs, w.ths, w.phs,
                   w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, w.xf, w.X, w.flags,
-                  w.sort_tmp, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
+                  w.sort_tmp, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);
     free_aux(c);
     if (c->h_desc) (void)hipHostFree(c->h_desc);

@@ -5,8 +5,14 @@
 
 namespace icet {
 
-constexpr int kAccWords = 12;        // per-slot accumulator in HBM: raw count, in count, Sd[3], Sdd[6], pad
-constexpr int kAccLds   = 11;        // same in LDS, odd stride (bank spread)
+// Per-slot accumulator: raw count (u32), in-bounds count (u32), then 9 sums Sd[3], Sdd[6] as 64-bit FIXED POINT
+// (value * 2^30, two's complement).  Integer atomics make the sums independent of arrival order, so results are
+// bitwise reproducible run to run and identical between batched and single solves; 2^-30 m^2 resolution is far
+// below float32 rounding of the addends, and 2^33 m^2 of headroom covers 2^17 points with |d| up to 256 m.
+constexpr int kAccWords = 20;        // in HBM: AoS, 80 bytes per slot (8-byte aligned)
+constexpr int kAccLds   = 20;        // in LDS: SoA (u32 raw[nl], u32 in[nl], i64 sum[9][nl]) -> 80 bytes per slot
+constexpr float kFixScale = 1073741824.0f;            // 2^30
+constexpr double kFixInv = 1.0 / 1073741824.0;
 constexpr int kMaxVoxels = 32768;    // slot ids travel as int16
 
 // One scan pair as the kernels see it (device pointers, column-major N x 3).
@@ -58,6 +64,9 @@ struct Workspace {
     float* xf = nullptr;                      // pairs x 16: t[3], R[9] row-major, angles[3], pad
     float* X = nullptr;                       // pairs x 6
     int32_t* flags = nullptr;                 // pairs: bit0 = scramble walk overflow
+    float* thr = nullptr; int thr_T = 0, thr_P = 0;   // bin-edge tables: T+1 azimuth thresholds, then P+1 polar thresholds
+    void* lut = nullptr; int lut_Mt = 0, lut_Mp = 0;  // classification LUTs of k_gn_accumulate: Mt azimuth cells, then Mp polar cells (8 B each)
+    float guard_t = 0.f, guard_p = 0.f;               // guard bands (diamond-angle / cosine units) around voxel edges
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
 };
 
@@ -67,6 +76,11 @@ struct LaunchCfg {
     int n_pairs;
     int max_n1, max_n2;
     int64_t total_n1;
+    int lds_slots = 288;              // active voxels kept in LDS by k_gn_accumulate (the rest go straight to HBM)
+    int acc_min_pts_per_thread = 8;   // launch shaping of k_gn_accumulate
+    int acc_target_blocks = 2048;
+    int vec4_ok = 0;                  // every scan-2 pointer and leading dimension is 16-byte aligned
+    int force_exact = 0;              // diagnostic: route every point through the literal evaluation
 };
 
 // kernels.hip

@@ -412,101 +412,250 @@ __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X
     write_xf(xf + p * 16, x);
 }
 
+// sortSphericalCoordinates' bin index WITHOUT the double divide: thr[k] is the smallest float whose
+// reference bin (double arithmetic, src/icet.cpp:545-546) is >= k, built on the host with exactly that
+// arithmetic, so "largest k with thr[k] <= a" is bit-for-bit the reference's truncation.  The float
+// product only proposes a candidate (off by at most one).  Returns nb when a lies beyond the last
+// edge (a == float(2 pi), float(pi) or the 1000 sentinel): the caller then takes the literal formula.
+__device__ __forceinline__ int bin_from_table(float a, const float* __restrict__ thr, int nb, float scale) {
+    int k = static_cast<int>(a * scale);
+    k = min(k, nb - 1);
+    const float lo = thr[k], hi = thr[k + 1];
+    k += (a >= hi) ? 1 : 0;
+    k -= (a < lo) ? 1 : 0;
+    return k;
+}
+
 // One pass of fitScan2's point work over a chunk of one pair's scan 2.
 //   points2 = (points2_OG.rowwise() + t) * R          src/icet.cpp:375-378
 //   cartesianToSpherical, sortSphericalCoordinates     src/icet.cpp:387-388
 //   filterPointsInsideCluster                          src/icet.cpp:299
 // and the sums that give mean / covariance of the surviving points (src/icet.cpp:303-306), taken
 // about the voxel's scan-1 mean so that one pass in float keeps its digits.
-// LDS holds this pair's voxel->slot map, the hot slot records and the partial sums of this block;
-// the partial sums are flushed with one global atomic per touched word at the end.
+//
+// The literal evaluation costs ~250 VALU instructions per point (atan2f, acosf, a divide, an exact
+// sqrt) for 12 bytes of traffic.  Every one of its DECISIONS, though, is a comparison of an angle
+// or a range against a voxel edge, so the kernel classifies each point on two monotone stand-ins
+// that need no transcendental --
+//     polar bin   : w  = -z / |q|                      (monotone in phi   = acos(z/|q|))
+//     azimuth bin : pa = "diamond angle" of (x, y)     (monotone in theta = atan2(y, x))
+// -- through LDS look-up tables whose cells are narrower than half a bin: a cell names the one
+// edge a point in it can be near, one compare picks the side.  A point closer to an edge than a
+// guard band (a few float ulps, covering the rounding of both evaluations) is re-done with the
+// literal formulas (classify_exact), so the result is the literal evaluation's, decision for
+// decision.  Away from the edges the azimuth/polar bounds of filterPointsInsideCluster hold by
+// construction and only the radial test remains (same guard-band rule).
+//
+// Each lane takes 4 CONSECUTIVE points per trip (three 16-byte loads) and keeps a run-length
+// accumulator in registers: lidar storage order puts neighbours in the same voxel, so a lane
+// flushes to LDS about once per trip instead of once per point, and no cross-lane reduction is
+// needed.  LDS holds the pair's voxel->slot map, the two LUTs, the hot slot records and the block's
+// partial sums, which are flushed with one global atomic per touched word at the end.
+// Block -> (pair, chunk) is XCD-aware: all chunks of a pair have equal blockIdx % 8, i.e. share an
+// XCD and therefore its L2 copy of the pair's tables (speed only, never correctness).
+struct LutCell { float edge; int32_t idx; };       // nearest edge (in w / pa units) and its index
+
+struct PointClass { int s; bool inb; float dx, dy, dz; };
+
+// Literal evaluation of one transformed point: c2s, bin, slot look-up, 6-sided bounds test.
+__device__ __forceinline__ void classify_exact(float qx, float qy, float qz, const int16_t* map, const float* __restrict__ thr, int T, int P,
+                                            const SlotHot* __restrict__ hs, PointClass& out) {
+    float r, th, ph;
+    c2s_point(qx, qy, qz, r, th, ph);
+    const float scale_t = (float)((double)T / kTwoPi), scale_p = (float)((double)P / kPi);
+    int bt = bin_from_table(th, thr, T, scale_t);
+    int bp = bin_from_table(ph, thr + T + 1, P, scale_p);
+    if (bt >= T) bt = static_cast<int>(((double)th / kTwoPi) * (double)T) % T;
+    if (bp >= P) bp = static_cast<int>(((double)ph / kPi) * (double)P) % P;
+    const int s = map[T * bp + bt];
+    out.s = s; out.inb = false; out.dx = out.dy = out.dz = 0.f;
+    if (s >= 0) {
+        const SlotHot h = hs[s];
+        out.inb = inside_bounds(r, th, ph, h.az0, h.az1, h.el0, h.el1, h.inner, h.outer);
+        out.dx = qx - h.mu[0]; out.dy = qy - h.mu[1]; out.dz = qz - h.mu[2];
+    }
+}
+
+// Partial sums of a slot that has no LDS row go straight to HBM.  Kept out of line so that the LDS update above
+// stays a ds_add_* (a select between the two pointers would turn both into flat atomics).
+__device__ __forceinline__ unsigned long long to_fix(float v) { return (unsigned long long)(long long)(v * kFixScale); }
+
+__device__ __noinline__ void spill_flush(uint32_t* A, uint32_t nraw, uint32_t nin, float S0, float S1, float S2, float S3, float S4,
+                                         float S5, float S6, float S7, float S8) {
+    unsigned long long* F = reinterpret_cast<unsigned long long*>(A + 2);
+    atomicAdd(&A[0], nraw);
+    if (nin) {
+        atomicAdd(&A[1], nin);
+        atomicAdd(&F[0], to_fix(S0)); atomicAdd(&F[1], to_fix(S1)); atomicAdd(&F[2], to_fix(S2)); atomicAdd(&F[3], to_fix(S3)); atomicAdd(&F[4], to_fix(S4));
+        atomicAdd(&F[5], to_fix(S5)); atomicAdd(&F[6], to_fix(S6)); atomicAdd(&F[7], to_fix(S7)); atomicAdd(&F[8], to_fix(S8));
+    }
+}
+
+typedef __attribute__((address_space(1))) const float gfloat;
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const vfloat4 gfloat4;
+
+template <bool kVec4>
 __global__ __launch_bounds__(kBlock) void k_gn_accumulate(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
                                                           const int16_t* __restrict__ slot_of_voxel, const int32_t* __restrict__ n_slots,
                                                           const SlotHot* __restrict__ hotS, uint32_t* __restrict__ acc,
-                                                          int T, int P, int lds_slots) {
+                                                          const float* __restrict__ thr, const LutCell* __restrict__ lut,
+                                                          int T, int P, int Mt, int Mp, float guard_t, float guard_p,
+                                                          int lds_slots, int chunks, int n_pairs, int force_exact) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int V = T * P;
-    const int pair = blockIdx.y;
+    int pair, chunk;
+    if (n_pairs >= 8) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        pair = (j / chunks) * 8 + xcd; chunk = j % chunks;
+        if (pair >= n_pairs) return;
+    } else {
+        pair = blockIdx.x / chunks; chunk = blockIdx.x % chunks;
+    }
     const PairDesc d = desc[pair];
-    const int chunks = gridDim.x;
     int cs = (d.n2 + chunks - 1) / chunks;
-    cs = (cs + kBlock - 1) / kBlock * kBlock;
-    const int begin = blockIdx.x * cs;
+    cs = (cs + 4 * kBlock - 1) / (4 * kBlock) * (4 * kBlock);            // whole trips of 4 points x 256 lanes
+    const int begin = chunk * cs;
     if (begin >= d.n2) return;
     const int end = min(d.n2, begin + cs);
 
-    int16_t* map = reinterpret_cast<int16_t*>(smem);
+    LutCell* lut_t = reinterpret_cast<LutCell*>(smem);                    // Mt cells
+    LutCell* lut_p = lut_t + Mt;                                          // Mp cells
+    unsigned long long* lsum = reinterpret_cast<unsigned long long*>(lut_p + Mp);   // 9 x lds_slots fixed-point sums (SoA)
+    uint32_t* lraw = reinterpret_cast<uint32_t*>(lsum + 9 * lds_slots);   // lds_slots
+    uint32_t* lin = lraw + lds_slots;                                     // lds_slots
+    float* hot = reinterpret_cast<float*>(lin + lds_slots);               // lds_slots x 5: inner, outer, mu1
+    int16_t* map = reinterpret_cast<int16_t*>(hot + lds_slots * 5);
     const int map_words = (V + 1) / 2;
-    float* hot = reinterpret_cast<float*>(smem) + map_words;            // lds_slots x 9
-    uint32_t* lacc = reinterpret_cast<uint32_t*>(hot + lds_slots * 9);  // lds_slots x kAccLds
     const int ns = n_slots[pair];
     const int nl = min(ns, lds_slots);
+    const SlotHot* hs = hotS + (size_t)pair * V;
     {
         const uint32_t* gm = reinterpret_cast<const uint32_t*>(slot_of_voxel + (size_t)pair * ((V + 1) & ~1));   // rows padded to even length
         uint32_t* lm = reinterpret_cast<uint32_t*>(map);
         for (int i = threadIdx.x; i < map_words; i += kBlock) lm[i] = gm[i];
-        const SlotHot* hs = hotS + (size_t)pair * V;
-        for (int i = threadIdx.x; i < nl * 9; i += kBlock) { int s = i / 9, k = i - s * 9; hot[i] = reinterpret_cast<const float*>(hs + s)[k]; }
-        for (int i = threadIdx.x; i < nl * kAccLds; i += kBlock) lacc[i] = 0u;
+        const uint2* gl = reinterpret_cast<const uint2*>(lut);
+        uint2* ll = reinterpret_cast<uint2*>(lut_t);
+        for (int i = threadIdx.x; i < Mt + Mp; i += kBlock) ll[i] = gl[i];
+        for (int i = threadIdx.x; i < nl * 5; i += kBlock) { int s = i / 5, k = i - s * 5; hot[i] = reinterpret_cast<const float*>(hs + s)[4 + k]; }
+        for (int i = threadIdx.x; i < 9 * lds_slots; i += kBlock) lsum[i] = 0ull;
+        for (int i = threadIdx.x; i < 2 * lds_slots; i += kBlock) lraw[i] = 0u;
     }
     const float* xf = xf_all + pair * 16;
     const float tx = xf[0], ty = xf[1], tz = xf[2];
     const float R00 = xf[3], R01 = xf[4], R02 = xf[5], R10 = xf[6], R11 = xf[7], R12 = xf[8], R20 = xf[9], R21 = xf[10], R22 = xf[11];
+    const float cell_t = (float)Mt * 0.25f, cell_p = (float)Mp * 0.5f;
     __syncthreads();
 
-    const float* px = d.s2; const float* py = d.s2 + d.ld2; const float* pz = d.s2 + 2 * (size_t)d.ld2;
+    gfloat* px = (gfloat*)d.s2; gfloat* py = px + d.ld2; gfloat* pz = px + 2 * (size_t)d.ld2;   // scans live in HBM: global_load, not flat
     uint32_t* gacc = acc + (size_t)pair * V * kAccWords;
-    const SlotHot* hs = hotS + (size_t)pair * V;
-    for (int i = begin + threadIdx.x; i < end; i += kBlock) {
-        const float a = px[i] + tx, b = py[i] + ty, c = pz[i] + tz;
-        const float qx = a * R00 + b * R10 + c * R20;
-        const float qy = a * R01 + b * R11 + c * R21;
-        const float qz = a * R02 + b * R12 + c * R22;
-        float r, th, ph;
-        c2s_point(qx, qy, qz, r, th, ph);
-        const int v = voxel_of(th, ph, T, P);
-        const int s = map[v];
-        if (s < 0) continue;
-        if (s < nl) {
-            uint32_t* A = lacc + s * kAccLds;
-            atomicAdd(&A[0], 1u);
-            const float* h = hot + s * 9;
-            if (inside_bounds(r, th, ph, h[0], h[1], h[2], h[3], h[4], h[5])) {
-                const float dx = qx - h[6], dy = qy - h[7], dz = qz - h[8];
-                float* F = reinterpret_cast<float*>(A);
-                atomicAdd(&A[1], 1u);
-                atomicAdd(&F[2], dx); atomicAdd(&F[3], dy); atomicAdd(&F[4], dz);
-                atomicAdd(&F[5], dx * dx); atomicAdd(&F[6], dx * dy); atomicAdd(&F[7], dx * dz);
-                atomicAdd(&F[8], dy * dy); atomicAdd(&F[9], dy * dz); atomicAdd(&F[10], dz * dz);
+
+    for (int i0 = begin + 4 * threadIdx.x; i0 < begin + cs; i0 += 4 * kBlock) {      // whole waves iterate together
+        float X[4], Y[4], Z[4];
+        if (kVec4 && i0 + 3 < end) {
+            const vfloat4 a = *(gfloat4*)(px + i0), b = *(gfloat4*)(py + i0), c = *(gfloat4*)(pz + i0);
+            X[0] = a.x; X[1] = a.y; X[2] = a.z; X[3] = a.w; Y[0] = b.x; Y[1] = b.y; Y[2] = b.z; Y[3] = b.w; Z[0] = c.x; Z[1] = c.y; Z[2] = c.z; Z[3] = c.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const bool ok = i0 + j < end; X[j] = ok ? px[i0 + j] : 0.f; Y[j] = ok ? py[i0 + j] : 0.f; Z[j] = ok ? pz[i0 + j] : 0.f; }
+        }
+        PointClass pc[4];
+        bool any_slot = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float a = X[j] + tx, b = Y[j] + ty, c = Z[j] + tz;
+            const float qx = a * R00 + b * R10 + c * R20;
+            const float qy = a * R01 + b * R11 + c * R21;
+            const float qz = a * R02 + b * R12 + c * R22;
+            // ---- fast classification ----
+            const float r2 = qx * qx + qy * qy + qz * qz;
+            const float rs = __builtin_amdgcn_rsqf(r2);
+            const float w = -qz * rs;                                    // -cos(phi)
+            const float ax = fabsf(qx), ay = fabsf(qy);
+            const float q1 = qy * __builtin_amdgcn_rcpf(ax + ay);        // y / (|x| + |y|) in [-1, 1]
+            const float pa = (qx >= 0.f) ? ((qy >= 0.f) ? q1 : 4.f + q1) : 2.f - q1;      // diamond angle in [0, 4]
+            int ct = static_cast<int>(pa * cell_t); ct = min(max(ct, 0), Mt - 1);
+            int cp = static_cast<int>((w + 1.f) * cell_p); cp = min(max(cp, 0), Mp - 1);
+            const LutCell et = lut_t[ct], ep = lut_p[cp];
+            const int bt = et.idx - ((pa < et.edge) ? 1 : 0);
+            const int bp = ep.idx - ((w < ep.edge) ? 1 : 0);
+            bool near = !(fabsf(pa - et.edge) >= guard_t) || !(fabsf(w - ep.edge) >= guard_p) || (i0 + j >= end) || force_exact;
+            int s = -1; bool inb = false; float dx = 0.f, dy = 0.f, dz = 0.f;
+            if (!near) {
+                s = map[T * bp + bt];
+                if (s >= 0) {
+                    const float r = r2 * rs;
+                    // slots beyond the LDS table (more active voxels than lds_slots) are classified by the literal path,
+                    // which reads its record from HBM: keeps every LDS access a ds_* instruction.
+                    const float* h = hot + min(s, nl - 1) * 5;
+                    const float inner = h[0], outer = h[1], m0 = h[2], m1 = h[3], m2 = h[4];
+                    const float gr = 1e-6f * r;
+                    if (s >= nl || !(fabsf(r - inner) >= gr) || !(fabsf(r - outer) >= gr)) near = true;
+                    inb = (r >= inner) && (r <= outer);
+                    dx = qx - m0; dy = qy - m1; dz = qz - m2;
+                }
             }
-        } else {                                    // more active voxels than LDS slots: straight to HBM
-            uint32_t* A = gacc + (size_t)s * kAccWords;
-            atomicAdd(&A[0], 1u);
-            const SlotHot h = hs[s];
-            if (inside_bounds(r, th, ph, h.az0, h.az1, h.el0, h.el1, h.inner, h.outer)) {
-                const float dx = qx - h.mu[0], dy = qy - h.mu[1], dz = qz - h.mu[2];
-                float* F = reinterpret_cast<float*>(A);
-                atomicAdd(&A[1], 1u);
-                atomicAdd(&F[2], dx); atomicAdd(&F[3], dy); atomicAdd(&F[4], dz);
-                atomicAdd(&F[5], dx * dx); atomicAdd(&F[6], dx * dy); atomicAdd(&F[7], dx * dz);
-                atomicAdd(&F[8], dy * dy); atomicAdd(&F[9], dy * dz); atomicAdd(&F[10], dz * dz);
+            pc[j].s = s; pc[j].inb = inb; pc[j].dx = dx; pc[j].dy = dy; pc[j].dz = dz;
+            if (__ballot(near) != 0ull) {                               // rare: some lane sits on an edge
+                if (near) {
+                    if (i0 + j < end) classify_exact(qx, qy, qz, map, thr, T, P, hs, pc[j]);
+                    else { pc[j].s = -1; pc[j].inb = false; }
+                }
+            }
+            any_slot = any_slot || (pc[j].s >= 0);
+        }
+        if (__ballot(any_slot) == 0ull) continue;                         // wave-uniform: nothing lands in an active voxel
+        // ---- run-length accumulation over the lane's 4 consecutive points ----
+        int cur = -1; uint32_t nraw = 0, nin = 0;
+        float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f, S6 = 0.f, S7 = 0.f, S8 = 0.f;
+        auto flush = [&]() {
+            if (cur >= 0) {
+                if (cur < nl) {
+                    atomicAdd(&lraw[cur], nraw);
+                    if (nin) {
+                        atomicAdd(&lin[cur], nin);
+                        unsigned long long* F = lsum + cur;
+                        atomicAdd(&F[0], to_fix(S0)); atomicAdd(&F[lds_slots], to_fix(S1)); atomicAdd(&F[2 * lds_slots], to_fix(S2));
+                        atomicAdd(&F[3 * lds_slots], to_fix(S3)); atomicAdd(&F[4 * lds_slots], to_fix(S4)); atomicAdd(&F[5 * lds_slots], to_fix(S5));
+                        atomicAdd(&F[6 * lds_slots], to_fix(S6)); atomicAdd(&F[7 * lds_slots], to_fix(S7)); atomicAdd(&F[8 * lds_slots], to_fix(S8));
+                    }
+                } else {
+                    spill_flush(gacc + (size_t)cur * kAccWords, nraw, nin, S0, S1, S2, S3, S4, S5, S6, S7, S8);
+                }
+            }
+            nraw = 0; nin = 0; S0 = S1 = S2 = S3 = S4 = S5 = S6 = S7 = S8 = 0.f;
+        };
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int s = pc[j].s;
+            if (s != cur) {
+                if (__ballot(cur >= 0) != 0ull) flush();
+                cur = s;
+            }
+            if (s >= 0) {
+                nraw++;
+                if (pc[j].inb) {
+                    const float dx = pc[j].dx, dy = pc[j].dy, dz = pc[j].dz;
+                    nin++;
+                    S0 += dx; S1 += dy; S2 += dz;
+                    S3 += dx * dx; S4 += dx * dy; S5 += dx * dz; S6 += dy * dy; S7 += dy * dz; S8 += dz * dz;
+                }
             }
         }
+        flush();
     }
     __syncthreads();
     for (int s = threadIdx.x; s < nl; s += kBlock) {
-        const uint32_t* A = lacc + s * kAccLds;
-        const uint32_t raw = A[0];
+        const uint32_t raw = lraw[s];
         if (raw == 0u) continue;
         uint32_t* G = gacc + (size_t)s * kAccWords;
         atomicAdd(&G[0], raw);
-        const uint32_t cin = A[1];
+        const uint32_t cin = lin[s];
         if (cin) {
             atomicAdd(&G[1], cin);
-            float* GF = reinterpret_cast<float*>(G);
-            const float* AF = reinterpret_cast<const float*>(A);
+            unsigned long long* GF = reinterpret_cast<unsigned long long*>(G + 2);
 #pragma unroll
-            for (int k = 2; k < kAccLds; k++) atomicAdd(&GF[k], AF[k]);
+            for (int k = 0; k < 9; k++) atomicAdd(&GF[k], lsum[k * lds_slots + s]);
         }
     }
 }
@@ -542,12 +691,13 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
         uint32_t* A = acc + ((size_t)pair * V + s) * kAccWords;
         const uint32_t n2 = A[0], m = A[1];
         float sd[3], sdd[6];
-        const float* AF = reinterpret_cast<const float*>(A);
-        sd[0] = AF[2]; sd[1] = AF[3]; sd[2] = AF[4];
+        const long long* AF = reinterpret_cast<const long long*>(A + 2);
 #pragma unroll
-        for (int k = 0; k < 6; k++) sdd[k] = AF[5 + k];
+        for (int k = 0; k < 3; k++) sd[k] = (float)((double)AF[k] * kFixInv);
 #pragma unroll
-        for (int k = 0; k < kAccLds; k++) A[k] = 0u;             // ready for the next iteration
+        for (int k = 0; k < 6; k++) sdd[k] = (float)((double)AF[3 + k] * kFixInv);
+#pragma unroll
+        for (int k = 0; k < kAccWords; k++) A[k] = 0u;           // ready for the next iteration
         const SlotFit f = fitS[(size_t)pair * V + s];
         if (aux.n2_raw) aux.n2_raw[((size_t)pair * runlen + iter) * V + f.v] = (int)n2;
         if (aux.n2_in) aux.n2_in[((size_t)pair * runlen + iter) * V + f.v] = (int)m;
@@ -733,11 +883,18 @@ hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float
 }
 
 hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
-    const int lds_slots = 384;
-    const int gx = chunks_for(c.n_pairs, c.max_n2, kBlock * 8, 2048);
-    const size_t lds = (size_t)((c.V + 1) / 2) * 4 + (size_t)lds_slots * (9 + kAccLds) * 4;
-    dim3 grid(gx, c.n_pairs), blk(kBlock);
-    k_gn_accumulate<<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, c.T, c.P, lds_slots);
+    const int lds_slots = c.lds_slots;
+    const int chunks = chunks_for(c.n_pairs, c.max_n2, kBlock * c.acc_min_pts_per_thread, c.acc_target_blocks);
+    const size_t lds = (size_t)(w.lut_Mt + w.lut_Mp) * sizeof(LutCell) + (size_t)lds_slots * (5 + kAccLds) * 4 + (size_t)((c.V + 1) / 2) * 4 + 16;
+    const int groups = c.n_pairs >= 8 ? (c.n_pairs + 7) / 8 * 8 : c.n_pairs;
+    dim3 grid(groups * chunks), blk(kBlock);
+    const LutCell* lut = reinterpret_cast<const LutCell*>(w.lut);
+    if (c.vec4_ok)
+        k_gn_accumulate<true><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp,
+                                                     w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact);
+    else
+        k_gn_accumulate<false><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp,
+                                                      w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -97,12 +97,13 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (n > w.cap_n1) {
             HIPCHK(c, dev_realloc(w.r1, n)); HIPCHK(c, dev_realloc(w.th1, n)); HIPCHK(c, dev_realloc(w.ph1, n));
+            HIPCHK(c, dev_realloc(w.key64A, n)); HIPCHK(c, dev_realloc(w.key64B, n)); HIPCHK(c, dev_realloc(w.bin16, n));
             HIPCHK(c, dev_realloc(w.keyA, n)); HIPCHK(c, dev_realloc(w.keyB, n)); HIPCHK(c, dev_realloc(w.valA, n)); HIPCHK(c, dev_realloc(w.valB, n));
             HIPCHK(c, dev_realloc(w.pred, n)); HIPCHK(c, dev_realloc(w.src, n)); HIPCHK(c, dev_realloc(w.exec, n));
             HIPCHK(c, dev_realloc(w.rs, n)); HIPCHK(c, dev_realloc(w.ths, n)); HIPCHK(c, dev_realloc(w.phs, n));
             w.cap_n1 = n;
         }
-        const size_t need = sort_temp_bytes(w.cap_n1, w.cap_pairs);
+        const size_t need = sort_temp_bytes(w.cap_n1);
         if (need > w.sort_tmp_bytes) {
             if (w.sort_tmp) { HIPCHK(c, hipFree(w.sort_tmp)); w.sort_tmp = nullptr; }
             HIPCHK(c, hipMalloc(&w.sort_tmp, need));
@@ -219,6 +220,7 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     if (const char* e = getenv("ICET_ACC_PTS")) cfg.acc_min_pts_per_thread = atoi(e);
     if (const char* e = getenv("ICET_ACC_BLOCKS")) cfg.acc_target_blocks = atoi(e);
     if (const char* e = getenv("ICET_FORCE_EXACT")) cfg.force_exact = atoi(e);
+    if (const char* e = getenv("ICET_KF_PTS")) cfg.kf_pts_per_thread = atoi(e);
     cfg.vec4_ok = 1;
     for (int k = 0; k < n_pairs; k++)
         if ((reinterpret_cast<uintptr_t>(c->h_desc[k].s2) & 15u) || (c->h_desc[k].ld2 & 3)) { cfg.vec4_ok = 0; break; }
@@ -290,7 +292,7 @@ icet_status icet_destroy(icet_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     Workspace& w = c->w;
-    void* ps[] = {w.desc, w.seg_off, w.r1, w.th1, w.ph1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src, w.exec, w.rs, w.ths, w.phs,
+    void* ps[] = {w.key64A, w.key64B, w.bin16, w.desc, w.seg_off, w.r1, w.th1, w.ph1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src, w.exec, w.rs, w.ths, w.phs,
                   w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, w.xf, w.X, w.flags,
                   w.sort_tmp, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);

@@ -53,7 +53,9 @@ struct Workspace {
     PairDesc* desc = nullptr;
     int32_t* seg_off = nullptr;               // pairs+1, scan-1 segment offsets
     float *r1 = nullptr, *th1 = nullptr, *ph1 = nullptr;            // spherical scan 1, input order
+    unsigned long long *key64A = nullptr, *key64B = nullptr;         // (pair << 32 | r bits)
     uint32_t *keyA = nullptr, *keyB = nullptr, *valA = nullptr, *valB = nullptr;
+    uint16_t* bin16 = nullptr;                                       // angular bin of every scan-1 row (input order)
     int32_t *pred = nullptr, *src = nullptr; uint8_t* exec = nullptr;
     float *rs = nullptr, *ths = nullptr, *phs = nullptr;            // spherical scan 1 in (bin, position) order
     int32_t *bin_count = nullptr, *bin_start = nullptr;             // pairs x V, pairs x (V+1)
@@ -79,6 +81,7 @@ struct LaunchCfg {
     int lds_slots = 288;              // active voxels kept in LDS by k_gn_accumulate (the rest go straight to HBM)
     int acc_min_pts_per_thread = 8;   // launch shaping of k_gn_accumulate
     int acc_target_blocks = 2048;
+    int kf_pts_per_thread = 8;        // keyframe kernels: points per thread (sets chunks per pair)
     int vec4_ok = 0;                  // every scan-2 pointer and leading dimension is 16-byte aligned
     int force_exact = 0;              // diagnostic: route every point through the literal evaluation
 };
@@ -90,9 +93,10 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st);
 
 // sort.hip
-size_t sort_temp_bytes(int64_t total_n, int n_segments);
-hipError_t sort_pairs_segmented(void* tmp, size_t tmp_bytes, const uint32_t* key_in, uint32_t* key_out,
-                                const uint32_t* val_in, uint32_t* val_out, int64_t total_n, int n_segments,
-                                const int32_t* d_seg_off, int begin_bit, int end_bit, hipStream_t st);
+size_t sort_temp_bytes(int64_t total_n);
+hipError_t sort_pairs_u64(void* tmp, size_t tmp_bytes, const unsigned long long* key_in, unsigned long long* key_out,
+                          const uint32_t* val_in, uint32_t* val_out, int64_t total_n, int end_bit, hipStream_t st);
+hipError_t sort_pairs_u32(void* tmp, size_t tmp_bytes, const uint32_t* key_in, uint32_t* key_out,
+                          const uint32_t* val_in, uint32_t* val_out, int64_t total_n, int end_bit, hipStream_t st);
 
 }  // namespace icet

@@ -8,7 +8,7 @@
 //     [stable radix sort by r]                         (src/icet.cpp:72-77)
 //     k_inverse_perm / k_exec_flags / k_scramble_src   the reference's one-step swap loop
 //                                                      (src/icet.cpp:78-83) in parallel closed form
-//     k_bin_positions + [stable sort by bin] + k_scan_bins + k_gather_sorted
+//     k_bin_positions + [stable sort by (pair, bin)] + k_bin_bounds + k_gather_sorted
 //                                                      sortSphericalCoordinates (src/icet.cpp:534-554)
 //     k_fit_scan1         fitCells1 (src/icet.cpp:109-252): findCluster (:557-607), bounds filter
 //                         (:609-652), mean/covariance, 3x3 eigen, sigma-point test (:654-696) -> L
@@ -39,6 +39,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -64,7 +69,9 @@ __device__ __forceinline__ void c2s_point(float x, float y, float z, float& r, f
 }
 
 __device__ __forceinline__ void s2c_point(float r, float th, float ph, float& x, float& y, float& z) {
-    float sp = sinf(ph), cp = cosf(ph), st = sinf(th), ct = cosf(th);
+    // separate sinf / cosf on purpose: they are the functions the reference calls (src/utils.cpp:135-137); the fused
+    // sincosf differs from them in the last ulp often enough to flip a sigma-point test on the sample scans
+    const float sp = sinf(ph), cp = cosf(ph), st = sinf(th), ct = cosf(th);
     x = r * sp * ct; y = r * sp * st; z = r * cp;
 }
 
@@ -80,28 +87,53 @@ __device__ __forceinline__ bool inside_bounds(float r, float az, float el, float
     return az >= az0 && az <= az1 && el >= el0 && el <= el1 && r >= inner && r <= outer;
 }
 
+// 1-D grid -> (pair, chunk).  With >= 8 pairs every chunk of a pair gets the same blockIdx % 8, i.e. (as the
+// dispatcher is observed to deal blocks round-robin over the 8 XCDs) the same XCD and the same 4 MiB L2, and
+// consecutive block ids walk through ONE group of 8 pairs before touching the next: the pointer-chasing keyframe
+// kernels (rank / scramble / gather, ~1 MB of randomly accessed tables per pair) then find their pair's tables in
+// L2 instead of HBM.  Speed only -- nothing depends on where a block actually lands.
+__device__ __forceinline__ bool decode_block(int n_pairs, int chunks, int& pair, int& chunk) {
+    if (n_pairs >= 8) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        pair = (j / chunks) * 8 + xcd; chunk = j % chunks;
+        return pair < n_pairs;
+    }
+    pair = blockIdx.x / chunks; chunk = blockIdx.x % chunks;
+    return true;
+}
+#define ICET_FOR_CHUNK_OF_SCAN1(i)                                                         \
+    int pair, chunk;                                                                       \
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;                               \
+    const PairDesc d = desc[pair];                                                         \
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;     \
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);                               \
+    for (int i = lo_ + threadIdx.x; i < hi_; i += kBlock)
+
 // ------------------------------------------------------------------------------------------------
 // keyframe build
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __restrict__ desc, float* __restrict__ r1, float* __restrict__ th1,
-                                                            float* __restrict__ ph1, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
-    const PairDesc d = desc[blockIdx.y];
-    const float* x = d.s1; const float* y = d.s1 + d.ld1; const float* z = d.s1 + 2 * (size_t)d.ld1;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.n1; i += gridDim.x * kBlock) {
+                                                            float* __restrict__ ph1, unsigned long long* __restrict__ key64, uint32_t* __restrict__ key32,
+                                                            uint32_t* __restrict__ val, uint16_t* __restrict__ bin16, int T, int P, int n_pairs, int chunks) {
+    ICET_FOR_CHUNK_OF_SCAN1(i) {
+        const float* x = d.s1; const float* y = d.s1 + d.ld1; const float* z = d.s1 + 2 * (size_t)d.ld1;
         float r, th, ph;
         c2s_point(x[i], y[i], z[i], r, th, ph);
         size_t o = (size_t)d.off1 + i;
         r1[o] = r; th1[o] = th; ph1[o] = ph;
-        key[o] = __float_as_uint(r);      // r >= +0 (or 1000 for NaN): the bit pattern orders like the float
+        // r >= +0 (or 1000 for NaN): the bit pattern orders like the float; the pair id in the high word keeps
+        // every pair's points contiguous, so one device-wide sort handles the whole batch
+        if (key64) key64[o] = ((unsigned long long)pair << 32) | (unsigned long long)__float_as_uint(r);
+        else key32[o] = __float_as_uint(r);
         val[o] = (uint32_t)i;
+        bin16[o] = (uint16_t)voxel_of(th, ph, T, P);
     }
 }
 
 // pred[s[i]] = i : rank of every original row.
-__global__ __launch_bounds__(kBlock) void k_inverse_perm(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, int32_t* __restrict__ pred) {
-    const PairDesc d = desc[blockIdx.y];
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.n1; i += gridDim.x * kBlock)
-        pred[(size_t)d.off1 + s[(size_t)d.off1 + i]] = i;
+__global__ __launch_bounds__(kBlock) void k_inverse_perm(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, int32_t* __restrict__ pred,
+                                                         int n_pairs, int chunks) {
+    ICET_FOR_CHUNK_OF_SCAN1(i) pred[(size_t)d.off1 + s[(size_t)d.off1 + i]] = i;
 }
 
 // The reference "sorts" rows in place with
@@ -111,10 +143,9 @@ __global__ __launch_bounds__(kBlock) void k_inverse_perm(const PairDesc* __restr
 // executed step i' = pred(i) < i.  So exec(v) is the parity of the length of the descending chain
 // v, pred(v), pred(pred(v)), ... taken while pred(u) < u.
 __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
-                                                       uint8_t* __restrict__ exec, int32_t* __restrict__ flags, int max_walk) {
-    const PairDesc d = desc[blockIdx.y];
-    const size_t o = d.off1;
-    for (int v = blockIdx.x * kBlock + threadIdx.x; v < d.n1; v += gridDim.x * kBlock) {
+                                                       uint8_t* __restrict__ exec, int32_t* __restrict__ flags, int max_walk, int n_pairs, int chunks) {
+    ICET_FOR_CHUNK_OF_SCAN1(v) {
+        const size_t o = d.off1;
         uint8_t e = 0;
         if ((int)s[o + v] != v) {
             int u = v, len = 0;
@@ -122,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
                 int p = pred[o + u];
                 if (p >= u) break;
                 u = p; len++;
-                if (len > max_walk) { atomicOr(&flags[blockIdx.y], 1); break; }
+                if (len > max_walk) { atomicOr(&flags[pair], 1); break; }
             }
             e = (len & 1) ? 0 : 1;
         }
@@ -134,10 +165,10 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
 // pred(v), except at the head of a run of executed steps, where the row arrives from the end of
 // the forward chain v -> s[v] -> s[s[v]] ... while the steps executed.
 __global__ __launch_bounds__(kBlock) void k_scramble_src(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
-                                                         const uint8_t* __restrict__ exec, int32_t* __restrict__ src, int32_t* __restrict__ flags, int max_walk) {
-    const PairDesc d = desc[blockIdx.y];
-    const size_t o = d.off1;
-    for (int v = blockIdx.x * kBlock + threadIdx.x; v < d.n1; v += gridDim.x * kBlock) {
+                                                         const uint8_t* __restrict__ exec, int32_t* __restrict__ src, int32_t* __restrict__ flags, int max_walk,
+                                                         int n_pairs, int chunks) {
+    ICET_FOR_CHUNK_OF_SCAN1(v) {
+        const size_t o = d.off1;
         int f = v;
         if ((int)s[o + v] != v) {
             int p = pred[o + v];
@@ -146,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_scramble_src(const PairDesc* __restr
                 int u = v, len = 0;
                 while (exec[o + u]) {
                     u = (int)s[o + u];
-                    if (++len > max_walk) { atomicOr(&flags[blockIdx.y], 1); break; }
+                    if (++len > max_walk) { atomicOr(&flags[pair], 1); break; }
                 }
                 f = u;
             }
@@ -173,53 +204,42 @@ __global__ void k_scramble_serial(const PairDesc* __restrict__ desc, const uint3
     }
 }
 
-// Angular bin of the row sitting at every position after the scramble; key for the second sort.
-__global__ __launch_bounds__(kBlock) void k_bin_positions(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const float* __restrict__ th1,
-                                                          const float* __restrict__ ph1, uint32_t* __restrict__ key, uint32_t* __restrict__ val,
-                                                          int32_t* __restrict__ bin_count, int T, int P) {
-    const PairDesc d = desc[blockIdx.y];
-    const size_t o = d.off1;
-    const int V = T * P;
-    for (int v = blockIdx.x * kBlock + threadIdx.x; v < d.n1; v += gridDim.x * kBlock) {
-        int row = src[o + v];
-        int b = voxel_of(th1[o + row], ph1[o + row], T, P);
-        key[o + v] = (uint32_t)b; val[o + v] = (uint32_t)v;
-        atomicAdd(&bin_count[(size_t)blockIdx.y * V + b], 1);
+// Angular bin of the row sitting at every position after the scramble: key (pair, bin) for the second (stable) sort,
+// value = the row itself, so the sorted values list every bin's rows in ascending POSITION order -- exactly the
+// order sortSphericalCoordinates' push_back produces (src/icet.cpp:539-550).
+__global__ __launch_bounds__(kBlock) void k_bin_positions(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const uint16_t* __restrict__ bin16,
+                                                          uint32_t* __restrict__ key, uint32_t* __restrict__ val, int vbits, int n_pairs, int chunks) {
+    ICET_FOR_CHUNK_OF_SCAN1(v) {
+        const size_t o = d.off1;
+        const int row = src[o + v];
+        key[o + v] = ((uint32_t)pair << vbits) | (uint32_t)bin16[o + row];
+        val[o + v] = (uint32_t)row;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_bins(const int32_t* __restrict__ bin_count, int32_t* __restrict__ bin_start, int V) {
-    __shared__ int wave_tot[kBlock / 64];
-    __shared__ int base;
-    const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) base = 0;
-    __syncthreads();
-    for (int v0 = 0; v0 < V; v0 += kBlock) {
-        int v = v0 + threadIdx.x;
-        int c = v < V ? bin_count[(size_t)pair * V + v] : 0;
-        int incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < wave; k++) woff += wave_tot[k];
-        int b = base;
-        if (v < V) bin_start[(size_t)pair * (V + 1) + v] = b + woff + incl - c;
-        __syncthreads();
-        if (threadIdx.x == kBlock - 1) base = b + woff + incl;
-        __syncthreads();
+// bin_start[pair][b] = first index (relative to the pair's segment) whose sorted key is >= (pair, b).
+__global__ __launch_bounds__(kBlock) void k_bin_bounds(const int32_t* __restrict__ seg_off, const uint32_t* __restrict__ sorted_key,
+                                                       int32_t* __restrict__ bin_start, int V, int vbits) {
+    const int pair = blockIdx.y;
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b > V) return;
+    const int lo0 = seg_off[pair], hi0 = seg_off[pair + 1];
+    const uint32_t want = ((uint32_t)pair << vbits) | (uint32_t)b;
+    int lo = lo0, hi = hi0;
+    if (b == V) lo = hi0;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sorted_key[mid] < want) lo = mid + 1; else hi = mid;
     }
-    if (threadIdx.x == 0) bin_start[(size_t)pair * (V + 1) + V] = base;
+    bin_start[(size_t)pair * (V + 1) + b] = lo - lo0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_gather_sorted(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ sorted_pos, const int32_t* __restrict__ src,
+__global__ __launch_bounds__(kBlock) void k_gather_sorted(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ sorted_row,
                                                           const float* __restrict__ r1, const float* __restrict__ th1, const float* __restrict__ ph1,
-                                                          float* __restrict__ rs, float* __restrict__ ths, float* __restrict__ phs) {
-    const PairDesc d = desc[blockIdx.y];
-    const size_t o = d.off1;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.n1; i += gridDim.x * kBlock) {
-        int row = src[o + sorted_pos[o + i]];
+                                                          float* __restrict__ rs, float* __restrict__ ths, float* __restrict__ phs, int n_pairs, int chunks) {
+    ICET_FOR_CHUNK_OF_SCAN1(i) {
+        const size_t o = d.off1;
+        const int row = (int)sorted_row[o + i];
         rs[o + i] = r1[o + row]; ths[o + i] = th1[o + row]; phs[o + i] = ph1[o + row];
     }
 }
@@ -278,31 +298,58 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
             if (front != 0.f) { const float back = rs[base + cnt - 1]; inner = front - buff; outer = back + buff; }
             else { inner = 0.f; outer = 0.f; }
         }
-        // ---- filterPointsInsideCluster + sphericalToCartesian + mean (src/icet.cpp:155-160)
-        float sx = 0.f, sy = 0.f, sz = 0.f; int rows = 0;
-        for (int i = lane; i < cnt; i += 64) {
+        // ---- filterPointsInsideCluster + sphericalToCartesian + mean (src/icet.cpp:155-160).  The Cartesian
+        // coordinates of the first 4 x 64 points of the bin stay in registers for the second (centred) pass.
+        constexpr int kCache = 4;
+        float cx[kCache], cy[kCache], cz[kCache]; bool cin[kCache];
+        // Sums in double: the reference's float sums run in Eigen's (unspecified, vectorised) order, so there is no
+        // order to reproduce; the exactly rounded value is the one every order approximates, and it keeps the
+        // eigenvectors -- and with them the sigma-point masks -- as stable as the data allows.
+        double sx = 0.0, sy = 0.0, sz = 0.0; int rows = 0;
+#pragma unroll
+        for (int k = 0; k < kCache; k++) {
+            const int i = lane + 64 * k;
+            cin[k] = false; cx[k] = cy[k] = cz[k] = 0.f;
+            if (i < cnt) {
+                const float r = rs[base + i], th = ths[base + i], ph = phs[base + i];
+                if (inside_bounds(r, th, ph, az0, az1, el0, el1, inner, outer)) {
+                    s2c_point(r, th, ph, cx[k], cy[k], cz[k]); cin[k] = true;
+                    sx += (double)cx[k]; sy += (double)cy[k]; sz += (double)cz[k]; rows++;
+                }
+            }
+        }
+        for (int i = lane + 64 * kCache; i < cnt; i += 64) {
             const float r = rs[base + i], th = ths[base + i], ph = phs[base + i];
             if (inside_bounds(r, th, ph, az0, az1, el0, el1, inner, outer)) {
                 float x, y, z; s2c_point(r, th, ph, x, y, z);
-                sx += x; sy += y; sz += z; rows++;
+                sx += (double)x; sy += (double)y; sz += (double)z; rows++;
             }
         }
-        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); rows = wave_sum_i(rows);
+        sx = wave_sum_d(sx); sy = wave_sum_d(sy); sz = wave_sum_d(sz); rows = wave_sum_i(rows);
         if ((double)outer > 0.1 && rows * 3 >= n) {       // src/icet.cpp:158 (size() counts coefficients)
             has_fit = 1;
-            mean[0] = sx / (float)rows; mean[1] = sy / (float)rows; mean[2] = sz / (float)rows;
-            float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int i = lane; i < cnt; i += 64) {
+            mean[0] = (float)(sx / (double)rows); mean[1] = (float)(sy / (double)rows); mean[2] = (float)(sz / (double)rows);
+            double c[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < kCache; k++) {
+                if (cin[k]) {
+                    const float dx = cx[k] - mean[0], dy = cy[k] - mean[1], dz = cz[k] - mean[2];
+                    c[0] += (double)(dx * dx); c[1] += (double)(dx * dy); c[2] += (double)(dx * dz);
+                    c[3] += (double)(dy * dy); c[4] += (double)(dy * dz); c[5] += (double)(dz * dz);
+                }
+            }
+            for (int i = lane + 64 * kCache; i < cnt; i += 64) {
                 const float r = rs[base + i], th = ths[base + i], ph = phs[base + i];
                 if (inside_bounds(r, th, ph, az0, az1, el0, el1, inner, outer)) {
                     float x, y, z; s2c_point(r, th, ph, x, y, z);
                     const float dx = x - mean[0], dy = y - mean[1], dz = z - mean[2];
-                    c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+                    c[0] += (double)(dx * dx); c[1] += (double)(dx * dy); c[2] += (double)(dx * dz);
+                    c[3] += (double)(dy * dy); c[4] += (double)(dy * dz); c[5] += (double)(dz * dz);
                 }
             }
             const float den = (float)(rows - 1);
 #pragma unroll
-            for (int k = 0; k < 6; k++) cov[k] = wave_sum(c[k]) / den;
+            for (int k = 0; k < 6; k++) cov[k] = (float)wave_sum_d(c[k]) / den;
             // ---- eigen-decomposition, sigma points, L (src/icet.cpp:181-232); every lane runs the same
             // scalar code on the same values, lane 0 publishes.
             icetdev::eig3_sym(cov[0], cov[1], cov[3], cov[2], cov[4], cov[5], ev, Vm);
@@ -579,28 +626,23 @@ __global__ __launch_bounds__(kBlock) void k_gn_accumulate(const PairDesc* __rest
             const LutCell et = lut_t[ct], ep = lut_p[cp];
             const int bt = et.idx - ((pa < et.edge) ? 1 : 0);
             const int bp = ep.idx - ((w < ep.edge) ? 1 : 0);
-            bool near = !(fabsf(pa - et.edge) >= guard_t) || !(fabsf(w - ep.edge) >= guard_p) || (i0 + j >= end) || force_exact;
-            int s = -1; bool inb = false; float dx = 0.f, dy = 0.f, dz = 0.f;
-            if (!near) {
-                s = map[T * bp + bt];
-                if (s >= 0) {
-                    const float r = r2 * rs;
-                    // slots beyond the LDS table (more active voxels than lds_slots) are classified by the literal path,
-                    // which reads its record from HBM: keeps every LDS access a ds_* instruction.
-                    const float* h = hot + min(s, nl - 1) * 5;
-                    const float inner = h[0], outer = h[1], m0 = h[2], m1 = h[3], m2 = h[4];
-                    const float gr = 1e-6f * r;
-                    if (s >= nl || !(fabsf(r - inner) >= gr) || !(fabsf(r - outer) >= gr)) near = true;
-                    inb = (r >= inner) && (r <= outer);
-                    dx = qx - m0; dy = qy - m1; dz = qz - m2;
-                }
-            }
-            pc[j].s = s; pc[j].inb = inb; pc[j].dx = dx; pc[j].dy = dy; pc[j].dz = dz;
+            // straight-line code (bitwise | and &, clamped indices): no divergent branches on the common path
+            const int vox = min(max(T * bp + bt, 0), V - 1);
+            const int sm = map[vox];
+            const float* h = hot + min(max(sm, 0), lds_slots - 1) * 5;
+            const float inner = h[0], outer = h[1];
+            const float r = r2 * rs;
+            const float gr = 1e-6f * r;
+            const bool has = sm >= 0;
+            // slots beyond the LDS table (more active voxels than lds_slots) are classified by the literal path, which
+            // reads its record from HBM: keeps every LDS access a ds_* instruction.
+            const bool near = (force_exact != 0) | (i0 + j >= end) | !(fabsf(pa - et.edge) >= guard_t) | !(fabsf(w - ep.edge) >= guard_p)
+                              | (has & ((sm >= nl) | !(fabsf(r - inner) >= gr) | !(fabsf(r - outer) >= gr)));
+            pc[j].s = near ? -1 : sm;
+            pc[j].inb = has & (r >= inner) & (r <= outer);
+            pc[j].dx = qx - h[2]; pc[j].dy = qy - h[3]; pc[j].dz = qz - h[4];
             if (__ballot(near) != 0ull) {                               // rare: some lane sits on an edge
-                if (near) {
-                    if (i0 + j < end) classify_exact(qx, qy, qz, map, thr, T, P, hs, pc[j]);
-                    else { pc[j].s = -1; pc[j].inb = false; }
-                }
+                if (near & (i0 + j < end)) classify_exact(qx, qy, qz, map, thr, T, P, hs, pc[j]);
             }
             any_slot = any_slot || (pc[j].s >= 0);
         }
@@ -840,33 +882,40 @@ inline int chunks_for(int n_pairs, int max_n, int per_block_min, int target_bloc
 
 hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* auxp, hipStream_t st) {
     AuxDev aux{}; if (auxp) aux = *auxp;
-    const int gx = chunks_for(c.n_pairs, c.max_n1, kBlock * 4, 2048);
-    dim3 grid(gx, c.n_pairs), blk(kBlock);
+    // many small chunks per pair: with the XCD-aware mapping only ~4 pairs are then in flight per XCD (see decode_block)
+    int chunks = (c.max_n1 + kBlock * c.kf_pts_per_thread - 1) / (kBlock * c.kf_pts_per_thread);
+    if (chunks < 1) chunks = 1;
+    const int groups = c.n_pairs >= 8 ? (c.n_pairs + 7) / 8 * 8 : c.n_pairs;
+    dim3 grid(groups * chunks), blk(kBlock);
+    const int np = c.n_pairs;
     hipError_t e;
-    k_scan1_spherical<<<grid, blk, 0, st>>>(w.desc, w.r1, w.th1, w.ph1, w.keyA, w.valA);
+    int pbits = 0; while ((1 << pbits) < c.n_pairs) pbits++;
+    int vbits = 1; while ((1 << vbits) < c.V) vbits++;
+    const bool batch = c.n_pairs > 1;
+    k_scan1_spherical<<<grid, blk, 0, st>>>(w.desc, w.r1, w.th1, w.ph1, batch ? w.key64A : nullptr, w.keyA, w.valA, w.bin16, c.T, c.P, np, chunks);
     ICET_LAUNCH_CHECK();
-    e = sort_pairs_segmented(w.sort_tmp, w.sort_tmp_bytes, w.keyA, w.keyB, w.valA, w.valB, c.total_n1, c.n_pairs, w.seg_off, 0, 32, st);
+    if (batch) e = sort_pairs_u64(w.sort_tmp, w.sort_tmp_bytes, w.key64A, w.key64B, w.valA, w.valB, c.total_n1, 32 + pbits, st);
+    else e = sort_pairs_u32(w.sort_tmp, w.sort_tmp_bytes, w.keyA, w.keyB, w.valA, w.valB, c.total_n1, 32, st);
     if (e != hipSuccess) return e;
     // valB = s : original index of the row with rank i
-    k_inverse_perm<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred);
+    k_inverse_perm<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, np, chunks);
     ICET_LAUNCH_CHECK();
     e = hipMemsetAsync(w.flags, 0, sizeof(int32_t) * c.n_pairs, st); if (e != hipSuccess) return e;
     const int max_walk = 4096;
-    k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.exec, w.flags, max_walk);
+    k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.exec, w.flags, max_walk, np, chunks);
     ICET_LAUNCH_CHECK();
-    k_scramble_src<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.exec, w.src, w.flags, max_walk);
+    k_scramble_src<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.exec, w.src, w.flags, max_walk, np, chunks);
     ICET_LAUNCH_CHECK();
     k_scramble_serial<<<c.n_pairs, 64, 0, st>>>(w.desc, w.valB, w.pred /* reused as scratch */, w.src, w.flags);
     ICET_LAUNCH_CHECK();
-    e = hipMemsetAsync(w.bin_count, 0, sizeof(int32_t) * (size_t)c.n_pairs * c.V, st); if (e != hipSuccess) return e;
-    k_bin_positions<<<grid, blk, 0, st>>>(w.desc, w.src, w.th1, w.ph1, w.keyA, w.valA, w.bin_count, c.T, c.P);
+    k_bin_positions<<<grid, blk, 0, st>>>(w.desc, w.src, w.bin16, w.keyA, w.valA, vbits, np, chunks);
     ICET_LAUNCH_CHECK();
-    int bits = 1; while ((1 << bits) < c.V) bits++;
-    e = sort_pairs_segmented(w.sort_tmp, w.sort_tmp_bytes, w.keyA, w.keyB, w.valA, w.valB, c.total_n1, c.n_pairs, w.seg_off, 0, bits, st);
+    e = sort_pairs_u32(w.sort_tmp, w.sort_tmp_bytes, w.keyA, w.keyB, w.valA, w.valB, c.total_n1, vbits + pbits, st);
     if (e != hipSuccess) return e;
-    k_scan_bins<<<c.n_pairs, blk, 0, st>>>(w.bin_count, w.bin_start, c.V);
+    dim3 gb((c.V + 1 + kBlock - 1) / kBlock, c.n_pairs);
+    k_bin_bounds<<<gb, blk, 0, st>>>(w.seg_off, w.keyB, w.bin_start, c.V, vbits);
     ICET_LAUNCH_CHECK();
-    k_gather_sorted<<<grid, blk, 0, st>>>(w.desc, w.valB, w.src, w.r1, w.th1, w.ph1, w.rs, w.ths, w.phs);
+    k_gather_sorted<<<grid, blk, 0, st>>>(w.desc, w.valB, w.r1, w.th1, w.ph1, w.rs, w.ths, w.phs, np, chunks);
     ICET_LAUNCH_CHECK();
     dim3 gfit((c.V + kBlock / 64 - 1) / (kBlock / 64), c.n_pairs);
     k_fit_scan1<<<gfit, blk, 0, st>>>(w.desc, w.bin_start, w.rs, w.ths, w.phs, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n, c.thresh, c.buff);

@@ -12,23 +12,27 @@
 
 namespace icet {
 
-size_t sort_temp_bytes(int64_t total_n, int n_segments) {
+// Device-wide (non-segmented) LSD radix sorts.  A batch of pairs is sorted in ONE pass structure by prefixing
+// the pair id to the key: (pair << 32 | r bits) for the radial sort, (pair << vbits | bin) for the bin sort.
+// rocPRIM's segmented sort gives each 116k-point segment to a single workgroup and was 5x slower here.
+size_t sort_temp_bytes(int64_t total_n) {
     size_t a = 0, b = 0;
-    uint32_t* k = nullptr; int32_t* off = nullptr;
-    hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, a, k, k, k, k, (int)total_n, n_segments, off, off + 1, 0, 32, 0);
-    hipcub::DeviceRadixSort::SortPairs(nullptr, b, k, k, k, k, (int)total_n, 0, 32, 0);
+    uint32_t* k = nullptr; unsigned long long* k64 = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, k64, k64, k, k, (int)total_n, 0, 64, 0);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, k, k, k, k, (int)total_n, 0, 32, 0);
     return (a > b ? a : b) + 256;
 }
 
-hipError_t sort_pairs_segmented(void* tmp, size_t tmp_bytes, const uint32_t* key_in, uint32_t* key_out,
-                                const uint32_t* val_in, uint32_t* val_out, int64_t total_n, int n_segments,
-                                const int32_t* d_seg_off, int begin_bit, int end_bit, hipStream_t st) {
+hipError_t sort_pairs_u64(void* tmp, size_t tmp_bytes, const unsigned long long* key_in, unsigned long long* key_out,
+                          const uint32_t* val_in, uint32_t* val_out, int64_t total_n, int end_bit, hipStream_t st) {
     if (total_n == 0) return hipSuccess;
-    if (n_segments == 1)
-        return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key_in, key_out, val_in, val_out, (int)total_n,
-                                                  begin_bit, end_bit, st);
-    return hipcub::DeviceSegmentedRadixSort::SortPairs(tmp, tmp_bytes, key_in, key_out, val_in, val_out, (int)total_n,
-                                                       n_segments, d_seg_off, d_seg_off + 1, begin_bit, end_bit, st);
+    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key_in, key_out, val_in, val_out, (int)total_n, 0, end_bit, st);
+}
+
+hipError_t sort_pairs_u32(void* tmp, size_t tmp_bytes, const uint32_t* key_in, uint32_t* key_out,
+                          const uint32_t* val_in, uint32_t* val_out, int64_t total_n, int end_bit, hipStream_t st) {
+    if (total_n == 0) return hipSuccess;
+    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key_in, key_out, val_in, val_out, (int)total_n, 0, end_bit, st);
 }
 
 }  // namespace icet

@@ -31,6 +31,14 @@ namespace icet {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef ICET_ACC_BLOCK
+#define ICET_ACC_BLOCK 512
+#endif
+#ifndef ICET_ACC_WAVES
+#define ICET_ACC_WAVES 6
+#endif
+constexpr int kAccBlock = ICET_ACC_BLOCK;        // k_gn_accumulate: the waves of a block share one copy of the pair's LDS tables
+constexpr int kAccWavesPerSimd = ICET_ACC_WAVES; // register budget (6 -> 80 VGPRs, no spills; measured equal to 4 and faster than 8, which spills)
 constexpr double kTwoPi = 6.283185307179586476925286766559;
 constexpr double kPi = 3.14159265358979323846;
 
@@ -543,7 +551,7 @@ typedef float vfloat4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const vfloat4 gfloat4;
 
 template <bool kVec4>
-__global__ __launch_bounds__(kBlock) void k_gn_accumulate(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
+__global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
                                                           const int16_t* __restrict__ slot_of_voxel, const int32_t* __restrict__ n_slots,
                                                           const SlotHot* __restrict__ hotS, uint32_t* __restrict__ acc,
                                                           const float* __restrict__ thr, const LutCell* __restrict__ lut,
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(kBlock) void k_gn_accumulate(const PairDesc* __rest
     }
     const PairDesc d = desc[pair];
     int cs = (d.n2 + chunks - 1) / chunks;
-    cs = (cs + 4 * kBlock - 1) / (4 * kBlock) * (4 * kBlock);            // whole trips of 4 points x 256 lanes
+    cs = (cs + 4 * kAccBlock - 1) / (4 * kAccBlock) * (4 * kAccBlock);            // whole trips of 4 points x 256 lanes
     const int begin = chunk * cs;
     if (begin >= d.n2) return;
     const int end = min(d.n2, begin + cs);
@@ -580,13 +588,13 @@ __global__ __launch_bounds__(kBlock) void k_gn_accumulate(const PairDesc* __rest
     {
         const uint32_t* gm = reinterpret_cast<const uint32_t*>(slot_of_voxel + (size_t)pair * ((V + 1) & ~1));   // rows padded to even length
         uint32_t* lm = reinterpret_cast<uint32_t*>(map);
-        for (int i = threadIdx.x; i < map_words; i += kBlock) lm[i] = gm[i];
+        for (int i = threadIdx.x; i < map_words; i += kAccBlock) lm[i] = gm[i];
         const uint2* gl = reinterpret_cast<const uint2*>(lut);
         uint2* ll = reinterpret_cast<uint2*>(lut_t);
-        for (int i = threadIdx.x; i < Mt + Mp; i += kBlock) ll[i] = gl[i];
-        for (int i = threadIdx.x; i < nl * 5; i += kBlock) { int s = i / 5, k = i - s * 5; hot[i] = reinterpret_cast<const float*>(hs + s)[4 + k]; }
-        for (int i = threadIdx.x; i < 9 * lds_slots; i += kBlock) lsum[i] = 0ull;
-        for (int i = threadIdx.x; i < 2 * lds_slots; i += kBlock) lraw[i] = 0u;
+        for (int i = threadIdx.x; i < Mt + Mp; i += kAccBlock) ll[i] = gl[i];
+        for (int i = threadIdx.x; i < nl * 5; i += kAccBlock) { int s = i / 5, k = i - s * 5; hot[i] = reinterpret_cast<const float*>(hs + s)[4 + k]; }
+        for (int i = threadIdx.x; i < 9 * lds_slots; i += kAccBlock) lsum[i] = 0ull;
+        for (int i = threadIdx.x; i < 2 * lds_slots; i += kAccBlock) lraw[i] = 0u;
     }
     const float* xf = xf_all + pair * 16;
     const float tx = xf[0], ty = xf[1], tz = xf[2];
@@ -597,8 +605,7 @@ __global__ __launch_bounds__(kBlock) void k_gn_accumulate(const PairDesc* __rest
     gfloat* px = (gfloat*)d.s2; gfloat* py = px + d.ld2; gfloat* pz = px + 2 * (size_t)d.ld2;   // scans live in HBM: global_load, not flat
     uint32_t* gacc = acc + (size_t)pair * V * kAccWords;
 
-    for (int i0 = begin + 4 * threadIdx.x; i0 < begin + cs; i0 += 4 * kBlock) {      // whole waves iterate together
-        float X[4], Y[4], Z[4];
+    auto load4 = [&](int i0, float (&X)[4], float (&Y)[4], float (&Z)[4]) {
         if (kVec4 && i0 + 3 < end) {
             const vfloat4 a = *(gfloat4*)(px + i0), b = *(gfloat4*)(py + i0), c = *(gfloat4*)(pz + i0);
             X[0] = a.x; X[1] = a.y; X[2] = a.z; X[3] = a.w; Y[0] = b.x; Y[1] = b.y; Y[2] = b.z; Y[3] = b.w; Z[0] = c.x; Z[1] = c.y; Z[2] = c.z; Z[3] = c.w;
@@ -606,15 +613,23 @@ __global__ __launch_bounds__(kBlock) void k_gn_accumulate(const PairDesc* __rest
 #pragma unroll
             for (int j = 0; j < 4; j++) { const bool ok = i0 + j < end; X[j] = ok ? px[i0 + j] : 0.f; Y[j] = ok ? py[i0 + j] : 0.f; Z[j] = ok ? pz[i0 + j] : 0.f; }
         }
+    };
+    for (int i0 = begin + 4 * threadIdx.x; i0 < begin + cs; i0 += 4 * kAccBlock) {      // whole waves iterate together
+        // no software prefetch: measured, it buys nothing here -- the kernel is VALU-issue-bound (PMC: ~150 VALU
+        // instructions per point, waves parked < 40 % of the time), not latency-bound
+        float X[4], Y[4], Z[4];
+        load4(i0, X, Y, Z);
         PointClass pc[4];
-        bool any_slot = false;
+        float QX[4], QY[4], QZ[4];
+        bool nr[4];
+        // ---- phase A: fast classification of the 4 points, straight-line so the four LDS look-up chains overlap ----
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const float a = X[j] + tx, b = Y[j] + ty, c = Z[j] + tz;
             const float qx = a * R00 + b * R10 + c * R20;
             const float qy = a * R01 + b * R11 + c * R21;
             const float qz = a * R02 + b * R12 + c * R22;
-            // ---- fast classification ----
+            QX[j] = qx; QY[j] = qy; QZ[j] = qz;
             const float r2 = qx * qx + qy * qy + qz * qz;
             const float rs = __builtin_amdgcn_rsqf(r2);
             const float w = -qz * rs;                                    // -cos(phi)
@@ -626,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void k_gn_accumulate(const PairDesc* __rest
             const LutCell et = lut_t[ct], ep = lut_p[cp];
             const int bt = et.idx - ((pa < et.edge) ? 1 : 0);
             const int bp = ep.idx - ((w < ep.edge) ? 1 : 0);
-            // straight-line code (bitwise | and &, clamped indices): no divergent branches on the common path
+            // bitwise | and &, clamped indices: no divergent branches on the common path
             const int vox = min(max(T * bp + bt, 0), V - 1);
             const int sm = map[vox];
             const float* h = hot + min(max(sm, 0), lds_slots - 1) * 5;
@@ -638,14 +653,18 @@ __global__ __launch_bounds__(kBlock) void k_gn_accumulate(const PairDesc* __rest
             // reads its record from HBM: keeps every LDS access a ds_* instruction.
             const bool near = (force_exact != 0) | (i0 + j >= end) | !(fabsf(pa - et.edge) >= guard_t) | !(fabsf(w - ep.edge) >= guard_p)
                               | (has & ((sm >= nl) | !(fabsf(r - inner) >= gr) | !(fabsf(r - outer) >= gr)));
+            nr[j] = near;
             pc[j].s = near ? -1 : sm;
             pc[j].inb = has & (r >= inner) & (r <= outer);
             pc[j].dx = qx - h[2]; pc[j].dy = qy - h[3]; pc[j].dz = qz - h[4];
-            if (__ballot(near) != 0ull) {                               // rare: some lane sits on an edge
-                if (near & (i0 + j < end)) classify_exact(qx, qy, qz, map, thr, T, P, hs, pc[j]);
-            }
-            any_slot = any_slot || (pc[j].s >= 0);
         }
+        // ---- phase B (rare): points within a guard band of a voxel edge are re-done with the literal formulas ----
+        if (__ballot(nr[0] | nr[1] | nr[2] | nr[3]) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (nr[j] & (i0 + j < end)) classify_exact(QX[j], QY[j], QZ[j], map, thr, T, P, hs, pc[j]);
+        }
+        const bool any_slot = (pc[0].s >= 0) | (pc[1].s >= 0) | (pc[2].s >= 0) | (pc[3].s >= 0);
         if (__ballot(any_slot) == 0ull) continue;                         // wave-uniform: nothing lands in an active voxel
         // ---- run-length accumulation over the lane's 4 consecutive points ----
         int cur = -1; uint32_t nraw = 0, nin = 0;
@@ -687,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void k_gn_accumulate(const PairDesc* __rest
         flush();
     }
     __syncthreads();
-    for (int s = threadIdx.x; s < nl; s += kBlock) {
+    for (int s = threadIdx.x; s < nl; s += kAccBlock) {
         const uint32_t raw = lraw[s];
         if (raw == 0u) continue;
         uint32_t* G = gacc + (size_t)s * kAccWords;
@@ -933,10 +952,10 @@ hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float
 
 hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
     const int lds_slots = c.lds_slots;
-    const int chunks = chunks_for(c.n_pairs, c.max_n2, kBlock * c.acc_min_pts_per_thread, c.acc_target_blocks);
+    const int chunks = chunks_for(c.n_pairs, c.max_n2, kAccBlock * c.acc_min_pts_per_thread, c.acc_target_blocks);
     const size_t lds = (size_t)(w.lut_Mt + w.lut_Mp) * sizeof(LutCell) + (size_t)lds_slots * (5 + kAccLds) * 4 + (size_t)((c.V + 1) / 2) * 4 + 16;
     const int groups = c.n_pairs >= 8 ? (c.n_pairs + 7) / 8 * 8 : c.n_pairs;
-    dim3 grid(groups * chunks), blk(kBlock);
+    dim3 grid(groups * chunks), blk(kAccBlock);
     const LutCell* lut = reinterpret_cast<const LutCell*>(w.lut);
     if (c.vec4_ok)
         k_gn_accumulate<true><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp,

@@ -1,0 +1,74 @@
+// include/icet.h -- drop-in replacement for the reference's include/icet.h (class ICET), backed by libicet_hip.so.
+//
+// Same class name, constructor signature, defaults and public data members as /root/reference/include/icet.h:36-116,
+// so src/odometry.cpp:73-79, src/simpleMapMaker.cpp:113-122, src/scanMatcher.cpp:55-64 and the demos compile
+// unchanged against it (they only construct the object and read X / pred_stds / points1 / points2 / clusterBounds /
+// ellipsoid*).  The whole registration runs on the MI355X inside the constructor through icet_solve()
+// (include/icet_hip.h); nothing of the reference's CPU implementation is reproduced here.
+//
+// Needs Eigen (as the reference does).  Eigen is not present in the build image of this repository, so this adapter
+// is deliberately a thin copy-in / copy-out shim over the Eigen-free icet_amd::ICET of include/icet_host.hpp, which
+// is what the test-suite compiles and runs (tests/cpp).  Members the reference keeps only for its own internals
+// (pointIndices1/2, the sigma1/mu1/U/L std::maps, points1Spherical, ...) are not exposed; no caller reads them.
+#ifndef ICET_H
+#define ICET_H
+
+#include <Eigen/Dense>
+#include <vector>
+#include "icet_host.hpp"
+
+class ICET {
+public:
+    ICET(Eigen::MatrixXf& scan1, Eigen::MatrixXf& scan2, int runlen, Eigen::VectorXf X0, int num_bins_phi, int num_bins_theta,
+         int n = 25, float thresh = 0.1, float buff = 0.1)
+        : rl(runlen), numBinsPhi(num_bins_phi), numBinsTheta(num_bins_theta), n(n), thresh(thresh), buff(buff),
+          points1(scan1), points2(scan2), points2_OG(scan2), X(X0) {
+        // Eigen::MatrixXf is column-major: data() is x[N] | y[N] | z[N] with leading dimension rows()
+        float x0[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 6 && k < X0.size(); k++) x0[k] = X0[k];
+        icet_amd::ICET it(scan1.data(), scan1.rows(), scan1.rows(), scan2.data(), scan2.rows(), scan2.rows(), runlen, x0,
+                          num_bins_phi, num_bins_theta, n, thresh, buff);
+        X = Eigen::VectorXf(6); pred_stds = Eigen::VectorXf(6); dx = Eigen::VectorXf(6);
+        for (int k = 0; k < 6; k++) { X[k] = it.X[k]; pred_stds[k] = it.pred_stds[k]; dx[k] = it.dx[k]; }
+        HTWH_i.resize(6, 6); HTWdz_i.resize(6, 1);
+        for (int a = 0; a < 6; a++) { HTWdz_i(a, 0) = it.HTWdz_i[a]; for (int b = 0; b < 6; b++) HTWH_i(a, b) = it.HTWH_i[a * 6 + b]; }
+        const int V = num_bins_phi * num_bins_theta;
+        clusterBounds = Eigen::MatrixXf::Zero(V, 6);
+        if ((int)it.clusterBounds.size() == V * 6)
+            for (int v = 0; v < V; v++) for (int k = 0; k < 6; k++) clusterBounds(v, k) = it.clusterBounds[v * 6 + k];
+        if ((long)it.points2.size() == scan2.rows() * 3)
+            points2 = Eigen::Map<const Eigen::MatrixXf>(it.points2.data(), scan2.rows(), 3);
+        for (size_t i = 0; i < it.ellipsoid1Means.size(); i++) {
+            ellipsoid1Means.emplace_back(it.ellipsoid1Means[i][0], it.ellipsoid1Means[i][1], it.ellipsoid1Means[i][2]);
+            Eigen::Matrix3f c;
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) c(a, b) = it.ellipsoid1Covariances[i][a * 3 + b];
+            ellipsoid1Covariances.push_back(c);
+            ellipsoid1Alphas.push_back(it.ellipsoid1Alphas[i]);
+        }
+        status = it.status; error = it.error;
+    }
+    ~ICET() {}
+
+    void step() { rl--; }
+
+    // algorithm params
+    int rl; int numBinsPhi; int numBinsTheta; int n; float thresh; float buff;
+
+    Eigen::MatrixXf points1, points2, points2_OG, clusterBounds, HTWH_i, HTWdz_i;
+    Eigen::VectorXf pred_stds;
+    Eigen::VectorXf X;    // global solution vector (x, y, z, roll, pitch, yaw)
+    Eigen::VectorXf dx;   // last linear perturbation
+
+    // for viz
+    std::vector<Eigen::Vector3f> ellipsoid1Means;
+    std::vector<Eigen::Matrix3f> ellipsoid1Covariances;
+    std::vector<float> ellipsoid1Alphas;
+    std::vector<Eigen::Vector3f> ellipsoid2Means;            // always empty, as in the reference (src/icet.cpp:49-61)
+    std::vector<Eigen::Matrix3f> ellipsoid2Covariances;
+    std::vector<float> ellipsoid2Alphas;
+
+    icet_status status = ICET_OK;   // additions: the reference signals no errors
+    std::string error;
+};
+
+#endif

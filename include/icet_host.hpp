@@ -1,0 +1,115 @@
+// include/icet_host.hpp -- Eigen-free C++ host class over the C ABI (include/icet_hip.h).
+//
+// Mirrors the reference's `class ICET` (/root/reference/include/icet.h:36-116): the constructor IS the solve
+// (src/icet.cpp:29-63) and callers read public members afterwards -- `X` and `pred_stds` in odometry_node /
+// map_maker_node (src/odometry.cpp:76-79,126-131; src/simpleMapMaker.cpp:119-122), plus `points1`, `points2`,
+// `clusterBounds` and the ellipsoid lists in the demos (src/icet_cpp_demo.cpp:47-57).  Same argument order,
+// names, defaults and meaning; scans are passed as raw COLUMN-MAJOR N x 3 float buffers (what
+// Eigen::MatrixXf::data() is), so this header needs no Eigen and is what tests/cpp exercises.
+// include/icet.h is the thin Eigen adapter with the reference's exact constructor signature.
+//
+// Errors: the reference signals none (degenerate input yields zeros/NaN in X).  Here `status` holds the
+// icet_status of the call and `error` its message; on failure X = X0 and pred_stds = 0, nothing throws.
+// There is NO CPU fallback: without a usable MI355X the status is ICET_ERR_NO_DEVICE / ICET_ERR_HIP.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+#include "icet_hip.h"
+
+namespace icet_amd {
+
+// One context (device + stream + workspace) per host thread and device, created on first use.
+inline icet_ctx* thread_context(int device, icet_status* st_out = nullptr) {
+    struct Holder {
+        std::vector<std::pair<int, icet_ctx*>> ctxs;
+        ~Holder() { for (auto& c : ctxs) icet_destroy(c.second); }
+    };
+    static thread_local Holder h;
+    for (auto& c : h.ctxs) if (c.first == device) { if (st_out) *st_out = ICET_OK; return c.second; }
+    icet_ctx* ctx = nullptr;
+    icet_status st = icet_create(&ctx, device, nullptr);
+    if (st_out) *st_out = st;
+    if (st != ICET_OK) return nullptr;
+    h.ctxs.emplace_back(device, ctx);
+    return ctx;
+}
+
+class ICET {
+public:
+    // scan1 / scan2: column-major N x 3 (x[0..n) | y[0..n) | z[0..n)), leading dimension ld >= n.
+    ICET(const float* scan1, int64_t n1, int64_t ld1, const float* scan2, int64_t n2, int64_t ld2, int runlen,
+         const float X0[6], int num_bins_phi, int num_bins_theta, int n = 25, float thresh = 0.1f, float buff = 0.1f,
+         int device = 0, bool side_tables = true)
+        : rl(runlen), numBinsPhi(num_bins_phi), numBinsTheta(num_bins_theta), n(n), thresh(thresh), buff(buff) {
+        for (int k = 0; k < 6; k++) { X[k] = X0 ? X0[k] : 0.f; pred_stds[k] = 0.f; dx[k] = 0.f; }
+        cov.fill(0.f); HTWH_i.fill(0.f); HTWdz_i.fill(0.f);
+        icet_ctx* ctx = thread_context(device, &status);
+        if (!ctx) { error = "icet_create failed (no usable HIP device; this path has no CPU fallback)"; return; }
+        icet_params p{runlen, num_bins_phi, num_bins_theta, n, thresh, buff, ICET_FLAG_NONE};
+        const int64_t V = (int64_t)num_bins_phi * num_bins_theta;
+        const int64_t RL = runlen > 0 ? runlen : 1;
+        std::vector<int32_t> has_fit;
+        std::vector<float> mu1, sigma1, x_hist, htwh, htwdz;
+        icet_aux aux{};
+        if (side_tables && V > 0) {
+            clusterBounds.assign((size_t)V * 6, 0.f); has_fit.assign(V, 0); mu1.assign((size_t)V * 3, 0.f); sigma1.assign((size_t)V * 9, 0.f);
+            x_hist.assign((size_t)RL * 6, 0.f); htwh.assign((size_t)RL * 36, 0.f); htwdz.assign((size_t)RL * 6, 0.f);
+            aux.cluster_bounds = clusterBounds.data(); aux.has_fit = has_fit.data(); aux.mu1 = mu1.data(); aux.sigma1 = sigma1.data();
+            aux.x_hist = x_hist.data(); aux.htwh = htwh.data(); aux.htwdz = htwdz.data();
+        }
+        float x0[6]; for (int k = 0; k < 6; k++) x0[k] = X[k];
+        status = icet_solve(ctx, &p, scan1, n1, ld1, scan2, n2, ld2, x0, X.data(), pred_stds.data(), cov.data(), side_tables ? &aux : nullptr);
+        if (status != ICET_OK) { error = icet_last_error(ctx); for (int k = 0; k < 6; k++) { X[k] = x0[k]; pred_stds[k] = 0.f; } return; }
+        if (!side_tables || runlen <= 0) return;
+        // ellipsoid1* : one entry per fitted scan-1 voxel, phi-major order (src/icet.cpp:95-102,236-239); ellipsoid2* stay empty
+        for (int64_t v = 0; v < V; v++) if (has_fit[v]) {
+            ellipsoid1Means.push_back({mu1[3 * v], mu1[3 * v + 1], mu1[3 * v + 2]});
+            std::array<float, 9> c; for (int k = 0; k < 9; k++) c[k] = sigma1[9 * v + k];
+            ellipsoid1Covariances.push_back(c); ellipsoid1Alphas.push_back(0.3f);
+        }
+        for (int k = 0; k < 36; k++) HTWH_i[k] = htwh[(size_t)(runlen - 1) * 36 + k];
+        for (int k = 0; k < 6; k++) HTWdz_i[k] = htwdz[(size_t)(runlen - 1) * 6 + k];
+        // `points2` = scan 2 under the transform of the LAST iteration, i.e. X before the final update
+        // (src/icet.cpp:375-378 precede :433): (p + t) * R(angles), column-major n2 x 3.
+        const float* xp = (runlen == 1) ? x0 : &x_hist[(size_t)(runlen - 2) * 6];
+        for (int k = 0; k < 6; k++) dx[k] = x_hist[(size_t)(runlen - 1) * 6 + k] - xp[k];
+        float R[9]; euler_R(xp[3], xp[4], xp[5], R);
+        points2.resize((size_t)n2 * 3);
+        for (int64_t i = 0; i < n2; i++) {
+            const float a = scan2[i] + xp[0], b = scan2[ld2 + i] + xp[1], c = scan2[2 * ld2 + i] + xp[2];
+            points2[i] = a * R[0] + b * R[3] + c * R[6];
+            points2[n2 + i] = a * R[1] + b * R[4] + c * R[7];
+            points2[2 * n2 + i] = a * R[2] + b * R[5] + c * R[8];
+        }
+    }
+
+    // utils::R (src/utils.cpp:144-152), row-major
+    static void euler_R(float phi, float theta, float psi, float R[9]) {
+        using std::cos; using std::sin;
+        R[0] = cos(theta) * cos(psi); R[1] = sin(psi) * cos(phi) + sin(phi) * sin(theta) * cos(psi); R[2] = sin(phi) * sin(psi) - sin(theta) * cos(phi) * cos(psi);
+        R[3] = -sin(psi) * cos(theta); R[4] = cos(phi) * cos(psi) - sin(phi) * sin(theta) * sin(psi); R[5] = sin(phi) * cos(psi) + sin(theta) * sin(psi) * cos(phi);
+        R[6] = sin(theta); R[7] = -sin(phi) * cos(theta); R[8] = cos(phi) * cos(theta);
+    }
+
+    void step() { rl--; }     // the reference's step() is a stub that only decrements rl (src/icet.cpp:438-441)
+
+    // algorithm params (include/icet.h:71-76)
+    int rl, numBinsPhi, numBinsTheta, n; float thresh, buff;
+    // results
+    std::array<float, 6> X{}, pred_stds{}, dx{};
+    std::array<float, 36> cov{};                 // 6x6 noise_mat, row-major (a local in the reference, src/icet.cpp:410-411)
+    std::array<float, 36> HTWH_i{}; std::array<float, 6> HTWdz_i{};
+    std::vector<float> clusterBounds;            // V x 6 row-major
+    std::vector<float> points2;                  // n2 x 3 column-major
+    std::vector<std::array<float, 3>> ellipsoid1Means, ellipsoid2Means;
+    std::vector<std::array<float, 9>> ellipsoid1Covariances, ellipsoid2Covariances;
+    std::vector<float> ellipsoid1Alphas, ellipsoid2Alphas;
+    icet_status status = ICET_OK;
+    std::string error;
+};
+
+}  // namespace icet_amd

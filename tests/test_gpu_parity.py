@@ -288,3 +288,25 @@ def test_error_behaviour(gpu_ctx, frames):
     # the context is still usable after errors
     r = gpu_ctx.solve(a, b, 1, np.zeros(6), 24, 75)
     assert np.isfinite(r["X"]).all()
+
+
+def test_cpp_host_class_demo(tmp_path, gpu_ctx, frames, frames_golden):
+    """The Eigen-free C++ class of include/icet_host.hpp (what include/icet.h adapts to Eigen), compiled with plain g++
+    against libicet_hip.so and run like the reference's demo harness: same answer as the Python mirror, bit for bit."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a, b = frames
+    (tmp_path / "s1.f32").write_bytes(np.ascontiguousarray(a.T).tobytes())
+    (tmp_path / "s2.f32").write_bytes(np.ascontiguousarray(b.T).tobytes())
+    exe = str(tmp_path / "host_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "host_demo.cpp"),
+                           "-L", os.path.join(root, "icet_amd", "lib"), "-licet_hip", "-Wl,-rpath," + os.path.join(root, "icet_amd", "lib"), "-o", exe])
+    out = subprocess.run([exe, str(tmp_path / "s1.f32"), str(tmp_path / "s2.f32"), str(a.shape[0]), str(b.shape[0]), "7", "24", "75"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+    X = np.array(lines["X"].split(), np.float32)
+    ref = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75)
+    assert np.array_equal(X, ref["X"])
+    assert np.abs(X[:3] - frames_golden["X"][:3]).max() <= TOL_T
+    assert lines["ellipsoids"].split()[0] == "86" and lines["bad_status"].strip() == "1"

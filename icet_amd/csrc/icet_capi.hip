@@ -97,7 +97,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (n > w.cap_n1) {
             HIPCHK(c, dev_realloc(w.r1, n)); HIPCHK(c, dev_realloc(w.th1, n)); HIPCHK(c, dev_realloc(w.ph1, n));
-            HIPCHK(c, dev_realloc(w.key64A, n)); HIPCHK(c, dev_realloc(w.key64B, n)); HIPCHK(c, dev_realloc(w.bin16, n));
+            HIPCHK(c, dev_realloc(w.key64A, n)); HIPCHK(c, dev_realloc(w.key64B, n)); HIPCHK(c, dev_realloc(w.bin16, n)); HIPCHK(c, dev_realloc(w.binpos, n));
             HIPCHK(c, dev_realloc(w.keyA, n)); HIPCHK(c, dev_realloc(w.keyB, n)); HIPCHK(c, dev_realloc(w.valA, n)); HIPCHK(c, dev_realloc(w.valB, n));
             HIPCHK(c, dev_realloc(w.pred, n)); HIPCHK(c, dev_realloc(w.src, n)); HIPCHK(c, dev_realloc(w.exec, n));
             HIPCHK(c, dev_realloc(w.rs, n)); HIPCHK(c, dev_realloc(w.ths, n)); HIPCHK(c, dev_realloc(w.phs, n));
@@ -158,14 +158,16 @@ icet_status ensure_thresholds(icet_ctx* c, int T, int P) {
         for (int k = 0; k <= P; k++) ep[k] = (k == 0) ? -1.0 : (k == P ? 1.0 : -std::cos(M_PI * k / P));
         std::vector<HostCell> lt, lp;
         const int Mt = build_lut(et, 0.0, 4.0, lt), Mp = build_lut(ep, -1.0, 2.0, lp);
-        std::vector<HostCell> all(lt); all.insert(all.end(), lp.begin(), lp.end());
+        // one spare cell per table: pa == 4 / w == 1 index cell M (it names the last edge, so the point goes to the literal path)
+        std::vector<HostCell> all(lt); all.push_back(HostCell{4.0f, T}); all.insert(all.end(), lp.begin(), lp.end()); all.push_back(HostCell{1.0f, P});
         if (w.lut) { HIPCHK(c, hipFree(w.lut)); w.lut = nullptr; }
         HIPCHK(c, hipMalloc(&w.lut, all.size() * sizeof(HostCell)));
         HIPCHK(c, hipMemcpy(w.lut, all.data(), all.size() * sizeof(HostCell), hipMemcpyHostToDevice));
         w.lut_Mt = Mt; w.lut_Mp = Mp;
         // Guard bands: a few float ulps of the coordinate plus the ulp-level disagreement between the LUT's
         // true edges and the literal evaluation's float thresholds ("exact fast path").
-        w.guard_t = 8e-6f; w.guard_p = 4e-6f;
+        w.guard_t = 5e-6f; w.guard_p = 2.5e-6f;
+        if (const char* e = getenv("ICET_GUARD_SCALE")) { w.guard_t *= (float)atof(e); w.guard_p *= (float)atof(e); }   // experiments only
     }
     std::vector<float> h((size_t)T + P + 2);
     build_thresholds(T, 2 * M_PI, h.data());
@@ -221,6 +223,8 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     if (const char* e = getenv("ICET_ACC_BLOCKS")) cfg.acc_target_blocks = atoi(e);
     if (const char* e = getenv("ICET_FORCE_EXACT")) cfg.force_exact = atoi(e);
     if (const char* e = getenv("ICET_KF_PTS")) cfg.kf_pts_per_thread = atoi(e);
+    if (cfg.kf_pts_per_thread > 8) cfg.kf_pts_per_thread = 8;      // k_bin_scatter: a tile is at most 4 waves x 8 rounds x 64 positions
+    if (cfg.kf_pts_per_thread < 1) cfg.kf_pts_per_thread = 1;
     cfg.vec4_ok = 1;
     for (int k = 0; k < n_pairs; k++)
         if ((reinterpret_cast<uintptr_t>(c->h_desc[k].s2) & 15u) || (c->h_desc[k].ld2 & 3)) { cfg.vec4_ok = 0; break; }
@@ -233,6 +237,16 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     }
     c->h_seg[n_pairs] = (int32_t)tot;
     cfg.total_n1 = tot; cfg.max_n1 = mx1; cfg.max_n2 = mx2;
+    cfg.kf_chunks = (mx1 + 256 * cfg.kf_pts_per_thread - 1) / (256 * cfg.kf_pts_per_thread);
+    if (cfg.kf_chunks < 1) cfg.kf_chunks = 1;
+    {
+        const size_t need = (size_t)n_pairs * cfg.kf_chunks * cfg.V;
+        if (need > w.cap_counts) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, dev_realloc(w.counts, need)); HIPCHK(c, dev_realloc(w.tile_base, need));
+            w.cap_counts = need;
+        }
+    }
     HIPCHK(c, hipMemcpyAsync(w.desc, c->h_desc, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(w.seg_off, c->h_seg, sizeof(int32_t) * (n_pairs + 1), hipMemcpyHostToDevice, c->stream));
     while ((int)c->ev_acc.size() < 2 * p->runlen) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_acc.push_back(e); }
@@ -292,7 +306,7 @@ icet_status icet_destroy(icet_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     Workspace& w = c->w;
-    void* ps[] = {w.key64A, w.key64B, w.bin16, w.desc, w.seg_off, w.r1, w.th1, w.ph1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src, w.exec, w.rs, w.ths, w.phs,
+    void* ps[] = {w.key64A, w.key64B, w.bin16, w.binpos, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.th1, w.ph1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src, w.exec, w.rs, w.ths, w.phs,
                   w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, w.xf, w.X, w.flags,
                   w.sort_tmp, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);

@@ -55,6 +55,8 @@ struct Workspace {
     float *r1 = nullptr, *th1 = nullptr, *ph1 = nullptr;            // spherical scan 1, input order
     unsigned long long *key64A = nullptr, *key64B = nullptr;         // (pair << 32 | r bits)
     uint32_t *keyA = nullptr, *keyB = nullptr, *valA = nullptr, *valB = nullptr;
+    uint16_t* binpos = nullptr;                                      // angular bin of the row at every position after the scramble
+    uint32_t* counts = nullptr; uint32_t* tile_base = nullptr; size_t cap_counts = 0;               // pairs x tiles x V histogram / tile base offsets
     uint16_t* bin16 = nullptr;                                       // angular bin of every scan-1 row (input order)
     int32_t *pred = nullptr, *src = nullptr; uint8_t* exec = nullptr;
     float *rs = nullptr, *ths = nullptr, *phs = nullptr;            // spherical scan 1 in (bin, position) order
@@ -81,6 +83,7 @@ struct LaunchCfg {
     int lds_slots = 288;              // active voxels kept in LDS by k_gn_accumulate (the rest go straight to HBM)
     int acc_min_pts_per_thread = 8;   // launch shaping of k_gn_accumulate
     int acc_target_blocks = 2048;
+    int kf_chunks = 1;                // tiles per pair in the keyframe kernels (set by the host from max_n1)
     int kf_pts_per_thread = 8;        // keyframe kernels: points per thread (sets chunks per pair)
     int vec4_ok = 0;                  // every scan-2 pointer and leading dimension is 16-byte aligned
     int force_exact = 0;              // diagnostic: route every point through the literal evaluation

@@ -8,7 +8,7 @@
 //     [stable radix sort by r]                         (src/icet.cpp:72-77)
 //     k_inverse_perm / k_exec_flags / k_scramble_src   the reference's one-step swap loop
 //                                                      (src/icet.cpp:78-83) in parallel closed form
-//     k_bin_positions + [stable sort by (pair, bin)] + k_bin_bounds + k_gather_sorted
+//     k_bin_hist + k_bin_scan + k_bin_scatter           stable multi-split of positions by voxel =
 //                                                      sortSphericalCoordinates (src/icet.cpp:534-554)
 //     k_fit_scan1         fitCells1 (src/icet.cpp:109-252): findCluster (:557-607), bounds filter
 //                         (:609-652), mean/covariance, 3x3 eigen, sigma-point test (:654-696) -> L
@@ -35,8 +35,12 @@ constexpr int kBlock = 256;
 #define ICET_ACC_BLOCK 512
 #endif
 #ifndef ICET_ACC_WAVES
-#define ICET_ACC_WAVES 6
+#define ICET_ACC_WAVES 4
 #endif
+#ifndef ICET_ACC_PTS
+#define ICET_ACC_PTS 16
+#endif
+constexpr int kAccPts = ICET_ACC_PTS;                      // consecutive points per lane per trip (two dwordx4 loads per coordinate)
 constexpr int kAccBlock = ICET_ACC_BLOCK;        // k_gn_accumulate: the waves of a block share one copy of the pair's LDS tables
 constexpr int kAccWavesPerSimd = ICET_ACC_WAVES; // register budget (6 -> 80 VGPRs, no spills; measured equal to 4 and faster than 8, which spills)
 constexpr double kTwoPi = 6.283185307179586476925286766559;
@@ -212,34 +216,138 @@ __global__ void k_scramble_serial(const PairDesc* __restrict__ desc, const uint3
     }
 }
 
-// Angular bin of the row sitting at every position after the scramble: key (pair, bin) for the second (stable) sort,
-// value = the row itself, so the sorted values list every bin's rows in ascending POSITION order -- exactly the
-// order sortSphericalCoordinates' push_back produces (src/icet.cpp:539-550).
-__global__ __launch_bounds__(kBlock) void k_bin_positions(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const uint16_t* __restrict__ bin16,
-                                                          uint32_t* __restrict__ key, uint32_t* __restrict__ val, int vbits, int n_pairs, int chunks) {
-    ICET_FOR_CHUNK_OF_SCAN1(v) {
-        const size_t o = d.off1;
-        const int row = src[o + v];
-        key[o + v] = ((uint32_t)pair << vbits) | (uint32_t)bin16[o + row];
-        val[o + v] = (uint32_t)row;
+// ---- grouping scan-1 rows by voxel, in ascending POSITION order inside each voxel -------------------------------
+// sortSphericalCoordinates appends point indices to per-voxel vectors while walking the (scrambled) array front to back
+// (src/icet.cpp:539-550), so findCluster later sees each voxel's rows in ascending position.  That is a STABLE
+// multi-split of the positions by voxel id.  Done here in three small kernels instead of a second library sort:
+//   k_bin_hist     per tile of positions: histogram of voxel ids (LDS), voxel id of every position
+//   k_bin_scan     per pair: exclusive scan over (voxel, tile) -> bin_start[] and each tile's base offset per voxel
+//   k_bin_scatter  one wave per tile walks its positions 64 at a time; lanes holding the same voxel find each other
+//                  with a ballot per id bit (match-any), so rank = popcount of lower peers -- stable by construction --
+//                  and the row's spherical coordinates are written straight to their final place.
+__global__ __launch_bounds__(kBlock) void k_bin_hist(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const uint16_t* __restrict__ bin16,
+                                                     uint16_t* __restrict__ binpos, uint32_t* __restrict__ counts, int V, int n_pairs, int chunks) {
+    extern __shared__ uint32_t lh[];
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const PairDesc d = desc[pair];
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
+    for (int b = threadIdx.x; b < V; b += kBlock) lh[b] = 0u;
+    __syncthreads();
+    const size_t o = d.off1;
+    for (int v = lo_ + threadIdx.x; v < hi_; v += kBlock) {
+        const uint16_t b = bin16[o + src[o + v]];
+        binpos[o + v] = b;
+        atomicAdd(&lh[b], 1u);
     }
+    __syncthreads();
+    uint32_t* out = counts + ((size_t)pair * chunks + chunk) * V;
+    for (int b = threadIdx.x; b < V; b += kBlock) out[b] = lh[b];
 }
 
-// bin_start[pair][b] = first index (relative to the pair's segment) whose sorted key is >= (pair, b).
-__global__ __launch_bounds__(kBlock) void k_bin_bounds(const int32_t* __restrict__ seg_off, const uint32_t* __restrict__ sorted_key,
-                                                       int32_t* __restrict__ bin_start, int V, int vbits) {
-    const int pair = blockIdx.y;
-    const int b = blockIdx.x * kBlock + threadIdx.x;
-    if (b > V) return;
-    const int lo0 = seg_off[pair], hi0 = seg_off[pair + 1];
-    const uint32_t want = ((uint32_t)pair << vbits) | (uint32_t)b;
-    int lo = lo0, hi = hi0;
-    if (b == V) lo = hi0;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (sorted_key[mid] < want) lo = mid + 1; else hi = mid;
+__global__ __launch_bounds__(kBlock) void k_bin_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ tile_base, int32_t* __restrict__ bin_start,
+                                                     int V, int chunks) {
+    __shared__ int wave_tot[kBlock / 64];
+    __shared__ int base;
+    const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int v0 = 0; v0 < V; v0 += kBlock) {
+        const int b = v0 + threadIdx.x;
+        int tot = 0;
+        if (b < V) {
+            const uint32_t* c = counts + (size_t)pair * chunks * V + b;
+            uint32_t* tb = tile_base + (size_t)pair * chunks * V + b;
+            int t = 0;
+            for (; t + 8 <= chunks; t += 8) {                         // 8 independent loads in flight
+                uint32_t x[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] = c[(size_t)(t + k) * V];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { tb[(size_t)(t + k) * V] = (uint32_t)tot; tot += (int)x[k]; }
+            }
+            for (; t < chunks; t++) { const uint32_t x = c[(size_t)t * V]; tb[(size_t)t * V] = (uint32_t)tot; tot += (int)x; }
+        }
+        int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; k++) woff += wave_tot[k];
+        const int bb = base;
+        if (b < V) bin_start[(size_t)pair * (V + 1) + b] = bb + woff + incl - tot;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) base = bb + woff + incl;
+        __syncthreads();
     }
-    bin_start[(size_t)pair * (V + 1) + b] = lo - lo0;
+    if (threadIdx.x == 0) bin_start[(size_t)pair * (V + 1) + V] = base;
+}
+
+// One block per tile (<= 2048 positions); wave w owns the w-th quarter (<= 8 rounds of 64 positions).  Everything
+// global is loaded up front and stored at the end, so the only serial chain is 8 rounds of ballots + LDS.
+constexpr int kScatterRounds = 8;
+__global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const uint16_t* __restrict__ binpos,
+                                                        const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bin_start,
+                                                        uint32_t* __restrict__ sorted_row, int V, int vbits, int n_pairs, int chunks) {
+    extern __shared__ uint32_t lb[];                                   // 4 x V : per-wave counts, then per-wave running offsets
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const PairDesc d = desc[pair];
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;      // multiple of 256, <= 64 * 4 * kScatterRounds
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
+    if (lo_ >= hi_) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qs = cs_ / 4;                                            // multiple of 64
+    const int wlo = lo_ + wave * qs, whi = min(hi_, wlo + qs);
+    const int rounds = qs / 64;
+    for (int i = threadIdx.x; i < 4 * V; i += kBlock) lb[i] = 0u;
+    __syncthreads();
+    const size_t o = d.off1;
+    uint32_t bb[kScatterRounds]; int row[kScatterRounds]; bool ok[kScatterRounds];
+    uint32_t* mine = lb + wave * V;
+#pragma unroll
+    for (int k = 0; k < kScatterRounds; k++) {
+        const int v = wlo + 64 * k + lane;
+        ok[k] = (k < rounds) & (v < whi);
+        bb[k] = ok[k] ? (uint32_t)binpos[o + v] : 0u;
+        row[k] = ok[k] ? src[o + v] : 0;
+        if (ok[k]) atomicAdd(&mine[bb[k]], 1u);
+    }
+    __syncthreads();
+    {
+        const uint32_t* tb = tile_base + ((size_t)pair * chunks + chunk) * V;
+        const int32_t* bst = bin_start + (size_t)pair * (V + 1);
+        for (int b = threadIdx.x; b < V; b += kBlock) {
+            const uint32_t c0 = lb[b], c1 = lb[V + b], c2 = lb[2 * V + b];
+            const uint32_t base = (uint32_t)bst[b] + tb[b];
+            lb[b] = base; lb[V + b] = base + c0; lb[2 * V + b] = base + c0 + c1; lb[3 * V + b] = base + c0 + c1 + c2;
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t dest[kScatterRounds];
+#pragma unroll
+    for (int k = 0; k < kScatterRounds; k++) {
+        unsigned long long peers = __ballot(ok[k]);
+        for (int q = 0; q < vbits; q++) {
+            const bool bit = (bb[k] >> q) & 1u;
+            const unsigned long long m = __ballot(ok[k] && bit);
+            peers &= bit ? m : ~m;
+        }
+        dest[k] = 0u;
+        if (ok[k]) {
+            const int rank = __popcll(peers & lt);
+            dest[k] = mine[bb[k]] + (uint32_t)rank;
+            if (rank == 0) mine[bb[k]] += (uint32_t)__popcll(peers);  // one leader per distinct voxel in this round
+        }
+    }
+    // one scattered 4-byte store per row; the coordinates follow in k_gather_sorted with coalesced stores (element-wise
+    // scattered stores of the three coordinate arrays cost 4x more than gathering them)
+#pragma unroll
+    for (int k = 0; k < kScatterRounds; k++)
+        if (ok[k]) sorted_row[o + dest[k]] = (uint32_t)row[k];
 }
 
 __global__ __launch_bounds__(kBlock) void k_gather_sorted(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ sorted_row,
@@ -533,7 +641,15 @@ __device__ __forceinline__ void classify_exact(float qx, float qy, float qz, con
 
 // Partial sums of a slot that has no LDS row go straight to HBM.  Kept out of line so that the LDS update above
 // stays a ds_add_* (a select between the two pointers would turn both into flat atomics).
-__device__ __forceinline__ unsigned long long to_fix(float v) { return (unsigned long long)(long long)(v * kFixScale); }
+// float -> 64-bit fixed point (floor(v * 2^30), two's complement) in 6 VALU instructions: the scaling is exact (power of
+// two), h = floor(x / 2^32) is a small integer held exactly in a float, and x - h * 2^32 is exact under fma and lies in
+// [0, 2^32).  Any fixed rounding rule would do; what matters is that integer addition is associative.
+__device__ __forceinline__ unsigned long long to_fix(float v) {
+    const float x = v * kFixScale;
+    const float h = floorf(x * 2.3283064365386963e-10f);            // 2^-32
+    const float lo = fmaf(h, -4294967296.0f, x);
+    return ((unsigned long long)(uint32_t)(int)h << 32) | (unsigned long long)(uint32_t)lo;
+}
 
 __device__ __noinline__ void spill_flush(uint32_t* A, uint32_t nraw, uint32_t nin, float S0, float S1, float S2, float S3, float S4,
                                          float S5, float S6, float S7, float S8) {
@@ -569,14 +685,14 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
     }
     const PairDesc d = desc[pair];
     int cs = (d.n2 + chunks - 1) / chunks;
-    cs = (cs + 4 * kAccBlock - 1) / (4 * kAccBlock) * (4 * kAccBlock);            // whole trips of 4 points x 256 lanes
+    cs = (cs + kAccPts * kAccBlock - 1) / (kAccPts * kAccBlock) * (kAccPts * kAccBlock);   // whole trips of kAccPts points per lane
     const int begin = chunk * cs;
     if (begin >= d.n2) return;
     const int end = min(d.n2, begin + cs);
 
-    LutCell* lut_t = reinterpret_cast<LutCell*>(smem);                    // Mt cells
-    LutCell* lut_p = lut_t + Mt;                                          // Mp cells
-    unsigned long long* lsum = reinterpret_cast<unsigned long long*>(lut_p + Mp);   // 9 x lds_slots fixed-point sums (SoA)
+    LutCell* lut_t = reinterpret_cast<LutCell*>(smem);                    // Mt + 1 cells (the spare one catches pa == 4)
+    LutCell* lut_p = lut_t + (Mt + 1);                                    // Mp + 1 cells (w == 1)
+    unsigned long long* lsum = reinterpret_cast<unsigned long long*>(lut_p + (Mp + 1));   // 9 x lds_slots fixed-point sums (SoA)
     uint32_t* lraw = reinterpret_cast<uint32_t*>(lsum + 9 * lds_slots);   // lds_slots
     uint32_t* lin = lraw + lds_slots;                                     // lds_slots
     float* hot = reinterpret_cast<float*>(lin + lds_slots);               // lds_slots x 5: inner, outer, mu1
@@ -589,9 +705,10 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
         const uint32_t* gm = reinterpret_cast<const uint32_t*>(slot_of_voxel + (size_t)pair * ((V + 1) & ~1));   // rows padded to even length
         uint32_t* lm = reinterpret_cast<uint32_t*>(map);
         for (int i = threadIdx.x; i < map_words; i += kAccBlock) lm[i] = gm[i];
+        for (int i = 2 * map_words + threadIdx.x; i < V + T + 2; i += kAccBlock) map[i] = (int16_t)-1;   // bt == T or bp == P land here
         const uint2* gl = reinterpret_cast<const uint2*>(lut);
         uint2* ll = reinterpret_cast<uint2*>(lut_t);
-        for (int i = threadIdx.x; i < Mt + Mp; i += kAccBlock) ll[i] = gl[i];
+        for (int i = threadIdx.x; i < Mt + Mp + 2; i += kAccBlock) ll[i] = gl[i];
         for (int i = threadIdx.x; i < nl * 5; i += kAccBlock) { int s = i / 5, k = i - s * 5; hot[i] = reinterpret_cast<const float*>(hs + s)[4 + k]; }
         for (int i = threadIdx.x; i < 9 * lds_slots; i += kAccBlock) lsum[i] = 0ull;
         for (int i = threadIdx.x; i < 2 * lds_slots; i += kAccBlock) lraw[i] = 0u;
@@ -614,15 +731,42 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
             for (int j = 0; j < 4; j++) { const bool ok = i0 + j < end; X[j] = ok ? px[i0 + j] : 0.f; Y[j] = ok ? py[i0 + j] : 0.f; Z[j] = ok ? pz[i0 + j] : 0.f; }
         }
     };
-    for (int i0 = begin + 4 * threadIdx.x; i0 < begin + cs; i0 += 4 * kAccBlock) {      // whole waves iterate together
-        // no software prefetch: measured, it buys nothing here -- the kernel is VALU-issue-bound (PMC: ~150 VALU
-        // instructions per point, waves parked < 40 % of the time), not latency-bound
+    for (int t0 = begin + kAccPts * threadIdx.x; t0 < begin + cs; t0 += kAccPts * kAccBlock) {   // whole waves iterate together
+      // Run state of this lane for the whole trip: the current run, and a stash holding one finished run (see phase C).
+      int cur = -1; uint32_t nraw = 0, nin = 0;
+      float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f, S6 = 0.f, S7 = 0.f, S8 = 0.f;
+      int bs = -1; uint32_t braw = 0, bin = 0;
+      float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, B4 = 0.f, B5 = 0.f, B6 = 0.f, B7 = 0.f, B8 = 0.f;
+      auto flush = [&](int slot, uint32_t cr, uint32_t ci, float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {
+          if (slot >= 0) {
+              if (slot < nl) {
+                  atomicAdd(&lraw[slot], cr);
+                  if (ci) {
+                      atomicAdd(&lin[slot], ci);
+                      unsigned long long* F = lsum + slot;
+                      atomicAdd(&F[0], to_fix(a0)); atomicAdd(&F[lds_slots], to_fix(a1)); atomicAdd(&F[2 * lds_slots], to_fix(a2));
+                      atomicAdd(&F[3 * lds_slots], to_fix(a3)); atomicAdd(&F[4 * lds_slots], to_fix(a4)); atomicAdd(&F[5 * lds_slots], to_fix(a5));
+                      atomicAdd(&F[6 * lds_slots], to_fix(a6)); atomicAdd(&F[7 * lds_slots], to_fix(a7)); atomicAdd(&F[8 * lds_slots], to_fix(a8));
+                  }
+              } else {
+                  spill_flush(gacc + (size_t)slot * kAccWords, cr, ci, a0, a1, a2, a3, a4, a5, a6, a7, a8);
+              }
+          }
+      };
+      // the lane's kAccPts CONSECUTIVE points are taken 4 at a time (one dwordx4 per coordinate)
+      for (int g = 0; g < kAccPts / 4; g++) {
+        const int i0 = t0 + 4 * g;
+        // no software prefetch: measured, it buys nothing here -- the kernel is VALU-issue-bound (PMC: SQ_ACTIVE_INST_VALU
+        // ~ 90 % of the SIMD cycles), not latency-bound
         float X[4], Y[4], Z[4];
         load4(i0, X, Y, Z);
         PointClass pc[4];
-        float QX[4], QY[4], QZ[4];
+        float QX[4], QY[4], QZ[4], RR[4];
+        int SM[4];
         bool nr[4];
-        // ---- phase A: fast classification of the 4 points, straight-line so the four LDS look-up chains overlap ----
+        // ---- phase A: angular classification of the 4 points.  Straight-line code (bitwise | and &, no clamps: the
+        // LUTs carry one spare cell and the map T+1 spare entries, so even a NaN or pa == 4 indexes inside LDS) so
+        // that the four look-up chains overlap. ----
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const float a = X[j] + tx, b = Y[j] + ty, c = Z[j] + tz;
@@ -632,31 +776,38 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
             QX[j] = qx; QY[j] = qy; QZ[j] = qz;
             const float r2 = qx * qx + qy * qy + qz * qz;
             const float rs = __builtin_amdgcn_rsqf(r2);
+            RR[j] = r2 * rs;                                             // |q|
             const float w = -qz * rs;                                    // -cos(phi)
-            const float ax = fabsf(qx), ay = fabsf(qy);
-            const float q1 = qy * __builtin_amdgcn_rcpf(ax + ay);        // y / (|x| + |y|) in [-1, 1]
+            const float q1 = qy * __builtin_amdgcn_rcpf(fabsf(qx) + fabsf(qy));            // y / (|x| + |y|) in [-1, 1]
             const float pa = (qx >= 0.f) ? ((qy >= 0.f) ? q1 : 4.f + q1) : 2.f - q1;      // diamond angle in [0, 4]
-            int ct = static_cast<int>(pa * cell_t); ct = min(max(ct, 0), Mt - 1);
-            int cp = static_cast<int>((w + 1.f) * cell_p); cp = min(max(cp, 0), Mp - 1);
-            const LutCell et = lut_t[ct], ep = lut_p[cp];
-            const int bt = et.idx - ((pa < et.edge) ? 1 : 0);
-            const int bp = ep.idx - ((w < ep.edge) ? 1 : 0);
-            // bitwise | and &, clamped indices: no divergent branches on the common path
-            const int vox = min(max(T * bp + bt, 0), V - 1);
-            const int sm = map[vox];
-            const float* h = hot + min(max(sm, 0), lds_slots - 1) * 5;
-            const float inner = h[0], outer = h[1];
-            const float r = r2 * rs;
-            const float gr = 1e-6f * r;
-            const bool has = sm >= 0;
-            // slots beyond the LDS table (more active voxels than lds_slots) are classified by the literal path, which
-            // reads its record from HBM: keeps every LDS access a ds_* instruction.
-            const bool near = (force_exact != 0) | (i0 + j >= end) | !(fabsf(pa - et.edge) >= guard_t) | !(fabsf(w - ep.edge) >= guard_p)
-                              | (has & ((sm >= nl) | !(fabsf(r - inner) >= gr) | !(fabsf(r - outer) >= gr)));
-            nr[j] = near;
-            pc[j].s = near ? -1 : sm;
-            pc[j].inb = has & (r >= inner) & (r <= outer);
-            pc[j].dx = qx - h[2]; pc[j].dy = qy - h[3]; pc[j].dz = qz - h[4];
+            const LutCell et = lut_t[static_cast<int>(pa * cell_t)];     // NaN converts to 0; pa in [0,4] -> cell in [0, Mt]
+            const LutCell ep = lut_p[static_cast<int>((w + 1.f) * cell_p)];
+            const int bt = et.idx - ((pa < et.edge) ? 1 : 0);            // in [0, T]
+            const int bp = ep.idx - ((w < ep.edge) ? 1 : 0);             // in [0, P]
+            SM[j] = map[T * bp + bt];
+            nr[j] = (force_exact != 0) | (i0 + j >= end) | !(fabsf(pa - et.edge) >= guard_t) | !(fabsf(w - ep.edge) >= guard_p);
+        }
+        // ---- phase A2: only waves that touch an active voxel look at the hot records (radial test, d = q - mu1) ----
+        const bool lane_has = ((SM[0] >= 0) & !nr[0]) | ((SM[1] >= 0) & !nr[1]) | ((SM[2] >= 0) & !nr[2]) | ((SM[3] >= 0) & !nr[3]);
+        if (__ballot(lane_has) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int sm = SM[j];
+                const bool has = (sm >= 0) & !nr[j];
+                // slots beyond the LDS table (more active voxels than lds_slots) are classified by the literal path,
+                // which reads its record from HBM: keeps every LDS access a ds_* instruction.
+                const float* h = hot + min(max(sm, 0), lds_slots - 1) * 5;
+                const float inner = h[0], outer = h[1];
+                const float r = RR[j];
+                const float gr = 1e-6f * r;
+                nr[j] = nr[j] | (has & ((sm >= nl) | !(fabsf(r - inner) >= gr) | !(fabsf(r - outer) >= gr)));
+                pc[j].s = nr[j] ? -1 : sm;
+                pc[j].inb = has & (r >= inner) & (r <= outer);
+                pc[j].dx = QX[j] - h[2]; pc[j].dy = QY[j] - h[3]; pc[j].dz = QZ[j] - h[4];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { pc[j].s = -1; pc[j].inb = false; pc[j].dx = pc[j].dy = pc[j].dz = 0.f; }
         }
         // ---- phase B (rare): points within a guard band of a voxel edge are re-done with the literal formulas ----
         if (__ballot(nr[0] | nr[1] | nr[2] | nr[3]) != 0ull) {
@@ -665,33 +816,19 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
                 if (nr[j] & (i0 + j < end)) classify_exact(QX[j], QY[j], QZ[j], map, thr, T, P, hs, pc[j]);
         }
         const bool any_slot = (pc[0].s >= 0) | (pc[1].s >= 0) | (pc[2].s >= 0) | (pc[3].s >= 0);
-        if (__ballot(any_slot) == 0ull) continue;                         // wave-uniform: nothing lands in an active voxel
-        // ---- run-length accumulation over the lane's 4 consecutive points ----
-        int cur = -1; uint32_t nraw = 0, nin = 0;
-        float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f, S6 = 0.f, S7 = 0.f, S8 = 0.f;
-        auto flush = [&]() {
-            if (cur >= 0) {
-                if (cur < nl) {
-                    atomicAdd(&lraw[cur], nraw);
-                    if (nin) {
-                        atomicAdd(&lin[cur], nin);
-                        unsigned long long* F = lsum + cur;
-                        atomicAdd(&F[0], to_fix(S0)); atomicAdd(&F[lds_slots], to_fix(S1)); atomicAdd(&F[2 * lds_slots], to_fix(S2));
-                        atomicAdd(&F[3 * lds_slots], to_fix(S3)); atomicAdd(&F[4 * lds_slots], to_fix(S4)); atomicAdd(&F[5 * lds_slots], to_fix(S5));
-                        atomicAdd(&F[6 * lds_slots], to_fix(S6)); atomicAdd(&F[7 * lds_slots], to_fix(S7)); atomicAdd(&F[8 * lds_slots], to_fix(S8));
-                    }
-                } else {
-                    spill_flush(gacc + (size_t)cur * kAccWords, nraw, nin, S0, S1, S2, S3, S4, S5, S6, S7, S8);
-                }
-            }
-            nraw = 0; nin = 0; S0 = S1 = S2 = S3 = S4 = S5 = S6 = S7 = S8 = 0.f;
-        };
+        if (__ballot(any_slot | (cur >= 0)) == 0ull) continue;           // wave-uniform: nothing here lands in an active voxel and no run is open
+        // ---- phase C: run-length accumulation over the lane's consecutive points.  A finished run is parked in a
+        // register stash instead of being flushed at once, so a lane converts to fixed point and touches LDS about
+        // twice per trip of kAccPts points (a third run inside one trip, rare, flushes the stash early). ----
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int s = pc[j].s;
             if (s != cur) {
-                if (__ballot(cur >= 0) != 0ull) flush();
-                cur = s;
+                if (cur >= 0) {
+                    if (__ballot(bs >= 0) != 0ull) { flush(bs, braw, bin, B0, B1, B2, B3, B4, B5, B6, B7, B8); bs = -1; }
+                    bs = cur; braw = nraw; bin = nin; B0 = S0; B1 = S1; B2 = S2; B3 = S3; B4 = S4; B5 = S5; B6 = S6; B7 = S7; B8 = S8;
+                }
+                cur = s; nraw = 0; nin = 0; S0 = S1 = S2 = S3 = S4 = S5 = S6 = S7 = S8 = 0.f;
             }
             if (s >= 0) {
                 nraw++;
@@ -703,7 +840,11 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
                 }
             }
         }
-        flush();
+      }   // sub-groups of 4
+      if (__ballot((cur >= 0) | (bs >= 0)) != 0ull) {
+          flush(cur, nraw, nin, S0, S1, S2, S3, S4, S5, S6, S7, S8);
+          if (__ballot(bs >= 0) != 0ull) flush(bs, braw, bin, B0, B1, B2, B3, B4, B5, B6, B7, B8);
+      }
     }
     __syncthreads();
     for (int s = threadIdx.x; s < nl; s += kAccBlock) {
@@ -902,8 +1043,7 @@ inline int chunks_for(int n_pairs, int max_n, int per_block_min, int target_bloc
 hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* auxp, hipStream_t st) {
     AuxDev aux{}; if (auxp) aux = *auxp;
     // many small chunks per pair: with the XCD-aware mapping only ~4 pairs are then in flight per XCD (see decode_block)
-    int chunks = (c.max_n1 + kBlock * c.kf_pts_per_thread - 1) / (kBlock * c.kf_pts_per_thread);
-    if (chunks < 1) chunks = 1;
+    const int chunks = c.kf_chunks;
     const int groups = c.n_pairs >= 8 ? (c.n_pairs + 7) / 8 * 8 : c.n_pairs;
     dim3 grid(groups * chunks), blk(kBlock);
     const int np = c.n_pairs;
@@ -927,14 +1067,13 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     ICET_LAUNCH_CHECK();
     k_scramble_serial<<<c.n_pairs, 64, 0, st>>>(w.desc, w.valB, w.pred /* reused as scratch */, w.src, w.flags);
     ICET_LAUNCH_CHECK();
-    k_bin_positions<<<grid, blk, 0, st>>>(w.desc, w.src, w.bin16, w.keyA, w.valA, vbits, np, chunks);
+    k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, c.V, np, chunks);
     ICET_LAUNCH_CHECK();
-    e = sort_pairs_u32(w.sort_tmp, w.sort_tmp_bytes, w.keyA, w.keyB, w.valA, w.valB, c.total_n1, vbits + pbits, st);
-    if (e != hipSuccess) return e;
-    dim3 gb((c.V + 1 + kBlock - 1) / kBlock, c.n_pairs);
-    k_bin_bounds<<<gb, blk, 0, st>>>(w.seg_off, w.keyB, w.bin_start, c.V, vbits);
+    k_bin_scan<<<c.n_pairs, blk, 0, st>>>(w.counts, w.tile_base, w.bin_start, c.V, chunks);
     ICET_LAUNCH_CHECK();
-    k_gather_sorted<<<grid, blk, 0, st>>>(w.desc, w.valB, w.r1, w.th1, w.ph1, w.rs, w.ths, w.phs, np, chunks);
+    k_bin_scatter<<<grid, blk, (size_t)c.V * 16, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks);
+    ICET_LAUNCH_CHECK();
+    k_gather_sorted<<<grid, blk, 0, st>>>(w.desc, w.valA, w.r1, w.th1, w.ph1, w.rs, w.ths, w.phs, np, chunks);
     ICET_LAUNCH_CHECK();
     dim3 gfit((c.V + kBlock / 64 - 1) / (kBlock / 64), c.n_pairs);
     k_fit_scan1<<<gfit, blk, 0, st>>>(w.desc, w.bin_start, w.rs, w.ths, w.phs, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n, c.thresh, c.buff);
@@ -953,7 +1092,7 @@ hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float
 hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
     const int lds_slots = c.lds_slots;
     const int chunks = chunks_for(c.n_pairs, c.max_n2, kAccBlock * c.acc_min_pts_per_thread, c.acc_target_blocks);
-    const size_t lds = (size_t)(w.lut_Mt + w.lut_Mp) * sizeof(LutCell) + (size_t)lds_slots * (5 + kAccLds) * 4 + (size_t)((c.V + 1) / 2) * 4 + 16;
+    const size_t lds = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)lds_slots * (5 + kAccLds) * 4 + (size_t)((c.V + c.T + 4) / 2) * 4 + 16;
     const int groups = c.n_pairs >= 8 ? (c.n_pairs + 7) / 8 * 8 : c.n_pairs;
     dim3 grid(groups * chunks), blk(kAccBlock);
     const LutCell* lut = reinterpret_cast<const LutCell*>(w.lut);

@@ -58,6 +58,9 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # rehearsal hook: several ranks on ONE card (the 1-GPU dev box) -- never set by the driver
+    if os.environ.get("ICET_BENCH_SHARE_DEVICE"):
+        local_rank = int(os.environ["ICET_BENCH_SHARE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist

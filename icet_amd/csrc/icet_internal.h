@@ -41,6 +41,8 @@ struct SlotFit {
     int32_t v;
 };
 
+static_assert(sizeof(SlotHot) == 48 && sizeof(SlotFit) == 80, "k_fit_scan1 stages these records as 12 + 20 words");
+
 // Optional dense (per-voxel) dump for the reference's public side tables; device pointers or null.
 struct AuxDev {
     float* bounds; int32_t* n1_raw; int32_t* has_fit; float* mu1; float* sigma1; float* evecs1; float* l_diag;

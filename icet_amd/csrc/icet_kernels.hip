@@ -81,9 +81,8 @@ __device__ __forceinline__ void c2s_point(float x, float y, float z, float& r, f
 }
 
 __device__ __forceinline__ void s2c_point(float r, float th, float ph, float& x, float& y, float& z) {
-    // separate sinf / cosf on purpose: they are the functions the reference calls (src/utils.cpp:135-137); the fused
-    // sincosf differs from them in the last ulp often enough to flip a sigma-point test on the sample scans
-    const float sp = sinf(ph), cp = cosf(ph), st = sinf(th), ct = cosf(th);
+    float sp, cp, st, ct;
+    sincosf(ph, &sp, &cp); sincosf(th, &st, &ct);          // one range reduction per angle
     x = r * sp * ct; y = r * sp * st; z = r * cp;
 }
 
@@ -389,12 +388,21 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
     float Ld[3] = {0.f, 0.f, 0.f};
 
     if (cnt >= n) {
+        // The bin's first 4 x 64 rows are fetched up front with independent loads (most bins hold ~100-400 rows), so
+        // the serial walks below run on registers instead of paying one memory round trip per 64 rows.
+        constexpr int kCache = 4;
+        float pr[kCache], pth[kCache], pph[kCache];
+#pragma unroll
+        for (int k = 0; k < kCache; k++) {
+            const int i = lane + 64 * k;
+            const bool okk = i < cnt;
+            pr[k] = okk ? rs[base + i] : 0.f; pth[k] = okk ? ths[base + i] : 0.f; pph[k] = okk ? phs[base + i] : 0.f;
+        }
         // ---- findCluster (src/icet.cpp:557-607): first run of >= n consecutive points whose
         // successive |dr| <= thresh, walking the bin in stored (scrambled) order.
         int run_start = 0; float front = 0.f; float carry_prev = 0.f; bool found = false;
-        for (int c0 = 0; c0 < cnt && !found; c0 += 64) {
+        auto walk = [&](int c0, float r) {
             const int i = c0 + lane; const bool valid = i < cnt;
-            const float r = valid ? rs[base + i] : 0.f;
             float prev = __shfl_up(r, 1);
             if (lane == 0) prev = carry_prev;
             const bool brk = valid && (i == 0 || !(fabsf(prev - r) <= thresh));
@@ -409,14 +417,16 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
                 run_start = g; front = __shfl(r, b);
             }
             carry_prev = __shfl(r, 63);
-        }
+        };
+#pragma unroll
+        for (int k = 0; k < kCache; k++) if (64 * k < cnt && !found) walk(64 * k, pr[k]);
+        for (int c0 = 64 * kCache; c0 < cnt && !found; c0 += 64) walk(c0, (c0 + lane < cnt) ? rs[base + c0 + lane] : 0.f);
         if (!found && cnt - run_start >= n) {
             if (front != 0.f) { const float back = rs[base + cnt - 1]; inner = front - buff; outer = back + buff; }
             else { inner = 0.f; outer = 0.f; }
         }
         // ---- filterPointsInsideCluster + sphericalToCartesian + mean (src/icet.cpp:155-160).  The Cartesian
-        // coordinates of the first 4 x 64 points of the bin stay in registers for the second (centred) pass.
-        constexpr int kCache = 4;
+        // coordinates of the cached rows stay in registers for the second (centred) pass.
         float cx[kCache], cy[kCache], cz[kCache]; bool cin[kCache];
         // Sums in double: the reference's float sums run in Eigen's (unspecified, vectorised) order, so there is no
         // order to reproduce; the exactly rounded value is the one every order approximates, and it keeps the
@@ -426,12 +436,9 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
         for (int k = 0; k < kCache; k++) {
             const int i = lane + 64 * k;
             cin[k] = false; cx[k] = cy[k] = cz[k] = 0.f;
-            if (i < cnt) {
-                const float r = rs[base + i], th = ths[base + i], ph = phs[base + i];
-                if (inside_bounds(r, th, ph, az0, az1, el0, el1, inner, outer)) {
-                    s2c_point(r, th, ph, cx[k], cy[k], cz[k]); cin[k] = true;
-                    sx += (double)cx[k]; sy += (double)cy[k]; sz += (double)cz[k]; rows++;
-                }
+            if (i < cnt && inside_bounds(pr[k], pth[k], pph[k], az0, az1, el0, el1, inner, outer)) {
+                s2c_point(pr[k], pth[k], pph[k], cx[k], cy[k], cz[k]); cin[k] = true;
+                sx += (double)cx[k]; sy += (double)cy[k]; sz += (double)cz[k]; rows++;
             }
         }
         for (int i = lane + 64 * kCache; i < cnt; i += 64) {
@@ -466,43 +473,55 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
             const float den = (float)(rows - 1);
 #pragma unroll
             for (int k = 0; k < 6; k++) cov[k] = (float)wave_sum_d(c[k]) / den;
-            // ---- eigen-decomposition, sigma points, L (src/icet.cpp:181-232); every lane runs the same
-            // scalar code on the same values, lane 0 publishes.
+            // ---- eigen-decomposition (every lane runs the same scalar code on the same values), then the six
+            // sigma points mu +- 2 sqrt(lambda_k) * (row k of V) on lanes 0..5 in parallel (src/icet.cpp:181-232)
             icetdev::eig3_sym(cov[0], cov[1], cov[3], cov[2], cov[4], cov[5], ev, Vm);
-            bool ins[6] = {false, false, false, false, false, false};
-            bool stop = false;
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                const int k = j >> 1;
-                const float al = 2.0f * sqrtf(ev[k]);
-                const float sgn = (j & 1) ? -1.f : 1.f;
+            bool in_j = false, beyond_j = false;
+            if (lane < 6) {
+                const int k = lane >> 1;
+                const float lam = (k == 0) ? ev[0] : ((k == 1) ? ev[1] : ev[2]);
+                const float v0 = (k == 0) ? Vm[0] : ((k == 1) ? Vm[3] : Vm[6]);
+                const float v1 = (k == 0) ? Vm[1] : ((k == 1) ? Vm[4] : Vm[7]);
+                const float v2 = (k == 0) ? Vm[2] : ((k == 1) ? Vm[5] : Vm[8]);
+                const float al = 2.0f * sqrtf(lam);
+                const float sgn = (lane & 1) ? -1.f : 1.f;
                 // rotated = diag(2 sqrt(lambda)) * U^T = diag(.) * V : ROW k of V (src/icet.cpp:193-202)
-                const float px = mean[0] + sgn * (al * Vm[3 * k + 0]);
-                const float py = mean[1] + sgn * (al * Vm[3 * k + 1]);
-                const float pz = mean[2] + sgn * (al * Vm[3 * k + 2]);
+                const float px = mean[0] + sgn * (al * v0), py = mean[1] + sgn * (al * v1), pz = mean[2] + sgn * (al * v2);
                 float r, az, el; c2s_point(px, py, pz, r, az, el);
-                if (!stop) {
-                    if (inside_bounds(r, az, el, az0, az1, el0, el1, inner, outer)) ins[j] = true;
-                    if (r > outer) stop = true;        // testSigmaPoints' early break (src/icet.cpp:683-685)
-                }
+                in_j = inside_bounds(r, az, el, az0, az1, el0, el1, inner, outer);
+                beyond_j = r > outer;
             }
-            Ld[0] = (ins[0] || ins[1]) ? 1.f : 0.f; Ld[1] = (ins[2] || ins[3]) ? 1.f : 0.f; Ld[2] = (ins[4] || ins[5]) ? 1.f : 0.f;
+            // testSigmaPoints walks j = 0..5 and leaves the loop AFTER testing the first point with r > outer
+            // (src/icet.cpp:669-686): points behind that one are never tested
+            const unsigned long long beyond = __ballot(beyond_j) & 0x3Full;
+            const int jb = beyond ? (__ffsll((long long)beyond) - 1) : 5;
+            const unsigned long long ins = __ballot(in_j) & ((2ull << jb) - 1ull);
+            Ld[0] = (ins & 0x03ull) ? 1.f : 0.f; Ld[1] = (ins & 0x0Cull) ? 1.f : 0.f; Ld[2] = (ins & 0x30ull) ? 1.f : 0.f;
             active = (cnt > n && outer > 1.f) ? 1 : 0;  // scan-1 half of the gate at src/icet.cpp:290
         }
     }
+    // Records are only needed for ACTIVE voxels (k_compact_slots copies nothing else); they are staged through LDS so
+    // that 32 lanes store them with two coalesced instructions instead of one lane issuing 32 scalar stores.
+    __shared__ float stage[kBlock / 64][32];
+    const size_t o = (size_t)pair * V + v;
+    if (active) {
+        if (lane == 0) {
+            float* g = stage[wave];
+            g[0] = az0; g[1] = az1; g[2] = el0; g[3] = el1; g[4] = inner; g[5] = outer;
+            g[6] = mean[0]; g[7] = mean[1]; g[8] = mean[2]; g[9] = __int_as_float(v); g[10] = 0.f; g[11] = 0.f;      // SlotHot
+            g[12] = mean[0]; g[13] = mean[1]; g[14] = mean[2];                                                            // SlotFit
+            const float d1 = (float)(cnt - 1);
+#pragma unroll
+            for (int k = 0; k < 6; k++) g[15 + k] = cov[k] / d1;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { g[21 + 3 * k] = Ld[k] * Vm[3 * k]; g[22 + 3 * k] = Ld[k] * Vm[3 * k + 1]; g[23 + 3 * k] = Ld[k] * Vm[3 * k + 2]; }
+            g[30] = __int_as_float(cnt); g[31] = __int_as_float(v);
+        }
+        // same wave wrote and reads: LDS operations of one wave complete in order
+        if (lane < 12) reinterpret_cast<float*>(hotD + o)[lane] = stage[wave][lane];
+        else if (lane < 32) reinterpret_cast<float*>(fitD + o)[lane - 12] = stage[wave][lane];
+    }
     if (lane == 0) {
-        const size_t o = (size_t)pair * V + v;
-        SlotHot h; h.az0 = az0; h.az1 = az1; h.el0 = el0; h.el1 = el1; h.inner = inner; h.outer = outer;
-        h.mu[0] = mean[0]; h.mu[1] = mean[1]; h.mu[2] = mean[2]; h.v = v; h.pad[0] = 0; h.pad[1] = 0;
-        hotD[o] = h;
-        SlotFit f; f.mu[0] = mean[0]; f.mu[1] = mean[1]; f.mu[2] = mean[2];
-        const float d1 = (float)(cnt - 1);
-#pragma unroll
-        for (int k = 0; k < 6; k++) f.s1n[k] = active ? cov[k] / d1 : 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { f.M[3 * k] = Ld[k] * Vm[3 * k]; f.M[3 * k + 1] = Ld[k] * Vm[3 * k + 1]; f.M[3 * k + 2] = Ld[k] * Vm[3 * k + 2]; }
-        f.n1 = cnt; f.v = v;
-        fitD[o] = f;
         activeD[o] = active;
         if (aux.bounds) { float* b = aux.bounds + o * 6; b[0] = az0; b[1] = az1; b[2] = el0; b[3] = el1; b[4] = inner; b[5] = outer; }
         if (aux.n1_raw) aux.n1_raw[o] = cnt;

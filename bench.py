@@ -64,9 +64,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    backend = os.environ.get("ICET_BENCH_BACKEND", "nccl")      # "gloo" only for rehearsing N ranks on one card
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import icet_amd
     from icet_amd import lidar_sim, api
@@ -126,7 +130,10 @@ def main():
         with torch.cuda.stream(stream):
             ctx.solve_batch_device(d1, d2, params, out.data_ptr())
             if world > 1:
-                return gather_results(out, n_global, rank, world)
+                if backend == "nccl":
+                    return gather_results(out, n_global, rank, world)
+                ctx.sync()
+                return gather_results(out.cpu(), n_global, rank, world).to(dev)
         return out
 
     def fence():
@@ -144,7 +151,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / max(args.steps, 1) * 1e3

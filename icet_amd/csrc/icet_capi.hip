@@ -85,6 +85,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, dev_realloc(w.xf, (size_t)np * 16));
         HIPCHK(c, dev_realloc(w.X, (size_t)np * 6));
         HIPCHK(c, dev_realloc(w.flags, np));
+        HIPCHK(c, dev_realloc(w.splitters, (size_t)np * 128)); HIPCHK(c, dev_realloc(w.n_buckets, np)); HIPCHK(c, dev_realloc(w.bucket_start, (size_t)np * 129));
         if (c->h_desc) { HIPCHK(c, hipHostFree(c->h_desc)); c->h_desc = nullptr; }
         if (c->h_seg) { HIPCHK(c, hipHostFree(c->h_seg)); c->h_seg = nullptr; }
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_desc), sizeof(PairDesc) * np));
@@ -97,7 +98,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (n > w.cap_n1) {
             HIPCHK(c, dev_realloc(w.r1, n)); HIPCHK(c, dev_realloc(w.th1, n)); HIPCHK(c, dev_realloc(w.ph1, n));
-            HIPCHK(c, dev_realloc(w.key64A, n)); HIPCHK(c, dev_realloc(w.key64B, n)); HIPCHK(c, dev_realloc(w.bin16, n)); HIPCHK(c, dev_realloc(w.binpos, n));
+            HIPCHK(c, dev_realloc(w.key64A, n)); HIPCHK(c, dev_realloc(w.key64B, n)); HIPCHK(c, dev_realloc(w.bin16, n)); HIPCHK(c, dev_realloc(w.binpos, n)); HIPCHK(c, dev_realloc(w.bkt, n));
             HIPCHK(c, dev_realloc(w.keyA, n)); HIPCHK(c, dev_realloc(w.keyB, n)); HIPCHK(c, dev_realloc(w.valA, n)); HIPCHK(c, dev_realloc(w.valB, n));
             HIPCHK(c, dev_realloc(w.pred, n)); HIPCHK(c, dev_realloc(w.src, n)); HIPCHK(c, dev_realloc(w.exec, n));
             HIPCHK(c, dev_realloc(w.rs, n)); HIPCHK(c, dev_realloc(w.ths, n)); HIPCHK(c, dev_realloc(w.phs, n));
@@ -222,6 +223,7 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     if (const char* e = getenv("ICET_ACC_PTS")) cfg.acc_min_pts_per_thread = atoi(e);
     if (const char* e = getenv("ICET_ACC_BLOCKS")) cfg.acc_target_blocks = atoi(e);
     if (const char* e = getenv("ICET_FORCE_EXACT")) cfg.force_exact = atoi(e);
+    if (const char* e = getenv("ICET_LIBRARY_SORT")) cfg.use_library_sort = atoi(e);
     if (const char* e = getenv("ICET_KF_PTS")) cfg.kf_pts_per_thread = atoi(e);
     if (cfg.kf_pts_per_thread > 8) cfg.kf_pts_per_thread = 8;      // k_bin_scatter: a tile is at most 4 waves x 8 rounds x 64 positions
     if (cfg.kf_pts_per_thread < 1) cfg.kf_pts_per_thread = 1;
@@ -240,7 +242,7 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     cfg.kf_chunks = (mx1 + 256 * cfg.kf_pts_per_thread - 1) / (256 * cfg.kf_pts_per_thread);
     if (cfg.kf_chunks < 1) cfg.kf_chunks = 1;
     {
-        const size_t need = (size_t)n_pairs * cfg.kf_chunks * cfg.V;
+        const size_t need = (size_t)n_pairs * cfg.kf_chunks * (cfg.V > 128 ? cfg.V : 128);
         if (need > w.cap_counts) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             HIPCHK(c, dev_realloc(w.counts, need)); HIPCHK(c, dev_realloc(w.tile_base, need));
@@ -306,7 +308,7 @@ icet_status icet_destroy(icet_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     Workspace& w = c->w;
-    void* ps[] = {w.key64A, w.key64B, w.bin16, w.binpos, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.th1, w.ph1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src, w.exec, w.rs, w.ths, w.phs,
+    void* ps[] = {w.key64A, w.key64B, w.bin16, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.th1, w.ph1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src, w.exec, w.rs, w.ths, w.phs,
                   w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, w.xf, w.X, w.flags,
                   w.sort_tmp, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);

@@ -57,6 +57,8 @@ struct Workspace {
     float *r1 = nullptr, *th1 = nullptr, *ph1 = nullptr;            // spherical scan 1, input order
     unsigned long long *key64A = nullptr, *key64B = nullptr;         // (pair << 32 | r bits)
     uint32_t *keyA = nullptr, *keyB = nullptr, *valA = nullptr, *valB = nullptr;
+    uint32_t* splitters = nullptr; int32_t* n_buckets = nullptr; int32_t* bucket_start = nullptr;   // rank sort: pairs x 128, pairs, pairs x 129
+    uint8_t* bkt = nullptr;                                          // rank sort: bucket id of every scan-1 row
     uint16_t* binpos = nullptr;                                      // angular bin of the row at every position after the scramble
     uint32_t* counts = nullptr; uint32_t* tile_base = nullptr; size_t cap_counts = 0;               // pairs x tiles x V histogram / tile base offsets
     uint16_t* bin16 = nullptr;                                       // angular bin of every scan-1 row (input order)
@@ -87,6 +89,7 @@ struct LaunchCfg {
     int acc_target_blocks = 2048;
     int kf_chunks = 1;                // tiles per pair in the keyframe kernels (set by the host from max_n1)
     int kf_pts_per_thread = 8;        // keyframe kernels: points per thread (sets chunks per pair)
+    int use_library_sort = 0;         // diagnostic: rocPRIM device radix sort instead of the hand-written rank sort
     int vec4_ok = 0;                  // every scan-2 pointer and leading dimension is 16-byte aligned
     int force_exact = 0;              // diagnostic: route every point through the literal evaluation
 };
@@ -96,6 +99,10 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
 hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st);
 hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st);
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st);
+
+// ranksort.hip
+hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t st);
+hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st);
 
 // sort.hip
 size_t sort_temp_bytes(int64_t total_n);

@@ -135,8 +135,8 @@ __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __re
         // r >= +0 (or 1000 for NaN): the bit pattern orders like the float; the pair id in the high word keeps
         // every pair's points contiguous, so one device-wide sort handles the whole batch
         if (key64) key64[o] = ((unsigned long long)pair << 32) | (unsigned long long)__float_as_uint(r);
-        else key32[o] = __float_as_uint(r);
-        val[o] = (uint32_t)i;
+        else if (key32) key32[o] = __float_as_uint(r);
+        if (key64 || key32) val[o] = (uint32_t)i;               // library-sort path only
         bin16[o] = (uint16_t)voxel_of(th, ph, T, P);
     }
 }
@@ -1070,14 +1070,19 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     int pbits = 0; while ((1 << pbits) < c.n_pairs) pbits++;
     int vbits = 1; while ((1 << vbits) < c.V) vbits++;
     const bool batch = c.n_pairs > 1;
-    k_scan1_spherical<<<grid, blk, 0, st>>>(w.desc, w.r1, w.th1, w.ph1, batch ? w.key64A : nullptr, w.keyA, w.valA, w.bin16, c.T, c.P, np, chunks);
+    k_scan1_spherical<<<grid, blk, 0, st>>>(w.desc, w.r1, w.th1, w.ph1, (batch && c.use_library_sort) ? w.key64A : nullptr, c.use_library_sort ? w.keyA : nullptr, w.valA, w.bin16, c.T, c.P, np, chunks);
     ICET_LAUNCH_CHECK();
-    if (batch) e = sort_pairs_u64(w.sort_tmp, w.sort_tmp_bytes, w.key64A, w.key64B, w.valA, w.valB, c.total_n1, 32 + pbits, st);
-    else e = sort_pairs_u32(w.sort_tmp, w.sort_tmp_bytes, w.keyA, w.keyB, w.valA, w.valB, c.total_n1, 32, st);
-    if (e != hipSuccess) return e;
-    // valB = s : original index of the row with rank i
-    k_inverse_perm<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, np, chunks);
-    ICET_LAUNCH_CHECK();
+    if (c.use_library_sort) {
+        if (batch) e = sort_pairs_u64(w.sort_tmp, w.sort_tmp_bytes, w.key64A, w.key64B, w.valA, w.valB, c.total_n1, 32 + pbits, st);
+        else e = sort_pairs_u32(w.sort_tmp, w.sort_tmp_bytes, w.keyA, w.keyB, w.valA, w.valB, c.total_n1, 32, st);
+        if (e != hipSuccess) return e;
+        // valB = s : original index of the row with rank i
+        k_inverse_perm<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, np, chunks);
+        ICET_LAUNCH_CHECK();
+    } else {
+        e = launch_rank_sort(w, c, st);        // valB = s, pred = s^-1  (icet_ranksort.hip)
+        if (e != hipSuccess) return e;
+    }
     e = hipMemsetAsync(w.flags, 0, sizeof(int32_t) * c.n_pairs, st); if (e != hipSuccess) return e;
     const int max_walk = 4096;
     k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.exec, w.flags, max_walk, np, chunks);
@@ -1098,6 +1103,12 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     k_fit_scan1<<<gfit, blk, 0, st>>>(w.desc, w.bin_start, w.rs, w.ths, w.phs, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n, c.thresh, c.buff);
     ICET_LAUNCH_CHECK();
     k_compact_slots<<<c.n_pairs, blk, 0, st>>>(w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, c.V);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st) {
+    k_bin_scan<<<n_pairs, kBlock, 0, st>>>(counts, tile_base, class_start, n_classes, chunks);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -1,0 +1,300 @@
+// icet_amd/csrc/icet_ranksort.hip -- hand-written stable rank sort of scan 1 by radial distance, per pair.
+//
+// The reference sorts an index vector by r with std::sort(std::execution::par) (/root/reference/src/icet.cpp:72-77)
+// and then walks it with its one-step swap loop (:78-83).  What the device needs from the sort is s[] (the row with
+// rank i) and pred[] = s^-1 (the rank of every row), with ties broken by original index (the oracle's rule).
+//
+// A device-wide library radix sort has to carry the pair id in the key (40 significant bits -> 5 digit passes over
+// 12 bytes per element, ~1.4 ms per 256 pairs) and still needs a separate inverse-permutation pass.  Per pair the
+// data is small (116 k keys), so this file does a sample sort instead:
+//   k_rs_splitters   one block per pair: sort ~2 k sampled keys in LDS (bitonic), publish <= 127 splitters
+//   k_rs_hist        per tile: bucket id of every row (branch-free binary search of the splitters), tile histogram
+//   [k_bin_scan]     (shared with the voxel multi-split) exclusive scan over (bucket, tile)
+//   k_rs_scatter     stable multi-split of the rows into their buckets (match-any ranking, as k_bin_scatter)
+//   k_rs_bucket_sort one block per (pair, bucket): LSD radix sort of the bucket's <= 2560 (key, row) pairs entirely in
+//                    LDS (4 stable 8-bit passes, passes whose digit is constant are skipped), then s[] and pred[] are
+//                    written -- no inverse-permutation kernel.  A bucket that does not fit LDS runs the same code on
+//                    global scratch; a bucket of identical keys (the zero rows of a real scan: thousands of exact
+//                    r = 0) is already in order because the multi-split is stable.
+// Equal keys always fall into one bucket (bucket = number of splitters strictly below the key), a repeated key that
+// reaches the sample becomes a bucket of its own, and every stage is stable, so ties end up ordered by row index.
+// Traffic ~30 B per row instead of ~130 B.
+#include <hip/hip_runtime.h>
+#include "icet_internal.h"
+
+namespace icet {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kSamples = 2048;       // sampled keys per pair (power of two, sorted by 1024 threads)
+constexpr int kMaxBuckets = 128;     // power of two
+constexpr int kBucketBits = 7;
+constexpr int kBucketTarget = 1024;  // aimed-for rows per bucket
+constexpr int kCap = 2560;           // rows a bucket may have and still be sorted in LDS (45 KB per block -> 3 blocks per CU)
+constexpr int kSortBlock = 256;
+constexpr int kSortWaves = kSortBlock / 64;
+
+__device__ __forceinline__ bool decode_block(int n_pairs, int chunks, int& pair, int& chunk) {
+    if (n_pairs >= 8) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        pair = (j / chunks) * 8 + xcd; chunk = j % chunks;
+        return pair < n_pairs;
+    }
+    pair = blockIdx.x / chunks; chunk = blockIdx.x % chunks;
+    return true;
+}
+
+// ---- splitters -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_rs_splitters(const PairDesc* __restrict__ desc, const float* __restrict__ r1,
+                                                       uint32_t* __restrict__ splitters, int32_t* __restrict__ n_buckets) {
+    __shared__ uint32_t sm[kSamples];
+    const int pair = blockIdx.x;
+    const PairDesc d = desc[pair];
+    const int n = d.n1;
+    const int stride = max(1, (n + kSamples - 1) / kSamples);
+    const int ns = n > 0 ? (n + stride - 1) / stride : 0;
+    for (int j = threadIdx.x; j < kSamples; j += 1024)
+        sm[j] = (j < ns) ? __float_as_uint(r1[(size_t)d.off1 + (size_t)j * stride]) : 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= kSamples; k <<= 1) {                   // bitonic sort, ascending
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < kSamples; t += 1024) {
+                const int p = t ^ j;
+                if (p > t) {
+                    const uint32_t a = sm[t], b = sm[p];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) { sm[t] = b; sm[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int nb = (n + kBucketTarget - 1) / kBucketTarget;
+    nb = min(max(nb, 1), kMaxBuckets);
+    if (n == 0) nb = 0;
+    if (threadIdx.x == 0) n_buckets[pair] = nb;
+    // splitters[j], j = 1..nb-1 ; slot 0 unused ; unused slots = +max so that the search never counts them
+    for (int j = threadIdx.x; j < kMaxBuckets; j += 1024)
+        splitters[(size_t)pair * kMaxBuckets + j] = (j >= 1 && j < nb) ? sm[(int)(((long long)j * ns) / nb)] : 0xFFFFFFFFu;
+}
+
+// bucket(key) = number of splitters strictly below key  (splitters sorted ascending in sp[1..63], sp[0] ignored)
+__device__ __forceinline__ int bucket_of(uint32_t key, const uint32_t* sp) {
+    int lo = 0;                                                  // count over sp[1 .. kMaxBuckets-1]
+#pragma unroll
+    for (int step = kMaxBuckets / 2; step > 0; step >>= 1) lo += (sp[lo + step] < key) ? step : 0;
+    return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void k_rs_hist(const PairDesc* __restrict__ desc, const float* __restrict__ r1, const uint32_t* __restrict__ splitters,
+                                                    uint8_t* __restrict__ bkt, uint32_t* __restrict__ counts, int n_pairs, int chunks) {
+    __shared__ uint32_t sp[kMaxBuckets];
+    __shared__ uint32_t lh[kMaxBuckets];
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const PairDesc d = desc[pair];
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
+    for (int j = threadIdx.x; j < kMaxBuckets; j += kBlock) { sp[j] = splitters[(size_t)pair * kMaxBuckets + j]; lh[j] = 0u; }
+    __syncthreads();
+    const size_t o = d.off1;
+    for (int v = lo_ + threadIdx.x; v < hi_; v += kBlock) {
+        const int b = bucket_of(__float_as_uint(r1[o + v]), sp);
+        bkt[o + v] = (uint8_t)b;
+        atomicAdd(&lh[b], 1u);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < kMaxBuckets; j += kBlock) counts[((size_t)pair * chunks + chunk) * kMaxBuckets + j] = lh[j];
+}
+
+// Stable multi-split of the rows of one tile into their buckets; wave w owns the w-th quarter of the tile.
+constexpr int kScatterRounds = 8;
+__global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restrict__ desc, const float* __restrict__ r1, const uint8_t* __restrict__ bkt,
+                                                       const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bucket_start,
+                                                       uint32_t* __restrict__ bkey, uint32_t* __restrict__ bidx, int n_pairs, int chunks) {
+    __shared__ uint32_t lb[4 * kMaxBuckets];
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const PairDesc d = desc[pair];
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
+    if (lo_ >= hi_) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qs = cs_ / 4;
+    const int wlo = lo_ + wave * qs, whi = min(hi_, wlo + qs);
+    const int rounds = qs / 64;
+    for (int j = threadIdx.x; j < 4 * kMaxBuckets; j += kBlock) lb[j] = 0u;
+    __syncthreads();
+    const size_t o = d.off1;
+    uint32_t bb[kScatterRounds], key[kScatterRounds]; bool ok[kScatterRounds];
+    uint32_t* mine = lb + wave * kMaxBuckets;
+#pragma unroll
+    for (int k = 0; k < kScatterRounds; k++) {
+        const int v = wlo + 64 * k + lane;
+        ok[k] = (k < rounds) & (v < whi);
+        bb[k] = ok[k] ? (uint32_t)bkt[o + v] : 0u;
+        key[k] = ok[k] ? __float_as_uint(r1[o + v]) : 0u;
+        if (ok[k]) atomicAdd(&mine[bb[k]], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < kMaxBuckets; b += kBlock) {
+        const uint32_t c0 = lb[b], c1 = lb[kMaxBuckets + b], c2 = lb[2 * kMaxBuckets + b];
+        const uint32_t base = (uint32_t)bucket_start[(size_t)pair * (kMaxBuckets + 1) + b] + tile_base[((size_t)pair * chunks + chunk) * kMaxBuckets + b];
+        lb[b] = base; lb[kMaxBuckets + b] = base + c0; lb[2 * kMaxBuckets + b] = base + c0 + c1; lb[3 * kMaxBuckets + b] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < kScatterRounds; k++) {
+        unsigned long long peers = __ballot(ok[k]);
+#pragma unroll
+        for (int q = 0; q < kBucketBits; q++) {
+            const bool bit = (bb[k] >> q) & 1u;
+            const unsigned long long m = __ballot(ok[k] && bit);
+            peers &= bit ? m : ~m;
+        }
+        if (ok[k]) {
+            const int rank = __popcll(peers & lt);
+            const uint32_t dest = mine[bb[k]] + (uint32_t)rank;
+            if (rank == 0) mine[bb[k]] += (uint32_t)__popcll(peers);
+            bkey[o + dest] = key[k];
+            bidx[o + dest] = (uint32_t)(wlo + 64 * k + lane);
+        }
+    }
+}
+
+// ---- per-bucket LSD radix sort (stable), in LDS or -- same code, generic pointers -- in global scratch ----------------
+__device__ void radix_pass(const uint32_t* inK, const uint32_t* inI, uint32_t* outK, uint32_t* outI, int n, int shift,
+                           uint32_t* cnt /* kSortWaves x 256 */, uint32_t* tot /* 256 */, int* wsum /* 4 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int seg = (n + kSortWaves - 1) / kSortWaves; seg = (seg + 63) / 64 * 64;
+    const int wlo = wave * seg, whi = min(n, wlo + seg);
+    uint32_t* mine = cnt + wave * 256;
+    for (int i = lane; i < 256; i += 64) mine[i] = 0u;
+    // (same wave zeroes and then adds: LDS operations of one wave complete in order)
+    for (int i = wlo + lane; i < whi; i += 64) atomicAdd(&mine[(inK[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    if (threadIdx.x < 256) {                                    // per digit: exclusive prefix over the waves, digit total
+        const int dgt = threadIdx.x;
+        uint32_t t = 0;
+        for (int w = 0; w < kSortWaves; w++) { const uint32_t c = cnt[w * 256 + dgt]; cnt[w * 256 + dgt] = t; t += c; }
+        // exclusive scan of the 256 totals across the first four waves
+        int incl = (int)t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        if (lane == 63) wsum[wave] = incl;
+        tot[dgt] = (uint32_t)(incl - (int)t);                   // exclusive within the wave
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        int woff = 0;
+        for (int k = 0; k < (threadIdx.x >> 6); k++) woff += wsum[k];
+        tot[threadIdx.x] += (uint32_t)woff;
+    }
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) mine[i] += tot[i];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int i0 = wlo; i0 < whi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool ok = i < whi;
+        const uint32_t k = ok ? inK[i] : 0u, id = ok ? inI[i] : 0u;
+        const uint32_t dgt = (k >> shift) & 255u;
+        unsigned long long peers = __ballot(ok);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const bool bit = (dgt >> q) & 1u;
+            const unsigned long long m = __ballot(ok && bit);
+            peers &= bit ? m : ~m;
+        }
+        if (ok) {
+            const int rank = __popcll(peers & lt);
+            const uint32_t dest = mine[dgt] + (uint32_t)rank;
+            if (rank == 0) mine[dgt] += (uint32_t)__popcll(peers);
+            outK[dest] = k; outI[dest] = id;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bucket_start,
+                                                               const int32_t* __restrict__ n_buckets, uint32_t* __restrict__ bkey, uint32_t* __restrict__ bidx,
+                                                               uint32_t* __restrict__ altkey, uint32_t* __restrict__ altidx,
+                                                               uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out) {
+    extern __shared__ uint32_t smem[];
+    const int pair = blockIdx.y, bucket = blockIdx.x;
+    if (bucket >= n_buckets[pair]) return;
+    const int lo = bucket_start[(size_t)pair * (kMaxBuckets + 1) + bucket];
+    const int n = bucket_start[(size_t)pair * (kMaxBuckets + 1) + bucket + 1] - lo;
+    if (n <= 0) return;
+    const size_t o = (size_t)desc[pair].off1 + lo;
+    uint32_t* cnt = smem;                                       // kSortWaves * 256
+    uint32_t* tot = cnt + kSortWaves * 256;                     // 256
+    int* wsum = reinterpret_cast<int*>(tot + 256);              // 4
+    uint32_t* red = tot + 256 + 4;                              // 2 * kSortWaves : block min / max of the keys
+    uint32_t* lA = red + 2 * kSortWaves;                        // kCap keys | kCap idx | kCap keys | kCap idx
+    const bool in_lds = n <= kCap;
+    uint32_t *K0, *I0, *K1, *I1;
+    if (in_lds) {
+        K0 = lA; I0 = lA + kCap; K1 = lA + 2 * kCap; I1 = lA + 3 * kCap;
+        for (int i = threadIdx.x; i < n; i += kSortBlock) { K0[i] = bkey[o + i]; I0[i] = bidx[o + i]; }
+    } else {
+        K0 = bkey + o; I0 = bidx + o; K1 = altkey + o; I1 = altidx + o;
+    }
+    __syncthreads();
+    // OR / AND of all keys: a digit position where every key agrees needs no pass (in particular a bucket of
+    // identical keys -- the zero rows of a real scan -- needs none at all)
+    uint32_t vor = 0u, vand = 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < n; i += kSortBlock) { const uint32_t k = K0[i]; vor |= k; vand &= k; }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) { vor |= __shfl_xor(vor, sft); vand &= __shfl_xor(vand, sft); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = vor; red[kSortWaves + (threadIdx.x >> 6)] = vand; }
+    __syncthreads();
+    vor = 0u; vand = 0xFFFFFFFFu;
+    for (int w = 0; w < kSortWaves; w++) { vor |= red[w]; vand &= red[kSortWaves + w]; }
+    const uint32_t differ = vor & ~vand;                        // bit set where the keys do not all agree
+    __syncthreads();
+    for (int pass = 0; pass < 4; pass++) {
+        if (((differ >> (8 * pass)) & 255u) == 0u) continue;    // block-uniform
+        radix_pass(K0, I0, K1, I1, n, 8 * pass, cnt, tot, wsum);
+        uint32_t* t; t = K0; K0 = K1; K1 = t; t = I0; I0 = I1; I1 = t;
+    }
+    for (int i = threadIdx.x; i < n; i += kSortBlock) {
+        const uint32_t row = I0[i];
+        s_out[o + i] = row;
+        pred_out[(o - lo) + row] = lo + i;
+    }
+}
+
+}  // namespace
+
+#define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+size_t rank_sort_lds_bytes() { return (size_t)(kSortWaves * 256 + 256 + 4 + 2 * kSortWaves + 4 * kCap) * 4; }
+
+// Outputs: w.valB = s (row with rank i), w.pred = rank of every row.  Scratch: w.keyA / w.valA (bucket-grouped keys and
+// rows), w.keyB / w.key64A (overflow buckets), w.bkt, w.counts / w.tile_base, w.splitters, w.n_buckets, w.bucket_start.
+hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
+    const int chunks = c.kf_chunks, np = c.n_pairs;
+    const int groups = np >= 8 ? (np + 7) / 8 * 8 : np;
+    dim3 grid(groups * chunks), blk(kBlock);
+    k_rs_splitters<<<np, 1024, 0, st>>>(w.desc, w.r1, w.splitters, w.n_buckets);
+    ICET_LAUNCH_CHECK();
+    k_rs_hist<<<grid, blk, 0, st>>>(w.desc, w.r1, w.splitters, w.bkt, w.counts, np, chunks);
+    ICET_LAUNCH_CHECK();
+    hipError_t e = launch_class_scan(w.counts, w.tile_base, w.bucket_start, kMaxBuckets, chunks, np, st);
+    if (e != hipSuccess) return e;
+    k_rs_scatter<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, w.keyA, w.valA, np, chunks);
+    ICET_LAUNCH_CHECK();
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_bucket_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_sort_lds_bytes());
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    k_rs_bucket_sort<<<dim3(kMaxBuckets, np), kSortBlock, rank_sort_lds_bytes(), st>>>(w.desc, w.bucket_start, w.n_buckets, w.keyA, w.valA, w.keyB,
+                                                                                     reinterpret_cast<uint32_t*>(w.key64A), w.valB, w.pred);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace icet

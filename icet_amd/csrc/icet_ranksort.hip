@@ -163,22 +163,34 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restric
     }
 }
 
-// ---- per-bucket LSD radix sort (stable), in LDS or -- same code, generic pointers -- in global scratch ----------------
-__device__ void radix_pass(const uint32_t* inK, const uint32_t* inI, uint32_t* outK, uint32_t* outI, int n, int shift,
-                           uint32_t* cnt /* kSortWaves x 256 */, uint32_t* tot /* 256 */, int* wsum /* 4 */) {
+// ---- per-bucket LSD radix sort (stable): in LDS, or -- same code on global scratch -- for a bucket that does not fit --
+// LDS layout (words): cnt[kSortWaves*256] | tot[256] | wsum[4] | red[2*kSortWaves] | buf0 keys[kCap] idx[kCap] | buf1 keys idx
+constexpr int kOffCnt = 0, kOffTot = kSortWaves * 256, kOffWsum = kOffTot + 256, kOffRed = kOffWsum + 4, kOffBuf = kOffRed + 2 * kSortWaves;
+
+// kLds selects, at compile time, LDS arrays (indexed off the extern __shared__ base, so the compiler emits ds_*
+// instructions) or the global scratch pointers; `sel` says which of the two buffers is the input.
+template <bool kLds>
+__device__ __forceinline__ void radix_pass(uint32_t* smem, int sel, const uint32_t* gK0, const uint32_t* gI0, uint32_t* gK1, uint32_t* gI1, int n, int shift) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* cnt = smem + kOffCnt; uint32_t* tot = smem + kOffTot; int* wsum = reinterpret_cast<int*>(smem + kOffWsum);
+    const int inB = kOffBuf + sel * 2 * kCap, outB = kOffBuf + (1 - sel) * 2 * kCap;
+    auto ldK = [&](int i) -> uint32_t { if constexpr (kLds) return smem[inB + i]; else return gK0[i]; };
+    auto ldI = [&](int i) -> uint32_t { if constexpr (kLds) return smem[inB + kCap + i]; else return gI0[i]; };
+    auto st = [&](uint32_t dest, uint32_t k, uint32_t id) {
+        if constexpr (kLds) { smem[outB + dest] = k; smem[outB + kCap + dest] = id; } else { gK1[dest] = k; gI1[dest] = id; }
+    };
     int seg = (n + kSortWaves - 1) / kSortWaves; seg = (seg + 63) / 64 * 64;
     const int wlo = wave * seg, whi = min(n, wlo + seg);
     uint32_t* mine = cnt + wave * 256;
     for (int i = lane; i < 256; i += 64) mine[i] = 0u;
     // (same wave zeroes and then adds: LDS operations of one wave complete in order)
-    for (int i = wlo + lane; i < whi; i += 64) atomicAdd(&mine[(inK[i] >> shift) & 255u], 1u);
+    for (int i = wlo + lane; i < whi; i += 64) atomicAdd(&mine[(ldK(i) >> shift) & 255u], 1u);
     __syncthreads();
-    if (threadIdx.x < 256) {                                    // per digit: exclusive prefix over the waves, digit total
+    {                                                           // kSortBlock == 256: one thread per digit
         const int dgt = threadIdx.x;
         uint32_t t = 0;
+#pragma unroll
         for (int w = 0; w < kSortWaves; w++) { const uint32_t c = cnt[w * 256 + dgt]; cnt[w * 256 + dgt] = t; t += c; }
-        // exclusive scan of the 256 totals across the first four waves
         int incl = (int)t;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
@@ -186,9 +198,9 @@ __device__ void radix_pass(const uint32_t* inK, const uint32_t* inI, uint32_t* o
         tot[dgt] = (uint32_t)(incl - (int)t);                   // exclusive within the wave
     }
     __syncthreads();
-    if (threadIdx.x < 256) {
+    {
         int woff = 0;
-        for (int k = 0; k < (threadIdx.x >> 6); k++) woff += wsum[k];
+        for (int k = 0; k < wave; k++) woff += wsum[k];
         tot[threadIdx.x] += (uint32_t)woff;
     }
     __syncthreads();
@@ -197,7 +209,7 @@ __device__ void radix_pass(const uint32_t* inK, const uint32_t* inI, uint32_t* o
     for (int i0 = wlo; i0 < whi; i0 += 64) {
         const int i = i0 + lane;
         const bool ok = i < whi;
-        const uint32_t k = ok ? inK[i] : 0u, id = ok ? inI[i] : 0u;
+        const uint32_t k = ok ? ldK(i) : 0u, id = ok ? ldI(i) : 0u;
         const uint32_t dgt = (k >> shift) & 255u;
         unsigned long long peers = __ballot(ok);
 #pragma unroll
@@ -210,10 +222,48 @@ __device__ void radix_pass(const uint32_t* inK, const uint32_t* inI, uint32_t* o
             const int rank = __popcll(peers & lt);
             const uint32_t dest = mine[dgt] + (uint32_t)rank;
             if (rank == 0) mine[dgt] += (uint32_t)__popcll(peers);
-            outK[dest] = k; outI[dest] = id;
+            st(dest, k, id);
         }
     }
     __syncthreads();
+}
+
+static_assert(kSortBlock == 256, "radix_pass assigns one thread per digit");
+
+template <bool kLds>
+__device__ __forceinline__ void bucket_sort_body(uint32_t* smem, const uint32_t* bkey, const uint32_t* bidx, uint32_t* gK0, uint32_t* gI0, uint32_t* gK1, uint32_t* gI1,
+                                                 int n, int lo, size_t off1, uint32_t* s_out, int32_t* pred_out) {
+    const size_t o = off1 + lo;
+    if constexpr (kLds) {
+        for (int i = threadIdx.x; i < n; i += kSortBlock) { smem[kOffBuf + i] = bkey[o + i]; smem[kOffBuf + kCap + i] = bidx[o + i]; }
+        __syncthreads();
+    }
+    // OR / AND of all keys: a digit position where every key agrees needs no pass (in particular a bucket of
+    // identical keys -- the zero rows of a real scan -- needs none at all)
+    uint32_t vor = 0u, vand = 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < n; i += kSortBlock) { uint32_t k; if constexpr (kLds) k = smem[kOffBuf + i]; else k = gK0[i]; vor |= k; vand &= k; }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) { vor |= __shfl_xor(vor, sft); vand &= __shfl_xor(vand, sft); }
+    uint32_t* red = smem + kOffRed;
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = vor; red[kSortWaves + (threadIdx.x >> 6)] = vand; }
+    __syncthreads();
+    vor = 0u; vand = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) { vor |= red[w]; vand &= red[kSortWaves + w]; }
+    const uint32_t differ = vor & ~vand;                        // bit set where the keys do not all agree
+    __syncthreads();
+    int sel = 0;
+    for (int pass = 0; pass < 4; pass++) {
+        if (((differ >> (8 * pass)) & 255u) == 0u) continue;    // block-uniform
+        radix_pass<kLds>(smem, sel, sel ? gK1 : gK0, sel ? gI1 : gI0, sel ? gK0 : gK1, sel ? gI0 : gI1, n, 8 * pass);
+        sel ^= 1;
+    }
+    for (int i = threadIdx.x; i < n; i += kSortBlock) {
+        uint32_t row;
+        if constexpr (kLds) row = smem[kOffBuf + sel * 2 * kCap + kCap + i]; else row = (sel ? gI1 : gI0)[i];
+        s_out[o + i] = row;
+        pred_out[off1 + row] = lo + i;
+    }
 }
 
 __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bucket_start,
@@ -226,50 +276,16 @@ __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* _
     const int lo = bucket_start[(size_t)pair * (kMaxBuckets + 1) + bucket];
     const int n = bucket_start[(size_t)pair * (kMaxBuckets + 1) + bucket + 1] - lo;
     if (n <= 0) return;
-    const size_t o = (size_t)desc[pair].off1 + lo;
-    uint32_t* cnt = smem;                                       // kSortWaves * 256
-    uint32_t* tot = cnt + kSortWaves * 256;                     // 256
-    int* wsum = reinterpret_cast<int*>(tot + 256);              // 4
-    uint32_t* red = tot + 256 + 4;                              // 2 * kSortWaves : block min / max of the keys
-    uint32_t* lA = red + 2 * kSortWaves;                        // kCap keys | kCap idx | kCap keys | kCap idx
-    const bool in_lds = n <= kCap;
-    uint32_t *K0, *I0, *K1, *I1;
-    if (in_lds) {
-        K0 = lA; I0 = lA + kCap; K1 = lA + 2 * kCap; I1 = lA + 3 * kCap;
-        for (int i = threadIdx.x; i < n; i += kSortBlock) { K0[i] = bkey[o + i]; I0[i] = bidx[o + i]; }
-    } else {
-        K0 = bkey + o; I0 = bidx + o; K1 = altkey + o; I1 = altidx + o;
-    }
-    __syncthreads();
-    // OR / AND of all keys: a digit position where every key agrees needs no pass (in particular a bucket of
-    // identical keys -- the zero rows of a real scan -- needs none at all)
-    uint32_t vor = 0u, vand = 0xFFFFFFFFu;
-    for (int i = threadIdx.x; i < n; i += kSortBlock) { const uint32_t k = K0[i]; vor |= k; vand &= k; }
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) { vor |= __shfl_xor(vor, sft); vand &= __shfl_xor(vand, sft); }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = vor; red[kSortWaves + (threadIdx.x >> 6)] = vand; }
-    __syncthreads();
-    vor = 0u; vand = 0xFFFFFFFFu;
-    for (int w = 0; w < kSortWaves; w++) { vor |= red[w]; vand &= red[kSortWaves + w]; }
-    const uint32_t differ = vor & ~vand;                        // bit set where the keys do not all agree
-    __syncthreads();
-    for (int pass = 0; pass < 4; pass++) {
-        if (((differ >> (8 * pass)) & 255u) == 0u) continue;    // block-uniform
-        radix_pass(K0, I0, K1, I1, n, 8 * pass, cnt, tot, wsum);
-        uint32_t* t; t = K0; K0 = K1; K1 = t; t = I0; I0 = I1; I1 = t;
-    }
-    for (int i = threadIdx.x; i < n; i += kSortBlock) {
-        const uint32_t row = I0[i];
-        s_out[o + i] = row;
-        pred_out[(o - lo) + row] = lo + i;
-    }
+    const size_t off1 = (size_t)desc[pair].off1;
+    if (n <= kCap) bucket_sort_body<true>(smem, bkey, bidx, nullptr, nullptr, nullptr, nullptr, n, lo, off1, s_out, pred_out);
+    else bucket_sort_body<false>(smem, bkey, bidx, bkey + off1 + lo, bidx + off1 + lo, altkey + off1 + lo, altidx + off1 + lo, n, lo, off1, s_out, pred_out);
 }
 
 }  // namespace
 
 #define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
-size_t rank_sort_lds_bytes() { return (size_t)(kSortWaves * 256 + 256 + 4 + 2 * kSortWaves + 4 * kCap) * 4; }
+size_t rank_sort_lds_bytes() { return (size_t)(kOffBuf + 4 * kCap) * 4; }
 
 // Outputs: w.valB = s (row with rank i), w.pred = rank of every row.  Scratch: w.keyA / w.valA (bucket-grouped keys and
 // rows), w.keyB / w.key64A (overflow buckets), w.bkt, w.counts / w.tile_base, w.splitters, w.n_buckets, w.bucket_start.

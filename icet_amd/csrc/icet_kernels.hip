@@ -401,20 +401,31 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
         // ---- findCluster (src/icet.cpp:557-607): first run of >= n consecutive points whose
         // successive |dr| <= thresh, walking the bin in stored (scrambled) order.
         int run_start = 0; float front = 0.f; float carry_prev = 0.f; bool found = false;
+        // A break is a point that does not continue the current run; a run is reported at the first break that closes
+        // >= n points.  In the scrambled order most points are breaks, so instead of visiting the breaks of a 64-point
+        // chunk one after another, every break lane looks up the break before it with a prefix-max scan and the first
+        // lane whose run is long enough is picked with a ballot.
         auto walk = [&](int c0, float r) {
             const int i = c0 + lane; const bool valid = i < cnt;
             float prev = __shfl_up(r, 1);
             if (lane == 0) prev = carry_prev;
             const bool brk = valid && (i == 0 || !(fabsf(prev - r) <= thresh));
-            unsigned long long m = __ballot(brk);
-            while (m) {
-                const int b = __ffsll((long long)m) - 1; m &= m - 1;
-                const int g = c0 + b;
-                if (g - run_start >= n) {
-                    const float back = (b > 0) ? __shfl(r, b - 1) : carry_prev;
-                    inner = front - buff; outer = back + buff; found = true; break;
-                }
-                run_start = g; front = __shfl(r, b);
+            int pm = brk ? i : -1;                                   // inclusive prefix max of break positions
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pm, o); if (lane >= o) pm = max(pm, t); }
+            int prevb = __shfl_up(pm, 1);                            // last break strictly before this lane ...
+            if (lane == 0) prevb = -1;
+            prevb = max(prevb, run_start);                           // ... or the run carried in from earlier chunks
+            const unsigned long long hit = __ballot(brk && (i - prevb >= n));
+            if (hit) {
+                const int b = __ffsll((long long)hit) - 1;
+                const int rs0 = __shfl(prevb, b);                    // start of the run that this break closes
+                const float back = (b > 0) ? __shfl(r, b - 1) : carry_prev;
+                const float fr = (rs0 >= c0) ? __shfl(r, rs0 - c0) : front;
+                inner = fr - buff; outer = back + buff; found = true;
+            } else {
+                const int last = __shfl(pm, 63);                     // last break of this chunk, if any
+                if (last >= 0) { run_start = last; front = __shfl(r, last - c0); }
             }
             carry_prev = __shfl(r, 63);
         };

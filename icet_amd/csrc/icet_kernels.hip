@@ -38,7 +38,7 @@ constexpr int kBlock = 256;
 #define ICET_ACC_WAVES 4
 #endif
 #ifndef ICET_ACC_PTS
-#define ICET_ACC_PTS 16
+#define ICET_ACC_PTS 4
 #endif
 constexpr int kAccPts = ICET_ACC_PTS;                      // consecutive points per lane per trip (two dwordx4 loads per coordinate)
 constexpr int kAccBlock = ICET_ACC_BLOCK;        // k_gn_accumulate: the waves of a block share one copy of the pair's LDS tables
@@ -761,6 +761,14 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
             for (int j = 0; j < 4; j++) { const bool ok = i0 + j < end; X[j] = ok ? px[i0 + j] : 0.f; Y[j] = ok ? py[i0 + j] : 0.f; Z[j] = ok ? pz[i0 + j] : 0.f; }
         }
     };
+    // Software pipeline across trips: the loads of trip t+1 are in flight while trip t is classified.  With the scans
+    // streaming from HBM (256 distinct pairs = 745 MB, well past the Infinity Cache) a wave that loads, waits and then
+    // computes leaves the memory pipe idle: measured 0.18 ms per launch without any prefetch and 0.146 with it; the
+    // cache-resident floor (VALU-issue-bound, 16 distinct pairs) is 0.13.  More points per trip would amortise the LDS
+    // flushes better but the second set of registers then spills (kAccPts 8: 128 VGPRs + scratch, 0.164 ms).
+    float XN[kAccPts / 4][4], YN[kAccPts / 4][4], ZN[kAccPts / 4][4];
+#pragma unroll
+    for (int g = 0; g < kAccPts / 4; g++) load4(begin + kAccPts * (int)threadIdx.x + 4 * g, XN[g], YN[g], ZN[g]);
     for (int t0 = begin + kAccPts * threadIdx.x; t0 < begin + cs; t0 += kAccPts * kAccBlock) {   // whole waves iterate together
       // Run state of this lane for the whole trip: the current run, and a stash holding one finished run (see phase C).
       int cur = -1; uint32_t nraw = 0, nin = 0;
@@ -783,13 +791,22 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
               }
           }
       };
-      // the lane's kAccPts CONSECUTIVE points are taken 4 at a time (one dwordx4 per coordinate)
+      // The lane's kAccPts CONSECUTIVE points are taken 4 at a time (one dwordx4 per coordinate).
+      float XA[kAccPts / 4][4], YA[kAccPts / 4][4], ZA[kAccPts / 4][4];
+#pragma unroll
+      for (int g = 0; g < kAccPts / 4; g++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) { XA[g][j] = XN[g][j]; YA[g][j] = YN[g][j]; ZA[g][j] = ZN[g][j]; }
+      if (t0 + kAccPts * kAccBlock < begin + cs) {
+#pragma unroll
+          for (int g = 0; g < kAccPts / 4; g++) load4(t0 + kAccPts * kAccBlock + 4 * g, XN[g], YN[g], ZN[g]);
+      }
+#pragma unroll
       for (int g = 0; g < kAccPts / 4; g++) {
         const int i0 = t0 + 4 * g;
-        // no software prefetch: measured, it buys nothing here -- the kernel is VALU-issue-bound (PMC: SQ_ACTIVE_INST_VALU
-        // ~ 90 % of the SIMD cycles), not latency-bound
         float X[4], Y[4], Z[4];
-        load4(i0, X, Y, Z);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { X[j] = XA[g][j]; Y[j] = YA[g][j]; Z[j] = ZA[g][j]; }
         PointClass pc[4];
         float QX[4], QY[4], QZ[4], RR[4];
         int SM[4];

@@ -153,48 +153,126 @@ __global__ __launch_bounds__(kBlock) void k_inverse_perm(const PairDesc* __restr
 // Visiting order makes step i execute iff row i is not a fixed point and was not frozen by an
 // executed step i' = pred(i) < i.  So exec(v) is the parity of the length of the descending chain
 // v, pred(v), pred(pred(v)), ... taken while pred(u) < u.
+// Both walks below are pointer chases through ~1 MB of per-pair tables that sit in the XCD's L2 (see decode_block): they
+// are bound by load latency, not bandwidth.  Each thread therefore advances EIGHT independent chains in lock step, so
+// that eight loads are in flight per thread instead of one.
+constexpr int kWalk = 8;
+
 __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
                                                        uint8_t* __restrict__ exec, int32_t* __restrict__ flags, int max_walk, int n_pairs, int chunks) {
-    ICET_FOR_CHUNK_OF_SCAN1(v) {
-        const size_t o = d.off1;
-        uint8_t e = 0;
-        if ((int)s[o + v] != v) {
-            int u = v, len = 0;
-            for (;;) {
-                int p = pred[o + u];
-                if (p >= u) break;
-                u = p; len++;
-                if (len > max_walk) { atomicOr(&flags[pair], 1); break; }
-            }
-            e = (len & 1) ? 0 : 1;
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const PairDesc d = desc[pair];
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
+    const size_t o = d.off1;
+    for (int base = lo_ + threadIdx.x; base < hi_; base += kWalk * kBlock) {
+        int u[kWalk], len[kWalk]; bool act[kWalk], moved[kWalk];
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) {
+            const int v = base + k * kBlock;
+            const bool valid = v < hi_;
+            moved[k] = valid && ((int)s[o + (valid ? v : lo_)] != v);
+            act[k] = moved[k]; u[k] = v; len[k] = 0;
         }
-        exec[o + v] = e;
+        bool any = true;
+        while (any) {
+            int p[kWalk];
+#pragma unroll
+            for (int k = 0; k < kWalk; k++) p[k] = act[k] ? pred[o + u[k]] : 0;
+            any = false;
+#pragma unroll
+            for (int k = 0; k < kWalk; k++) {
+                if (act[k]) {
+                    if (p[k] >= u[k]) act[k] = false;
+                    else { u[k] = p[k]; len[k]++; if (len[k] > max_walk) { atomicOr(&flags[pair], 1); act[k] = false; } }
+                }
+                any |= act[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) {
+            const int v = base + k * kBlock;
+            if (v < hi_) exec[o + v] = (moved[k] && !(len[k] & 1)) ? 1 : 0;
+        }
     }
 }
 
 // src[v] = original row that ends at position v after the swap loop.  Position v receives row
 // pred(v), except at the head of a run of executed steps, where the row arrives from the end of
 // the forward chain v -> s[v] -> s[s[v]] ... while the steps executed.
+// Fused with the first step of the voxel multi-split (k_bin_hist): the row that lands on a position is known here, so
+// its voxel id and this tile's voxel histogram cost no extra pass over src[].
 __global__ __launch_bounds__(kBlock) void k_scramble_src(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
                                                          const uint8_t* __restrict__ exec, int32_t* __restrict__ src, int32_t* __restrict__ flags, int max_walk,
+                                                         const uint16_t* __restrict__ bin16, uint16_t* __restrict__ binpos, uint32_t* __restrict__ counts, int V,
                                                          int n_pairs, int chunks) {
-    ICET_FOR_CHUNK_OF_SCAN1(v) {
-        const size_t o = d.off1;
-        int f = v;
-        if ((int)s[o + v] != v) {
-            int p = pred[o + v];
-            f = p;
-            if (exec[o + v] && !exec[o + p]) {
-                int u = v, len = 0;
-                while (exec[o + u]) {
-                    u = (int)s[o + u];
-                    if (++len > max_walk) { atomicOr(&flags[pair], 1); break; }
+    extern __shared__ uint32_t lh[];
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const PairDesc d = desc[pair];
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
+    const size_t o = d.off1;
+    for (int b = threadIdx.x; b < V; b += kBlock) lh[b] = 0u;
+    __syncthreads();
+    for (int base = lo_ + threadIdx.x; base < hi_; base += kWalk * kBlock) {
+        int f[kWalk], u[kWalk], len[kWalk]; bool act[kWalk];
+        int sv[kWalk], pv[kWalk]; uint8_t ev[kWalk];
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) {
+            const int v = base + k * kBlock;
+            const bool valid = v < hi_;
+            const size_t i = o + (valid ? v : lo_);
+            sv[k] = (int)s[i]; pv[k] = pred[i]; ev[k] = exec[i];
+        }
+        uint8_t ep[kWalk];
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) ep[k] = exec[o + pv[k]];
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) {
+            const int v = base + k * kBlock;
+            const bool valid = v < hi_;
+            const bool moved = valid && sv[k] != v;
+            f[k] = moved ? pv[k] : v;
+            act[k] = moved && ev[k] && !ep[k];                  // head of a run of executed steps
+            u[k] = v; len[k] = 0;
+        }
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) any |= act[k];
+        while (any) {
+            int nu[kWalk];
+#pragma unroll
+            for (int k = 0; k < kWalk; k++) nu[k] = act[k] ? (int)s[o + u[k]] : 0;
+            uint8_t ne[kWalk];
+#pragma unroll
+            for (int k = 0; k < kWalk; k++) ne[k] = act[k] ? exec[o + nu[k]] : 0;
+            any = false;
+#pragma unroll
+            for (int k = 0; k < kWalk; k++) {
+                if (act[k]) {
+                    u[k] = nu[k]; len[k]++;
+                    if (!ne[k]) { f[k] = u[k]; act[k] = false; }
+                    else if (len[k] > max_walk) { atomicOr(&flags[pair], 1); f[k] = u[k]; act[k] = false; }
                 }
-                f = u;
+                any |= act[k];
             }
         }
-        src[o + v] = f;
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) {
+            const int v = base + k * kBlock;
+            if (v < hi_) {
+                src[o + v] = f[k];
+                const uint16_t b = bin16[o + f[k]];
+                binpos[o + v] = b;
+                atomicAdd(&lh[b], 1u);
+            }
+        }
     }
+    __syncthreads();
+    uint32_t* out = counts + ((size_t)pair * chunks + chunk) * V;
+    for (int b = threadIdx.x; b < V; b += kBlock) out[b] = lh[b];
 }
 
 // Serial fallback for adversarial permutations (walks longer than max_walk): one lane replays the
@@ -225,10 +303,12 @@ __global__ void k_scramble_serial(const PairDesc* __restrict__ desc, const uint3
 //                  with a ballot per id bit (match-any), so rank = popcount of lower peers -- stable by construction --
 //                  and the row's spherical coordinates are written straight to their final place.
 __global__ __launch_bounds__(kBlock) void k_bin_hist(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const uint16_t* __restrict__ bin16,
-                                                     uint16_t* __restrict__ binpos, uint32_t* __restrict__ counts, int V, int n_pairs, int chunks) {
+                                                     uint16_t* __restrict__ binpos, uint32_t* __restrict__ counts, const int32_t* __restrict__ flags,
+                                                     int V, int n_pairs, int chunks) {
     extern __shared__ uint32_t lh[];
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    if (!(flags[pair] & 1)) return;          // k_scramble_src already produced binpos / counts; redo only after the serial replay
     const PairDesc d = desc[pair];
     int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
     const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
@@ -754,7 +834,8 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
 
     auto load4 = [&](int i0, float (&X)[4], float (&Y)[4], float (&Z)[4]) {
         if (kVec4 && i0 + 3 < end) {
-            const vfloat4 a = *(gfloat4*)(px + i0), b = *(gfloat4*)(py + i0), c = *(gfloat4*)(pz + i0);
+            // read-once stream: non-temporal, so the scans do not evict the pair tables from L2
+            const vfloat4 a = __builtin_nontemporal_load((gfloat4*)(px + i0)), b = __builtin_nontemporal_load((gfloat4*)(py + i0)), c = __builtin_nontemporal_load((gfloat4*)(pz + i0));
             X[0] = a.x; X[1] = a.y; X[2] = a.z; X[3] = a.w; Y[0] = b.x; Y[1] = b.y; Y[2] = b.z; Y[3] = b.w; Z[0] = c.x; Z[1] = c.y; Z[2] = c.z; Z[3] = c.w;
         } else {
 #pragma unroll
@@ -1115,11 +1196,11 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     const int max_walk = 4096;
     k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.exec, w.flags, max_walk, np, chunks);
     ICET_LAUNCH_CHECK();
-    k_scramble_src<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.exec, w.src, w.flags, max_walk, np, chunks);
+    k_scramble_src<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.valB, w.pred, w.exec, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);
     ICET_LAUNCH_CHECK();
     k_scramble_serial<<<c.n_pairs, 64, 0, st>>>(w.desc, w.valB, w.pred /* reused as scratch */, w.src, w.flags);
     ICET_LAUNCH_CHECK();
-    k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, c.V, np, chunks);
+    k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, w.flags, c.V, np, chunks);
     ICET_LAUNCH_CHECK();
     k_bin_scan<<<c.n_pairs, blk, 0, st>>>(w.counts, w.tile_base, w.bin_start, c.V, chunks);
     ICET_LAUNCH_CHECK();

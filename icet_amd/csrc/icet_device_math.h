@@ -32,7 +32,7 @@ __device__ __forceinline__ void make_givens(float p, float q, float& c, float& s
 
 // One implicit-shift QR sweep on the unreduced block [start, end] of a symmetric tridiagonal matrix;
 // the rotations are accumulated into Q (N x N row-major) on the right.
-template <int N>
+template <int N, bool kVec = true>
 __device__ inline void tridiag_qr_step(float* diag, float* sub, int start, int end, float* Q) {
 #pragma clang fp contract(off)
     float td = (diag[end - 1] - diag[end]) * 0.5f;
@@ -58,17 +58,19 @@ __device__ inline void tridiag_qr_step(float* diag, float* sub, int start, int e
         if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
         x = sub[k];
         if (k < end - 1) { z = -s * sub[k + 1]; sub[k + 1] = c * sub[k + 1]; }
+        if (kVec) {
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            float xi = Q[i * N + k], yi = Q[i * N + k + 1];
-            Q[i * N + k]     = c * xi - s * yi;
-            Q[i * N + k + 1] = s * xi + c * yi;
+            for (int i = 0; i < N; i++) {
+                float xi = Q[i * N + k], yi = Q[i * N + k + 1];
+                Q[i * N + k]     = c * xi - s * yi;
+                Q[i * N + k + 1] = s * xi + c * yi;
+            }
         }
     }
 }
 
 // Deflate / iterate / sort ascending (eigenvector columns follow).  Returns false on no convergence.
-template <int N>
+template <int N, bool kVec = true>
 __device__ inline bool tridiag_eigen(float* diag, float* sub, float* Q) {
 #pragma clang fp contract(off)
     int end = N - 1, start = 0, iter = 0;
@@ -83,7 +85,7 @@ __device__ inline bool tridiag_eigen(float* diag, float* sub, float* Q) {
         if (iter > 30 * N) break;
         start = end - 1;
         while (start > 0 && sub[start - 1] != 0.f) start--;
-        tridiag_qr_step<N>(diag, sub, start, end, Q);
+        tridiag_qr_step<N, kVec>(diag, sub, start, end, Q);
     }
     bool ok = iter <= 30 * N;
     if (ok) {
@@ -92,7 +94,7 @@ __device__ inline bool tridiag_eigen(float* diag, float* sub, float* Q) {
             for (int j = i + 1; j < N; j++) if (diag[j] < mn) { mn = diag[j]; k = j; }
             if (k != i) {
                 float t = diag[i]; diag[i] = diag[k]; diag[k] = t;
-                for (int r = 0; r < N; r++) { float q = Q[r * N + i]; Q[r * N + i] = Q[r * N + k]; Q[r * N + k] = q; }
+                if (kVec) for (int r = 0; r < N; r++) { float q = Q[r * N + i]; Q[r * N + i] = Q[r * N + k]; Q[r * N + k] = q; }
             }
         }
     }
@@ -146,6 +148,9 @@ __device__ inline void make_householder(float* x, int m, int stride, float& tau,
 }
 
 // Symmetric 6x6 (row-major, lower triangle read): eigenvalues ascending, eigenvectors = columns of Q.
+// kVec = false computes the eigenvalues only: the tridiagonal recurrences never read Q, so the values are
+// bit-identical to the full solve at less than half the work.
+template <bool kVec = true>
 __device__ inline bool eig6_sym(const float* Ain, float ev[6], float* Q) {
 #pragma clang fp contract(off)
     constexpr int n = 6;
@@ -182,22 +187,68 @@ __device__ inline bool eig6_sym(const float* Ain, float ev[6], float* Q) {
     float diag[6], sub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < n; i++) diag[i] = A[i * n + i];
     for (int i = 0; i < n - 1; i++) sub[i] = A[(i + 1) * n + i];
-    for (int i = 0; i < 36; i++) Q[i] = 0.f;
-    for (int i = 0; i < n; i++) Q[i * n + i] = 1.f;
-    for (int k = n - 2; k >= 0; k--) {
-        int rem = n - k - 1;
-        float v[6]; v[0] = 1.f;
-        for (int t = 1; t < rem; t++) v[t] = A[(k + 1 + t) * n + k];
-        for (int col = 0; col < n; col++) {
-            float s = 0.f;
-            for (int t = 0; t < rem; t++) s += v[t] * Q[(k + 1 + t) * n + col];
-            s *= h[k];
-            for (int t = 0; t < rem; t++) Q[(k + 1 + t) * n + col] -= s * v[t];
+    if (kVec) {
+        for (int i = 0; i < 36; i++) Q[i] = 0.f;
+        for (int i = 0; i < n; i++) Q[i * n + i] = 1.f;
+        for (int k = n - 2; k >= 0; k--) {
+            int rem = n - k - 1;
+            float v[6]; v[0] = 1.f;
+            for (int t = 1; t < rem; t++) v[t] = A[(k + 1 + t) * n + k];
+            for (int col = 0; col < n; col++) {
+                float s = 0.f;
+                for (int t = 0; t < rem; t++) s += v[t] * Q[(k + 1 + t) * n + col];
+                s *= h[k];
+                for (int t = 0; t < rem; t++) Q[(k + 1 + t) * n + col] -= s * v[t];
+            }
         }
     }
-    bool ok = tridiag_eigen<6>(diag, sub, Q);
+    bool ok = tridiag_eigen<6, kVec>(diag, sub, Q);
     for (int i = 0; i < n; i++) ev[i] = diag[i] * scale;
     return ok;
+}
+
+// Inverse of a symmetric positive-definite 6x6 (row-major) by Cholesky, fully unrolled (registers only).
+// Returns false when a pivot is not positive (the caller then takes the eigen-decomposition route).
+__device__ inline bool chol6_inverse(const float* A, float* inv) {
+    float L[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        float sd = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) sd -= L[j][k] * L[j][k];
+        if (!(sd > 0.f)) return false;
+        const float dg = sqrtf(sd), rd = 1.f / dg;
+        L[j][j] = dg;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            float t = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+            L[i][j] = t * rd;
+        }
+    }
+    float Li[6][6];                                             // inverse of L (lower triangular)
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        Li[j][j] = 1.f / L[j][j];
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = j; k < i; k++) t -= L[i][k] * Li[k][j];
+            Li[i][j] = t / L[i][i];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = a; k < 6; k++) t += Li[k][a] * Li[k][b];       // (L^-T L^-1)(a,b), k >= max(a,b) = a
+            inv[a * 6 + b] = t; inv[b * 6 + a] = t;
+        }
+    return true;
 }
 
 // Moore-Penrose pseudo-inverse of a symmetric PSD 3x3 (xx,xy,xz,yy,yz,zz) by cyclic Jacobi.

@@ -1111,40 +1111,51 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
         }
         for (int a = 0; a < 6; a++) { float t = 0.f; for (int w = 0; w < kBlock / 64; w++) t += red[w][21 + a]; g[a] = t; }
     }
-    float ev[6], Q[36];
-    icetdev::eig6_sym(Hm, ev, Q);
-    // noise_mat = pinv(HTWH) (src/icet.cpp:410-411); rank rule eps*6 relative to the largest eigenvalue
+    // Eigenvalues first (they decide rank and conditioning exactly as below).  With full rank and no axis to prune --
+    // the normal case -- pinv(HTWH) is the inverse and dx = HTWH^-1 HTWdz: a Cholesky factorisation gives both without
+    // eigenvectors.  Otherwise the eigenvector route reproduces the reference's pruning.
+    float ev[6];
+    icetdev::eig6_sym<false>(Hm, ev, nullptr);
     float emax = 0.f;
     for (int k = 0; k < 6; k++) emax = fmaxf(emax, fabsf(ev[k]));
-    const float rthr = 6.0f * FLT_EPSILON * emax;
-    float inv[6];
-    for (int k = 0; k < 6; k++) inv[k] = (fabsf(ev[k]) > rthr) ? 1.f / ev[k] : 0.f;
-    float cov[36];
-    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) {
-        float t = 0.f; for (int k = 0; k < 6; k++) t += Q[a * 6 + k] * inv[k] * Q[b * 6 + k];
-        cov[a * 6 + b] = t;
-    }
-    float ps[6];
-    for (int k = 0; k < 6; k++) ps[k] = sqrtf(fabsf(cov[k * 6 + k]));             // src/icet.cpp:412-417
-    // checkCondition (src/icet.cpp:443-492)
-    int k0 = 0;
-    {
-        float condition = ev[5] / ev[0];
-        int eyecount = 1;
-        while (fabsf(condition) > 1e6f && eyecount < 6) {
-            for (int k = 0; k < 6; k++) ps[k] += Q[k * 6 + eyecount - 1];           // src/icet.cpp:479
-            k0++;
-            condition = ev[5] / ev[eyecount];
-            eyecount++;
+    const float rthr = 6.0f * FLT_EPSILON * emax;                  // rank rule eps*6 relative to the largest eigenvalue
+    bool plain = !(fabsf(ev[5] / ev[0]) > 1e6f);
+    for (int k = 0; k < 6; k++) plain = plain && (fabsf(ev[k]) > rthr);
+    float cov[36], ps[6], dx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (plain) plain = icetdev::chol6_inverse(Hm, cov);
+    if (plain) {
+        for (int k = 0; k < 6; k++) ps[k] = sqrtf(fabsf(cov[k * 6 + k]));         // src/icet.cpp:412-417
+        for (int a = 0; a < 6; a++) { float t = 0.f; for (int b = 0; b < 6; b++) t += cov[a * 6 + b] * g[b]; dx[a] = t; }
+    } else {
+        float Q[36];
+        icetdev::eig6_sym<true>(Hm, ev, Q);
+        // noise_mat = pinv(HTWH) (src/icet.cpp:410-411)
+        float inv[6];
+        for (int k = 0; k < 6; k++) inv[k] = (fabsf(ev[k]) > rthr) ? 1.f / ev[k] : 0.f;
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) {
+            float t = 0.f; for (int k = 0; k < 6; k++) t += Q[a * 6 + k] * inv[k] * Q[b * 6 + k];
+            cov[a * 6 + b] = t;
         }
-    }
-    // dx = pinv(L2 lam U2^T) L2 U2^T HTWdz  = sum_{k >= k0} q_k (q_k . g) / lam_k     src/icet.cpp:427-430
-    float dx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k = k0; k < 6; k++) {
-        if (inv[k] == 0.f) continue;
-        float pj = 0.f; for (int a = 0; a < 6; a++) pj += Q[a * 6 + k] * g[a];
-        pj *= inv[k];
-        for (int a = 0; a < 6; a++) dx[a] += Q[a * 6 + k] * pj;
+        for (int k = 0; k < 6; k++) ps[k] = sqrtf(fabsf(cov[k * 6 + k]));         // src/icet.cpp:412-417
+        // checkCondition (src/icet.cpp:443-492)
+        int k0 = 0;
+        {
+            float condition = ev[5] / ev[0];
+            int eyecount = 1;
+            while (fabsf(condition) > 1e6f && eyecount < 6) {
+                for (int k = 0; k < 6; k++) ps[k] += Q[k * 6 + eyecount - 1];       // src/icet.cpp:479
+                k0++;
+                condition = ev[5] / ev[eyecount];
+                eyecount++;
+            }
+        }
+        // dx = pinv(L2 lam U2^T) L2 U2^T HTWdz  = sum_{k >= k0} q_k (q_k . g) / lam_k     src/icet.cpp:427-430
+        for (int k = k0; k < 6; k++) {
+            if (inv[k] == 0.f) continue;
+            float pj = 0.f; for (int a = 0; a < 6; a++) pj += Q[a * 6 + k] * g[a];
+            pj *= inv[k];
+            for (int a = 0; a < 6; a++) dx[a] += Q[a * 6 + k] * pj;
+        }
     }
     float Xn[6];
     for (int k = 0; k < 6; k++) { Xn[k] = X[k] + dx[k]; X[k] = Xn[k]; }

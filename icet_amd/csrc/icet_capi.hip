@@ -82,7 +82,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, dev_realloc(w.n_slots, np));
         HIPCHK(c, dev_realloc(w.acc, pv * kAccWords));
         HIPCHK(c, hipMemset(w.acc, 0, pv * kAccWords * sizeof(uint32_t)));
-        HIPCHK(c, dev_realloc(w.xf, (size_t)np * 16));
+        HIPCHK(c, dev_realloc(w.xf, (size_t)np * 48));
         HIPCHK(c, dev_realloc(w.X, (size_t)np * 6));
         HIPCHK(c, dev_realloc(w.flags, np));
         HIPCHK(c, dev_realloc(w.splitters, (size_t)np * 128)); HIPCHK(c, dev_realloc(w.n_buckets, np)); HIPCHK(c, dev_realloc(w.bucket_start, (size_t)np * 129));

@@ -69,7 +69,7 @@ struct Workspace {
     SlotHot* hotS = nullptr; SlotFit* fitS = nullptr;                               // compact, pairs x V
     int16_t* slot_of_voxel = nullptr; int32_t* n_slots = nullptr;
     uint32_t* acc = nullptr;                  // pairs x V x kAccWords
-    float* xf = nullptr;                      // pairs x 16: t[3], R[9] row-major, angles[3], pad
+    float* xf = nullptr;                      // pairs x 48: t[3], R[9] row-major, angles[3], pad, J[27] (see write_xf)
     float* X = nullptr;                       // pairs x 6
     int32_t* flags = nullptr;                 // pairs: bit0 = scramble walk overflow
     float* thr = nullptr; int thr_T = 0, thr_P = 0;   // bin-edge tables: T+1 azimuth thresholds, then P+1 polar thresholds

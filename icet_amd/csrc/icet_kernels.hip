@@ -666,15 +666,29 @@ __global__ __launch_bounds__(kBlock) void k_compact_slots(const SlotHot* __restr
 // ------------------------------------------------------------------------------------------------
 // Gauss-Newton loop
 // ------------------------------------------------------------------------------------------------
+// Per-pair transform record, kXf floats: t[3] | R[9] (utils::R, src/utils.cpp:144-152, row-major) | angles[3] | pad |
+// J[27] (get_H's three derivative matrices, src/icet.cpp:507-529).  Written once per iteration by the lane that updates
+// X, so the six sin/cos are evaluated once and serve both the next point pass (R) and the next voxel pass (J).
+constexpr int kXf = 48;
 __device__ __forceinline__ void write_xf(float* xf, const float X[6]) {
-    // utils::R(phi, theta, psi) (src/utils.cpp:144-152), row-major
     const float phi = X[3], theta = X[4], psi = X[5];
-    const float cph = cosf(phi), sph = sinf(phi), cth = cosf(theta), sth = sinf(theta), cps = cosf(psi), sps = sinf(psi);
+    float sph, cph, sth, cth, sps, cps;
+    sincosf(phi, &sph, &cph); sincosf(theta, &sth, &cth); sincosf(psi, &sps, &cps);
     xf[0] = X[0]; xf[1] = X[1]; xf[2] = X[2];
     xf[3] = cth * cps;  xf[4] = sps * cph + sph * sth * cps;  xf[5] = sph * sps - sth * cph * cps;
     xf[6] = -sps * cth; xf[7] = cph * cps - sph * sth * sps;  xf[8] = sph * cps + sth * sps * cph;
     xf[9] = sth;        xf[10] = -sph * cth;                  xf[11] = cph * cth;
     xf[12] = phi; xf[13] = theta; xf[14] = psi; xf[15] = 0.f;
+    float* J = xf + 16;
+    J[0] = 0.f; J[1] = -sps * sph + cph * sth * cps; J[2] = cph * sps + sth * sph * cps;
+    J[3] = 0.f; J[4] = -sph * cps - cph * sth * sps; J[5] = cph * cps - sth * sps * sph;
+    J[6] = 0.f; J[7] = -cph * cth;                   J[8] = -sph * cth;
+    J[9] = -sth * cps;  J[10] = cth * sph * cps;  J[11] = -cth * cph * cps;
+    J[12] = sps * sth;  J[13] = -cth * sph * sps; J[14] = cth * sps * cph;
+    J[15] = cth;        J[16] = sph * sth;        J[17] = -sth * cph;
+    J[18] = -cth * sps; J[19] = cps * cph - sph * sth * sps;  J[20] = cps * sph + sth * cph * sps;
+    J[21] = -cps * cth; J[22] = -sps * cph - sph * sth * cps; J[23] = -sph * sps + sth * cps * cph;
+    J[24] = 0.f; J[25] = 0.f; J[26] = 0.f;
 }
 
 __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X, float* __restrict__ xf, int n_pairs) {
@@ -682,7 +696,7 @@ __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X
     if (p >= n_pairs) return;
     float x[6];
     for (int k = 0; k < 6; k++) { x[k] = x0 ? x0[p * 6 + k] : 0.f; X[p * 6 + k] = x[k]; }
-    write_xf(xf + p * 16, x);
+    write_xf(xf + p * kXf, x);
 }
 
 // sortSphericalCoordinates' bin index WITHOUT the double divide: thr[k] is the smallest float whose
@@ -823,7 +837,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
         for (int i = threadIdx.x; i < 9 * lds_slots; i += kAccBlock) lsum[i] = 0ull;
         for (int i = threadIdx.x; i < 2 * lds_slots; i += kAccBlock) lraw[i] = 0u;
     }
-    const float* xf = xf_all + pair * 16;
+    const float* xf = xf_all + pair * kXf;
     const float tx = xf[0], ty = xf[1], tz = xf[2];
     const float R00 = xf[3], R01 = xf[4], R02 = xf[5], R10 = xf[6], R11 = xf[7], R12 = xf[8], R20 = xf[9], R21 = xf[10], R22 = xf[11];
     const float cell_t = (float)Mt * 0.25f, cell_p = (float)Mp * 0.5f;
@@ -998,20 +1012,7 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
     __shared__ float red[kBlock / 64][27];
     const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* X = X_all + pair * 6;
-    if (threadIdx.x == 0) {
-        // get_H's three derivative matrices (src/icet.cpp:507-529), row-major
-        const float phi = X[3], theta = X[4], psi = X[5];
-        const float cph = cosf(phi), sph = sinf(phi), cth = cosf(theta), sth = sinf(theta), cps = cosf(psi), sps = sinf(psi);
-        J[0] = 0.f; J[1] = -sps * sph + cph * sth * cps; J[2] = cph * sps + sth * sph * cps;
-        J[3] = 0.f; J[4] = -sph * cps - cph * sth * sps; J[5] = cph * cps - sth * sps * sph;
-        J[6] = 0.f; J[7] = -cph * cth;                   J[8] = -sph * cth;
-        J[9] = -sth * cps;  J[10] = cth * sph * cps;  J[11] = -cth * cph * cps;
-        J[12] = sps * sth;  J[13] = -cth * sph * sps; J[14] = cth * sps * cph;
-        J[15] = cth;        J[16] = sph * sth;        J[17] = -sth * cph;
-        J[18] = -cth * sps; J[19] = cps * cph - sph * sth * sps;  J[20] = cps * sph + sth * cph * sps;
-        J[21] = -cps * cth; J[22] = -sps * cph - sph * sth * cps; J[23] = -sph * sps + sth * cps * cph;
-        J[24] = 0.f; J[25] = 0.f; J[26] = 0.f;
-    }
+    if (threadIdx.x < 27) J[threadIdx.x] = xf_all[pair * kXf + 16 + threadIdx.x];      // written by the previous update (write_xf)
     __syncthreads();
     const int ns = n_slots[pair];
     float S[27];
@@ -1111,24 +1112,35 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
         }
         for (int a = 0; a < 6; a++) { float t = 0.f; for (int w = 0; w < kBlock / 64; w++) t += red[w][21 + a]; g[a] = t; }
     }
-    // Eigenvalues first (they decide rank and conditioning exactly as below).  With full rank and no axis to prune --
-    // the normal case -- pinv(HTWH) is the inverse and dx = HTWH^-1 HTWdz: a Cholesky factorisation gives both without
-    // eigenvectors.  Otherwise the eigenvector route reproduces the reference's pruning.
+    // Normal case first: HTWH positive definite with condition number <= 1e6.  Then nothing is pruned
+    // (checkCondition's cutoff, src/icet.cpp:453,469), every eigenvalue is above the pseudo-inverse's rank threshold
+    // (eps * 6 < 1e-6), pinv(HTWH) is the inverse and dx = HTWH^-1 HTWdz -- a Cholesky factorisation gives both.
+    // cond_2 <= |A|_F |A^-1|_F, so that product <= 1e6 PROVES the case without an eigen-solve.  When the bound is
+    // inconclusive the eigenvalues decide, exactly as the reference does, and only a genuinely ill-conditioned or
+    // rank-deficient HTWH takes the eigenvector route with its pruning.
     float ev[6];
-    icetdev::eig6_sym<false>(Hm, ev, nullptr);
-    float emax = 0.f;
-    for (int k = 0; k < 6; k++) emax = fmaxf(emax, fabsf(ev[k]));
-    const float rthr = 6.0f * FLT_EPSILON * emax;                  // rank rule eps*6 relative to the largest eigenvalue
-    bool plain = !(fabsf(ev[5] / ev[0]) > 1e6f);
-    for (int k = 0; k < 6; k++) plain = plain && (fabsf(ev[k]) > rthr);
     float cov[36], ps[6], dx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (plain) plain = icetdev::chol6_inverse(Hm, cov);
+    bool plain = icetdev::chol6_inverse(Hm, cov);
+    if (plain) {
+        float fa = 0.f, fi = 0.f;
+        for (int k = 0; k < 36; k++) { fa += Hm[k] * Hm[k]; fi += cov[k] * cov[k]; }
+        if (!(fa * fi <= 1e12f)) {                                  // bound inconclusive (or NaN): ask the eigenvalues
+            icetdev::eig6_sym<false>(Hm, ev, nullptr);
+            float emax = 0.f;
+            for (int k = 0; k < 6; k++) emax = fmaxf(emax, fabsf(ev[k]));
+            plain = !(fabsf(ev[5] / ev[0]) > 1e6f);
+            for (int k = 0; k < 6; k++) plain = plain && (fabsf(ev[k]) > 6.0f * FLT_EPSILON * emax);
+        }
+    }
     if (plain) {
         for (int k = 0; k < 6; k++) ps[k] = sqrtf(fabsf(cov[k * 6 + k]));         // src/icet.cpp:412-417
         for (int a = 0; a < 6; a++) { float t = 0.f; for (int b = 0; b < 6; b++) t += cov[a * 6 + b] * g[b]; dx[a] = t; }
     } else {
         float Q[36];
         icetdev::eig6_sym<true>(Hm, ev, Q);
+        float emax = 0.f;
+        for (int k = 0; k < 6; k++) emax = fmaxf(emax, fabsf(ev[k]));
+        const float rthr = 6.0f * FLT_EPSILON * emax;              // rank rule eps*6 relative to the largest eigenvalue
         // noise_mat = pinv(HTWH) (src/icet.cpp:410-411)
         float inv[6];
         for (int k = 0; k < 6; k++) inv[k] = (fabsf(ev[k]) > rthr) ? 1.f / ev[k] : 0.f;
@@ -1159,7 +1171,7 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
     }
     float Xn[6];
     for (int k = 0; k < 6; k++) { Xn[k] = X[k] + dx[k]; X[k] = Xn[k]; }
-    write_xf(xf_all + pair * 16, Xn);
+    write_xf(xf_all + pair * kXf, Xn);
     float* o = out + (size_t)pair * 48;
     for (int k = 0; k < 6; k++) { o[k] = Xn[k]; o[6 + k] = ps[k]; }
     for (int k = 0; k < 36; k++) o[12 + k] = cov[k];

@@ -261,6 +261,49 @@ def test_device_resident_batch_full_size(gpu_ctx):
     ctx.close()
 
 
+def _keyframe_vs_oracle(gpu_ctx, a, b):
+    from oracle import pyoracle as po
+    r = gpu_ctx.solve(a, b, 2, np.zeros(6), 24, 75, aux=True)
+    n = a.shape[0]
+    sph = po.c2s(a)
+    assert np.array_equal(gpu_ctx.debug_fetch("r", n).view(np.uint32), sph[:, 0].view(np.uint32))      # r bit-exact
+    assert np.array_equal(gpu_ctx.debug_fetch("src", n), po.scramble(sph[:, 0]))                       # sort + swap loop exact
+    ref = po.solve(a, b, runlen=2, trace=True)
+    assert np.array_equal(r["aux"]["n1_raw"], ref["trace"]["n1_raw"])
+    assert np.array_equal(r["aux"]["cluster_bounds"], ref["trace"]["bounds"])
+    return r, ref
+
+
+def test_rank_sort_and_scramble_corner_cases(gpu_ctx, frames):
+    """The hand-written rank sort and the parallel form of the reference's swap loop on inputs built to hit their
+    rare paths: (1) thousands of exactly equal keys (zero rows, more than an LDS bucket holds) -- stays in row order;
+    (2) a sample that aliases with the data so that ONE bucket receives almost every row with differing keys -- sorted
+    by the same code on global scratch; (3) a permutation whose descending chains are longer than the bounded walk --
+    the one-lane replay of the literal loop takes over (flag bit 0)."""
+    a, b = frames
+    rng = np.random.default_rng(42)
+    # (1) 9000 zero rows (signed zeros mixed) + real points
+    z = a.copy(); z[rng.choice(z.shape[0], 9000, replace=False)] = 0.0; z[::7] *= np.float32(1.0)
+    z[rng.choice(z.shape[0], 500, replace=False), 1] = -0.0
+    _keyframe_vs_oracle(gpu_ctx, z, b)
+    assert gpu_ctx.debug_fetch("flags", 1)[0] == 0
+    # (2) every sampled position (stride = ceil(n / 2048)) holds the same radius -> all splitters equal
+    n = a.shape[0]; stride = (n + 2047) // 2048
+    c = a.copy()
+    d = c[::stride]; nrm = np.linalg.norm(d, axis=1, keepdims=True); nrm[nrm == 0] = 1
+    c[::stride] = (d / nrm * np.float32(5.0)).astype(np.float32)
+    rr = np.linalg.norm(c[::stride].astype(np.float64), axis=1)
+    assert np.unique(np.sqrt((c[::stride].astype(np.float32) ** 2).sum(1, dtype=np.float32))).size < 50      # (nearly) one key in the sample
+    _keyframe_vs_oracle(gpu_ctx, c, b)
+    # (3) radii that make s a long shift: rank(i) = i + 1 (mod n) -> descending chains of length ~n
+    m = 20000
+    ang = rng.uniform(0, 2 * np.pi, m); el = rng.uniform(-0.3, 0.3, m)
+    rad = (5.0 + 1e-3 * ((np.arange(m) + 1) % m)).astype(np.float32)
+    p = np.stack([rad * np.cos(el) * np.cos(ang), rad * np.cos(el) * np.sin(ang), rad * np.sin(el)], 1).astype(np.float32)
+    _keyframe_vs_oracle(gpu_ctx, p, p)
+    assert gpu_ctx.debug_fetch("flags", 1)[0] & 1          # the bounded walk overflowed and the serial replay ran
+
+
 def test_icet_class_mirrors_reference_members(frames, frames_golden):
     import icet_amd
     a, b = frames

@@ -171,7 +171,8 @@ def main():
     bytes_path = sum(12.0 * a + 12.0 * b * iters + 192.0 for a, b in zip(n1, n2))
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and args.workload == "batch" and n_local == 256 and args.distinct == 0:
+        # PMC numbers are collected by profiles/collect.sh on exactly this workload (256 distinct pairs per GPU)
         try:
             traffic = json.load(open(tpath)).get("k_gn_accumulate_bytes_per_launch")
         except Exception:

@@ -84,7 +84,7 @@ struct LaunchCfg {
     int n_pairs;
     int max_n1, max_n2;
     int64_t total_n1;
-    int lds_slots = 288;              // active voxels kept in LDS by k_gn_accumulate (the rest go straight to HBM)
+    int lds_slots = 0;   /* 0 = sized from the LDS budget in launch_gn_accumulate */              // active voxels kept in LDS by k_gn_accumulate (the rest go straight to HBM)
     int acc_min_pts_per_thread = 8;   // launch shaping of k_gn_accumulate
     int acc_target_blocks = 2048;
     int kf_chunks = 1;                // tiles per pair in the keyframe kernels (set by the host from max_n1)

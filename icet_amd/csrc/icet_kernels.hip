@@ -834,8 +834,8 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
         uint2* ll = reinterpret_cast<uint2*>(lut_t);
         for (int i = threadIdx.x; i < Mt + Mp + 2; i += kAccBlock) ll[i] = gl[i];
         for (int i = threadIdx.x; i < nl * 5; i += kAccBlock) { int s = i / 5, k = i - s * 5; hot[i] = reinterpret_cast<const float*>(hs + s)[4 + k]; }
-        for (int i = threadIdx.x; i < 9 * lds_slots; i += kAccBlock) lsum[i] = 0ull;
-        for (int i = threadIdx.x; i < 2 * lds_slots; i += kAccBlock) lraw[i] = 0u;
+        for (int i = threadIdx.x; i < 9 * nl; i += kAccBlock) lsum[(i / nl) * lds_slots + (i % nl)] = 0ull;   // only the rows in use
+        for (int i = threadIdx.x; i < nl; i += kAccBlock) { lraw[i] = 0u; lin[i] = 0u; }
     }
     const float* xf = xf_all + pair * kXf;
     const float tx = xf[0], ty = xf[1], tz = xf[2];
@@ -1252,9 +1252,25 @@ hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float
 }
 
 hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
-    const int lds_slots = c.lds_slots;
+    // LDS rows for active voxels: a throughput batch keeps 320 rows (measured optimum on 64-channel scans: fewer rows
+    // spill busy voxels to HBM atomics, more rows cost occupancy); a small batch has
+    // CUs to spare, so a block may take most of a CU's LDS and keep every active voxel of a fine grid (150 x 48: often
+    // > 1000) out of the slow HBM-atomic path.
+    const size_t fixed = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)((c.V + c.T + 4) / 2) * 4 + 16;
+    const size_t row = (5 + kAccLds) * 4;
+    const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : 144 * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU
+    int lds_slots = c.lds_slots > 0 ? c.lds_slots : (int)((budget > fixed ? budget - fixed : 0) / row);
+    lds_slots = lds_slots < 32 ? 32 : lds_slots;
+    if (lds_slots > c.V) lds_slots = c.V;
     const int chunks = chunks_for(c.n_pairs, c.max_n2, kAccBlock * c.acc_min_pts_per_thread, c.acc_target_blocks);
-    const size_t lds = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)lds_slots * (5 + kAccLds) * 4 + (size_t)((c.V + c.T + 4) / 2) * 4 + 16;
+    const size_t lds = fixed + (size_t)lds_slots * (5 + kAccLds) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ea == hipSuccess) ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ea != hipSuccess) return ea;
+        attr_set = true;
+    }
     const int groups = c.n_pairs >= 8 ? (c.n_pairs + 7) / 8 * 8 : c.n_pairs;
     dim3 grid(groups * chunks), blk(kAccBlock);
     const LutCell* lut = reinterpret_cast<const LutCell*>(w.lut);

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libicet_hip.so")
+LIB_PATH = os.environ.get("ICET_HIP_LIB") or os.path.join(_HERE, "lib", "libicet_hip.so")   # override: kernel experiments only
 
 ICET_OK, ICET_ERR_BAD_ARG, ICET_ERR_NO_DEVICE, ICET_ERR_HIP, ICET_ERR_NOMEM, ICET_ERR_UNSUPPORTED = range(6)
 _STATUS_NAMES = {0: "ICET_OK", 1: "ICET_ERR_BAD_ARG", 2: "ICET_ERR_NO_DEVICE", 3: "ICET_ERR_HIP", 4: "ICET_ERR_NOMEM", 5: "ICET_ERR_UNSUPPORTED"}

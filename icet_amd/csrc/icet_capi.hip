@@ -160,7 +160,8 @@ icet_status ensure_thresholds(icet_ctx* c, int T, int P) {
         std::vector<HostCell> lt, lp;
         const int Mt = build_lut(et, 0.0, 4.0, lt), Mp = build_lut(ep, -1.0, 2.0, lp);
         // one spare cell per table: pa == 4 / w == 1 index cell M (it names the last edge, so the point goes to the literal path)
-        std::vector<HostCell> all(lt); all.push_back(HostCell{4.0f, T}); all.insert(all.end(), lp.begin(), lp.end()); all.push_back(HostCell{1.0f, P});
+        for (HostCell& c : lp) c.idx *= T;                                 // polar cells carry the map row offset T * edge index
+        std::vector<HostCell> all(lt); all.push_back(HostCell{4.0f, T}); all.insert(all.end(), lp.begin(), lp.end()); all.push_back(HostCell{1.0f, P * T});
         if (w.lut) { HIPCHK(c, hipFree(w.lut)); w.lut = nullptr; }
         HIPCHK(c, hipMalloc(&w.lut, all.size() * sizeof(HostCell)));
         HIPCHK(c, hipMemcpy(w.lut, all.data(), all.size() * sizeof(HostCell), hipMemcpyHostToDevice));

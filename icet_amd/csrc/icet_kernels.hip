@@ -853,7 +853,8 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
             X[0] = a.x; X[1] = a.y; X[2] = a.z; X[3] = a.w; Y[0] = b.x; Y[1] = b.y; Y[2] = b.z; Y[3] = b.w; Z[0] = c.x; Z[1] = c.y; Z[2] = c.z; Z[3] = c.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) { const bool ok = i0 + j < end; X[j] = ok ? px[i0 + j] : 0.f; Y[j] = ok ? py[i0 + j] : 0.f; Z[j] = ok ? pz[i0 + j] : 0.f; }
+            // past the end: NaN coordinates fail every guard-band test below, so the point drops out in phase B without a per-point range check
+            for (int j = 0; j < 4; j++) { const bool ok = i0 + j < end; X[j] = ok ? px[i0 + j] : __builtin_nanf(""); Y[j] = ok ? py[i0 + j] : 0.f; Z[j] = ok ? pz[i0 + j] : 0.f; }
         }
     };
     // Software pipeline across trips: the loads of trip t+1 are in flight while trip t is classified.  With the scans
@@ -925,9 +926,9 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
             const LutCell et = lut_t[static_cast<int>(pa * cell_t)];     // NaN converts to 0; pa in [0,4] -> cell in [0, Mt]
             const LutCell ep = lut_p[static_cast<int>((w + 1.f) * cell_p)];
             const int bt = et.idx - ((pa < et.edge) ? 1 : 0);            // in [0, T]
-            const int bp = ep.idx - ((w < ep.edge) ? 1 : 0);             // in [0, P]
-            SM[j] = map[T * bp + bt];
-            nr[j] = (force_exact != 0) | (i0 + j >= end) | !(fabsf(pa - et.edge) >= guard_t) | !(fabsf(w - ep.edge) >= guard_p);
+            const int row = ep.idx - ((w < ep.edge) ? T : 0);            // T * polar bin, polar bin in [0, P] (the table stores T * edge index)
+            SM[j] = map[row + bt];
+            nr[j] = (force_exact != 0) | !(fabsf(pa - et.edge) >= guard_t) | !(fabsf(w - ep.edge) >= guard_p);
         }
         // ---- phase A2: only waves that touch an active voxel look at the hot records (radial test, d = q - mu1) ----
         const bool lane_has = ((SM[0] >= 0) & !nr[0]) | ((SM[1] >= 0) & !nr[1]) | ((SM[2] >= 0) & !nr[2]) | ((SM[3] >= 0) & !nr[3]);

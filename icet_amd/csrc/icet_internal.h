@@ -89,6 +89,8 @@ struct LaunchCfg {
     int acc_target_blocks = 2048;
     int kf_chunks = 1;                // tiles per pair in the keyframe kernels (set by the host from max_n1)
     int kf_pts_per_thread = 8;        // keyframe kernels: points per thread (sets chunks per pair)
+    hipEvent_t stage_event = nullptr; /* recorded inside launch_keyframe after stage `stage_at` (4 spherical, 1 sort, 2 scramble, 3 gather): lets the next batch part start there */
+    int stage_at = 0;
     int use_library_sort = 0;         // diagnostic: rocPRIM device radix sort instead of the hand-written rank sort
     int vec4_ok = 0;                  // every scan-2 pointer and leading dimension is 16-byte aligned
     int force_exact = 0;              // diagnostic: route every point through the literal evaluation

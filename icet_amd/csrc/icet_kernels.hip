@@ -1205,6 +1205,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     const bool batch = c.n_pairs > 1;
     k_scan1_spherical<<<grid, blk, 0, st>>>(w.desc, w.r1, w.th1, w.ph1, (batch && c.use_library_sort) ? w.key64A : nullptr, c.use_library_sort ? w.keyA : nullptr, w.valA, w.bin16, c.T, c.P, np, chunks);
     ICET_LAUNCH_CHECK();
+    if (c.stage_event && c.stage_at == 4) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     if (c.use_library_sort) {
         if (batch) e = sort_pairs_u64(w.sort_tmp, w.sort_tmp_bytes, w.key64A, w.key64B, w.valA, w.valB, c.total_n1, 32 + pbits, st);
         else e = sort_pairs_u32(w.sort_tmp, w.sort_tmp_bytes, w.keyA, w.keyB, w.valA, w.valB, c.total_n1, 32, st);
@@ -1216,6 +1217,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
         e = launch_rank_sort(w, c, st);        // valB = s, pred = s^-1  (icet_ranksort.hip)
         if (e != hipSuccess) return e;
     }
+    if (c.stage_event && c.stage_at == 1) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     e = hipMemsetAsync(w.flags, 0, sizeof(int32_t) * c.n_pairs, st); if (e != hipSuccess) return e;
     const int max_walk = 4096;
     k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.exec, w.flags, max_walk, np, chunks);
@@ -1224,6 +1226,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     ICET_LAUNCH_CHECK();
     k_scramble_serial<<<c.n_pairs, 64, 0, st>>>(w.desc, w.valB, w.pred /* reused as scratch */, w.src, w.flags);
     ICET_LAUNCH_CHECK();
+    if (c.stage_event && c.stage_at == 2) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, w.flags, c.V, np, chunks);
     ICET_LAUNCH_CHECK();
     k_bin_scan<<<c.n_pairs, blk, 0, st>>>(w.counts, w.tile_base, w.bin_start, c.V, chunks);
@@ -1232,6 +1235,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     ICET_LAUNCH_CHECK();
     k_gather_sorted<<<grid, blk, 0, st>>>(w.desc, w.valA, w.r1, w.th1, w.ph1, w.rs, w.ths, w.phs, np, chunks);
     ICET_LAUNCH_CHECK();
+    if (c.stage_event && c.stage_at == 3) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     dim3 gfit((c.V + kBlock / 64 - 1) / (kBlock / 64), c.n_pairs);
     k_fit_scan1<<<gfit, blk, 0, st>>>(w.desc, w.bin_start, w.rs, w.ths, w.phs, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n, c.thresh, c.buff);
     ICET_LAUNCH_CHECK();

@@ -11,6 +11,7 @@ Tolerances (float32 path, stated per SURVEY.md section 8(c)):
     the 7-iteration loop amplifies it: the oracle's own float64 NumPy twin differs from it by 7e-5 m);
   * pred_stds / cov: 1 % relative.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -256,6 +257,24 @@ def test_device_resident_batch_full_size(gpu_ctx):
         single = gpu_ctx.solve(pairs[k][0].T.cpu().numpy(), pairs[k][1].T.cpu().numpy(), 7, np.zeros(6), 24, 75)
         block = res[k::4]
         assert (block[:, :6] == single["X"]).all() and (block[:, 6:12] == single["pred_stds"]).all()   # bitwise, see above
+    # A batch this large is cut into parts that run on helper streams (icet_capi.hip, batch_parts): the cut must not show.
+    # Per-pair X0 checks that each part reads its own slice of x0 / writes its own slice of the output.
+    x0 = torch.zeros((4 * n_rep, 6), dtype=torch.float32, device=dev)
+    x0[:, 0] = 0.01 * (torch.arange(4 * n_rep, device=dev) % 7).float(); x0[:, 5] = 0.001 * (torch.arange(4 * n_rep, device=dev) % 3).float()
+    outs = {}
+    for parts in ("1", "2", "3"):
+        os.environ["ICET_BATCH_PARTS"] = parts
+        try:
+            o = torch.zeros_like(out)
+            ctx.solve_batch_device(d1, d2, p, o.data_ptr(), x0.data_ptr())
+            ctx.sync()
+            outs[parts] = o.cpu().numpy()
+        finally:
+            del os.environ["ICET_BATCH_PARTS"]
+    assert np.array_equal(outs["1"], outs["2"]) and np.array_equal(outs["1"], outs["3"])
+    j = 4 * n_rep - 3                                      # a pair in the last part, with its own X0
+    single = gpu_ctx.solve(pairs[j % 4][0].T.cpu().numpy(), pairs[j % 4][1].T.cpu().numpy(), 7, x0[j].cpu().numpy(), 24, 75)
+    assert np.array_equal(outs["3"][j, :6], single["X"])
     ref = po.solve(pairs[0][0].T.cpu().numpy(), pairs[0][1].T.cpu().numpy())
     _check_solution(dict(X=res[0, :6], pred_stds=res[0, 6:12], cov=res[0, 12:].reshape(6, 6)), ref)
     ctx.close()

@@ -19,9 +19,12 @@ ICET_OK, ICET_ERR_BAD_ARG, ICET_ERR_NO_DEVICE, ICET_ERR_HIP, ICET_ERR_NOMEM, ICE
 _STATUS_NAMES = {0: "ICET_OK", 1: "ICET_ERR_BAD_ARG", 2: "ICET_ERR_NO_DEVICE", 3: "ICET_ERR_HIP", 4: "ICET_ERR_NOMEM", 5: "ICET_ERR_UNSUPPORTED"}
 FLAG_TIMING = 1
 
-# every symbol include/icet_hip.h declares
+# every symbol include/icet_hip.h and include/icet_nodes.h declare
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_batch",
-                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch")
+                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch",
+                    "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_map",
+                    "icet_node_prev_scan", "icet_node_last_timing", "icet_stream", "icet_device")
+_NON_STATUS = ("icet_version", "icet_last_error", "icet_stream", "icet_device")
 
 
 class IcetError(RuntimeError):
@@ -33,6 +36,17 @@ class IcetError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("runlen", C.c_int32), ("bins_phi", C.c_int32), ("bins_theta", C.c_int32), ("n", C.c_int32),
                 ("thresh", C.c_float), ("buff", C.c_float), ("flags", C.c_int32)]
+
+
+class NodeParams(C.Structure):
+    """icet_node_params (include/icet_nodes.h)."""
+    _fields_ = [("solve", Params), ("min_range", C.c_float), ("seed_x0", C.c_int32), ("trans_thresh", C.c_float), ("rot_thresh", C.c_float),
+                ("map_capacity", C.c_int32), ("map_downsample", C.c_int32)]
+
+
+class NodeResult(C.Structure):
+    _fields_ = [("solved", C.c_int32), ("diverged", C.c_int32), ("n_kept", C.c_int64), ("X", C.c_float * 6), ("pred_stds", C.c_float * 6),
+                ("pose", C.c_float * 16), ("quat", C.c_float * 4), ("map_rows", C.c_int64)]
 
 
 class DevScan(C.Structure):
@@ -74,9 +88,18 @@ def load_library():
     L.icet_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.POINTER(DevScan), C.c_void_p, C.c_void_p]
     L.icet_last_timing.argtypes = [C.c_void_p, C.c_void_p]
     L.icet_debug_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    L.icet_node_create.argtypes = [C.c_void_p, C.POINTER(NodeParams), C.POINTER(C.c_void_p)]
+    L.icet_node_destroy.argtypes = [C.c_void_p]
+    L.icet_node_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(NodeResult)]
+    L.icet_node_push_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(NodeResult)]
+    L.icet_node_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.icet_node_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+    L.icet_node_prev_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.icet_stream.argtypes = [C.c_void_p]; L.icet_stream.restype = C.c_void_p
+    L.icet_device.argtypes = [C.c_void_p]; L.icet_device.restype = C.c_int
     for name in EXPORTED_SYMBOLS:
         getattr(L, name)
-        if name not in ("icet_version", "icet_last_error"):
+        if name not in _NON_STATUS:
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -103,6 +126,11 @@ class Context:
         self.device = device
 
     def close(self):
+        for ref in getattr(self, "_nodes", []):          # nodes borrow this context: they go first
+            nd = ref()
+            if nd is not None:
+                nd.close()
+        self._nodes = []
         if getattr(self, "_h", None):
             load_library().icet_destroy(self._h)
             self._h = None
@@ -239,3 +267,104 @@ class ICET:
                 xprev = np.asarray(X0, np.float32).reshape(6) if runlen == 1 else a["x_hist"][runlen - 2]
                 self.dx = a["x_hist"][runlen - 1] - xprev
                 self.points2 = (np.asarray(scan2, np.float32) + xprev[:3]) @ euler_R(xprev[3], xprev[4], xprev[5])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The callers around the constructor (include/icet_nodes.h): the per-frame body of the reference's odometry_node and
+# map_maker_node (src/odometry.cpp:46-98, src/simpleMapMaker.cpp:86-172), state kept in HBM between frames.
+ODOMETRY_NODE = dict(runlen=7, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1, min_range=2.0, seed_x0=1,
+                     trans_thresh=0.0, rot_thresh=0.0, map_capacity=0, map_downsample=0)              # src/odometry.cpp:58,73-82
+MAP_MAKER_NODE = dict(runlen=12, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1, min_range=0.2, seed_x0=0,
+                      trans_thresh=0.3, rot_thresh=0.3, map_capacity=600000, map_downsample=2000)      # src/simpleMapMaker.cpp:62,98,113-124,147,241-242
+
+
+def node_params(**kw):
+    d = dict(ODOMETRY_NODE); d.update(kw)
+    return NodeParams(Params(d["runlen"], d["bins_phi"], d["bins_theta"], d["n"], d["thresh"], d["buff"], 0), d["min_range"], d["seed_x0"],
+                      d["trans_thresh"], d["rot_thresh"], d["map_capacity"], d["map_downsample"])
+
+
+def _result_dict(r):
+    return dict(solved=bool(r.solved), diverged=bool(r.diverged), n_kept=int(r.n_kept), X=np.array(r.X[:], np.float32),
+                pred_stds=np.array(r.pred_stds[:], np.float32), pose=np.array(r.pose[:], np.float32).reshape(4, 4),
+                quat=np.array(r.quat[:], np.float32), map_rows=int(r.map_rows))
+
+
+class Node:
+    """``icet_node``: feed lidar frames one by one; every frame after the first returns X, pred_stds and the chained pose."""
+
+    def __init__(self, ctx=None, device=0, **kw):
+        self._ctx = ctx if ctx is not None else Context(device)
+        self._p = node_params(**kw)
+        h = C.c_void_p()
+        st = load_library().icet_node_create(self._ctx._h, C.byref(self._p), C.byref(h))
+        if st != ICET_OK:
+            raise IcetError(st, "icet_node_create")
+        self._h = h
+        import weakref
+        if not hasattr(self._ctx, "_nodes"):
+            self._ctx._nodes = []
+        self._ctx._nodes.append(weakref.ref(self))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().icet_node_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, scan):
+        """scan: N x 3 host array."""
+        a = _colmajor(scan)
+        r = NodeResult()
+        st = load_library().icet_node_push(self._h, a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[1], C.byref(r))
+        if st != ICET_OK:
+            raise IcetError(st, "icet_node_push")
+        return _result_dict(r)
+
+    def push_device(self, d_ptr, n, ld):
+        """scan already in HBM on the context's device: column-major N x 3, leading dimension ld."""
+        r = NodeResult()
+        st = load_library().icet_node_push_device(self._h, C.c_void_p(int(d_ptr)), int(n), int(ld), C.byref(r))
+        if st != ICET_OK:
+            raise IcetError(st, "icet_node_push_device")
+        return _result_dict(r)
+
+    def map(self):
+        """``EigenQueue::getQueue()``: rows x 3, oldest first."""
+        rows = C.c_int64()
+        L = load_library()
+        st = L.icet_node_map(self._h, None, 0, C.byref(rows))
+        if st != ICET_OK:
+            raise IcetError(st, "icet_node_map")
+        out = np.zeros((3, max(rows.value, 1)), np.float32)
+        if rows.value:
+            st = L.icet_node_map(self._h, out.ctypes.data_as(C.c_void_p), rows.value, C.byref(rows))
+            if st != ICET_OK:
+                raise IcetError(st, "icet_node_map")
+        return np.ascontiguousarray(out[:, :rows.value].T)
+
+    def prev_scan(self):
+        """The node's ``prev_pcl_matrix``: rows x 3."""
+        rows = C.c_int64()
+        L = load_library()
+        st = L.icet_node_prev_scan(self._h, None, 0, C.byref(rows))
+        if st != ICET_OK:
+            raise IcetError(st, "icet_node_prev_scan")
+        out = np.zeros((3, max(rows.value, 1)), np.float32)
+        if rows.value:
+            st = L.icet_node_prev_scan(self._h, out.ctypes.data_as(C.c_void_p), rows.value, C.byref(rows))
+            if st != ICET_OK:
+                raise IcetError(st, "icet_node_prev_scan")
+        return np.ascontiguousarray(out[:, :rows.value].T)
+
+    def last_timing(self):
+        t = (C.c_float * 3)()
+        st = load_library().icet_node_last_timing(self._h, t)
+        if st != ICET_OK:
+            raise IcetError(st, "icet_node_last_timing")
+        return dict(filter_ms=t[0], solve_ms=t[1], map_ms=t[2])

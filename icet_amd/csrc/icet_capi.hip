@@ -5,6 +5,7 @@
 // implementation of the algorithm lives here: if the device or the kernels are unavailable every
 // entry point returns ICET_ERR_NO_DEVICE / ICET_ERR_HIP.
 #include "../../include/icet_hip.h"
+#include "../../include/icet_nodes.h"
 #include "icet_internal.h"
 
 #include <hip/hip_runtime.h>
@@ -567,6 +568,9 @@ icet_status icet_debug_fetch(icet_ctx* c, int32_t what, void* out, int64_t count
     HIPCHK(c, hipMemcpy(out, src, (size_t)count * 4, hipMemcpyDeviceToHost));
     return ICET_OK;
 }
+
+void* icet_stream(icet_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
+int icet_device(const icet_ctx* c) { return c ? c->device : -1; }
 
 icet_status icet_last_timing(icet_ctx* c, float out_ms[4]) {
     if (!c || !out_ms) return ICET_ERR_BAD_ARG;

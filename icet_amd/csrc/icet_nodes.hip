@@ -1,0 +1,442 @@
+// icet_amd/csrc/icet_nodes.hip -- the callers on either side of the hot path, on the device (include/icet_nodes.h):
+// the per-frame body of the reference's odometry_node / map_maker_node (src/odometry.cpp:46-98,
+// src/simpleMapMaker.cpp:86-172) and the HD-map FIFO `EigenQueue` (src/simpleMapMaker.cpp:18-59).
+//
+// Built only on the public C ABI of icet_hip.h (one single-pair icet_solve_batch_device per frame) plus three small
+// HBM-bound kernels of its own:
+//   k_range_count / k_range_scan / k_range_scatter   the `row.norm() > minD` filter as a stable stream compaction
+//                                                    (12 B read twice + 12 B written per kept row)
+//   k_map_add_scan                                    EigenQueue::add_new_scan: the down-sampled rows enter the ring and
+//                                                    the whole ring is re-expressed as (row - t) * R^-1 in ONE pass
+//                                                    (12 B read + 12 B written per ring row)
+// Host-side scalar work (pose chaining, quaternion, the 3x3 inverse, std::shuffle of the index vector) stays on the
+// host as in the reference: it is O(1) or inherently sequential (Fisher-Yates with one RNG stream).
+// No CPU implementation of the solve lives here; without a device every entry point fails with an error status.
+#include "../../include/icet_nodes.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <random>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int kFB = 256;            // threads per block of the filter kernels
+constexpr int kFRows = 8;           // rows per thread: a block owns 2048 consecutive rows
+
+__device__ __forceinline__ bool keep_row(float x, float y, float z, float min_range) {
+    float d;
+    {
+#pragma clang fp contract(off)
+        float s = x * x + y * y;      // Eigen's row(i).norm(): sqrt of the plain sum of squares (src/odometry.cpp:61-64)
+        s = s + z * z;
+        d = sqrtf(s);
+    }
+    return d > min_range;
+}
+
+// pass 1: kept rows per block
+__global__ __launch_bounds__(kFB) void k_range_count(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+                                                    float min_range, int32_t* __restrict__ counts) {
+    __shared__ int wsum[kFB / 64];
+    const int base = blockIdx.x * kFB * kFRows;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kFRows; k++) {
+        const int i = base + k * kFB + threadIdx.x;
+        if (i < n) c += keep_row(x[i], y[i], z[i], min_range) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kFB / 64; w++) t += wsum[w]; counts[blockIdx.x] = t; }
+}
+
+// pass 2: exclusive scan of the block counts (one block; at most a few thousand entries), total -> n_kept
+__global__ __launch_bounds__(kFB) void k_range_scan(const int32_t* __restrict__ counts, int32_t* __restrict__ bases, int n_blocks, int32_t* __restrict__ n_kept) {
+    __shared__ int part[kFB];
+    const int per = (n_blocks + kFB - 1) / kFB;
+    const int lo = threadIdx.x * per, hi = min(n_blocks, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; i++) s += counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int t = 0; t < kFB; t++) { const int v = part[t]; part[t] = run; run += v; } *n_kept = run; }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; i++) { bases[i] = run; run += counts[i]; }
+}
+
+// pass 3: stable scatter.  Row order inside a block is k-major (row = base + k * kFB + thread), so the rank of a kept
+// row is: kept rows in earlier k-slices + kept rows of lower threads in its own slice.
+__global__ __launch_bounds__(kFB) void k_range_scatter(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+                                                      float min_range, const int32_t* __restrict__ bases,
+                                                      float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz) {
+    __shared__ int wcnt[kFRows][kFB / 64];
+    const int base = blockIdx.x * kFB * kFRows;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float vx[kFRows], vy[kFRows], vz[kFRows];
+    bool keep[kFRows];
+    int below[kFRows];
+#pragma unroll
+    for (int k = 0; k < kFRows; k++) {
+        const int i = base + k * kFB + threadIdx.x;
+        keep[k] = false; vx[k] = vy[k] = vz[k] = 0.f;
+        if (i < n) { vx[k] = x[i]; vy[k] = y[i]; vz[k] = z[i]; keep[k] = keep_row(vx[k], vy[k], vz[k], min_range); }
+        const unsigned long long m = __ballot(keep[k]);
+        below[k] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[k][wave] = __popcll(m);
+    }
+    __syncthreads();
+    int run = bases[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kFRows; k++) {
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kFB / 64; w++) { const int cw = wcnt[k][w]; before += (w < wave) ? cw : 0; total += cw; }
+        if (keep[k]) { const int o = run + before + below[k]; ox[o] = vx[k]; oy[o] = vy[k]; oz[o] = vz[k]; }
+        run += total;
+    }
+}
+
+// EigenQueue::add_new_scan (src/simpleMapMaker.cpp:34-41): rows [pos, pos + m) (mod cap) take the down-sampled scan
+// rows, then EVERY ring row becomes (row - trans) * Rinv.  One pass over the ring.
+__global__ __launch_bounds__(256) void k_map_add_scan(float* __restrict__ qx, float* __restrict__ qy, float* __restrict__ qz, int cap, int pos, int m,
+                                                     const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                                                     const int32_t* __restrict__ idx, float tx, float ty, float tz,
+                                                     float i00, float i01, float i02, float i10, float i11, float i12, float i20, float i21, float i22) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
+        int j = i - pos; if (j < 0) j += cap;             // position in this frame's write window
+        float a, b, c;
+        if (j < m) { const int r = idx[j]; a = sx[r]; b = sy[r]; c = sz[r]; }
+        else { a = qx[i]; b = qy[i]; c = qz[i]; }
+        a -= tx; b -= ty; c -= tz;
+        {
+#pragma clang fp contract(off)
+            qx[i] = (a * i00 + b * i10) + c * i20;
+            qy[i] = (a * i01 + b * i11) + c * i21;
+            qz[i] = (a * i02 + b * i12) + c * i22;
+        }
+    }
+}
+
+// getQueue (src/simpleMapMaker.cpp:43-50): oldest row first
+__global__ __launch_bounds__(256) void k_map_unroll(const float* __restrict__ qx, const float* __restrict__ qy, const float* __restrict__ qz, int cap, int pos,
+                                                   int filled, int rows, float* __restrict__ out, int ld) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) {
+        const int s = filled ? (pos + i) % cap : i;
+        out[i] = qx[s]; out[ld + i] = qy[s]; out[2 * (size_t)ld + i] = qz[s];
+    }
+}
+
+// utils::R (src/utils.cpp:144-152) in host float arithmetic, as the nodes evaluate it (odometry.cpp:85)
+void euler_R_host(float phi, float theta, float psi, float* R) {
+    const float cph = std::cos(phi), sph = std::sin(phi), cth = std::cos(theta), sth = std::sin(theta), cps = std::cos(psi), sps = std::sin(psi);
+    R[0] = cth * cps;  R[1] = sps * cph + sph * sth * cps;  R[2] = sph * sps - sth * cph * cps;
+    R[3] = -sps * cth; R[4] = cph * cps - sph * sth * sps;  R[5] = sph * cps + sth * sps * cph;
+    R[6] = sth;        R[7] = -sph * cth;                   R[8] = cph * cth;
+}
+
+// MatrixXf::inverse() of a dynamic matrix goes through PartialPivLU (Eigen/src/LU/InverseImpl.h): LU with row pivoting,
+// then the two triangular solves against the permuted identity.
+void inverse3_lu(const float* A, float* inv) {
+    float lu[9]; std::memcpy(lu, A, sizeof(lu));
+    int perm[3] = {0, 1, 2};
+    for (int k = 0; k < 3; k++) {
+        int piv = k; float best = std::fabs(lu[k * 3 + k]);
+        for (int r = k + 1; r < 3; r++) if (std::fabs(lu[r * 3 + k]) > best) { best = std::fabs(lu[r * 3 + k]); piv = r; }
+        if (piv != k) { for (int c = 0; c < 3; c++) std::swap(lu[k * 3 + c], lu[piv * 3 + c]); std::swap(perm[k], perm[piv]); }
+        if (lu[k * 3 + k] == 0.f) continue;
+        for (int r = k + 1; r < 3; r++) {
+            lu[r * 3 + k] /= lu[k * 3 + k];
+            for (int c = k + 1; c < 3; c++) lu[r * 3 + c] -= lu[r * 3 + k] * lu[k * 3 + c];
+        }
+    }
+    for (int col = 0; col < 3; col++) {
+        float b[3];
+        for (int r = 0; r < 3; r++) b[r] = (perm[r] == col) ? 1.f : 0.f;
+        for (int r = 1; r < 3; r++) for (int c = 0; c < r; c++) b[r] -= lu[r * 3 + c] * b[c];
+        for (int r = 2; r >= 0; r--) { for (int c = r + 1; c < 3; c++) b[r] -= lu[r * 3 + c] * b[c]; b[r] /= lu[r * 3 + r]; }
+        for (int r = 0; r < 3; r++) inv[r * 3 + col] = b[r];
+    }
+}
+
+// Eigen::Quaternionf(Matrix3f) (Eigen/src/Geometry/Quaternion.h, Shoemake's method); q = x, y, z, w
+void quat_of(const float* P /* 4x4 row-major */, float q[4]) {
+    const float m00 = P[0], m01 = P[1], m02 = P[2], m10 = P[4], m11 = P[5], m12 = P[6], m20 = P[8], m21 = P[9], m22 = P[10];
+    const float m[3][3] = {{m00, m01, m02}, {m10, m11, m12}, {m20, m21, m22}};
+    float t = m00 + m11 + m22;
+    if (t > 0.f) {
+        t = std::sqrt(t + 1.0f); q[3] = 0.5f * t; t = 0.5f / t;
+        q[0] = (m21 - m12) * t; q[1] = (m02 - m20) * t; q[2] = (m10 - m01) * t;
+    } else {
+        int i = 0;
+        if (m11 > m00) i = 1;
+        if (m22 > m[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0f);
+        q[i] = 0.5f * t; t = 0.5f / t;
+        q[3] = (m[k][j] - m[j][k]) * t; q[j] = (m[j][i] + m[i][j]) * t; q[k] = (m[k][i] + m[i][k]) * t;
+    }
+}
+
+}  // namespace
+
+struct icet_node {
+    icet_ctx* ctx = nullptr;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    icet_node_params p{};
+    std::string err;
+    bool initialized = false;
+    // previous / current filtered scan (column-major, ld = cap rounded to 64)
+    float* d_scan[2] = {nullptr, nullptr}; int64_t cap_scan[2] = {0, 0}; int64_t n_scan[2] = {0, 0}; int64_t ld_scan[2] = {0, 0};
+    int prev = 0;
+    float* d_stage = nullptr; int64_t cap_stage = 0;              // host scans land here first
+    int32_t* d_counts = nullptr; int32_t* d_bases = nullptr; int cap_blocks = 0;
+    int32_t* d_nkept = nullptr; int32_t* h_nkept = nullptr;
+    float* d_x0 = nullptr; float* d_out = nullptr; float* h_out = nullptr; float* h_x0 = nullptr;
+    float X0[6] = {0, 0, 0, 0, 0, 0};
+    float pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::mt19937 gen;                                              // default seed: simpleMapMaker.cpp:258
+    std::vector<std::size_t> indices;
+    float* d_map = nullptr; int64_t map_pos = 0; bool map_filled = false;
+    int32_t* d_idx = nullptr; int32_t* h_idx = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timing_valid = false, timed_map = false;
+};
+
+namespace {
+
+#define NCHK(nd, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (nd)->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+    return e_ == hipErrorOutOfMemory ? ICET_ERR_NOMEM : ICET_ERR_HIP; } } while (0)
+
+icet_status ensure_scan(icet_node* nd, int which, int64_t n) {
+    if (n <= nd->cap_scan[which]) return ICET_OK;
+    NCHK(nd, hipStreamSynchronize(nd->stream));
+    if (nd->d_scan[which]) { NCHK(nd, hipFree(nd->d_scan[which])); nd->d_scan[which] = nullptr; }
+    const int64_t cap = (n + n / 8 + 63) / 64 * 64;
+    NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_scan[which]), sizeof(float) * 3 * (size_t)cap));
+    nd->cap_scan[which] = cap;
+    return ICET_OK;
+}
+
+// One frame with the raw scan already in HBM (column-major, ld).
+icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t ld, icet_node_result* res) {
+    std::memset(res, 0, sizeof(*res));
+    hipStream_t st = nd->stream;
+    const int cur = nd->prev ^ 1;
+    nd->timing_valid = false;
+    if (!nd->initialized) {
+        // odometry.cpp:46-52: the first cloud is stored as it is (no range filter) and nothing is solved
+        icet_status s = ensure_scan(nd, nd->prev, n); if (s != ICET_OK) return s;
+        const int64_t l = nd->cap_scan[nd->prev];
+        if (n) NCHK(nd, hipMemcpy2DAsync(nd->d_scan[nd->prev], l * sizeof(float), d_scan, ld * sizeof(float), n * sizeof(float), 3, hipMemcpyDeviceToDevice, st));
+        NCHK(nd, hipStreamSynchronize(st));
+        nd->n_scan[nd->prev] = n; nd->ld_scan[nd->prev] = l;
+        nd->initialized = true;
+        res->solved = 0; res->n_kept = n;
+        std::memcpy(res->pose, nd->pose, sizeof(nd->pose)); quat_of(nd->pose, res->quat);
+        res->map_rows = nd->map_filled ? nd->p.map_capacity : nd->map_pos;
+        return ICET_OK;
+    }
+    // ---- range filter: stable compaction into the "current" buffer (odometry.cpp:57-70) ----
+    icet_status s = ensure_scan(nd, cur, n); if (s != ICET_OK) return s;
+    const int64_t lcur = nd->cap_scan[cur];
+    const int n_blocks = (int)((n + kFB * kFRows - 1) / (kFB * kFRows));
+    if (n_blocks > nd->cap_blocks) {
+        NCHK(nd, hipStreamSynchronize(st));
+        if (nd->d_counts) NCHK(nd, hipFree(nd->d_counts));
+        if (nd->d_bases) NCHK(nd, hipFree(nd->d_bases));
+        nd->d_counts = nd->d_bases = nullptr;
+        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_counts), sizeof(int32_t) * n_blocks));
+        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_bases), sizeof(int32_t) * n_blocks));
+        nd->cap_blocks = n_blocks;
+    }
+    NCHK(nd, hipEventRecord(nd->ev[0], st));
+    if (n > 0) {
+        const float *x = d_scan, *y = d_scan + ld, *z = d_scan + 2 * ld;
+        float* o = nd->d_scan[cur];
+        k_range_count<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_counts);
+        k_range_scan<<<1, kFB, 0, st>>>(nd->d_counts, nd->d_bases, n_blocks, nd->d_nkept);
+        k_range_scatter<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_bases, o, o + lcur, o + 2 * lcur);
+        NCHK(nd, hipGetLastError());
+        NCHK(nd, hipMemcpyAsync(nd->h_nkept, nd->d_nkept, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    } else {
+        *nd->h_nkept = 0;
+    }
+    NCHK(nd, hipEventRecord(nd->ev[1], st));
+    NCHK(nd, hipStreamSynchronize(st));                           // the solve's launch geometry needs the row count
+    const int64_t nk = *nd->h_nkept;
+    nd->n_scan[cur] = nk; nd->ld_scan[cur] = lcur;
+    // ---- ICET it(prev, cur, runlen, X0, bins_phi, bins_theta, n, thresh, buff)  (odometry.cpp:76) ----
+    std::memcpy(nd->h_x0, nd->X0, sizeof(nd->X0));
+    NCHK(nd, hipMemcpyAsync(nd->d_x0, nd->h_x0, sizeof(float) * 6, hipMemcpyHostToDevice, st));
+    icet_dev_scan a{nd->d_scan[nd->prev], nd->n_scan[nd->prev], nd->ld_scan[nd->prev]}, b{nd->d_scan[cur], nk, lcur};
+    icet_params sp = nd->p.solve; sp.flags = ICET_FLAG_NONE;
+    s = icet_solve_batch_device(nd->ctx, &sp, 1, &a, &b, nd->d_x0, nd->d_out);
+    if (s != ICET_OK) { nd->err = icet_last_error(nd->ctx); return s; }
+    NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, st));
+    NCHK(nd, hipEventRecord(nd->ev[2], st));
+    NCHK(nd, hipStreamSynchronize(st));
+    float X[6];
+    std::memcpy(X, nd->h_out, sizeof(X)); std::memcpy(res->pred_stds, nd->h_out + 6, sizeof(float) * 6);
+    // seed for the next frame (odometry.cpp:82 / simpleMapMaker.cpp:124), then the guard (simpleMapMaker.cpp:129-137)
+    for (int k = 0; k < 6; k++) nd->X0[k] = nd->p.seed_x0 ? X[k] : 0.f;
+    if (nd->p.trans_thresh > 0.f || nd->p.rot_thresh > 0.f) {
+        if (std::fabs(X[0]) > nd->p.trans_thresh || std::fabs(X[1]) > nd->p.trans_thresh || std::fabs(X[2]) > nd->p.trans_thresh ||
+            std::fabs(X[3]) > nd->p.rot_thresh || std::fabs(X[4]) > nd->p.rot_thresh || std::fabs(X[5]) > nd->p.rot_thresh) {
+            for (int k = 0; k < 6; k++) X[k] = 0.f;
+            res->diverged = 1;
+        }
+    }
+    float R[9]; euler_R_host(X[3], X[4], X[5], R);
+    // ---- map queue (simpleMapMaker.cpp:147-158, 34-41) ----
+    nd->timed_map = false;
+    if (nd->p.map_capacity > 0) {
+        nd->indices.resize((size_t)nk);
+        std::iota(nd->indices.begin(), nd->indices.end(), (std::size_t)0);
+        std::shuffle(nd->indices.begin(), nd->indices.end(), nd->gen);
+        const int m = (int)std::min<int64_t>(nd->p.map_downsample, nk);
+        for (int i = 0; i < m; i++) nd->h_idx[i] = (int32_t)nd->indices[i];
+        if (m) NCHK(nd, hipMemcpyAsync(nd->d_idx, nd->h_idx, sizeof(int32_t) * m, hipMemcpyHostToDevice, st));
+        float Ri[9]; inverse3_lu(R, Ri);
+        const int cap = nd->p.map_capacity;
+        float* q = nd->d_map; const float* sc = nd->d_scan[cur];
+        const int blocks = std::min((cap + 255) / 256, 256 * 8);
+        k_map_add_scan<<<blocks, 256, 0, st>>>(q, q + cap, q + 2 * (size_t)cap, cap, (int)nd->map_pos, m, sc, sc + lcur, sc + 2 * lcur, nd->d_idx,
+                                               X[0], X[1], X[2], Ri[0], Ri[1], Ri[2], Ri[3], Ri[4], Ri[5], Ri[6], Ri[7], Ri[8]);
+        NCHK(nd, hipGetLastError());
+        NCHK(nd, hipEventRecord(nd->ev[3], st));
+        NCHK(nd, hipStreamSynchronize(st));                       // h_idx is reused by the next frame
+        if (nd->map_pos + m >= cap) nd->map_filled = true;
+        nd->map_pos = (nd->map_pos + m) % cap;
+        nd->timed_map = true;
+    }
+    nd->prev = cur;                                               // prev_pcl_matrix = pcl_matrix (odometry.cpp:88)
+    // X_homo = X_homo * X_homo_i (odometry.cpp:91-98)
+    const float Hi[16] = {R[0], R[1], R[2], X[0], R[3], R[4], R[5], X[1], R[6], R[7], R[8], X[2], 0, 0, 0, 1};
+    float P[16];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { float acc = 0.f; for (int k = 0; k < 4; k++) acc += nd->pose[r * 4 + k] * Hi[k * 4 + c]; P[r * 4 + c] = acc; }
+    std::memcpy(nd->pose, P, sizeof(P));
+    res->solved = 1; res->n_kept = nk;
+    std::memcpy(res->X, X, sizeof(X)); std::memcpy(res->pose, P, sizeof(P)); quat_of(P, res->quat);
+    res->map_rows = nd->map_filled ? nd->p.map_capacity : nd->map_pos;
+    nd->timing_valid = true;
+    return ICET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+icet_status icet_node_create(icet_ctx* ctx, const icet_node_params* p, icet_node** out) {
+    if (!out) return ICET_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!ctx || !p || p->map_capacity < 0 || p->map_downsample < 0 || (p->map_capacity > 0 && p->map_downsample > p->map_capacity) ||
+        p->solve.bins_phi <= 0 || p->solve.bins_theta <= 0 || p->solve.n < 1 || p->solve.runlen < 0) return ICET_ERR_BAD_ARG;
+    icet_node* nd = new (std::nothrow) icet_node();
+    if (!nd) return ICET_ERR_NOMEM;
+    nd->ctx = ctx; nd->p = *p; nd->stream = reinterpret_cast<hipStream_t>(icet_stream(ctx)); nd->device = icet_device(ctx);
+    auto fail = [&](icet_status s) { icet_node_destroy(nd); return s; };
+    if (hipSetDevice(nd->device) != hipSuccess) return fail(ICET_ERR_NO_DEVICE);
+    if (hipMalloc(reinterpret_cast<void**>(&nd->d_nkept), sizeof(int32_t)) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_nkept), sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&nd->d_x0), sizeof(float) * 6) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&nd->d_out), sizeof(float) * 48) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&nd->h_out), sizeof(float) * 48) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_x0), sizeof(float) * 6) != hipSuccess)
+        return fail(ICET_ERR_NOMEM);
+    for (hipEvent_t& e : nd->ev) if (hipEventCreate(&e) != hipSuccess) return fail(ICET_ERR_HIP);
+    if (p->map_capacity > 0) {
+        if (hipMalloc(reinterpret_cast<void**>(&nd->d_map), sizeof(float) * 3 * (size_t)p->map_capacity) != hipSuccess) return fail(ICET_ERR_NOMEM);
+        if (hipMemset(nd->d_map, 0, sizeof(float) * 3 * (size_t)p->map_capacity) != hipSuccess) return fail(ICET_ERR_HIP);      // Eigen leaves MatrixXf(maxSize, 3) uninitialised; unfilled rows are never returned by getQueue
+        const size_t m = p->map_downsample > 0 ? p->map_downsample : 1;
+        if (hipMalloc(reinterpret_cast<void**>(&nd->d_idx), sizeof(int32_t) * m) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_idx), sizeof(int32_t) * m) != hipSuccess)
+            return fail(ICET_ERR_NOMEM);
+    }
+    *out = nd;
+    return ICET_OK;
+}
+
+icet_status icet_node_destroy(icet_node* nd) {
+    if (!nd) return ICET_ERR_BAD_ARG;
+    (void)hipSetDevice(nd->device);
+    (void)hipDeviceSynchronize();            // not the borrowed stream: the context may already be gone
+    void* dp[] = {nd->d_scan[0], nd->d_scan[1], nd->d_stage, nd->d_counts, nd->d_bases, nd->d_nkept, nd->d_x0, nd->d_out, nd->d_map, nd->d_idx};
+    for (void* q : dp) if (q) (void)hipFree(q);
+    void* hp[] = {nd->h_nkept, nd->h_out, nd->h_x0, nd->h_idx};
+    for (void* q : hp) if (q) (void)hipHostFree(q);
+    for (hipEvent_t e : nd->ev) if (e) (void)hipEventDestroy(e);
+    delete nd;
+    return ICET_OK;
+}
+
+icet_status icet_node_push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t ld, icet_node_result* res) {
+    if (!nd || !res || n < 0 || ld < n || (n > 0 && !d_scan) || n >= ((int64_t)1 << 30)) return ICET_ERR_BAD_ARG;
+    if (hipSetDevice(nd->device) != hipSuccess) return ICET_ERR_NO_DEVICE;
+    return push_device(nd, d_scan, n, ld, res);
+}
+
+icet_status icet_node_push(icet_node* nd, const float* scan, int64_t n, int64_t ld, icet_node_result* res) {
+    if (!nd || !res || n < 0 || ld < n || (n > 0 && !scan) || n >= ((int64_t)1 << 30)) return ICET_ERR_BAD_ARG;
+    if (hipSetDevice(nd->device) != hipSuccess) return ICET_ERR_NO_DEVICE;
+    const int64_t l = (n + 63) / 64 * 64;
+    if (3 * l > nd->cap_stage) {
+        NCHK(nd, hipStreamSynchronize(nd->stream));
+        if (nd->d_stage) { NCHK(nd, hipFree(nd->d_stage)); nd->d_stage = nullptr; }
+        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_stage), sizeof(float) * 3 * (size_t)(l + l / 8)));
+        nd->cap_stage = 3 * (l + l / 8);
+    }
+    if (n) NCHK(nd, hipMemcpy2DAsync(nd->d_stage, l * sizeof(float), scan, ld * sizeof(float), n * sizeof(float), 3, hipMemcpyHostToDevice, nd->stream));
+    return push_device(nd, nd->d_stage, n, l, res);
+}
+
+icet_status icet_node_map(icet_node* nd, float* out, int64_t ld, int64_t* rows_out) {
+    if (!nd || !rows_out) return ICET_ERR_BAD_ARG;
+    const int64_t rows = nd->map_filled ? nd->p.map_capacity : nd->map_pos;
+    *rows_out = rows;
+    if (!out || rows == 0) return ICET_OK;
+    if (ld < rows) return ICET_ERR_BAD_ARG;
+    if (hipSetDevice(nd->device) != hipSuccess) return ICET_ERR_NO_DEVICE;
+    float* tmp = nullptr;
+    NCHK(nd, hipMalloc(reinterpret_cast<void**>(&tmp), sizeof(float) * 3 * (size_t)rows));
+    const int cap = nd->p.map_capacity;
+    k_map_unroll<<<std::min((int)((rows + 255) / 256), 2048), 256, 0, nd->stream>>>(nd->d_map, nd->d_map + cap, nd->d_map + 2 * (size_t)cap, cap, (int)nd->map_pos,
+                                                                                     nd->map_filled ? 1 : 0, (int)rows, tmp, (int)rows);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy2DAsync(out, ld * sizeof(float), tmp, rows * sizeof(float), rows * sizeof(float), 3, hipMemcpyDeviceToHost, nd->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(nd->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) { nd->err = hipGetErrorString(e); return ICET_ERR_HIP; }
+    return ICET_OK;
+}
+
+icet_status icet_node_prev_scan(icet_node* nd, float* out, int64_t ld, int64_t* rows_out) {
+    if (!nd || !rows_out) return ICET_ERR_BAD_ARG;
+    const int64_t rows = nd->initialized ? nd->n_scan[nd->prev] : 0;
+    *rows_out = rows;
+    if (!out || rows == 0) return ICET_OK;
+    if (ld < rows) return ICET_ERR_BAD_ARG;
+    if (hipSetDevice(nd->device) != hipSuccess) return ICET_ERR_NO_DEVICE;
+    NCHK(nd, hipMemcpy2DAsync(out, ld * sizeof(float), nd->d_scan[nd->prev], nd->ld_scan[nd->prev] * sizeof(float), rows * sizeof(float), 3, hipMemcpyDeviceToHost, nd->stream));
+    NCHK(nd, hipStreamSynchronize(nd->stream));
+    return ICET_OK;
+}
+
+icet_status icet_node_last_timing(icet_node* nd, float out_ms[3]) {
+    if (!nd || !out_ms) return ICET_ERR_BAD_ARG;
+    if (!nd->timing_valid) return ICET_ERR_BAD_ARG;
+    float a = 0, b = 0, c = 0;
+    NCHK(nd, hipEventElapsedTime(&a, nd->ev[0], nd->ev[1]));
+    NCHK(nd, hipEventElapsedTime(&b, nd->ev[1], nd->ev[2]));
+    if (nd->timed_map) NCHK(nd, hipEventElapsedTime(&c, nd->ev[2], nd->ev[3]));
+    out_ms[0] = a; out_ms[1] = b; out_ms[2] = c;
+    return ICET_OK;
+}
+
+}  // extern "C"

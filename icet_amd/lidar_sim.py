@@ -159,3 +159,19 @@ def batch_motion(k):
 def make_batch_pair(k, rings=64, steps=2048, device="cpu", order="ring"):
     """Pair k of configs 3/4: scene seed 1000+2k, noise seed 1001+2k, motion seed 5000+k."""
     return make_pair(1000 + 2 * k, 1001 + 2 * k, batch_motion(k), rings, steps, device, order)
+
+
+def make_sequence(n_frames, scene_seed=2000, noise_seed=2001, motion=DEFAULT_MOTION, rings=64, steps=2048, device="cpu", order="ring", sigma=0.02):
+    """A drive through one scene: frame k+1 is observed after `motion` relative to frame k (same convention as make_pair,
+    so registering frame k -> k+1 should return about `motion`).  Returns a list of float32 (3, N_k) tensors."""
+    scene = make_scene(scene_seed)
+    X = np.asarray(motion, np.float64)
+    R = euler_R(X[3], X[4], X[5])
+    R_step, t_step = R.T, R.T @ X[:3]
+    t, Rw = np.zeros(3), np.eye(3)
+    scans = []
+    for k in range(n_frames):
+        scans.append(make_scan(scene, (t.copy(), Rw.copy()), noise_seed * 2 + 1 + k, rings, steps, sigma, device=device, order=order))
+        t = t + Rw @ t_step
+        Rw = Rw @ R_step
+    return scans

@@ -1,0 +1,79 @@
+/* include/icet_nodes.h -- C ABI of the callers on either side of the hot path,
+ * kept on the MI355X so that a scan stream never leaves HBM between frames.
+ *
+ * What it restates (the ROS plumbing itself -- subscribers, publishers, tf -- is out of scope):
+ *   * the per-frame body of `OdometryNode::pointCloudCallback`   /root/reference/src/odometry.cpp:46-98
+ *   * the per-frame body of `MapMakerNode::pointCloudCallback`   /root/reference/src/simpleMapMaker.cpp:86-172
+ *   * `EigenQueue` (the HD-map FIFO)                             /root/reference/src/simpleMapMaker.cpp:18-59
+ * i.e. first scan stored as-is, every later scan range-filtered (row norm > min_range), ICET(prev, cur, ...) solved
+ * through icet_hip.h, X0 seeded for the next frame, the divergence guard, the accumulated pose X_homo, and the map
+ * queue re-expressed in the new sensor frame.  Scan layout as in icet_hip.h: N x 3 float32 column-major, ld >= N.
+ *
+ * Quirks kept (do not "fix"): the FIRST scan is not range-filtered (odometry.cpp:46-52); the guard zeroes X but the
+ * pose is still chained with the zeroed X (simpleMapMaker.cpp:129-172); the map transform is applied to all
+ * `map_capacity` rows, filled or not (simpleMapMaker.cpp:40); the down-sample is the head of a std::shuffle driven by a
+ * default-seeded std::mt19937 that lives as long as the node (simpleMapMaker.cpp:147-158,257-258).
+ * One deviation: the reference copies `map_downsample` rows even when the scan has fewer (reads past the shuffled
+ * index vector, simpleMapMaker.cpp:155-157); here min(map_downsample, rows) rows are taken.
+ */
+#ifndef ICET_NODES_H
+#define ICET_NODES_H
+#include "icet_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct icet_node_params {
+    icet_params solve;        /* odometry: {7, 24, 75, 25, .1, .1} (odometry.cpp:73-76); map maker: runlen 12 (simpleMapMaker.cpp:113-119) */
+    float   min_range;        /* keep rows with norm > min_range: 2.0 (odometry.cpp:58) / 0.2 (simpleMapMaker.cpp:98)     */
+    int32_t seed_x0;          /* 1: X0 <- X for the next frame (odometry.cpp:82); 0: X0 <- 0 (simpleMapMaker.cpp:124)       */
+    float   trans_thresh;     /* divergence guard |X[0..2]| > trans_thresh ... (simpleMapMaker.cpp:129-137, 0.3 / 0.3);   */
+    float   rot_thresh;       /*   both <= 0: no guard (the odometry node has none)                                        */
+    int32_t map_capacity;     /* rows of the map FIFO: 600000 (simpleMapMaker.cpp:62); 0: no map (odometry node)           */
+    int32_t map_downsample;   /* rows of each scan that enter the map: 2000 (simpleMapMaker.cpp:147)                        */
+} icet_node_params;
+
+typedef struct icet_node_result {
+    int32_t solved;           /* 0 for the first scan: it is only stored (odometry.cpp:46-52)                              */
+    int32_t diverged;         /* 1 if the guard zeroed X                                                                   */
+    int64_t n_kept;           /* rows of this scan after the range filter (= rows of the next frame's scan 1)              */
+    float   X[6];             /* solution of this frame (after the guard)                                                  */
+    float   pred_stds[6];     /* `it.pred_stds`                                                                            */
+    float   pose[16];         /* accumulated X_homo, row-major 4 x 4 (odometry.cpp:91-98)                                  */
+    float   quat[4];          /* x, y, z, w of Eigen::Quaternionf(X_homo.topLeftCorner(3,3)) (odometry.cpp:113-118)        */
+    int64_t map_rows;         /* rows currently valid in the map queue (getQueue().rows())                                 */
+} icet_node_result;
+
+typedef struct icet_node icet_node;   /* opaque: previous scan in HBM, X0, pose, RNG, map queue */
+
+/* The node borrows `ctx` (its device, stream and workspace); destroy the node before the context. */
+icet_status icet_node_create(icet_ctx* ctx, const icet_node_params* p, icet_node** out);
+icet_status icet_node_destroy(icet_node* node);
+
+/* One lidar frame.  `scan` is a HOST pointer in icet_node_push and a DEVICE pointer in icet_node_push_device (the
+ * buffer may be reused as soon as the call returns: the node keeps its own filtered copy).  Both return after the frame's
+ * result is on the host (the nodes publish every frame; the next frame's X0 depends on it). */
+icet_status icet_node_push(icet_node* node, const float* scan, int64_t n, int64_t ld, icet_node_result* res);
+icet_status icet_node_push_device(icet_node* node, const float* d_scan, int64_t n, int64_t ld, icet_node_result* res);
+
+/* `EigenQueue::getQueue()` (simpleMapMaker.cpp:43-50): copies the valid rows, oldest first, to the host as rows x 3
+ * column-major with leading dimension `ld` (>= rows).  `out` may be NULL to query `rows` only. */
+icet_status icet_node_map(icet_node* node, float* out, int64_t ld, int64_t* rows);
+
+/* The node's `prev_pcl_matrix` (odometry.cpp:88): the scan the next frame will be registered against, i.e. the most
+ * recent push after the range filter (the first push unfiltered).  rows x 3 column-major, leading dimension ld;
+ * `out` may be NULL to query `rows` only. */
+icet_status icet_node_prev_scan(icet_node* node, float* out, int64_t ld, int64_t* rows);
+
+/* Device-side time of the pieces of the most recent push, measured with HIP events on the context's stream:
+ * [0] range filter ms, [1] ICET solve ms, [2] map update ms (0 if no map). */
+icet_status icet_node_last_timing(icet_node* node, float out_ms[3]);
+
+/* The HIP stream (hipStream_t as void*) and device a context enqueues on -- for callers that produce scans on the GPU. */
+void* icet_stream(icet_ctx* ctx);
+int   icet_device(const icet_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICET_NODES_H */

@@ -68,6 +68,29 @@ void icet_oracle_scramble(const float* r, int64_t n, int32_t* src);
 void icet_oracle_get_H(const float mu[3], const float angs[3], float* H18);
 void icet_oracle_R(const float angs[3], float* R9);
 
+/* ---- the callers around the constructor (icet_nodes_oracle.cpp): odometry.cpp:46-98, simpleMapMaker.cpp:18-59,86-172 ---- */
+typedef struct icet_oracle_node_params {
+    icet_oracle_params solve;
+    float   min_range;       /* 2.0 odometry.cpp:58 / 0.2 simpleMapMaker.cpp:98 */
+    int32_t seed_x0;         /* 1 odometry.cpp:82 / 0 simpleMapMaker.cpp:124    */
+    float   trans_thresh;    /* simpleMapMaker.cpp:241-242; both <= 0: no guard  */
+    float   rot_thresh;
+    int32_t map_capacity;    /* 600000 simpleMapMaker.cpp:62; 0 = no map         */
+    int32_t map_downsample;  /* 2000 simpleMapMaker.cpp:147                      */
+} icet_oracle_node_params;
+
+typedef struct icet_oracle_node_result {
+    int32_t solved, diverged;
+    int64_t n_kept;
+    float   X[6], pred_stds[6], pose[16], quat[4];
+    int64_t map_rows;
+} icet_oracle_node_result;
+
+void*   icet_oracle_node_create(const icet_oracle_node_params* p);
+void    icet_oracle_node_destroy(void* node);
+int     icet_oracle_node_push(void* node, const float* scan, int64_t n, int64_t ld, icet_oracle_node_result* res);
+int64_t icet_oracle_node_map(void* node, float* out, int64_t ld);   /* rows; out may be NULL */
+
 #ifdef __cplusplus
 }
 #endif

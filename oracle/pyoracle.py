@@ -35,7 +35,7 @@ def build(force=False):
     """Compile the oracle with its Makefile (g++ only; no GPU, no reference sources)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("icet_oracle.cpp", "icet_oracle.h", "smalllinalg.h")):
+            for f in ("icet_oracle.cpp", "icet_nodes_oracle.cpp", "icet_oracle.h", "smalllinalg.h")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
@@ -172,3 +172,60 @@ def euler_R(angs):
     angs = np.asarray(angs, np.float32); R = np.zeros(9, np.float32)
     lib().icet_oracle_R(angs.ctypes.data, R.ctypes.data)
     return R.reshape(3, 3)
+
+
+# ---- the callers around the constructor (icet_nodes_oracle.cpp) ------------------------------------------------------
+class NodeParams(C.Structure):
+    _fields_ = [("solve", Params), ("min_range", C.c_float), ("seed_x0", C.c_int32), ("trans_thresh", C.c_float), ("rot_thresh", C.c_float),
+                ("map_capacity", C.c_int32), ("map_downsample", C.c_int32)]
+
+
+class NodeResult(C.Structure):
+    _fields_ = [("solved", C.c_int32), ("diverged", C.c_int32), ("n_kept", C.c_int64), ("X", C.c_float * 6), ("pred_stds", C.c_float * 6),
+                ("pose", C.c_float * 16), ("quat", C.c_float * 4), ("map_rows", C.c_int64)]
+
+
+class Node:
+    """CPU restatement of the per-frame body of odometry_node / map_maker_node (src/odometry.cpp:46-98,
+    src/simpleMapMaker.cpp:86-172).  Same keyword arguments as icet_amd.api.Node."""
+
+    def __init__(self, runlen=7, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1, min_range=2.0, seed_x0=1,
+                 trans_thresh=0.0, rot_thresh=0.0, map_capacity=0, map_downsample=0, mode=SERIAL):
+        L = lib()
+        L.icet_oracle_node_create.restype = C.c_void_p
+        L.icet_oracle_node_create.argtypes = [C.POINTER(NodeParams)]
+        L.icet_oracle_node_destroy.argtypes = [C.c_void_p]
+        L.icet_oracle_node_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(NodeResult)]
+        L.icet_oracle_node_map.restype = C.c_int64
+        L.icet_oracle_node_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        self._p = NodeParams(make_params(runlen, bins_phi, bins_theta, n, thresh, buff, mode), min_range, seed_x0, trans_thresh, rot_thresh,
+                             map_capacity, map_downsample)
+        self._h = C.c_void_p(L.icet_oracle_node_create(C.byref(self._p)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().icet_oracle_node_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, scan):
+        a = colmajor(scan)
+        r = NodeResult()
+        rc = lib().icet_oracle_node_push(self._h, a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[1], C.byref(r))
+        if rc != 0:
+            raise RuntimeError("icet_oracle_node_push -> %d" % rc)
+        return dict(solved=bool(r.solved), diverged=bool(r.diverged), n_kept=int(r.n_kept), X=np.array(r.X[:], np.float32),
+                    pred_stds=np.array(r.pred_stds[:], np.float32), pose=np.array(r.pose[:], np.float32).reshape(4, 4),
+                    quat=np.array(r.quat[:], np.float32), map_rows=int(r.map_rows))
+
+    def map(self):
+        rows = lib().icet_oracle_node_map(self._h, None, 0)
+        out = np.zeros((3, max(rows, 1)), np.float32)
+        if rows:
+            lib().icet_oracle_node_map(self._h, out.ctypes.data_as(C.c_void_p), rows)
+        return np.ascontiguousarray(out[:, :rows].T)

@@ -14,9 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "icet_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(icet_[a-z_0-9]+)\s*\(", txt)))
+    names = set()
+    for h in ("icet_hip.h", "icet_nodes.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(icet_[a-z_0-9]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -32,7 +35,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_header_compiles_as_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "icet_hip.h"\nint main(void){ icet_params p = {7,24,75,25,0.1f,0.1f,0}; return p.runlen == 7 ? 0 : 1; }\n')
+    src.write_text('#include "icet_hip.h"\n#include "icet_nodes.h"\nint main(void){ icet_params p = {7,24,75,25,0.1f,0.1f,0}; icet_node_params q = {{7,24,75,25,0.1f,0.1f,0}, 2.0f, 1, 0.f, 0.f, 0, 0}; '
+                   'return p.runlen == 7 && q.seed_x0 == 1 ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "t")])
     subprocess.check_call([str(tmp_path / "t")])
 
@@ -54,6 +58,12 @@ def test_null_and_bad_arguments_do_not_crash():
     assert lib.icet_destroy(None) == icet_amd.api.ICET_ERR_BAD_ARG
     assert lib.icet_sync(None) == icet_amd.api.ICET_ERR_BAD_ARG
     assert lib.icet_last_error(None) == b"null context"
+    assert lib.icet_node_create(None, None, None) == icet_amd.api.ICET_ERR_BAD_ARG
+    nh = C.c_void_p()
+    assert lib.icet_node_create(None, C.byref(icet_amd.api.node_params()), C.byref(nh)) == icet_amd.api.ICET_ERR_BAD_ARG and not nh.value
+    assert lib.icet_node_destroy(None) == icet_amd.api.ICET_ERR_BAD_ARG
+    assert lib.icet_node_push(None, None, 0, 0, None) == icet_amd.api.ICET_ERR_BAD_ARG
+    assert lib.icet_stream(None) is None and lib.icet_device(None) == -1
     h = C.c_void_p()
     assert lib.icet_create(C.byref(h), -1, None) in (icet_amd.api.ICET_ERR_NO_DEVICE,)
     assert not h.value

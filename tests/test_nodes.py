@@ -1,0 +1,188 @@
+"""The callers around the constructor: per-frame body of odometry_node and
+map_maker_node (/root/reference/src/odometry.cpp:46-98, src/simpleMapMaker.cpp:18-59,86-172).
+
+CPU tests pin the oracle's restatement (oracle/icet_nodes_oracle.cpp) against the already-tested single-pair oracle and
+against NumPy restatements of the bookkeeping; GPU tests compare include/icet_nodes.h (through icet_amd.api.Node) with it:
+  * range filter: kept rows and their order BIT-EXACT (it is a comparison of a correctly rounded float norm);
+  * X / pred_stds: the single-pair tolerances of test_gpu_parity.py (3e-4 m, 1e-4 rad per frame);
+  * pose: 1e-3 after a few frames (it chains the per-frame X);
+  * map queue: bit-exact when the guard zeroes X (R = I, t = 0: pure data movement), 2e-3 m otherwise.
+"""
+import numpy as np
+import pytest
+import torch   # before libicet_hip.so is loaded: both must share one HIP runtime (torch ships its own libamdhip64)
+
+
+
+def _sequence(n_frames=4, rings=32, steps=1024):
+    from icet_amd import lidar_sim as ls
+    motion = (0.25, 0.02, 0.005, 0.001, -0.001, 0.006)
+    return [s.T.contiguous().numpy() for s in ls.make_sequence(n_frames, motion=motion, rings=rings, steps=steps)]
+
+
+def _range_filter(scan, min_range):
+    x, y, z = scan[:, 0], scan[:, 1], scan[:, 2]
+    d = np.sqrt((x * x + y * y) + z * z)          # float32 throughout, no fused multiply-add in NumPy
+    return scan[d > np.float32(min_range)]
+
+
+def _euler_R(a):
+    from oracle import pyoracle as po
+    return po.euler_R(np.asarray(a, np.float32)).reshape(3, 3).astype(np.float64)
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the oracle itself
+def test_node_oracle_first_frame_and_pair_selection():
+    """First scan stored unfiltered, nothing solved; afterwards frame k is ICET(prev, filter(cur), X0)."""
+    from oracle import pyoracle as po
+    seq = _sequence(3)
+    nd = po.Node(min_range=2.0, seed_x0=1)
+    r0 = nd.push(seq[0])
+    assert not r0["solved"] and r0["n_kept"] == len(seq[0]) and np.array_equal(r0["pose"], np.eye(4, dtype=np.float32))
+    assert np.array_equal(r0["quat"], np.array([0, 0, 0, 1], np.float32))
+    r1 = nd.push(seq[1])
+    f1 = _range_filter(seq[1], 2.0)
+    assert r1["solved"] and r1["n_kept"] == len(f1) < len(seq[1])
+    ref1 = po.solve(seq[0], f1, x0=np.zeros(6))                      # scan 1 = UNFILTERED first frame (odometry.cpp:46-52)
+    assert np.array_equal(r1["X"], ref1["X"]) and np.array_equal(r1["pred_stds"], ref1["pred_stds"])
+    r2 = nd.push(seq[2])
+    f2 = _range_filter(seq[2], 2.0)
+    ref2 = po.solve(f1, f2, x0=ref1["X"])                            # X0 seeded with the previous X (odometry.cpp:82)
+    assert np.array_equal(r2["X"], ref2["X"])
+    # pose = product of the per-frame [R t; 0 1]
+    H = np.eye(4)
+    for X in (ref1["X"], ref2["X"]):
+        Hi = np.eye(4); Hi[:3, :3] = _euler_R(X[3:]); Hi[:3, 3] = X[:3]
+        H = H @ Hi
+    assert np.allclose(r2["pose"], H, atol=2e-6)
+    from scipy.spatial.transform import Rotation
+    q = Rotation.from_matrix(H[:3, :3]).as_quat()
+    assert min(np.abs(r2["quat"] - q).max(), np.abs(r2["quat"] + q).max()) < 2e-6
+    nd.close()
+
+
+def test_node_oracle_map_maker_settings_guard_and_reset():
+    """simpleMapMaker: X0 reset to zero every frame; guard zeroes X (pose unchanged) when a component exceeds the threshold."""
+    from oracle import pyoracle as po
+    seq = _sequence(3)
+    nd = po.Node(runlen=3, min_range=0.2, seed_x0=0, trans_thresh=0.3, rot_thresh=0.3)
+    nd.push(seq[0])
+    r1 = nd.push(seq[1]); r2 = nd.push(seq[2])
+    f1, f2 = _range_filter(seq[1], 0.2), _range_filter(seq[2], 0.2)
+    assert np.array_equal(r2["X"], po.solve(f1, f2, x0=np.zeros(6), runlen=3)["X"]) and not r2["diverged"]
+    tight = po.Node(runlen=3, min_range=0.2, seed_x0=0, trans_thresh=1e-4, rot_thresh=1e-4)
+    tight.push(seq[0])
+    g = tight.push(seq[1])
+    assert g["diverged"] and not g["X"].any() and np.array_equal(g["pose"], np.eye(4, dtype=np.float32))
+    assert g["pred_stds"].any()                                       # pred_stds are published as they are
+    nd.close(); tight.close()
+
+
+def test_node_oracle_map_queue_matches_numpy_ring():
+    """EigenQueue: m rows per frame enter at `pos`, then ALL rows become (row - t) R^-1; getQueue returns oldest first.
+    With a capacity of 2.5 frames the ring wraps on the third insertion."""
+    from oracle import pyoracle as po
+    seq = _sequence(5, rings=16, steps=512)
+    m, cap = 1000, 2500
+    kw = dict(runlen=2, min_range=0.2, seed_x0=0, trans_thresh=0.3, rot_thresh=0.3, map_capacity=cap, map_downsample=m)
+    a, b = po.Node(**kw), po.Node(**kw)
+    a.push(seq[0]); b.push(seq[0])
+    assert a.map().shape == (0, 3)
+    for k in range(1, 5):
+        r = a.push(seq[k]); b.push(seq[k])
+        f = _range_filter(seq[k], 0.2)
+        mp = a.map()
+        assert r["map_rows"] == min(k * m, cap) == len(mp)
+        # the newest m rows are a subset of this frame's filtered scan, expressed in the new sensor frame
+        Rinv = np.linalg.inv(_euler_R(r["X"][3:])); t = r["X"][:3].astype(np.float64)
+        back = mp[-m:].astype(np.float64) @ np.linalg.inv(Rinv) + t
+        # every older row moved rigidly: distances between consecutive rows are preserved
+        if k >= 2:
+            old_now = mp[-2 * m:-m].astype(np.float64)
+            assert np.allclose(np.linalg.norm(np.diff(old_now, axis=0), axis=1), np.linalg.norm(np.diff(prev_newest, axis=0), axis=1), atol=2e-4)
+        prev_newest = mp[-m:].astype(np.float64)
+        # exact membership: undo the transform in float64 and match to the nearest scan row
+        from scipy.spatial import cKDTree
+        dist, _ = cKDTree(f.astype(np.float64)).query(back)
+        assert dist.max() < 1e-4
+    assert np.array_equal(a.map(), b.map())                           # default-seeded mt19937: two nodes agree
+    a.close(); b.close()
+
+
+# ------------------------------------------------------------------------------------------------ GPU: parity
+@pytest.fixture(scope="module")
+def seq64():
+    return _sequence(4, rings=64, steps=2048)
+
+
+@pytest.mark.gpu
+def test_gpu_odometry_node_matches_oracle(gpu_ctx, seq64):
+    from oracle import pyoracle as po
+    from icet_amd import api
+    g = api.Node(gpu_ctx, **api.ODOMETRY_NODE)
+    o = po.Node(**api.ODOMETRY_NODE)
+    for k, s in enumerate(seq64):
+        rg, ro = g.push(s), o.push(s)
+        assert rg["solved"] == ro["solved"] and rg["n_kept"] == ro["n_kept"] and rg["diverged"] == ro["diverged"]
+        expect = s if k == 0 else _range_filter(s, 2.0)
+        assert np.array_equal(g.prev_scan(), expect)                  # filter: same rows, same order, bit for bit
+        if k:
+            assert np.abs(rg["X"][:3] - ro["X"][:3]).max() <= 3e-4 * k and np.abs(rg["X"][3:] - ro["X"][3:]).max() <= 1e-4 * k, (k, rg["X"], ro["X"])
+            assert np.allclose(rg["pred_stds"], ro["pred_stds"], rtol=2e-2, atol=1e-7)
+            assert np.abs(rg["pose"] - ro["pose"]).max() <= 1e-3
+            assert min(np.abs(rg["quat"] - ro["quat"]).max(), np.abs(rg["quat"] + ro["quat"]).max()) <= 1e-3
+            t = g.last_timing()
+            assert t["filter_ms"] > 0 and t["solve_ms"] > 0
+    g.close(); o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_map_maker_node_matches_oracle(gpu_ctx, seq64):
+    from oracle import pyoracle as po
+    from icet_amd import api
+    kw = dict(api.MAP_MAKER_NODE); kw.update(map_capacity=5000, map_downsample=2000, runlen=7)     # wraps on the third frame
+    g, o = api.Node(gpu_ctx, **kw), po.Node(**kw)
+    for k, s in enumerate(seq64):
+        rg, ro = g.push(s), o.push(s)
+        assert rg["n_kept"] == ro["n_kept"] and rg["map_rows"] == ro["map_rows"] and rg["diverged"] == ro["diverged"]
+        if k:
+            assert np.abs(rg["X"] - ro["X"]).max() <= 3e-4
+        mg, mo = g.map(), o.map()
+        assert mg.shape == mo.shape and (len(mg) == 0 or np.abs(mg - mo).max() <= 2e-3)
+    g.close(); o.close()
+    # guard tripped on every frame: X = 0, R = I, the queue only moves data -> bit-exact ring behaviour incl. wrap-around
+    kw.update(trans_thresh=1e-6, rot_thresh=1e-6, map_capacity=4500)
+    g, o = api.Node(gpu_ctx, **kw), po.Node(**kw)
+    for s in seq64:
+        rg, ro = g.push(s), o.push(s)
+        assert rg["diverged"] == ro["diverged"] and rg["map_rows"] == ro["map_rows"]
+        assert np.array_equal(g.map(), o.map())
+        assert np.array_equal(rg["pose"], ro["pose"])
+    g.close(); o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_range_filter_full_size_and_device_push(gpu_ctx):
+    """config-5 size (524288 rows), rows on both sides of the threshold and exactly on it, pushed from HBM."""
+    from icet_amd import api
+    rs = np.random.RandomState(7)
+    n = 524288
+    dirs = rs.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    r = rs.uniform(0.0, 4.0, n); r[::1000] = 2.0; r[5::1000] = 0.0
+    scan = (dirs * r[:, None]).astype(np.float32)
+    g = api.Node(gpu_ctx, runlen=1, min_range=2.0)
+    dev = torch.device("cuda", 0)
+    first = torch.from_numpy(np.ascontiguousarray(scan.T)).to(dev)
+    g.push_device(first.data_ptr(), n, n)
+    assert np.array_equal(g.prev_scan(), scan)                        # first frame: unfiltered
+    ld = n + 64
+    buf = torch.zeros((3, ld), dtype=torch.float32, device=dev); buf[:, :n] = first
+    torch.cuda.synchronize()
+    res = g.push_device(buf.data_ptr(), n, ld)
+    expect = _range_filter(scan, 2.0)
+    assert res["n_kept"] == len(expect) and np.array_equal(g.prev_scan(), expect)
+    # ragged / degenerate inputs
+    for m in (0, 1, 63, 2049):
+        res = g.push(scan[:m])
+        assert res["n_kept"] == len(_range_filter(scan[:m], 2.0))
+    g.close()

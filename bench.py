@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-gpu", type=int, default=256)
-    ap.add_argument("--workload", choices=["batch", "highres"], default="batch")
+    ap.add_argument("--workload", choices=["batch", "highres", "odometry", "mapmaker"], default="batch")
     ap.add_argument("--order", choices=["ring", "azimuth"], default="ring")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -49,8 +49,94 @@ def parse():
     return ap.parse_args()
 
 
+def run_nodes(args):
+    """--workload odometry | mapmaker: the per-frame body of the reference's two nodes (include/icet_nodes.h).
+    A step is ONE lidar frame pushed from HBM: range filter -> ICET(prev, cur) -> pose chain (-> 600k-row map update).
+    Sequential by construction (frame k+1 needs frame k's X): N > 1 runs independent replicas."""
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    import icet_amd
+    from icet_amd import lidar_sim, api
+    kw = dict(api.ODOMETRY_NODE if args.workload == "odometry" else api.MAP_MAKER_NODE)
+    n_frames = args.warmup + args.steps + 1
+    frames = lidar_sim.make_sequence(n_frames, motion=(0.25, 0.02, 0.005, 0.001, -0.001, 0.006), device=dev)
+    def padded(s):
+        n = s.shape[1]; ld = (n + 63) // 64 * 64
+        buf = torch.zeros((3, ld), dtype=torch.float32, device=dev); buf[:, :n] = s
+        return buf
+    bufs = [padded(s) for s in frames]
+    torch.cuda.synchronize()
+    ctx = icet_amd.Context(local_rank)
+    node = api.Node(ctx, **kw)
+    push = lambda k: node.push_device(bufs[k].data_ptr(), frames[k].shape[1], bufs[k].shape[1])
+    for k in range(args.warmup + 1):
+        push(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    tim = {"filter_ms": 0.0, "solve_ms": 0.0, "map_ms": 0.0}
+    t0 = time.perf_counter()
+    for k in range(args.warmup + 1, n_frames):
+        r = push(k)
+        t = node.last_timing()
+        for key in tim: tim[key] += t[key]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+    for key in tim: tim[key] /= max(args.steps, 1)
+    n_mean = int(np.mean([f.shape[1] for f in frames]))
+    cap = kw["map_capacity"]
+    if cap:
+        kern, bytes_per_launch, ms = "k_map_add_scan", 24.0 * cap, tim["map_ms"]
+        note = "12 B read + 12 B written per ring row x %d rows; HIP events around the kernel" % cap
+    else:
+        kern, bytes_per_launch, ms = "k_range_count+k_range_scan+k_range_scatter", 36.0 * n_mean, tim["filter_ms"]
+        note = "x|y|z read by the count and the scatter pass + kept rows written (~36 B/row); filter_ms also holds the 4-byte row-count download"
+    achieved = bytes_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        o = po.Node(**kw)
+        host = [f.T.cpu().numpy() for f in frames]
+        m = min(len(host) - 1, 8)
+        o.push(host[0])
+        tc = time.perf_counter()
+        for k in range(1, m + 1):
+            ro = o.push(host[k])
+        tc = time.perf_counter() - tc
+        cpu = {"value": round(m / tc, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "first %d frames of the same sequence through oracle/icet_nodes_oracle.cpp (serial), %.1f s wall" % (m, tc)}
+        o.close()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/sec, sequential %s (64-ch, 75x24 voxels, %d iters)" % ("odometry_node" if args.workload == "odometry" else "map_maker_node + 600k-row map", kw["runlen"]),
+            "value": round(world * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SURVEY 8 f1/f3: %s per-frame body, one synthetic 64-ch frame (~%dk pts) per step pushed from HBM, result on the host every frame; replicas only when N>1"
+                                   % (args.workload, n_mean // 1000), "points_per_frame_mean": n_mean, **{k2: v for k2, v in kw.items()}},
+            "roofline": {"kernel": kern, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(ms, 5), "note": note,
+                         "filter_ms": round(tim["filter_ms"], 4), "solve_ms": round(tim["solve_ms"], 4), "map_ms": round(tim["map_ms"], 4)},
+            "cpu_baseline": cpu, "last_X": [round(float(v), 5) for v in r["X"]]}), flush=True)
+    node.close(); ctx.close()
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.workload in ("odometry", "mapmaker"):
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        return run_nodes(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

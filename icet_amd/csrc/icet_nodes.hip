@@ -208,7 +208,7 @@ struct icet_node {
     std::vector<std::size_t> indices;
     float* d_map = nullptr; int64_t map_pos = 0; bool map_filled = false;
     int32_t* d_idx = nullptr; int32_t* h_idx = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false, timed_map = false;
 };
 
@@ -285,6 +285,18 @@ icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t l
     if (s != ICET_OK) { nd->err = icet_last_error(nd->ctx); return s; }
     NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, st));
     NCHK(nd, hipEventRecord(nd->ev[2], st));
+    // While the device solves: the down-sample indices of this frame (simpleMapMaker.cpp:147-158).  They depend only on the
+    // row count and on the node's RNG stream, and Fisher-Yates over ~10^5 indices costs about as much host time as the solve
+    // costs device time.  (The previous frame's map kernel, which read d_idx, finished before the row-count sync above.)
+    int m_map = 0;
+    if (nd->p.map_capacity > 0) {
+        nd->indices.resize((size_t)nk);
+        std::iota(nd->indices.begin(), nd->indices.end(), (std::size_t)0);
+        std::shuffle(nd->indices.begin(), nd->indices.end(), nd->gen);
+        m_map = (int)std::min<int64_t>(nd->p.map_downsample, nk);
+        for (int i = 0; i < m_map; i++) nd->h_idx[i] = (int32_t)nd->indices[i];
+        if (m_map) NCHK(nd, hipMemcpyAsync(nd->d_idx, nd->h_idx, sizeof(int32_t) * m_map, hipMemcpyHostToDevice, st));
+    }
     NCHK(nd, hipStreamSynchronize(st));
     float X[6];
     std::memcpy(X, nd->h_out, sizeof(X)); std::memcpy(res->pred_stds, nd->h_out + 6, sizeof(float) * 6);
@@ -301,21 +313,16 @@ icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t l
     // ---- map queue (simpleMapMaker.cpp:147-158, 34-41) ----
     nd->timed_map = false;
     if (nd->p.map_capacity > 0) {
-        nd->indices.resize((size_t)nk);
-        std::iota(nd->indices.begin(), nd->indices.end(), (std::size_t)0);
-        std::shuffle(nd->indices.begin(), nd->indices.end(), nd->gen);
-        const int m = (int)std::min<int64_t>(nd->p.map_downsample, nk);
-        for (int i = 0; i < m; i++) nd->h_idx[i] = (int32_t)nd->indices[i];
-        if (m) NCHK(nd, hipMemcpyAsync(nd->d_idx, nd->h_idx, sizeof(int32_t) * m, hipMemcpyHostToDevice, st));
+        const int m = m_map;
         float Ri[9]; inverse3_lu(R, Ri);
         const int cap = nd->p.map_capacity;
         float* q = nd->d_map; const float* sc = nd->d_scan[cur];
         const int blocks = std::min((cap + 255) / 256, 256 * 8);
+        NCHK(nd, hipEventRecord(nd->ev[4], st));
         k_map_add_scan<<<blocks, 256, 0, st>>>(q, q + cap, q + 2 * (size_t)cap, cap, (int)nd->map_pos, m, sc, sc + lcur, sc + 2 * lcur, nd->d_idx,
                                                X[0], X[1], X[2], Ri[0], Ri[1], Ri[2], Ri[3], Ri[4], Ri[5], Ri[6], Ri[7], Ri[8]);
         NCHK(nd, hipGetLastError());
-        NCHK(nd, hipEventRecord(nd->ev[3], st));
-        NCHK(nd, hipStreamSynchronize(st));                       // h_idx is reused by the next frame
+        NCHK(nd, hipEventRecord(nd->ev[3], st));                  // not waited for: the next push (or icet_node_map) synchronises the stream
         if (nd->map_pos + m >= cap) nd->map_filled = true;
         nd->map_pos = (nd->map_pos + m) % cap;
         nd->timed_map = true;
@@ -434,7 +441,7 @@ icet_status icet_node_last_timing(icet_node* nd, float out_ms[3]) {
     float a = 0, b = 0, c = 0;
     NCHK(nd, hipEventElapsedTime(&a, nd->ev[0], nd->ev[1]));
     NCHK(nd, hipEventElapsedTime(&b, nd->ev[1], nd->ev[2]));
-    if (nd->timed_map) NCHK(nd, hipEventElapsedTime(&c, nd->ev[2], nd->ev[3]));
+    if (nd->timed_map) { NCHK(nd, hipEventSynchronize(nd->ev[3])); NCHK(nd, hipEventElapsedTime(&c, nd->ev[4], nd->ev[3])); }
     out_ms[0] = a; out_ms[1] = b; out_ms[2] = c;
     return ICET_OK;
 }

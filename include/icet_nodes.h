@@ -66,7 +66,7 @@ icet_status icet_node_map(icet_node* node, float* out, int64_t ld, int64_t* rows
 icet_status icet_node_prev_scan(icet_node* node, float* out, int64_t ld, int64_t* rows);
 
 /* Device-side time of the pieces of the most recent push, measured with HIP events on the context's stream:
- * [0] range filter ms, [1] ICET solve ms, [2] map update ms (0 if no map). */
+ * [0] range filter ms, [1] ICET solve ms, [2] map-queue kernel ms (0 if no map). */
 icet_status icet_node_last_timing(icet_node* node, float out_ms[3]);
 
 /* The HIP stream (hipStream_t as void*) and device a context enqueues on -- for callers that produce scans on the GPU. */

@@ -19,12 +19,13 @@ ICET_OK, ICET_ERR_BAD_ARG, ICET_ERR_NO_DEVICE, ICET_ERR_HIP, ICET_ERR_NOMEM, ICE
 _STATUS_NAMES = {0: "ICET_OK", 1: "ICET_ERR_BAD_ARG", 2: "ICET_ERR_NO_DEVICE", 3: "ICET_ERR_HIP", 4: "ICET_ERR_NOMEM", 5: "ICET_ERR_UNSUPPORTED"}
 FLAG_TIMING = 1
 
-# every symbol include/icet_hip.h and include/icet_nodes.h declare
+# every symbol include/icet_hip.h, include/icet_nodes.h and include/icet_io.h declare
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_batch",
                     "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch",
                     "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_map",
-                    "icet_node_prev_scan", "icet_node_last_timing", "icet_stream", "icet_device")
-_NON_STATUS = ("icet_version", "icet_last_error", "icet_stream", "icet_device")
+                    "icet_node_prev_scan", "icet_node_last_timing", "icet_stream", "icet_device",
+                    "icet_load_scan", "icet_free_scan", "icet_save_scan_npy")
+_NON_STATUS = ("icet_version", "icet_last_error", "icet_stream", "icet_device", "icet_free_scan")
 
 
 class IcetError(RuntimeError):
@@ -95,6 +96,9 @@ def load_library():
     L.icet_node_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.icet_node_last_timing.argtypes = [C.c_void_p, C.c_void_p]
     L.icet_node_prev_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.icet_load_scan.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int64)]
+    L.icet_free_scan.argtypes = [C.POINTER(C.c_float)]; L.icet_free_scan.restype = None
+    L.icet_save_scan_npy.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64]
     L.icet_stream.argtypes = [C.c_void_p]; L.icet_stream.restype = C.c_void_p
     L.icet_device.argtypes = [C.c_void_p]; L.icet_device.restype = C.c_int
     for name in EXPORTED_SYMBOLS:
@@ -368,3 +372,30 @@ class Node:
         if st != ICET_OK:
             raise IcetError(st, "icet_node_last_timing")
         return dict(filter_ms=t[0], solve_ms=t[1], map_ms=t[2])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Scan files (include/icet_io.h): what utils::loadPointCloudCSV (src/utils.cpp:12-91) and the Python side's np.load / KITTI
+# readers hand to the constructor.
+FMT_AUTO, FMT_NPY, FMT_OUSTER_CSV, FMT_XYZ_TSV, FMT_KITTI_BIN = range(5)
+
+
+def load_scan(path, fmt=FMT_AUTO):
+    """-> N x 3 float32 array (row-major view of the library's column-major buffer)."""
+    L = load_library()
+    p = C.POINTER(C.c_float)(); n = C.c_int64()
+    st = L.icet_load_scan(os.fsencode(path), int(fmt), C.byref(p), C.byref(n))
+    if st != ICET_OK:
+        raise IcetError(st, "icet_load_scan(%s)" % path)
+    try:
+        a = np.ctypeslib.as_array(p, shape=(3, max(n.value, 1)))[:, :n.value].T.copy()
+    finally:
+        L.icet_free_scan(p)
+    return a
+
+
+def save_scan_npy(path, scan):
+    a = _colmajor(scan)
+    st = load_library().icet_save_scan_npy(os.fsencode(path), a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[1])
+    if st != ICET_OK:
+        raise IcetError(st, "icet_save_scan_npy(%s)" % path)

@@ -1,0 +1,123 @@
+"""Scan file formats: include/icet_io.h against oracle/scan_io.py, and both against the
+reference's own third-party CSV parser (oracle/_ref/csv_ref, built from /root/reference/include/csv.hpp when that tree is
+present).  Bit-exact: the loaders only parse and convert."""
+import os
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+def _ouster_file(path, n=300, seed=3, crlf=False, blank_lines=False, trailing_newline=True):
+    rs = np.random.RandomState(seed)
+    nl = "\r\n" if crlf else "\n"
+    lines = ["# ouster pcap dump", ",".join("col%d" % i for i in range(14))]
+    vals = rs.randint(-120000, 120000, size=(n, 14))
+    for k, r in enumerate(vals):
+        lines.append(",".join(str(int(v)) for v in r))
+        if blank_lines and k % 50 == 7:
+            lines.append("")
+    txt = nl.join(lines) + (nl if trailing_newline else "")
+    open(path, "w", newline="").write(txt)
+    return vals
+
+
+def _tsv_file(path, n=200, seed=4):
+    rs = np.random.RandomState(seed)
+    pts = (rs.normal(size=(n, 3)) * 20).astype(np.float32)
+    with open(path, "w") as f:
+        for p in pts:
+            f.write("%.6f\t%.7g\t%.4e\n" % (p[0], p[1], p[2]))
+    return pts
+
+
+@pytest.mark.parametrize("crlf,blank,trail", [(False, False, True), (True, False, True), (False, True, False)])
+def test_ouster_csv_matches_oracle_and_reference_parser(tmp_path, crlf, blank, trail):
+    from icet_amd import api
+    from oracle import scan_io
+    p = str(tmp_path / "pcap_out_000261.csv")
+    vals = _ouster_file(p, crlf=crlf, blank_lines=blank, trailing_newline=trail)
+    got = api.load_scan(p)                                   # .csv -> Ouster
+    ref = scan_io.load_ouster_csv(p)
+    assert got.dtype == np.float32 and np.array_equal(got, ref)
+    # the quirk: two header lines AND the first two data rows are gone (utils.cpp:21-29)
+    assert len(got) == len(vals) - 2 and np.array_equal(got[0], vals[2, 8:11].astype(np.float32) / np.float32(1000))
+    rows = scan_io.reference_parser_rows(p, "ouster")
+    if rows is not None:                                     # the reference's own csv.hpp
+        assert np.array_equal(rows.astype(np.int64).astype(np.float32) / np.float32(1000), got)
+
+
+def test_xyz_tsv_matches_oracle_and_reference_parser(tmp_path):
+    from icet_amd import api
+    from oracle import scan_io
+    p = str(tmp_path / "desk_test_20.txt")
+    pts = _tsv_file(p)
+    got = api.load_scan(p)
+    assert np.array_equal(got, scan_io.load_xyz_tsv(p))
+    assert len(got) == len(pts) - 1                          # the quirk: the first point is taken for a header (utils.cpp:65)
+    rows = scan_io.reference_parser_rows(p, "xyz")
+    if rows is not None:
+        assert np.array_equal(rows.astype(np.float32), got)
+
+
+@pytest.mark.parametrize("dtype,order", [("<f8", "C"), ("<f8", "F"), ("<f4", "C"), ("<f4", "F")])
+def test_npy_all_layouts(tmp_path, dtype, order):
+    from icet_amd import api
+    from oracle import scan_io
+    d = np.load(os.path.join(GOLDEN, "scans_frame_804_805.npz"))["scan1"][:5000].astype(np.float64)
+    d[3] = [np.nan, -0.0, 1e-30]
+    a = np.asarray(d.astype(dtype), order=order)
+    p = str(tmp_path / "frame.npy")
+    np.save(p, a)
+    got = api.load_scan(p)
+    assert np.array_equal(got.view(np.uint32), scan_io.load_npy(p).view(np.uint32))
+    # and back: icet_save_scan_npy writes what np.load reads
+    q = str(tmp_path / "out.npy")
+    api.save_scan_npy(q, got)
+    assert np.array_equal(np.load(q).view(np.uint32), got.view(np.uint32))
+
+
+def test_npy_v2_header_and_kitti_bin(tmp_path):
+    from icet_amd import api
+    from oracle import scan_io
+    import numpy.lib.format as fmt
+    a = np.arange(30, dtype=np.float64).reshape(10, 3)
+    p = str(tmp_path / "v2.npy")
+    with open(p, "wb") as f:
+        fmt.write_array(f, a, version=(2, 0))
+    assert np.array_equal(api.load_scan(p), a.astype(np.float32))
+    rs = np.random.RandomState(5)
+    velo = rs.normal(size=(1234, 4)).astype(np.float32)
+    b = str(tmp_path / "0000000001.bin")
+    velo.tofile(b)
+    assert np.array_equal(api.load_scan(b), scan_io.load_kitti_bin(b)) and np.array_equal(api.load_scan(b), velo[:, :3])
+
+
+def test_loader_errors(tmp_path):
+    from icet_amd import api
+    with pytest.raises(api.IcetError) as e:
+        api.load_scan(str(tmp_path / "missing.npy"))
+    assert e.value.status == api.ICET_ERR_BAD_ARG
+    bad = tmp_path / "bad.npy"; bad.write_bytes(b"not a numpy file")
+    with pytest.raises(api.IcetError) as e:
+        api.load_scan(str(bad))
+    assert e.value.status == api.ICET_ERR_UNSUPPORTED
+    i4 = str(tmp_path / "ints.npy"); np.save(i4, np.zeros((4, 3), np.int32))
+    with pytest.raises(api.IcetError):
+        api.load_scan(i4)
+    short = tmp_path / "short.csv"; short.write_text("a\nb\n1,2,3\n4,5,6\n7,8,9\n")      # fewer than 11 columns
+    with pytest.raises(api.IcetError):
+        api.load_scan(str(short))
+    empty = tmp_path / "empty.txt"; empty.write_text("")
+    assert api.load_scan(str(empty)).shape == (0, 3)
+    assert api.load_scan(str(tmp_path / "nothing.bin") if (tmp_path / "nothing.bin").write_bytes(b"") == 0 else "").shape == (0, 3)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/sample_data/frame_804.npy"), reason="reference tree not present (GPU box)")
+def test_reference_sample_data_loads_to_the_committed_fixture():
+    """The reference's own sample files (float64, C order) through the C loader == the float32 scans the golden fixtures hold."""
+    from icet_amd import api
+    d = np.load(os.path.join(GOLDEN, "scans_frame_804_805.npz"))
+    for name, key in (("frame_804.npy", "scan1"), ("frame_805.npy", "scan2")):
+        got = api.load_scan("/root/reference/src/sample_data/" + name)
+        assert np.array_equal(got.view(np.uint32), d[key].view(np.uint32))

@@ -186,3 +186,32 @@ def test_gpu_range_filter_full_size_and_device_push(gpu_ctx):
         res = g.push(scan[:m])
         assert res["n_kept"] == len(_range_filter(scan[:m], 2.0))
     g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_cpp_node_demo(tmp_path, gpu_ctx, seq64):
+    """include/icet_nodes.hpp compiled with plain g++: frames read from .npy files by icet_load_scan, fed to OdometryNode /
+    MapMakerNode::pointCloudCallback; same numbers as the Python mirror of the same C ABI, bit for bit."""
+    import os, subprocess
+    from icet_amd import api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = []
+    for k, s in enumerate(seq64[:3]):
+        p = str(tmp_path / ("frame_%03d.npy" % k)); np.save(p, s.astype(np.float64)); files.append(p)      # float64 like the reference's sample data
+    exe = str(tmp_path / "node_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "node_demo.cpp"),
+                           "-L", os.path.join(root, "icet_amd", "lib"), "-licet_hip", "-Wl,-rpath," + os.path.join(root, "icet_amd", "lib"), "-o", exe])
+    for mode, kw in (("odometry", api.ODOMETRY_NODE), ("mapmaker", api.MAP_MAKER_NODE)):
+        out = subprocess.run([exe, mode] + files, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        rows = [l.split() for l in out.stdout.strip().splitlines() if l.startswith("frame")]
+        g = api.Node(gpu_ctx, **kw)
+        for k, s in enumerate(seq64[:3]):
+            r = g.push(s)
+            assert int(rows[k][3]) == int(r["solved"]) and int(rows[k][5]) == r["n_kept"]
+            assert np.array_equal(np.array(rows[k][7:13], np.float32), r["X"])
+            assert np.array_equal(np.array(rows[k][14:17], np.float32), r["pose"][:3, 3])
+            assert int(rows[k][-1]) == r["map_rows"]
+        g.close()
+        if mode == "mapmaker":
+            assert out.stdout.strip().splitlines()[-1] == "map_rows 4000"

@@ -158,8 +158,12 @@ __global__ __launch_bounds__(kBlock) void k_inverse_perm(const PairDesc* __restr
 // that eight loads are in flight per thread instead of one.
 constexpr int kWalk = 8;
 
+// The flag goes into bit 15 of the row's voxel id (V <= 32768): k_scramble_src needs "did step u execute" and "which voxel is
+// row u in" for the same u, so one 2-byte random read serves both.
+constexpr uint16_t kExecBit = 0x8000u, kBinMask = 0x7FFFu;
+
 __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
-                                                       uint8_t* __restrict__ exec, int32_t* __restrict__ flags, int max_walk, int n_pairs, int chunks) {
+                                                       uint16_t* __restrict__ bin16, int32_t* __restrict__ flags, int max_walk, int n_pairs, int chunks) {
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;
     const PairDesc d = desc[pair];
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
 #pragma unroll
         for (int k = 0; k < kWalk; k++) {
             const int v = base + k * kBlock;
-            if (v < hi_) exec[o + v] = (moved[k] && !(len[k] & 1)) ? 1 : 0;
+            if (v < hi_ && moved[k] && !(len[k] & 1)) bin16[o + v] |= kExecBit;      // k_scan1_spherical wrote the id with the bit clear
         }
     }
 }
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
 // Fused with the first step of the voxel multi-split (k_bin_hist): the row that lands on a position is known here, so
 // its voxel id and this tile's voxel histogram cost no extra pass over src[].
 __global__ __launch_bounds__(kBlock) void k_scramble_src(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
-                                                         const uint8_t* __restrict__ exec, int32_t* __restrict__ src, int32_t* __restrict__ flags, int max_walk,
+                                                         int32_t* __restrict__ src, int32_t* __restrict__ flags, int max_walk,
                                                          const uint16_t* __restrict__ bin16, uint16_t* __restrict__ binpos, uint32_t* __restrict__ counts, int V,
                                                          int n_pairs, int chunks) {
     extern __shared__ uint32_t lh[];
@@ -218,24 +222,24 @@ __global__ __launch_bounds__(kBlock) void k_scramble_src(const PairDesc* __restr
     __syncthreads();
     for (int base = lo_ + threadIdx.x; base < hi_; base += kWalk * kBlock) {
         int f[kWalk], u[kWalk], len[kWalk]; bool act[kWalk];
-        int sv[kWalk], pv[kWalk]; uint8_t ev[kWalk];
+        int sv[kWalk], pv[kWalk]; uint16_t wv[kWalk], fb[kWalk];    // fb: packed word of the row f[] (its voxel id is what the histogram needs)
 #pragma unroll
         for (int k = 0; k < kWalk; k++) {
             const int v = base + k * kBlock;
             const bool valid = v < hi_;
             const size_t i = o + (valid ? v : lo_);
-            sv[k] = (int)s[i]; pv[k] = pred[i]; ev[k] = exec[i];
+            sv[k] = (int)s[i]; pv[k] = pred[i]; wv[k] = bin16[i];
         }
-        uint8_t ep[kWalk];
+        uint16_t wp[kWalk];
 #pragma unroll
-        for (int k = 0; k < kWalk; k++) ep[k] = exec[o + pv[k]];
+        for (int k = 0; k < kWalk; k++) wp[k] = bin16[o + pv[k]];
 #pragma unroll
         for (int k = 0; k < kWalk; k++) {
             const int v = base + k * kBlock;
             const bool valid = v < hi_;
             const bool moved = valid && sv[k] != v;
-            f[k] = moved ? pv[k] : v;
-            act[k] = moved && ev[k] && !ep[k];                  // head of a run of executed steps
+            f[k] = moved ? pv[k] : v; fb[k] = moved ? wp[k] : wv[k];
+            act[k] = moved && (wv[k] & kExecBit) && !(wp[k] & kExecBit);   // head of a run of executed steps
             u[k] = v; len[k] = 0;
         }
         bool any = false;
@@ -245,16 +249,16 @@ __global__ __launch_bounds__(kBlock) void k_scramble_src(const PairDesc* __restr
             int nu[kWalk];
 #pragma unroll
             for (int k = 0; k < kWalk; k++) nu[k] = act[k] ? (int)s[o + u[k]] : 0;
-            uint8_t ne[kWalk];
+            uint16_t ne[kWalk];
 #pragma unroll
-            for (int k = 0; k < kWalk; k++) ne[k] = act[k] ? exec[o + nu[k]] : 0;
+            for (int k = 0; k < kWalk; k++) ne[k] = act[k] ? bin16[o + nu[k]] : (uint16_t)0;
             any = false;
 #pragma unroll
             for (int k = 0; k < kWalk; k++) {
                 if (act[k]) {
                     u[k] = nu[k]; len[k]++;
-                    if (!ne[k]) { f[k] = u[k]; act[k] = false; }
-                    else if (len[k] > max_walk) { atomicOr(&flags[pair], 1); f[k] = u[k]; act[k] = false; }
+                    if (!(ne[k] & kExecBit)) { f[k] = u[k]; fb[k] = ne[k]; act[k] = false; }
+                    else if (len[k] > max_walk) { atomicOr(&flags[pair], 1); f[k] = u[k]; fb[k] = ne[k]; act[k] = false; }
                 }
                 any |= act[k];
             }
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void k_scramble_src(const PairDesc* __restr
             const int v = base + k * kBlock;
             if (v < hi_) {
                 src[o + v] = f[k];
-                const uint16_t b = bin16[o + f[k]];
+                const uint16_t b = fb[k] & kBinMask;
                 binpos[o + v] = b;
                 atomicAdd(&lh[b], 1u);
             }
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_hist(const PairDesc* __restrict_
     __syncthreads();
     const size_t o = d.off1;
     for (int v = lo_ + threadIdx.x; v < hi_; v += kBlock) {
-        const uint16_t b = bin16[o + src[o + v]];
+        const uint16_t b = bin16[o + src[o + v]] & kBinMask;
         binpos[o + v] = b;
         atomicAdd(&lh[b], 1u);
     }
@@ -432,6 +436,8 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
 __global__ __launch_bounds__(kBlock) void k_gather_sorted(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ sorted_row,
                                                           const float* __restrict__ r1, const float* __restrict__ th1, const float* __restrict__ ph1,
                                                           float* __restrict__ rs, float* __restrict__ ths, float* __restrict__ phs, int n_pairs, int chunks) {
+    // (a 16-byte (r, theta, phi, -) record per row, gathered with one load, was measured SLOWER: +0.16 ms per 256-pair
+    // keyframe -- the extra 16 B/row written by k_scan1_spherical cost more than the two saved gathers)
     ICET_FOR_CHUNK_OF_SCAN1(i) {
         const size_t o = d.off1;
         const int row = (int)sorted_row[o + i];
@@ -1220,9 +1226,9 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     if (c.stage_event && c.stage_at == 1) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     e = hipMemsetAsync(w.flags, 0, sizeof(int32_t) * c.n_pairs, st); if (e != hipSuccess) return e;
     const int max_walk = 4096;
-    k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.exec, w.flags, max_walk, np, chunks);
+    k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.bin16, w.flags, max_walk, np, chunks);
     ICET_LAUNCH_CHECK();
-    k_scramble_src<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.valB, w.pred, w.exec, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);
+    k_scramble_src<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.valB, w.pred, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);
     ICET_LAUNCH_CHECK();
     k_scramble_serial<<<c.n_pairs, 64, 0, st>>>(w.desc, w.valB, w.pred /* reused as scratch */, w.src, w.flags);
     ICET_LAUNCH_CHECK();

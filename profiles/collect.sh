@@ -15,8 +15,9 @@ cd /tmp && export TMPDIR=/tmp
 # all 256 pairs distinct: 745 MB of scans, well past the 256 MiB Infinity Cache, so FETCH_SIZE is real HBM traffic
 CMD="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- $CMD > $OUT/stats.log 2>&1
-cp /tmp/p_stats/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
+grep -E "^\"Name\"|icet::" /tmp/p_stats/*/*kernel_stats.csv > $OUT/${TAG}_kernel_stats.csv      # this library's kernels only (torch's generator kernels dropped)
 python3 $R/profiles/summarize.py $OUT/${TAG}_kernel_stats.csv 7 > $OUT/${TAG}_kernels.txt
+python3 $R/profiles/trace_summary.py $(ls /tmp/p_stats/*/*kernel_trace.csv | head -1) >> $OUT/${TAG}_kernels.txt
 tail -1 $OUT/stats.log > $OUT/${TAG}_bench_under_rocprof.json
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d /tmp/p_write -- $CMD > $OUT/write.log 2>&1
@@ -31,7 +32,7 @@ python3 - <<PY
 import csv, json, re, collections
 def mean_counter(path, kernel, counter):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
-    v = sorted(v)[len(v) // 4:]            # drop the single-pair / warm-up tail (small launches)
+    v = [x for x in v if x >= 0.6 * max(v)]   # the whole-batch launches of the timed steps (the parts of the untimed steps are ~1/3 the size)
     return sum(v) / len(v)
 fetch_kb = mean_counter("/tmp/p_fetch.csv", "k_gn_accumulate", "FETCH_SIZE")
 write_kb = mean_counter("/tmp/p_write.csv", "k_gn_accumulate", "WRITE_SIZE")

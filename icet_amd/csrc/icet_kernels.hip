@@ -974,7 +974,9 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
             const int s = pc[j].s;
             if (s != cur) {
                 if (cur >= 0) {
-                    if (__ballot(bs >= 0) != 0ull) { flush(bs, braw, bin, B0, B1, B2, B3, B4, B5, B6, B7, B8); bs = -1; }
+                    // only a lane whose OWN stash is occupied (a third run inside its 4 points: rare) flushes here; a wave-wide
+                    // "any lane has a stash" test would run the flush at almost every j, for lanes that could have waited
+                    if (bs >= 0) flush(bs, braw, bin, B0, B1, B2, B3, B4, B5, B6, B7, B8);
                     bs = cur; braw = nraw; bin = nin; B0 = S0; B1 = S1; B2 = S2; B3 = S3; B4 = S4; B5 = S5; B6 = S6; B7 = S7; B8 = S8;
                 }
                 cur = s; nraw = 0; nin = 0; S0 = S1 = S2 = S3 = S4 = S5 = S6 = S7 = S8 = 0.f;

@@ -1,0 +1,6 @@
+#!/bin/bash
+# Times bench.py against alternative builds of the library (icet_amd/lib_exp*/, made with `make OUT=../lib_expN EXTRA=-D...`).
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+run() { echo "== $*"; env "$@" python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-latency 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], d['ms_per_step'], 'acc_ms', r['avg_launch_ms'], 'frac', r['frac'], 'kf', r['keyframe_ms_per_step'], 'gn', r['gn_loop_ms_per_step'])"; }
+run ICET_BATCH_PARTS=1
+for l in icet_amd/lib_exp*/libicet_hip.so; do run ICET_BATCH_PARTS=1 ICET_HIP_LIB=$PWD/$l; done

@@ -227,6 +227,9 @@ struct Solver {
         for (int i = 0; i < N; i++) idx[cur[b[i]]++] = i;
     }
 
+    const float* sign_ref = nullptr;   // optional V x 9 eigenvectors (columns, row-major) to align signs with; see fitCells1
+    int n_sign_flips = 0;
+
     void boundsRow(int theta, int phi, float inner, float outer) {
         float azimMin_i = (static_cast<float>(theta) / T) * (2 * M_PI);
         float azimMax_i = (static_cast<float>(theta + 1) / T) * (2 * M_PI);
@@ -267,6 +270,19 @@ struct Solver {
                 f.has_fit = true; f.sigma = cov; for (int a = 0; a < 3; a++) f.mu[a] = mean[a];
                 float ev[3]; Mat evec(3, 3);
                 selfadjoint_eigen(cov, /*fixed3=*/true, ev, evec);
+                // Eigenvector signs are implementation-defined, and the reference's result DEPENDS on them: through the
+                // rows-of-V sigma points (Q9) and through L*U^T with U = V^T, which applies V and is therefore not
+                // invariant under column sign flips (Q8).  On near-degenerate voxels the QR iteration's signs flip with
+                // the last bits of the covariance, so two correct builds of the reference disagree there.  A test may pass
+                // the eigenvectors another implementation obtained: columns are then flipped to agree with them, which
+                // separates "different signs" from "different algebra".  NULL (the default) keeps the natural signs.
+                if (sign_ref) {
+                    const float* ref = sign_ref + (size_t)v * 9;
+                    for (int k = 0; k < 3; k++) {
+                        const float dot = evec(0, k) * ref[k] + evec(1, k) * ref[3 + k] + evec(2, k) * ref[6 + k];
+                        if (dot < 0.f) { for (int r = 0; r < 3; r++) evec(r, k) = -evec(r, k); n_sign_flips++; }
+                    }
+                }
                 f.V = evec;
                 // axislen = 2*sqrt(lambda);  rotated = diag(axislen) * U^T = diag(axislen) * V  (rows!)  icet.cpp:187-193
                 float sp[6][3];
@@ -502,6 +518,21 @@ int icet_oracle_solve(const icet_oracle_params* p, const float* scan1, int64_t n
     s.run(scan1, n1, ld1, scan2, n2, ld2, x0);
     for (int k = 0; k < 6; k++) { x_out[k] = s.X[k]; pred_stds_out[k] = s.pred_stds[k]; }
     if (cov_out) for (int a = 0; a < 36; a++) cov_out[a] = s.noise_mat.a[a];
+    return 0;
+}
+
+// Same solve with the eigenvector signs of every fitted voxel aligned to `evecs_ref` (V x 9, columns = eigenvectors, row-major;
+// all-zero rows are ignored).  Returns the number of columns that had to be flipped in *n_flips.  TESTS ONLY.
+int icet_oracle_solve_signed(const icet_oracle_params* p, const float* scan1, int64_t n1, int64_t ld1,
+                             const float* scan2, int64_t n2, int64_t ld2, const float x0[6], const float* evecs_ref,
+                             float x_out[6], float pred_stds_out[6], float cov_out[36], icet_oracle_trace* trace, int32_t* n_flips) {
+    if (!p || !scan1 || !scan2 || !x0 || n1 < 0 || n2 < 0 || ld1 < n1 || ld2 < n2 || p->bins_phi <= 0 || p->bins_theta <= 0 || p->runlen < 0) return 1;
+    ico::Solver s; s.prm = *p; s.tr = trace; s.sign_ref = evecs_ref;
+    if (trace) trace->n_ub_voxels = 0;
+    s.run(scan1, n1, ld1, scan2, n2, ld2, x0);
+    for (int k = 0; k < 6; k++) { x_out[k] = s.X[k]; pred_stds_out[k] = s.pred_stds[k]; }
+    if (cov_out) for (int a = 0; a < 36; a++) cov_out[a] = s.noise_mat.a[a];
+    if (n_flips) *n_flips = s.n_sign_flips;
     return 0;
 }
 

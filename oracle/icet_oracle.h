@@ -54,6 +54,12 @@ int icet_oracle_solve(const icet_oracle_params* p, const float* scan1, int64_t n
                       const float* scan2, int64_t n2, int64_t ld2, const float x0[6],
                       float x_out[6], float pred_stds_out[6], float cov_out[36], icet_oracle_trace* trace);
 
+/* TESTS ONLY: the same solve with every fitted voxel's eigenvector signs aligned to evecs_ref (V x 9, eigenvectors as columns,
+ * row-major; zero rows ignored).  Separates implementation-defined sign differences from algebra differences. */
+int icet_oracle_solve_signed(const icet_oracle_params* p, const float* scan1, int64_t n1, int64_t ld1,
+                             const float* scan2, int64_t n2, int64_t ld2, const float x0[6], const float* evecs_ref,
+                             float x_out[6], float pred_stds_out[6], float cov_out[36], icet_oracle_trace* trace, int32_t* n_flips);
+
 int icet_oracle_solve_batch(const icet_oracle_params* p, int n_pairs, const float* const* scan1, const int64_t* n1,
                             const float* const* scan2, const int64_t* n2, const float* x0,
                             float* x_out, float* pred_stds_out, float* cov_out, int n_threads);

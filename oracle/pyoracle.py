@@ -63,6 +63,9 @@ def lib():
         L.icet_oracle_scramble.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.icet_oracle_get_H.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.icet_oracle_R.argtypes = [C.c_void_p, C.c_void_p]
+        L.icet_oracle_solve_signed.restype = C.c_int
+        L.icet_oracle_solve_signed.argtypes = [C.POINTER(Params), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 
@@ -78,8 +81,10 @@ def make_params(runlen=7, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1
     return Params(runlen, bins_phi, bins_theta, n, thresh, buff, mode)
 
 
-def solve(scan1, scan2, x0=None, trace=False, **kw):
-    """Run the restated ICET constructor.  Returns dict(X, pred_stds, cov[, trace arrays])."""
+def solve(scan1, scan2, x0=None, trace=False, sign_ref=None, **kw):
+    """Run the restated ICET constructor.  Returns dict(X, pred_stds, cov[, trace arrays]).
+    sign_ref: optional (V, 3, 3) eigenvectors (as columns) of another implementation; the oracle's eigenvector signs are
+    aligned with them (icet_oracle_solve_signed) and the number of flipped columns is returned as ``n_sign_flips``."""
     p = make_params(**kw)
     s1, s2 = colmajor(scan1), colmajor(scan2)
     x0 = np.zeros(6, np.float32) if x0 is None else np.asarray(x0, np.float32).copy()
@@ -100,8 +105,16 @@ def solve(scan1, scan2, x0=None, trace=False, **kw):
         for k, v in arr.items():
             setattr(tr, k, v.ctypes.data_as(_I32P if v.dtype == np.int32 else _F32P))
         out["trace"] = arr
-    rc = lib().icet_oracle_solve(C.byref(p), s1.ctypes.data, s1.shape[1], s1.shape[1], s2.ctypes.data, s2.shape[1], s2.shape[1],
-                                 x0.ctypes.data, X.ctypes.data, ps.ctypes.data, cov.ctypes.data, C.byref(tr) if tr is not None else None)
+    if sign_ref is not None:
+        ref = np.ascontiguousarray(np.asarray(sign_ref, np.float32).reshape(p.bins_phi * p.bins_theta, 9))
+        flips = C.c_int32(0)
+        rc = lib().icet_oracle_solve_signed(C.byref(p), s1.ctypes.data, s1.shape[1], s1.shape[1], s2.ctypes.data, s2.shape[1], s2.shape[1],
+                                            x0.ctypes.data, ref.ctypes.data, X.ctypes.data, ps.ctypes.data, cov.ctypes.data,
+                                            C.byref(tr) if tr is not None else None, C.byref(flips))
+        out["n_sign_flips"] = int(flips.value)
+    else:
+        rc = lib().icet_oracle_solve(C.byref(p), s1.ctypes.data, s1.shape[1], s1.shape[1], s2.ctypes.data, s2.shape[1], s2.shape[1],
+                                     x0.ctypes.data, X.ctypes.data, ps.ctypes.data, cov.ctypes.data, C.byref(tr) if tr is not None else None)
     if rc:
         raise ValueError("icet_oracle_solve: bad argument (rc=%d)" % rc)
     out.update(X=X, pred_stds=ps, cov=cov.reshape(6, 6))

@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- $CMD > $
 grep -E "^\"Name\"|icet::" /tmp/p_stats/*/*kernel_stats.csv > $OUT/${TAG}_kernel_stats.csv      # this library's kernels only (torch's generator kernels dropped)
 python3 $R/profiles/summarize.py $OUT/${TAG}_kernel_stats.csv 7 > $OUT/${TAG}_kernels.txt
 python3 $R/profiles/trace_summary.py $(ls /tmp/p_stats/*/*kernel_trace.csv | head -1) >> $OUT/${TAG}_kernels.txt
-tail -1 $OUT/stats.log > $OUT/${TAG}_bench_under_rocprof.json
+grep "^{\"metric\"" $OUT/stats.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d /tmp/p_write -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/p_sq1 -- $CMD > $OUT/sq1.log 2>&1

@@ -372,3 +372,35 @@ def test_cpp_host_class_demo(tmp_path, gpu_ctx, frames, frames_golden):
     assert np.array_equal(X, ref["X"])
     assert np.abs(X[:3] - frames_golden["X"][:3]).max() <= TOL_T
     assert lines["ellipsoids"].split()[0] == "86" and lines["bad_status"].strip() == "1"
+
+
+def test_many_pairs_parity_given_equal_eigenvector_signs(gpu_ctx):
+    """48 pairs of the bench batch (k = 120..167, which include pairs whose natural eigenvector signs differ between the two
+    implementations).  The reference's result depends on the implementation-defined SIGNS of the scan-1 eigenvectors -- through
+    the rows-of-V sigma points and through `L*U^T` with U = V^T, which applies V and is not invariant under column
+    flips (Q8; one 27-point far voxel of pair 159 changes its 6x6 contribution 18-fold and X by 2.7 cm under a flip).  On
+    near-degenerate voxels the QR iteration's signs flip with the last bits of the covariance (0.11 % of all eigenvector
+    columns over the 256-pair batch), so two correct builds of the reference disagree there.  Parity is therefore asserted with
+    the oracle's signs aligned to the device's; the natural-sign discordance is reported and bounded."""
+    from icet_amd import lidar_sim as ls
+    from oracle import pyoracle as po
+    dev = torch.device("cuda", 0)
+    over, flips, cols, nat_over = [], 0, 0, 0
+    for k in range(120, 168):
+        s1, s2, _ = ls.make_batch_pair(k, device=dev)
+        a, b = s1.T.cpu().numpy(), s2.T.cpu().numpy()
+        g = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
+        ref = po.solve(a, b, sign_ref=g["aux"]["evecs1"])
+        flips += ref["n_sign_flips"]; cols += 3 * int(g["aux"]["has_fit"].sum())
+        dt, dr = np.abs(g["X"][:3] - ref["X"][:3]).max(), np.abs(g["X"][3:] - ref["X"][3:]).max()
+        if ref["n_sign_flips"]:
+            nat = po.solve(a, b)
+            nat_over += int(np.abs(g["X"][:3] - nat["X"][:3]).max() > TOL_T)
+        if dt > TOL_T or dr > TOL_R:
+            # an edge-flipping point somewhere in the 7 iterations: must be explained by the oracle's own 1-ulp sensitivity
+            sens = oracle_sensitivity(a, b, sign_ref=g["aux"]["evecs1"])
+            over.append((k, dt, dr, sens))
+            assert dt <= max(TOL_T, 5 * sens[:3].max()) and dr <= max(TOL_R, 5 * sens[3:].max()), (k, dt, dr, sens)
+    assert len(over) <= 2, over
+    assert 0 < flips <= 0.01 * cols, (flips, cols)          # this range of pairs does contain sign-discordant voxels, and they are rare
+    print("sign-discordant eigenvector columns: %d of %d; pairs moved beyond tolerance by them: %d; aligned-sign outliers: %s" % (flips, cols, nat_over, over))

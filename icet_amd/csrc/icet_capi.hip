@@ -92,7 +92,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, dev_realloc(w.xf, (size_t)np * 48));
         HIPCHK(c, dev_realloc(w.X, (size_t)np * 6));
         HIPCHK(c, dev_realloc(w.flags, np));
-        HIPCHK(c, dev_realloc(w.splitters, (size_t)np * 128)); HIPCHK(c, dev_realloc(w.n_buckets, np)); HIPCHK(c, dev_realloc(w.bucket_start, (size_t)np * 129));
+        HIPCHK(c, dev_realloc(w.splitters, (size_t)np * kRankSortMaxBuckets)); HIPCHK(c, dev_realloc(w.n_buckets, np)); HIPCHK(c, dev_realloc(w.bucket_start, (size_t)np * (kRankSortMaxBuckets + 1)));
         if (c->h_desc) { HIPCHK(c, hipHostFree(c->h_desc)); c->h_desc = nullptr; }
         if (c->h_seg) { HIPCHK(c, hipHostFree(c->h_seg)); c->h_seg = nullptr; }
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_desc), sizeof(PairDesc) * np));
@@ -251,7 +251,7 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     cfg.kf_chunks = (mx1 + 256 * cfg.kf_pts_per_thread - 1) / (256 * cfg.kf_pts_per_thread);
     if (cfg.kf_chunks < 1) cfg.kf_chunks = 1;
     {
-        const size_t need = (size_t)n_pairs * cfg.kf_chunks * (cfg.V > 128 ? cfg.V : 128);
+        const size_t need = (size_t)n_pairs * cfg.kf_chunks * (cfg.V > kRankSortMaxBuckets ? cfg.V : kRankSortMaxBuckets);
         if (need > w.cap_counts) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             HIPCHK(c, dev_realloc(w.counts, need)); HIPCHK(c, dev_realloc(w.tile_base, need));

@@ -13,6 +13,11 @@ constexpr int kAccWords = 20;        // in HBM: AoS, 80 bytes per slot (8-byte a
 constexpr int kAccLds   = 20;        // in LDS: SoA (u32 raw[nl], u32 in[nl], i64 sum[9][nl]) -> 80 bytes per slot
 constexpr float kFixScale = 1073741824.0f;            // 2^30
 constexpr double kFixInv = 1.0 / 1073741824.0;
+#ifndef ICET_RS_BUCKET_BITS
+#define ICET_RS_BUCKET_BITS 7
+#endif
+constexpr int kRankSortBucketBits = ICET_RS_BUCKET_BITS;       // rank sort (icet_ranksort.hip): at most 2^bits buckets per pair, ids travel as u8
+constexpr int kRankSortMaxBuckets = 1 << kRankSortBucketBits;
 constexpr int kMaxVoxels = 32768;    // slot ids travel as int16
 
 // One scan pair as the kernels see it (device pointers, column-major N x 3).

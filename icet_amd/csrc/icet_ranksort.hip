@@ -21,16 +21,27 @@
 // Traffic ~30 B per row instead of ~130 B.
 #include <hip/hip_runtime.h>
 #include "icet_internal.h"
+#include <cstdlib>
 
 namespace icet {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kSamples = 2048;       // sampled keys per pair (power of two, sorted by 1024 threads)
-constexpr int kMaxBuckets = 128;     // power of two
-constexpr int kBucketBits = 7;
-constexpr int kBucketTarget = 1024;  // aimed-for rows per bucket
-constexpr int kCap = 2560;           // rows a bucket may have and still be sorted in LDS (45 KB per block -> 3 blocks per CU)
+#ifndef ICET_RS_SAMPLES
+#define ICET_RS_SAMPLES 2048
+#endif
+constexpr int kSamples = ICET_RS_SAMPLES;          // sampled keys per pair (power of two, sorted by 1024 threads)
+constexpr int kMaxBuckets = kRankSortMaxBuckets;   // power of two (icet_internal.h: the workspace is sized with it)
+constexpr int kBucketBits = kRankSortBucketBits;
+#ifndef ICET_RS_TARGET
+#define ICET_RS_TARGET 512
+#endif
+// Rows per bucket aimed for.  With at most 128 buckets a 64-channel scan (~116 k rows) gets ~900-row buckets; the LDS
+// capacity of the per-bucket sort is chosen per launch from the largest scan (rank_sort_cap): measured on 256 such pairs,
+// 1280 rows (25 KB, 6 blocks per CU) beats the earlier fixed 2560 (45 KB, 3 blocks) by 0.2 ms -- the sort is latency bound
+// and wants the occupancy -- even though a few per cent of the buckets then overflow to the global-scratch path.
+constexpr int kBucketTarget = ICET_RS_TARGET;
+constexpr int kCapMin = 1280, kCapMax = 9216;  // 9216 rows = 152 KB: one block per CU, still far better than global scratch
 constexpr int kSortBlock = 256;
 constexpr int kSortWaves = kSortBlock / 64;
 
@@ -170,7 +181,7 @@ constexpr int kOffCnt = 0, kOffTot = kSortWaves * 256, kOffWsum = kOffTot + 256,
 // kLds selects, at compile time, LDS arrays (indexed off the extern __shared__ base, so the compiler emits ds_*
 // instructions) or the global scratch pointers; `sel` says which of the two buffers is the input.
 template <bool kLds>
-__device__ __forceinline__ void radix_pass(uint32_t* smem, int sel, const uint32_t* gK0, const uint32_t* gI0, uint32_t* gK1, uint32_t* gI1, int n, int shift) {
+__device__ __forceinline__ void radix_pass(uint32_t* smem, int kCap, int sel, const uint32_t* gK0, const uint32_t* gI0, uint32_t* gK1, uint32_t* gI1, int n, int shift) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* cnt = smem + kOffCnt; uint32_t* tot = smem + kOffTot; int* wsum = reinterpret_cast<int*>(smem + kOffWsum);
     const int inB = kOffBuf + sel * 2 * kCap, outB = kOffBuf + (1 - sel) * 2 * kCap;
@@ -231,7 +242,7 @@ __device__ __forceinline__ void radix_pass(uint32_t* smem, int sel, const uint32
 static_assert(kSortBlock == 256, "radix_pass assigns one thread per digit");
 
 template <bool kLds>
-__device__ __forceinline__ void bucket_sort_body(uint32_t* smem, const uint32_t* bkey, const uint32_t* bidx, uint32_t* gK0, uint32_t* gI0, uint32_t* gK1, uint32_t* gI1,
+__device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int kCap, const uint32_t* bkey, const uint32_t* bidx, uint32_t* gK0, uint32_t* gI0, uint32_t* gK1, uint32_t* gI1,
                                                  int n, int lo, size_t off1, uint32_t* s_out, int32_t* pred_out) {
     const size_t o = off1 + lo;
     if constexpr (kLds) {
@@ -255,7 +266,7 @@ __device__ __forceinline__ void bucket_sort_body(uint32_t* smem, const uint32_t*
     int sel = 0;
     for (int pass = 0; pass < 4; pass++) {
         if (((differ >> (8 * pass)) & 255u) == 0u) continue;    // block-uniform
-        radix_pass<kLds>(smem, sel, sel ? gK1 : gK0, sel ? gI1 : gI0, sel ? gK0 : gK1, sel ? gI0 : gI1, n, 8 * pass);
+        radix_pass<kLds>(smem, kCap, sel, sel ? gK1 : gK0, sel ? gI1 : gI0, sel ? gK0 : gK1, sel ? gI0 : gI1, n, 8 * pass);
         sel ^= 1;
     }
     for (int i = threadIdx.x; i < n; i += kSortBlock) {
@@ -269,7 +280,7 @@ __device__ __forceinline__ void bucket_sort_body(uint32_t* smem, const uint32_t*
 __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bucket_start,
                                                                const int32_t* __restrict__ n_buckets, uint32_t* __restrict__ bkey, uint32_t* __restrict__ bidx,
                                                                uint32_t* __restrict__ altkey, uint32_t* __restrict__ altidx,
-                                                               uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out) {
+                                                               uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out, int kCap) {
     extern __shared__ uint32_t smem[];
     const int pair = blockIdx.y, bucket = blockIdx.x;
     if (bucket >= n_buckets[pair]) return;
@@ -277,15 +288,22 @@ __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* _
     const int n = bucket_start[(size_t)pair * (kMaxBuckets + 1) + bucket + 1] - lo;
     if (n <= 0) return;
     const size_t off1 = (size_t)desc[pair].off1;
-    if (n <= kCap) bucket_sort_body<true>(smem, bkey, bidx, nullptr, nullptr, nullptr, nullptr, n, lo, off1, s_out, pred_out);
-    else bucket_sort_body<false>(smem, bkey, bidx, bkey + off1 + lo, bidx + off1 + lo, altkey + off1 + lo, altidx + off1 + lo, n, lo, off1, s_out, pred_out);
+    if (n <= kCap) bucket_sort_body<true>(smem, kCap, bkey, bidx, nullptr, nullptr, nullptr, nullptr, n, lo, off1, s_out, pred_out);
+    else bucket_sort_body<false>(smem, kCap, bkey, bidx, bkey + off1 + lo, bidx + off1 + lo, altkey + off1 + lo, altidx + off1 + lo, n, lo, off1, s_out, pred_out);
 }
 
 }  // namespace
 
 #define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
-size_t rank_sort_lds_bytes() { return (size_t)(kOffBuf + 4 * kCap) * 4; }
+// LDS rows of the per-bucket sort for scans of at most max_n rows: 1.3 x the mean bucket, rounded up to 128
+static int rank_sort_cap(int max_n) {
+    int nb = (max_n + kBucketTarget - 1) / kBucketTarget; nb = nb < 1 ? 1 : (nb > kMaxBuckets ? kMaxBuckets : nb);
+    int cap = (int)(1.3 * (double)max_n / nb); cap = (cap + 127) / 128 * 128;
+    if (const char* e = getenv("ICET_RS_CAP")) cap = atoi(e);
+    return cap < kCapMin ? kCapMin : (cap > kCapMax ? kCapMax : cap);
+}
+static size_t rank_sort_lds_bytes(int cap) { return (size_t)(kOffBuf + 4 * cap) * 4; }
 
 // Outputs: w.valB = s (row with rank i), w.pred = rank of every row.  Scratch: w.keyA / w.valA (bucket-grouped keys and
 // rows), w.keyB / w.key64A (overflow buckets), w.bkt, w.counts / w.tile_base, w.splitters, w.n_buckets, w.bucket_start.
@@ -303,12 +321,13 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
     ICET_LAUNCH_CHECK();
     static bool attr_set = false;
     if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_bucket_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_sort_lds_bytes());
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_bucket_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_sort_lds_bytes(kCapMax));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    k_rs_bucket_sort<<<dim3(kMaxBuckets, np), kSortBlock, rank_sort_lds_bytes(), st>>>(w.desc, w.bucket_start, w.n_buckets, w.keyA, w.valA, w.keyB,
-                                                                                     reinterpret_cast<uint32_t*>(w.key64A), w.valB, w.pred);
+    const int cap = rank_sort_cap(c.max_n1);
+    k_rs_bucket_sort<<<dim3(kMaxBuckets, np), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, w.keyA, w.valA, w.keyB,
+                                                                                        reinterpret_cast<uint32_t*>(w.key64A), w.valB, w.pred, cap);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

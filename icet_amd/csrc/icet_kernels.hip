@@ -1277,7 +1277,9 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     if (lds_slots > c.V) lds_slots = c.V;
     const int chunks = chunks_for(c.n_pairs, c.max_n2, kAccBlock * c.acc_min_pts_per_thread, c.acc_target_blocks);
     const size_t lds = fixed + (size_t)lds_slots * (5 + kAccLds) * 4;
-    static bool attr_set = false;
+    static bool attr_done[64] = {};          // per device: a process may hold contexts on several GPUs
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_done[dev_ & 63];
     if (!attr_set) {
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (ea == hipSuccess) ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

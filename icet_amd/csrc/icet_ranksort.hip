@@ -319,7 +319,9 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
     if (e != hipSuccess) return e;
     k_rs_scatter<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, w.keyA, w.valA, np, chunks);
     ICET_LAUNCH_CHECK();
-    static bool attr_set = false;
+    static bool attr_done[64] = {};          // per device: a process may hold contexts on several GPUs
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_done[dev_ & 63];
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_bucket_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_sort_lds_bytes(kCapMax));
         if (e != hipSuccess) return e;

@@ -46,7 +46,18 @@ struct SlotFit {
     int32_t v;
 };
 
-static_assert(sizeof(SlotHot) == 48 && sizeof(SlotFit) == 80, "k_fit_scan1 stages these records as 12 + 20 words");
+// What k_fit_scan1 (one wave per angular bin) hands to k_fit_finish (one lane per bin): the Gaussian of the bin's cluster.
+struct FitMid {
+    float mean[3];
+    float cov[6];                             // xx xy xz yy yz zz
+    float inner, outer;                       // findCluster's bounds (0, 0 when there is no cluster)
+    int32_t cnt;                              // rows in the bin
+    int32_t has_fit;
+    int32_t pad[3];
+};
+static_assert(sizeof(FitMid) == 64, "k_fit_scan1 stages this record as 16 words");
+
+static_assert(sizeof(SlotHot) == 48 && sizeof(SlotFit) == 80, "k_compact_slots copies these records as 12 + 20 words");
 
 // Optional dense (per-voxel) dump for the reference's public side tables; device pointers or null.
 struct AuxDev {
@@ -71,6 +82,7 @@ struct Workspace {
     float *rs = nullptr, *ths = nullptr, *phs = nullptr;            // spherical scan 1 in (bin, position) order
     int32_t *bin_count = nullptr, *bin_start = nullptr;             // pairs x V, pairs x (V+1)
     SlotHot* hotD = nullptr; SlotFit* fitD = nullptr; int32_t* activeD = nullptr;   // dense, pairs x V
+    FitMid* midD = nullptr;                                                          // dense, pairs x V
     SlotHot* hotS = nullptr; SlotFit* fitS = nullptr;                               // compact, pairs x V
     int16_t* slot_of_voxel = nullptr; int32_t* n_slots = nullptr;
     uint32_t* acc = nullptr;                  // pairs x V x kAccWords

@@ -446,10 +446,12 @@ __global__ __launch_bounds__(kBlock) void k_gather_sorted(const PairDesc* __rest
 }
 
 // fitCells1 (src/icet.cpp:109-252): one wavefront per angular bin.
+// The per-bin tail -- 3x3 eigen-decomposition, the six sigma points, the slot records -- is scalar work: it runs in
+// k_fit_finish with one LANE per bin instead of here with one WAVE per bin (measured: 0.21 ms of the 0.42 ms this kernel
+// took on 256 pairs was 64 lanes executing the same eigen-solve).
 __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
                                                       const float* __restrict__ rs, const float* __restrict__ ths, const float* __restrict__ phs,
-                                                      SlotHot* __restrict__ hotD, SlotFit* __restrict__ fitD, int32_t* __restrict__ activeD,
-                                                      AuxDev aux, int T, int P, int n, float thresh, float buff) {
+                                                      FitMid* __restrict__ midD, int T, int P, int n, float thresh, float buff) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int V = T * P;
     const int v = blockIdx.x * (kBlock / 64) + wave;
@@ -467,11 +469,9 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
     const size_t base = (size_t)d.off1 + bs;
 
     float inner = 0.f, outer = 0.f;
-    int has_fit = 0, active = 0;
+    int has_fit = 0;
     float mean[3] = {0.f, 0.f, 0.f};
     float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // xx xy xz yy yz zz
-    float ev[3] = {0.f, 0.f, 0.f}, Vm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float Ld[3] = {0.f, 0.f, 0.f};
 
     if (cnt >= n) {
         // The bin's first 4 x 64 rows are fetched up front with independent loads (most bins hold ~100-400 rows), so
@@ -570,64 +570,84 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
             const float den = (float)(rows - 1);
 #pragma unroll
             for (int k = 0; k < 6; k++) cov[k] = (float)wave_sum_d(c[k]) / den;
-            // ---- eigen-decomposition (every lane runs the same scalar code on the same values), then the six
-            // sigma points mu +- 2 sqrt(lambda_k) * (row k of V) on lanes 0..5 in parallel (src/icet.cpp:181-232)
-            icetdev::eig3_sym(cov[0], cov[1], cov[3], cov[2], cov[4], cov[5], ev, Vm);
-            bool in_j = false, beyond_j = false;
-            if (lane < 6) {
-                const int k = lane >> 1;
-                const float lam = (k == 0) ? ev[0] : ((k == 1) ? ev[1] : ev[2]);
-                const float v0 = (k == 0) ? Vm[0] : ((k == 1) ? Vm[3] : Vm[6]);
-                const float v1 = (k == 0) ? Vm[1] : ((k == 1) ? Vm[4] : Vm[7]);
-                const float v2 = (k == 0) ? Vm[2] : ((k == 1) ? Vm[5] : Vm[8]);
-                const float al = 2.0f * sqrtf(lam);
-                const float sgn = (lane & 1) ? -1.f : 1.f;
-                // rotated = diag(2 sqrt(lambda)) * U^T = diag(.) * V : ROW k of V (src/icet.cpp:193-202)
-                const float px = mean[0] + sgn * (al * v0), py = mean[1] + sgn * (al * v1), pz = mean[2] + sgn * (al * v2);
-                float r, az, el; c2s_point(px, py, pz, r, az, el);
-                in_j = inside_bounds(r, az, el, az0, az1, el0, el1, inner, outer);
-                beyond_j = r > outer;
-            }
-            // testSigmaPoints walks j = 0..5 and leaves the loop AFTER testing the first point with r > outer
-            // (src/icet.cpp:669-686): points behind that one are never tested
-            const unsigned long long beyond = __ballot(beyond_j) & 0x3Full;
-            const int jb = beyond ? (__ffsll((long long)beyond) - 1) : 5;
-            const unsigned long long ins = __ballot(in_j) & ((2ull << jb) - 1ull);
-            Ld[0] = (ins & 0x03ull) ? 1.f : 0.f; Ld[1] = (ins & 0x0Cull) ? 1.f : 0.f; Ld[2] = (ins & 0x30ull) ? 1.f : 0.f;
-            active = (cnt > n && outer > 1.f) ? 1 : 0;  // scan-1 half of the gate at src/icet.cpp:290
         }
     }
-    // Records are only needed for ACTIVE voxels (k_compact_slots copies nothing else); they are staged through LDS so
-    // that 32 lanes store them with two coalesced instructions instead of one lane issuing 32 scalar stores.
-    __shared__ float stage[kBlock / 64][32];
-    const size_t o = (size_t)pair * V + v;
-    if (active) {
-        if (lane == 0) {
-            float* g = stage[wave];
-            g[0] = az0; g[1] = az1; g[2] = el0; g[3] = el1; g[4] = inner; g[5] = outer;
-            g[6] = mean[0]; g[7] = mean[1]; g[8] = mean[2]; g[9] = __int_as_float(v); g[10] = 0.f; g[11] = 0.f;      // SlotHot
-            g[12] = mean[0]; g[13] = mean[1]; g[14] = mean[2];                                                            // SlotFit
-            const float d1 = (float)(cnt - 1);
-#pragma unroll
-            for (int k = 0; k < 6; k++) g[15 + k] = cov[k] / d1;
-#pragma unroll
-            for (int k = 0; k < 3; k++) { g[21 + 3 * k] = Ld[k] * Vm[3 * k]; g[22 + 3 * k] = Ld[k] * Vm[3 * k + 1]; g[23 + 3 * k] = Ld[k] * Vm[3 * k + 2]; }
-            g[30] = __int_as_float(cnt); g[31] = __int_as_float(v);
-        }
-        // same wave wrote and reads: LDS operations of one wave complete in order
-        if (lane < 12) reinterpret_cast<float*>(hotD + o)[lane] = stage[wave][lane];
-        else if (lane < 32) reinterpret_cast<float*>(fitD + o)[lane - 12] = stage[wave][lane];
-    }
+    // one 64-byte record per bin, staged through LDS so that 16 lanes store it with one coalesced instruction
+    __shared__ float stage[kBlock / 64][16];
     if (lane == 0) {
-        activeD[o] = active;
-        if (aux.bounds) { float* b = aux.bounds + o * 6; b[0] = az0; b[1] = az1; b[2] = el0; b[3] = el1; b[4] = inner; b[5] = outer; }
-        if (aux.n1_raw) aux.n1_raw[o] = cnt;
-        if (aux.has_fit) aux.has_fit[o] = has_fit;
-        if (aux.mu1) { aux.mu1[o * 3] = mean[0]; aux.mu1[o * 3 + 1] = mean[1]; aux.mu1[o * 3 + 2] = mean[2]; }
-        if (aux.sigma1) { float* sg = aux.sigma1 + o * 9; sg[0] = cov[0]; sg[1] = cov[1]; sg[2] = cov[2]; sg[3] = cov[1]; sg[4] = cov[3]; sg[5] = cov[4]; sg[6] = cov[2]; sg[7] = cov[4]; sg[8] = cov[5]; }
-        if (aux.evecs1) for (int k = 0; k < 9; k++) aux.evecs1[o * 9 + k] = Vm[k];
-        if (aux.l_diag) { aux.l_diag[o * 3] = Ld[0]; aux.l_diag[o * 3 + 1] = Ld[1]; aux.l_diag[o * 3 + 2] = Ld[2]; }
+        float* g = stage[wave];
+        g[0] = mean[0]; g[1] = mean[1]; g[2] = mean[2];
+#pragma unroll
+        for (int k = 0; k < 6; k++) g[3 + k] = cov[k];
+        g[9] = inner; g[10] = outer; g[11] = __int_as_float(cnt); g[12] = __int_as_float(has_fit); g[13] = g[14] = g[15] = 0.f;
     }
+    // same wave wrote and reads: LDS operations of one wave complete in order
+    if (lane < 16) reinterpret_cast<float*>(midD + (size_t)pair * V + v)[lane] = stage[wave][lane];
+}
+
+// fitCells1's per-bin tail (src/icet.cpp:181-252), one lane per angular bin: eigen-decomposition, U = eigenvectors^T, the six
+// sigma points and their inside test -> L, the scan-1 half of the gate at :290, and the records of the active voxels.
+__global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict__ midD, SlotHot* __restrict__ hotD, SlotFit* __restrict__ fitD,
+                                                       int32_t* __restrict__ activeD, AuxDev aux, int T, int P, int n) {
+    const int V = T * P;
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    const int pair = blockIdx.y;
+    if (v >= V) return;
+    const size_t o = (size_t)pair * V + v;
+    const FitMid m = midD[o];
+    const int theta = v % T, phi = v / T;
+    // src/icet.cpp:136-139: (float / int) -> float, times a double constant, stored to float
+    const float az0 = (float)((double)((float)theta / (float)T) * kTwoPi);
+    const float az1 = (float)((double)((float)(theta + 1) / (float)T) * kTwoPi);
+    const float el0 = (float)((double)((float)phi / (float)P) * kPi);
+    const float el1 = (float)((double)((float)(phi + 1) / (float)P) * kPi);
+    const float inner = m.inner, outer = m.outer;
+    float ev[3] = {0.f, 0.f, 0.f}, Vm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float Ld[3] = {0.f, 0.f, 0.f};
+    int active = 0;
+    if (m.has_fit) {
+        icetdev::eig3_sym(m.cov[0], m.cov[1], m.cov[3], m.cov[2], m.cov[4], m.cov[5], ev, Vm);
+        // sigma points mu +- 2 sqrt(lambda_k) * (row k of V): rotated = diag(2 sqrt(lambda)) * U^T = diag(.) * V (src/icet.cpp:187-202).
+        // testSigmaPoints walks j = 0..5 and leaves the loop AFTER testing the first point with r > outer (:669-686).
+        bool inside[6] = {false, false, false, false, false, false};
+        bool done = false;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const int k = j >> 1;
+            const float al = 2.0f * sqrtf(ev[k]);
+            const float sgn = (j & 1) ? -1.f : 1.f;
+            const float px = m.mean[0] + sgn * (al * Vm[3 * k]), py = m.mean[1] + sgn * (al * Vm[3 * k + 1]), pz = m.mean[2] + sgn * (al * Vm[3 * k + 2]);
+            if (!done) {
+                float r, az, el; c2s_point(px, py, pz, r, az, el);
+                inside[j] = inside_bounds(r, az, el, az0, az1, el0, el1, inner, outer);
+                done = r > outer;
+            }
+        }
+        Ld[0] = (inside[0] || inside[1]) ? 1.f : 0.f; Ld[1] = (inside[2] || inside[3]) ? 1.f : 0.f; Ld[2] = (inside[4] || inside[5]) ? 1.f : 0.f;
+        active = (m.cnt > n && outer > 1.f) ? 1 : 0;      // scan-1 half of the gate at src/icet.cpp:290
+    }
+    // Records are only needed for ACTIVE voxels (k_compact_slots copies nothing else)
+    if (active) {
+        SlotHot h; h.az0 = az0; h.az1 = az1; h.el0 = el0; h.el1 = el1; h.inner = inner; h.outer = outer;
+        h.mu[0] = m.mean[0]; h.mu[1] = m.mean[1]; h.mu[2] = m.mean[2]; h.v = v; h.pad[0] = h.pad[1] = 0;
+        hotD[o] = h;
+        SlotFit f; f.mu[0] = m.mean[0]; f.mu[1] = m.mean[1]; f.mu[2] = m.mean[2];
+        const float d1 = (float)(m.cnt - 1);
+#pragma unroll
+        for (int k = 0; k < 6; k++) f.s1n[k] = m.cov[k] / d1;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { f.M[3 * k] = Ld[k] * Vm[3 * k]; f.M[3 * k + 1] = Ld[k] * Vm[3 * k + 1]; f.M[3 * k + 2] = Ld[k] * Vm[3 * k + 2]; }
+        f.n1 = m.cnt; f.v = v;
+        fitD[o] = f;
+    }
+    activeD[o] = active;
+    if (aux.bounds) { float* b = aux.bounds + o * 6; b[0] = az0; b[1] = az1; b[2] = el0; b[3] = el1; b[4] = inner; b[5] = outer; }
+    if (aux.n1_raw) aux.n1_raw[o] = m.cnt;
+    if (aux.has_fit) aux.has_fit[o] = m.has_fit;
+    if (aux.mu1) { aux.mu1[o * 3] = m.mean[0]; aux.mu1[o * 3 + 1] = m.mean[1]; aux.mu1[o * 3 + 2] = m.mean[2]; }
+    if (aux.sigma1) { float* sg = aux.sigma1 + o * 9; sg[0] = m.cov[0]; sg[1] = m.cov[1]; sg[2] = m.cov[2]; sg[3] = m.cov[1]; sg[4] = m.cov[3]; sg[5] = m.cov[4]; sg[6] = m.cov[2]; sg[7] = m.cov[4]; sg[8] = m.cov[5]; }
+    if (aux.evecs1) for (int k = 0; k < 9; k++) aux.evecs1[o * 9 + k] = Vm[k];
+    if (aux.l_diag) { aux.l_diag[o * 3] = Ld[0]; aux.l_diag[o * 3 + 1] = Ld[1]; aux.l_diag[o * 3 + 2] = Ld[2]; }
 }
 
 // Dense per-voxel records -> compact slots in voxel order (phi-major, theta inner: the reference's
@@ -1245,7 +1265,9 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 3) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     dim3 gfit((c.V + kBlock / 64 - 1) / (kBlock / 64), c.n_pairs);
-    k_fit_scan1<<<gfit, blk, 0, st>>>(w.desc, w.bin_start, w.rs, w.ths, w.phs, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n, c.thresh, c.buff);
+    k_fit_scan1<<<gfit, blk, 0, st>>>(w.desc, w.bin_start, w.rs, w.ths, w.phs, w.midD, c.T, c.P, c.n, c.thresh, c.buff);
+    ICET_LAUNCH_CHECK();
+    k_fit_finish<<<dim3((c.V + kBlock - 1) / kBlock, c.n_pairs), blk, 0, st>>>(w.midD, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n);
     ICET_LAUNCH_CHECK();
     k_compact_slots<<<c.n_pairs, blk, 0, st>>>(w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, c.V);
     ICET_LAUNCH_CHECK();

@@ -108,7 +108,6 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
             HIPCHK(c, dev_realloc(w.key64A, n)); HIPCHK(c, dev_realloc(w.key64B, n)); HIPCHK(c, dev_realloc(w.bin16, n)); HIPCHK(c, dev_realloc(w.binpos, n)); HIPCHK(c, dev_realloc(w.bkt, n));
             HIPCHK(c, dev_realloc(w.keyA, n)); HIPCHK(c, dev_realloc(w.keyB, n)); HIPCHK(c, dev_realloc(w.valA, n)); HIPCHK(c, dev_realloc(w.valB, n));
             HIPCHK(c, dev_realloc(w.pred, n)); HIPCHK(c, dev_realloc(w.src, n));
-            HIPCHK(c, dev_realloc(w.rs, n)); HIPCHK(c, dev_realloc(w.ths, n)); HIPCHK(c, dev_realloc(w.phs, n));
             w.cap_n1 = n;
         }
         const size_t need = sort_temp_bytes(w.cap_n1);
@@ -319,7 +318,7 @@ icet_status icet_destroy(icet_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     Workspace& w = c->w;
-    void* ps[] = {w.key64A, w.key64B, w.bin16, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.th1, w.ph1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src, w.rs, w.ths, w.phs,
+    void* ps[] = {w.key64A, w.key64B, w.bin16, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.th1, w.ph1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src,
                   w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, w.xf, w.X, w.flags,
                   w.sort_tmp, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);

@@ -79,7 +79,6 @@ struct Workspace {
     uint32_t* counts = nullptr; uint32_t* tile_base = nullptr; size_t cap_counts = 0;               // pairs x tiles x V histogram / tile base offsets
     uint16_t* bin16 = nullptr;                                       // angular bin of every scan-1 row (input order)
     int32_t *pred = nullptr, *src = nullptr;
-    float *rs = nullptr, *ths = nullptr, *phs = nullptr;            // spherical scan 1 in (bin, position) order
     int32_t *bin_count = nullptr, *bin_start = nullptr;             // pairs x V, pairs x (V+1)
     SlotHot* hotD = nullptr; SlotFit* fitD = nullptr; int32_t* activeD = nullptr;   // dense, pairs x V
     FitMid* midD = nullptr;                                                          // dense, pairs x V

@@ -426,23 +426,12 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
             if (rank == 0) mine[bb[k]] += (uint32_t)__popcll(peers);  // one leader per distinct voxel in this round
         }
     }
-    // one scattered 4-byte store per row; the coordinates follow in k_gather_sorted with coalesced stores (element-wise
-    // scattered stores of the three coordinate arrays cost 4x more than gathering them)
+    // one scattered 4-byte store per row; k_fit_scan1 gathers the coordinates through it (element-wise scattered stores of
+    // the three coordinate arrays cost 4x more than gathering them, and a separate gather pass 0.15 ms more than gathering
+    // inside the fit, whose independent loads hide the latency)
 #pragma unroll
     for (int k = 0; k < kScatterRounds; k++)
         if (ok[k]) sorted_row[o + dest[k]] = (uint32_t)row[k];
-}
-
-__global__ __launch_bounds__(kBlock) void k_gather_sorted(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ sorted_row,
-                                                          const float* __restrict__ r1, const float* __restrict__ th1, const float* __restrict__ ph1,
-                                                          float* __restrict__ rs, float* __restrict__ ths, float* __restrict__ phs, int n_pairs, int chunks) {
-    // (a 16-byte (r, theta, phi, -) record per row, gathered with one load, was measured SLOWER: +0.16 ms per 256-pair
-    // keyframe -- the extra 16 B/row written by k_scan1_spherical cost more than the two saved gathers)
-    ICET_FOR_CHUNK_OF_SCAN1(i) {
-        const size_t o = d.off1;
-        const int row = (int)sorted_row[o + i];
-        rs[o + i] = r1[o + row]; ths[o + i] = th1[o + row]; phs[o + i] = ph1[o + row];
-    }
 }
 
 // fitCells1 (src/icet.cpp:109-252): one wavefront per angular bin.
@@ -450,7 +439,8 @@ __global__ __launch_bounds__(kBlock) void k_gather_sorted(const PairDesc* __rest
 // k_fit_finish with one LANE per bin instead of here with one WAVE per bin (measured: 0.21 ms of the 0.42 ms this kernel
 // took on 256 pairs was 64 lanes executing the same eigen-solve).
 __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
-                                                      const float* __restrict__ rs, const float* __restrict__ ths, const float* __restrict__ phs,
+                                                      const uint32_t* __restrict__ sorted_row,
+                                                      const float* __restrict__ r1, const float* __restrict__ th1, const float* __restrict__ ph1,
                                                       FitMid* __restrict__ midD, int T, int P, int n, float thresh, float buff) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int V = T * P;
@@ -467,6 +457,9 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
     const int bs = bin_start[(size_t)pair * (V + 1) + v];
     const int cnt = bin_start[(size_t)pair * (V + 1) + v + 1] - bs;
     const size_t base = (size_t)d.off1 + bs;
+    // rows of this bin in (scrambled) position order: sorted_row[base + i] is the row of the pair's input-order tables
+    const size_t po = (size_t)d.off1;
+    auto RS = [&](int i) { return r1[po + sorted_row[base + i]]; };
 
     float inner = 0.f, outer = 0.f;
     int has_fit = 0;
@@ -482,7 +475,8 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
         for (int k = 0; k < kCache; k++) {
             const int i = lane + 64 * k;
             const bool okk = i < cnt;
-            pr[k] = okk ? rs[base + i] : 0.f; pth[k] = okk ? ths[base + i] : 0.f; pph[k] = okk ? phs[base + i] : 0.f;
+            const uint32_t row = okk ? sorted_row[base + i] : 0u;
+            pr[k] = okk ? r1[po + row] : 0.f; pth[k] = okk ? th1[po + row] : 0.f; pph[k] = okk ? ph1[po + row] : 0.f;
         }
         // ---- findCluster (src/icet.cpp:557-607): first run of >= n consecutive points whose
         // successive |dr| <= thresh, walking the bin in stored (scrambled) order.
@@ -517,9 +511,9 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
         };
 #pragma unroll
         for (int k = 0; k < kCache; k++) if (64 * k < cnt && !found) walk(64 * k, pr[k]);
-        for (int c0 = 64 * kCache; c0 < cnt && !found; c0 += 64) walk(c0, (c0 + lane < cnt) ? rs[base + c0 + lane] : 0.f);
+        for (int c0 = 64 * kCache; c0 < cnt && !found; c0 += 64) walk(c0, (c0 + lane < cnt) ? RS(c0 + lane) : 0.f);
         if (!found && cnt - run_start >= n) {
-            if (front != 0.f) { const float back = rs[base + cnt - 1]; inner = front - buff; outer = back + buff; }
+            if (front != 0.f) { const float back = RS(cnt - 1); inner = front - buff; outer = back + buff; }
             else { inner = 0.f; outer = 0.f; }
         }
         // ---- filterPointsInsideCluster + sphericalToCartesian + mean (src/icet.cpp:155-160).  The Cartesian
@@ -539,7 +533,8 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
             }
         }
         for (int i = lane + 64 * kCache; i < cnt; i += 64) {
-            const float r = rs[base + i], th = ths[base + i], ph = phs[base + i];
+            const uint32_t row = sorted_row[base + i];
+            const float r = r1[po + row], th = th1[po + row], ph = ph1[po + row];
             if (inside_bounds(r, th, ph, az0, az1, el0, el1, inner, outer)) {
                 float x, y, z; s2c_point(r, th, ph, x, y, z);
                 sx += (double)x; sy += (double)y; sz += (double)z; rows++;
@@ -559,7 +554,8 @@ __global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict
                 }
             }
             for (int i = lane + 64 * kCache; i < cnt; i += 64) {
-                const float r = rs[base + i], th = ths[base + i], ph = phs[base + i];
+                const uint32_t row = sorted_row[base + i];
+            const float r = r1[po + row], th = th1[po + row], ph = ph1[po + row];
                 if (inside_bounds(r, th, ph, az0, az1, el0, el1, inner, outer)) {
                     float x, y, z; s2c_point(r, th, ph, x, y, z);
                     const float dx = x - mean[0], dy = y - mean[1], dz = z - mean[2];
@@ -1261,11 +1257,9 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     ICET_LAUNCH_CHECK();
     k_bin_scatter<<<grid, blk, (size_t)c.V * 16, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks);
     ICET_LAUNCH_CHECK();
-    k_gather_sorted<<<grid, blk, 0, st>>>(w.desc, w.valA, w.r1, w.th1, w.ph1, w.rs, w.ths, w.phs, np, chunks);
-    ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 3) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     dim3 gfit((c.V + kBlock / 64 - 1) / (kBlock / 64), c.n_pairs);
-    k_fit_scan1<<<gfit, blk, 0, st>>>(w.desc, w.bin_start, w.rs, w.ths, w.phs, w.midD, c.T, c.P, c.n, c.thresh, c.buff);
+    k_fit_scan1<<<gfit, blk, 0, st>>>(w.desc, w.bin_start, w.valA, w.r1, w.th1, w.ph1, w.midD, c.T, c.P, c.n, c.thresh, c.buff);
     ICET_LAUNCH_CHECK();
     k_fit_finish<<<dim3((c.V + kBlock - 1) / kBlock, c.n_pairs), blk, 0, st>>>(w.midD, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n);
     ICET_LAUNCH_CHECK();

@@ -119,7 +119,16 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st);
 
 // ranksort.hip
-hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t st);
+hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st);   // before k_scan1_spherical
+hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t st);             // after it (buckets + histogram done there)
+
+// bucket(key) = number of splitters strictly below key (splitters sorted ascending in sp[1 .. kRankSortMaxBuckets-1], sp[0] ignored)
+__device__ __forceinline__ int rank_sort_bucket_of(uint32_t key, const uint32_t* sp) {
+    int lo = 0;
+#pragma unroll
+    for (int step = kRankSortMaxBuckets / 2; step > 0; step >>= 1) lo += (sp[lo + step] < key) ? step : 0;
+    return lo;
+}
 hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st);
 
 // sort.hip

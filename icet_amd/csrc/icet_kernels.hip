@@ -125,19 +125,40 @@ __device__ __forceinline__ bool decode_block(int n_pairs, int chunks, int& pair,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __restrict__ desc, float* __restrict__ r1, float* __restrict__ th1,
                                                             float* __restrict__ ph1, unsigned long long* __restrict__ key64, uint32_t* __restrict__ key32,
-                                                            uint32_t* __restrict__ val, uint16_t* __restrict__ bin16, int T, int P, int n_pairs, int chunks) {
+                                                            uint32_t* __restrict__ val, uint16_t* __restrict__ bin16, int T, int P, int n_pairs, int chunks,
+                                                            const uint32_t* __restrict__ splitters, uint8_t* __restrict__ bkt, uint32_t* __restrict__ counts) {
+    // First step of the rank sort fused in (icet_ranksort.hip): the pair's splitters are already known (k_rs_splitters
+    // samples the radii straight from the Cartesian rows), so each row's bucket and this tile's bucket histogram cost no
+    // extra pass over r1[].  splitters == nullptr: library-sort diagnostic path, nothing of this is needed.
+    __shared__ uint32_t sp[kRankSortMaxBuckets];
+    __shared__ uint32_t lh[kRankSortMaxBuckets];
+    if (splitters) {
+        int pair_, chunk_;
+        if (decode_block(n_pairs, chunks, pair_, chunk_))
+            for (int j = threadIdx.x; j < kRankSortMaxBuckets; j += kBlock) { sp[j] = splitters[(size_t)pair_ * kRankSortMaxBuckets + j]; lh[j] = 0u; }
+        __syncthreads();
+    }
     ICET_FOR_CHUNK_OF_SCAN1(i) {
         const float* x = d.s1; const float* y = d.s1 + d.ld1; const float* z = d.s1 + 2 * (size_t)d.ld1;
         float r, th, ph;
         c2s_point(x[i], y[i], z[i], r, th, ph);
         size_t o = (size_t)d.off1 + i;
         r1[o] = r; th1[o] = th; ph1[o] = ph;
+        if (splitters) {
+            const int b = rank_sort_bucket_of(__float_as_uint(r), sp);
+            bkt[o] = (uint8_t)b;
+            atomicAdd(&lh[b], 1u);
+        }
         // r >= +0 (or 1000 for NaN): the bit pattern orders like the float; the pair id in the high word keeps
         // every pair's points contiguous, so one device-wide sort handles the whole batch
         if (key64) key64[o] = ((unsigned long long)pair << 32) | (unsigned long long)__float_as_uint(r);
         else if (key32) key32[o] = __float_as_uint(r);
         if (key64 || key32) val[o] = (uint32_t)i;               // library-sort path only
         bin16[o] = (uint16_t)voxel_of(th, ph, T, P);
+    }
+    if (splitters) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < kRankSortMaxBuckets; j += kBlock) counts[((size_t)pair * chunks + chunk) * kRankSortMaxBuckets + j] = lh[j];
     }
 }
 
@@ -156,7 +177,10 @@ __global__ __launch_bounds__(kBlock) void k_inverse_perm(const PairDesc* __restr
 // Both walks below are pointer chases through ~1 MB of per-pair tables that sit in the XCD's L2 (see decode_block): they
 // are bound by load latency, not bandwidth.  Each thread therefore advances EIGHT independent chains in lock step, so
 // that eight loads are in flight per thread instead of one.
-constexpr int kWalk = 8;
+#ifndef ICET_WALK
+#define ICET_WALK 8
+#endif
+constexpr int kWalk = ICET_WALK;
 
 // The flag goes into bit 15 of the row's voxel id (V <= 32768): k_scramble_src needs "did step u execute" and "which voxel is
 // row u in" for the same u, so one 2-byte random read serves both.
@@ -1227,7 +1251,9 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     int pbits = 0; while ((1 << pbits) < c.n_pairs) pbits++;
     int vbits = 1; while ((1 << vbits) < c.V) vbits++;
     const bool batch = c.n_pairs > 1;
-    k_scan1_spherical<<<grid, blk, 0, st>>>(w.desc, w.r1, w.th1, w.ph1, (batch && c.use_library_sort) ? w.key64A : nullptr, c.use_library_sort ? w.keyA : nullptr, w.valA, w.bin16, c.T, c.P, np, chunks);
+    if (!c.use_library_sort) { e = launch_rank_sort_splitters(w, c, st); if (e != hipSuccess) return e; }
+    k_scan1_spherical<<<grid, blk, 0, st>>>(w.desc, w.r1, w.th1, w.ph1, (batch && c.use_library_sort) ? w.key64A : nullptr, c.use_library_sort ? w.keyA : nullptr, w.valA, w.bin16, c.T, c.P, np, chunks,
+                                            c.use_library_sort ? nullptr : w.splitters, w.bkt, w.counts);
     ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 4) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     if (c.use_library_sort) {

@@ -7,11 +7,13 @@
 // A device-wide library radix sort has to carry the pair id in the key (40 significant bits -> 5 digit passes over
 // 12 bytes per element, ~1.4 ms per 256 pairs) and still needs a separate inverse-permutation pass.  Per pair the
 // data is small (116 k keys), so this file does a sample sort instead:
-//   k_rs_splitters   one block per pair: sort ~2 k sampled keys in LDS (bitonic), publish <= 127 splitters
-//   k_rs_hist        per tile: bucket id of every row (branch-free binary search of the splitters), tile histogram
+//   k_rs_splitters   one block per pair: radii of ~2 k sampled rows straight from the Cartesian scan, sorted in LDS
+//                    (bitonic), <= 127 splitters published -- runs BEFORE k_scan1_spherical, which then
+//   [k_scan1_spherical, icet_kernels.hip] also finds every row's bucket (branch-free binary search of the splitters)
+//                    and its tile's bucket histogram, at no extra pass over r
 //   [k_bin_scan]     (shared with the voxel multi-split) exclusive scan over (bucket, tile)
 //   k_rs_scatter     stable multi-split of the rows into their buckets (match-any ranking, as k_bin_scatter)
-//   k_rs_bucket_sort one block per (pair, bucket): LSD radix sort of the bucket's <= 2560 (key, row) pairs entirely in
+//   k_rs_bucket_sort one block per (pair, bucket): LSD radix sort of the bucket's (key, row) pairs entirely in
 //                    LDS (4 stable 8-bit passes, passes whose digit is constant are skipped), then s[] and pred[] are
 //                    written -- no inverse-permutation kernel.  A bucket that does not fit LDS runs the same code on
 //                    global scratch; a bucket of identical keys (the zero rows of a real scan: thousands of exact
@@ -56,7 +58,18 @@ __device__ __forceinline__ bool decode_block(int n_pairs, int chunks, int& pair,
 }
 
 // ---- splitters -----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_rs_splitters(const PairDesc* __restrict__ desc, const float* __restrict__ r1,
+__device__ __forceinline__ float radius_of(float x, float y, float z) {     // the r of c2s_point (icet_kernels.hip), bit for bit
+    float r;
+    {
+#pragma clang fp contract(off)
+        float s = x * x + y * y;
+        s = s + z * z;
+        r = sqrtf(s);
+    }
+    return (r != r) ? 1000.0f : r;
+}
+
+__global__ __launch_bounds__(1024) void k_rs_splitters(const PairDesc* __restrict__ desc,
                                                        uint32_t* __restrict__ splitters, int32_t* __restrict__ n_buckets) {
     __shared__ uint32_t sm[kSamples];
     const int pair = blockIdx.x;
@@ -65,7 +78,7 @@ __global__ __launch_bounds__(1024) void k_rs_splitters(const PairDesc* __restric
     const int stride = max(1, (n + kSamples - 1) / kSamples);
     const int ns = n > 0 ? (n + stride - 1) / stride : 0;
     for (int j = threadIdx.x; j < kSamples; j += 1024)
-        sm[j] = (j < ns) ? __float_as_uint(r1[(size_t)d.off1 + (size_t)j * stride]) : 0xFFFFFFFFu;
+        sm[j] = (j < ns) ? __float_as_uint(radius_of(d.s1[(size_t)j * stride], d.s1[d.ld1 + (size_t)j * stride], d.s1[2 * (size_t)d.ld1 + (size_t)j * stride])) : 0xFFFFFFFFu;
     __syncthreads();
     for (int k = 2; k <= kSamples; k <<= 1) {                   // bitonic sort, ascending
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -87,35 +100,6 @@ __global__ __launch_bounds__(1024) void k_rs_splitters(const PairDesc* __restric
     // splitters[j], j = 1..nb-1 ; slot 0 unused ; unused slots = +max so that the search never counts them
     for (int j = threadIdx.x; j < kMaxBuckets; j += 1024)
         splitters[(size_t)pair * kMaxBuckets + j] = (j >= 1 && j < nb) ? sm[(int)(((long long)j * ns) / nb)] : 0xFFFFFFFFu;
-}
-
-// bucket(key) = number of splitters strictly below key  (splitters sorted ascending in sp[1..63], sp[0] ignored)
-__device__ __forceinline__ int bucket_of(uint32_t key, const uint32_t* sp) {
-    int lo = 0;                                                  // count over sp[1 .. kMaxBuckets-1]
-#pragma unroll
-    for (int step = kMaxBuckets / 2; step > 0; step >>= 1) lo += (sp[lo + step] < key) ? step : 0;
-    return lo;
-}
-
-__global__ __launch_bounds__(kBlock) void k_rs_hist(const PairDesc* __restrict__ desc, const float* __restrict__ r1, const uint32_t* __restrict__ splitters,
-                                                    uint8_t* __restrict__ bkt, uint32_t* __restrict__ counts, int n_pairs, int chunks) {
-    __shared__ uint32_t sp[kMaxBuckets];
-    __shared__ uint32_t lh[kMaxBuckets];
-    int pair, chunk;
-    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
-    const PairDesc d = desc[pair];
-    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
-    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
-    for (int j = threadIdx.x; j < kMaxBuckets; j += kBlock) { sp[j] = splitters[(size_t)pair * kMaxBuckets + j]; lh[j] = 0u; }
-    __syncthreads();
-    const size_t o = d.off1;
-    for (int v = lo_ + threadIdx.x; v < hi_; v += kBlock) {
-        const int b = bucket_of(__float_as_uint(r1[o + v]), sp);
-        bkt[o + v] = (uint8_t)b;
-        atomicAdd(&lh[b], 1u);
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < kMaxBuckets; j += kBlock) counts[((size_t)pair * chunks + chunk) * kMaxBuckets + j] = lh[j];
 }
 
 // Stable multi-split of the rows of one tile into their buckets; wave w owns the w-th quarter of the tile.
@@ -307,14 +291,17 @@ static size_t rank_sort_lds_bytes(int cap) { return (size_t)(kOffBuf + 4 * cap) 
 
 // Outputs: w.valB = s (row with rank i), w.pred = rank of every row.  Scratch: w.keyA / w.valA (bucket-grouped keys and
 // rows), w.keyB / w.key64A (overflow buckets), w.bkt, w.counts / w.tile_base, w.splitters, w.n_buckets, w.bucket_start.
+hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
+    k_rs_splitters<<<c.n_pairs, 1024, 0, st>>>(w.desc, w.splitters, w.n_buckets);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
     const int chunks = c.kf_chunks, np = c.n_pairs;
     const int groups = np >= 8 ? (np + 7) / 8 * 8 : np;
     dim3 grid(groups * chunks), blk(kBlock);
-    k_rs_splitters<<<np, 1024, 0, st>>>(w.desc, w.r1, w.splitters, w.n_buckets);
-    ICET_LAUNCH_CHECK();
-    k_rs_hist<<<grid, blk, 0, st>>>(w.desc, w.r1, w.splitters, w.bkt, w.counts, np, chunks);
-    ICET_LAUNCH_CHECK();
+    // (buckets bkt[] and the per-tile histograms counts[] were produced by k_scan1_spherical)
     hipError_t e = launch_class_scan(w.counts, w.tile_base, w.bucket_start, kMaxBuckets, chunks, np, st);
     if (e != hipSuccess) return e;
     k_rs_scatter<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, w.keyA, w.valA, np, chunks);

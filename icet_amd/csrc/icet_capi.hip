@@ -232,7 +232,7 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     if (const char* e = getenv("ICET_FORCE_EXACT")) cfg.force_exact = atoi(e);
     if (const char* e = getenv("ICET_LIBRARY_SORT")) cfg.use_library_sort = atoi(e);
     if (const char* e = getenv("ICET_KF_PTS")) cfg.kf_pts_per_thread = atoi(e);
-    if (cfg.kf_pts_per_thread > 8) cfg.kf_pts_per_thread = 8;      // k_bin_scatter: a tile is at most 4 waves x 8 rounds x 64 positions
+    if (cfg.kf_pts_per_thread > kKfMaxPtsPerThread) cfg.kf_pts_per_thread = kKfMaxPtsPerThread;      // k_bin_scatter: a tile is at most 4 waves x that many rounds x 64 positions
     if (cfg.kf_pts_per_thread < 1) cfg.kf_pts_per_thread = 1;
     cfg.stage_event = c->stage_at ? c->ev_stage : nullptr; cfg.stage_at = c->stage_at;
     cfg.vec4_ok = 1;

@@ -18,6 +18,10 @@ constexpr double kFixInv = 1.0 / 1073741824.0;
 #endif
 constexpr int kRankSortBucketBits = ICET_RS_BUCKET_BITS;       // rank sort (icet_ranksort.hip): at most 2^bits buckets per pair, ids travel as u8
 constexpr int kRankSortMaxBuckets = 1 << kRankSortBucketBits;
+#ifndef ICET_KF_MAXPTS
+#define ICET_KF_MAXPTS 8
+#endif
+constexpr int kKfMaxPtsPerThread = ICET_KF_MAXPTS;   // keyframe kernels: largest tile = 256 threads x this many rows
 constexpr int kMaxVoxels = 32768;    // slot ids travel as int16
 
 // One scan pair as the kernels see it (device pointers, column-major N x 3).
@@ -104,7 +108,7 @@ struct LaunchCfg {
     int acc_min_pts_per_thread = 8;   // launch shaping of k_gn_accumulate
     int acc_target_blocks = 2048;
     int kf_chunks = 1;                // tiles per pair in the keyframe kernels (set by the host from max_n1)
-    int kf_pts_per_thread = 8;        // keyframe kernels: points per thread (sets chunks per pair)
+    int kf_pts_per_thread = kKfMaxPtsPerThread;        // keyframe kernels: points per thread (sets chunks per pair)
     hipEvent_t stage_event = nullptr; /* recorded inside launch_keyframe after stage `stage_at` (4 spherical, 1 sort, 2 scramble, 3 gather): lets the next batch part start there */
     int stage_at = 0;
     int use_library_sort = 0;         // diagnostic: rocPRIM device radix sort instead of the hand-written rank sort

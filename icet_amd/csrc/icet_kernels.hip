@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scan(const uint32_t* __restrict_
 
 // One block per tile (<= 2048 positions); wave w owns the w-th quarter (<= 8 rounds of 64 positions).  Everything
 // global is loaded up front and stored at the end, so the only serial chain is 8 rounds of ballots + LDS.
-constexpr int kScatterRounds = 8;
+constexpr int kScatterRounds = kKfMaxPtsPerThread;   // a tile is at most 4 waves x this many rounds x 64 positions
 __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const uint16_t* __restrict__ binpos,
                                                         const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bin_start,
                                                         uint32_t* __restrict__ sorted_row, int V, int vbits, int n_pairs, int chunks) {

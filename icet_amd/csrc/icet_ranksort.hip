@@ -103,7 +103,7 @@ __global__ __launch_bounds__(1024) void k_rs_splitters(const PairDesc* __restric
 }
 
 // Stable multi-split of the rows of one tile into their buckets; wave w owns the w-th quarter of the tile.
-constexpr int kScatterRounds = 8;
+constexpr int kScatterRounds = kKfMaxPtsPerThread;   // a tile is at most 4 waves x this many rounds x 64 positions
 __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restrict__ desc, const float* __restrict__ r1, const uint8_t* __restrict__ bkt,
                                                        const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bucket_start,
                                                        uint32_t* __restrict__ bkey, uint32_t* __restrict__ bidx, int n_pairs, int chunks) {
@@ -284,8 +284,9 @@ __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* _
 static int rank_sort_cap(int max_n) {
     int nb = (max_n + kBucketTarget - 1) / kBucketTarget; nb = nb < 1 ? 1 : (nb > kMaxBuckets ? kMaxBuckets : nb);
     int cap = (int)(1.3 * (double)max_n / nb); cap = (cap + 127) / 128 * 128;
-    if (const char* e = getenv("ICET_RS_CAP")) cap = atoi(e);
-    return cap < kCapMin ? kCapMin : (cap > kCapMax ? kCapMax : cap);
+    cap = cap < kCapMin ? kCapMin : (cap > kCapMax ? kCapMax : cap);
+    if (const char* e = getenv("ICET_RS_CAP")) { cap = atoi(e); cap = cap < 64 ? 64 : (cap > kCapMax ? kCapMax : cap); }   // tests: force the global-scratch path
+    return cap;
 }
 static size_t rank_sort_lds_bytes(int cap) { return (size_t)(kOffBuf + 4 * cap) * 4; }
 

@@ -404,3 +404,25 @@ def test_many_pairs_parity_given_equal_eigenvector_signs(gpu_ctx):
     assert len(over) <= 2, over
     assert 0 < flips <= 0.01 * cols, (flips, cols)          # this range of pairs does contain sign-discordant voxels, and they are rare
     print("sign-discordant eigenvector columns: %d of %d; pairs moved beyond tolerance by them: %d; aligned-sign outliers: %s" % (flips, cols, nat_over, over))
+
+
+def test_rarely_taken_paths_give_the_same_bits(gpu_ctx, frames, sample_pc):
+    """Every launch-shape knob selects a code path that exists for unusual inputs; on ordinary inputs they must all produce
+    the same bits as the default: accumulator rows that do not fit LDS (HBM-atomic spill path), rank-sort buckets that do not
+    fit LDS (global-scratch radix sort), small keyframe tiles, few / many accumulate blocks, and the library (rocPRIM) sort
+    that the hand-written rank sort replaced."""
+    a, b = frames; c, d = sample_pc
+    base1 = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
+    base2 = gpu_ctx.solve(c, d, 7, np.zeros(6), 48, 150)
+    knobs = [("ICET_LDS_SLOTS", "32"), ("ICET_RS_CAP", "128"), ("ICET_KF_PTS", "1"), ("ICET_KF_PTS", "3"), ("ICET_ACC_BLOCKS", "7"),
+             ("ICET_ACC_PTS", "64"), ("ICET_LIBRARY_SORT", "1"), ("ICET_BATCH_STAGE", "0")]
+    for key, val in knobs:
+        os.environ[key] = val
+        try:
+            r1 = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
+            r2 = gpu_ctx.solve(c, d, 7, np.zeros(6), 48, 150)
+        finally:
+            del os.environ[key]
+        assert np.array_equal(r1["X"], base1["X"]) and np.array_equal(r1["pred_stds"], base1["pred_stds"]), (key, val)
+        assert np.array_equal(r1["aux"]["n2_in"], base1["aux"]["n2_in"]) and np.array_equal(r1["aux"]["htwh"], base1["aux"]["htwh"]), (key, val)
+        assert np.array_equal(r2["X"], base2["X"]), (key, val)

@@ -132,21 +132,33 @@ void build_thresholds(int nb, double period, float* out) {
     }
 }
 
-// Classification LUT over a monotone coordinate c in [lo, lo + range): M cells, each naming the edge nearest to
-// its centre.  M is the smallest power of two whose cells are narrower than half the narrowest bin, so a point
-// can only ever be near the edge its cell names.
+// Classification LUT over a monotone coordinate c in [lo, lo + range): M cells, each naming the edge nearest to its centre.
+// M is the smallest power of two whose cells are narrower than 0.45 x a reference bin width -- the narrowest bin
+// (quantile 0: azimuth, whose bins differ by 2x at most) or a low quantile of the widths (polar angle: in w = -cos(phi) the
+// two bins at the poles are 15x narrower than those at the horizon, where the lidar's points are; sizing the table for them
+// made it 8 KB of LDS and block start-up time for rows nobody visits).  A cell is usable by the fast path iff no OTHER edge
+// lies between any of its points and the edge it names, nor within the guard band of the cell: then "compare with the named
+// edge" yields the bin and "far from the named edge" implies far from every edge.  Cells that fail this (near the poles) get
+// edge = NaN, which fails the kernel's guard test, so their points take the literal path.
 struct HostCell { float edge; int32_t idx; };
-int build_lut(const std::vector<double>& edges, double lo, double range, std::vector<HostCell>& out) {
-    double min_w = range;
-    for (size_t k = 1; k < edges.size(); k++) min_w = std::min(min_w, edges[k] - edges[k - 1]);
+int build_lut(const std::vector<double>& edges, double lo, double range, double quantile, double guard, std::vector<HostCell>& out) {
+    std::vector<double> widths;
+    for (size_t k = 1; k < edges.size(); k++) widths.push_back(edges[k] - edges[k - 1]);
+    std::sort(widths.begin(), widths.end());
+    const double w_ref = widths.empty() ? range : widths[(size_t)(quantile * (double)(widths.size() - 1))];
     int M = 64;
-    while (range / M > 0.45 * min_w && M < (1 << 16)) M *= 2;
+    while (range / M > 0.45 * w_ref && M < (1 << 16)) M *= 2;
     out.resize(M);
+    const double cw = range / M, slack = 0.02 * cw + guard;      // the kernel's float cell index may be off by a rounding at a cell boundary
     for (int c = 0; c < M; c++) {
-        const double ctr = lo + (c + 0.5) * range / M;
+        const double ctr = lo + (c + 0.5) * cw;
         size_t best = 0;
         for (size_t k = 1; k < edges.size(); k++) if (std::fabs(edges[k] - ctr) < std::fabs(edges[best] - ctr)) best = k;
-        out[c].edge = (float)edges[best]; out[c].idx = (int32_t)best;
+        const double e = edges[best];
+        const double h0 = std::min(lo + c * cw - slack, e) - guard, h1 = std::max(lo + (c + 1) * cw + slack, e) + guard;
+        bool ambiguous = false;
+        for (size_t k = 0; k < edges.size(); k++) if (k != best && edges[k] >= h0 && edges[k] <= h1) ambiguous = true;
+        out[c].edge = ambiguous ? std::nanf("") : (float)e; out[c].idx = (int32_t)best;
     }
     return M;
 }
@@ -163,8 +175,14 @@ icet_status ensure_thresholds(icet_ctx* c, int T, int P) {
             et[k] = (k == T) ? 4.0 : (k == 0 ? 0.0 : (x >= 0 ? (y >= 0 ? q : 4.0 + q) : 2.0 - q));
         }
         for (int k = 0; k <= P; k++) ep[k] = (k == 0) ? -1.0 : (k == P ? 1.0 : -std::cos(M_PI * k / P));
+        // Guard bands: a few float ulps of the coordinate plus the ulp-level disagreement between the LUT's
+        // true edges and the literal evaluation's float thresholds (see DESIGN.md, "exact fast path").
+        w.guard_t = 5e-6f; w.guard_p = 2.5e-6f;
+        if (const char* e = getenv("ICET_GUARD_SCALE")) { w.guard_t *= (float)atof(e); w.guard_p *= (float)atof(e); }   // experiments only
         std::vector<HostCell> lt, lp;
-        const int Mt = build_lut(et, 0.0, 4.0, lt), Mp = build_lut(ep, -1.0, 2.0, lp);
+        double qp = 0.25;
+        if (const char* e = getenv("ICET_LUT_POLAR_QUANTILE")) qp = atof(e);                                              // experiments only
+        const int Mt = build_lut(et, 0.0, 4.0, 0.0, w.guard_t, lt), Mp = build_lut(ep, -1.0, 2.0, qp, w.guard_p, lp);
         // one spare cell per table: pa == 4 / w == 1 index cell M (it names the last edge, so the point goes to the literal path)
         for (HostCell& c : lp) c.idx *= T;                                 // polar cells carry the map row offset T * edge index
         std::vector<HostCell> all(lt); all.push_back(HostCell{4.0f, T}); all.insert(all.end(), lp.begin(), lp.end()); all.push_back(HostCell{1.0f, P * T});
@@ -172,10 +190,6 @@ icet_status ensure_thresholds(icet_ctx* c, int T, int P) {
         HIPCHK(c, hipMalloc(&w.lut, all.size() * sizeof(HostCell)));
         HIPCHK(c, hipMemcpy(w.lut, all.data(), all.size() * sizeof(HostCell), hipMemcpyHostToDevice));
         w.lut_Mt = Mt; w.lut_Mp = Mp;
-        // Guard bands: a few float ulps of the coordinate plus the ulp-level disagreement between the LUT's
-        // true edges and the literal evaluation's float thresholds (see DESIGN.md, "exact fast path").
-        w.guard_t = 5e-6f; w.guard_p = 2.5e-6f;
-        if (const char* e = getenv("ICET_GUARD_SCALE")) { w.guard_t *= (float)atof(e); w.guard_p *= (float)atof(e); }   // experiments only
     }
     std::vector<float> h((size_t)T + P + 2);
     build_thresholds(T, 2 * M_PI, h.data());

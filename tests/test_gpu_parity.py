@@ -218,7 +218,16 @@ def test_fast_classification_equals_literal_evaluation(gpu_ctx, frames, sample_p
     import os
     from icet_amd import lidar_sim as ls
     s1, s2, _ = ls.make_pair()
-    cases = [(frames[0], frames[1], 24, 75, 7), (sample_pc[0], sample_pc[1], 48, 150, 4), (s1.T.numpy(), s2.T.numpy(), 24, 75, 7)]
+    # a cloud that covers the WHOLE sphere, poles included: the polar look-up table is sized for the bins near the horizon, so the
+    # narrow polar bins near the poles are marked "ask the literal path" cell by cell -- dense shells make every such voxel active
+    rng = np.random.default_rng(11)
+    dirs = rng.normal(size=(150000, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    shell = (dirs * (8.0 + 0.03 * rng.normal(size=(150000, 1)))).astype(np.float32)
+    ang = np.float32(0.01)
+    Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    shell2 = ((dirs * (8.0 + 0.03 * rng.normal(size=(150000, 1)))) @ Rz.T + np.array([0.05, -0.02, 0.03])).astype(np.float32)
+    cases = [(frames[0], frames[1], 24, 75, 7), (sample_pc[0], sample_pc[1], 48, 150, 4), (s1.T.numpy(), s2.T.numpy(), 24, 75, 7),
+             (shell, shell2, 24, 75, 4), (shell, shell2, 48, 150, 3)]
     for a, b, P, T, rl in cases:
         fast = gpu_ctx.solve(a, b, rl, np.zeros(6), P, T, aux=True)
         os.environ["ICET_FORCE_EXACT"] = "1"

@@ -353,8 +353,28 @@ __global__ __launch_bounds__(kBlock) void k_bin_hist(const PairDesc* __restrict_
     for (int b = threadIdx.x; b < V; b += kBlock) out[b] = lh[b];
 }
 
-__global__ __launch_bounds__(kBlock) void k_bin_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ tile_base, int32_t* __restrict__ bin_start,
-                                                     int V, int chunks) {
+// Exclusive scan over (class, tile) in class-major order, in two steps so that a single large pair (7200 voxels x 240 tiles)
+// is not scanned by ONE block: k_bin_tiles (one thread per class, blocks over classes) turns each class's per-tile counts into
+// per-tile offsets and leaves the class total in class_start[]; k_bin_scan (one block per pair) scans the totals in place.
+__global__ __launch_bounds__(kBlock) void k_bin_tiles(const uint32_t* __restrict__ counts, uint32_t* __restrict__ tile_base, int32_t* __restrict__ class_start,
+                                                      int V, int chunks) {
+    const int pair = blockIdx.y, b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= V) return;
+    const uint32_t* c = counts + (size_t)pair * chunks * V + b;
+    uint32_t* tb = tile_base + (size_t)pair * chunks * V + b;
+    int tot = 0, t = 0;
+    for (; t + 8 <= chunks; t += 8) {                         // 8 independent loads in flight
+        uint32_t x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = c[(size_t)(t + k) * V];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { tb[(size_t)(t + k) * V] = (uint32_t)tot; tot += (int)x[k]; }
+    }
+    for (; t < chunks; t++) { const uint32_t x = c[(size_t)t * V]; tb[(size_t)t * V] = (uint32_t)tot; tot += (int)x; }
+    class_start[(size_t)pair * (V + 1) + b] = tot;
+}
+
+__global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class_start, int V) {
     __shared__ int wave_tot[kBlock / 64];
     __shared__ int base;
     const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -362,20 +382,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scan(const uint32_t* __restrict_
     __syncthreads();
     for (int v0 = 0; v0 < V; v0 += kBlock) {
         const int b = v0 + threadIdx.x;
-        int tot = 0;
-        if (b < V) {
-            const uint32_t* c = counts + (size_t)pair * chunks * V + b;
-            uint32_t* tb = tile_base + (size_t)pair * chunks * V + b;
-            int t = 0;
-            for (; t + 8 <= chunks; t += 8) {                         // 8 independent loads in flight
-                uint32_t x[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) x[k] = c[(size_t)(t + k) * V];
-#pragma unroll
-                for (int k = 0; k < 8; k++) { tb[(size_t)(t + k) * V] = (uint32_t)tot; tot += (int)x[k]; }
-            }
-            for (; t < chunks; t++) { const uint32_t x = c[(size_t)t * V]; tb[(size_t)t * V] = (uint32_t)tot; tot += (int)x; }
-        }
+        const int tot = (b < V) ? class_start[(size_t)pair * (V + 1) + b] : 0;
         int incl = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
@@ -384,12 +391,12 @@ __global__ __launch_bounds__(kBlock) void k_bin_scan(const uint32_t* __restrict_
         int woff = 0;
         for (int k = 0; k < wave; k++) woff += wave_tot[k];
         const int bb = base;
-        if (b < V) bin_start[(size_t)pair * (V + 1) + b] = bb + woff + incl - tot;
+        if (b < V) class_start[(size_t)pair * (V + 1) + b] = bb + woff + incl - tot;
         __syncthreads();
         if (threadIdx.x == kBlock - 1) base = bb + woff + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) bin_start[(size_t)pair * (V + 1) + V] = base;
+    if (threadIdx.x == 0) class_start[(size_t)pair * (V + 1) + V] = base;
 }
 
 // One block per tile (<= 2048 positions); wave w owns the w-th quarter (<= 8 rounds of 64 positions).  Everything
@@ -1279,8 +1286,8 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     if (c.stage_event && c.stage_at == 2) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, w.flags, c.V, np, chunks);
     ICET_LAUNCH_CHECK();
-    k_bin_scan<<<c.n_pairs, blk, 0, st>>>(w.counts, w.tile_base, w.bin_start, c.V, chunks);
-    ICET_LAUNCH_CHECK();
+    e = launch_class_scan(w.counts, w.tile_base, w.bin_start, c.V, chunks, c.n_pairs, st);
+    if (e != hipSuccess) return e;
     k_bin_scatter<<<grid, blk, (size_t)c.V * 16, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks);
     ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 3) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
@@ -1295,7 +1302,9 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
 }
 
 hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st) {
-    k_bin_scan<<<n_pairs, kBlock, 0, st>>>(counts, tile_base, class_start, n_classes, chunks);
+    k_bin_tiles<<<dim3((n_classes + kBlock - 1) / kBlock, n_pairs), kBlock, 0, st>>>(counts, tile_base, class_start, n_classes, chunks);
+    ICET_LAUNCH_CHECK();
+    k_bin_scan<<<n_pairs, kBlock, 0, st>>>(class_start, n_classes);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

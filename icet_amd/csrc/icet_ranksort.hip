@@ -165,7 +165,7 @@ constexpr int kOffCnt = 0, kOffTot = kSortWaves * 256, kOffWsum = kOffTot + 256,
 // kLds selects, at compile time, LDS arrays (indexed off the extern __shared__ base, so the compiler emits ds_*
 // instructions) or the global scratch pointers; `sel` says which of the two buffers is the input.
 template <bool kLds>
-__device__ __forceinline__ void radix_pass(uint32_t* smem, int kCap, int sel, const uint32_t* gK0, const uint32_t* gI0, uint32_t* gK1, uint32_t* gI1, int n, int shift) {
+__device__ __forceinline__ void radix_pass(uint32_t* smem, int kCap, int sel, const uint32_t* gK0, const uint32_t* gI0, uint32_t* gK1, uint32_t* gI1, int n, int shift, uint32_t dmask) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* cnt = smem + kOffCnt; uint32_t* tot = smem + kOffTot; int* wsum = reinterpret_cast<int*>(smem + kOffWsum);
     const int inB = kOffBuf + sel * 2 * kCap, outB = kOffBuf + (1 - sel) * 2 * kCap;
@@ -209,6 +209,7 @@ __device__ __forceinline__ void radix_pass(uint32_t* smem, int kCap, int sel, co
         unsigned long long peers = __ballot(ok);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
+            if (!((dmask >> q) & 1u)) continue;                 // block-uniform: every key of the bucket has the same bit here
             const bool bit = (dgt >> q) & 1u;
             const unsigned long long m = __ballot(ok && bit);
             peers &= bit ? m : ~m;
@@ -250,7 +251,7 @@ __device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int kCap, const
     int sel = 0;
     for (int pass = 0; pass < 4; pass++) {
         if (((differ >> (8 * pass)) & 255u) == 0u) continue;    // block-uniform
-        radix_pass<kLds>(smem, kCap, sel, sel ? gK1 : gK0, sel ? gI1 : gI0, sel ? gK0 : gK1, sel ? gI0 : gI1, n, 8 * pass);
+        radix_pass<kLds>(smem, kCap, sel, sel ? gK1 : gK0, sel ? gI1 : gI0, sel ? gK0 : gK1, sel ? gI0 : gI1, n, 8 * pass, (differ >> (8 * pass)) & 255u);
         sel ^= 1;
     }
     for (int i = threadIdx.x; i < n; i += kSortBlock) {

@@ -435,3 +435,17 @@ def test_rarely_taken_paths_give_the_same_bits(gpu_ctx, frames, sample_pc):
         assert np.array_equal(r1["X"], base1["X"]) and np.array_equal(r1["pred_stds"], base1["pred_stds"]), (key, val)
         assert np.array_equal(r1["aux"]["n2_in"], base1["aux"]["n2_in"]) and np.array_equal(r1["aux"]["htwh"], base1["aux"]["htwh"]), (key, val)
         assert np.array_equal(r2["X"], base2["X"]), (key, val)
+    # wider guard bands / a coarser polar table send more points through the literal path and must not change a single decision
+    # (the tables are built when a context first sees a grid, so these need fresh contexts)
+    import icet_amd
+    for key, val in (("ICET_GUARD_SCALE", "16"), ("ICET_LUT_POLAR_QUANTILE", "0.6"), ("ICET_LUT_POLAR_QUANTILE", "0")):
+        os.environ[key] = val
+        try:
+            ctx = icet_amd.Context(0)
+            r1 = ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
+            r2 = ctx.solve(c, d, 7, np.zeros(6), 48, 150)
+            ctx.close()
+        finally:
+            del os.environ[key]
+        assert np.array_equal(r1["X"], base1["X"]) and np.array_equal(r1["aux"]["n2_in"], base1["aux"]["n2_in"]), (key, val)
+        assert np.array_equal(r2["X"], base2["X"]), (key, val)

@@ -386,7 +386,7 @@ icet_status icet_reserve(icet_ctx* c, const icet_params* p, int32_t n_pairs, int
 // kernel is measured alone on the device.
 static int batch_parts(const icet_params* p, int32_t n_pairs) {
     if (p->flags & ICET_FLAG_TIMING) return 1;
-    int parts = n_pairs >= 192 ? 3 : (n_pairs >= 64 ? 2 : 1);
+    int parts = n_pairs >= 64 ? 2 : 1;      // measured at the end of round 1 on 256 pairs (30 steps): 1 part 84.7 k, 2 parts 89.2 k, 3 parts 88.0 k pairs/s
     if (const char* e = getenv("ICET_BATCH_PARTS")) { parts = atoi(e); if (parts < 1) parts = 1; if (parts > 8) parts = 8; }
     if (parts > n_pairs) parts = n_pairs > 0 ? n_pairs : 1;
     return parts;
@@ -426,7 +426,8 @@ icet_status icet_solve_batch_device(icet_ctx* c, const icet_params* p, int32_t n
     // fork: helpers start after whatever the caller queued on this context's stream (e.g. the writes of the scans)
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     // Stagger: part i+1 starts once part i has finished the first keyframe stage, so the parts do not move through the
-    // same phase in lock step (measured on 256 pairs: 1 part 70.6k pairs/s; 3 parts in lock step 73.2k; staggered 76.8k).
+    // same phase in lock step (measured on 256 pairs with the kernels of that day: 1 part 70.6k pairs/s; 3 parts in lock
+    // step 73.2k; staggered 76.8k).
     int stage = 4;
     if (const char* e = getenv("ICET_BATCH_STAGE")) stage = atoi(e);
     for (int i = 0; i < parts; i++) {

@@ -32,7 +32,7 @@ python3 - <<PY
 import csv, json, re, collections
 def mean_counter(path, kernel, counter):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
-    v = [x for x in v if x >= 0.6 * max(v)]   # the whole-batch launches of the timed steps (the parts of the untimed steps are ~1/3 the size)
+    v = [x for x in v if x >= 0.6 * max(v)]   # the whole-batch launches of the timed steps (the parts of the untimed steps are half the size or less)
     return sum(v) / len(v)
 fetch_kb = mean_counter("/tmp/p_fetch.csv", "k_gn_accumulate", "FETCH_SIZE")
 write_kb = mean_counter("/tmp/p_write.csv", "k_gn_accumulate", "WRITE_SIZE")

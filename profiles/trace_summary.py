@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel summary from a rocprofv3 `--kernel-trace` CSV (one row per dispatch), split by launch size.
-Large device batches are solved in 2-3 parts on helper streams (icet_capi.hip, batch_parts), while the roofline steps of
+Large device batches are solved in parts on helper streams (icet_capi.hip, batch_parts), while the roofline steps of
 bench.py (ICET_FLAG_TIMING) launch every kernel ONCE over the whole batch, alone on the device: the two populations of
 k_gn_accumulate are listed separately and the whole-batch one is what bench.py's `roofline.avg_launch_ms` must agree with.
 usage: trace_summary.py <kernel_trace.csv> [steps_profiled]"""

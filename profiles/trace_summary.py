@@ -7,6 +7,7 @@ usage: trace_summary.py <kernel_trace.csv> [steps_profiled]"""
 import csv, re, sys, collections
 path = sys.argv[1]
 groups = collections.defaultdict(list)
+starts = collections.defaultdict(list)
 with open(path, newline="") as f:
     rd = csv.DictReader(f)
     gcol = next(c for c in rd.fieldnames if c.lower().startswith("grid_size") and c.lower().endswith("x"))
@@ -19,6 +20,7 @@ with open(path, newline="") as f:
         name = m.group(1) if m else n[:40]
         blocks = int(r[gcol]) // max(int(r[wcol]), 1)
         groups[(name, blocks)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        starts[name].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 by_kernel = collections.defaultdict(list)
 for (name, blocks), v in groups.items():
     by_kernel[name].append((blocks, v))
@@ -31,9 +33,14 @@ for name in sorted(by_kernel, key=lambda k: -sum(sum(v) for _, v in by_kernel[k]
 print("total %.1f us over all profiled launches" % tot)
 acc, sol = by_kernel.get("k_gn_accumulate"), by_kernel.get("k_gn_solve")
 if acc and sol:
-    # k_gn_solve runs one block per pair: its largest grid marks the whole-batch launches, and every accumulate launch is
-    # followed by exactly one solve launch, so the accumulate population with the same call count is the whole-batch one
+    # k_gn_solve runs one block per pair: its largest grid marks the whole-batch launches.  bench.py runs its roofline steps
+    # (ICET_FLAG_TIMING: whole batch, one launch per kernel) AFTER the untimed steps, and every accumulate launch is followed by
+    # exactly one solve launch, so the LAST n_whole accumulate dispatches are the whole-batch ones (block counts may coincide
+    # with those of the part launches, so they cannot be told apart by grid size).
     n_whole = len(max(sol, key=lambda t: t[0])[1])
-    cand = [t for t in acc if len(t[1]) == n_whole] or acc
-    blocks, v = max(cand, key=lambda t: sum(t[1]) / len(t[1]))
-    print("k_gn_accumulate, whole-batch launches (the population bench.py's roofline times): %d calls, avg %.1f us" % (len(v), sum(v) / len(v)))
+    v = [d for _, d in sorted(starts["k_gn_accumulate"])[-n_whole:]]
+    print("k_gn_accumulate, whole-batch launches (the population bench.py's roofline times): %d calls, avg %.1f us, min %.1f, max %.1f"
+          % (len(v), sum(v) / len(v), min(v), max(v)))
+    rest = [d for _, d in sorted(starts["k_gn_accumulate"])[:-n_whole]]
+    if rest:
+        print("k_gn_accumulate, part launches of the untimed steps (run beside other kernels): %d calls, avg %.1f us" % (len(rest), sum(rest) / len(rest)))

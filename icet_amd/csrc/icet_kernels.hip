@@ -231,7 +231,10 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
 // the forward chain v -> s[v] -> s[s[v]] ... while the steps executed.
 // Fused with the first step of the voxel multi-split (k_bin_hist): the row that lands on a position is known here, so
 // its voxel id and this tile's voxel histogram cost no extra pass over src[].
-__global__ __launch_bounds__(kBlock) void k_scramble_src(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
+#ifndef ICET_SCR_WAVES
+#define ICET_SCR_WAVES 6      /* <= 80 VGPRs: 6 waves per SIMD for a latency-bound walk (measured: -35 us per 256-pair keyframe; 8 spills) */
+#endif
+__global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
                                                          int32_t* __restrict__ src, int32_t* __restrict__ flags, int max_walk,
                                                          const uint16_t* __restrict__ bin16, uint16_t* __restrict__ binpos, uint32_t* __restrict__ counts, int V,
                                                          int n_pairs, int chunks) {
@@ -469,7 +472,10 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
 // The per-bin tail -- 3x3 eigen-decomposition, the six sigma points, the slot records -- is scalar work: it runs in
 // k_fit_finish with one LANE per bin instead of here with one WAVE per bin (measured: 0.21 ms of the 0.42 ms this kernel
 // took on 256 pairs was 64 lanes executing the same eigen-solve).
-__global__ __launch_bounds__(kBlock) void k_fit_scan1(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
+#ifndef ICET_FIT_WAVES
+#define ICET_FIT_WAVES 7      /* <= 72 VGPRs: one more wave per SIMD hides the gather latency (measured: -47 us per 256-pair keyframe; 8 is worse) */
+#endif
+__global__ __launch_bounds__(kBlock, ICET_FIT_WAVES) void k_fit_scan1(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
                                                       const uint32_t* __restrict__ sorted_row,
                                                       const float* __restrict__ r1, const float* __restrict__ th1, const float* __restrict__ ph1,
                                                       FitMid* __restrict__ midD, int T, int P, int n, float thresh, float buff) {

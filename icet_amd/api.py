@@ -23,7 +23,7 @@ FLAG_TIMING = 1
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_batch",
                     "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch",
                     "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_map",
-                    "icet_node_prev_scan", "icet_node_last_timing", "icet_stream", "icet_device",
+                    "icet_node_prev_scan", "icet_node_aligned", "icet_node_snail_trail", "icet_node_last_timing", "icet_stream", "icet_device",
                     "icet_load_scan", "icet_free_scan", "icet_save_scan_npy")
 _NON_STATUS = ("icet_version", "icet_last_error", "icet_stream", "icet_device", "icet_free_scan")
 
@@ -42,7 +42,7 @@ class Params(C.Structure):
 class NodeParams(C.Structure):
     """icet_node_params (include/icet_nodes.h)."""
     _fields_ = [("solve", Params), ("min_range", C.c_float), ("seed_x0", C.c_int32), ("trans_thresh", C.c_float), ("rot_thresh", C.c_float),
-                ("map_capacity", C.c_int32), ("map_downsample", C.c_int32)]
+                ("map_capacity", C.c_int32), ("map_downsample", C.c_int32), ("flags", C.c_int32)]
 
 
 class NodeResult(C.Structure):
@@ -96,6 +96,8 @@ def load_library():
     L.icet_node_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.icet_node_last_timing.argtypes = [C.c_void_p, C.c_void_p]
     L.icet_node_prev_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.icet_node_aligned.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.icet_node_snail_trail.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.icet_load_scan.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int64)]
     L.icet_free_scan.argtypes = [C.POINTER(C.c_float)]; L.icet_free_scan.restype = None
     L.icet_save_scan_npy.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64]
@@ -280,12 +282,15 @@ ODOMETRY_NODE = dict(runlen=7, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buf
                      trans_thresh=0.0, rot_thresh=0.0, map_capacity=0, map_downsample=0)              # src/odometry.cpp:58,73-82
 MAP_MAKER_NODE = dict(runlen=12, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1, min_range=0.2, seed_x0=0,
                       trans_thresh=0.3, rot_thresh=0.3, map_capacity=600000, map_downsample=2000)      # src/simpleMapMaker.cpp:62,98,113-124,147,241-242
+NODE_NO_RANGE_FILTER, NODE_ALIGNED_CLOUD, NODE_SNAIL_TRAIL = 1, 2, 4
+SCAN_REGISTRATION_NODE = dict(runlen=7, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1, min_range=0.0, seed_x0=0,
+                              trans_thresh=0.0, rot_thresh=0.0, map_capacity=0, map_downsample=0, flags=7)  # src/scanMatcher.cpp:44,55-64,76,79-84
 
 
 def node_params(**kw):
     d = dict(ODOMETRY_NODE); d.update(kw)
     return NodeParams(Params(d["runlen"], d["bins_phi"], d["bins_theta"], d["n"], d["thresh"], d["buff"], 0), d["min_range"], d["seed_x0"],
-                      d["trans_thresh"], d["rot_thresh"], d["map_capacity"], d["map_downsample"])
+                      d["trans_thresh"], d["rot_thresh"], d["map_capacity"], d["map_downsample"], d.get("flags", 0))
 
 
 def _result_dict(r):
@@ -365,6 +370,26 @@ class Node:
             if st != ICET_OK:
                 raise IcetError(st, "icet_node_prev_scan")
         return np.ascontiguousarray(out[:, :rows.value].T)
+
+    def _rows(self, fn, what):
+        rows = C.c_int64()
+        st = fn(self._h, None, 0, C.byref(rows))
+        if st != ICET_OK:
+            raise IcetError(st, what)
+        out = np.zeros((3, max(rows.value, 1)), np.float32)
+        if rows.value:
+            st = fn(self._h, out.ctypes.data_as(C.c_void_p), rows.value, C.byref(rows))
+            if st != ICET_OK:
+                raise IcetError(st, what)
+        return np.ascontiguousarray(out[:, :rows.value].T)
+
+    def aligned(self):
+        """``scan2_in_scan1_frame`` of the last frame (src/scanMatcher.cpp:76): rows x 3."""
+        return self._rows(load_library().icet_node_aligned, "icet_node_aligned")
+
+    def snail_trail(self):
+        """``snailTrail`` (src/scanMatcher.cpp:79-84): rows x 3."""
+        return self._rows(load_library().icet_node_snail_trail, "icet_node_snail_trail")
 
     def last_timing(self):
         t = (C.c_float * 3)()

@@ -126,6 +126,21 @@ __global__ __launch_bounds__(256) void k_map_add_scan(float* __restrict__ qx, fl
     }
 }
 
+// scan2_in_scan1_frame = (pcl_matrix * rot_mat.inverse()).rowwise() - trans  (src/scanMatcher.cpp:76): rotate first, then subtract
+__global__ __launch_bounds__(256) void k_align_cloud(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int n,
+                                                    float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, float tx, float ty, float tz,
+                                                    float i00, float i01, float i02, float i10, float i11, float i12, float i20, float i21, float i22) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float a = sx[i], b = sy[i], c = sz[i];
+        {
+#pragma clang fp contract(off)
+            ox[i] = ((a * i00 + b * i10) + c * i20) - tx;
+            oy[i] = ((a * i01 + b * i11) + c * i21) - ty;
+            oz[i] = ((a * i02 + b * i12) + c * i22) - tz;
+        }
+    }
+}
+
 // getQueue (src/simpleMapMaker.cpp:43-50): oldest row first
 __global__ __launch_bounds__(256) void k_map_unroll(const float* __restrict__ qx, const float* __restrict__ qy, const float* __restrict__ qz, int cap, int pos,
                                                    int filled, int rows, float* __restrict__ out, int ld) {
@@ -208,6 +223,8 @@ struct icet_node {
     std::vector<std::size_t> indices;
     float* d_map = nullptr; int64_t map_pos = 0; bool map_filled = false;
     int32_t* d_idx = nullptr; int32_t* h_idx = nullptr;
+    float* d_aligned = nullptr; int64_t cap_aligned = 0, n_aligned = 0, ld_aligned = 0;     // scanMatcher.cpp:76
+    std::vector<float> snail;                                                               // scanMatcher.cpp:27-28,79-84: rows x 3 row-major, host
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false, timed_map = false;
 };
@@ -261,7 +278,10 @@ icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t l
         nd->cap_blocks = n_blocks;
     }
     NCHK(nd, hipEventRecord(nd->ev[0], st));
-    if (n > 0) {
+    if (nd->p.flags & ICET_NODE_NO_RANGE_FILTER) {               // scanMatcher.cpp:44: the cloud goes to the constructor as it is
+        if (n) NCHK(nd, hipMemcpy2DAsync(nd->d_scan[cur], lcur * sizeof(float), d_scan, ld * sizeof(float), n * sizeof(float), 3, hipMemcpyDeviceToDevice, st));
+        *nd->h_nkept = (int32_t)n;
+    } else if (n > 0) {
         const float *x = d_scan, *y = d_scan + ld, *z = d_scan + 2 * ld;
         float* o = nd->d_scan[cur];
         k_range_count<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_counts);
@@ -327,6 +347,31 @@ icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t l
         nd->map_pos = (nd->map_pos + m) % cap;
         nd->timed_map = true;
     }
+    if (nd->p.flags & (ICET_NODE_ALIGNED_CLOUD | ICET_NODE_SNAIL_TRAIL)) {
+        float Ri[9]; inverse3_lu(R, Ri);
+        if (nd->p.flags & ICET_NODE_ALIGNED_CLOUD) {
+            if (lcur > nd->cap_aligned) {
+                NCHK(nd, hipStreamSynchronize(st));
+                if (nd->d_aligned) { NCHK(nd, hipFree(nd->d_aligned)); nd->d_aligned = nullptr; }
+                NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_aligned), sizeof(float) * 3 * (size_t)lcur));
+                nd->cap_aligned = lcur;
+            }
+            const float* sc = nd->d_scan[cur]; float* o = nd->d_aligned; const int64_t la = nd->cap_aligned;
+            if (nk) k_align_cloud<<<(int)std::min<int64_t>((nk + 255) / 256, 2048), 256, 0, st>>>(sc, sc + lcur, sc + 2 * lcur, (int)nk, o, o + la, o + 2 * la, X[0], X[1], X[2],
+                                                                                               Ri[0], Ri[1], Ri[2], Ri[3], Ri[4], Ri[5], Ri[6], Ri[7], Ri[8]);
+            NCHK(nd, hipGetLastError());
+            nd->n_aligned = nk; nd->ld_aligned = la;
+        }
+        if (nd->p.flags & ICET_NODE_SNAIL_TRAIL) {               // snailTrail = (snailTrail * rot_mat.inverse()).rowwise() - trans; append the origin
+            for (size_t i = 0; i + 2 < nd->snail.size(); i += 3) {
+                const float a = nd->snail[i], b = nd->snail[i + 1], c = nd->snail[i + 2];
+                nd->snail[i] = ((a * Ri[0] + b * Ri[3]) + c * Ri[6]) - X[0];
+                nd->snail[i + 1] = ((a * Ri[1] + b * Ri[4]) + c * Ri[7]) - X[1];
+                nd->snail[i + 2] = ((a * Ri[2] + b * Ri[5]) + c * Ri[8]) - X[2];
+            }
+            nd->snail.insert(nd->snail.end(), {0.f, 0.f, 0.f});
+        }
+    }
     nd->prev = cur;                                               // prev_pcl_matrix = pcl_matrix (odometry.cpp:88)
     // X_homo = X_homo * X_homo_i (odometry.cpp:91-98)
     const float Hi[16] = {R[0], R[1], R[2], X[0], R[3], R[4], R[5], X[1], R[6], R[7], R[8], X[2], 0, 0, 0, 1};
@@ -359,6 +404,7 @@ icet_status icet_node_create(icet_ctx* ctx, const icet_node_params* p, icet_node
         hipHostMalloc(reinterpret_cast<void**>(&nd->h_out), sizeof(float) * 48) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_x0), sizeof(float) * 6) != hipSuccess)
         return fail(ICET_ERR_NOMEM);
     for (hipEvent_t& e : nd->ev) if (hipEventCreate(&e) != hipSuccess) return fail(ICET_ERR_HIP);
+    if (p->flags & ICET_NODE_SNAIL_TRAIL) nd->snail.assign(3, 0.f);      // scanMatcher.cpp:27-28: one row at the origin
     if (p->map_capacity > 0) {
         if (hipMalloc(reinterpret_cast<void**>(&nd->d_map), sizeof(float) * 3 * (size_t)p->map_capacity) != hipSuccess) return fail(ICET_ERR_NOMEM);
         if (hipMemset(nd->d_map, 0, sizeof(float) * 3 * (size_t)p->map_capacity) != hipSuccess) return fail(ICET_ERR_HIP);      // Eigen leaves MatrixXf(maxSize, 3) uninitialised; unfilled rows are never returned by getQueue
@@ -374,7 +420,7 @@ icet_status icet_node_destroy(icet_node* nd) {
     if (!nd) return ICET_ERR_BAD_ARG;
     (void)hipSetDevice(nd->device);
     (void)hipDeviceSynchronize();            // not the borrowed stream: the context may already be gone
-    void* dp[] = {nd->d_scan[0], nd->d_scan[1], nd->d_stage, nd->d_counts, nd->d_bases, nd->d_nkept, nd->d_x0, nd->d_out, nd->d_map, nd->d_idx};
+    void* dp[] = {nd->d_scan[0], nd->d_scan[1], nd->d_stage, nd->d_counts, nd->d_bases, nd->d_nkept, nd->d_x0, nd->d_out, nd->d_map, nd->d_idx, nd->d_aligned};
     for (void* q : dp) if (q) (void)hipFree(q);
     void* hp[] = {nd->h_nkept, nd->h_out, nd->h_x0, nd->h_idx};
     for (void* q : hp) if (q) (void)hipHostFree(q);
@@ -432,6 +478,28 @@ icet_status icet_node_prev_scan(icet_node* nd, float* out, int64_t ld, int64_t* 
     if (hipSetDevice(nd->device) != hipSuccess) return ICET_ERR_NO_DEVICE;
     NCHK(nd, hipMemcpy2DAsync(out, ld * sizeof(float), nd->d_scan[nd->prev], nd->ld_scan[nd->prev] * sizeof(float), rows * sizeof(float), 3, hipMemcpyDeviceToHost, nd->stream));
     NCHK(nd, hipStreamSynchronize(nd->stream));
+    return ICET_OK;
+}
+
+icet_status icet_node_aligned(icet_node* nd, float* out, int64_t ld, int64_t* rows_out) {
+    if (!nd || !rows_out) return ICET_ERR_BAD_ARG;
+    const int64_t rows = nd->n_aligned;
+    *rows_out = rows;
+    if (!out || rows == 0) return ICET_OK;
+    if (ld < rows) return ICET_ERR_BAD_ARG;
+    if (hipSetDevice(nd->device) != hipSuccess) return ICET_ERR_NO_DEVICE;
+    NCHK(nd, hipMemcpy2DAsync(out, ld * sizeof(float), nd->d_aligned, nd->ld_aligned * sizeof(float), rows * sizeof(float), 3, hipMemcpyDeviceToHost, nd->stream));
+    NCHK(nd, hipStreamSynchronize(nd->stream));
+    return ICET_OK;
+}
+
+icet_status icet_node_snail_trail(icet_node* nd, float* out, int64_t ld, int64_t* rows_out) {
+    if (!nd || !rows_out) return ICET_ERR_BAD_ARG;
+    const int64_t rows = (int64_t)(nd->snail.size() / 3);
+    *rows_out = rows;
+    if (!out || rows == 0) return ICET_OK;
+    if (ld < rows) return ICET_ERR_BAD_ARG;
+    for (int64_t i = 0; i < rows; i++) { out[i] = nd->snail[3 * i]; out[ld + i] = nd->snail[3 * i + 1]; out[2 * ld + i] = nd->snail[3 * i + 2]; }
     return ICET_OK;
 }
 

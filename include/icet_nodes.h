@@ -5,6 +5,7 @@
  *   * the per-frame body of `OdometryNode::pointCloudCallback`   /root/reference/src/odometry.cpp:46-98
  *   * the per-frame body of `MapMakerNode::pointCloudCallback`   /root/reference/src/simpleMapMaker.cpp:86-172
  *   * `EigenQueue` (the HD-map FIFO)                             /root/reference/src/simpleMapMaker.cpp:18-59
+ *   * the per-frame body of `ScanRegistrationNode::pointcloudCallback` /root/reference/src/scanMatcher.cpp:30-110
  * i.e. first scan stored as-is, every later scan range-filtered (row norm > min_range), ICET(prev, cur, ...) solved
  * through icet_hip.h, X0 seeded for the next frame, the divergence guard, the accumulated pose X_homo, and the map
  * queue re-expressed in the new sensor frame.  Scan layout as in icet_hip.h: N x 3 float32 column-major, ld >= N.
@@ -31,7 +32,17 @@ typedef struct icet_node_params {
     float   rot_thresh;       /*   both <= 0: no guard (the odometry node has none)                                        */
     int32_t map_capacity;     /* rows of the map FIFO: 600000 (simpleMapMaker.cpp:62); 0: no map (odometry node)           */
     int32_t map_downsample;   /* rows of each scan that enter the map: 2000 (simpleMapMaker.cpp:147)                        */
+    int32_t flags;            /* ICET_NODE_* below; 0 for the two nodes above                                              */
 } icet_node_params;
+
+/* scan_registration_node (src/scanMatcher.cpp:30-110): no range filter at all (:44, every row -- NaN rows included -- goes
+ * to the constructor), X0 = 0 every frame (:59-62), and two published clouds: scan 2 expressed in scan 1's frame,
+ * `(pcl_matrix * rot_mat.inverse()).rowwise() - trans` (:76; note the order: rotate, THEN subtract -- the map queue does the
+ * opposite), and the "snail trail" of past sensor positions, transformed the same way each frame with a new origin row
+ * appended (:79-84). */
+enum { ICET_NODE_NO_RANGE_FILTER = 1,   /* every row of every scan is kept (min_range ignored)                              */
+       ICET_NODE_ALIGNED_CLOUD   = 2,   /* keep scan2_in_scan1_frame of the last frame on the device (icet_node_aligned)    */
+       ICET_NODE_SNAIL_TRAIL     = 4 }; /* maintain the snail trail (icet_node_snail_trail)                                 */
 
 typedef struct icet_node_result {
     int32_t solved;           /* 0 for the first scan: it is only stored (odometry.cpp:46-52)                              */
@@ -64,6 +75,10 @@ icet_status icet_node_map(icet_node* node, float* out, int64_t ld, int64_t* rows
  * recent push after the range filter (the first push unfiltered).  rows x 3 column-major, leading dimension ld;
  * `out` may be NULL to query `rows` only. */
 icet_status icet_node_prev_scan(icet_node* node, float* out, int64_t ld, int64_t* rows);
+
+/* scanMatcher.cpp:76 / :79-84 (flags ICET_NODE_ALIGNED_CLOUD / ICET_NODE_SNAIL_TRAIL): rows x 3 column-major copies to the host. */
+icet_status icet_node_aligned(icet_node* node, float* out, int64_t ld, int64_t* rows);
+icet_status icet_node_snail_trail(icet_node* node, float* out, int64_t ld, int64_t* rows);
 
 /* Device-side time of the pieces of the most recent push, measured with HIP events on the context's stream:
  * [0] range filter ms, [1] ICET solve ms, [2] map-queue kernel ms (0 if no map). */

@@ -79,13 +79,20 @@ private:
 
 // odometry_node's settings: src/odometry.cpp:58 (minD = 2), :73-76 (7, 24, 75), :82 (X0 <- X)
 struct OdometryNode : LidarNode {
-    explicit OdometryNode(int device = 0) : LidarNode(icet_node_params{{7, 24, 75, 25, 0.1f, 0.1f, ICET_FLAG_NONE}, 2.0f, 1, 0.f, 0.f, 0, 0}, device) {}
+    explicit OdometryNode(int device = 0) : LidarNode(icet_node_params{{7, 24, 75, 25, 0.1f, 0.1f, ICET_FLAG_NONE}, 2.0f, 1, 0.f, 0.f, 0, 0, 0}, device) {}
 };
 
 // map_maker_node's settings: src/simpleMapMaker.cpp:62 (600000 x 3), :98 (minD = 0.2), :113-119, :124 (X0 <- 0), :147, :241-242
 struct MapMakerNode : LidarNode {
     explicit MapMakerNode(int device = 0)
-        : LidarNode(icet_node_params{{12, 24, 75, 25, 0.1f, 0.1f, ICET_FLAG_NONE}, 0.2f, 0, 0.3f, 0.3f, 600000, 2000}, device) {}
+        : LidarNode(icet_node_params{{12, 24, 75, 25, 0.1f, 0.1f, ICET_FLAG_NONE}, 0.2f, 0, 0.3f, 0.3f, 600000, 2000, 0}, device) {}
+};
+
+// scan_registration_node's settings: src/scanMatcher.cpp:44 (no range filter), :55-62 (7, 24, 75, X0 = 0), :76 and :79-84 (published clouds)
+struct ScanRegistrationNode : LidarNode {
+    explicit ScanRegistrationNode(int device = 0)
+        : LidarNode(icet_node_params{{7, 24, 75, 25, 0.1f, 0.1f, ICET_FLAG_NONE}, 0.f, 0, 0.f, 0.f, 0, 0,
+                                     ICET_NODE_NO_RANGE_FILTER | ICET_NODE_ALIGNED_CLOUD | ICET_NODE_SNAIL_TRAIL}, device) {}
 };
 
 }  // namespace icet_amd

@@ -6,6 +6,7 @@
 //   OdometryNode::pointCloudCallback   /root/reference/src/odometry.cpp:46-98,113-118
 //   MapMakerNode::pointCloudCallback   /root/reference/src/simpleMapMaker.cpp:86-172
 //   EigenQueue                         /root/reference/src/simpleMapMaker.cpp:18-59
+//   ScanRegistrationNode::pointcloudCallback  /root/reference/src/scanMatcher.cpp:30-110
 // PARITY UNPINNED against the real reference for the same reason as icet_oracle.cpp (Eigen, PCL and ROS are absent
 // from this image and the reference has no tests or golden data for these nodes).  Under-specified points and the
 // choice made here:
@@ -40,6 +41,9 @@ struct Node {
     std::mt19937 gen;                     // default seed, simpleMapMaker.cpp:258
     // EigenQueue (simpleMapMaker.cpp:18-59)
     std::vector<float> qx, qy, qz; int64_t pos = 0; bool filled = false;
+    // scanMatcher.cpp: scan2_in_scan1_frame (:76) and snailTrail (:27-28, 79-84)
+    Scan aligned;
+    Scan snail;
 };
 
 // Eigen's PartialPivLU inverse of a 3 x 3 (row-major in, row-major out)
@@ -92,6 +96,7 @@ void* icet_oracle_node_create(const icet_oracle_node_params* p) {
     if (!p) return nullptr;
     Node* nd = new Node(); nd->p = *p;
     if (p->map_capacity > 0) { nd->qx.assign(p->map_capacity, 0.f); nd->qy.assign(p->map_capacity, 0.f); nd->qz.assign(p->map_capacity, 0.f); }
+    if (p->flags & 4) { nd->snail.x.assign(1, 0.f); nd->snail.y.assign(1, 0.f); nd->snail.z.assign(1, 0.f); }      // scanMatcher.cpp:27-28
     return nd;
 }
 
@@ -114,7 +119,7 @@ int icet_oracle_node_push(void* h, const float* scan, int64_t n, int64_t ld, ice
     Scan cur;
     for (int64_t i = 0; i < n; i++) {
         const float d = std::sqrt((sx[i] * sx[i] + sy[i] * sy[i]) + sz[i] * sz[i]);
-        if (d > nd->p.min_range) { cur.x.push_back(sx[i]); cur.y.push_back(sy[i]); cur.z.push_back(sz[i]); }
+        if ((nd->p.flags & 1) || d > nd->p.min_range) { cur.x.push_back(sx[i]); cur.y.push_back(sy[i]); cur.z.push_back(sz[i]); }
     }
     auto pack = [](const Scan& s) { std::vector<float> m; m.reserve(3 * s.x.size()); m.insert(m.end(), s.x.begin(), s.x.end()); m.insert(m.end(), s.y.begin(), s.y.end()); m.insert(m.end(), s.z.begin(), s.z.end()); return m; };
     const std::vector<float> m1 = pack(nd->prev), m2 = pack(cur);
@@ -153,6 +158,20 @@ int icet_oracle_node_push(void* h, const float* scan, int64_t n, int64_t ld, ice
             nd->qz[i] = (a * Rinv[2] + b * Rinv[5]) + c * Rinv[8];
         }
     }
+    if (nd->p.flags & 6) {
+        // (M * rot_mat.inverse()).rowwise() - trans : rotate first, then subtract (scanMatcher.cpp:76, 80)
+        float Rinv[9]; inverse3_partial_piv_lu(R, Rinv);
+        auto xf = [&](Scan& sc) {
+            for (int64_t i = 0; i < sc.n(); i++) {
+                const float a = sc.x[i], b = sc.y[i], c = sc.z[i];
+                sc.x[i] = ((a * Rinv[0] + b * Rinv[3]) + c * Rinv[6]) - X[0];
+                sc.y[i] = ((a * Rinv[1] + b * Rinv[4]) + c * Rinv[7]) - X[1];
+                sc.z[i] = ((a * Rinv[2] + b * Rinv[5]) + c * Rinv[8]) - X[2];
+            }
+        };
+        if (nd->p.flags & 2) { nd->aligned = cur; xf(nd->aligned); }
+        if (nd->p.flags & 4) { xf(nd->snail); nd->snail.x.push_back(0.f); nd->snail.y.push_back(0.f); nd->snail.z.push_back(0.f); }
+    }
     nd->prev = cur;                                               // odometry.cpp:88
     // X_homo = X_homo * X_homo_i  (odometry.cpp:91-98)
     const float Hi[16] = {R[0], R[1], R[2], X[0], R[3], R[4], R[5], X[1], R[6], R[7], R[8], X[2], 0, 0, 0, 1};
@@ -180,5 +199,15 @@ int64_t icet_oracle_node_map(void* h, float* out, int64_t ld) {
     }
     return rows;
 }
+
+static int64_t copy_scan(const Scan& sc, float* out, int64_t ld) {
+    const int64_t rows = sc.n();
+    if (!out) return rows;
+    if (ld < rows) return -1;
+    for (int64_t i = 0; i < rows; i++) { out[i] = sc.x[i]; out[ld + i] = sc.y[i]; out[2 * ld + i] = sc.z[i]; }
+    return rows;
+}
+int64_t icet_oracle_node_aligned(void* h, float* out, int64_t ld) { Node* nd = static_cast<Node*>(h); return nd ? copy_scan(nd->aligned, out, ld) : -1; }
+int64_t icet_oracle_node_snail_trail(void* h, float* out, int64_t ld) { Node* nd = static_cast<Node*>(h); return nd ? copy_scan(nd->snail, out, ld) : -1; }
 
 }  // extern "C"

@@ -83,6 +83,7 @@ typedef struct icet_oracle_node_params {
     float   rot_thresh;
     int32_t map_capacity;    /* 600000 simpleMapMaker.cpp:62; 0 = no map         */
     int32_t map_downsample;  /* 2000 simpleMapMaker.cpp:147                      */
+    int32_t flags;           /* 1 no range filter, 2 aligned cloud, 4 snail trail: scanMatcher.cpp:44,76,79-84 */
 } icet_oracle_node_params;
 
 typedef struct icet_oracle_node_result {
@@ -96,6 +97,8 @@ void*   icet_oracle_node_create(const icet_oracle_node_params* p);
 void    icet_oracle_node_destroy(void* node);
 int     icet_oracle_node_push(void* node, const float* scan, int64_t n, int64_t ld, icet_oracle_node_result* res);
 int64_t icet_oracle_node_map(void* node, float* out, int64_t ld);   /* rows; out may be NULL */
+int64_t icet_oracle_node_aligned(void* node, float* out, int64_t ld);      /* scanMatcher.cpp:76   */
+int64_t icet_oracle_node_snail_trail(void* node, float* out, int64_t ld);  /* scanMatcher.cpp:79-84 */
 
 #ifdef __cplusplus
 }

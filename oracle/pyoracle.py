@@ -190,7 +190,7 @@ def euler_R(angs):
 # ---- the callers around the constructor (icet_nodes_oracle.cpp) ------------------------------------------------------
 class NodeParams(C.Structure):
     _fields_ = [("solve", Params), ("min_range", C.c_float), ("seed_x0", C.c_int32), ("trans_thresh", C.c_float), ("rot_thresh", C.c_float),
-                ("map_capacity", C.c_int32), ("map_downsample", C.c_int32)]
+                ("map_capacity", C.c_int32), ("map_downsample", C.c_int32), ("flags", C.c_int32)]
 
 
 class NodeResult(C.Structure):
@@ -203,7 +203,7 @@ class Node:
     src/simpleMapMaker.cpp:86-172).  Same keyword arguments as icet_amd.api.Node."""
 
     def __init__(self, runlen=7, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1, min_range=2.0, seed_x0=1,
-                 trans_thresh=0.0, rot_thresh=0.0, map_capacity=0, map_downsample=0, mode=SERIAL):
+                 trans_thresh=0.0, rot_thresh=0.0, map_capacity=0, map_downsample=0, flags=0, mode=SERIAL):
         L = lib()
         L.icet_oracle_node_create.restype = C.c_void_p
         L.icet_oracle_node_create.argtypes = [C.POINTER(NodeParams)]
@@ -211,8 +211,10 @@ class Node:
         L.icet_oracle_node_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(NodeResult)]
         L.icet_oracle_node_map.restype = C.c_int64
         L.icet_oracle_node_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        for f in (L.icet_oracle_node_aligned, L.icet_oracle_node_snail_trail):
+            f.restype = C.c_int64; f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         self._p = NodeParams(make_params(runlen, bins_phi, bins_theta, n, thresh, buff, mode), min_range, seed_x0, trans_thresh, rot_thresh,
-                             map_capacity, map_downsample)
+                             map_capacity, map_downsample, flags)
         self._h = C.c_void_p(L.icet_oracle_node_create(C.byref(self._p)))
 
     def close(self):
@@ -242,3 +244,16 @@ class Node:
         if rows:
             lib().icet_oracle_node_map(self._h, out.ctypes.data_as(C.c_void_p), rows)
         return np.ascontiguousarray(out[:, :rows].T)
+
+    def _rows(self, fn):
+        rows = fn(self._h, None, 0)
+        out = np.zeros((3, max(rows, 1)), np.float32)
+        if rows:
+            fn(self._h, out.ctypes.data_as(C.c_void_p), rows)
+        return np.ascontiguousarray(out[:, :rows].T)
+
+    def aligned(self):
+        return self._rows(lib().icet_oracle_node_aligned)
+
+    def snail_trail(self):
+        return self._rows(lib().icet_oracle_node_snail_trail)

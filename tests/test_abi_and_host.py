@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_header_compiles_as_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "icet_hip.h"\n#include "icet_nodes.h"\n#include "icet_io.h"\nint main(void){ icet_params p = {7,24,75,25,0.1f,0.1f,0}; icet_node_params q = {{7,24,75,25,0.1f,0.1f,0}, 2.0f, 1, 0.f, 0.f, 0, 0}; '
+    src.write_text('#include "icet_hip.h"\n#include "icet_nodes.h"\n#include "icet_io.h"\nint main(void){ icet_params p = {7,24,75,25,0.1f,0.1f,0}; icet_node_params q = {{7,24,75,25,0.1f,0.1f,0}, 2.0f, 1, 0.f, 0.f, 0, 0, 0}; '
                    'return p.runlen == 7 && q.seed_x0 == 1 ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "t")])
     subprocess.check_call([str(tmp_path / "t")])

@@ -215,3 +215,58 @@ def test_gpu_cpp_node_demo(tmp_path, gpu_ctx, seq64):
         g.close()
         if mode == "mapmaker":
             assert out.stdout.strip().splitlines()[-1] == "map_rows 4000"
+
+
+def test_node_oracle_scan_registration_mode():
+    """scanMatcher.cpp: no range filter, X0 = 0 every frame, scan 2 re-expressed in scan 1's frame as (M R^-1) - t (rotate, THEN
+    subtract) and the snail trail transformed the same way with a fresh origin row appended."""
+    from oracle import pyoracle as po
+    seq = _sequence(3)
+    seq[1] = seq[1].copy(); seq[1][5] = [np.nan, 1.0, 2.0]; seq[1][6] = 0.0          # NaN and zero rows are NOT filtered here (:44)
+    nd = po.Node(min_range=2.0, seed_x0=0, flags=7)
+    nd.push(seq[0])
+    assert nd.snail_trail().shape == (1, 3) and nd.aligned().shape == (0, 3)
+    r1 = nd.push(seq[1])
+    assert r1["n_kept"] == len(seq[1])
+    ref = po.solve(seq[0], seq[1], x0=np.zeros(6))
+    assert np.array_equal(r1["X"], ref["X"])
+    Rinv = np.linalg.inv(_euler_R(r1["X"][3:])); t = r1["X"][:3].astype(np.float64)
+    al = nd.aligned()
+    ok = np.isfinite(seq[1]).all(1)
+    assert al.shape == seq[1].shape and np.allclose(al[ok], seq[1][ok].astype(np.float64) @ Rinv - t, atol=2e-5)
+    assert np.isnan(al[5]).any()
+    st = nd.snail_trail()
+    assert st.shape == (2, 3) and not st[1].any() and np.allclose(st[0], -t, atol=1e-6)      # the old origin seen from the new frame
+    r2 = nd.push(seq[2])
+    assert np.array_equal(r2["X"], po.solve(seq[1], seq[2], x0=np.zeros(6))["X"])             # X0 reset, prev = unfiltered scan 1
+    assert nd.snail_trail().shape == (3, 3)
+    nd.close()
+
+
+@pytest.mark.gpu
+def test_gpu_scan_registration_node_matches_oracle(gpu_ctx, seq64):
+    from oracle import pyoracle as po
+    from icet_amd import api
+    seq = [s.copy() for s in seq64]
+    seq[2][100] = [np.nan, 0.5, 0.5]; seq[2][101] = 0.0
+    g, o = api.Node(gpu_ctx, **api.SCAN_REGISTRATION_NODE), po.Node(**api.SCAN_REGISTRATION_NODE)
+    for k, s in enumerate(seq):
+        rg, ro = g.push(s), o.push(s)
+        assert rg["n_kept"] == ro["n_kept"] == len(s)
+        assert np.array_equal(g.prev_scan().view(np.uint32), s.view(np.uint32))               # nothing filtered, NaN row included
+        if k:
+            assert np.abs(rg["X"] - ro["X"]).max() <= 3e-4
+            ag, ao = g.aligned(), o.aligned()
+            fin = np.isfinite(ao).all(1)
+            assert ag.shape == ao.shape and np.abs(ag[fin] - ao[fin]).max() <= 5e-3 and np.isnan(ag[~fin]).any(1).all()
+            sg, so = g.snail_trail(), o.snail_trail()
+            assert sg.shape == so.shape == (k + 1, 3) and np.abs(sg - so).max() <= 2e-3
+    g.close(); o.close()
+    # with X forced to zero (guard) the two clouds are pure data movement: bit-exact
+    kw = dict(api.SCAN_REGISTRATION_NODE); kw.update(trans_thresh=1e-6, rot_thresh=1e-6)
+    g, o = api.Node(gpu_ctx, **kw), po.Node(**kw)
+    for s in seq[:3]:
+        g.push(s); o.push(s)
+        assert np.array_equal(g.aligned().view(np.uint32), o.aligned().view(np.uint32))
+        assert np.array_equal(g.snail_trail(), o.snail_trail())
+    g.close(); o.close()

@@ -106,7 +106,7 @@ struct LaunchCfg {
     int64_t total_n1;
     int lds_slots = 0;   /* 0 = sized from the LDS budget in launch_gn_accumulate */              // active voxels kept in LDS by k_gn_accumulate (the rest go straight to HBM)
     int acc_min_pts_per_thread = 4;   // launch shaping of k_gn_accumulate: a block handles at least one trip (512 threads x 4 points); matters for single pairs
-    int acc_target_blocks = 1024;     // ~4 blocks per CU: each block's start-up (LUTs, map, hot records into LDS) is paid once per ~30 k points
+    int acc_target_blocks = 1536;     // 6 blocks per CU = two rounds of the three that are resident; each block's start-up (LUTs, map, hot records into LDS) is paid once per ~20 k points
     int kf_chunks = 1;                // tiles per pair in the keyframe kernels (set by the host from max_n1)
     int kf_pts_per_thread = kKfMaxPtsPerThread;        // keyframe kernels: points per thread (sets chunks per pair)
     hipEvent_t stage_event = nullptr; /* recorded inside launch_keyframe after stage `stage_at` (4 spherical, 1 sort, 2 scramble, 3 gather): lets the next batch part start there */

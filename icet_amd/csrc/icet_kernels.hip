@@ -35,14 +35,14 @@ constexpr int kBlock = 256;
 #define ICET_ACC_BLOCK 512
 #endif
 #ifndef ICET_ACC_WAVES
-#define ICET_ACC_WAVES 4
+#define ICET_ACC_WAVES 6
 #endif
 #ifndef ICET_ACC_PTS
 #define ICET_ACC_PTS 4
 #endif
 constexpr int kAccPts = ICET_ACC_PTS;                      // consecutive points per lane per trip (two dwordx4 loads per coordinate)
 constexpr int kAccBlock = ICET_ACC_BLOCK;        // k_gn_accumulate: the waves of a block share one copy of the pair's LDS tables
-constexpr int kAccWavesPerSimd = ICET_ACC_WAVES; // register budget (6 -> 80 VGPRs, no spills; measured equal to 4 and faster than 8, which spills)
+constexpr int kAccWavesPerSimd = ICET_ACC_WAVES; // register budget: 6 -> 84 VGPRs, no spills, three 512-thread blocks per CU (with 1536 blocks per 256-pair launch: 130 -> 121 us); 8 spills
 constexpr double kTwoPi = 6.283185307179586476925286766559;
 constexpr double kPi = 3.14159265358979323846;
 

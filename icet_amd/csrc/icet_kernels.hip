@@ -921,9 +921,11 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
     // computes leaves the memory pipe idle: measured 0.18 ms per launch without any prefetch and 0.146 with it; the
     // cache-resident floor (VALU-issue-bound, 16 distinct pairs) is 0.13.  More points per trip would amortise the LDS
     // flushes better but the second set of registers then spills (kAccPts 8: 128 VGPRs + scratch, 0.164 ms).
-    float XN[kAccPts / 4][4], YN[kAccPts / 4][4], ZN[kAccPts / 4][4];
-#pragma unroll
-    for (int g = 0; g < kAccPts / 4; g++) load4(begin + kAccPts * (int)threadIdx.x + 4 * g, XN[g], YN[g], ZN[g]);
+    // The pipeline runs over GROUPS of 4 points (one dwordx4 per coordinate): while a group is classified the next group of the
+    // same lane -- the next 4 of its kAccPts consecutive points, or the first 4 of its next trip -- is already in flight, so the
+    // prefetch costs 12 registers however many points a lane takes per trip.
+    float XN[4], YN[4], ZN[4];
+    load4(begin + kAccPts * (int)threadIdx.x, XN, YN, ZN);
     for (int t0 = begin + kAccPts * threadIdx.x; t0 < begin + cs; t0 += kAccPts * kAccBlock) {   // whole waves iterate together
       // Run state of this lane for the whole trip: the current run, and a stash holding one finished run (see phase C).
       int cur = -1; uint32_t nraw = 0, nin = 0;
@@ -946,22 +948,15 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
               }
           }
       };
-      // The lane's kAccPts CONSECUTIVE points are taken 4 at a time (one dwordx4 per coordinate).
-      float XA[kAccPts / 4][4], YA[kAccPts / 4][4], ZA[kAccPts / 4][4];
-#pragma unroll
-      for (int g = 0; g < kAccPts / 4; g++)
-#pragma unroll
-          for (int j = 0; j < 4; j++) { XA[g][j] = XN[g][j]; YA[g][j] = YN[g][j]; ZA[g][j] = ZN[g][j]; }
-      if (t0 + kAccPts * kAccBlock < begin + cs) {
-#pragma unroll
-          for (int g = 0; g < kAccPts / 4; g++) load4(t0 + kAccPts * kAccBlock + 4 * g, XN[g], YN[g], ZN[g]);
-      }
+      // The lane's kAccPts CONSECUTIVE points are taken 4 at a time.
 #pragma unroll
       for (int g = 0; g < kAccPts / 4; g++) {
         const int i0 = t0 + 4 * g;
         float X[4], Y[4], Z[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { X[j] = XA[g][j]; Y[j] = YA[g][j]; Z[j] = ZA[g][j]; }
+        for (int j = 0; j < 4; j++) { X[j] = XN[j]; Y[j] = YN[j]; Z[j] = ZN[j]; }
+        if (g + 1 < kAccPts / 4) load4(i0 + 4, XN, YN, ZN);
+        else if (t0 + kAccPts * kAccBlock < begin + cs) load4(t0 + kAccPts * kAccBlock, XN, YN, ZN);
         PointClass pc[4];
         float QX[4], QY[4], QZ[4], RR[4];
         int SM[4];

@@ -10,7 +10,7 @@ namespace icet {
 // bitwise reproducible run to run and identical between batched and single solves; 2^-30 m^2 resolution is far
 // below float32 rounding of the addends, and 2^33 m^2 of headroom covers 2^17 points with |d| up to 256 m.
 constexpr int kAccWords = 20;        // in HBM: AoS, 80 bytes per slot (8-byte aligned)
-constexpr int kAccLds   = 20;        // in LDS: SoA (u32 raw[nl], u32 in[nl], i64 sum[9][nl]) -> 80 bytes per slot
+constexpr int kAccLds   = 20;        // in LDS: the same 80-byte record per slot ([raw | in << 32], 9 x i64)
 constexpr float kFixScale = 1073741824.0f;            // 2^30
 constexpr double kFixInv = 1.0 / 1073741824.0;
 #ifndef ICET_RS_BUCKET_BITS

@@ -834,12 +834,23 @@ __device__ __forceinline__ unsigned long long to_fix(float v) {
     return ((unsigned long long)(uint32_t)(int)h << 32) | (unsigned long long)(uint32_t)lo;
 }
 
+// Two values at once: the three multiplies / the fma are packed-FP32 instructions (v_pk_mul_f32, v_pk_fma_f32).
+typedef float vfloat2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void to_fix2(float a, float b, unsigned long long& fa, unsigned long long& fb) {
+    const vfloat2 v = {a, b};
+    const vfloat2 x = v * kFixScale;
+    vfloat2 h = x * 2.3283064365386963e-10f;                        // 2^-32
+    h.x = floorf(h.x); h.y = floorf(h.y);
+    const vfloat2 lo = __builtin_elementwise_fma(h, (vfloat2){-4294967296.0f, -4294967296.0f}, x);
+    fa = ((unsigned long long)(uint32_t)(int)h.x << 32) | (unsigned long long)(uint32_t)lo.x;
+    fb = ((unsigned long long)(uint32_t)(int)h.y << 32) | (unsigned long long)(uint32_t)lo.y;
+}
+
 __device__ __noinline__ void spill_flush(uint32_t* A, uint32_t nraw, uint32_t nin, float S0, float S1, float S2, float S3, float S4,
                                          float S5, float S6, float S7, float S8) {
     unsigned long long* F = reinterpret_cast<unsigned long long*>(A + 2);
-    atomicAdd(&A[0], nraw);
+    atomicAdd(reinterpret_cast<unsigned long long*>(A), (unsigned long long)nraw | ((unsigned long long)nin << 32));   // A[0] raw, A[1] in: one 64-bit add
     if (nin) {
-        atomicAdd(&A[1], nin);
         atomicAdd(&F[0], to_fix(S0)); atomicAdd(&F[1], to_fix(S1)); atomicAdd(&F[2], to_fix(S2)); atomicAdd(&F[3], to_fix(S3)); atomicAdd(&F[4], to_fix(S4));
         atomicAdd(&F[5], to_fix(S5)); atomicAdd(&F[6], to_fix(S6)); atomicAdd(&F[7], to_fix(S7)); atomicAdd(&F[8], to_fix(S8));
     }
@@ -875,10 +886,10 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
 
     LutCell* lut_t = reinterpret_cast<LutCell*>(smem);                    // Mt + 1 cells (the spare one catches pa == 4)
     LutCell* lut_p = lut_t + (Mt + 1);                                    // Mp + 1 cells (w == 1)
-    unsigned long long* lsum = reinterpret_cast<unsigned long long*>(lut_p + (Mp + 1));   // 9 x lds_slots fixed-point sums (SoA)
-    uint32_t* lraw = reinterpret_cast<uint32_t*>(lsum + 9 * lds_slots);   // lds_slots
-    uint32_t* lin = lraw + lds_slots;                                     // lds_slots
-    float* hot = reinterpret_cast<float*>(lin + lds_slots);               // lds_slots x 5: inner, outer, mu1
+    // per slot 10 x u64, the layout of the HBM accumulator: [raw | in << 32], then the 9 fixed-point sums -- constant offsets
+    // inside a flush, one 64-bit add for the two counts
+    unsigned long long* lacc = reinterpret_cast<unsigned long long*>(lut_p + (Mp + 1));
+    float* hot = reinterpret_cast<float*>(lacc + 10 * lds_slots);         // lds_slots x 5: inner, outer, mu1
     int16_t* map = reinterpret_cast<int16_t*>(hot + lds_slots * 5);
     const int map_words = (V + 1) / 2;
     const int ns = n_slots[pair];
@@ -893,8 +904,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
         uint2* ll = reinterpret_cast<uint2*>(lut_t);
         for (int i = threadIdx.x; i < Mt + Mp + 2; i += kAccBlock) ll[i] = gl[i];
         for (int i = threadIdx.x; i < nl * 5; i += kAccBlock) { int s = i / 5, k = i - s * 5; hot[i] = reinterpret_cast<const float*>(hs + s)[4 + k]; }
-        for (int i = threadIdx.x; i < 9 * nl; i += kAccBlock) lsum[(i / nl) * lds_slots + (i % nl)] = 0ull;   // only the rows in use
-        for (int i = threadIdx.x; i < nl; i += kAccBlock) { lraw[i] = 0u; lin[i] = 0u; }
+        for (int i = threadIdx.x; i < 10 * nl; i += kAccBlock) lacc[i] = 0ull;   // only the rows in use
     }
     const float* xf = xf_all + pair * kXf;
     const float tx = xf[0], ty = xf[1], tz = xf[2];
@@ -935,13 +945,13 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
       auto flush = [&](int slot, uint32_t cr, uint32_t ci, float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {
           if (slot >= 0) {
               if (slot < nl) {
-                  atomicAdd(&lraw[slot], cr);
+                  unsigned long long* F = lacc + slot * 10;
+                  atomicAdd(&F[0], (unsigned long long)cr | ((unsigned long long)ci << 32));
                   if (ci) {
-                      atomicAdd(&lin[slot], ci);
-                      unsigned long long* F = lsum + slot;
-                      atomicAdd(&F[0], to_fix(a0)); atomicAdd(&F[lds_slots], to_fix(a1)); atomicAdd(&F[2 * lds_slots], to_fix(a2));
-                      atomicAdd(&F[3 * lds_slots], to_fix(a3)); atomicAdd(&F[4 * lds_slots], to_fix(a4)); atomicAdd(&F[5 * lds_slots], to_fix(a5));
-                      atomicAdd(&F[6 * lds_slots], to_fix(a6)); atomicAdd(&F[7 * lds_slots], to_fix(a7)); atomicAdd(&F[8 * lds_slots], to_fix(a8));
+                      unsigned long long f0, f1, f2, f3, f4, f5, f6, f7;
+                      to_fix2(a0, a1, f0, f1); to_fix2(a2, a3, f2, f3); to_fix2(a4, a5, f4, f5); to_fix2(a6, a7, f6, f7);
+                      atomicAdd(&F[1], f0); atomicAdd(&F[2], f1); atomicAdd(&F[3], f2); atomicAdd(&F[4], f3); atomicAdd(&F[5], f4);
+                      atomicAdd(&F[6], f5); atomicAdd(&F[7], f6); atomicAdd(&F[8], f7); atomicAdd(&F[9], to_fix(a8));
                   }
               } else {
                   spill_flush(gacc + (size_t)slot * kAccWords, cr, ci, a0, a1, a2, a3, a4, a5, a6, a7, a8);
@@ -1047,16 +1057,14 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
     }
     __syncthreads();
     for (int s = threadIdx.x; s < nl; s += kAccBlock) {
-        const uint32_t raw = lraw[s];
-        if (raw == 0u) continue;
-        uint32_t* G = gacc + (size_t)s * kAccWords;
-        atomicAdd(&G[0], raw);
-        const uint32_t cin = lin[s];
-        if (cin) {
-            atomicAdd(&G[1], cin);
-            unsigned long long* GF = reinterpret_cast<unsigned long long*>(G + 2);
+        const unsigned long long* L = lacc + s * 10;
+        const unsigned long long cnt = L[0];
+        if ((uint32_t)cnt == 0u) continue;                                  // no point of this chunk reached the voxel
+        unsigned long long* G = reinterpret_cast<unsigned long long*>(gacc + (size_t)s * kAccWords);
+        atomicAdd(&G[0], cnt);
+        if ((uint32_t)(cnt >> 32)) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) atomicAdd(&GF[k], lsum[k * lds_slots + s]);
+            for (int k = 1; k < 10; k++) atomicAdd(&G[k], L[k]);
         }
     }
 }

@@ -294,10 +294,11 @@ def main():
         ref = po.solve_batch(h1, h2, runlen=iters, bins_phi=P, bins_theta=T, n_threads=cores)
         tc = time.perf_counter() - tc
         sec1, _ = po.time_pair(h1[0], h2[0], reps=3, runlen=iters, bins_phi=P, bins_theta=T)
+        sec4, _ = po.time_pair(h1[0], h2[0], reps=3, runlen=iters, bins_phi=P, bins_theta=T, mode=po.POOL4)   # parallelFitCells2 structure, 4 workers (src/icet.cpp:31,346-370)
         dXp = np.abs(ref["X"] - res[:m, :6].cpu().numpy())
         cpu = {"value": round(m / tc, 3), "unit": "scan-pairs/s", "cores": cores, "kind": "port",
                "sample": "first %d pairs of the same batch, one pair per host thread (oracle/icet_oracle.cpp, -O3 -march=native), %.1f s wall" % (m, tc),
-               "single_thread_ms_per_pair": round(sec1 * 1e3, 2),
+               "single_thread_ms_per_pair": round(sec1 * 1e3, 2), "threadpool4_ms_per_pair": round(sec4 * 1e3, 2),
                # informational cross-check, not the parity test: with the oracle's NATURAL eigenvector signs.  The reference's result
                # depends on those implementation-defined signs; tests/test_gpu_parity.py asserts 3e-4 m / 1e-4 rad
                # on every pair once the signs are aligned.

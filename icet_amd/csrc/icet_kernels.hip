@@ -200,8 +200,8 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
         for (int k = 0; k < kWalk; k++) {
             const int v = base + k * kBlock;
             const bool valid = v < hi_;
-            moved[k] = valid && ((int)s[o + (valid ? v : lo_)] != v);
-            act[k] = moved[k]; u[k] = v; len[k] = 0;
+            moved[k] = false;                                    // a fixed point of the permutation: pred[v] == v (known after the first load)
+            act[k] = valid; u[k] = v; len[k] = 0;
         }
         bool any = true;
         while (any) {
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
 #pragma unroll
             for (int k = 0; k < kWalk; k++) {
                 if (act[k]) {
+                    if (len[k] == 0) moved[k] = (p[k] != u[k]);   // first step reads pred[v] itself: no separate pass over s[]
                     if (p[k] >= u[k]) act[k] = false;
                     else { u[k] = p[k]; len[k]++; if (len[k] > max_walk) { atomicOr(&flags[pair], 1); act[k] = false; } }
                 }

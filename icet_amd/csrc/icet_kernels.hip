@@ -250,13 +250,13 @@ __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const P
     __syncthreads();
     for (int base = lo_ + threadIdx.x; base < hi_; base += kWalk * kBlock) {
         int f[kWalk], u[kWalk], len[kWalk]; bool act[kWalk];
-        int sv[kWalk], pv[kWalk]; uint16_t wv[kWalk], fb[kWalk];    // fb: packed word of the row f[] (its voxel id is what the histogram needs)
+        int pv[kWalk]; uint16_t wv[kWalk], fb[kWalk];    // fb: packed word of the row f[] (its voxel id is what the histogram needs)
 #pragma unroll
         for (int k = 0; k < kWalk; k++) {
             const int v = base + k * kBlock;
             const bool valid = v < hi_;
             const size_t i = o + (valid ? v : lo_);
-            sv[k] = (int)s[i]; pv[k] = pred[i]; wv[k] = bin16[i];
+            pv[k] = pred[i]; wv[k] = bin16[i];
         }
         uint16_t wp[kWalk];
 #pragma unroll
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const P
         for (int k = 0; k < kWalk; k++) {
             const int v = base + k * kBlock;
             const bool valid = v < hi_;
-            const bool moved = valid && sv[k] != v;
+            const bool moved = valid && pv[k] != v;             // s[v] != v  <=>  pred[v] != v (fixed points of a permutation)
             f[k] = moved ? pv[k] : v; fb[k] = moved ? wp[k] : wv[k];
             act[k] = moved && (wv[k] & kExecBit) && !(wp[k] & kExecBit);   // head of a run of executed steps
             u[k] = v; len[k] = 0;

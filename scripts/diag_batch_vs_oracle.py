@@ -27,4 +27,11 @@ print("natural signs : pairs with dt > 3e-4: %d, dr > 1e-4: %d of %d; max dt %.2
 print("aligned signs : pairs with dt > 3e-4: %d, dr > 1e-4: %d of %d; max dt %.2e max dr %.2e" % ((da[:, :3].max(1) > 3e-4).sum(), (da[:, 3:].max(1) > 1e-4).sum(), N, da[:, :3].max(), da[:, 3:].max()))
 print("eigenvector columns flipped: %d of %d (%.3f %%), in %d pairs" % (flips.sum(), 3 * fits.sum(), 100.0 * flips.sum() / (3 * fits.sum()), (flips > 0).sum()))
 for k in np.argsort(-da[:, :3].max(1))[:5]:
-    print("  pair %3d aligned dt %.2e dr %.2e (natural dt %.2e) flips %d" % (k, da[k, :3].max(), da[k, 3:].max(), dn[k, :3].max(), flips[k]))
+    # the oracle's own answer under a 1-ulp perturbation of scan 2 (same sign alignment): how much of the difference is the pair's sensitivity
+    rng = np.random.default_rng(123); sens = np.zeros(6)
+    base = res[k][1]
+    for _ in range(3):
+        bp = (h2[k].astype(np.float64) * (1.0 + rng.uniform(-1e-7, 1e-7, h2[k].shape))).astype(np.float32)
+        sens = np.maximum(sens, np.abs(po.solve(h1[k], bp, sign_ref=gpu[k]["aux"]["evecs1"])["X"] - base))
+    print("  pair %3d aligned dt %.2e dr %.2e (natural dt %.2e) flips %d | oracle 1-ulp sensitivity dt %.2e dr %.2e" % (
+        k, da[k, :3].max(), da[k, 3:].max(), dn[k, :3].max(), flips[k], sens[:3].max(), sens[3:].max()))

@@ -121,3 +121,17 @@ def test_reference_sample_data_loads_to_the_committed_fixture():
     for name, key in (("frame_804.npy", "scan1"), ("frame_805.npy", "scan2")):
         got = api.load_scan("/root/reference/src/sample_data/" + name)
         assert np.array_equal(got.view(np.uint32), d[key].view(np.uint32))
+
+
+def test_loaders_survive_garbage_under_sanitizers(tmp_path):
+    """4000 random / half-valid files through every loader, compiled with AddressSanitizer + UBSan (host code only)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "io_fuzz")
+    r = subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "tests", "cpp", "io_fuzz.cpp"), os.path.join(root, "icet_amd", "csrc", "icet_io.cpp"), "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stderr[-2000:]

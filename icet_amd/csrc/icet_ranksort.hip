@@ -265,9 +265,12 @@ __device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int kCap, const
 __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bucket_start,
                                                                const int32_t* __restrict__ n_buckets, uint32_t* __restrict__ bkey, uint32_t* __restrict__ bidx,
                                                                uint32_t* __restrict__ altkey, uint32_t* __restrict__ altidx,
-                                                               uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out, int kCap) {
+                                                               uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out, int kCap, int n_pairs) {
     extern __shared__ uint32_t smem[];
-    const int pair = blockIdx.y, bucket = blockIdx.x;
+    // all buckets of a pair on one XCD (decode_block): their scattered 4-byte writes of pred[] then complete whole cache lines in
+    // ONE L2 instead of leaving partial lines in eight
+    int pair, bucket;
+    if (!decode_block(n_pairs, kMaxBuckets, pair, bucket)) return;
     if (bucket >= n_buckets[pair]) return;
     const int lo = bucket_start[(size_t)pair * (kMaxBuckets + 1) + bucket];
     const int n = bucket_start[(size_t)pair * (kMaxBuckets + 1) + bucket + 1] - lo;
@@ -317,8 +320,8 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
         attr_set = true;
     }
     const int cap = rank_sort_cap(c.max_n1);
-    k_rs_bucket_sort<<<dim3(kMaxBuckets, np), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, w.keyA, w.valA, w.keyB,
-                                                                                        reinterpret_cast<uint32_t*>(w.key64A), w.valB, w.pred, cap);
+    k_rs_bucket_sort<<<dim3(groups * kMaxBuckets), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, w.keyA, w.valA, w.keyB,
+                                                                                             reinterpret_cast<uint32_t*>(w.key64A), w.valB, w.pred, cap, np);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

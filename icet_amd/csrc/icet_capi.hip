@@ -240,6 +240,7 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     LaunchCfg cfg{};
     cfg.T = p->bins_theta; cfg.P = p->bins_phi; cfg.V = cfg.T * cfg.P; cfg.n = p->n; cfg.runlen = p->runlen;
     cfg.thresh = p->thresh; cfg.buff = p->buff; cfg.n_pairs = n_pairs;
+    cfg.true_sort = (p->flags & ICET_FLAG_TRUE_SORT) ? 1 : 0;
     if (const char* e = getenv("ICET_LDS_SLOTS")) cfg.lds_slots = atoi(e);
     if (const char* e = getenv("ICET_ACC_PTS")) cfg.acc_min_pts_per_thread = atoi(e);
     if (const char* e = getenv("ICET_ACC_BLOCKS")) cfg.acc_target_blocks = atoi(e);

@@ -113,6 +113,7 @@ struct LaunchCfg {
     int stage_at = 0;
     int use_library_sort = 0;         // diagnostic: rocPRIM device radix sort instead of the hand-written rank sort
     int vec4_ok = 0;                  // every scan-2 pointer and leading dimension is 16-byte aligned
+    int true_sort = 0;                // ICET_FLAG_TRUE_SORT (non-parity extension): src[] = the sorted order itself
     int force_exact = 0;              // diagnostic: route every point through the literal evaluation
 };
 

@@ -336,11 +336,11 @@ __global__ void k_scramble_serial(const PairDesc* __restrict__ desc, const uint3
 //                  and the row's spherical coordinates are written straight to their final place.
 __global__ __launch_bounds__(kBlock) void k_bin_hist(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const uint16_t* __restrict__ bin16,
                                                      uint16_t* __restrict__ binpos, uint32_t* __restrict__ counts, const int32_t* __restrict__ flags,
-                                                     int V, int n_pairs, int chunks) {
+                                                     int V, int n_pairs, int chunks, int force) {
     extern __shared__ uint32_t lh[];
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;
-    if (!(flags[pair] & 1)) return;          // k_scramble_src already produced binpos / counts; redo only after the serial replay
+    if (!force && !(flags[pair] & 1)) return;   // k_scramble_src already produced binpos / counts; redo only after the serial replay (or when it did not run)
     const PairDesc d = desc[pair];
     int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
     const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
@@ -1286,6 +1286,12 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     }
     if (c.stage_event && c.stage_at == 1) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     e = hipMemsetAsync(w.flags, 0, sizeof(int32_t) * c.n_pairs, st); if (e != hipSuccess) return e;
+    if (c.true_sort) {
+        // non-parity extension: the rows stay in sorted order (what the reference's comment says the loop is meant to do)
+        e = hipMemcpyAsync(w.src, w.valB, sizeof(int32_t) * (size_t)c.total_n1, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return e;
+        k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, w.flags, c.V, np, chunks, 1);
+        ICET_LAUNCH_CHECK();
+    } else {
     const int max_walk = 4096;
     k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.bin16, w.flags, max_walk, np, chunks);
     ICET_LAUNCH_CHECK();
@@ -1294,8 +1300,9 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     k_scramble_serial<<<c.n_pairs, 64, 0, st>>>(w.desc, w.valB, w.pred /* reused as scratch */, w.src, w.flags);
     ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 2) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
-    k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, w.flags, c.V, np, chunks);
+    k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, w.flags, c.V, np, chunks, 0);
     ICET_LAUNCH_CHECK();
+    }
     e = launch_class_scan(w.counts, w.tile_base, w.bin_start, c.V, chunks, c.n_pairs, st);
     if (e != hipSuccess) return e;
     k_bin_scatter<<<grid, blk, (size_t)c.V * 16, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks);

@@ -43,7 +43,12 @@ typedef struct icet_params {
 } icet_params;
 
 enum { ICET_FLAG_NONE = 0,
-       ICET_FLAG_TIMING = 1   /* record HIP events around every bin/accumulate launch (icet_last_timing[2]) */ };
+       ICET_FLAG_TIMING = 1,  /* record HIP events around every bin/accumulate launch (icet_last_timing[2]) */
+       ICET_FLAG_TRUE_SORT = 2 /* NON-PARITY EXTENSION: really sort scan 1 by range before clustering, instead of reproducing
+                                  the reference's one-step swap loop (src/icet.cpp:78-83), which leaves the rows scrambled so
+                                  that findCluster sees most bins in a shuffled order and only ~1/4 of the populated bins get a
+                                  Gaussian.  Results then differ from the reference by design (more voxels, better conditioned);
+                                  the oracle has the same switch so that the extension is still checked against a CPU twin. */ };
 
 /* A scan that already lives in device memory (HBM) on the context's device. */
 typedef struct icet_dev_scan {

@@ -177,11 +177,17 @@ static inline bool insideBounds(float r, float azim, float elev, const float* li
 }
 
 // In-place "sort" by r with the reference's one-step swap loop (icet.cpp:72-83, 264-274; quirk Q3).
-static void sortAndScramble(Sph& s) {
+static void sortAndScramble(Sph& s, bool true_sort = false) {
     const int N = (int)s.r.size();
     std::vector<int> index(N);
     std::iota(index.begin(), index.end(), 0);
     std::stable_sort(index.begin(), index.end(), [&](int a, int b) { return s.r[a] < s.r[b]; });
+    if (true_sort) {                      // NON-PARITY EXTENSION (ICET_ORACLE_TRUE_SORT): apply the permutation properly
+        Sph t; t.resize(N);
+        for (int i = 0; i < N; i++) { t.r[i] = s.r[index[i]]; t.th[i] = s.th[index[i]]; t.ph[i] = s.ph[index[i]]; }
+        s = t;
+        return;
+    }
     for (int i = 0; i < N; i++) {
         if (index[i] != i) {
             int j = index[i];
@@ -313,7 +319,7 @@ struct Solver {
         const int N = (int)p1x.size();
         sph1.resize(N);
         for (int i = 0; i < N; i++) c2s_one(p1x[i], p1y[i], p1z[i], sph1.r[i], sph1.th[i], sph1.ph[i]);
-        sortAndScramble(sph1);
+        sortAndScramble(sph1, (prm.mode & ICET_ORACLE_TRUE_SORT) != 0);
         binPoints(sph1, bin1_start, bin1_idx);
         for (int phi = 0; phi < P; phi++)
             for (int theta = 0; theta < T; theta++) {
@@ -327,7 +333,7 @@ struct Solver {
         const int N = (int)p2x.size();
         sph2.resize(N);
         for (int i = 0; i < N; i++) c2s_one(p2x[i], p2y[i], p2z[i], sph2.r[i], sph2.th[i], sph2.ph[i]);
-        sortAndScramble(sph2);
+        sortAndScramble(sph2, (prm.mode & ICET_ORACLE_TRUE_SORT) != 0);
         ogx.resize(N); ogy.resize(N); ogz.resize(N);
         for (int i = 0; i < N; i++) s2c_one(sph2.r[i], sph2.th[i], sph2.ph[i], ogx[i], ogy[i], ogz[i]);
     }
@@ -451,7 +457,7 @@ struct Solver {
         sph2.resize(N);
         for (int i = 0; i < N; i++) c2s_one(p2x[i], p2y[i], p2z[i], sph2.r[i], sph2.th[i], sph2.ph[i]);
         binPoints(sph2, bin2_start, bin2_idx);
-        if (prm.mode == ICET_ORACLE_POOL4) {
+        if ((prm.mode & ICET_ORACLE_POOL4)) {
             voxelLoopPool();
         } else {
             for (int phi = 0; phi < P; phi++)
@@ -488,7 +494,7 @@ struct Solver {
         for (int k = 0; k < 6; k++) { X[k] = x0[k]; pred_stds[k] = 0.f; dx[k] = 0.f; }
         clusterBounds.assign((size_t)V * 6, 0.f);
         fit.assign(V, VoxelFit());
-        if (prm.mode == ICET_ORACLE_POOL4) pool.reset(new Pool(4));               // icet.cpp:31
+        if ((prm.mode & ICET_ORACLE_POOL4)) pool.reset(new Pool(4));               // icet.cpp:31
         fitScan1();
         prepScan2();
         for (int iter = 0; iter < prm.runlen; iter++) fitScan2();

@@ -9,7 +9,8 @@ extern "C" {
 #endif
 
 enum { ICET_ORACLE_SERIAL = 0,   /* live path: serial voxel loop, src/icet.cpp:391-404            */
-       ICET_ORACLE_POOL4  = 1 }; /* parallelFitCells2 structure, 4 workers, src/icet.cpp:346-370,31 */
+       ICET_ORACLE_POOL4  = 1,   /* parallelFitCells2 structure, 4 workers, src/icet.cpp:346-370,31 */
+       ICET_ORACLE_TRUE_SORT = 2 }; /* OR-ed in: non-parity extension, rows really sorted by range (twin of ICET_FLAG_TRUE_SORT) */
 
 typedef struct icet_oracle_params {
     int32_t runlen;      /* include/icet.h:38  */

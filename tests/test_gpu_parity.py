@@ -454,3 +454,22 @@ def test_rarely_taken_paths_give_the_same_bits(gpu_ctx, frames, sample_pc):
             del os.environ[key]
         assert np.array_equal(r1["X"], base1["X"]) and np.array_equal(r1["aux"]["n2_in"], base1["aux"]["n2_in"]), (key, val)
         assert np.array_equal(r2["X"], base2["X"]), (key, val)
+
+
+def test_true_sort_extension_matches_its_oracle_twin(gpu_ctx, frames, sample_pc):
+    """ICET_FLAG_TRUE_SORT is a labelled NON-PARITY extension (rows really sorted by range before clustering).  It is still held to
+    a CPU twin: the oracle with ICET_ORACLE_TRUE_SORT -- keyframe decisions bit-exact, final X within the usual tolerance."""
+    from oracle import pyoracle as po
+    from icet_amd import api
+    for a, b in (frames, sample_pc):
+        g = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True, flags=api.FLAG_TRUE_SORT)
+        o = po.solve(a, b, trace=True, mode=po.TRUE_SORT)
+        n = a.shape[0]
+        r = po.c2s(a)[:, 0]
+        assert np.array_equal(gpu_ctx.debug_fetch("src", n), np.argsort(r, kind="stable"))      # src = the stable sorted order itself
+        assert np.array_equal(g["aux"]["n1_raw"], o["trace"]["n1_raw"]) and np.array_equal(g["aux"]["cluster_bounds"], o["trace"]["bounds"])
+        assert np.array_equal(g["aux"]["has_fit"], o["trace"]["has_fit"])
+        ref = po.solve(a, b, mode=po.TRUE_SORT, sign_ref=g["aux"]["evecs1"])
+        _check_solution(dict(X=g["X"], pred_stds=g["pred_stds"], cov=g["cov"]), ref, 5e-4, 1.5e-4)
+        plain = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
+        assert g["aux"]["has_fit"].sum() > 2 * plain["aux"]["has_fit"].sum()                   # and it is a different answer by design

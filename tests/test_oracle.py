@@ -276,3 +276,18 @@ def test_result_depends_on_eigenvector_signs(frames):
     assert r1["n_sign_flips"] == fits
     assert not np.array_equal(r1["trace"]["Ldiag"], base["trace"]["Ldiag"]) or not np.array_equal(r1["X"], base["X"])
     assert np.abs(r1["X"] - base["X"]).max() > 1e-5               # a different answer from the same data: sign-dependent
+
+
+def test_true_sort_extension_is_a_labelled_deviation(frames):
+    """ICET_ORACLE_TRUE_SORT (twin of ICET_FLAG_TRUE_SORT, a NON-PARITY extension): with the rows really sorted by range, far more
+    populated bins yield a cluster (SURVEY Q4 estimated 336 instead of 86 on frame_804) and the answer differs from the reference's."""
+    from oracle import pyoracle as po
+    a, b = frames
+    ref = po.solve(a, b, trace=True)
+    ext = po.solve(a, b, trace=True, mode=po.TRUE_SORT)
+    nr, ne = int(ref["trace"]["has_fit"].sum()), int(ext["trace"]["has_fit"].sum())
+    assert nr == 86 and ne > 3 * nr, (nr, ne)
+    assert np.array_equal(ref["trace"]["n1_raw"], ext["trace"]["n1_raw"])          # the same points in the same bins, another order inside
+    assert np.isfinite(ext["X"]).all() and np.abs(ext["X"] - ref["X"]).max() > 1e-4
+    pool = po.solve(a, b, mode=po.TRUE_SORT | po.POOL4)
+    assert np.array_equal(pool["X"], ext["X"])

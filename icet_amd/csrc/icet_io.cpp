@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -59,6 +60,8 @@ bool field(const char* b, const char* e, char delim, int k, const char*& fb, con
 }
 
 icet_status alloc_out(int64_t n, float** out) {
+    *out = nullptr;
+    if (n < 0 || (uint64_t)n > SIZE_MAX / (3 * sizeof(float))) return ICET_ERR_NOMEM;      // 12 * n must not wrap
     *out = static_cast<float*>(std::malloc(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1)));
     return *out ? ICET_OK : ICET_ERR_NOMEM;
 }
@@ -149,9 +152,12 @@ icet_status load_npy(const std::vector<char>& buf, float** out, int64_t* n) {
     const bool fortran = order.compare(0, 4, "True") == 0;
     long long d0 = -1, d1 = -1;
     if (std::sscanf(shape.c_str(), "(%lld, %lld", &d0, &d1) != 2 || d0 < 0 || d1 != 3) return ICET_ERR_UNSUPPORTED;
+    // The shape comes from the file: bound it by DIVISION against the payload actually present before any multiply
+    // (a header claiming 2^62 rows would otherwise wrap 12 * N to 0 and pass a product-based check).
+    const uint64_t avail = (uint64_t)(buf.size() - hoff - hlen);
+    if ((uint64_t)d0 > avail / (3u * (uint64_t)width)) return ICET_ERR_UNSUPPORTED;
     const int64_t N = d0;
     const char* data = buf.data() + hoff + hlen;
-    if ((size_t)(buf.size() - hoff - hlen) < (size_t)N * 3 * width) return ICET_ERR_UNSUPPORTED;
     icet_status s = alloc_out(N, out); if (s != ICET_OK) return s;
     for (int64_t r = 0; r < N; r++)
         for (int c = 0; c < 3; c++) {
@@ -177,13 +183,24 @@ icet_status icet_load_scan(const char* path, int32_t format, float** out, int64_
         format = ends_with(p, ".npy") ? ICET_FMT_NPY : ends_with(p, ".bin") ? ICET_FMT_KITTI_BIN : ends_with(p, ".csv") ? ICET_FMT_OUSTER_CSV : ICET_FMT_XYZ_TSV;
     }
     if (format < ICET_FMT_NPY || format > ICET_FMT_KITTI_BIN) return ICET_ERR_BAD_ARG;
-    std::vector<char> buf;
-    if (!read_file(path, buf)) return ICET_ERR_BAD_ARG;
-    switch (format) {
-        case ICET_FMT_NPY: return load_npy(buf, out, n);
-        case ICET_FMT_OUSTER_CSV: return load_ouster(buf, out, n);
-        case ICET_FMT_XYZ_TSV: return load_tsv(buf, out, n);
-        default: return load_kitti(buf, out, n);
+    // std::vector / std::string allocations below may throw: nothing may unwind across the C ABI
+    try {
+        std::vector<char> buf;
+        if (!read_file(path, buf)) return ICET_ERR_BAD_ARG;
+        switch (format) {
+            case ICET_FMT_NPY: return load_npy(buf, out, n);
+            case ICET_FMT_OUSTER_CSV: return load_ouster(buf, out, n);
+            case ICET_FMT_XYZ_TSV: return load_tsv(buf, out, n);
+            default: return load_kitti(buf, out, n);
+        }
+    } catch (const std::bad_alloc&) {
+        if (*out) { std::free(*out); *out = nullptr; }
+        *n = 0;
+        return ICET_ERR_NOMEM;
+    } catch (...) {
+        if (*out) { std::free(*out); *out = nullptr; }
+        *n = 0;
+        return ICET_ERR_UNSUPPORTED;
     }
 }
 
@@ -191,6 +208,8 @@ void icet_free_scan(float* scan) { std::free(scan); }
 
 icet_status icet_save_scan_npy(const char* path, const float* scan, int64_t n, int64_t ld) {
     if (!path || n < 0 || ld < n || (n > 0 && !scan)) return ICET_ERR_BAD_ARG;
+    if ((uint64_t)n > SIZE_MAX / (3 * sizeof(float))) return ICET_ERR_NOMEM;
+    try {
     FILE* f = std::fopen(path, "wb");
     if (!f) return ICET_ERR_BAD_ARG;
     char dict[128];
@@ -205,6 +224,7 @@ icet_status icet_save_scan_npy(const char* path, const float* scan, int64_t n, i
     if (n) ok = ok && std::fwrite(row.data(), sizeof(float), 3 * (size_t)n, f) == 3 * (size_t)n;
     ok = (std::fclose(f) == 0) && ok;
     return ok ? ICET_OK : ICET_ERR_BAD_ARG;
+    } catch (const std::bad_alloc&) { return ICET_ERR_NOMEM; }
 }
 
 }  // extern "C"

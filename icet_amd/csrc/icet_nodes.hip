@@ -322,9 +322,12 @@ icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t l
     std::memcpy(X, nd->h_out, sizeof(X)); std::memcpy(res->pred_stds, nd->h_out + 6, sizeof(float) * 6);
     // seed for the next frame (odometry.cpp:82 / simpleMapMaker.cpp:124), then the guard (simpleMapMaker.cpp:129-137)
     for (int k = 0; k < 6; k++) nd->X0[k] = nd->p.seed_x0 ? X[k] : 0.f;
-    if (nd->p.trans_thresh > 0.f || nd->p.rot_thresh > 0.f) {
-        if (std::fabs(X[0]) > nd->p.trans_thresh || std::fabs(X[1]) > nd->p.trans_thresh || std::fabs(X[2]) > nd->p.trans_thresh ||
-            std::fabs(X[3]) > nd->p.rot_thresh || std::fabs(X[4]) > nd->p.rot_thresh || std::fabs(X[5]) > nd->p.rot_thresh) {
+    {
+        // each group is guarded only when ITS threshold is set (0 = off, include/icet_nodes.h): a caller who sets one of the two
+        // must not have the other group compared against 0
+        const float tt = nd->p.trans_thresh, rt = nd->p.rot_thresh;
+        if ((tt > 0.f && (std::fabs(X[0]) > tt || std::fabs(X[1]) > tt || std::fabs(X[2]) > tt)) ||
+            (rt > 0.f && (std::fabs(X[3]) > rt || std::fabs(X[4]) > rt || std::fabs(X[5]) > rt))) {
             for (int k = 0; k < 6; k++) X[k] = 0.f;
             res->diverged = 1;
         }

@@ -32,6 +32,22 @@
 //     such a voxel contributes nothing and is counted in Trace::n_ub_voxels.
 //   * float expression contraction: built with -ffp-contract=off so results do not depend on the
 //     host's FMA support (the reference's -O3 -march=native build is free to fuse).
+//   * THE SHARED ARITHMETIC RULE (round 2).  Two things in the reference are not pinned by its source: which libm its
+//     float atan2/acos/sin/cos come from (glibc's are accurate to an ulp, not correctly rounded, and change between
+//     versions), and the order in which Eigen adds up the rows for mean / covariance (vectorised, unspecified).  Both
+//     reach the per-voxel covariance in its last bits, and the reference's result depends on those bits through the
+//     SIGNS of the scan-1 eigenvectors (Q8/Q9).  So that device and oracle can be compared WITHOUT aligning signs,
+//     both follow one rule, stated mathematically rather than by shared code:
+//       - every transcendental is the correctly rounded float of the exact value: evaluated in double, rounded once
+//         (here glibc's double functions; on the device ocml's double atan2/acos and an algebraic double evaluation of
+//         sin/cos -- independent implementations that agree unless a double result lies within ~1e-16 of a float
+//         rounding boundary, probability ~1e-8 per call);
+//       - the per-voxel sums (mean, centred products) are exact: accumulated in double from float addends, rounded to
+//         float once, then divided in float -- the value every summation order approximates;
+//       - hypot in the QR step is Eigen 3.3's own formula p * sqrt(1 + (q/p)^2) (numext::hypot), not libm's.
+//     mode | ICET_ORACLE_LIBMF switches all three back to the literal expression types of the reference source (glibc float
+//     functions, sequential float sums, std::hypot): tests use it to show that the choice moves X by less than the
+//     algorithm's own 1-ulp sensitivity.
 // PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path
 // (SURVEY.md section 4), and neither its C++ (needs Eigen) nor its Python (needs TensorFlow)
 // can run in this image.
@@ -53,19 +69,52 @@
 namespace ico {
 
 // ---------------------------------------------------------------- utils.cpp:93-152
-static inline void c2s_one(float x, float y, float z, float& r, float& th, float& ph) {
+static inline float atan2_cr(float y, float x) { return (float)std::atan2((double)y, (double)x); }
+static inline float acos_cr(float q) { return (float)std::acos((double)q); }
+static inline float sin_cr(float a) { return (float)std::sin((double)a); }
+static inline float cos_cr(float a) { return (float)std::cos((double)a); }
+
+static inline void c2s_one(float x, float y, float z, float& r, float& th, float& ph, bool libmf = false) {
     r = std::sqrt(x * x + y * y + z * z);               // rowwise().norm()
-    th = std::atan2(y, x);                              // float overload
+    th = libmf ? std::atan2(y, x) : atan2_cr(y, x);     // float overload in the reference (src/utils.cpp:103)
     if (th < 0.0) th = (float)((double)th + 2.0 * M_PI);
-    ph = std::acos(z / r);
+    ph = libmf ? std::acos(z / r) : acos_cr(z / r);
     if (std::isnan(r)) r = 1000.0f;                     // (isNaN).select(1000.0, .)
     if (std::isnan(th)) th = 1000.0f;
     if (std::isnan(ph)) ph = 1000.0f;
 }
-static inline void s2c_one(float r, float th, float ph, float& x, float& y, float& z) {
-    x = r * std::sin(ph) * std::cos(th);
-    y = r * std::sin(ph) * std::sin(th);
-    z = r * std::cos(ph);
+static inline void s2c_one(float r, float th, float ph, float& x, float& y, float& z, bool libmf = false) {
+    const float sp = libmf ? std::sin(ph) : sin_cr(ph), cp = libmf ? std::cos(ph) : cos_cr(ph);
+    const float st = libmf ? std::sin(th) : sin_cr(th), ct = libmf ? std::cos(th) : cos_cr(th);
+    x = r * sp * ct;                                    // src/utils.cpp:134-136, left to right in float
+    y = r * sp * st;
+    z = r * cp;
+}
+// mean and covariance of m Cartesian rows (src/icet.cpp:160-162, 304-306): unbiased two-pass form.  Shared rule: exact sums
+// (double accumulators over float addends), rounded once; libmf: sequential float sums.
+static inline void mean_cov(const std::vector<float>& cx, const std::vector<float>& cy, const std::vector<float>& cz, bool libmf, float mean[3], Mat& cov) {
+    const long rows = (long)cx.size();
+    cov = Mat(3, 3);
+    if (libmf) {
+        mean[0] = mean[1] = mean[2] = 0.f;
+        for (long k = 0; k < rows; k++) { mean[0] += cx[k]; mean[1] += cy[k]; mean[2] += cz[k]; }
+        for (int a = 0; a < 3; a++) mean[a] /= (float)rows;
+        for (long k = 0; k < rows; k++) {
+            float d[3] = {cx[k] - mean[0], cy[k] - mean[1], cz[k] - mean[2]};
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) cov(a, b) += d[a] * d[b];
+        }
+        for (int a = 0; a < 9; a++) cov.a[a] = cov.a[a] / static_cast<float>(rows - 1);
+        return;
+    }
+    double s[3] = {0.0, 0.0, 0.0};
+    for (long k = 0; k < rows; k++) { s[0] += (double)cx[k]; s[1] += (double)cy[k]; s[2] += (double)cz[k]; }
+    for (int a = 0; a < 3; a++) mean[a] = (float)s[a] / (float)rows;
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (long k = 0; k < rows; k++) {
+        const float d[3] = {cx[k] - mean[0], cy[k] - mean[1], cz[k] - mean[2]};
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) c[3 * a + b] += (double)(d[a] * d[b]);     // float product, exact sum
+    }
+    for (int a = 0; a < 9; a++) cov.a[a] = (float)c[a] / static_cast<float>(rows - 1);
 }
 static Mat eulerR(float phi, float theta, float psi) {
     using std::cos; using std::sin;
@@ -233,6 +282,7 @@ struct Solver {
         for (int i = 0; i < N; i++) idx[cur[b[i]]++] = i;
     }
 
+    bool libmf = false;                // ICET_ORACLE_LIBMF: float libm + sequential float sums instead of the shared rule
     const float* sign_ref = nullptr;   // optional V x 9 eigenvectors (columns, row-major) to align signs with; see fitCells1
     int n_sign_flips = 0;
 
@@ -257,25 +307,18 @@ struct Solver {
             for (int k = 0; k < cnt; k++) {
                 int i = indices[k];
                 if (insideBounds(sph1.r[i], sph1.th[i], sph1.ph[i], lims)) {
-                    float x, y, z; s2c_one(sph1.r[i], sph1.th[i], sph1.ph[i], x, y, z);
+                    float x, y, z; s2c_one(sph1.r[i], sph1.th[i], sph1.ph[i], x, y, z, libmf);
                     cx.push_back(x); cy.push_back(y); cz.push_back(z);
                 }
             }
             long rows = (long)cx.size();
             if (outerDistance > 0.1 && rows * 3 >= n) {
                 VoxelFit& f = fit[v];
-                float mean[3] = {0, 0, 0};
-                for (long k = 0; k < rows; k++) { mean[0] += cx[k]; mean[1] += cy[k]; mean[2] += cz[k]; }
-                for (int a = 0; a < 3; a++) mean[a] /= (float)rows;
-                Mat cov(3, 3);
-                for (long k = 0; k < rows; k++) {
-                    float d[3] = {cx[k] - mean[0], cy[k] - mean[1], cz[k] - mean[2]};
-                    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) cov(a, b) += d[a] * d[b];
-                }
-                for (int a = 0; a < 9; a++) cov.a[a] = cov.a[a] / static_cast<float>(rows - 1);
+                float mean[3]; Mat cov;
+                mean_cov(cx, cy, cz, libmf, mean, cov);
                 f.has_fit = true; f.sigma = cov; for (int a = 0; a < 3; a++) f.mu[a] = mean[a];
                 float ev[3]; Mat evec(3, 3);
-                selfadjoint_eigen(cov, /*fixed3=*/true, ev, evec);
+                selfadjoint_eigen(cov, /*fixed3=*/true, ev, evec, libmf);
                 // Eigenvector signs are implementation-defined, and the reference's result DEPENDS on them: through the
                 // rows-of-V sigma points (Q9) and through L*U^T with U = V^T, which applies V and is therefore not
                 // invariant under column sign flips (Q8).  On near-degenerate voxels the QR iteration's signs flip with
@@ -302,7 +345,7 @@ struct Solver {
                 }
                 bool inside[6] = {false, false, false, false, false, false};
                 for (int j = 0; j < 6; j++) {       // icet.cpp:669-686 incl. the early break
-                    float r, az, el; c2s_one(sp[j][0], sp[j][1], sp[j][2], r, az, el);
+                    float r, az, el; c2s_one(sp[j][0], sp[j][1], sp[j][2], r, az, el, libmf);
                     if (insideBounds(r, az, el, lims)) inside[j] = true;
                     if (r > lims[5]) break;
                 }
@@ -318,7 +361,7 @@ struct Solver {
     void fitScan1() {
         const int N = (int)p1x.size();
         sph1.resize(N);
-        for (int i = 0; i < N; i++) c2s_one(p1x[i], p1y[i], p1z[i], sph1.r[i], sph1.th[i], sph1.ph[i]);
+        for (int i = 0; i < N; i++) c2s_one(p1x[i], p1y[i], p1z[i], sph1.r[i], sph1.th[i], sph1.ph[i], libmf);
         sortAndScramble(sph1, (prm.mode & ICET_ORACLE_TRUE_SORT) != 0);
         binPoints(sph1, bin1_start, bin1_idx);
         for (int phi = 0; phi < P; phi++)
@@ -332,10 +375,10 @@ struct Solver {
     void prepScan2() {
         const int N = (int)p2x.size();
         sph2.resize(N);
-        for (int i = 0; i < N; i++) c2s_one(p2x[i], p2y[i], p2z[i], sph2.r[i], sph2.th[i], sph2.ph[i]);
+        for (int i = 0; i < N; i++) c2s_one(p2x[i], p2y[i], p2z[i], sph2.r[i], sph2.th[i], sph2.ph[i], libmf);
         sortAndScramble(sph2, (prm.mode & ICET_ORACLE_TRUE_SORT) != 0);
         ogx.resize(N); ogy.resize(N); ogz.resize(N);
-        for (int i = 0; i < N; i++) s2c_one(sph2.r[i], sph2.th[i], sph2.ph[i], ogx[i], ogy[i], ogz[i]);
+        for (int i = 0; i < N; i++) s2c_one(sph2.r[i], sph2.th[i], sph2.ph[i], ogx[i], ogy[i], ogz[i], libmf);
     }
 
     // icet.cpp:279-344
@@ -351,7 +394,7 @@ struct Solver {
             for (size_t k = 0; k < n2; k++) {
                 int i = idx2[k];
                 if (insideBounds(sph2.r[i], sph2.th[i], sph2.ph[i], lims)) {
-                    float x, y, z; s2c_one(sph2.r[i], sph2.th[i], sph2.ph[i], x, y, z);
+                    float x, y, z; s2c_one(sph2.r[i], sph2.th[i], sph2.ph[i], x, y, z, libmf);
                     cx.push_back(x); cy.push_back(y); cz.push_back(z);
                 }
             }
@@ -360,15 +403,8 @@ struct Solver {
             if (rows > n) {                                  // filteredPoints2.size()/3 > n, icet.cpp:302
                 const VoxelFit& f = fit[v];
                 if (!f.has_fit) { out.used = false; out.n_in = -(int)rows - 1; return out; }   // reference UB, see header
-                float mean[3] = {0, 0, 0};
-                for (long k = 0; k < rows; k++) { mean[0] += cx[k]; mean[1] += cy[k]; mean[2] += cz[k]; }
-                for (int a = 0; a < 3; a++) mean[a] /= (float)rows;
-                Mat cov(3, 3);
-                for (long k = 0; k < rows; k++) {
-                    float d[3] = {cx[k] - mean[0], cy[k] - mean[1], cz[k] - mean[2]};
-                    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) cov(a, b) += d[a] * d[b];
-                }
-                for (int a = 0; a < 9; a++) cov.a[a] = cov.a[a] / static_cast<float>(rows - 1);
+                float mean[3]; Mat cov;
+                mean_cov(cx, cy, cz, libmf, mean, cov);
                 // R_noise = sigma1/(n1-1) + cov/(n2-1)            icet.cpp:315 (raw bin counts, Q10)
                 Mat Rn(3, 3);
                 const float d1 = (float)(n1 - 1), d2 = (float)(n2 - 1);
@@ -426,7 +462,7 @@ struct Solver {
     void checkCondition(const Mat& HTWH, Mat& L2, Mat& lam, Mat& U2) {
         const float cutoff = 1e6f;
         float ev[6];
-        selfadjoint_eigen(HTWH, /*fixed3=*/false, ev, U2);
+        selfadjoint_eigen(HTWH, /*fixed3=*/false, ev, U2, libmf);
         float condition = ev[5] / ev[0];
         int keep_from = 0;
         int eyecount = 1;
@@ -455,7 +491,7 @@ struct Solver {
         }
         HTWH_i = Mat(6, 6); HTWdz_i = Mat(6, 1);
         sph2.resize(N);
-        for (int i = 0; i < N; i++) c2s_one(p2x[i], p2y[i], p2z[i], sph2.r[i], sph2.th[i], sph2.ph[i]);
+        for (int i = 0; i < N; i++) c2s_one(p2x[i], p2y[i], p2z[i], sph2.r[i], sph2.th[i], sph2.ph[i], libmf);
         binPoints(sph2, bin2_start, bin2_idx);
         if ((prm.mode & ICET_ORACLE_POOL4)) {
             voxelLoopPool();
@@ -489,6 +525,7 @@ struct Solver {
     // icet.cpp:29-63
     int run(const float* s1, int64_t n1, int64_t ld1, const float* s2, int64_t n2, int64_t ld2, const float* x0) {
         T = prm.bins_theta; P = prm.bins_phi; V = T * P; n = prm.n;
+        libmf = (prm.mode & ICET_ORACLE_LIBMF) != 0;
         p1x.assign(s1, s1 + n1); p1y.assign(s1 + ld1, s1 + ld1 + n1); p1z.assign(s1 + 2 * ld1, s1 + 2 * ld1 + n1);
         p2x.assign(s2, s2 + n2); p2y.assign(s2 + ld2, s2 + ld2 + n2); p2z.assign(s2 + 2 * ld2, s2 + 2 * ld2 + n2);
         for (int k = 0; k < 6; k++) { X[k] = x0[k]; pred_stds[k] = 0.f; dx[k] = 0.f; }

@@ -10,7 +10,10 @@ extern "C" {
 
 enum { ICET_ORACLE_SERIAL = 0,   /* live path: serial voxel loop, src/icet.cpp:391-404            */
        ICET_ORACLE_POOL4  = 1,   /* parallelFitCells2 structure, 4 workers, src/icet.cpp:346-370,31 */
-       ICET_ORACLE_TRUE_SORT = 2 }; /* OR-ed in: non-parity extension, rows really sorted by range (twin of ICET_FLAG_TRUE_SORT) */
+       ICET_ORACLE_TRUE_SORT = 2,   /* OR-ed in: non-parity extension, rows really sorted by range (twin of ICET_FLAG_TRUE_SORT) */
+       ICET_ORACLE_LIBMF = 4 };     /* OR-ed in: glibc FLOAT atan2/acos/sin/cos, sequential float sums and std::hypot -- the literal
+                                       expression types of the reference source -- instead of the shared arithmetic rule (correctly
+                                       rounded transcendentals, exact sums, Eigen's hypot; icet_oracle.cpp header) */
 
 typedef struct icet_oracle_params {
     int32_t runlen;      /* include/icet.h:38  */

@@ -80,9 +80,19 @@ inline void make_givens(float p, float q, float& c, float& s) {
     }
 }
 
+// Eigen 3.3.7 numext::hypot (MathFunctions.h, hypot_impl): p * sqrt(1 + (q/p)^2) with p = max(|x|,|y|) -- plain IEEE
+// operations, so the device kernel can reproduce it bit for bit (libm's hypotf is not specified to the last bit).
+inline float eigen_hypot(float x, float y) {
+    float ax = std::fabs(x), ay = std::fabs(y);
+    float p, qp;
+    if (ax > ay) { p = ax; qp = ay / p; } else { p = ay; qp = ax / p; }
+    if (p == 0.f) return 0.f;
+    return p * std::sqrt(1.f + qp * qp);
+}
+
 // Eigen SelfAdjointEigenSolver.h tridiagonal_qr_step; Q is n x n row-major, rotation applied on the
-// right to columns k,k+1 (q.applyOnTheRight(k,k+1,rot)).
-inline void tridiagonal_qr_step(float* diag, float* subdiag, int start, int end, float* Q, int n) {
+// right to columns k,k+1 (q.applyOnTheRight(k,k+1,rot)).  libm_hypot: std::hypot instead of Eigen's formula.
+inline void tridiagonal_qr_step(float* diag, float* subdiag, int start, int end, float* Q, int n, bool libm_hypot = false) {
     float td = (diag[end - 1] - diag[end]) * 0.5f;
     float e = subdiag[end - 1];
     float mu = diag[end];
@@ -90,7 +100,7 @@ inline void tridiagonal_qr_step(float* diag, float* subdiag, int start, int end,
         mu -= std::fabs(e);
     } else if (e != 0.f) {
         const float e2 = e * e;
-        const float h = std::hypot(td, e);
+        const float h = libm_hypot ? std::hypot(td, e) : eigen_hypot(td, e);
         if (e2 == 0.f) mu -= e / ((td + (td > 0.f ? h : -h)) / e);
         else           mu -= e2 / (td + (td > 0.f ? h : -h));
     }
@@ -120,7 +130,7 @@ inline void tridiagonal_qr_step(float* diag, float* subdiag, int start, int end,
 // tridiagonalisation, Tridiagonalization.h tridiagonalization_inplace_selector<MatrixType,3,false>)
 // and for general n <= 6 (Householder tridiagonalisation).  Only the lower triangle of A is read.
 // Output: evals ascending, evecs columns (row-major n x n).  Returns false on no-convergence.
-inline bool selfadjoint_eigen(const Mat& Ain, bool fixed3, float* evals, Mat& evecs) {
+inline bool selfadjoint_eigen(const Mat& Ain, bool fixed3, float* evals, Mat& evecs, bool libm_hypot = false) {
     const int n = Ain.r;
     Mat A(n, n);
     float scale = 0.f;
@@ -204,7 +214,7 @@ inline bool selfadjoint_eigen(const Mat& Ain, bool fixed3, float* evals, Mat& ev
         if (iter > maxIterations * n) break;
         start = end - 1;
         while (start > 0 && sub[start - 1] != 0.f) start--;
-        tridiagonal_qr_step(diag, sub, start, end, Q.a, n);
+        tridiagonal_qr_step(diag, sub, start, end, Q.a, n, libm_hypot);
     }
     bool ok = iter <= maxIterations * n;
     if (ok) {

@@ -36,12 +36,15 @@ def main():
         np.savez_compressed(os.path.join(HERE, "scans_%s.npz" % name), scan1=a32, scan2=b32)
         o = po.solve(a32, b32, trace=True, runlen=7, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1)
         t = o["trace"]
+        # the same pair with the literal expression types of the reference source (glibc float functions, sequential float sums,
+        # std::hypot) instead of the shared arithmetic rule: how far the choice of rule moves the answer (oracle/icet_oracle.cpp header)
+        lm = po.solve(a32, b32, runlen=7, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1, mode=po.LIBMF)
         np.savez_compressed(os.path.join(HERE, "golden_%s.npz" % name), X=o["X"], pred_stds=o["pred_stds"], cov=o["cov"],
                             X_hist=t["X"], HTWH=t["HTWH"], HTWdz=t["HTWdz"], dx=t["dx"], eigvals=t["eigvals"], pruned=t["pruned"],
                             bounds=t["bounds"], n1_raw=t["n1_raw"], has_fit=t["has_fit"], mu1=t["mu1"], sigma1=t["sigma1"],
                             Ldiag=t["Ldiag"], evecs1=t["evecs1"], n2_raw=t["n2_raw"], n2_in=t["n2_in"], used=t["used"],
-                            n_ub_voxels=np.int32(o["n_ub_voxels"]))
-        print(name, "X =", o["X"], "fits =", int(t["has_fit"].sum()), "ub =", o["n_ub_voxels"])
+                            n_ub_voxels=np.int32(o["n_ub_voxels"]), X_libmf=lm["X"], pred_stds_libmf=lm["pred_stds"])
+        print(name, "X =", o["X"], "fits =", int(t["has_fit"].sum()), "ub =", o["n_ub_voxels"], "|X - X_libmf| =", np.abs(o["X"] - lm["X"]).max())
 
 
 if __name__ == "__main__":

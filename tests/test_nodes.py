@@ -76,6 +76,16 @@ def test_node_oracle_map_maker_settings_guard_and_reset():
     assert g["diverged"] and not g["X"].any() and np.array_equal(g["pose"], np.eye(4, dtype=np.float32))
     assert g["pred_stds"].any()                                       # pred_stds are published as they are
     nd.close(); tight.close()
+    # a threshold of 0 switches ITS group off (include/icet_nodes.h): with only the rotation threshold set -- generously -- the
+    # translation components must not be compared against 0 (every frame used to be flagged)
+    rot_only = po.Node(runlen=3, min_range=0.2, seed_x0=0, trans_thresh=0.0, rot_thresh=0.3)
+    rot_only.push(seq[0])
+    g = rot_only.push(seq[1])
+    assert not g["diverged"] and np.array_equal(g["X"], r1["X"])
+    trans_only = po.Node(runlen=3, min_range=0.2, seed_x0=0, trans_thresh=1e-4, rot_thresh=0.0)
+    trans_only.push(seq[0])
+    assert trans_only.push(seq[1])["diverged"]
+    rot_only.close(); trans_only.close()
 
 
 def test_node_oracle_map_queue_matches_numpy_ring():
@@ -158,6 +168,13 @@ def test_gpu_map_maker_node_matches_oracle(gpu_ctx, seq64):
         assert rg["diverged"] == ro["diverged"] and rg["map_rows"] == ro["map_rows"]
         assert np.array_equal(g.map(), o.map())
         assert np.array_equal(rg["pose"], ro["pose"])
+    g.close(); o.close()
+    # one threshold set, the other 0 (= off): only the set group is tested
+    kw.update(trans_thresh=0.0, rot_thresh=0.3, map_capacity=5000)
+    g, o = api.Node(gpu_ctx, **kw), po.Node(**kw)
+    for s in seq64[:3]:
+        rg, ro = g.push(s), o.push(s)
+        assert rg["diverged"] == ro["diverged"] == 0
     g.close(); o.close()
 
 

@@ -22,7 +22,7 @@ FLAG_TRUE_SORT = 2      # non-parity extension, see include/icet_hip.h
 
 # every symbol include/icet_hip.h, include/icet_nodes.h and include/icet_io.h declare
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_batch",
-                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch",
+                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_set_option",
                     "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_map",
                     "icet_node_prev_scan", "icet_node_aligned", "icet_node_snail_trail", "icet_node_last_timing", "icet_stream", "icet_device",
                     "icet_load_scan", "icet_free_scan", "icet_save_scan_npy")
@@ -90,6 +90,7 @@ def load_library():
     L.icet_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.POINTER(DevScan), C.c_void_p, C.c_void_p]
     L.icet_last_timing.argtypes = [C.c_void_p, C.c_void_p]
     L.icet_debug_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    L.icet_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.icet_node_create.argtypes = [C.c_void_p, C.POINTER(NodeParams), C.POINTER(C.c_void_p)]
     L.icet_node_destroy.argtypes = [C.c_void_p]
     L.icet_node_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(NodeResult)]
@@ -159,11 +160,16 @@ class Context:
         self._check(load_library().icet_reserve(self._h, C.byref(params), n_pairs, total_n1, total_n2))
 
     def debug_fetch(self, what, count):
-        """Diagnostic: 'r' / 'theta' / 'phi' (float32, scan 1 in input order), 'src' (int32 scramble result), 'flags'."""
-        code = {"r": 0, "theta": 1, "phi": 2, "src": 3, "flags": 4}[what]
-        out = np.zeros(count, np.float32 if code < 3 else np.int32)
+        """Diagnostic: 'r' (float32, scan 1 in input order), 'bin' (uint16 per row: voxel id | literal-path flag << 14 |
+        swap-step flag << 15), 'src' (int32 scramble result), 'flags' (int32 per pair)."""
+        code = {"r": 0, "bin": 1, "src": 3, "flags": 4}[what]
+        out = np.zeros(count, {0: np.float32, 1: np.uint16}.get(code, np.int32))
         self._check(load_library().icet_debug_fetch(self._h, code, out.ctypes.data, count))
         return out
+
+    def set_option(self, name, value):
+        """Launch-shape / diagnostic knob of this context (icet_set_option, include/icet_hip.h); results are bitwise unaffected."""
+        self._check(load_library().icet_set_option(self._h, name.encode(), float(value)))
 
     def last_timing(self):
         t = np.zeros(4, np.float32)

@@ -1,0 +1,384 @@
+// icet_amd/csrc/icet_accumulate.hip -- the point pass of one Gauss-Newton iteration: the hot kernel of the path.
+//
+// ICET::fitScan2 (/root/reference/src/icet.cpp:372-436) up to the per-voxel sums: transform (:375-378), cartesianToSpherical
+// (:387), sortSphericalCoordinates (:388), filterPointsInsideCluster (:299) and the sums behind mean / covariance (:303-306),
+// 12 bytes of HBM traffic per scan-2 point per iteration and nothing N-sized written back.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "icet_internal.h"
+#include "icet_device_common.h"
+
+namespace icet {
+namespace {
+
+#ifndef ICET_ACC_BLOCK
+#define ICET_ACC_BLOCK 512
+#endif
+#ifndef ICET_ACC_WAVES
+#define ICET_ACC_WAVES 6
+#endif
+#ifndef ICET_ACC_PTS
+#define ICET_ACC_PTS 4
+#endif
+constexpr int kAccPts = ICET_ACC_PTS;                      // consecutive points per lane per trip (two dwordx4 loads per coordinate)
+constexpr int kAccBlock = ICET_ACC_BLOCK;        // k_gn_accumulate: the waves of a block share one copy of the pair's LDS tables
+constexpr int kAccWavesPerSimd = ICET_ACC_WAVES; // register budget: 6 -> 84 VGPRs, no spills, three 512-thread blocks per CU (with 1536 blocks per 256-pair launch: 130 -> 121 us); 8 spills
+constexpr int kXf = 48;                          // per-pair transform record, see write_xf (icet_solve.hip)
+
+// sortSphericalCoordinates' bin index WITHOUT the double divide: thr[k] is the smallest float whose
+// reference bin (double arithmetic, src/icet.cpp:545-546) is >= k, built on the host with exactly that
+// arithmetic, so "largest k with thr[k] <= a" is bit-for-bit the reference's truncation.  The float
+// product only proposes a candidate (off by at most one).  Returns nb when a lies beyond the last
+// edge (a == float(2 pi), float(pi) or the 1000 sentinel): the caller then takes the literal formula.
+__device__ __forceinline__ int bin_from_table(float a, const float* __restrict__ thr, int nb, float scale) {
+    int k = static_cast<int>(a * scale);
+    k = min(k, nb - 1);
+    const float lo = thr[k], hi = thr[k + 1];
+    k += (a >= hi) ? 1 : 0;
+    k -= (a < lo) ? 1 : 0;
+    return k;
+}
+
+// One pass of fitScan2's point work over a chunk of one pair's scan 2.
+//   points2 = (points2_OG.rowwise() + t) * R          src/icet.cpp:375-378
+//   cartesianToSpherical, sortSphericalCoordinates     src/icet.cpp:387-388
+//   filterPointsInsideCluster                          src/icet.cpp:299
+// and the sums that give mean / covariance of the surviving points (src/icet.cpp:303-306), taken
+// about the voxel's scan-1 mean so that one pass in float keeps its digits.
+//
+// The literal evaluation costs ~250 VALU instructions per point (atan2f, acosf, a divide, an exact
+// sqrt) for 12 bytes of traffic.  Every one of its DECISIONS, though, is a comparison of an angle
+// or a range against a voxel edge, so the kernel classifies each point on two monotone stand-ins
+// that need no transcendental --
+//     polar bin   : w  = -z / |q|                      (monotone in phi   = acos(z/|q|))
+//     azimuth bin : pa = "diamond angle" of (x, y)     (monotone in theta = atan2(y, x))
+// -- through LDS look-up tables whose cells are narrower than half a bin: a cell names the one
+// edge a point in it can be near, one compare picks the side.  A point closer to an edge than a
+// guard band (a few float ulps, covering the rounding of both evaluations) is re-done with the
+// literal formulas (classify_exact), so the result is the literal evaluation's, decision for
+// decision.  Away from the edges the azimuth/polar bounds of filterPointsInsideCluster hold by
+// construction and only the radial test remains (same guard-band rule).
+//
+// Each lane takes 4 CONSECUTIVE points per trip (three 16-byte loads) and keeps a run-length
+// accumulator in registers: lidar storage order puts neighbours in the same voxel, so a lane
+// flushes to LDS about once per trip instead of once per point, and no cross-lane reduction is
+// needed.  LDS holds the pair's voxel->slot map, the two LUTs, the hot slot records and the block's
+// partial sums, which are flushed with one global atomic per touched word at the end.
+// Block -> (pair, chunk) is XCD-aware: all chunks of a pair have equal blockIdx % 8, i.e. share an
+// XCD and therefore its L2 copy of the pair's tables (speed only, never correctness).
+struct PointClass { int s; bool inb; float dx, dy, dz; };
+
+// Literal evaluation of one transformed point: c2s (shared rule: correctly rounded theta / phi), bin, slot look-up,
+// 6-sided bounds test.  Kept out of line: it is reached by ~0.02 % of the points, and its double-precision atan2 / acos must
+// not share a register budget with the hot loop.
+__device__ __noinline__ void classify_exact(float qx, float qy, float qz, const int16_t* map, const float* __restrict__ thr, int T, int P,
+                                            const SlotHot* __restrict__ hs, PointClass& out) {
+    float r, th, ph;
+    c2s_cr(qx, qy, qz, r, th, ph);
+    const float scale_t = (float)((double)T / kTwoPi), scale_p = (float)((double)P / kPi);
+    int bt = bin_from_table(th, thr, T, scale_t);
+    int bp = bin_from_table(ph, thr + T + 1, P, scale_p);
+    if (bt >= T) bt = static_cast<int>(((double)th / kTwoPi) * (double)T) % T;
+    if (bp >= P) bp = static_cast<int>(((double)ph / kPi) * (double)P) % P;
+    const int s = map[T * bp + bt];
+    out.s = s; out.inb = false; out.dx = out.dy = out.dz = 0.f;
+    if (s >= 0) {
+        const SlotHot h = hs[s];
+        out.inb = inside_bounds(r, th, ph, h.az0, h.az1, h.el0, h.el1, h.inner, h.outer);
+        out.dx = qx - h.mu[0]; out.dy = qy - h.mu[1]; out.dz = qz - h.mu[2];
+    }
+}
+
+// Partial sums of a slot that has no LDS row go straight to HBM.  Kept out of line so that the LDS update above
+// stays a ds_add_* (a select between the two pointers would turn both into flat atomics).
+// float -> 64-bit fixed point (floor(v * 2^30), two's complement) in 6 VALU instructions: the scaling is exact (power of
+// two), h = floor(x / 2^32) is a small integer held exactly in a float, and x - h * 2^32 is exact under fma and lies in
+// [0, 2^32).  Any fixed rounding rule would do; what matters is that integer addition is associative.
+__device__ __forceinline__ unsigned long long to_fix(float v) {
+    const float x = v * kFixScale;
+    const float h = floorf(x * 2.3283064365386963e-10f);            // 2^-32
+    const float lo = fmaf(h, -4294967296.0f, x);
+    return ((unsigned long long)(uint32_t)(int)h << 32) | (unsigned long long)(uint32_t)lo;
+}
+
+// Two values at once: the three multiplies / the fma are packed-FP32 instructions (v_pk_mul_f32, v_pk_fma_f32).
+typedef float vfloat2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void to_fix2(float a, float b, unsigned long long& fa, unsigned long long& fb) {
+    const vfloat2 v = {a, b};
+    const vfloat2 x = v * kFixScale;
+    vfloat2 h = x * 2.3283064365386963e-10f;                        // 2^-32
+    h.x = floorf(h.x); h.y = floorf(h.y);
+    const vfloat2 lo = __builtin_elementwise_fma(h, (vfloat2){-4294967296.0f, -4294967296.0f}, x);
+    fa = ((unsigned long long)(uint32_t)(int)h.x << 32) | (unsigned long long)(uint32_t)lo.x;
+    fb = ((unsigned long long)(uint32_t)(int)h.y << 32) | (unsigned long long)(uint32_t)lo.y;
+}
+
+__device__ __noinline__ void spill_flush(uint32_t* A, uint32_t nraw, uint32_t nin, float S0, float S1, float S2, float S3, float S4,
+                                         float S5, float S6, float S7, float S8) {
+    unsigned long long* F = reinterpret_cast<unsigned long long*>(A + 2);
+    atomicAdd(reinterpret_cast<unsigned long long*>(A), (unsigned long long)nraw | ((unsigned long long)nin << 32));   // A[0] raw, A[1] in: one 64-bit add
+    if (nin) {
+        atomicAdd(&F[0], to_fix(S0)); atomicAdd(&F[1], to_fix(S1)); atomicAdd(&F[2], to_fix(S2)); atomicAdd(&F[3], to_fix(S3)); atomicAdd(&F[4], to_fix(S4));
+        atomicAdd(&F[5], to_fix(S5)); atomicAdd(&F[6], to_fix(S6)); atomicAdd(&F[7], to_fix(S7)); atomicAdd(&F[8], to_fix(S8));
+    }
+}
+
+typedef __attribute__((address_space(1))) const float gfloat;
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const vfloat4 gfloat4;
+
+template <bool kVec4>
+__global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
+                                                          const int16_t* __restrict__ slot_of_voxel, const int32_t* __restrict__ n_slots,
+                                                          const SlotHot* __restrict__ hotS, uint32_t* __restrict__ acc,
+                                                          const float* __restrict__ thr, const LutCell* __restrict__ lut,
+                                                          int T, int P, int Mt, int Mp, float guard_t, float guard_p,
+                                                          int lds_slots, int chunks, int n_pairs, int force_exact) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int V = T * P;
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const PairDesc d = desc[pair];
+    int cs = (d.n2 + chunks - 1) / chunks;
+    cs = (cs + kAccPts * kAccBlock - 1) / (kAccPts * kAccBlock) * (kAccPts * kAccBlock);   // whole trips of kAccPts points per lane
+    const int begin = chunk * cs;
+    if (begin >= d.n2) return;
+    const int end = min(d.n2, begin + cs);
+
+    LutCell* lut_t = reinterpret_cast<LutCell*>(smem);                    // Mt + 1 cells (the spare one catches pa == 4)
+    LutCell* lut_p = lut_t + (Mt + 1);                                    // Mp + 1 cells (w == 1)
+    // per slot 10 x u64, the layout of the HBM accumulator: [raw | in << 32], then the 9 fixed-point sums -- constant offsets
+    // inside a flush, one 64-bit add for the two counts
+    unsigned long long* lacc = reinterpret_cast<unsigned long long*>(lut_p + (Mp + 1));
+    float* hot = reinterpret_cast<float*>(lacc + 10 * lds_slots);         // lds_slots x 5: inner, outer, mu1
+    int16_t* map = reinterpret_cast<int16_t*>(hot + lds_slots * 5);
+    const int map_words = (V + 1) / 2;
+    const int ns = n_slots[pair];
+    const int nl = min(ns, lds_slots);
+    const SlotHot* hs = hotS + (size_t)pair * V;
+    {
+        const uint32_t* gm = reinterpret_cast<const uint32_t*>(slot_of_voxel + (size_t)pair * ((V + 1) & ~1));   // rows padded to even length
+        uint32_t* lm = reinterpret_cast<uint32_t*>(map);
+        for (int i = threadIdx.x; i < map_words; i += kAccBlock) lm[i] = gm[i];
+        for (int i = 2 * map_words + threadIdx.x; i < V + T + 2; i += kAccBlock) map[i] = (int16_t)-1;   // bt == T or bp == P land here
+        const uint2* gl = reinterpret_cast<const uint2*>(lut);
+        uint2* ll = reinterpret_cast<uint2*>(lut_t);
+        for (int i = threadIdx.x; i < Mt + Mp + 2; i += kAccBlock) ll[i] = gl[i];
+        for (int i = threadIdx.x; i < nl * 5; i += kAccBlock) { int s = i / 5, k = i - s * 5; hot[i] = reinterpret_cast<const float*>(hs + s)[4 + k]; }
+        for (int i = threadIdx.x; i < 10 * nl; i += kAccBlock) lacc[i] = 0ull;   // only the rows in use
+    }
+    const float* xf = xf_all + pair * kXf;
+    const float tx = xf[0], ty = xf[1], tz = xf[2];
+    const float R00 = xf[3], R01 = xf[4], R02 = xf[5], R10 = xf[6], R11 = xf[7], R12 = xf[8], R20 = xf[9], R21 = xf[10], R22 = xf[11];
+    const float cell_t = (float)Mt * 0.25f, cell_p = (float)Mp * 0.5f;
+    __syncthreads();
+
+    gfloat* px = (gfloat*)d.s2; gfloat* py = px + d.ld2; gfloat* pz = px + 2 * (size_t)d.ld2;   // scans live in HBM: global_load, not flat
+    uint32_t* gacc = acc + (size_t)pair * V * kAccWords;
+
+    auto load4 = [&](int i0, float (&X)[4], float (&Y)[4], float (&Z)[4]) {
+        if (kVec4 && i0 + 3 < end) {
+            // read-once stream: non-temporal, so the scans do not evict the pair tables from L2
+            const vfloat4 a = __builtin_nontemporal_load((gfloat4*)(px + i0)), b = __builtin_nontemporal_load((gfloat4*)(py + i0)), c = __builtin_nontemporal_load((gfloat4*)(pz + i0));
+            X[0] = a.x; X[1] = a.y; X[2] = a.z; X[3] = a.w; Y[0] = b.x; Y[1] = b.y; Y[2] = b.z; Y[3] = b.w; Z[0] = c.x; Z[1] = c.y; Z[2] = c.z; Z[3] = c.w;
+        } else {
+#pragma unroll
+            // past the end: NaN coordinates fail every guard-band test below, so the point drops out in phase B without a per-point range check
+            for (int j = 0; j < 4; j++) { const bool ok = i0 + j < end; X[j] = ok ? px[i0 + j] : __builtin_nanf(""); Y[j] = ok ? py[i0 + j] : 0.f; Z[j] = ok ? pz[i0 + j] : 0.f; }
+        }
+    };
+    // Software pipeline across trips: the loads of trip t+1 are in flight while trip t is classified.  With the scans
+    // streaming from HBM (256 distinct pairs = 745 MB, well past the Infinity Cache) a wave that loads, waits and then
+    // computes leaves the memory pipe idle: measured 0.18 ms per launch without any prefetch and 0.146 with it; the
+    // cache-resident floor (VALU-issue-bound, 16 distinct pairs) is 0.13.  More points per trip would amortise the LDS
+    // flushes better but the second set of registers then spills (kAccPts 8: 128 VGPRs + scratch, 0.164 ms).
+    // The pipeline runs over GROUPS of 4 points (one dwordx4 per coordinate): while a group is classified the next group of the
+    // same lane -- the next 4 of its kAccPts consecutive points, or the first 4 of its next trip -- is already in flight, so the
+    // prefetch costs 12 registers however many points a lane takes per trip.
+    float XN[4], YN[4], ZN[4];
+    load4(begin + kAccPts * (int)threadIdx.x, XN, YN, ZN);
+    for (int t0 = begin + kAccPts * threadIdx.x; t0 < begin + cs; t0 += kAccPts * kAccBlock) {   // whole waves iterate together
+      // Run state of this lane for the whole trip: the current run, and a stash holding one finished run (see phase C).
+      int cur = -1; uint32_t nraw = 0, nin = 0;
+      float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f, S6 = 0.f, S7 = 0.f, S8 = 0.f;
+      int bs = -1; uint32_t braw = 0, bin = 0;
+      float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, B4 = 0.f, B5 = 0.f, B6 = 0.f, B7 = 0.f, B8 = 0.f;
+      auto flush = [&](int slot, uint32_t cr, uint32_t ci, float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {
+          if (slot >= 0) {
+              if (slot < nl) {
+                  unsigned long long* F = lacc + slot * 10;
+                  atomicAdd(&F[0], (unsigned long long)cr | ((unsigned long long)ci << 32));
+                  if (ci) {
+                      unsigned long long f0, f1, f2, f3, f4, f5, f6, f7;
+                      to_fix2(a0, a1, f0, f1); to_fix2(a2, a3, f2, f3); to_fix2(a4, a5, f4, f5); to_fix2(a6, a7, f6, f7);
+                      atomicAdd(&F[1], f0); atomicAdd(&F[2], f1); atomicAdd(&F[3], f2); atomicAdd(&F[4], f3); atomicAdd(&F[5], f4);
+                      atomicAdd(&F[6], f5); atomicAdd(&F[7], f6); atomicAdd(&F[8], f7); atomicAdd(&F[9], to_fix(a8));
+                  }
+              } else {
+                  spill_flush(gacc + (size_t)slot * kAccWords, cr, ci, a0, a1, a2, a3, a4, a5, a6, a7, a8);
+              }
+          }
+      };
+      // The lane's kAccPts CONSECUTIVE points are taken 4 at a time.
+#pragma unroll
+      for (int g = 0; g < kAccPts / 4; g++) {
+        const int i0 = t0 + 4 * g;
+        float X[4], Y[4], Z[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { X[j] = XN[j]; Y[j] = YN[j]; Z[j] = ZN[j]; }
+        if (g + 1 < kAccPts / 4) load4(i0 + 4, XN, YN, ZN);
+        else if (t0 + kAccPts * kAccBlock < begin + cs) load4(t0 + kAccPts * kAccBlock, XN, YN, ZN);
+        PointClass pc[4];
+        float QX[4], QY[4], QZ[4], RR[4];
+        int SM[4];
+        bool nr[4];
+        float R2[4];
+        // ---- phase A: angular classification of the 4 points.  Straight-line code (bitwise | and &, no clamps: the
+        // LUTs carry one spare cell and the map T+1 spare entries, so even a NaN or pa == 4 indexes inside LDS) so
+        // that the four look-up chains overlap. ----
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float a = X[j] + tx, b = Y[j] + ty, c = Z[j] + tz;
+            const float qx = a * R00 + b * R10 + c * R20;
+            const float qy = a * R01 + b * R11 + c * R21;
+            const float qz = a * R02 + b * R12 + c * R22;
+            QX[j] = qx; QY[j] = qy; QZ[j] = qz;
+            const float r2 = qx * qx + qy * qy + qz * qz;
+            const float rs = __builtin_amdgcn_rsqf(r2);
+            RR[j] = r2 * rs;                                             // |q|
+            const float w = -qz * rs;                                    // -cos(phi)
+            const float q1 = qy * __builtin_amdgcn_rcpf(fabsf(qx) + fabsf(qy));            // y / (|x| + |y|) in [-1, 1]
+            const float pa = (qx >= 0.f) ? ((qy >= 0.f) ? q1 : 4.f + q1) : 2.f - q1;      // diamond angle in [0, 4]
+            const LutCell et = lut_t[static_cast<int>(pa * cell_t)];     // NaN converts to 0; pa in [0,4] -> cell in [0, Mt]
+            const LutCell ep = lut_p[static_cast<int>((w + 1.f) * cell_p)];
+            const int bt = et.idx - ((pa < et.edge) ? 1 : 0);            // in [0, T]
+            const int row = ep.idx - ((w < ep.edge) ? T : 0);            // T * polar bin, polar bin in [0, P] (the table stores T * edge index)
+            SM[j] = map[row + bt];
+            nr[j] = (force_exact != 0) | !(fabsf(pa - et.edge) >= guard_t) | !(fabsf(w - ep.edge) >= guard_p);
+            R2[j] = r2;
+        }
+        // |q|^2 outside [1e-30, 1e30] over- or underflows the stand-in coordinates while the literal formulas stay well defined
+        // (absurd inputs, but the claim is "never decides differently"): one min / max over the lane's 4 points, literal path for all 4
+        {
+            const float lo = fminf(fminf(R2[0], R2[1]), fminf(R2[2], R2[3])), hi = fmaxf(fmaxf(R2[0], R2[1]), fmaxf(R2[2], R2[3]));
+            const bool odd = !(lo >= kR2Min) | !(hi <= kR2Max);
+            nr[0] |= odd; nr[1] |= odd; nr[2] |= odd; nr[3] |= odd;
+        }
+        // ---- phase A2: only waves that touch an active voxel look at the hot records (radial test, d = q - mu1) ----
+        const bool lane_has = ((SM[0] >= 0) & !nr[0]) | ((SM[1] >= 0) & !nr[1]) | ((SM[2] >= 0) & !nr[2]) | ((SM[3] >= 0) & !nr[3]);
+        if (__ballot(lane_has) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int sm = SM[j];
+                const bool has = (sm >= 0) & !nr[j];
+                // slots beyond the LDS table (more active voxels than lds_slots) are classified by the literal path,
+                // which reads its record from HBM: keeps every LDS access a ds_* instruction.
+                const float* h = hot + min(max(sm, 0), lds_slots - 1) * 5;
+                const float inner = h[0], outer = h[1];
+                const float r = RR[j];
+                const float gr = 1e-6f * r;
+                nr[j] = nr[j] | (has & ((sm >= nl) | !(fabsf(r - inner) >= gr) | !(fabsf(r - outer) >= gr)));
+                pc[j].s = nr[j] ? -1 : sm;
+                pc[j].inb = has & (r >= inner) & (r <= outer);
+                pc[j].dx = QX[j] - h[2]; pc[j].dy = QY[j] - h[3]; pc[j].dz = QZ[j] - h[4];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { pc[j].s = -1; pc[j].inb = false; pc[j].dx = pc[j].dy = pc[j].dz = 0.f; }
+        }
+        // ---- phase B (rare): points within a guard band of a voxel edge are re-done with the literal formulas ----
+        if (__ballot(nr[0] | nr[1] | nr[2] | nr[3]) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (nr[j] & (i0 + j < end)) classify_exact(QX[j], QY[j], QZ[j], map, thr, T, P, hs, pc[j]);
+        }
+        const bool any_slot = (pc[0].s >= 0) | (pc[1].s >= 0) | (pc[2].s >= 0) | (pc[3].s >= 0);
+        if (__ballot(any_slot | (cur >= 0)) == 0ull) continue;           // wave-uniform: nothing here lands in an active voxel and no run is open
+        // ---- phase C: run-length accumulation over the lane's consecutive points.  A finished run is parked in a
+        // register stash instead of being flushed at once, so a lane converts to fixed point and touches LDS about
+        // twice per trip of kAccPts points (a third run inside one trip, rare, flushes the stash early). ----
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int s = pc[j].s;
+            if (s != cur) {
+                if (cur >= 0) {
+                    // only a lane whose OWN stash is occupied (a third run inside its 4 points: rare) flushes here; a wave-wide
+                    // "any lane has a stash" test would run the flush at almost every j, for lanes that could have waited
+                    if (bs >= 0) flush(bs, braw, bin, B0, B1, B2, B3, B4, B5, B6, B7, B8);
+                    bs = cur; braw = nraw; bin = nin; B0 = S0; B1 = S1; B2 = S2; B3 = S3; B4 = S4; B5 = S5; B6 = S6; B7 = S7; B8 = S8;
+                }
+                cur = s; nraw = 0; nin = 0; S0 = S1 = S2 = S3 = S4 = S5 = S6 = S7 = S8 = 0.f;
+            }
+            if (s >= 0) {
+                nraw++;
+                if (pc[j].inb) {
+                    const float dx = pc[j].dx, dy = pc[j].dy, dz = pc[j].dz;
+                    nin++;
+                    S0 += dx; S1 += dy; S2 += dz;
+                    S3 += dx * dx; S4 += dx * dy; S5 += dx * dz; S6 += dy * dy; S7 += dy * dz; S8 += dz * dz;
+                }
+            }
+        }
+      }   // sub-groups of 4
+      if (__ballot((cur >= 0) | (bs >= 0)) != 0ull) {
+          flush(cur, nraw, nin, S0, S1, S2, S3, S4, S5, S6, S7, S8);
+          if (__ballot(bs >= 0) != 0ull) flush(bs, braw, bin, B0, B1, B2, B3, B4, B5, B6, B7, B8);
+      }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < nl; s += kAccBlock) {
+        const unsigned long long* L = lacc + s * 10;
+        const unsigned long long cnt = L[0];
+        if ((uint32_t)cnt == 0u) continue;                                  // no point of this chunk reached the voxel
+        unsigned long long* G = reinterpret_cast<unsigned long long*>(gacc + (size_t)s * kAccWords);
+        atomicAdd(&G[0], cnt);
+        if ((uint32_t)(cnt >> 32)) {
+#pragma unroll
+            for (int k = 1; k < 10; k++) atomicAdd(&G[k], L[k]);
+        }
+    }
+}
+
+inline int chunks_for(int n_pairs, int max_n, int per_block_min, int target_blocks) {
+    int by_work = (max_n + per_block_min - 1) / per_block_min;
+    int want = (target_blocks + n_pairs - 1) / n_pairs;
+    int c = want < by_work ? want : by_work;
+    return c < 1 ? 1 : c;
+}
+
+}  // namespace
+
+#define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t init_accumulate_kernels() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
+}
+
+hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
+    // LDS rows for active voxels: a throughput batch keeps 320 rows (measured optimum on 64-channel scans: fewer rows
+    // spill busy voxels to HBM atomics, more rows cost occupancy); a small batch has
+    // CUs to spare, so a block may take most of a CU's LDS and keep every active voxel of a fine grid (150 x 48: often
+    // > 1000) out of the slow HBM-atomic path.
+    const size_t fixed = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)((c.V + c.T + 4) / 2) * 4 + 16;
+    const size_t row = (5 + kAccLds) * 4;
+    const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : 144 * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU
+    int lds_slots = c.lds_slots > 0 ? c.lds_slots : (int)((budget > fixed ? budget - fixed : 0) / row);
+    lds_slots = lds_slots < 32 ? 32 : lds_slots;
+    if (lds_slots > c.V) lds_slots = c.V;
+    const int chunks = chunks_for(c.n_pairs, c.max_n2, kAccBlock * c.acc_min_pts_per_thread, c.acc_target_blocks);
+    const size_t lds = fixed + (size_t)lds_slots * (5 + kAccLds) * 4;
+    dim3 grid(grid_groups(c.n_pairs) * chunks), blk(kAccBlock);
+    const LutCell* lut = reinterpret_cast<const LutCell*>(w.lut);
+    if (c.vec4_ok)
+        k_gn_accumulate<true><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp,
+                                                     w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact);
+    else
+        k_gn_accumulate<false><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp,
+                                                      w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace icet

@@ -26,6 +26,8 @@ struct icet_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     Workspace w;
+    Tuning tune;                    // icet_set_option
+    int max_lds = 160 * 1024;       // hipDeviceAttributeMaxSharedMemoryPerBlock of the device
     std::string err;
     // host staging (pinned) for descriptors and results
     PairDesc* h_desc = nullptr; int32_t* h_seg = nullptr; int32_t h_cap_pairs = 0;
@@ -71,7 +73,8 @@ bool params_ok(const icet_params* p) {
 icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs, int64_t total_n1) {
     Workspace& w = c->w;
     const int V = p->bins_phi * p->bins_theta;
-    if ((int64_t)p->bins_phi * p->bins_theta > kMaxVoxels) { c->err = "bins_phi*bins_theta exceeds the compiled voxel limit"; return ICET_ERR_UNSUPPORTED; }
+    if ((int64_t)p->bins_phi * p->bins_theta > kMaxVoxels) { c->err = "bins_phi*bins_theta exceeds the voxel limit (10000: the multi-split keeps 16 B per voxel in one block's LDS)"; return ICET_ERR_UNSUPPORTED; }
+    if ((size_t)V * 16 + 4096 > (size_t)c->max_lds) { c->err = "grid too fine for this device's LDS (16 B per voxel per block)"; return ICET_ERR_UNSUPPORTED; }
     if (total_n1 >= (int64_t)1 << 31) { c->err = "total scan-1 points per call must be < 2^31"; return ICET_ERR_UNSUPPORTED; }
     const bool grow_pairs = n_pairs > w.cap_pairs || V > w.cap_V;
     if (grow_pairs) {
@@ -104,7 +107,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         const int64_t n = total_n1 > w.cap_n1 ? total_n1 : w.cap_n1;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (n > w.cap_n1) {
-            HIPCHK(c, dev_realloc(w.r1, n)); HIPCHK(c, dev_realloc(w.th1, n)); HIPCHK(c, dev_realloc(w.ph1, n));
+            HIPCHK(c, dev_realloc(w.r1, n)); HIPCHK(c, dev_realloc(w.cart1, (size_t)3 * n));
             HIPCHK(c, dev_realloc(w.key64A, n)); HIPCHK(c, dev_realloc(w.key64B, n)); HIPCHK(c, dev_realloc(w.bin16, n)); HIPCHK(c, dev_realloc(w.binpos, n)); HIPCHK(c, dev_realloc(w.bkt, n));
             HIPCHK(c, dev_realloc(w.keyA, n)); HIPCHK(c, dev_realloc(w.keyB, n)); HIPCHK(c, dev_realloc(w.valA, n)); HIPCHK(c, dev_realloc(w.valB, n));
             HIPCHK(c, dev_realloc(w.pred, n)); HIPCHK(c, dev_realloc(w.src, n));
@@ -177,11 +180,9 @@ icet_status ensure_thresholds(icet_ctx* c, int T, int P) {
         for (int k = 0; k <= P; k++) ep[k] = (k == 0) ? -1.0 : (k == P ? 1.0 : -std::cos(M_PI * k / P));
         // Guard bands: a few float ulps of the coordinate plus the ulp-level disagreement between the LUT's
         // true edges and the literal evaluation's float thresholds ("exact fast path").
-        w.guard_t = 5e-6f; w.guard_p = 2.5e-6f;
-        if (const char* e = getenv("ICET_GUARD_SCALE")) { w.guard_t *= (float)atof(e); w.guard_p *= (float)atof(e); }   // experiments only
+        w.guard_t = 5e-6f * (float)c->tune.guard_scale; w.guard_p = 2.5e-6f * (float)c->tune.guard_scale;       // scale: experiments / tests only
         std::vector<HostCell> lt, lp;
-        double qp = 0.25;
-        if (const char* e = getenv("ICET_LUT_POLAR_QUANTILE")) qp = atof(e);                                              // experiments only
+        const double qp = c->tune.lut_polar_quantile;
         const int Mt = build_lut(et, 0.0, 4.0, 0.0, w.guard_t, lt), Mp = build_lut(ep, -1.0, 2.0, qp, w.guard_p, lp);
         // one spare cell per table: pa == 4 / w == 1 index cell M (it names the last edge, so the point goes to the literal path)
         for (HostCell& c : lp) c.idx *= T;                                 // polar cells carry the map row offset T * edge index
@@ -241,12 +242,8 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     cfg.T = p->bins_theta; cfg.P = p->bins_phi; cfg.V = cfg.T * cfg.P; cfg.n = p->n; cfg.runlen = p->runlen;
     cfg.thresh = p->thresh; cfg.buff = p->buff; cfg.n_pairs = n_pairs;
     cfg.true_sort = (p->flags & ICET_FLAG_TRUE_SORT) ? 1 : 0;
-    if (const char* e = getenv("ICET_LDS_SLOTS")) cfg.lds_slots = atoi(e);
-    if (const char* e = getenv("ICET_ACC_PTS")) cfg.acc_min_pts_per_thread = atoi(e);
-    if (const char* e = getenv("ICET_ACC_BLOCKS")) cfg.acc_target_blocks = atoi(e);
-    if (const char* e = getenv("ICET_FORCE_EXACT")) cfg.force_exact = atoi(e);
-    if (const char* e = getenv("ICET_LIBRARY_SORT")) cfg.use_library_sort = atoi(e);
-    if (const char* e = getenv("ICET_KF_PTS")) cfg.kf_pts_per_thread = atoi(e);
+    cfg.lds_slots = c->tune.lds_slots; cfg.acc_min_pts_per_thread = c->tune.acc_pts; cfg.acc_target_blocks = c->tune.acc_blocks;
+    cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap;
     if (cfg.kf_pts_per_thread > kKfMaxPtsPerThread) cfg.kf_pts_per_thread = kKfMaxPtsPerThread;      // k_bin_scatter: a tile is at most 4 waves x that many rounds x 64 positions
     if (cfg.kf_pts_per_thread < 1) cfg.kf_pts_per_thread = 1;
     cfg.stage_event = c->stage_at ? c->ev_stage : nullptr; cfg.stage_at = c->stage_at;
@@ -324,6 +321,14 @@ icet_status icet_create(icet_ctx** out, int device_id, void* hip_stream) {
         c->own_stream = true;
     }
     if (hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess || hipEventCreate(&c->ev_c) != hipSuccess) { delete c; return ICET_ERR_HIP; }
+    // per context, with its device current: raise the dynamic-LDS limits of the kernels that need it (no process-global flags)
+    int lds = 0;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds > 0) c->max_lds = lds;
+    if (init_keyframe_kernels() != hipSuccess || init_accumulate_kernels() != hipSuccess || init_rank_sort_kernels() != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c; return ICET_ERR_HIP;       // no usable kernel image for this device: fail loudly, there is no fallback
+    }
     *out = c;
     return ICET_OK;
 }
@@ -333,7 +338,7 @@ icet_status icet_destroy(icet_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     Workspace& w = c->w;
-    void* ps[] = {w.key64A, w.key64B, w.bin16, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.th1, w.ph1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src,
+    void* ps[] = {w.key64A, w.key64B, w.bin16, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.cart1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src,
                   w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, w.xf, w.X, w.flags,
                   w.sort_tmp, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);
@@ -361,13 +366,13 @@ icet_status icet_sync(icet_ctx* c) {
     return ICET_OK;
 }
 
-static int batch_parts(const icet_params* p, int32_t n_pairs);
+static int batch_parts(const icet_ctx* c, const icet_params* p, int32_t n_pairs);
 static icet_status ensure_helpers(icet_ctx* c, int parts);
 
 icet_status icet_reserve(icet_ctx* c, const icet_params* p, int32_t n_pairs, int64_t total_n1, int64_t total_n2) {
     if (!c || !params_ok(p) || n_pairs < 0 || total_n1 < 0 || total_n2 < 0) return ICET_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    const int parts = batch_parts(p, n_pairs);
+    const int parts = batch_parts(c, p, n_pairs);
     if (parts > 1) {            // the batch will be solved in parts (icet_solve_batch_device); 12.5 % headroom for uneven scans
         icet_status hs = ensure_helpers(c, parts);
         if (hs != ICET_OK) return hs;
@@ -385,10 +390,10 @@ icet_status icet_reserve(icet_ctx* c, const icet_params* p, int32_t n_pairs, int
 
 // How many parts a device batch is cut into (see icet_ctx::helpers).  Timed calls stay in one part so that every
 // kernel is measured alone on the device.
-static int batch_parts(const icet_params* p, int32_t n_pairs) {
+static int batch_parts(const icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     if (p->flags & ICET_FLAG_TIMING) return 1;
     int parts = n_pairs >= 64 ? 2 : 1;      // measured at the end of round 1 on 256 pairs (30 steps): 1 part 84.7 k, 2 parts 89.2 k, 3 parts 88.0 k pairs/s
-    if (const char* e = getenv("ICET_BATCH_PARTS")) { parts = atoi(e); if (parts < 1) parts = 1; if (parts > 8) parts = 8; }
+    if (c->tune.batch_parts > 0) parts = c->tune.batch_parts > 8 ? 8 : c->tune.batch_parts;
     if (parts > n_pairs) parts = n_pairs > 0 ? n_pairs : 1;
     return parts;
 }
@@ -420,7 +425,7 @@ icet_status icet_solve_batch_device(icet_ctx* c, const icet_params* p, int32_t n
             a.ld >= ((int64_t)1 << 30) || b.ld >= ((int64_t)1 << 30)) { c->err = "bad scan descriptor"; return ICET_ERR_BAD_ARG; }
     }
     HIPCHK(c, hipSetDevice(c->device));
-    const int parts = (p->runlen == 0) ? 1 : batch_parts(p, n_pairs);
+    const int parts = (p->runlen == 0) ? 1 : batch_parts(c, p, n_pairs);
     auto range_tot = [&](int b, int e) { int64_t t = 0; for (int k = b; k < e; k++) t += scan1[k].n; return t; };
     if (parts == 1) return solve_device_part(c, p, n_pairs, scan1, scan2, d_x0, d_out, range_tot(0, n_pairs));
     { icet_status s = ensure_helpers(c, parts); if (s != ICET_OK) return s; }
@@ -429,23 +434,35 @@ icet_status icet_solve_batch_device(icet_ctx* c, const icet_params* p, int32_t n
     // Stagger: part i+1 starts once part i has finished the first keyframe stage, so the parts do not move through the
     // same phase in lock step (measured on 256 pairs with the kernels of that day: 1 part 70.6k pairs/s; 3 parts in lock
     // step 73.2k; staggered 76.8k).
-    int stage = 4;
-    if (const char* e = getenv("ICET_BATCH_STAGE")) stage = atoi(e);
-    for (int i = 0; i < parts; i++) {
+    const int stage = c->tune.batch_stage;
+    icet_status status = ICET_OK;
+    int started = 0;                        // helpers whose stream has work queued
+    for (int i = 0; i < parts && status == ICET_OK; i++) {
         const int b = (int)((int64_t)n_pairs * i / parts), e = (int)((int64_t)n_pairs * (i + 1) / parts);
         icet_ctx* h = (i == 0) ? c : c->helpers[i - 1];
-        if (stage && !h->ev_stage) HIPCHK(c, hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
+        if (h != c) { const bool relut = h->tune.guard_scale != c->tune.guard_scale || h->tune.lut_polar_quantile != c->tune.lut_polar_quantile; h->tune = c->tune; if (relut) h->w.thr_T = 0; }
+        hipError_t he = hipSuccess;
+        if (stage && !h->ev_stage) he = hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming);
         h->stage_at = (i + 1 < parts) ? stage : 0;
-        if (i > 0) {
-            HIPCHK(c, hipStreamWaitEvent(h->stream, c->ev_fork, 0));
-            if (stage) { icet_ctx* prev = (i == 1) ? c : c->helpers[i - 2]; HIPCHK(c, hipStreamWaitEvent(h->stream, prev->ev_stage, 0)); }
+        if (he == hipSuccess && i > 0) {
+            he = hipStreamWaitEvent(h->stream, c->ev_fork, 0);
+            if (he == hipSuccess && stage) { icet_ctx* prev = (i == 1) ? c : c->helpers[i - 2]; he = hipStreamWaitEvent(h->stream, prev->ev_stage, 0); }
         }
-        icet_status s = solve_device_part(h, p, e - b, scan1 + b, scan2 + b, d_x0 ? d_x0 + 6 * (size_t)b : nullptr, d_out + 48 * (size_t)b, range_tot(b, e));
-        if (s != ICET_OK) { if (h != c) c->err = h->err; return s; }
-        if (i > 0) HIPCHK(c, hipEventRecord(h->ev_join, h->stream));
+        if (he != hipSuccess) { c->err = std::string("batch part fork: ") + hipGetErrorString(he); status = ICET_ERR_HIP; break; }
+        if (i > 0) started = i;
+        status = solve_device_part(h, p, e - b, scan1 + b, scan2 + b, d_x0 ? d_x0 + 6 * (size_t)b : nullptr, d_out + 48 * (size_t)b, range_tot(b, e));
+        if (status != ICET_OK && h != c) c->err = h->err;
     }
-    for (int i = 1; i < parts; i++) HIPCHK(c, hipStreamWaitEvent(c->stream, c->helpers[i - 1]->ev_join, 0));   // join
-    return ICET_OK;
+    // join -- ALSO on failure: every helper that was started may still be reading the caller's scans / x0 and writing d_out, so
+    // the caller's stream must not pass this call (and the caller must not free those buffers) before they have drained
+    for (int i = 1; i <= started; i++) {
+        icet_ctx* h = c->helpers[i - 1];
+        if (hipEventRecord(h->ev_join, h->stream) != hipSuccess || hipStreamWaitEvent(c->stream, h->ev_join, 0) != hipSuccess) {
+            (void)hipStreamSynchronize(h->stream);          // last resort: block the host until the helper is idle
+            if (status == ICET_OK) { c->err = "batch part join failed"; status = ICET_ERR_HIP; }
+        }
+    }
+    return status;
 }
 
 static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1, const icet_dev_scan* scan2,
@@ -568,11 +585,10 @@ icet_status icet_solve(icet_ctx* c, const icet_params* p, const float* scan1, in
 icet_status icet_debug_fetch(icet_ctx* c, int32_t what, void* out, int64_t count) {
     if (!c || !out || count < 0) return ICET_ERR_BAD_ARG;
     const Workspace& w = c->w;
-    const void* src = nullptr; int64_t cap = w.cap_n1;
+    const void* src = nullptr; int64_t cap = w.cap_n1; size_t elem = 4;
     switch (what) {
         case 0: src = w.r1; break;
-        case 1: src = w.th1; break;
-        case 2: src = w.ph1; break;
+        case 1: src = w.bin16; elem = 2; break;
         case 3: src = w.src; break;
         case 4: src = w.flags; cap = w.cap_pairs; break;
         default: c->err = "unknown array id"; return ICET_ERR_BAD_ARG;
@@ -580,7 +596,27 @@ icet_status icet_debug_fetch(icet_ctx* c, int32_t what, void* out, int64_t count
     if (!src || count > cap) { c->err = "nothing to fetch / count too large"; return ICET_ERR_BAD_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, src, (size_t)count * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, src, (size_t)count * elem, hipMemcpyDeviceToHost));
+    return ICET_OK;
+}
+
+icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
+    if (!c || !name) return ICET_ERR_BAD_ARG;
+    Tuning& t = c->tune;
+    const std::string k(name);
+    const int iv = (int)value;
+    if (k == "lds_slots") t.lds_slots = iv < 0 ? 0 : iv;
+    else if (k == "acc_pts") t.acc_pts = iv < 1 ? 1 : iv;
+    else if (k == "acc_blocks") t.acc_blocks = iv < 1 ? 1 : iv;
+    else if (k == "force_exact") t.force_exact = iv != 0;
+    else if (k == "library_sort") t.library_sort = iv != 0;
+    else if (k == "kf_pts") t.kf_pts = iv < 1 ? 1 : (iv > kKfMaxPtsPerThread ? kKfMaxPtsPerThread : iv);
+    else if (k == "batch_parts") t.batch_parts = iv < 0 ? 0 : (iv > 8 ? 8 : iv);
+    else if (k == "batch_stage") t.batch_stage = (iv < 0 || iv > 4) ? 0 : iv;
+    else if (k == "rs_cap") t.rs_cap = iv < 0 ? 0 : iv;
+    else if (k == "guard_scale") { if (!(value >= 1.0 && value <= 1024.0)) { c->err = "guard_scale must lie in [1, 1024]"; return ICET_ERR_BAD_ARG; } t.guard_scale = value; c->w.thr_T = 0; }   // tables are rebuilt by the next call
+    else if (k == "lut_polar_quantile") { if (!(value >= 0.0 && value <= 1.0)) { c->err = "lut_polar_quantile must lie in [0, 1]"; return ICET_ERR_BAD_ARG; } t.lut_polar_quantile = value; c->w.thr_T = 0; }
+    else { c->err = "unknown option: " + k; return ICET_ERR_BAD_ARG; }
     return ICET_OK;
 }
 

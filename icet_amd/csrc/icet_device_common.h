@@ -1,0 +1,174 @@
+// icet_amd/csrc/icet_device_common.h -- device helpers shared by the keyframe, accumulate and solve translation units.
+//
+// THE SHARED ARITHMETIC RULE (the CPU checker used by the tests states the same rule independently).  The reference takes its
+// float atan2 / acos / sin / cos from whatever glibc it is built against (accurate to an ulp, not correctly rounded) and adds
+// up rows in Eigen's unspecified vectorised order.  Both reach the per-voxel covariance in its last bits, and the result
+// depends on those bits through the SIGNS of the scan-1 eigenvectors.  Device and oracle therefore follow one
+// rule that is a mathematical statement, not shared code:
+//   * every transcendental that feeds a stored value is the CORRECTLY ROUNDED float of the exact function value: evaluated
+//     in double, rounded once (theta_cr, phi_cr, roundtrip_cr below; glibc's double functions in the CPU checker);
+//   * per-voxel sums are exact (double accumulators over float addends), rounded once, then divided in float;
+//   * no contraction where the oracle has separate roundings (#pragma clang fp contract(off)).
+// Decisions (which voxel, inside the bounds or not) are comparisons; they are taken on cheap monotone stand-ins with guard
+// bands and fall back to these formulas near an edge, so they equal the literal decisions everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "icet_internal.h"
+
+namespace icet {
+
+constexpr int kBlock = 256;
+constexpr double kTwoPi = 6.283185307179586476925286766559;      // == 2.0 * M_PI as a double, the reference's constant (src/utils.cpp:105)
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kTwoPiTail = 2.4492935982947064e-16;             // (exact 2 pi) - kTwoPi
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// 1-D grid -> (pair, chunk).  With >= 8 pairs every chunk of a pair gets the same blockIdx % 8, i.e. (as the
+// dispatcher is observed to deal blocks round-robin over the 8 XCDs) the same XCD and the same 4 MiB L2, and
+// consecutive block ids walk through ONE group of 8 pairs before touching the next: the pointer-chasing keyframe
+// kernels (rank / scramble / gather, ~1 MB of randomly accessed tables per pair) then find their pair's tables in
+// L2 instead of HBM.  Speed only -- nothing depends on where a block actually lands.
+__device__ __forceinline__ bool decode_block(int n_pairs, int chunks, int& pair, int& chunk) {
+    if (n_pairs >= 8) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        pair = (j / chunks) * 8 + xcd; chunk = j % chunks;
+        return pair < n_pairs;
+    }
+    pair = blockIdx.x / chunks; chunk = blockIdx.x % chunks;
+    return true;
+}
+inline int grid_groups(int n_pairs) { return n_pairs >= 8 ? (n_pairs + 7) / 8 * 8 : n_pairs; }
+
+// r of utils::cartesianToSpherical (src/utils.cpp:99, rowwise().norm()) BEFORE the NaN -> 1000 replacement: no contraction,
+// correctly rounded sqrt, so its bits match a plain IEEE evaluation -- the radial sort + swap loop downstream is chaotic in
+// the order of r.
+__device__ __forceinline__ float radius_raw(float x, float y, float z) {
+    float r;
+    {
+#pragma clang fp contract(off)
+        float s = x * x + y * y;
+        s = s + z * z;
+        r = sqrtf(s);
+    }
+    return r;
+}
+
+// theta and phi of utils::cartesianToSpherical (src/utils.cpp:103-108,116) under the shared rule.
+__device__ __forceinline__ float theta_cr(float y, float x) {
+    float th = (float)atan2((double)y, (double)x);
+    if (th < 0.0f) th = (float)((double)th + kTwoPi);
+    return (th != th) ? 1000.0f : th;
+}
+__device__ __forceinline__ float phi_cr(float z, float r_raw) {
+    const float ph = (float)acos((double)(z / r_raw));
+    return (ph != ph) ? 1000.0f : ph;
+}
+__device__ __forceinline__ void c2s_cr(float x, float y, float z, float& r, float& th, float& ph) {
+    const float rr = radius_raw(x, y, z);
+    th = theta_cr(y, x); ph = phi_cr(z, rr);
+    r = (rr != rr) ? 1000.0f : rr;
+}
+
+// sortSphericalCoordinates' bin of one (theta, phi) pair: double arithmetic on float angles, truncation, modulo
+// (src/icet.cpp:545-546).
+__device__ __forceinline__ int voxel_of(float th, float ph, int T, int P) {
+    int bt = static_cast<int>(((double)th / kTwoPi) * (double)T) % T;
+    int bp = static_cast<int>(((double)ph / kPi) * (double)P) % P;
+    return T * bp + bt;
+}
+
+__device__ __forceinline__ bool inside_bounds(float r, float az, float el, float az0, float az1, float el0, float el1, float inner, float outer) {
+    return az >= az0 && az <= az1 && el >= el0 && el <= el1 && r >= inner && r <= outer;
+}
+
+// clusterBounds' angular limits of voxel (theta, phi): (float / int) -> float, times a double constant, stored to float
+// (src/icet.cpp:136-139).
+__device__ __forceinline__ void voxel_limits(int theta, int phi, int T, int P, float& az0, float& az1, float& el0, float& el1) {
+    az0 = (float)((double)((float)theta / (float)T) * kTwoPi);
+    az1 = (float)((double)((float)(theta + 1) / (float)T) * kTwoPi);
+    el0 = (float)((double)((float)phi / (float)P) * kPi);
+    el1 = (float)((double)((float)(phi + 1) / (float)P) * kPi);
+}
+
+// cartesianToSpherical followed by sphericalToCartesian (src/utils.cpp:93-142) for one finite point with r > 0, under the
+// shared rule: th = fl(atan2), ph = fl(acos(z / r)), out = (r sin ph cos th, r sin ph sin th, r cos ph) with the four
+// sines / cosines correctly rounded -- WITHOUT a double sin / cos.  With a_d the double angle and a_f its float rounding
+// (plus the wrap of theta), sin a_f = sin(a_d + d) = sin a_d (1 - d^2/2) + cos a_d d, and sin a_d, cos a_d are algebraic in
+// the Cartesian inputs (y / rho, x / rho; sqrt(1 - q^2), q).  |d| < 5e-7, so the dropped d^3 term is below 1e-20.
+__device__ __forceinline__ void roundtrip_cr(float x, float y, float z, float r_raw, float& th, float& ph, float& ox, float& oy, float& oz) {
+    const double xd = (double)x, yd = (double)y;
+    const double td = atan2(yd, xd);
+    const float t0 = (float)td;
+    const bool wrap = t0 < 0.0f;
+    th = wrap ? (float)((double)t0 + kTwoPi) : t0;
+    const double dth = wrap ? ((((double)th - kTwoPi) - td) - kTwoPiTail) : ((double)th - td);
+    const double rho2 = xd * xd + yd * yd;                       // both products exact in double
+    const double inv = 1.0 / sqrt(rho2);
+    const double s0 = (rho2 > 0.0) ? yd * inv : 0.0;
+    const double c0 = (rho2 > 0.0) ? xd * inv : (__builtin_signbit(x) ? -1.0 : 1.0);
+    const double hth = 0.5 * dth * dth;
+    const double st = s0 + (c0 * dth - s0 * hth);
+    const double ct = c0 - (s0 * dth + c0 * hth);
+    const double qd = (double)(z / r_raw);                       // float division, as the reference's acos argument
+    const double pd = acos(qd);
+    ph = (float)pd;
+    const double dph = (double)ph - pd;
+    const double sp0 = sqrt((1.0 - qd) * (1.0 + qd));            // sin(acos q) >= 0; 1 -+ q exact for float q
+    const double hph = 0.5 * dph * dph;
+    const double sp = sp0 + (qd * dph - sp0 * hph);
+    const double cp = qd - (sp0 * dph + qd * hph);
+    const float stf = (float)st, ctf = (float)ct, spf = (float)sp, cpf = (float)cp;
+    {
+#pragma clang fp contract(off)
+        ox = r_raw * spf * ctf;                                  // src/utils.cpp:134-136, left to right in float
+        oy = r_raw * spf * stf;
+        oz = r_raw * cpf;
+    }
+}
+
+// ---- fast angular classification -------------------------------------------------------------------------------------
+// Every decision the reference takes on a point's angles is a comparison against a voxel edge: the azimuth bin
+// int(theta / 2pi * T) in double (src/icet.cpp:545), the polar bin, and the f32 azimuth / polar bounds (:632-633, Q6).  Two
+// monotone, transcendental-free coordinates stand in for the angles --
+//     polar   : w  = -z / |q|                      (monotone in phi   = acos(z/|q|))
+//     azimuth : pa = "diamond angle" of (x, y)     (monotone in theta = atan2(y, x)), unfolded to [0, 4]
+// -- and are looked up in tables whose cells are narrower than half a bin: a cell names the single edge a point in it can be
+// near, one compare picks the side.  `near` is set when the point lies within a guard band of that edge (a few float ulps:
+// the summed worst-case rounding of this evaluation and of the literal one), when the cell is marked ambiguous (edge = NaN,
+// near the poles), or when the coordinates are not ordinary numbers; such a point must be classified with the literal
+// formulas.  Away from the edges the azimuth / polar bounds of filterPointsInsideCluster hold by construction.  Invariant,
+// tested bitwise (test_fast_classification_equals_literal_evaluation): the fast path never decides differently.
+struct LutCell { float edge; int32_t idx; };       // nearest edge (in pa / w units) and its index (polar: T * index)
+
+__device__ __forceinline__ void classify_angular_fast(float qx, float qy, float qz, float rs /* 1/|q| */, const LutCell* lut_t, const LutCell* lut_p,
+                                                      float cell_t, float cell_p, int T, float guard_t, float guard_p, int& bt, int& prow, bool& near) {
+    const float w = -qz * rs;                                            // -cos(phi)
+    const float q1 = qy * __builtin_amdgcn_rcpf(fabsf(qx) + fabsf(qy));  // y / (|x| + |y|) in [-1, 1]
+    const float pa = (qx >= 0.f) ? ((qy >= 0.f) ? q1 : 4.f + q1) : 2.f - q1;      // diamond angle in [0, 4]
+    const LutCell et = lut_t[static_cast<int>(pa * cell_t)];             // NaN converts to 0; pa in [0,4] -> cell in [0, Mt]
+    const LutCell ep = lut_p[static_cast<int>((w + 1.f) * cell_p)];
+    bt = et.idx - ((pa < et.edge) ? 1 : 0);                              // in [0, T]
+    prow = ep.idx - ((w < ep.edge) ? T : 0);                             // T * polar bin, polar bin in [0, P]
+    near = !(fabsf(pa - et.edge) >= guard_t) | !(fabsf(w - ep.edge) >= guard_p);
+}
+// |q|^2 outside this range over- or underflows the stand-in coordinates (the literal formulas stay well defined): literal path.
+constexpr float kR2Min = 1e-30f, kR2Max = 1e30f;
+
+}  // namespace icet

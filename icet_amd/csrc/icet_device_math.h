@@ -30,6 +30,17 @@ __device__ __forceinline__ void make_givens(float p, float q, float& c, float& s
     }
 }
 
+// Eigen 3.3's numext::hypot (MathFunctions.h, hypot_impl): plain IEEE operations, reproduced bit for bit by the CPU checker of the tests;
+// libm's hypotf is not specified to the last bit.
+__device__ __forceinline__ float eigen_hypot(float x, float y) {
+#pragma clang fp contract(off)
+    const float ax = fabsf(x), ay = fabsf(y);
+    float p, qp;
+    if (ax > ay) { p = ax; qp = ay / p; } else { p = ay; qp = ax / p; }
+    if (p == 0.f) return 0.f;
+    return p * sqrtf(1.f + qp * qp);
+}
+
 // One implicit-shift QR sweep on the unreduced block [start, end] of a symmetric tridiagonal matrix;
 // the rotations are accumulated into Q (N x N row-major) on the right.
 template <int N, bool kVec = true>
@@ -42,7 +53,7 @@ __device__ inline void tridiag_qr_step(float* diag, float* sub, int start, int e
         mu -= fabsf(e);
     } else if (e != 0.f) {
         const float e2 = e * e;
-        const float h = hypotf(td, e);
+        const float h = eigen_hypot(td, e);
         if (e2 == 0.f) mu -= e / ((td + (td > 0.f ? h : -h)) / e);
         else           mu -= e2 / (td + (td > 0.f ? h : -h));
     }

@@ -22,7 +22,15 @@ constexpr int kRankSortMaxBuckets = 1 << kRankSortBucketBits;
 #define ICET_KF_MAXPTS 8
 #endif
 constexpr int kKfMaxPtsPerThread = ICET_KF_MAXPTS;   // keyframe kernels: largest tile = 256 threads x this many rows
-constexpr int kMaxVoxels = 32768;    // slot ids travel as int16
+// Largest grid the kernels accept.  Binding constraint: k_bin_scatter keeps 4 x V running offsets (16 B per voxel) in one
+// block's LDS (160 KB per CU) -- validated up front in ensure_workspace so that a too-fine grid is refused with
+// ICET_ERR_UNSUPPORTED instead of failing a launch mid-sequence.  Voxel ids travel in 14 bits of a 16-bit word whose two top
+// bits carry per-row flags (kRowNearBit, kRowExecBit); slot ids travel as int16.
+constexpr int kMaxVoxels = 10000;
+constexpr uint16_t kRowExecBit = 0x8000u;   // the reference's swap loop executes its step at this row (icet_keyframe.hip, k_exec_flags)
+constexpr uint16_t kRowNearBit = 0x4000u;   // the row lies within a guard band of a voxel edge: its azimuth / polar bounds test must be done with the literal formulas
+constexpr uint16_t kRowBinMask = 0x3FFFu;
+constexpr uint32_t kSortedNearBit = 0x80000000u;   // the same flag in the sorted-row table (rows < 2^31)
 
 // One scan pair as the kernels see it (device pointers, column-major N x 3).
 struct PairDesc {
@@ -74,7 +82,8 @@ struct Workspace {
     int32_t cap_pairs = 0; int64_t cap_n1 = 0; int32_t cap_V = 0;
     PairDesc* desc = nullptr;
     int32_t* seg_off = nullptr;               // pairs+1, scan-1 segment offsets
-    float *r1 = nullptr, *th1 = nullptr, *ph1 = nullptr;            // spherical scan 1, input order
+    float *r1 = nullptr;                                             // radial distance of every scan-1 row, input order (bit-exact c2s r)
+    float *cart1 = nullptr;                                          // 3 x cap_n1: round-tripped Cartesian rows of large bins (k_fit_scan1's second pass)
     unsigned long long *key64A = nullptr, *key64B = nullptr;         // (pair << 32 | r bits)
     uint32_t *keyA = nullptr, *keyB = nullptr, *valA = nullptr, *valB = nullptr;
     uint32_t* splitters = nullptr; int32_t* n_buckets = nullptr; int32_t* bucket_start = nullptr;   // rank sort: pairs x 128, pairs, pairs x 129
@@ -98,6 +107,23 @@ struct Workspace {
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
 };
 
+// Launch-shape and diagnostic knobs.  Defaults are the measured optima; every value gives the same bits
+// (tests/test_gpu_parity.py::test_rarely_taken_paths_give_the_same_bits).  Set per context through icet_set_option -- the
+// library never reads the environment.
+struct Tuning {
+    int lds_slots = 0;            // active-voxel rows kept in LDS by k_gn_accumulate (0 = sized from the LDS budget)
+    int acc_pts = 4;              // k_gn_accumulate: minimum points per thread per block
+    int acc_blocks = 1536;        // k_gn_accumulate: target blocks per launch
+    int force_exact = 0;          // route every scan-2 point through the literal classification
+    int library_sort = 0;         // rocPRIM radix sort instead of the hand-written rank sort
+    int kf_pts = kKfMaxPtsPerThread;   // keyframe tile = 256 threads x this many rows
+    int batch_parts = 0;          // parts a device batch is cut into (0 = automatic)
+    int batch_stage = 4;          // keyframe stage after which the next part may start (0 = lock step)
+    int rs_cap = 0;               // LDS rows of the per-bucket sort (0 = from the largest scan)
+    double guard_scale = 1.0;     // multiplies the classification guard bands (tables are rebuilt)
+    double lut_polar_quantile = 0.25;   // polar LUT cell width = this quantile of the polar bin widths
+};
+
 struct LaunchCfg {
     int T, P, V, n, runlen;
     float thresh, buff;
@@ -115,13 +141,21 @@ struct LaunchCfg {
     int vec4_ok = 0;                  // every scan-2 pointer and leading dimension is 16-byte aligned
     int true_sort = 0;                // ICET_FLAG_TRUE_SORT (non-parity extension): src[] = the sorted order itself
     int force_exact = 0;              // diagnostic: route every point through the literal evaluation
+    int rs_cap = 0;                   // Tuning::rs_cap
 };
 
-// kernels.hip
+// icet_keyframe.hip
 hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* aux, hipStream_t st);
+// icet_solve.hip
 hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st);
-hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st);
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st);
+// icet_accumulate.hip
+hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st);
+// Raise the dynamic-LDS limit of the kernels that need more than the default; called once per context (icet_create) with the
+// context's device current -- no process-global "done" flags.
+hipError_t init_keyframe_kernels();
+hipError_t init_accumulate_kernels();
+hipError_t init_rank_sort_kernels();
 
 // ranksort.hip
 hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st);   // before k_scan1_spherical

@@ -1,0 +1,785 @@
+// icet_amd/csrc/icet_keyframe.hip -- keyframe build: everything the reference does ONCE per pair on scan 1.
+//
+// Reference path (all under /root/reference): ICET::fitScan1 src/icet.cpp:68-107 and fitCells1 :109-252.  The device
+// formulation is NOT a translation:
+//     k_scan1_spherical   utils::cartesianToSpherical (src/utils.cpp:93-119): r of every row (bit-exact), its voxel
+//                         (sortSphericalCoordinates, src/icet.cpp:534-554) through the fast classification with the literal
+//                         fallback, its rank-sort bucket and the tile's bucket histogram
+//     [rank sort, icet_ranksort.hip]                      std::sort by r (src/icet.cpp:72-77)
+//     k_exec_flags / k_scramble_src (+ serial replay)     the reference's one-step swap loop (src/icet.cpp:78-83) in
+//                                                          parallel closed form
+//     k_bin_tiles + k_bin_scan + k_bin_scatter             stable multi-split of positions by voxel = the order in which
+//                                                          sortSphericalCoordinates appends rows to each voxel
+//     k_fit_scan1         fitCells1: findCluster (:557-607), bounds filter (:609-652), the spherical -> Cartesian round
+//                         trip of the surviving rows (:159) and their mean / covariance (:160-162), one wave per bin
+//     k_fit_finish        per-bin tail, one lane per bin: 3x3 eigen-decomposition (:181-184), sigma points (:187-232) -> L,
+//                         records of the active voxels
+//     k_compact_slots     dense voxel table -> compact "slots" of active voxels
+// theta / phi of a row are never stored: only decisions (which voxel, inside the bounds) and the Gaussians need them, and
+// those evaluate them where needed under the shared arithmetic rule (icet_device_common.h).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "icet_internal.h"
+#include "icet_device_common.h"
+#include "icet_device_math.h"
+
+namespace icet {
+namespace {
+
+#define ICET_FOR_CHUNK_OF_SCAN1(i)                                                         \
+    int pair, chunk;                                                                       \
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;                               \
+    const PairDesc d = desc[pair];                                                         \
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;     \
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);                               \
+    for (int i = lo_ + threadIdx.x; i < hi_; i += kBlock)
+
+// ------------------------------------------------------------------------------------------------
+// cartesianToSpherical + sortSphericalCoordinates of scan 1, decisions only
+// ------------------------------------------------------------------------------------------------
+// The literal formulas for a row within a guard band of a voxel edge (~0.02 % of the rows, plus zero / NaN rows).  Out of line:
+// the double-precision atan2 / acos would otherwise set the register budget of the streaming loop.
+__device__ __noinline__ int voxel_literal(float px, float py, float pz, float r_raw, int T, int P) {
+    return voxel_of(theta_cr(py, px), phi_cr(pz, r_raw), T, P);
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __restrict__ desc, float* __restrict__ r1,
+                                                            unsigned long long* __restrict__ key64, uint32_t* __restrict__ key32,
+                                                            uint32_t* __restrict__ val, uint16_t* __restrict__ bin16, int T, int P, int n_pairs, int chunks,
+                                                            const uint32_t* __restrict__ splitters, uint8_t* __restrict__ bkt, uint32_t* __restrict__ counts,
+                                                            const LutCell* __restrict__ lut, int Mt, int Mp, float guard_t, float guard_p) {
+    // First step of the rank sort fused in (icet_ranksort.hip): the pair's splitters are already known (k_rs_splitters
+    // samples the radii straight from the Cartesian rows), so each row's bucket and this tile's bucket histogram cost no
+    // extra pass over r1[].  splitters == nullptr: library-sort diagnostic path, nothing of this is needed.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s1[];
+    LutCell* lut_t = reinterpret_cast<LutCell*>(smem_s1);               // Mt + 1 cells (the spare one catches pa == 4)
+    LutCell* lut_p = lut_t + (Mt + 1);                                  // Mp + 1 cells (w == 1)
+    __shared__ uint32_t sp[kRankSortMaxBuckets];
+    __shared__ uint32_t lh[kRankSortMaxBuckets];
+    {
+        const uint2* gl = reinterpret_cast<const uint2*>(lut);
+        uint2* ll = reinterpret_cast<uint2*>(lut_t);
+        for (int i = threadIdx.x; i < Mt + Mp + 2; i += kBlock) ll[i] = gl[i];
+        int pair_, chunk_;
+        if (splitters && decode_block(n_pairs, chunks, pair_, chunk_))
+            for (int j = threadIdx.x; j < kRankSortMaxBuckets; j += kBlock) { sp[j] = splitters[(size_t)pair_ * kRankSortMaxBuckets + j]; lh[j] = 0u; }
+        __syncthreads();
+    }
+    const float cell_t = (float)Mt * 0.25f, cell_p = (float)Mp * 0.5f;
+    ICET_FOR_CHUNK_OF_SCAN1(i) {
+        const float* x = d.s1; const float* y = d.s1 + d.ld1; const float* z = d.s1 + 2 * (size_t)d.ld1;
+        const float px = x[i], py = y[i], pz = z[i];
+        const float rr = radius_raw(px, py, pz);
+        // which voxel: fast classification, literal formulas within a guard band of an edge (and for anything that is not an
+        // ordinary number: zero rows, NaN, inf, magnitudes whose square leaves the float range)
+        const float r2 = px * px + py * py + pz * pz;
+        const bool ordinary = (r2 >= kR2Min) & (r2 <= kR2Max);
+        int bt, prow; bool near;
+        classify_angular_fast(ordinary ? px : 1.f, ordinary ? py : 0.f, ordinary ? pz : 0.f, ordinary ? __builtin_amdgcn_rsqf(r2) : 1.f,
+                              lut_t, lut_p, cell_t, cell_p, T, guard_t, guard_p, bt, prow, near);
+        near = near | !ordinary;
+        int v = prow + bt;
+        if (near) v = voxel_literal(px, py, pz, rr, T, P);
+        const float r = (rr != rr) ? 1000.0f : rr;                      // src/utils.cpp:116
+        size_t o = (size_t)d.off1 + i;
+        r1[o] = r;
+        if (splitters) {
+            const int b = rank_sort_bucket_of(__float_as_uint(r), sp);
+            bkt[o] = (uint8_t)b;
+            atomicAdd(&lh[b], 1u);
+        }
+        // r >= +0 (or 1000 for NaN): the bit pattern orders like the float; the pair id in the high word keeps
+        // every pair's points contiguous, so one device-wide sort handles the whole batch
+        if (key64) key64[o] = ((unsigned long long)pair << 32) | (unsigned long long)__float_as_uint(r);
+        else if (key32) key32[o] = __float_as_uint(r);
+        if (key64 || key32) val[o] = (uint32_t)i;               // library-sort path only
+        bin16[o] = (uint16_t)v | (near ? kRowNearBit : (uint16_t)0);
+    }
+    if (splitters) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < kRankSortMaxBuckets; j += kBlock) counts[((size_t)pair * chunks + chunk) * kRankSortMaxBuckets + j] = lh[j];
+    }
+}
+
+// pred[s[i]] = i : rank of every original row.
+__global__ __launch_bounds__(kBlock) void k_inverse_perm(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, int32_t* __restrict__ pred,
+                                                         int n_pairs, int chunks) {
+    ICET_FOR_CHUNK_OF_SCAN1(i) pred[(size_t)d.off1 + s[(size_t)d.off1 + i]] = i;
+}
+
+// The reference "sorts" rows in place with
+//     for i: if (index[i] != i) { swap(row i, row index[i]); swap(index[i], index[index[i]]); }
+// (src/icet.cpp:78-83), which executes ONE step of each permutation cycle instead of following it.
+// Visiting order makes step i execute iff row i is not a fixed point and was not frozen by an
+// executed step i' = pred(i) < i.  So exec(v) is the parity of the length of the descending chain
+// v, pred(v), pred(pred(v)), ... taken while pred(u) < u.
+// Both walks below are pointer chases through ~1 MB of per-pair tables that sit in the XCD's L2 (see decode_block): they
+// are bound by load latency, not bandwidth.  Each thread therefore advances EIGHT independent chains in lock step, so
+// that eight loads are in flight per thread instead of one.
+#ifndef ICET_WALK
+#define ICET_WALK 8
+#endif
+constexpr int kWalk = ICET_WALK;
+
+// The flag goes into bit 15 of the row's voxel word (icet_internal.h): k_scramble_src needs "did step u execute" and "which voxel
+// is row u in" for the same u, so one 2-byte random read serves both.
+constexpr uint16_t kExecBit = kRowExecBit, kBinMask = kRowBinMask;
+
+__global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
+                                                       uint16_t* __restrict__ bin16, int32_t* __restrict__ flags, int max_walk, int n_pairs, int chunks) {
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const PairDesc d = desc[pair];
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
+    const size_t o = d.off1;
+    for (int base = lo_ + threadIdx.x; base < hi_; base += kWalk * kBlock) {
+        int u[kWalk], len[kWalk]; bool act[kWalk], moved[kWalk];
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) {
+            const int v = base + k * kBlock;
+            const bool valid = v < hi_;
+            moved[k] = false;                                    // a fixed point of the permutation: pred[v] == v (known after the first load)
+            act[k] = valid; u[k] = v; len[k] = 0;
+        }
+        bool any = true;
+        while (any) {
+            int p[kWalk];
+#pragma unroll
+            for (int k = 0; k < kWalk; k++) p[k] = act[k] ? pred[o + u[k]] : 0;
+            any = false;
+#pragma unroll
+            for (int k = 0; k < kWalk; k++) {
+                if (act[k]) {
+                    if (len[k] == 0) moved[k] = (p[k] != u[k]);   // first step reads pred[v] itself: no separate pass over s[]
+                    if (p[k] >= u[k]) act[k] = false;
+                    else { u[k] = p[k]; len[k]++; if (len[k] > max_walk) { atomicOr(&flags[pair], 1); act[k] = false; } }
+                }
+                any |= act[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) {
+            const int v = base + k * kBlock;
+            if (v < hi_ && moved[k] && !(len[k] & 1)) bin16[o + v] |= kExecBit;      // k_scan1_spherical wrote the id with the bit clear
+        }
+    }
+}
+
+// src[v] = original row that ends at position v after the swap loop.  Position v receives row
+// pred(v), except at the head of a run of executed steps, where the row arrives from the end of
+// the forward chain v -> s[v] -> s[s[v]] ... while the steps executed.
+// Fused with the first step of the voxel multi-split (k_bin_hist): the row that lands on a position is known here, so
+// its voxel id and this tile's voxel histogram cost no extra pass over src[].
+#ifndef ICET_SCR_WAVES
+#define ICET_SCR_WAVES 6      /* <= 80 VGPRs: 6 waves per SIMD for a latency-bound walk (measured: -35 us per 256-pair keyframe; 8 spills) */
+#endif
+__global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
+                                                         int32_t* __restrict__ src, int32_t* __restrict__ flags, int max_walk,
+                                                         const uint16_t* __restrict__ bin16, uint16_t* __restrict__ binpos, uint32_t* __restrict__ counts, int V,
+                                                         int n_pairs, int chunks) {
+    extern __shared__ uint32_t lh[];
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const PairDesc d = desc[pair];
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
+    const size_t o = d.off1;
+    for (int b = threadIdx.x; b < V; b += kBlock) lh[b] = 0u;
+    __syncthreads();
+    for (int base = lo_ + threadIdx.x; base < hi_; base += kWalk * kBlock) {
+        int f[kWalk], u[kWalk], len[kWalk]; bool act[kWalk];
+        int pv[kWalk]; uint16_t wv[kWalk], fb[kWalk];    // fb: packed word of the row f[] (its voxel id is what the histogram needs)
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) {
+            const int v = base + k * kBlock;
+            const bool valid = v < hi_;
+            const size_t i = o + (valid ? v : lo_);
+            pv[k] = pred[i]; wv[k] = bin16[i];
+        }
+        uint16_t wp[kWalk];
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) wp[k] = bin16[o + pv[k]];
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) {
+            const int v = base + k * kBlock;
+            const bool valid = v < hi_;
+            const bool moved = valid && pv[k] != v;             // s[v] != v  <=>  pred[v] != v (fixed points of a permutation)
+            f[k] = moved ? pv[k] : v; fb[k] = moved ? wp[k] : wv[k];
+            act[k] = moved && (wv[k] & kExecBit) && !(wp[k] & kExecBit);   // head of a run of executed steps
+            u[k] = v; len[k] = 0;
+        }
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) any |= act[k];
+        while (any) {
+            int nu[kWalk];
+#pragma unroll
+            for (int k = 0; k < kWalk; k++) nu[k] = act[k] ? (int)s[o + u[k]] : 0;
+            uint16_t ne[kWalk];
+#pragma unroll
+            for (int k = 0; k < kWalk; k++) ne[k] = act[k] ? bin16[o + nu[k]] : (uint16_t)0;
+            any = false;
+#pragma unroll
+            for (int k = 0; k < kWalk; k++) {
+                if (act[k]) {
+                    u[k] = nu[k]; len[k]++;
+                    if (!(ne[k] & kExecBit)) { f[k] = u[k]; fb[k] = ne[k]; act[k] = false; }
+                    else if (len[k] > max_walk) { atomicOr(&flags[pair], 1); f[k] = u[k]; fb[k] = ne[k]; act[k] = false; }
+                }
+                any |= act[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) {
+            const int v = base + k * kBlock;
+            if (v < hi_) {
+                src[o + v] = f[k];
+                const uint16_t b = fb[k] & kBinMask;
+                binpos[o + v] = fb[k] & (uint16_t)~kExecBit;       // voxel id + the row's near-edge flag
+                atomicAdd(&lh[b], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* out = counts + ((size_t)pair * chunks + chunk) * V;
+    for (int b = threadIdx.x; b < V; b += kBlock) out[b] = lh[b];
+}
+
+// Serial fallback for adversarial permutations (walks longer than max_walk): one lane replays the
+// literal swap loop on indices.  Never taken on lidar data (observed walk depth <= 14).
+__global__ void k_scramble_serial(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, int32_t* __restrict__ idx_tmp,
+                                  int32_t* __restrict__ src, const int32_t* __restrict__ flags) {
+    const int pair = blockIdx.x;
+    if (threadIdx.x != 0 || !(flags[pair] & 1)) return;
+    const PairDesc d = desc[pair];
+    const size_t o = d.off1;
+    for (int i = 0; i < d.n1; i++) { idx_tmp[o + i] = (int)s[o + i]; src[o + i] = i; }
+    for (int i = 0; i < d.n1; i++) {
+        int j = idx_tmp[o + i];
+        if (j != i) {
+            int t = src[o + i]; src[o + i] = src[o + j]; src[o + j] = t;
+            idx_tmp[o + i] = idx_tmp[o + j]; idx_tmp[o + j] = j;
+        }
+    }
+}
+
+// ---- grouping scan-1 rows by voxel, in ascending POSITION order inside each voxel -------------------------------
+// sortSphericalCoordinates appends point indices to per-voxel vectors while walking the (scrambled) array front to back
+// (src/icet.cpp:539-550), so findCluster later sees each voxel's rows in ascending position.  That is a STABLE
+// multi-split of the positions by voxel id.  Done here in three small kernels instead of a second library sort:
+//   k_bin_hist     per tile of positions: histogram of voxel ids (LDS), voxel id of every position
+//   k_bin_scan     per pair: exclusive scan over (voxel, tile) -> bin_start[] and each tile's base offset per voxel
+//   k_bin_scatter  one wave per tile walks its positions 64 at a time; lanes holding the same voxel find each other
+//                  with a ballot per id bit (match-any), so rank = popcount of lower peers -- stable by construction --
+//                  and the row's spherical coordinates are written straight to their final place.
+__global__ __launch_bounds__(kBlock) void k_bin_hist(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const uint16_t* __restrict__ bin16,
+                                                     uint16_t* __restrict__ binpos, uint32_t* __restrict__ counts, const int32_t* __restrict__ flags,
+                                                     int V, int n_pairs, int chunks, int force) {
+    extern __shared__ uint32_t lh[];
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    if (!force && !(flags[pair] & 1)) return;   // k_scramble_src already produced binpos / counts; redo only after the serial replay (or when it did not run)
+    const PairDesc d = desc[pair];
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
+    for (int b = threadIdx.x; b < V; b += kBlock) lh[b] = 0u;
+    __syncthreads();
+    const size_t o = d.off1;
+    for (int v = lo_ + threadIdx.x; v < hi_; v += kBlock) {
+        const uint16_t wd = bin16[o + src[o + v]];
+        binpos[o + v] = wd & (uint16_t)~kExecBit;
+        atomicAdd(&lh[wd & kBinMask], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = counts + ((size_t)pair * chunks + chunk) * V;
+    for (int b = threadIdx.x; b < V; b += kBlock) out[b] = lh[b];
+}
+
+// Exclusive scan over (class, tile) in class-major order, in two steps so that a single large pair (7200 voxels x 240 tiles)
+// is not scanned by ONE block: k_bin_tiles (one thread per class, blocks over classes) turns each class's per-tile counts into
+// per-tile offsets and leaves the class total in class_start[]; k_bin_scan (one block per pair) scans the totals in place.
+__global__ __launch_bounds__(kBlock) void k_bin_tiles(const uint32_t* __restrict__ counts, uint32_t* __restrict__ tile_base, int32_t* __restrict__ class_start,
+                                                      int V, int chunks) {
+    const int pair = blockIdx.y, b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= V) return;
+    const uint32_t* c = counts + (size_t)pair * chunks * V + b;
+    uint32_t* tb = tile_base + (size_t)pair * chunks * V + b;
+    int tot = 0, t = 0;
+    for (; t + 8 <= chunks; t += 8) {                         // 8 independent loads in flight
+        uint32_t x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = c[(size_t)(t + k) * V];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { tb[(size_t)(t + k) * V] = (uint32_t)tot; tot += (int)x[k]; }
+    }
+    for (; t < chunks; t++) { const uint32_t x = c[(size_t)t * V]; tb[(size_t)t * V] = (uint32_t)tot; tot += (int)x; }
+    class_start[(size_t)pair * (V + 1) + b] = tot;
+}
+
+__global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class_start, int V) {
+    __shared__ int wave_tot[kBlock / 64];
+    __shared__ int base;
+    const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int v0 = 0; v0 < V; v0 += kBlock) {
+        const int b = v0 + threadIdx.x;
+        const int tot = (b < V) ? class_start[(size_t)pair * (V + 1) + b] : 0;
+        int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; k++) woff += wave_tot[k];
+        const int bb = base;
+        if (b < V) class_start[(size_t)pair * (V + 1) + b] = bb + woff + incl - tot;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) base = bb + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) class_start[(size_t)pair * (V + 1) + V] = base;
+}
+
+// One block per tile (<= 2048 positions); wave w owns the w-th quarter (<= 8 rounds of 64 positions).  Everything
+// global is loaded up front and stored at the end, so the only serial chain is 8 rounds of ballots + LDS.
+constexpr int kScatterRounds = kKfMaxPtsPerThread;   // a tile is at most 4 waves x this many rounds x 64 positions
+__global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const uint16_t* __restrict__ binpos,
+                                                        const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bin_start,
+                                                        uint32_t* __restrict__ sorted_row, int V, int vbits, int n_pairs, int chunks) {
+    extern __shared__ uint32_t lb[];                                   // 4 x V : per-wave counts, then per-wave running offsets
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const PairDesc d = desc[pair];
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;      // multiple of 256, <= 64 * 4 * kScatterRounds
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
+    if (lo_ >= hi_) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qs = cs_ / 4;                                            // multiple of 64
+    const int wlo = lo_ + wave * qs, whi = min(hi_, wlo + qs);
+    const int rounds = qs / 64;
+    for (int i = threadIdx.x; i < 4 * V; i += kBlock) lb[i] = 0u;
+    __syncthreads();
+    const size_t o = d.off1;
+    uint32_t bb[kScatterRounds]; uint32_t row[kScatterRounds]; bool ok[kScatterRounds];
+    uint32_t* mine = lb + wave * V;
+#pragma unroll
+    for (int k = 0; k < kScatterRounds; k++) {
+        const int v = wlo + 64 * k + lane;
+        ok[k] = (k < rounds) & (v < whi);
+        const uint32_t wd = ok[k] ? (uint32_t)binpos[o + v] : 0u;
+        bb[k] = wd & kRowBinMask;
+        row[k] = (ok[k] ? (uint32_t)src[o + v] : 0u) | ((wd & kRowNearBit) ? kSortedNearBit : 0u);   // the flag travels with the row
+        if (ok[k]) atomicAdd(&mine[bb[k]], 1u);
+    }
+    __syncthreads();
+    {
+        const uint32_t* tb = tile_base + ((size_t)pair * chunks + chunk) * V;
+        const int32_t* bst = bin_start + (size_t)pair * (V + 1);
+        for (int b = threadIdx.x; b < V; b += kBlock) {
+            const uint32_t c0 = lb[b], c1 = lb[V + b], c2 = lb[2 * V + b];
+            const uint32_t base = (uint32_t)bst[b] + tb[b];
+            lb[b] = base; lb[V + b] = base + c0; lb[2 * V + b] = base + c0 + c1; lb[3 * V + b] = base + c0 + c1 + c2;
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t dest[kScatterRounds];
+#pragma unroll
+    for (int k = 0; k < kScatterRounds; k++) {
+        unsigned long long peers = __ballot(ok[k]);
+        for (int q = 0; q < vbits; q++) {
+            const bool bit = (bb[k] >> q) & 1u;
+            const unsigned long long m = __ballot(ok[k] && bit);
+            peers &= bit ? m : ~m;
+        }
+        dest[k] = 0u;
+        if (ok[k]) {
+            const int rank = __popcll(peers & lt);
+            dest[k] = mine[bb[k]] + (uint32_t)rank;
+            if (rank == 0) mine[bb[k]] += (uint32_t)__popcll(peers);  // one leader per distinct voxel in this round
+        }
+    }
+    // one scattered 4-byte store per row; k_fit_scan1 gathers the coordinates through it (element-wise scattered stores of
+    // the three coordinate arrays cost 4x more than gathering them, and a separate gather pass 0.15 ms more than gathering
+    // inside the fit, whose independent loads hide the latency)
+#pragma unroll
+    for (int k = 0; k < kScatterRounds; k++)
+        if (ok[k]) sorted_row[o + dest[k]] = row[k];
+}
+// fitCells1 (src/icet.cpp:109-252): one wavefront per angular bin.
+// The per-bin tail -- 3x3 eigen-decomposition, the six sigma points, the slot records -- is scalar work: it runs in
+// k_fit_finish with one LANE per bin instead of here with one WAVE per bin (measured: 0.21 ms of the 0.42 ms this kernel
+// took on 256 pairs was 64 lanes executing the same eigen-solve).
+#ifndef ICET_FIT_WAVES
+#define ICET_FIT_WAVES 4      /* register budget of the double-precision round trip (128 VGPRs) */
+#endif
+constexpr int kFitKeep = 256;                 // round-tripped rows per bin kept in LDS for the second (centred) pass; the rest goes through cart1[]
+struct FitLds { uint32_t qrow[128]; float qr[128]; float kx[kFitKeep], ky[kFitKeep], kz[kFitKeep]; };   // per wave: candidate queue + kept rows, 4 KB
+__global__ __launch_bounds__(kBlock, ICET_FIT_WAVES) void k_fit_scan1(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
+                                                      const uint32_t* __restrict__ sorted_row, const float* __restrict__ r1,
+                                                      float* __restrict__ cart1, size_t cart_stride,
+                                                      FitMid* __restrict__ midD, int T, int P, int n, float thresh, float buff, int n_pairs, int chunks) {
+    __shared__ FitLds fl[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int V = T * P;
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;          // all bins of a pair on one XCD: its tables stay in that L2
+    const int v = chunk * (kBlock / 64) + wave;
+    if (v >= V) return;
+    const PairDesc d = desc[pair];
+    const int theta = v % T, phi = v / T;
+    float az0, az1, el0, el1;
+    voxel_limits(theta, phi, T, P, az0, az1, el0, el1);
+    const int bs = bin_start[(size_t)pair * (V + 1) + v];
+    const int cnt = bin_start[(size_t)pair * (V + 1) + v + 1] - bs;
+    const size_t base = (size_t)d.off1 + bs;
+    // rows of this bin in (scrambled) position order: sorted_row[base + i] is the row of the pair's input-order tables
+    // (top bit: the row lies within a guard band of a voxel edge)
+    const size_t po = (size_t)d.off1;
+    constexpr uint32_t kRowMask = ~kSortedNearBit;
+    auto RS = [&](int i) { return r1[po + (sorted_row[base + i] & kRowMask)]; };
+
+    float inner = 0.f, outer = 0.f;
+    int has_fit = 0;
+    float mean[3] = {0.f, 0.f, 0.f};
+    float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // xx xy xz yy yz zz
+
+    if (cnt >= n) {
+        // The bin's first 4 x 64 rows are fetched up front with independent loads (most bins hold ~100-400 rows), so
+        // the serial walks below run on registers instead of paying one memory round trip per 64 rows.
+        constexpr int kCache = 4;
+        float pr[kCache]; uint32_t prw[kCache];
+#pragma unroll
+        for (int k = 0; k < kCache; k++) {
+            const int i = lane + 64 * k;
+            prw[k] = (i < cnt) ? sorted_row[base + i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kCache; k++) pr[k] = (lane + 64 * k < cnt) ? r1[po + (prw[k] & kRowMask)] : 0.f;
+        // ---- findCluster (src/icet.cpp:557-607): first run of >= n consecutive points whose
+        // successive |dr| <= thresh, walking the bin in stored (scrambled) order.
+        int run_start = 0; float front = 0.f; float carry_prev = 0.f; bool found = false;
+        // A break is a point that does not continue the current run; a run is reported at the first break that closes
+        // >= n points.  In the scrambled order most points are breaks, so instead of visiting the breaks of a 64-point
+        // chunk one after another, every break lane looks up the break before it with a prefix-max scan and the first
+        // lane whose run is long enough is picked with a ballot.
+        auto walk = [&](int c0, float r) {
+            const int i = c0 + lane; const bool valid = i < cnt;
+            float prev = __shfl_up(r, 1);
+            if (lane == 0) prev = carry_prev;
+            const bool brk = valid && (i == 0 || !(fabsf(prev - r) <= thresh));
+            int pm = brk ? i : -1;                                   // inclusive prefix max of break positions
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pm, o); if (lane >= o) pm = max(pm, t); }
+            int prevb = __shfl_up(pm, 1);                            // last break strictly before this lane ...
+            if (lane == 0) prevb = -1;
+            prevb = max(prevb, run_start);                           // ... or the run carried in from earlier chunks
+            const unsigned long long hit = __ballot(brk && (i - prevb >= n));
+            if (hit) {
+                const int b = __ffsll((long long)hit) - 1;
+                const int rs0 = __shfl(prevb, b);                    // start of the run that this break closes
+                const float back = (b > 0) ? __shfl(r, b - 1) : carry_prev;
+                const float fr = (rs0 >= c0) ? __shfl(r, rs0 - c0) : front;
+                inner = fr - buff; outer = back + buff; found = true;
+            } else {
+                const int last = __shfl(pm, 63);                     // last break of this chunk, if any
+                if (last >= 0) { run_start = last; front = __shfl(r, last - c0); }
+            }
+            carry_prev = __shfl(r, 63);
+        };
+#pragma unroll
+        for (int k = 0; k < kCache; k++) if (64 * k < cnt && !found) walk(64 * k, pr[k]);
+        for (int c0 = 64 * kCache; c0 < cnt && !found; c0 += 64) walk(c0, (c0 + lane < cnt) ? RS(c0 + lane) : 0.f);
+        if (!found && cnt - run_start >= n) {
+            if (front != 0.f) { const float back = RS(cnt - 1); inner = front - buff; outer = back + buff; }
+            else { inner = 0.f; outer = 0.f; }
+        }
+        // ---- filterPointsInsideCluster + sphericalToCartesian + mean / covariance (src/icet.cpp:155-162).  Nothing is fitted
+        // unless outerDistance > 0.1 (:158, float against a double literal), so bins without a cluster stop here.
+        if ((double)outer > 0.1) {
+            const float* sx = d.s1; const float* sy = d.s1 + d.ld1; const float* sz = d.s1 + 2 * (size_t)d.ld1;
+            float* qx = cart1 + base; float* qy = qx + cart_stride; float* qz = qy + cart_stride;     // second-pass scratch beyond kFitKeep rows
+            FitLds& L = fl[wave];
+            // A row survives the filter iff its r lies in [inner, outer] and its angles lie inside the voxel's f32 limits.  The
+            // angular half holds by construction for a row classified away from every edge (the same argument as for the bin
+            // itself); a row flagged near-edge is tested with the literal formulas.  Survivors go through the reference's
+            // spherical -> Cartesian round trip under the shared rule (roundtrip_cr: double-precision atan2 / acos).  That is the
+            // expensive part, so the rows inside the radial range are first COMPACTED into a per-wave LDS queue and the round trip
+            // runs on full 64-lane batches; the sums are exact (double accumulators over float addends: the shared rule), so the
+            // order in which rows are visited does not matter.
+            double sumx = 0.0, sumy = 0.0, sumz = 0.0; int rows = 0;
+            int qn = 0, done = 0;                                     // queue fill, candidates processed (both wave-uniform)
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            int c0 = 0;
+            while (c0 < cnt || qn > 0) {
+                if (c0 < cnt) {
+                    const int i = c0 + lane, c = c0 >> 6;
+                    uint32_t rw; float r;
+                    if (c < kCache) {                                 // block-uniform: the cached chunks, selected without indexing the register arrays
+                        rw = (c == 0) ? prw[0] : (c == 1) ? prw[1] : (c == 2) ? prw[2] : prw[3];
+                        r = (c == 0) ? pr[0] : (c == 1) ? pr[1] : (c == 2) ? pr[2] : pr[3];
+                    } else {
+                        rw = (i < cnt) ? sorted_row[base + i] : 0u;
+                        r = (i < cnt) ? r1[po + (rw & kRowMask)] : 0.f;
+                    }
+                    const bool cand = (i < cnt) && (r >= inner) && (r <= outer);
+                    const unsigned long long m = __ballot(cand);
+                    if (cand) { const int pos = qn + __popcll(m & lt); L.qrow[pos] = rw; L.qr[pos] = r; }
+                    qn += __popcll(m);
+                    c0 += 64;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                }
+                if (qn >= 64 || (c0 >= cnt && qn > 0)) {
+                    const int nb = min(qn, 64);
+                    if (lane < nb) {
+                        const uint32_t rw = L.qrow[lane]; const float r = L.qr[lane];
+                        const uint32_t row = rw & kRowMask;
+                        float th, ph, X, Y, Z;
+                        roundtrip_cr(sx[row], sy[row], sz[row], r, th, ph, X, Y, Z);
+                        // NaN angles (r = 0, NaN rows) fail the test, like the reference's 1000 sentinel
+                        const bool in = !(rw & kSortedNearBit) || (th >= az0 && th <= az1 && ph >= el0 && ph <= el1);
+                        if (in) { sumx += (double)X; sumy += (double)Y; sumz += (double)Z; rows++; }
+                        else X = __builtin_nanf("");              // marks "did not survive" for the second pass
+                        const int k = done + lane;                    // done is a multiple of 64: lane l always owns the words k = l (mod 64)
+                        if (k < kFitKeep) { L.kx[k] = X; L.ky[k] = Y; L.kz[k] = Z; } else { qx[k] = X; qy[k] = Y; qz[k] = Z; }
+                    }
+                    const uint32_t w2 = L.qrow[lane + 64]; const float r2 = L.qr[lane + 64];     // shift the queue down by one batch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    L.qrow[lane] = w2; L.qr[lane] = r2;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    done += nb; qn -= nb;
+                }
+            }
+            sumx = wave_sum_d(sumx); sumy = wave_sum_d(sumy); sumz = wave_sum_d(sumz); rows = wave_sum_i(rows);
+            if (rows * 3 >= n) {                              // src/icet.cpp:158 (size() counts coefficients)
+#pragma clang fp contract(off)
+                has_fit = 1;
+                mean[0] = (float)sumx / (float)rows; mean[1] = (float)sumy / (float)rows; mean[2] = (float)sumz / (float)rows;
+                double c[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                for (int k = lane; k < done; k += 64) {                     // the lane that wrote word k reads it: no fence needed
+                    const bool lds = k < kFitKeep;
+                    const float X = lds ? L.kx[k] : qx[k];
+                    if (X == X) {
+                        const float Y = lds ? L.ky[k] : qy[k], Z = lds ? L.kz[k] : qz[k];
+                        const float dx = X - mean[0], dy = Y - mean[1], dz = Z - mean[2];
+                        c[0] += (double)(dx * dx); c[1] += (double)(dx * dy); c[2] += (double)(dx * dz);
+                        c[3] += (double)(dy * dy); c[4] += (double)(dy * dz); c[5] += (double)(dz * dz);
+                    }
+                }
+                const float den = (float)(rows - 1);
+#pragma unroll
+                for (int k = 0; k < 6; k++) cov[k] = (float)wave_sum_d(c[k]) / den;
+            }
+        }
+    }
+    // one 64-byte record per bin, staged through LDS so that 16 lanes store it with one coalesced instruction
+    __shared__ float stage[kBlock / 64][16];
+    if (lane == 0) {
+        float* g = stage[wave];
+        g[0] = mean[0]; g[1] = mean[1]; g[2] = mean[2];
+#pragma unroll
+        for (int k = 0; k < 6; k++) g[3 + k] = cov[k];
+        g[9] = inner; g[10] = outer; g[11] = __int_as_float(cnt); g[12] = __int_as_float(has_fit); g[13] = g[14] = g[15] = 0.f;
+    }
+    // same wave wrote and reads: LDS operations of one wave complete in order
+    if (lane < 16) reinterpret_cast<float*>(midD + (size_t)pair * V + v)[lane] = stage[wave][lane];
+}
+
+// fitCells1's per-bin tail (src/icet.cpp:181-252), one lane per angular bin: eigen-decomposition, U = eigenvectors^T, the six
+// sigma points and their inside test -> L, the scan-1 half of the gate at :290, and the records of the active voxels.
+__global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict__ midD, SlotHot* __restrict__ hotD, SlotFit* __restrict__ fitD,
+                                                       int32_t* __restrict__ activeD, AuxDev aux, int T, int P, int n) {
+    const int V = T * P;
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    const int pair = blockIdx.y;
+    if (v >= V) return;
+    const size_t o = (size_t)pair * V + v;
+    const FitMid m = midD[o];
+    const int theta = v % T, phi = v / T;
+    float az0, az1, el0, el1;
+    voxel_limits(theta, phi, T, P, az0, az1, el0, el1);
+    const float inner = m.inner, outer = m.outer;
+    float ev[3] = {0.f, 0.f, 0.f}, Vm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float Ld[3] = {0.f, 0.f, 0.f};
+    int active = 0;
+    if (m.has_fit) {
+        icetdev::eig3_sym(m.cov[0], m.cov[1], m.cov[3], m.cov[2], m.cov[4], m.cov[5], ev, Vm);
+        // sigma points mu +- 2 sqrt(lambda_k) * (row k of V): rotated = diag(2 sqrt(lambda)) * U^T = diag(.) * V (src/icet.cpp:187-202).
+        // testSigmaPoints walks j = 0..5 and leaves the loop AFTER testing the first point with r > outer (:669-686).
+        bool inside[6] = {false, false, false, false, false, false};
+        bool done = false;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const int k = j >> 1;
+            float px, py, pz;
+            {
+#pragma clang fp contract(off)
+                // rot = axislen * V (row k), rounded, THEN added to / subtracted from the mean (src/icet.cpp:193-202)
+                const float al = 2.0f * sqrtf(ev[k]);
+                const float r0 = al * Vm[3 * k], r1_ = al * Vm[3 * k + 1], r2_ = al * Vm[3 * k + 2];
+                px = (j & 1) ? m.mean[0] - r0 : m.mean[0] + r0;
+                py = (j & 1) ? m.mean[1] - r1_ : m.mean[1] + r1_;
+                pz = (j & 1) ? m.mean[2] - r2_ : m.mean[2] + r2_;
+            }
+            if (!done) {
+                float r, az, el; c2s_cr(px, py, pz, r, az, el);
+                inside[j] = inside_bounds(r, az, el, az0, az1, el0, el1, inner, outer);
+                done = r > outer;
+            }
+        }
+        Ld[0] = (inside[0] || inside[1]) ? 1.f : 0.f; Ld[1] = (inside[2] || inside[3]) ? 1.f : 0.f; Ld[2] = (inside[4] || inside[5]) ? 1.f : 0.f;
+        active = (m.cnt > n && outer > 1.f) ? 1 : 0;      // scan-1 half of the gate at src/icet.cpp:290
+    }
+    // Records are only needed for ACTIVE voxels (k_compact_slots copies nothing else)
+    if (active) {
+        SlotHot h; h.az0 = az0; h.az1 = az1; h.el0 = el0; h.el1 = el1; h.inner = inner; h.outer = outer;
+        h.mu[0] = m.mean[0]; h.mu[1] = m.mean[1]; h.mu[2] = m.mean[2]; h.v = v; h.pad[0] = h.pad[1] = 0;
+        hotD[o] = h;
+        SlotFit f; f.mu[0] = m.mean[0]; f.mu[1] = m.mean[1]; f.mu[2] = m.mean[2];
+        const float d1 = (float)(m.cnt - 1);
+#pragma unroll
+        for (int k = 0; k < 6; k++) f.s1n[k] = m.cov[k] / d1;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { f.M[3 * k] = Ld[k] * Vm[3 * k]; f.M[3 * k + 1] = Ld[k] * Vm[3 * k + 1]; f.M[3 * k + 2] = Ld[k] * Vm[3 * k + 2]; }
+        f.n1 = m.cnt; f.v = v;
+        fitD[o] = f;
+    }
+    activeD[o] = active;
+    if (aux.bounds) { float* b = aux.bounds + o * 6; b[0] = az0; b[1] = az1; b[2] = el0; b[3] = el1; b[4] = inner; b[5] = outer; }
+    if (aux.n1_raw) aux.n1_raw[o] = m.cnt;
+    if (aux.has_fit) aux.has_fit[o] = m.has_fit;
+    if (aux.mu1) { aux.mu1[o * 3] = m.mean[0]; aux.mu1[o * 3 + 1] = m.mean[1]; aux.mu1[o * 3 + 2] = m.mean[2]; }
+    if (aux.sigma1) { float* sg = aux.sigma1 + o * 9; sg[0] = m.cov[0]; sg[1] = m.cov[1]; sg[2] = m.cov[2]; sg[3] = m.cov[1]; sg[4] = m.cov[3]; sg[5] = m.cov[4]; sg[6] = m.cov[2]; sg[7] = m.cov[4]; sg[8] = m.cov[5]; }
+    if (aux.evecs1) for (int k = 0; k < 9; k++) aux.evecs1[o * 9 + k] = Vm[k];
+    if (aux.l_diag) { aux.l_diag[o * 3] = Ld[0]; aux.l_diag[o * 3 + 1] = Ld[1]; aux.l_diag[o * 3 + 2] = Ld[2]; }
+}
+
+// Dense per-voxel records -> compact slots in voxel order (phi-major, theta inner: the reference's
+// accumulation order, src/icet.cpp:391-404).
+__global__ __launch_bounds__(kBlock) void k_compact_slots(const SlotHot* __restrict__ hotD, const SlotFit* __restrict__ fitD, const int32_t* __restrict__ activeD,
+                                                          SlotHot* __restrict__ hotS, SlotFit* __restrict__ fitS, int16_t* __restrict__ slot_of_voxel,
+                                                          int32_t* __restrict__ n_slots, uint32_t* __restrict__ acc, int V) {
+    __shared__ int wave_tot[kBlock / 64];
+    __shared__ int base;
+    const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int v0 = 0; v0 < V; v0 += kBlock) {
+        const int v = v0 + threadIdx.x;
+        const int a = (v < V) ? activeD[(size_t)pair * V + v] : 0;
+        const unsigned long long m = __ballot(a != 0);
+        const int excl = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; k++) woff += wave_tot[k];
+        const int b = base;
+        if (v < V) {
+            if (a) {
+                const int s = b + woff + excl;
+                slot_of_voxel[(size_t)pair * ((V + 1) & ~1) + v] = (int16_t)s;
+                hotS[(size_t)pair * V + s] = hotD[(size_t)pair * V + v];
+                fitS[(size_t)pair * V + s] = fitD[(size_t)pair * V + v];
+            } else {
+                slot_of_voxel[(size_t)pair * ((V + 1) & ~1) + v] = (int16_t)-1;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < kBlock / 64; k++) t += wave_tot[k]; base = b + t; }
+        __syncthreads();
+    }
+    const int ns = base;
+    if (threadIdx.x == 0) n_slots[pair] = ns;
+    for (int i = threadIdx.x; i < ns * kAccWords; i += kBlock) acc[(size_t)pair * V * kAccWords + i] = 0u;
+}
+
+
+}  // namespace
+
+#define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+// dynamic LDS of the keyframe kernels, bytes: the voxel-indexed ones grow with the grid (validated against the device in ensure_workspace)
+static size_t scan1_lds_bytes(const Workspace& w) { return (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell); }
+
+hipError_t init_keyframe_kernels() {
+    const int cap = 160 * 1024 - 2048;        // static __shared__ of the kernels comes on top
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scramble_src), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_hist), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan1_spherical), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    return e;
+}
+
+hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* auxp, hipStream_t st) {
+    AuxDev aux{}; if (auxp) aux = *auxp;
+    // many small chunks per pair: with the XCD-aware mapping only ~4 pairs are then in flight per XCD (see decode_block)
+    const int chunks = c.kf_chunks;
+    const int groups = grid_groups(c.n_pairs);
+    dim3 grid(groups * chunks), blk(kBlock);
+    const int np = c.n_pairs;
+    hipError_t e;
+    int pbits = 0; while ((1 << pbits) < c.n_pairs) pbits++;
+    int vbits = 1; while ((1 << vbits) < c.V) vbits++;
+    const bool batch = c.n_pairs > 1;
+    if (!c.use_library_sort) { e = launch_rank_sort_splitters(w, c, st); if (e != hipSuccess) return e; }
+    k_scan1_spherical<<<grid, blk, scan1_lds_bytes(w), st>>>(w.desc, w.r1, (batch && c.use_library_sort) ? w.key64A : nullptr, c.use_library_sort ? w.keyA : nullptr, w.valA, w.bin16,
+                                                              c.T, c.P, np, chunks, c.use_library_sort ? nullptr : w.splitters, w.bkt, w.counts,
+                                                              reinterpret_cast<const LutCell*>(w.lut), w.lut_Mt, w.lut_Mp, w.guard_t, w.guard_p);
+    ICET_LAUNCH_CHECK();
+    if (c.stage_event && c.stage_at == 4) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
+    if (c.use_library_sort) {
+        if (batch) e = sort_pairs_u64(w.sort_tmp, w.sort_tmp_bytes, w.key64A, w.key64B, w.valA, w.valB, c.total_n1, 32 + pbits, st);
+        else e = sort_pairs_u32(w.sort_tmp, w.sort_tmp_bytes, w.keyA, w.keyB, w.valA, w.valB, c.total_n1, 32, st);
+        if (e != hipSuccess) return e;
+        // valB = s : original index of the row with rank i
+        k_inverse_perm<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, np, chunks);
+        ICET_LAUNCH_CHECK();
+    } else {
+        e = launch_rank_sort(w, c, st);        // valB = s, pred = s^-1  (icet_ranksort.hip)
+        if (e != hipSuccess) return e;
+    }
+    if (c.stage_event && c.stage_at == 1) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
+    e = hipMemsetAsync(w.flags, 0, sizeof(int32_t) * c.n_pairs, st); if (e != hipSuccess) return e;
+    if (c.true_sort) {
+        // non-parity extension: the rows stay in sorted order (what the reference's comment says the loop is meant to do)
+        e = hipMemcpyAsync(w.src, w.valB, sizeof(int32_t) * (size_t)c.total_n1, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return e;
+        k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, w.flags, c.V, np, chunks, 1);
+        ICET_LAUNCH_CHECK();
+    } else {
+        const int max_walk = 4096;
+        k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.bin16, w.flags, max_walk, np, chunks);
+        ICET_LAUNCH_CHECK();
+        k_scramble_src<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.valB, w.pred, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);
+        ICET_LAUNCH_CHECK();
+        k_scramble_serial<<<c.n_pairs, 64, 0, st>>>(w.desc, w.valB, w.pred /* reused as scratch */, w.src, w.flags);
+        ICET_LAUNCH_CHECK();
+        if (c.stage_event && c.stage_at == 2) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
+        k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, w.flags, c.V, np, chunks, 0);
+        ICET_LAUNCH_CHECK();
+    }
+    e = launch_class_scan(w.counts, w.tile_base, w.bin_start, c.V, chunks, c.n_pairs, st);
+    if (e != hipSuccess) return e;
+    k_bin_scatter<<<grid, blk, (size_t)c.V * 16, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks);
+    ICET_LAUNCH_CHECK();
+    if (c.stage_event && c.stage_at == 3) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
+    const int fit_chunks = (c.V + kBlock / 64 - 1) / (kBlock / 64);
+    k_fit_scan1<<<dim3(groups * fit_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.valA, w.r1, w.cart1, (size_t)w.cap_n1, w.midD, c.T, c.P, c.n, c.thresh, c.buff, np, fit_chunks);
+    ICET_LAUNCH_CHECK();
+    k_fit_finish<<<dim3((c.V + kBlock - 1) / kBlock, c.n_pairs), blk, 0, st>>>(w.midD, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n);
+    ICET_LAUNCH_CHECK();
+    k_compact_slots<<<c.n_pairs, blk, 0, st>>>(w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, c.V);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st) {
+    k_bin_tiles<<<dim3((n_classes + kBlock - 1) / kBlock, n_pairs), kBlock, 0, st>>>(counts, tile_base, class_start, n_classes, chunks);
+    ICET_LAUNCH_CHECK();
+    k_bin_scan<<<n_pairs, kBlock, 0, st>>>(class_start, n_classes);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace icet

@@ -23,12 +23,11 @@
 // Traffic ~30 B per row instead of ~130 B.
 #include <hip/hip_runtime.h>
 #include "icet_internal.h"
-#include <cstdlib>
+#include "icet_device_common.h"
 
 namespace icet {
 namespace {
 
-constexpr int kBlock = 256;
 #ifndef ICET_RS_SAMPLES
 #define ICET_RS_SAMPLES 2048
 #endif
@@ -47,25 +46,9 @@ constexpr int kCapMin = 1280, kCapMax = 9216;  // 9216 rows = 152 KB: one block 
 constexpr int kSortBlock = 256;
 constexpr int kSortWaves = kSortBlock / 64;
 
-__device__ __forceinline__ bool decode_block(int n_pairs, int chunks, int& pair, int& chunk) {
-    if (n_pairs >= 8) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        pair = (j / chunks) * 8 + xcd; chunk = j % chunks;
-        return pair < n_pairs;
-    }
-    pair = blockIdx.x / chunks; chunk = blockIdx.x % chunks;
-    return true;
-}
-
 // ---- splitters -----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float radius_of(float x, float y, float z) {     // the r of c2s_point (icet_kernels.hip), bit for bit
-    float r;
-    {
-#pragma clang fp contract(off)
-        float s = x * x + y * y;
-        s = s + z * z;
-        r = sqrtf(s);
-    }
+__device__ __forceinline__ float radius_of(float x, float y, float z) {     // the r that k_scan1_spherical stores, bit for bit
+    const float r = radius_raw(x, y, z);
     return (r != r) ? 1000.0f : r;
 }
 
@@ -285,17 +268,21 @@ __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* _
 #define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
 // LDS rows of the per-bucket sort for scans of at most max_n rows: 1.3 x the mean bucket, rounded up to 128
-static int rank_sort_cap(int max_n) {
+static int rank_sort_cap(int max_n, int forced) {
     int nb = (max_n + kBucketTarget - 1) / kBucketTarget; nb = nb < 1 ? 1 : (nb > kMaxBuckets ? kMaxBuckets : nb);
     int cap = (int)(1.3 * (double)max_n / nb); cap = (cap + 127) / 128 * 128;
     cap = cap < kCapMin ? kCapMin : (cap > kCapMax ? kCapMax : cap);
-    if (const char* e = getenv("ICET_RS_CAP")) { cap = atoi(e); cap = cap < 64 ? 64 : (cap > kCapMax ? kCapMax : cap); }   // tests: force the global-scratch path
+    if (forced > 0) cap = forced < 64 ? 64 : (forced > kCapMax ? kCapMax : forced);     // Tuning::rs_cap (tests: force the global-scratch path)
     return cap;
 }
 static size_t rank_sort_lds_bytes(int cap) { return (size_t)(kOffBuf + 4 * cap) * 4; }
 
 // Outputs: w.valB = s (row with rank i), w.pred = rank of every row.  Scratch: w.keyA / w.valA (bucket-grouped keys and
 // rows), w.keyB / w.key64A (overflow buckets), w.bkt, w.counts / w.tile_base, w.splitters, w.n_buckets, w.bucket_start.
+hipError_t init_rank_sort_kernels() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_bucket_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_sort_lds_bytes(kCapMax));
+}
+
 hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
     k_rs_splitters<<<c.n_pairs, 1024, 0, st>>>(w.desc, w.splitters, w.n_buckets);
     ICET_LAUNCH_CHECK();
@@ -304,22 +291,14 @@ hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hi
 
 hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
     const int chunks = c.kf_chunks, np = c.n_pairs;
-    const int groups = np >= 8 ? (np + 7) / 8 * 8 : np;
+    const int groups = grid_groups(np);
     dim3 grid(groups * chunks), blk(kBlock);
     // (buckets bkt[] and the per-tile histograms counts[] were produced by k_scan1_spherical)
     hipError_t e = launch_class_scan(w.counts, w.tile_base, w.bucket_start, kMaxBuckets, chunks, np, st);
     if (e != hipSuccess) return e;
     k_rs_scatter<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, w.keyA, w.valA, np, chunks);
     ICET_LAUNCH_CHECK();
-    static bool attr_done[64] = {};          // per device: a process may hold contexts on several GPUs
-    int dev_ = 0; (void)hipGetDevice(&dev_);
-    bool& attr_set = attr_done[dev_ & 63];
-    if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_bucket_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_sort_lds_bytes(kCapMax));
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const int cap = rank_sort_cap(c.max_n1);
+    const int cap = rank_sort_cap(c.max_n1, c.rs_cap);
     k_rs_bucket_sort<<<dim3(groups * kMaxBuckets), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, w.keyA, w.valA, w.keyB,
                                                                                              reinterpret_cast<uint32_t*>(w.key64A), w.valB, w.pred, cap, np);
     ICET_LAUNCH_CHECK();

@@ -1,0 +1,240 @@
+// icet_amd/csrc/icet_solve.hip -- the per-voxel and 6x6 part of one Gauss-Newton iteration (ICET::fitScan2,
+// /root/reference/src/icet.cpp:372-436, after the point pass of icet_accumulate.hip):
+//     k_init_state   X = X0, transform record
+//     k_gn_solve     per-voxel fitCells2 algebra (:314-338), block reduction of H^T W H and H^T W dz (:401-402), 6x6
+//                    covariance (:410-417), conditioning (:443-492), dx and X += dx (:427-433); one block per pair
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "icet_internal.h"
+#include "icet_device_common.h"
+#include "icet_device_math.h"
+
+namespace icet {
+namespace {
+
+// Per-pair transform record, kXf floats: t[3] | R[9] (utils::R, src/utils.cpp:144-152, row-major) | angles[3] | pad |
+// J[27] (get_H's three derivative matrices, src/icet.cpp:507-529).  Written once per iteration by the lane that updates
+// X, so the six sin/cos are evaluated once and serve both the next point pass (R) and the next voxel pass (J).
+constexpr int kXf = 48;
+__device__ __forceinline__ void write_xf(float* xf, const float X[6]) {
+    const float phi = X[3], theta = X[4], psi = X[5];
+    float sph, cph, sth, cth, sps, cps;
+    sincosf(phi, &sph, &cph); sincosf(theta, &sth, &cth); sincosf(psi, &sps, &cps);
+    xf[0] = X[0]; xf[1] = X[1]; xf[2] = X[2];
+    xf[3] = cth * cps;  xf[4] = sps * cph + sph * sth * cps;  xf[5] = sph * sps - sth * cph * cps;
+    xf[6] = -sps * cth; xf[7] = cph * cps - sph * sth * sps;  xf[8] = sph * cps + sth * sps * cph;
+    xf[9] = sth;        xf[10] = -sph * cth;                  xf[11] = cph * cth;
+    xf[12] = phi; xf[13] = theta; xf[14] = psi; xf[15] = 0.f;
+    float* J = xf + 16;
+    J[0] = 0.f; J[1] = -sps * sph + cph * sth * cps; J[2] = cph * sps + sth * sph * cps;
+    J[3] = 0.f; J[4] = -sph * cps - cph * sth * sps; J[5] = cph * cps - sth * sps * sph;
+    J[6] = 0.f; J[7] = -cph * cth;                   J[8] = -sph * cth;
+    J[9] = -sth * cps;  J[10] = cth * sph * cps;  J[11] = -cth * cph * cps;
+    J[12] = sps * sth;  J[13] = -cth * sph * sps; J[14] = cth * sps * cph;
+    J[15] = cth;        J[16] = sph * sth;        J[17] = -sth * cph;
+    J[18] = -cth * sps; J[19] = cps * cph - sph * sth * sps;  J[20] = cps * sph + sth * cph * sps;
+    J[21] = -cps * cth; J[22] = -sps * cph - sph * sth * cps; J[23] = -sph * sps + sth * cps * cph;
+    J[24] = 0.f; J[25] = 0.f; J[26] = 0.f;
+}
+
+__global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X, float* __restrict__ xf, int n_pairs) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    float x[6];
+    for (int k = 0; k < 6; k++) { x[k] = x0 ? x0[p * 6 + k] : 0.f; X[p * 6 + k] = x[k]; }
+    write_xf(xf + p * kXf, x);
+}
+
+// fitCells2's per-voxel algebra + reduction + the 6x6 solve.  One block per pair.
+__global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__ n_slots, const SlotFit* __restrict__ fitS, uint32_t* __restrict__ acc,
+                                                     float* __restrict__ X_all, float* __restrict__ xf_all, float* __restrict__ out, AuxDev aux,
+                                                     int V, int n, int iter, int runlen) {
+    __shared__ float J[27];
+    __shared__ float red[kBlock / 64][27];
+    const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* X = X_all + pair * 6;
+    if (threadIdx.x < 27) J[threadIdx.x] = xf_all[pair * kXf + 16 + threadIdx.x];      // written by the previous update (write_xf)
+    __syncthreads();
+    const int ns = n_slots[pair];
+    float S[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) S[k] = 0.f;
+    for (int s = threadIdx.x; s < ns; s += kBlock) {
+        uint32_t* A = acc + ((size_t)pair * V + s) * kAccWords;
+        const uint32_t n2 = A[0], m = A[1];
+        float sd[3], sdd[6];
+        const long long* AF = reinterpret_cast<const long long*>(A + 2);
+#pragma unroll
+        for (int k = 0; k < 3; k++) sd[k] = (float)((double)AF[k] * kFixInv);
+#pragma unroll
+        for (int k = 0; k < 6; k++) sdd[k] = (float)((double)AF[3 + k] * kFixInv);
+#pragma unroll
+        for (int k = 0; k < kAccWords; k++) A[k] = 0u;           // ready for the next iteration
+        const SlotFit f = fitS[(size_t)pair * V + s];
+        if (aux.n2_raw) aux.n2_raw[((size_t)pair * runlen + iter) * V + f.v] = (int)n2;
+        if (aux.n2_in) aux.n2_in[((size_t)pair * runlen + iter) * V + f.v] = (int)m;
+        if (!((int)n2 > n && (int)m > n)) continue;               // src/icet.cpp:290 (scan-2 half), :302
+        const float fm = (float)m;
+        const float db[3] = {sd[0] / fm, sd[1] / fm, sd[2] / fm};   // mean - mu1
+        const float mu2[3] = {f.mu[0] + db[0], f.mu[1] + db[1], f.mu[2] + db[2]};
+        const float den = (float)(m - 1), d2 = (float)(n2 - 1);
+        // R_noise = sigma1/(|idx1|-1) + cov2/(|idx2|-1)                         src/icet.cpp:315
+        float Rn[6];
+        Rn[0] = f.s1n[0] + ((sdd[0] - fm * db[0] * db[0]) / den) / d2;
+        Rn[1] = f.s1n[1] + ((sdd[1] - fm * db[0] * db[1]) / den) / d2;
+        Rn[2] = f.s1n[2] + ((sdd[2] - fm * db[0] * db[2]) / den) / d2;
+        Rn[3] = f.s1n[3] + ((sdd[3] - fm * db[1] * db[1]) / den) / d2;
+        Rn[4] = f.s1n[4] + ((sdd[4] - fm * db[1] * db[2]) / den) / d2;
+        Rn[5] = f.s1n[5] + ((sdd[5] - fm * db[2] * db[2]) / den) / d2;
+        // Rp = M Rn M^T  (M = L U^T)                                             src/icet.cpp:317
+        const float* M = f.M;
+        float MR[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            MR[3 * i + 0] = M[3 * i] * Rn[0] + M[3 * i + 1] * Rn[1] + M[3 * i + 2] * Rn[2];
+            MR[3 * i + 1] = M[3 * i] * Rn[1] + M[3 * i + 1] * Rn[3] + M[3 * i + 2] * Rn[4];
+            MR[3 * i + 2] = M[3 * i] * Rn[2] + M[3 * i + 1] * Rn[4] + M[3 * i + 2] * Rn[5];
+        }
+        float Rp[6];
+        Rp[0] = MR[0] * M[0] + MR[1] * M[1] + MR[2] * M[2];
+        Rp[1] = MR[0] * M[3] + MR[1] * M[4] + MR[2] * M[5];
+        Rp[2] = MR[0] * M[6] + MR[1] * M[7] + MR[2] * M[8];
+        Rp[3] = MR[3] * M[3] + MR[4] * M[4] + MR[5] * M[5];
+        Rp[4] = MR[3] * M[6] + MR[4] * M[7] + MR[5] * M[8];
+        Rp[5] = MR[6] * M[6] + MR[7] * M[7] + MR[8] * M[8];
+        float W[6];
+        icetdev::pinv3_sym(Rp, 3.0f * FLT_EPSILON, W);                        // src/icet.cpp:320-321
+        // H_z = M * [-I | Jx mu | Jy mu | Jz mu]                                  src/icet.cpp:324-329
+        float Hj[9];      // columns 3..5 of H_j, row-major 3x3
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            Hj[3 * i + 0] = J[3 * i] * mu2[0] + J[3 * i + 1] * mu2[1] + J[3 * i + 2] * mu2[2];
+            Hj[3 * i + 1] = J[9 + 3 * i] * mu2[0] + J[9 + 3 * i + 1] * mu2[1] + J[9 + 3 * i + 2] * mu2[2];
+            Hj[3 * i + 2] = J[18 + 3 * i] * mu2[0] + J[18 + 3 * i + 1] * mu2[1] + J[18 + 3 * i + 2] * mu2[2];
+        }
+        float Hz[18];     // 3 x 6 row-major
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            Hz[6 * i + 0] = -M[3 * i]; Hz[6 * i + 1] = -M[3 * i + 1]; Hz[6 * i + 2] = -M[3 * i + 2];
+#pragma unroll
+            for (int j = 0; j < 3; j++) Hz[6 * i + 3 + j] = M[3 * i] * Hj[j] + M[3 * i + 1] * Hj[3 + j] + M[3 * i + 2] * Hj[6 + j];
+        }
+        float WH[18];     // W * Hz
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            WH[j]      = W[0] * Hz[j] + W[1] * Hz[6 + j] + W[2] * Hz[12 + j];
+            WH[6 + j]  = W[1] * Hz[j] + W[3] * Hz[6 + j] + W[4] * Hz[12 + j];
+            WH[12 + j] = W[2] * Hz[j] + W[4] * Hz[6 + j] + W[5] * Hz[12 + j];
+        }
+        // dz = M (mu2 - mu1)                                                       src/icet.cpp:335-337
+        float dz[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) dz[i] = M[3 * i] * db[0] + M[3 * i + 1] * db[1] + M[3 * i + 2] * db[2];
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int b = a; b < 6; b++) { S[q] += Hz[a] * WH[b] + Hz[6 + a] * WH[6 + b] + Hz[12 + a] * WH[12 + b]; q++; }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) S[21 + a] += WH[a] * dz[0] + WH[6 + a] * dz[1] + WH[12 + a] * dz[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 27; k++) { float t = wave_sum(S[k]); if (lane == 0) red[wave][k] = t; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+
+    float Hm[36], g[6];
+    {
+        int q = 0;
+        for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) {
+            float t = 0.f; for (int w = 0; w < kBlock / 64; w++) t += red[w][q];
+            Hm[a * 6 + b] = t; Hm[b * 6 + a] = t; q++;
+        }
+        for (int a = 0; a < 6; a++) { float t = 0.f; for (int w = 0; w < kBlock / 64; w++) t += red[w][21 + a]; g[a] = t; }
+    }
+    // Normal case first: HTWH positive definite with condition number <= 1e6.  Then nothing is pruned
+    // (checkCondition's cutoff, src/icet.cpp:453,469), every eigenvalue is above the pseudo-inverse's rank threshold
+    // (eps * 6 < 1e-6), pinv(HTWH) is the inverse and dx = HTWH^-1 HTWdz -- a Cholesky factorisation gives both.
+    // cond_2 <= |A|_F |A^-1|_F, so that product <= 1e6 PROVES the case without an eigen-solve.  When the bound is
+    // inconclusive the eigenvalues decide, exactly as the reference does, and only a genuinely ill-conditioned or
+    // rank-deficient HTWH takes the eigenvector route with its pruning.
+    float ev[6];
+    float cov[36], ps[6], dx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool plain = icetdev::chol6_inverse(Hm, cov);
+    if (plain) {
+        float fa = 0.f, fi = 0.f;
+        for (int k = 0; k < 36; k++) { fa += Hm[k] * Hm[k]; fi += cov[k] * cov[k]; }
+        if (!(fa * fi <= 1e12f)) {                                  // bound inconclusive (or NaN): ask the eigenvalues
+            icetdev::eig6_sym<false>(Hm, ev, nullptr);
+            float emax = 0.f;
+            for (int k = 0; k < 6; k++) emax = fmaxf(emax, fabsf(ev[k]));
+            plain = !(fabsf(ev[5] / ev[0]) > 1e6f);
+            for (int k = 0; k < 6; k++) plain = plain && (fabsf(ev[k]) > 6.0f * FLT_EPSILON * emax);
+        }
+    }
+    if (plain) {
+        for (int k = 0; k < 6; k++) ps[k] = sqrtf(fabsf(cov[k * 6 + k]));         // src/icet.cpp:412-417
+        for (int a = 0; a < 6; a++) { float t = 0.f; for (int b = 0; b < 6; b++) t += cov[a * 6 + b] * g[b]; dx[a] = t; }
+    } else {
+        float Q[36];
+        icetdev::eig6_sym<true>(Hm, ev, Q);
+        float emax = 0.f;
+        for (int k = 0; k < 6; k++) emax = fmaxf(emax, fabsf(ev[k]));
+        const float rthr = 6.0f * FLT_EPSILON * emax;              // rank rule eps*6 relative to the largest eigenvalue
+        // noise_mat = pinv(HTWH) (src/icet.cpp:410-411)
+        float inv[6];
+        for (int k = 0; k < 6; k++) inv[k] = (fabsf(ev[k]) > rthr) ? 1.f / ev[k] : 0.f;
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) {
+            float t = 0.f; for (int k = 0; k < 6; k++) t += Q[a * 6 + k] * inv[k] * Q[b * 6 + k];
+            cov[a * 6 + b] = t;
+        }
+        for (int k = 0; k < 6; k++) ps[k] = sqrtf(fabsf(cov[k * 6 + k]));         // src/icet.cpp:412-417
+        // checkCondition (src/icet.cpp:443-492)
+        int k0 = 0;
+        {
+            float condition = ev[5] / ev[0];
+            int eyecount = 1;
+            while (fabsf(condition) > 1e6f && eyecount < 6) {
+                for (int k = 0; k < 6; k++) ps[k] += Q[k * 6 + eyecount - 1];       // src/icet.cpp:479
+                k0++;
+                condition = ev[5] / ev[eyecount];
+                eyecount++;
+            }
+        }
+        // dx = pinv(L2 lam U2^T) L2 U2^T HTWdz  = sum_{k >= k0} q_k (q_k . g) / lam_k     src/icet.cpp:427-430
+        for (int k = k0; k < 6; k++) {
+            if (inv[k] == 0.f) continue;
+            float pj = 0.f; for (int a = 0; a < 6; a++) pj += Q[a * 6 + k] * g[a];
+            pj *= inv[k];
+            for (int a = 0; a < 6; a++) dx[a] += Q[a * 6 + k] * pj;
+        }
+    }
+    float Xn[6];
+    for (int k = 0; k < 6; k++) { Xn[k] = X[k] + dx[k]; X[k] = Xn[k]; }
+    write_xf(xf_all + pair * kXf, Xn);
+    float* o = out + (size_t)pair * 48;
+    for (int k = 0; k < 6; k++) { o[k] = Xn[k]; o[6 + k] = ps[k]; }
+    for (int k = 0; k < 36; k++) o[12 + k] = cov[k];
+    if (aux.x_hist) for (int k = 0; k < 6; k++) aux.x_hist[((size_t)pair * runlen + iter) * 6 + k] = Xn[k];
+    if (aux.htwh) for (int k = 0; k < 36; k++) aux.htwh[((size_t)pair * runlen + iter) * 36 + k] = Hm[k];
+    if (aux.htwdz) for (int k = 0; k < 6; k++) aux.htwdz[((size_t)pair * runlen + iter) * 6 + k] = g[k];
+}
+}  // namespace
+
+#define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st) {
+    k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* auxp, hipStream_t st) {
+    AuxDev aux{}; if (auxp) aux = *auxp;
+    k_gn_solve<<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace icet

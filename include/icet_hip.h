@@ -27,7 +27,7 @@ typedef enum icet_status {
     ICET_ERR_NO_DEVICE = 2,   /* no HIP device / device id out of range                          */
     ICET_ERR_HIP = 3,         /* a HIP runtime call or kernel launch failed (see icet_last_error) */
     ICET_ERR_NOMEM = 4,       /* device or host allocation failed                                 */
-    ICET_ERR_UNSUPPORTED = 5  /* e.g. bins_phi*bins_theta above the compiled voxel limit          */
+    ICET_ERR_UNSUPPORTED = 5  /* e.g. bins_phi*bins_theta above the voxel limit (10000: 16 B of one block's LDS per voxel) */
 } icet_status;
 
 /* Mirrors the reference constructor's scalar arguments (include/icet.h:38-40, defaults n=25,
@@ -122,12 +122,23 @@ icet_status icet_reserve(icet_ctx* ctx, const icet_params* p, int32_t n_pairs, i
 icet_status icet_last_timing(icet_ctx* ctx, float out_ms[4]);
 
 /* Diagnostic hook for the parity tests: copy an internal per-point array of the scan-1 (keyframe) build
- * of the most recent call to the host.  `what`: 0 = r, 1 = theta, 2 = phi of scan 1 in input order
- * (float32, utils::cartesianToSpherical, src/utils.cpp:93-119); 3 = int32 src[v], the original row that
+ * of the most recent call to the host.  `what`: 0 = float32 r of scan 1 in input order
+ * (utils::cartesianToSpherical, src/utils.cpp:99,116); 1 = uint16 per row: bits 0-13 the row's voxel
+ * bins_theta * binPhi + binTheta (sortSphericalCoordinates, src/icet.cpp:545-549), bit 14 "classified with
+ * the literal formulas", bit 15 "the swap loop executes its step at this row" (theta / phi themselves are
+ * not materialised: only decisions and the Gaussians need them); 3 = int32 src[v], the original row that
  * sits at position v after the reference's sort + swap loop (src/icet.cpp:72-83); 4 = int32 per-pair
  * flags (bit 0: the bounded parallel walk overflowed and the serial replay was used).  `count` elements
  * from the start of the batch's concatenated scan-1 arrays (pairs for what = 4). */
 icet_status icet_debug_fetch(icet_ctx* ctx, int32_t what, void* out, int64_t count);
+
+/* Launch-shape and diagnostic knobs of ONE context (the library never reads the environment).  Every value
+ * yields the same result bits; defaults are the measured optima.  Names: "lds_slots", "acc_pts",
+ * "acc_blocks", "kf_pts", "rs_cap", "batch_parts" (0 = automatic), "batch_stage" (0..4), "force_exact"
+ * (every scan-2 point through the literal classification), "library_sort" (rocPRIM radix sort instead of
+ * the hand-written rank sort), "guard_scale" (>= 1), "lut_polar_quantile" (0..1).  Unknown name or value
+ * out of range: ICET_ERR_BAD_ARG. */
+icet_status icet_set_option(icet_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus
 }

@@ -81,10 +81,18 @@ def make_params(runlen=7, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1
     return Params(runlen, bins_phi, bins_theta, n, thresh, buff, mode)
 
 
+def voxel_of(sph, bins_phi=24, bins_theta=75):
+    """sortSphericalCoordinates' voxel T * binPhi + binTheta of every row of c2s() output (src/icet.cpp:545-549)."""
+    bt = ((sph[:, 1].astype(np.float64) / (2 * np.pi)) * bins_theta).astype(np.int64) % bins_theta
+    bp = ((sph[:, 2].astype(np.float64) / np.pi) * bins_phi).astype(np.int64) % bins_phi
+    return bins_theta * bp + bt
+
+
 def solve(scan1, scan2, x0=None, trace=False, sign_ref=None, **kw):
     """Run the restated ICET constructor.  Returns dict(X, pred_stds, cov[, trace arrays]).
-    sign_ref: optional (V, 3, 3) eigenvectors (as columns) of another implementation; the oracle's eigenvector signs are
-    aligned with them (icet_oracle_solve_signed) and the number of flipped columns is returned as ``n_sign_flips``."""
+    sign_ref (DIAGNOSTIC, scripts/ only -- no test uses it since the shared arithmetic rule made the signs agree): optional
+    (V, 3, 3) eigenvectors (as columns) of another implementation; the oracle's eigenvector signs are aligned with them
+    (icet_oracle_solve_signed) and the number of flipped columns is returned as ``n_sign_flips``."""
     p = make_params(**kw)
     s1, s2 = colmajor(scan1), colmajor(scan2)
     x0 = np.zeros(6, np.float32) if x0 is None else np.asarray(x0, np.float32).copy()

@@ -1,6 +1,8 @@
-"""Diagnostic: per-pair |X_gpu - X_oracle| over the bench batch, with the oracle's natural eigenvector signs and with its
-signs aligned to the device's (oracle/pyoracle.solve(sign_ref=...)).  Run on the GPU box.  env N = number of pairs."""
-import os, sys
+"""Diagnostic / measurement behind DESIGN.md section 7: the device against the UNMODIFIED oracle (natural eigenvector signs) over
+the bench batch -- keyframe bit-exactness per pair, and the per-quantity maxima of the Gauss-Newton result that the test
+tolerances are derived from.  Also how far the oracle itself moves between its two arithmetic modes (shared rule vs the literal
+float-libm expression types, ICET_ORACLE_LIBMF).  Run on the GPU box.  env N = number of pairs (default 256)."""
+import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import icet_amd
@@ -15,23 +17,41 @@ h1 = [p[0].T.cpu().numpy() for p in pairs]; h2 = [p[1].T.cpu().numpy() for p in 
 ctx = icet_amd.Context(0)
 gpu = [ctx.solve(h1[k], h2[k], 7, np.zeros(6), 24, 75, aux=True) for k in range(N)]
 def one(k):
-    nat = po.solve(h1[k], h2[k])
-    ali = po.solve(h1[k], h2[k], sign_ref=gpu[k]["aux"]["evecs1"])
-    return nat["X"], ali["X"], ali["n_sign_flips"], int(gpu[k]["aux"]["has_fit"].sum())
+    ref = po.solve(h1[k], h2[k], trace=True)
+    lm = po.solve(h1[k], h2[k], mode=po.LIBMF)
+    return ref, lm["X"]
 with ThreadPoolExecutor(16) as ex:
     res = list(ex.map(one, range(N)))
-X = np.stack([g["X"] for g in gpu])
-dn = np.abs(X - np.stack([r[0] for r in res])); da = np.abs(X - np.stack([r[1] for r in res]))
-flips = np.array([r[2] for r in res]); fits = np.array([r[3] for r in res])
-print("natural signs : pairs with dt > 3e-4: %d, dr > 1e-4: %d of %d; max dt %.2e" % ((dn[:, :3].max(1) > 3e-4).sum(), (dn[:, 3:].max(1) > 1e-4).sum(), N, dn[:, :3].max()))
-print("aligned signs : pairs with dt > 3e-4: %d, dr > 1e-4: %d of %d; max dt %.2e max dr %.2e" % ((da[:, :3].max(1) > 3e-4).sum(), (da[:, 3:].max(1) > 1e-4).sum(), N, da[:, :3].max(), da[:, 3:].max()))
-print("eigenvector columns flipped: %d of %d (%.3f %%), in %d pairs" % (flips.sum(), 3 * fits.sum(), 100.0 * flips.sum() / (3 * fits.sum()), (flips > 0).sum()))
-for k in np.argsort(-da[:, :3].max(1))[:5]:
-    # the oracle's own answer under a 1-ulp perturbation of scan 2 (same sign alignment): how much of the difference is the pair's sensitivity
-    rng = np.random.default_rng(123); sens = np.zeros(6)
-    base = res[k][1]
+kf_bad, cols, sign_diff, lmask_diff, fits = [], 0, 0, 0, 0
+dX = np.zeros((N, 6)); dps = np.zeros(N); dcov = np.zeros(N); dlib = np.zeros((N, 6))
+for k in range(N):
+    ref, xl = res[k]; t, ax = ref["trace"], gpu[k]["aux"]
+    f = t["has_fit"] == 1
+    same = (np.array_equal(ax["n1_raw"], t["n1_raw"]) and np.array_equal(ax["cluster_bounds"], t["bounds"]) and np.array_equal(ax["has_fit"], t["has_fit"])
+            and all(np.array_equal(ax[g][f].view(np.uint32), t[o][f].view(np.uint32)) for g, o in (("mu1", "mu1"), ("sigma1", "sigma1"), ("evecs1", "evecs1"), ("l_diag", "Ldiag"))))
+    if not same: kf_bad.append(k)
+    dots = np.einsum("vij,vij->vj", ax["evecs1"][f], t["evecs1"][f])
+    cols += dots.size; sign_diff += int((dots < 0).sum()); lmask_diff += int((ax["l_diag"][f] != t["Ldiag"][f]).any(1).sum()); fits += int(f.sum())
+    dX[k] = np.abs(gpu[k]["X"] - ref["X"]); dlib[k] = np.abs(ref["X"] - xl)
+    dps[k] = np.abs(gpu[k]["pred_stds"] / ref["pred_stds"] - 1).max()
+    d = np.sqrt(np.abs(np.diag(ref["cov"]))); dcov[k] = (np.abs(gpu[k]["cov"] - ref["cov"]) / np.outer(d, d)).max()
+out = {
+    "pairs": N, "pairs_with_any_keyframe_bit_difference": len(kf_bad), "first_such": kf_bad[:8],
+    "eigenvector_columns": cols, "columns_with_opposite_sign": sign_diff, "fitted_voxels": fits, "L_masks_differing": lmask_diff,
+    "dX_t_max": float(dX[:, :3].max()), "dX_t_median": float(np.median(dX[:, :3].max(1))), "dX_t_p99": float(np.quantile(dX[:, :3].max(1), 0.99)),
+    "dX_r_max": float(dX[:, 3:].max()), "dX_r_median": float(np.median(dX[:, 3:].max(1))), "dX_r_p99": float(np.quantile(dX[:, 3:].max(1), 0.99)),
+    "rel_pred_stds_max": float(dps.max()), "rel_cov_max": float(dcov.max()),
+    "pairs_over_1e-4m_or_1e-5rad": int(((dX[:, :3].max(1) > 1e-4) | (dX[:, 3:].max(1) > 1e-5)).sum()),
+    "pairs_over_3e-4m_or_1e-4rad": int(((dX[:, :3].max(1) > 3e-4) | (dX[:, 3:].max(1) > 1e-4)).sum()),
+    "oracle_rule_vs_libmf_dX_t_max": float(dlib[:, :3].max()), "oracle_rule_vs_libmf_dX_t_median": float(np.median(dlib[:, :3].max(1))),
+    "oracle_rule_vs_libmf_pairs_over_3e-4m": int((dlib[:, :3].max(1) > 3e-4).sum()),
+}
+print(json.dumps(out, indent=1))
+worst = np.argsort(-dX[:, :3].max(1))[:6]
+for k in worst:
+    rng = np.random.default_rng(123); sens = np.zeros(6); base = res[k][0]["X"]
     for _ in range(3):
         bp = (h2[k].astype(np.float64) * (1.0 + rng.uniform(-1e-7, 1e-7, h2[k].shape))).astype(np.float32)
-        sens = np.maximum(sens, np.abs(po.solve(h1[k], bp, sign_ref=gpu[k]["aux"]["evecs1"])["X"] - base))
-    print("  pair %3d aligned dt %.2e dr %.2e (natural dt %.2e) flips %d | oracle 1-ulp sensitivity dt %.2e dr %.2e" % (
-        k, da[k, :3].max(), da[k, 3:].max(), dn[k, :3].max(), flips[k], sens[:3].max(), sens[3:].max()))
+        sens = np.maximum(sens, np.abs(po.solve(h1[k], bp)["X"] - base))
+    print("  pair %3d dt %.2e dr %.2e | oracle 1-ulp(scan 2) sensitivity dt %.2e dr %.2e | rule-vs-libmf dt %.2e" % (
+        k, dX[k, :3].max(), dX[k, 3:].max(), sens[:3].max(), sens[3:].max(), dlib[k, :3].max()))

@@ -25,20 +25,6 @@ constexpr int kAccBlock = ICET_ACC_BLOCK;        // k_gn_accumulate: the waves o
 constexpr int kAccWavesPerSimd = ICET_ACC_WAVES; // register budget: 6 -> 84 VGPRs, no spills, three 512-thread blocks per CU (with 1536 blocks per 256-pair launch: 130 -> 121 us); 8 spills
 constexpr int kXf = 48;                          // per-pair transform record, see write_xf (icet_solve.hip)
 
-// sortSphericalCoordinates' bin index WITHOUT the double divide: thr[k] is the smallest float whose
-// reference bin (double arithmetic, src/icet.cpp:545-546) is >= k, built on the host with exactly that
-// arithmetic, so "largest k with thr[k] <= a" is bit-for-bit the reference's truncation.  The float
-// product only proposes a candidate (off by at most one).  Returns nb when a lies beyond the last
-// edge (a == float(2 pi), float(pi) or the 1000 sentinel): the caller then takes the literal formula.
-__device__ __forceinline__ int bin_from_table(float a, const float* __restrict__ thr, int nb, float scale) {
-    int k = static_cast<int>(a * scale);
-    k = min(k, nb - 1);
-    const float lo = thr[k], hi = thr[k + 1];
-    k += (a >= hi) ? 1 : 0;
-    k -= (a < lo) ? 1 : 0;
-    return k;
-}
-
 // One pass of fitScan2's point work over a chunk of one pair's scan 2.
 //   points2 = (points2_OG.rowwise() + t) * R          src/icet.cpp:375-378
 //   cartesianToSpherical, sortSphericalCoordinates     src/icet.cpp:387-388
@@ -66,41 +52,6 @@ __device__ __forceinline__ int bin_from_table(float a, const float* __restrict__
 // partial sums, which are flushed with one global atomic per touched word at the end.
 // Block -> (pair, chunk) is XCD-aware: all chunks of a pair have equal blockIdx % 8, i.e. share an
 // XCD and therefore its L2 copy of the pair's tables (speed only, never correctness).
-struct PointClass { int s; bool inb; float dx, dy, dz; };
-
-// Literal evaluation of one transformed point: c2s (shared rule: correctly rounded theta / phi), bin, slot look-up,
-// 6-sided bounds test.  Kept out of line: it is reached by ~0.02 % of the points, and its double-precision atan2 / acos must
-// not share a register budget with the hot loop.
-__device__ __noinline__ void classify_exact(float qx, float qy, float qz, const int16_t* map, const float* __restrict__ thr, int T, int P,
-                                            const SlotHot* __restrict__ hs, PointClass& out) {
-    float r, th, ph;
-    c2s_cr(qx, qy, qz, r, th, ph);
-    const float scale_t = (float)((double)T / kTwoPi), scale_p = (float)((double)P / kPi);
-    int bt = bin_from_table(th, thr, T, scale_t);
-    int bp = bin_from_table(ph, thr + T + 1, P, scale_p);
-    if (bt >= T) bt = static_cast<int>(((double)th / kTwoPi) * (double)T) % T;
-    if (bp >= P) bp = static_cast<int>(((double)ph / kPi) * (double)P) % P;
-    const int s = map[T * bp + bt];
-    out.s = s; out.inb = false; out.dx = out.dy = out.dz = 0.f;
-    if (s >= 0) {
-        const SlotHot h = hs[s];
-        out.inb = inside_bounds(r, th, ph, h.az0, h.az1, h.el0, h.el1, h.inner, h.outer);
-        out.dx = qx - h.mu[0]; out.dy = qy - h.mu[1]; out.dz = qz - h.mu[2];
-    }
-}
-
-// Partial sums of a slot that has no LDS row go straight to HBM.  Kept out of line so that the LDS update above
-// stays a ds_add_* (a select between the two pointers would turn both into flat atomics).
-// float -> 64-bit fixed point (floor(v * 2^30), two's complement) in 6 VALU instructions: the scaling is exact (power of
-// two), h = floor(x / 2^32) is a small integer held exactly in a float, and x - h * 2^32 is exact under fma and lies in
-// [0, 2^32).  Any fixed rounding rule would do; what matters is that integer addition is associative.
-__device__ __forceinline__ unsigned long long to_fix(float v) {
-    const float x = v * kFixScale;
-    const float h = floorf(x * 2.3283064365386963e-10f);            // 2^-32
-    const float lo = fmaf(h, -4294967296.0f, x);
-    return ((unsigned long long)(uint32_t)(int)h << 32) | (unsigned long long)(uint32_t)lo;
-}
-
 // Two values at once: the three multiplies / the fma are packed-FP32 instructions (v_pk_mul_f32, v_pk_fma_f32).
 typedef float vfloat2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void to_fix2(float a, float b, unsigned long long& fa, unsigned long long& fb) {
@@ -113,15 +64,14 @@ __device__ __forceinline__ void to_fix2(float a, float b, unsigned long long& fa
     fb = ((unsigned long long)(uint32_t)(int)h.y << 32) | (unsigned long long)(uint32_t)lo.y;
 }
 
+// Partial sums of a slot that has no LDS row go straight to HBM.  Kept out of line so that the LDS update in the hot loop
+// stays a ds_add_* (a select between the two pointers would turn both into flat atomics).
 __device__ __noinline__ void spill_flush(uint32_t* A, uint32_t nraw, uint32_t nin, float S0, float S1, float S2, float S3, float S4,
                                          float S5, float S6, float S7, float S8) {
-    unsigned long long* F = reinterpret_cast<unsigned long long*>(A + 2);
-    atomicAdd(reinterpret_cast<unsigned long long*>(A), (unsigned long long)nraw | ((unsigned long long)nin << 32));   // A[0] raw, A[1] in: one 64-bit add
-    if (nin) {
-        atomicAdd(&F[0], to_fix(S0)); atomicAdd(&F[1], to_fix(S1)); atomicAdd(&F[2], to_fix(S2)); atomicAdd(&F[3], to_fix(S3)); atomicAdd(&F[4], to_fix(S4));
-        atomicAdd(&F[5], to_fix(S5)); atomicAdd(&F[6], to_fix(S6)); atomicAdd(&F[7], to_fix(S7)); atomicAdd(&F[8], to_fix(S8));
-    }
+    acc_add_hbm(A, nraw, nin, S0, S1, S2, S3, S4, S5, S6, S7, S8);
 }
+
+constexpr uint32_t kNearCap = 512;      // undecided points a block parks in LDS (2 KB); the rest goes to the per-pair overflow list in HBM
 
 typedef __attribute__((address_space(1))) const float gfloat;
 typedef float vfloat4 __attribute__((ext_vector_type(4)));
@@ -133,7 +83,8 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
                                                           const SlotHot* __restrict__ hotS, uint32_t* __restrict__ acc,
                                                           const float* __restrict__ thr, const LutCell* __restrict__ lut,
                                                           int T, int P, int Mt, int Mp, float guard_t, float guard_p,
-                                                          int lds_slots, int chunks, int n_pairs, int force_exact) {
+                                                          int lds_slots, int chunks, int n_pairs, int force_exact,
+                                                          uint32_t* __restrict__ near_over, uint32_t* __restrict__ near_over_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int V = T * P;
     int pair, chunk;
@@ -153,6 +104,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
     float* hot = reinterpret_cast<float*>(lacc + 10 * lds_slots);         // lds_slots x 5: inner, outer, mu1
     int16_t* map = reinterpret_cast<int16_t*>(hot + lds_slots * 5);
     const int map_words = (V + 1) / 2;
+    uint32_t* nearq = reinterpret_cast<uint32_t*>(map) + (V + T + 4) / 2;   // kNearCap point indices, then the fill counter
     const int ns = n_slots[pair];
     const int nl = min(ns, lds_slots);
     const SlotHot* hs = hotS + (size_t)pair * V;
@@ -166,6 +118,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
         for (int i = threadIdx.x; i < Mt + Mp + 2; i += kAccBlock) ll[i] = gl[i];
         for (int i = threadIdx.x; i < nl * 5; i += kAccBlock) { int s = i / 5, k = i - s * 5; hot[i] = reinterpret_cast<const float*>(hs + s)[4 + k]; }
         for (int i = threadIdx.x; i < 10 * nl; i += kAccBlock) lacc[i] = 0ull;   // only the rows in use
+        if (threadIdx.x == 0) nearq[kNearCap] = 0u;
     }
     const float* xf = xf_all + pair * kXf;
     const float tx = xf[0], ty = xf[1], tz = xf[2];
@@ -238,10 +191,11 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
         // that the four look-up chains overlap. ----
 #pragma unroll
         for (int j = 0; j < 4; j++) {
+            // == transform_point (icet_device_common.h), on the scalars already in registers: the deferred literal path must see the same bits
             const float a = X[j] + tx, b = Y[j] + ty, c = Z[j] + tz;
-            const float qx = a * R00 + b * R10 + c * R20;
-            const float qy = a * R01 + b * R11 + c * R21;
-            const float qz = a * R02 + b * R12 + c * R22;
+            const float qx = fmaf(c, R20, fmaf(b, R10, a * R00));
+            const float qy = fmaf(c, R21, fmaf(b, R11, a * R01));
+            const float qz = fmaf(c, R22, fmaf(b, R12, a * R02));
             QX[j] = qx; QY[j] = qy; QZ[j] = qz;
             const float r2 = qx * qx + qy * qy + qz * qz;
             const float rs = __builtin_amdgcn_rsqf(r2);
@@ -267,30 +221,45 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
         // ---- phase A2: only waves that touch an active voxel look at the hot records (radial test, d = q - mu1) ----
         const bool lane_has = ((SM[0] >= 0) & !nr[0]) | ((SM[1] >= 0) & !nr[1]) | ((SM[2] >= 0) & !nr[2]) | ((SM[3] >= 0) & !nr[3]);
         if (__ballot(lane_has) != 0ull) {
+            // A slot beyond the LDS table (more active voxels than lds_slots; the launch sizes the table so that this is rare) keeps
+            // its record in HBM.  Its points stay in the lane's runs like any other -- how the sums are grouped must not depend on a
+            // launch-shape knob, or the knob would show in the result bits -- so the record is fetched here, in a wave-uniform branch
+            // that ordinary waves skip (every LDS access stays a ds_* instruction, every HBM access a global_*).
+            const bool beyond = __ballot(((SM[0] >= nl) & !nr[0]) | ((SM[1] >= nl) & !nr[1]) | ((SM[2] >= nl) & !nr[2]) | ((SM[3] >= nl) & !nr[3])) != 0ull;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int sm = SM[j];
                 const bool has = (sm >= 0) & !nr[j];
-                // slots beyond the LDS table (more active voxels than lds_slots) are classified by the literal path,
-                // which reads its record from HBM: keeps every LDS access a ds_* instruction.
                 const float* h = hot + min(max(sm, 0), lds_slots - 1) * 5;
-                const float inner = h[0], outer = h[1];
+                float inner = h[0], outer = h[1], m0 = h[2], m1 = h[3], m2 = h[4];
+                if (beyond) {
+                    if (has & (sm >= nl)) { const SlotHot g = hs[sm]; inner = g.inner; outer = g.outer; m0 = g.mu[0]; m1 = g.mu[1]; m2 = g.mu[2]; }
+                }
                 const float r = RR[j];
                 const float gr = 1e-6f * r;
-                nr[j] = nr[j] | (has & ((sm >= nl) | !(fabsf(r - inner) >= gr) | !(fabsf(r - outer) >= gr)));
+                nr[j] = nr[j] | (has & (!(fabsf(r - inner) >= gr) | !(fabsf(r - outer) >= gr)));
                 pc[j].s = nr[j] ? -1 : sm;
                 pc[j].inb = has & (r >= inner) & (r <= outer);
-                pc[j].dx = QX[j] - h[2]; pc[j].dy = QY[j] - h[3]; pc[j].dz = QZ[j] - h[4];
+                pc[j].dx = QX[j] - m0; pc[j].dy = QY[j] - m1; pc[j].dz = QZ[j] - m2;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) { pc[j].s = -1; pc[j].inb = false; pc[j].dx = pc[j].dy = pc[j].dz = 0.f; }
         }
-        // ---- phase B (rare): points within a guard band of a voxel edge are re-done with the literal formulas ----
+        // ---- phase B (rare): a point within a guard band of a voxel edge must be classified with the literal formulas (double-
+        // precision atan2 / acos).  Not here: a call or that much code inside this loop costs every trip registers and scratch
+        // traffic (measured: 119 -> 238 us per launch).  The point's INDEX is parked in the block's LDS queue and classified
+        // after the loop, as a run of one; past kNearCap entries (adversarial input, or the force_exact diagnostic) it goes to
+        // the pair's overflow list in HBM, which k_gn_solve drains.  Integer accumulation makes the order irrelevant. ----
         if (__ballot(nr[0] | nr[1] | nr[2] | nr[3]) != 0ull) {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (nr[j] & (i0 + j < end)) classify_exact(QX[j], QY[j], QZ[j], map, thr, T, P, hs, pc[j]);
+            for (int j = 0; j < 4; j++) {
+                if (nr[j] & (i0 + j < end)) {
+                    const uint32_t e = atomicAdd(&nearq[kNearCap], 1u);
+                    if (e < kNearCap) nearq[e] = (uint32_t)(i0 + j);
+                    else near_over[(size_t)d.off2 + atomicAdd(&near_over_count[pair], 1u)] = (uint32_t)(i0 + j);
+                }
+            }
         }
         const bool any_slot = (pc[0].s >= 0) | (pc[1].s >= 0) | (pc[2].s >= 0) | (pc[3].s >= 0);
         if (__ballot(any_slot | (cur >= 0)) == 0ull) continue;           // wave-uniform: nothing here lands in an active voxel and no run is open
@@ -324,6 +293,31 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
           flush(cur, nraw, nin, S0, S1, S2, S3, S4, S5, S6, S7, S8);
           if (__ballot(bs >= 0) != 0ull) flush(bs, braw, bin, B0, B1, B2, B3, B4, B5, B6, B7, B8);
       }
+    }
+    __syncthreads();
+    {   // ---- the parked points: literal classification, each a run of one ----
+        const uint32_t nq = min(nearq[kNearCap], kNearCap);
+        for (uint32_t e = threadIdx.x; e < nq; e += kAccBlock) {
+            const int i = (int)nearq[e];
+            float qx, qy, qz;
+            transform_point(px[i], py[i], pz[i], xf, qx, qy, qz);
+            PointClass pc1;
+            classify_literal(qx, qy, qz, map, thr, T, P, hs, pc1);
+            if (pc1.s >= 0) {
+                const float dx = pc1.dx, dy = pc1.dy, dz = pc1.dz;
+                unsigned long long* F = lacc + min(pc1.s, nl > 0 ? nl - 1 : 0) * 10;
+                if (pc1.s < nl) {
+                    atomicAdd(&F[0], 1ull | ((unsigned long long)(pc1.inb ? 1u : 0u) << 32));
+                    if (pc1.inb) {
+                        atomicAdd(&F[1], to_fix(dx)); atomicAdd(&F[2], to_fix(dy)); atomicAdd(&F[3], to_fix(dz));
+                        atomicAdd(&F[4], to_fix(dx * dx)); atomicAdd(&F[5], to_fix(dx * dy)); atomicAdd(&F[6], to_fix(dx * dz));
+                        atomicAdd(&F[7], to_fix(dy * dy)); atomicAdd(&F[8], to_fix(dy * dz)); atomicAdd(&F[9], to_fix(dz * dz));
+                    }
+                } else {
+                    acc_add_hbm(gacc + (size_t)pc1.s * kAccWords, 1u, pc1.inb ? 1u : 0u, dx, dy, dz, dx * dx, dx * dy, dx * dz, dy * dy, dy * dz, dz * dz);
+                }
+            }
+        }
     }
     __syncthreads();
     for (int s = threadIdx.x; s < nl; s += kAccBlock) {
@@ -361,7 +355,7 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     // spill busy voxels to HBM atomics, more rows cost occupancy); a small batch has
     // CUs to spare, so a block may take most of a CU's LDS and keep every active voxel of a fine grid (150 x 48: often
     // > 1000) out of the slow HBM-atomic path.
-    const size_t fixed = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)((c.V + c.T + 4) / 2) * 4 + 16;
+    const size_t fixed = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)((c.V + c.T + 4) / 2) * 4 + (kNearCap + 1) * 4 + 16;
     const size_t row = (5 + kAccLds) * 4;
     const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : 144 * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU
     int lds_slots = c.lds_slots > 0 ? c.lds_slots : (int)((budget > fixed ? budget - fixed : 0) / row);
@@ -373,10 +367,10 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     const LutCell* lut = reinterpret_cast<const LutCell*>(w.lut);
     if (c.vec4_ok)
         k_gn_accumulate<true><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp,
-                                                     w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact);
+                                                     w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count);
     else
         k_gn_accumulate<false><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp,
-                                                      w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact);
+                                                      w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -70,7 +70,7 @@ bool params_ok(const icet_params* p) {
     return true;
 }
 
-icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs, int64_t total_n1) {
+icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs, int64_t total_n1, int64_t total_n2) {
     Workspace& w = c->w;
     const int V = p->bins_phi * p->bins_theta;
     if ((int64_t)p->bins_phi * p->bins_theta > kMaxVoxels) { c->err = "bins_phi*bins_theta exceeds the voxel limit (10000: the multi-split keeps 16 B per voxel in one block's LDS)"; return ICET_ERR_UNSUPPORTED; }
@@ -89,7 +89,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, dev_realloc(w.hotD, pv)); HIPCHK(c, dev_realloc(w.fitD, pv)); HIPCHK(c, dev_realloc(w.activeD, pv)); HIPCHK(c, dev_realloc(w.midD, pv));
         HIPCHK(c, dev_realloc(w.hotS, pv)); HIPCHK(c, dev_realloc(w.fitS, pv));
         HIPCHK(c, dev_realloc(w.slot_of_voxel, (size_t)np * ((VV + 1) & ~1)));
-        HIPCHK(c, dev_realloc(w.n_slots, np));
+        HIPCHK(c, dev_realloc(w.n_slots, np)); HIPCHK(c, dev_realloc(w.near_over_count, np));
         HIPCHK(c, dev_realloc(w.acc, pv * kAccWords));
         HIPCHK(c, hipMemset(w.acc, 0, pv * kAccWords * sizeof(uint32_t)));
         HIPCHK(c, dev_realloc(w.xf, (size_t)np * 48));
@@ -102,6 +102,12 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_seg), sizeof(int32_t) * ((size_t)np + 1)));
         c->h_cap_pairs = np;
         w.cap_pairs = np; w.cap_V = VV;
+    }
+    if (total_n2 >= (int64_t)1 << 31) { c->err = "total scan-2 points per call must be < 2^31"; return ICET_ERR_UNSUPPORTED; }
+    if (total_n2 > w.cap_n2) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, dev_realloc(w.near_over, (size_t)total_n2));
+        w.cap_n2 = total_n2;
     }
     if (total_n1 > w.cap_n1 || grow_pairs) {
         const int64_t n = total_n1 > w.cap_n1 ? total_n1 : w.cap_n1;
@@ -251,9 +257,10 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     for (int k = 0; k < n_pairs; k++)
         if ((reinterpret_cast<uintptr_t>(c->h_desc[k].s2) & 15u) || (c->h_desc[k].ld2 & 3)) { cfg.vec4_ok = 0; break; }
     { icet_status ts = ensure_thresholds(c, cfg.T, cfg.P); if (ts != ICET_OK) return ts; }
-    int64_t tot = 0; int mx1 = 0, mx2 = 0;
+    int64_t tot = 0, tot2 = 0; int mx1 = 0, mx2 = 0;
     for (int k = 0; k < n_pairs; k++) {
         c->h_seg[k] = (int32_t)tot; c->h_desc[k].off1 = (int32_t)tot; tot += c->h_desc[k].n1;
+        c->h_desc[k].off2 = (int32_t)tot2; tot2 += c->h_desc[k].n2;
         if (c->h_desc[k].n1 > mx1) mx1 = c->h_desc[k].n1;
         if (c->h_desc[k].n2 > mx2) mx2 = c->h_desc[k].n2;
     }
@@ -339,7 +346,7 @@ icet_status icet_destroy(icet_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     Workspace& w = c->w;
     void* ps[] = {w.key64A, w.key64B, w.bin16, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.cart1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src,
-                  w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, w.xf, w.X, w.flags,
+                  w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.near_over, w.near_over_count, w.acc, w.xf, w.X, w.flags,
                   w.sort_tmp, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);
     free_aux(c);
@@ -378,12 +385,13 @@ icet_status icet_reserve(icet_ctx* c, const icet_params* p, int32_t n_pairs, int
         if (hs != ICET_OK) return hs;
         const int np = (n_pairs + parts - 1) / parts;
         const int64_t n1 = total_n1 / parts + total_n1 / (8 * parts) + 1;
-        for (icet_ctx* h : c->helpers) { hs = ensure_workspace(h, p, np, n1); if (hs != ICET_OK) { c->err = h->err; return hs; } }
-        hs = ensure_workspace(c, p, np, n1);
+        const int64_t n2 = total_n2 / parts + total_n2 / (8 * parts) + 1;
+        for (icet_ctx* h : c->helpers) { hs = ensure_workspace(h, p, np, n1, n2); if (hs != ICET_OK) { c->err = h->err; return hs; } }
+        hs = ensure_workspace(c, p, np, n1, n2);
         if (hs != ICET_OK) return hs;
         return ensure_out(c, n_pairs);
     }
-    icet_status s = ensure_workspace(c, p, n_pairs, total_n1);
+    icet_status s = ensure_workspace(c, p, n_pairs, total_n1, total_n2);
     if (s != ICET_OK) return s;
     return ensure_out(c, n_pairs);
 }
@@ -467,7 +475,8 @@ icet_status icet_solve_batch_device(icet_ctx* c, const icet_params* p, int32_t n
 
 static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1, const icet_dev_scan* scan2,
                                      const float* d_x0, float* d_out, int64_t tot1) {
-    icet_status s = ensure_workspace(c, p, n_pairs, tot1);
+    int64_t tot2 = 0; for (int k = 0; k < n_pairs; k++) tot2 += scan2[k].n;
+    icet_status s = ensure_workspace(c, p, n_pairs, tot1, tot2);
     if (s != ICET_OK) return s;
     // the previous call may still be copying out of the pinned descriptor staging; its kernels may still be running
     // (the device entry point never waits for them: calls queue up behind each other on the stream)
@@ -476,7 +485,7 @@ static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t 
         PairDesc& d = c->h_desc[k];
         d.s1 = scan1[k].ptr; d.s2 = scan2[k].ptr;
         d.n1 = (int32_t)scan1[k].n; d.ld1 = (int32_t)scan1[k].ld; d.n2 = (int32_t)scan2[k].n; d.ld2 = (int32_t)scan2[k].ld;
-        d.off1 = 0; d.pad = 0;
+        d.off1 = 0; d.off2 = 0;
     }
     if (p->runlen == 0) return write_runlen0(c, n_pairs, d_x0, d_out);
     return enqueue(c, p, n_pairs, d_x0, d_out, nullptr);
@@ -494,7 +503,7 @@ icet_status icet_solve_batch(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         tot1 += (n1[k] + 63) / 64 * 64; tot2 += (n2[k] + 63) / 64 * 64;
     }
     HIPCHK(c, hipSetDevice(c->device));
-    icet_status s = ensure_workspace(c, p, n_pairs, tot1);
+    icet_status s = ensure_workspace(c, p, n_pairs, tot1, tot2);
     if (s != ICET_OK) return s;
     s = ensure_out(c, n_pairs);
     if (s != ICET_OK) return s;
@@ -506,7 +515,7 @@ icet_status icet_solve_batch(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         const int64_t l1 = (n1[k] + 63) / 64 * 64, l2 = (n2[k] + 63) / 64 * 64;
         PairDesc& d = c->h_desc[k];
         d.s1 = c->d_stage1 + 3 * o1; d.s2 = c->d_stage2 + 3 * o2;
-        d.n1 = (int32_t)n1[k]; d.ld1 = (int32_t)l1; d.n2 = (int32_t)n2[k]; d.ld2 = (int32_t)l2; d.off1 = 0; d.pad = 0;
+        d.n1 = (int32_t)n1[k]; d.ld1 = (int32_t)l1; d.n2 = (int32_t)n2[k]; d.ld2 = (int32_t)l2; d.off1 = 0; d.off2 = 0;
         // host scans are dense column-major (ld == n) in this entry point
         if (n1[k]) HIPCHK(c, hipMemcpy2DAsync(c->d_stage1 + 3 * o1, l1 * sizeof(float), scan1[k], n1[k] * sizeof(float), n1[k] * sizeof(float), 3, hipMemcpyHostToDevice, c->stream));
         if (n2[k]) HIPCHK(c, hipMemcpy2DAsync(c->d_stage2 + 3 * o2, l2 * sizeof(float), scan2[k], n2[k] * sizeof(float), n2[k] * sizeof(float), 3, hipMemcpyHostToDevice, c->stream));
@@ -537,7 +546,7 @@ icet_status icet_solve(icet_ctx* c, const icet_params* p, const float* scan1, in
     HIPCHK(c, hipSetDevice(c->device));
     const int V = p->bins_phi * p->bins_theta;
     const int64_t l1 = (n1 + 63) / 64 * 64, l2 = (n2 + 63) / 64 * 64;
-    icet_status s = ensure_workspace(c, p, 1, l1);
+    icet_status s = ensure_workspace(c, p, 1, l1, l2);
     if (s != ICET_OK) return s;
     s = ensure_out(c, 1);
     if (s != ICET_OK) return s;
@@ -548,7 +557,7 @@ icet_status icet_solve(icet_ctx* c, const icet_params* p, const float* scan1, in
     if (n2) HIPCHK(c, hipMemcpy2DAsync(c->d_stage2, l2 * sizeof(float), scan2, ld2 * sizeof(float), n2 * sizeof(float), 3, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_x0, x0, sizeof(float) * 6, hipMemcpyHostToDevice, c->stream));
     PairDesc& d = c->h_desc[0];
-    d.s1 = c->d_stage1; d.s2 = c->d_stage2; d.n1 = (int32_t)n1; d.ld1 = (int32_t)l1; d.n2 = (int32_t)n2; d.ld2 = (int32_t)l2; d.off1 = 0; d.pad = 0;
+    d.s1 = c->d_stage1; d.s2 = c->d_stage2; d.n1 = (int32_t)n1; d.ld1 = (int32_t)l1; d.n2 = (int32_t)n2; d.ld2 = (int32_t)l2; d.off1 = 0; d.off2 = 0;
     const AuxDev* ad = nullptr;
     if (aux) {
         s = ensure_aux(c, V, p->runlen);

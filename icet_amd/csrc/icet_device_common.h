@@ -168,6 +168,74 @@ __device__ __forceinline__ void classify_angular_fast(float qx, float qy, float 
     prow = ep.idx - ((w < ep.edge) ? T : 0);                             // T * polar bin, polar bin in [0, P]
     near = !(fabsf(pa - et.edge) >= guard_t) | !(fabsf(w - ep.edge) >= guard_p);
 }
+// ---- the literal path for points the fast classification cannot decide ------------------------------------------------
+// sortSphericalCoordinates' bin index WITHOUT the double divide: thr[k] is the smallest float whose reference bin (double
+// arithmetic, src/icet.cpp:545-546) is >= k, built on the host with exactly that arithmetic, so "largest k with
+// thr[k] <= a" is bit-for-bit the reference's truncation.  The float product only proposes a candidate (off by at most
+// one).  Returns nb when a lies beyond the last edge (a == float(2 pi), float(pi) or the 1000 sentinel): the caller then
+// takes the literal formula.
+__device__ __forceinline__ int bin_from_table(float a, const float* __restrict__ thr, int nb, float scale) {
+    int k = static_cast<int>(a * scale);
+    k = min(k, nb - 1);
+    const float lo = thr[k], hi = thr[k + 1];
+    k += (a >= hi) ? 1 : 0;
+    k -= (a < lo) ? 1 : 0;
+    return k;
+}
+
+// points2 = (points2_OG.rowwise() + t) * R (src/icet.cpp:375-378) for one point.  xf = t[3] | R[9] row-major.  The fused
+// multiply-adds are written out so that every place that transforms a point (the hot loop, the deferred literal path) gets
+// the same bits whatever the compiler's contraction choices.
+__device__ __forceinline__ void transform_point(float x, float y, float z, const float* __restrict__ xf, float& qx, float& qy, float& qz) {
+    const float a = x + xf[0], b = y + xf[1], c = z + xf[2];
+    qx = fmaf(c, xf[9], fmaf(b, xf[6], a * xf[3]));
+    qy = fmaf(c, xf[10], fmaf(b, xf[7], a * xf[4]));
+    qz = fmaf(c, xf[11], fmaf(b, xf[8], a * xf[5]));
+}
+
+struct PointClass { int s; bool inb; float dx, dy, dz; };
+
+// Literal evaluation of one transformed point: cartesianToSpherical under the shared rule (correctly rounded theta / phi),
+// bin, slot look-up, 6-sided bounds test (src/icet.cpp:387-388, 299).  map: voxel -> slot (int16, -1 = inactive).
+__device__ __forceinline__ void classify_literal(float qx, float qy, float qz, const int16_t* map, const float* __restrict__ thr, int T, int P,
+                                                 const SlotHot* __restrict__ hs, PointClass& out) {
+    float r, th, ph;
+    c2s_cr(qx, qy, qz, r, th, ph);
+    const float scale_t = (float)((double)T / kTwoPi), scale_p = (float)((double)P / kPi);
+    int bt = bin_from_table(th, thr, T, scale_t);
+    int bp = bin_from_table(ph, thr + T + 1, P, scale_p);
+    if (bt >= T) bt = static_cast<int>(((double)th / kTwoPi) * (double)T) % T;
+    if (bp >= P) bp = static_cast<int>(((double)ph / kPi) * (double)P) % P;
+    const int s = map[T * bp + bt];
+    out.s = s; out.inb = false; out.dx = out.dy = out.dz = 0.f;
+    if (s >= 0) {
+        const SlotHot h = hs[s];
+        out.inb = inside_bounds(r, th, ph, h.az0, h.az1, h.el0, h.el1, h.inner, h.outer);
+        out.dx = qx - h.mu[0]; out.dy = qy - h.mu[1]; out.dz = qz - h.mu[2];
+    }
+}
+
+// float -> 64-bit fixed point (floor(v * 2^36), two's complement) in 6 VALU instructions: the scaling is exact (power of
+// two), h = floor(x / 2^32) is a small integer held exactly in a float, and x - h * 2^32 is exact under fma and lies in
+// [0, 2^32).  Any fixed rounding rule would do; what matters is that integer addition is associative.
+__device__ __forceinline__ unsigned long long to_fix(float v) {
+    const float x = v * kFixScale;
+    const float h = floorf(x * 2.3283064365386963e-10f);            // 2^-32
+    const float lo = fmaf(h, -4294967296.0f, x);
+    return ((unsigned long long)(uint32_t)(int)h << 32) | (unsigned long long)(uint32_t)lo;
+}
+
+// One run's partial sums into a slot's HBM accumulator record (kAccWords words: [raw | in << 32], then 9 fixed-point sums).
+__device__ __forceinline__ void acc_add_hbm(uint32_t* A, uint32_t nraw, uint32_t nin, float S0, float S1, float S2, float S3, float S4,
+                                            float S5, float S6, float S7, float S8) {
+    unsigned long long* F = reinterpret_cast<unsigned long long*>(A + 2);
+    atomicAdd(reinterpret_cast<unsigned long long*>(A), (unsigned long long)nraw | ((unsigned long long)nin << 32));   // A[0] raw, A[1] in: one 64-bit add
+    if (nin) {
+        atomicAdd(&F[0], to_fix(S0)); atomicAdd(&F[1], to_fix(S1)); atomicAdd(&F[2], to_fix(S2)); atomicAdd(&F[3], to_fix(S3)); atomicAdd(&F[4], to_fix(S4));
+        atomicAdd(&F[5], to_fix(S5)); atomicAdd(&F[6], to_fix(S6)); atomicAdd(&F[7], to_fix(S7)); atomicAdd(&F[8], to_fix(S8));
+    }
+}
+
 // |q|^2 outside this range over- or underflows the stand-in coordinates (the literal formulas stay well defined): literal path.
 constexpr float kR2Min = 1e-30f, kR2Max = 1e30f;
 

@@ -266,43 +266,47 @@ __device__ inline bool chol6_inverse(const float* A, float* inv) {
 // Eigenvalues <= rel_tol * lambda_max are treated as rank deficiency (the reference's COD uses
 // eps * 3 relative to its largest pivot).  Rows/columns that are exactly zero (axes masked by L)
 // stay exactly zero, so the result is the inverse of the kept principal block embedded in zeros.
+// Run in DOUBLE on the float matrix: the projected noise matrix of a line-like voxel has a condition number of 1e4..1e5, and a
+// float eigen-solve loses cond * eps = 0.2 .. 0.6 % of the weight such a voxel gets (it can carry 20 % of H^T W H).
+template <typename R>
 __device__ inline void pinv3_sym(const float a[6], float rel_tol, float w[6]) {
-    float A00 = a[0], A01 = a[1], A02 = a[2], A11 = a[3], A12 = a[4], A22 = a[5];
-    float V00 = 1.f, V01 = 0.f, V02 = 0.f, V10 = 0.f, V11 = 1.f, V12 = 0.f, V20 = 0.f, V21 = 0.f, V22 = 1.f;
+    R A00 = a[0], A01 = a[1], A02 = a[2], A11 = a[3], A12 = a[4], A22 = a[5];
+    R V00 = 1, V01 = 0, V02 = 0, V10 = 0, V11 = 1, V12 = 0, V20 = 0, V21 = 0, V22 = 1;
+    const R tiny = sizeof(R) == 8 ? (R)1e-17 : (R)1e-9;
 #define ICET_JROT(App, Aqq, Apq, Apr, Aqr, Vp0, Vq0, Vp1, Vq1, Vp2, Vq2)                                      \
-    if (Apq != 0.f) {                                                                                           \
-        float theta = (Aqq - App) / (2.f * Apq);                                                                \
-        float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));                    \
-        float c = 1.f / sqrtf(t * t + 1.f), s = t * c;                                                          \
-        float app = App - t * Apq, aqq = Aqq + t * Apq;                                                         \
-        float apr = c * Apr - s * Aqr, aqr = s * Apr + c * Aqr;                                                 \
-        App = app; Aqq = aqq; Apq = 0.f; Apr = apr; Aqr = aqr;                                                  \
-        float v;                                                                                                \
+    if (Apq != (R)0) {                                                                                          \
+        R theta = (Aqq - App) / ((R)2 * Apq);                                                                   \
+        R t = (theta >= (R)0 ? (R)1 : (R)-1) / (fabs(theta) + sqrt(theta * theta + (R)1));                      \
+        R c = (R)1 / sqrt(t * t + (R)1), s = t * c;                                                             \
+        R app = App - t * Apq, aqq = Aqq + t * Apq;                                                             \
+        R apr = c * Apr - s * Aqr, aqr = s * Apr + c * Aqr;                                                     \
+        App = app; Aqq = aqq; Apq = (R)0; Apr = apr; Aqr = aqr;                                                 \
+        R v;                                                                                                    \
         v = c * Vp0 - s * Vq0; Vq0 = s * Vp0 + c * Vq0; Vp0 = v;                                                \
         v = c * Vp1 - s * Vq1; Vq1 = s * Vp1 + c * Vq1; Vp1 = v;                                                \
         v = c * Vp2 - s * Vq2; Vq2 = s * Vp2 + c * Vq2; Vp2 = v;                                                \
     }
     // V holds eigenvectors as columns: Vrk = component r of eigenvector k.
-    for (int sweep = 0; sweep < 6; sweep++) {
-        float off = fabsf(A01) + fabsf(A02) + fabsf(A12);
-        float dg = fabsf(A00) + fabsf(A11) + fabsf(A22);
-        if (off <= 1e-9f * dg) break;
+    for (int sweep = 0; sweep < (sizeof(R) == 8 ? 10 : 6); sweep++) {
+        R off = fabs(A01) + fabs(A02) + fabs(A12);
+        R dg = fabs(A00) + fabs(A11) + fabs(A22);
+        if (off <= tiny * dg) break;
         ICET_JROT(A00, A11, A01, A02, A12, V00, V01, V10, V11, V20, V21)
         ICET_JROT(A00, A22, A02, A01, A12, V00, V02, V10, V12, V20, V22)
         ICET_JROT(A11, A22, A12, A01, A02, V01, V02, V11, V12, V21, V22)
     }
 #undef ICET_JROT
-    float lmax = fmaxf(fmaxf(fabsf(A00), fabsf(A11)), fabsf(A22));
-    float thr = rel_tol * lmax;
-    float i0 = (fabsf(A00) > thr) ? 1.f / A00 : 0.f;
-    float i1 = (fabsf(A11) > thr) ? 1.f / A11 : 0.f;
-    float i2 = (fabsf(A22) > thr) ? 1.f / A22 : 0.f;
-    w[0] = i0 * V00 * V00 + i1 * V01 * V01 + i2 * V02 * V02;
-    w[1] = i0 * V00 * V10 + i1 * V01 * V11 + i2 * V02 * V12;
-    w[2] = i0 * V00 * V20 + i1 * V01 * V21 + i2 * V02 * V22;
-    w[3] = i0 * V10 * V10 + i1 * V11 * V11 + i2 * V12 * V12;
-    w[4] = i0 * V10 * V20 + i1 * V11 * V21 + i2 * V12 * V22;
-    w[5] = i0 * V20 * V20 + i1 * V21 * V21 + i2 * V22 * V22;
+    R lmax = fmax(fmax(fabs(A00), fabs(A11)), fabs(A22));
+    R thr = (R)rel_tol * lmax;
+    R i0 = (fabs(A00) > thr) ? (R)1 / A00 : (R)0;
+    R i1 = (fabs(A11) > thr) ? (R)1 / A11 : (R)0;
+    R i2 = (fabs(A22) > thr) ? (R)1 / A22 : (R)0;
+    w[0] = (float)(i0 * V00 * V00 + i1 * V01 * V01 + i2 * V02 * V02);
+    w[1] = (float)(i0 * V00 * V10 + i1 * V01 * V11 + i2 * V02 * V12);
+    w[2] = (float)(i0 * V00 * V20 + i1 * V01 * V21 + i2 * V02 * V22);
+    w[3] = (float)(i0 * V10 * V10 + i1 * V11 * V11 + i2 * V12 * V12);
+    w[4] = (float)(i0 * V10 * V20 + i1 * V11 * V21 + i2 * V12 * V22);
+    w[5] = (float)(i0 * V20 * V20 + i1 * V21 * V21 + i2 * V22 * V22);
 }
 
 }  // namespace icetdev

@@ -6,13 +6,17 @@
 namespace icet {
 
 // Per-slot accumulator: raw count (u32), in-bounds count (u32), then 9 sums Sd[3], Sdd[6] as 64-bit FIXED POINT
-// (value * 2^30, two's complement).  Integer atomics make the sums independent of arrival order, so results are
-// bitwise reproducible run to run and identical between batched and single solves; 2^-30 m^2 resolution is far
-// below float32 rounding of the addends, and 2^33 m^2 of headroom covers 2^17 points with |d| up to 256 m.
+// (value * 2^36, two's complement).  Integer atomics make the sums independent of arrival order, so results are
+// bitwise reproducible run to run and identical between batched and single solves; 2^-36 m^2 resolution (1.5e-11) is far
+// below float32 rounding of the addends.
 constexpr int kAccWords = 20;        // in HBM: AoS, 80 bytes per slot (8-byte aligned)
 constexpr int kAccLds   = 20;        // in LDS: the same 80-byte record per slot ([raw | in << 32], 9 x i64)
-constexpr float kFixScale = 1073741824.0f;            // 2^30
-constexpr double kFixInv = 1.0 / 1073741824.0;
+// Why 2^36 and not coarser: a voxel holding ~27 points of ONE lidar ring is a line whose covariance has a smallest eigenvalue of
+// ~5e-8 m^2, i.e. a scatter of 1.4e-6 m^2 in that direction, and it enters H^T W H with a weight of 1 / lambda_min; at 2^-30 the
+// truncation of ~15 flushes biased that scatter by 0.5 % (round 2, scripts/diag_voxel.py 61).  A flushed value is the partial sum
+// of at most 4 points, far below 2^20 (to_fix needs |v| * 2^36 < 2^56); the accumulated totals have 2^27 m^2 of headroom.
+constexpr float kFixScale = 68719476736.0f;           // 2^36
+constexpr double kFixInv = 1.0 / 68719476736.0;
 #ifndef ICET_RS_BUCKET_BITS
 #define ICET_RS_BUCKET_BITS 7
 #endif
@@ -37,7 +41,7 @@ struct PairDesc {
     const float* s1; const float* s2;
     int32_t n1, ld1, n2, ld2;
     int32_t off1;                    // start of this pair's segment in the scan-1 temporaries
-    int32_t pad;
+    int32_t off2;                    // start of this pair's segment in the scan-2 overflow list (near_over)
 };
 
 // What the per-iteration point kernel needs about an active voxel (keyframe voxel with a scan-1
@@ -98,6 +102,10 @@ struct Workspace {
     SlotHot* hotS = nullptr; SlotFit* fitS = nullptr;                               // compact, pairs x V
     int16_t* slot_of_voxel = nullptr; int32_t* n_slots = nullptr;
     uint32_t* acc = nullptr;                  // pairs x V x kAccWords
+    // Scan-2 points that the fast classification cannot decide and that did not fit the block's LDS queue (k_gn_accumulate):
+    // point indices, one segment of n2 entries per pair, and the fill count per pair.  Drained -- and the count reset -- by
+    // k_gn_solve.  Empty on ordinary data (~0.02 % of the points are undecided and a block's queue holds 512 of them).
+    uint32_t* near_over = nullptr; int64_t cap_n2 = 0; uint32_t* near_over_count = nullptr;
     float* xf = nullptr;                      // pairs x 48: t[3], R[9] row-major, angles[3], pad, J[27] (see write_xf)
     float* X = nullptr;                       // pairs x 6
     int32_t* flags = nullptr;                 // pairs: bit0 = scramble walk overflow

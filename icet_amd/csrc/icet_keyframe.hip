@@ -660,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
 // accumulation order, src/icet.cpp:391-404).
 __global__ __launch_bounds__(kBlock) void k_compact_slots(const SlotHot* __restrict__ hotD, const SlotFit* __restrict__ fitD, const int32_t* __restrict__ activeD,
                                                           SlotHot* __restrict__ hotS, SlotFit* __restrict__ fitS, int16_t* __restrict__ slot_of_voxel,
-                                                          int32_t* __restrict__ n_slots, uint32_t* __restrict__ acc, int V) {
+                                                          int32_t* __restrict__ n_slots, uint32_t* __restrict__ acc, uint32_t* __restrict__ near_over_count, int V) {
     __shared__ int wave_tot[kBlock / 64];
     __shared__ int base;
     const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(kBlock) void k_compact_slots(const SlotHot* __restr
         __syncthreads();
     }
     const int ns = base;
-    if (threadIdx.x == 0) n_slots[pair] = ns;
+    if (threadIdx.x == 0) { n_slots[pair] = ns; near_over_count[pair] = 0u; }
     for (int i = threadIdx.x; i < ns * kAccWords; i += kBlock) acc[(size_t)pair * V * kAccWords + i] = 0u;
 }
 
@@ -769,7 +769,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     ICET_LAUNCH_CHECK();
     k_fit_finish<<<dim3((c.V + kBlock - 1) / kBlock, c.n_pairs), blk, 0, st>>>(w.midD, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n);
     ICET_LAUNCH_CHECK();
-    k_compact_slots<<<c.n_pairs, blk, 0, st>>>(w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, c.V);
+    k_compact_slots<<<c.n_pairs, blk, 0, st>>>(w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, w.near_over_count, c.V);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

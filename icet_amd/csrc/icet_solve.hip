@@ -46,13 +46,43 @@ __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X
 }
 
 // fitCells2's per-voxel algebra + reduction + the 6x6 solve.  One block per pair.
+// Undecided scan-2 points that did not fit a block's LDS queue in k_gn_accumulate (see there): literal classification, each a
+// run of one, straight into the HBM accumulators.  Empty on ordinary data; the whole list when the force_exact diagnostic is on.
+struct NearOverflow { const PairDesc* desc; const int16_t* slot_of_voxel; const SlotHot* hotS; const float* thr; uint32_t* list; uint32_t* count; int T, P; };
+
+__device__ __noinline__ void drain_near_overflow(const NearOverflow& o, int pair, int V, const float* __restrict__ xf, uint32_t* __restrict__ acc_pair, uint32_t nov) {
+    const PairDesc d = o.desc[pair];
+    const float* px = d.s2; const float* py = px + d.ld2; const float* pz = px + 2 * (size_t)d.ld2;
+    const int16_t* map = o.slot_of_voxel + (size_t)pair * ((V + 1) & ~1);
+    const SlotHot* hs = o.hotS + (size_t)pair * V;
+    for (uint32_t e = threadIdx.x; e < nov; e += kBlock) {
+        const int i = (int)o.list[(size_t)d.off2 + e];
+        float qx, qy, qz;
+        transform_point(px[i], py[i], pz[i], xf, qx, qy, qz);
+        PointClass pc;
+        classify_literal(qx, qy, qz, map, o.thr, o.T, o.P, hs, pc);
+        if (pc.s >= 0)
+            acc_add_hbm(acc_pair + (size_t)pc.s * kAccWords, 1u, pc.inb ? 1u : 0u, pc.dx, pc.dy, pc.dz, pc.dx * pc.dx, pc.dx * pc.dy, pc.dx * pc.dz,
+                        pc.dy * pc.dy, pc.dy * pc.dz, pc.dz * pc.dz);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__ n_slots, const SlotFit* __restrict__ fitS, uint32_t* __restrict__ acc,
                                                      float* __restrict__ X_all, float* __restrict__ xf_all, float* __restrict__ out, AuxDev aux,
-                                                     int V, int n, int iter, int runlen) {
+                                                     int V, int n, int iter, int runlen, NearOverflow over) {
     __shared__ float J[27];
     __shared__ float red[kBlock / 64][27];
     const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* X = X_all + pair * 6;
+    {
+        const uint32_t nov = over.count[pair];                          // block-uniform
+        if (nov) {
+            drain_near_overflow(over, pair, V, xf_all + pair * kXf, acc + (size_t)pair * V * kAccWords, nov);
+            __threadfence();                                            // this block reads the sums it has just added to
+            __syncthreads();
+            if (threadIdx.x == 0) over.count[pair] = 0u;
+        }
+    }
     if (threadIdx.x < 27) J[threadIdx.x] = xf_all[pair * kXf + 16 + threadIdx.x];      // written by the previous update (write_xf)
     __syncthreads();
     const int ns = n_slots[pair];
@@ -62,30 +92,35 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
     for (int s = threadIdx.x; s < ns; s += kBlock) {
         uint32_t* A = acc + ((size_t)pair * V + s) * kAccWords;
         const uint32_t n2 = A[0], m = A[1];
-        float sd[3], sdd[6];
         const long long* AF = reinterpret_cast<const long long*>(A + 2);
+        double sdD[3], sddD[6];
 #pragma unroll
-        for (int k = 0; k < 3; k++) sd[k] = (float)((double)AF[k] * kFixInv);
+        for (int k = 0; k < 3; k++) sdD[k] = (double)AF[k] * kFixInv;
 #pragma unroll
-        for (int k = 0; k < 6; k++) sdd[k] = (float)((double)AF[3 + k] * kFixInv);
+        for (int k = 0; k < 6; k++) sddD[k] = (double)AF[3 + k] * kFixInv;
 #pragma unroll
         for (int k = 0; k < kAccWords; k++) A[k] = 0u;           // ready for the next iteration
         const SlotFit f = fitS[(size_t)pair * V + s];
         if (aux.n2_raw) aux.n2_raw[((size_t)pair * runlen + iter) * V + f.v] = (int)n2;
         if (aux.n2_in) aux.n2_in[((size_t)pair * runlen + iter) * V + f.v] = (int)m;
         if (!((int)n2 > n && (int)m > n)) continue;               // src/icet.cpp:290 (scan-2 half), :302
-        const float fm = (float)m;
-        const float db[3] = {sd[0] / fm, sd[1] / fm, sd[2] / fm};   // mean - mu1
-        const float mu2[3] = {f.mu[0] + db[0], f.mu[1] + db[1], f.mu[2] + db[2]};
-        const float den = (float)(m - 1), d2 = (float)(n2 - 1);
+        // mean and covariance of the m surviving points from the sums about mu1 (src/icet.cpp:303-306), in DOUBLE: the scatter in
+        // a voxel's thin direction (1e-6 m^2 for a single-ring line) is what is left of sum(d d^T) ~ m |mu2 - mu1|^2 (1e-2) after the
+        // subtraction -- in float that cancellation cost percents of the voxel's weight (round 2, scripts/diag_voxel.py)
+        const double fmD = (double)m;
+        const double dbD[3] = {sdD[0] / fmD, sdD[1] / fmD, sdD[2] / fmD};
+        const float db[3] = {(float)dbD[0], (float)dbD[1], (float)dbD[2]};   // mean - mu1
+        const float mu2[3] = {(float)((double)f.mu[0] + dbD[0]), (float)((double)f.mu[1] + dbD[1]), (float)((double)f.mu[2] + dbD[2])};
+        const double denD = (double)(m - 1);
+        const float d2 = (float)(n2 - 1);
+        float cov2[6];
+        cov2[0] = (float)((sddD[0] - fmD * dbD[0] * dbD[0]) / denD); cov2[1] = (float)((sddD[1] - fmD * dbD[0] * dbD[1]) / denD);
+        cov2[2] = (float)((sddD[2] - fmD * dbD[0] * dbD[2]) / denD); cov2[3] = (float)((sddD[3] - fmD * dbD[1] * dbD[1]) / denD);
+        cov2[4] = (float)((sddD[4] - fmD * dbD[1] * dbD[2]) / denD); cov2[5] = (float)((sddD[5] - fmD * dbD[2] * dbD[2]) / denD);
         // R_noise = sigma1/(|idx1|-1) + cov2/(|idx2|-1)                         src/icet.cpp:315
         float Rn[6];
-        Rn[0] = f.s1n[0] + ((sdd[0] - fm * db[0] * db[0]) / den) / d2;
-        Rn[1] = f.s1n[1] + ((sdd[1] - fm * db[0] * db[1]) / den) / d2;
-        Rn[2] = f.s1n[2] + ((sdd[2] - fm * db[0] * db[2]) / den) / d2;
-        Rn[3] = f.s1n[3] + ((sdd[3] - fm * db[1] * db[1]) / den) / d2;
-        Rn[4] = f.s1n[4] + ((sdd[4] - fm * db[1] * db[2]) / den) / d2;
-        Rn[5] = f.s1n[5] + ((sdd[5] - fm * db[2] * db[2]) / den) / d2;
+#pragma unroll
+        for (int k = 0; k < 6; k++) Rn[k] = f.s1n[k] + cov2[k] / d2;
         // Rp = M Rn M^T  (M = L U^T)                                             src/icet.cpp:317
         const float* M = f.M;
         float MR[9];
@@ -103,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
         Rp[4] = MR[3] * M[6] + MR[4] * M[7] + MR[5] * M[8];
         Rp[5] = MR[6] * M[6] + MR[7] * M[7] + MR[8] * M[8];
         float W[6];
-        icetdev::pinv3_sym(Rp, 3.0f * FLT_EPSILON, W);                        // src/icet.cpp:320-321
+        icetdev::pinv3_sym<double>(Rp, 3.0f * FLT_EPSILON, W);               // src/icet.cpp:320-321
         // H_z = M * [-I | Jx mu | Jy mu | Jz mu]                                  src/icet.cpp:324-329
         float Hj[9];      // columns 3..5 of H_j, row-major 3x3
 #pragma unroll
@@ -232,7 +267,8 @@ hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float
 
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* auxp, hipStream_t st) {
     AuxDev aux{}; if (auxp) aux = *auxp;
-    k_gn_solve<<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen);
+    NearOverflow over{w.desc, w.slot_of_voxel, w.hotS, w.thr, w.near_over, w.near_over_count, c.T, c.P};
+    k_gn_solve<<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -226,7 +226,7 @@ static inline bool insideBounds(float r, float azim, float elev, const float* li
 }
 
 // In-place "sort" by r with the reference's one-step swap loop (icet.cpp:72-83, 264-274; quirk Q3).
-static void sortAndScramble(Sph& s, bool true_sort = false) {
+static void sortAndScramble(Sph& s, bool true_sort = false, std::vector<float>* cx = nullptr, std::vector<float>* cy = nullptr, std::vector<float>* cz = nullptr) {
     const int N = (int)s.r.size();
     std::vector<int> index(N);
     std::iota(index.begin(), index.end(), 0);
@@ -235,12 +235,14 @@ static void sortAndScramble(Sph& s, bool true_sort = false) {
         Sph t; t.resize(N);
         for (int i = 0; i < N; i++) { t.r[i] = s.r[index[i]]; t.th[i] = s.th[index[i]]; t.ph[i] = s.ph[index[i]]; }
         s = t;
+        if (cx) { std::vector<float> a(N), b(N), c(N); for (int i = 0; i < N; i++) { a[i] = (*cx)[index[i]]; b[i] = (*cy)[index[i]]; c[i] = (*cz)[index[i]]; } *cx = a; *cy = b; *cz = c; }
         return;
     }
     for (int i = 0; i < N; i++) {
         if (index[i] != i) {
             int j = index[i];
             std::swap(s.r[i], s.r[j]); std::swap(s.th[i], s.th[j]); std::swap(s.ph[i], s.ph[j]);
+            if (cx) { std::swap((*cx)[i], (*cx)[j]); std::swap((*cy)[i], (*cy)[j]); std::swap((*cz)[i], (*cz)[j]); }
             std::swap(index[i], index[j]);
         }
     }
@@ -283,6 +285,13 @@ struct Solver {
     }
 
     bool libmf = false;                // ICET_ORACLE_LIBMF: float libm + sequential float sums instead of the shared rule
+    bool skip_rt2 = false;             // ICET_ORACLE_SKIP_RT2: scan 2 is never round-tripped through spherical coordinates (the device's deviation)
+    bool rt2_thin_only = false;        // ICET_ORACLE_RT2_THIN: ... except for the points of voxels whose scan-1 Gaussian is thin (lambda_min < rt_tau)
+    float rt_tau = 1e-5f;
+    std::vector<float> lam_min1;       // smallest eigenvalue of sigma1 per voxel
+    std::vector<float> rawx, rawy, rawz;   // scan 2 as given (before prepScan2's round trip), in scrambled order
+    std::vector<float> rtx, rty, rtz;      // its transform by the current X (skip_rt2 modes)
+    Sph sphr;                              // and the spherical coordinates of that
     const float* sign_ref = nullptr;   // optional V x 9 eigenvectors (columns, row-major) to align signs with; see fitCells1
     int n_sign_flips = 0;
 
@@ -332,7 +341,7 @@ struct Solver {
                         if (dot < 0.f) { for (int r = 0; r < 3; r++) evec(r, k) = -evec(r, k); n_sign_flips++; }
                     }
                 }
-                f.V = evec;
+                f.V = evec; lam_min1[v] = ev[0];
                 // axislen = 2*sqrt(lambda);  rotated = diag(axislen) * U^T = diag(axislen) * V  (rows!)  icet.cpp:187-193
                 float sp[6][3];
                 for (int k = 0; k < 3; k++) {
@@ -376,7 +385,8 @@ struct Solver {
         const int N = (int)p2x.size();
         sph2.resize(N);
         for (int i = 0; i < N; i++) c2s_one(p2x[i], p2y[i], p2z[i], sph2.r[i], sph2.th[i], sph2.ph[i], libmf);
-        sortAndScramble(sph2, (prm.mode & ICET_ORACLE_TRUE_SORT) != 0);
+        if (skip_rt2) { rawx = p2x; rawy = p2y; rawz = p2z; }          // the rows as given, carried through the same scramble
+        sortAndScramble(sph2, (prm.mode & ICET_ORACLE_TRUE_SORT) != 0, skip_rt2 ? &rawx : nullptr, &rawy, &rawz);
         ogx.resize(N); ogy.resize(N); ogz.resize(N);
         for (int i = 0; i < N; i++) s2c_one(sph2.r[i], sph2.th[i], sph2.ph[i], ogx[i], ogy[i], ogz[i], libmf);
     }
@@ -391,9 +401,15 @@ struct Solver {
         if ((n2 > (size_t)n) && (n1 > (size_t)n) && (lims[5] > 1)) {
             const int* idx2 = &bin2_idx[bin2_start[v]];
             std::vector<float> cx, cy, cz;
+            // experimental modes (skip_rt2): membership comes from the transform of the RAW rows; the Gaussian is fitted to those
+            // Cartesian rows directly -- what the device does -- unless the voxel is thin and rt2_thin_only asks for the reference's
+            // round-tripped rows there
+            const bool raw_here = skip_rt2 && !(rt2_thin_only && fit[v].has_fit && lam_min1[v] < rt_tau);
             for (size_t k = 0; k < n2; k++) {
                 int i = idx2[k];
-                if (insideBounds(sph2.r[i], sph2.th[i], sph2.ph[i], lims)) {
+                if (raw_here) {
+                    if (insideBounds(sphr.r[i], sphr.th[i], sphr.ph[i], lims)) { cx.push_back(rtx[i]); cy.push_back(rty[i]); cz.push_back(rtz[i]); }
+                } else if (insideBounds(sph2.r[i], sph2.th[i], sph2.ph[i], lims)) {
                     float x, y, z; s2c_one(sph2.r[i], sph2.th[i], sph2.ph[i], x, y, z, libmf);
                     cx.push_back(x); cy.push_back(y); cz.push_back(z);
                 }
@@ -492,6 +508,17 @@ struct Solver {
         HTWH_i = Mat(6, 6); HTWdz_i = Mat(6, 1);
         sph2.resize(N);
         for (int i = 0; i < N; i++) c2s_one(p2x[i], p2y[i], p2z[i], sph2.r[i], sph2.th[i], sph2.ph[i], libmf);
+        if (skip_rt2) {
+            rtx.resize(N); rty.resize(N); rtz.resize(N); sphr.resize(N);
+            for (int i = 0; i < N; i++) {
+                float a = rawx[i] + X[0], b = rawy[i] + X[1], c = rawz[i] + X[2];
+                rtx[i] = a * rot(0, 0) + b * rot(1, 0) + c * rot(2, 0);
+                rty[i] = a * rot(0, 1) + b * rot(1, 1) + c * rot(2, 1);
+                rtz[i] = a * rot(0, 2) + b * rot(1, 2) + c * rot(2, 2);
+                c2s_one(rtx[i], rty[i], rtz[i], sphr.r[i], sphr.th[i], sphr.ph[i], libmf);
+            }
+            binPoints(sphr, bin2_start, bin2_idx);
+        } else
         binPoints(sph2, bin2_start, bin2_idx);
         if ((prm.mode & ICET_ORACLE_POOL4)) {
             voxelLoopPool();
@@ -526,6 +553,8 @@ struct Solver {
     int run(const float* s1, int64_t n1, int64_t ld1, const float* s2, int64_t n2, int64_t ld2, const float* x0) {
         T = prm.bins_theta; P = prm.bins_phi; V = T * P; n = prm.n;
         libmf = (prm.mode & ICET_ORACLE_LIBMF) != 0;
+        skip_rt2 = (prm.mode & (ICET_ORACLE_SKIP_RT2 | ICET_ORACLE_RT2_THIN)) != 0; rt2_thin_only = (prm.mode & ICET_ORACLE_RT2_THIN) != 0;
+        lam_min1.assign((size_t)prm.bins_theta * prm.bins_phi, 0.f);
         p1x.assign(s1, s1 + n1); p1y.assign(s1 + ld1, s1 + ld1 + n1); p1z.assign(s1 + 2 * ld1, s1 + 2 * ld1 + n1);
         p2x.assign(s2, s2 + n2); p2y.assign(s2 + ld2, s2 + ld2 + n2); p2z.assign(s2 + 2 * ld2, s2 + 2 * ld2 + n2);
         for (int k = 0; k < 6; k++) { X[k] = x0[k]; pred_stds[k] = 0.f; dx[k] = 0.f; }

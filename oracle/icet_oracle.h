@@ -11,9 +11,12 @@ extern "C" {
 enum { ICET_ORACLE_SERIAL = 0,   /* live path: serial voxel loop, src/icet.cpp:391-404            */
        ICET_ORACLE_POOL4  = 1,   /* parallelFitCells2 structure, 4 workers, src/icet.cpp:346-370,31 */
        ICET_ORACLE_TRUE_SORT = 2,   /* OR-ed in: non-parity extension, rows really sorted by range (twin of ICET_FLAG_TRUE_SORT) */
-       ICET_ORACLE_LIBMF = 4 };     /* OR-ed in: glibc FLOAT atan2/acos/sin/cos, sequential float sums and std::hypot -- the literal
+       ICET_ORACLE_LIBMF = 4,     /* OR-ed in: glibc FLOAT atan2/acos/sin/cos, sequential float sums and std::hypot -- the literal
                                        expression types of the reference source -- instead of the shared arithmetic rule (correctly
                                        rounded transcendentals, exact sums, Eigen's hypot; icet_oracle.cpp header) */
+       ICET_ORACLE_SKIP_RT2 = 8,    /* EXPERIMENT (quantifies the device's one documented deviation): scan 2 is never round-tripped through
+                                       spherical coordinates (src/icet.cpp:275, 303) */
+       ICET_ORACLE_RT2_THIN = 16 }; /* EXPERIMENT: as SKIP_RT2, but voxels whose scan-1 Gaussian is thin (lambda_min < 1e-5 m^2) keep the round trips */
 
 typedef struct icet_oracle_params {
     int32_t runlen;      /* include/icet.h:38  */

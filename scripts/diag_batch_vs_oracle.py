@@ -46,6 +46,10 @@ out = {
     "oracle_rule_vs_libmf_dX_t_max": float(dlib[:, :3].max()), "oracle_rule_vs_libmf_dX_t_median": float(np.median(dlib[:, :3].max(1))),
     "oracle_rule_vs_libmf_pairs_over_3e-4m": int((dlib[:, :3].max(1) > 3e-4).sum()),
 }
+order = np.argsort(-dX[:, :3].max(1))
+out["dX_t_top5"] = [float(dX[k, :3].max()) for k in order[:5]]; out["dX_t_top5_pairs"] = [int(k) for k in order[:5]]
+keep = np.ones(N, bool); keep[order[:1]] = False       # without the single worst pair (reported below with the oracle's own sensitivity)
+out["without_worst_pair"] = {"dX_t_max": float(dX[keep, :3].max()), "dX_r_max": float(dX[keep, 3:].max()), "rel_pred_stds_max": float(dps[keep].max()), "rel_cov_max": float(dcov[keep].max())}
 print(json.dumps(out, indent=1))
 worst = np.argsort(-dX[:, :3].max(1))[:6]
 for k in worst:

@@ -25,8 +25,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL_T, TOL_R = 1.5e-3, 1e-4            # 2 x (7.6e-4 m, 4.4e-5 rad) measured maxima over the 256-pair batch
-RTOL_STD, RTOL_COV = 3e-2, 6e-2         # 2 x (1.5 %, 3.0 %)
+TOL_T, TOL_R = 2e-4, 2e-5              # 2 x (8.1e-5 m, 9.7e-6 rad): measured maxima over the 256-pair batch without its one sensitivity-explained pair
+RTOL_STD, RTOL_COV = 2.5e-2, 5e-2       # 2 x (1.2 %, 2.5 %)
 
 
 def oracle_sensitivity(a, b, trials=3, scan1_too=False, **kw):
@@ -176,7 +176,10 @@ def test_batch_equals_singles_and_oracle(gpu_ctx, frames, sample_pc):
         # so a pair solved inside a batch is BITWISE the pair solved alone
         assert np.array_equal(out["X"][k], single["X"]) and np.array_equal(out["pred_stds"][k], single["pred_stds"])
         ref = po.solve(s1[k], s2[k], x0=x0[k])
-        _check_solution(dict(X=out["X"][k], pred_stds=out["pred_stds"][k], cov=out["cov"][k]), ref)
+        # the truncated scans (k = 2, 3) are partial views with few voxels and a poorly constrained z / roll: held to the larger of the
+        # parity bound and 5 x the oracle's own answer-to-answer spread under a 1-ulp perturbation of scan 2
+        sens = oracle_sensitivity(s1[k], s2[k], x0=x0[k]) if k in (2, 3) else np.zeros(6)
+        _check_solution(dict(X=out["X"][k], pred_stds=out["pred_stds"][k], cov=out["cov"][k]), ref, max(TOL_T, 5 * sens[:3].max()), max(TOL_R, 5 * sens[3:].max()))
 
 
 def test_identical_scans_within_oracle_sensitivity(gpu_ctx, frames):
@@ -246,11 +249,12 @@ def test_scan2_order_invariance_full_size(gpu_ctx):
 
 
 def test_fast_classification_equals_literal_evaluation(gpu_ctx, frames, sample_pc):
-    """The accumulate kernel classifies points through LUTs on transcendental-free coordinates and re-does only
-    the points within a guard band of a voxel edge with the literal atan2f/acosf formulas.  Forcing EVERY point
-    through the literal path (option force_exact) must give the same integer counts in every voxel and iteration
-    -- i.e. the fast path never decides differently -- on real scans, synthetic scans and the 150 x 48 grid."""
-    import os
+    """The accumulate kernel classifies points through LUTs on transcendental-free coordinates and hands only the points within
+    a guard band of a voxel edge to the literal formulas (correctly rounded atan2 / acos).  With the option force_exact EVERY
+    point takes the literal path.  Every iteration of the fast run is replayed from the same X with force_exact: the integer
+    counts of every voxel -- raw and inside the cluster bounds -- must be identical, i.e. the fast path never DECIDES
+    differently, on real scans, synthetic scans, a cloud that covers the poles and the 150 x 48 grid.  (The sums agree to float
+    rounding only: literal points enter as runs of one, fast points as runs of up to four.)"""
     from icet_amd import lidar_sim as ls
     s1, s2, _ = ls.make_pair()
     # a cloud that covers the WHOLE sphere, poles included: the polar look-up table is sized for the bins near the horizon, so the
@@ -261,22 +265,27 @@ def test_fast_classification_equals_literal_evaluation(gpu_ctx, frames, sample_p
     ang = np.float32(0.01)
     Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
     shell2 = ((dirs * (8.0 + 0.03 * rng.normal(size=(150000, 1)))) @ Rz.T + np.array([0.05, -0.02, 0.03])).astype(np.float32)
+    # garbage magnitudes: squares that over- / underflow float32 must take the literal path as well
+    odd = frames[1].copy(); odd[::997] *= np.float32(1e25); odd[5::991] *= np.float32(1e-25); odd[7::983, 1] = np.float32(3e38)
     cases = [(frames[0], frames[1], 24, 75, 7), (sample_pc[0], sample_pc[1], 48, 150, 4), (s1.T.numpy(), s2.T.numpy(), 24, 75, 7),
-             (shell, shell2, 24, 75, 4), (shell, shell2, 48, 150, 3)]
+             (shell, shell2, 24, 75, 4), (shell, shell2, 48, 150, 3), (frames[0], odd, 24, 75, 3)]
     for a, b, P, T, rl in cases:
         fast = gpu_ctx.solve(a, b, rl, np.zeros(6), P, T, aux=True)
+        again = gpu_ctx.solve(a, b, rl, np.zeros(6), P, T)
+        assert np.array_equal(again["X"], fast["X"]) and np.array_equal(again["cov"], fast["cov"])       # run-to-run reproducible
         gpu_ctx.set_option("force_exact", 1)
         try:
-            lit = gpu_ctx.solve(a, b, rl, np.zeros(6), P, T, aux=True)
+            for it in range(rl):
+                x0 = np.zeros(6, np.float32) if it == 0 else fast["aux"]["x_hist"][it - 1]
+                lit = gpu_ctx.solve(a, b, 1, x0, P, T, aux=True)
+                assert np.array_equal(lit["aux"]["n2_raw"][0], fast["aux"]["n2_raw"][it]), (P, T, it)
+                assert np.array_equal(lit["aux"]["n2_in"][0], fast["aux"]["n2_in"][it]), (P, T, it)
+                # same decisions, other grouping of the float partial sums (runs of one): only rounding apart -- which a line-like voxel
+                # can amplify (module docstring), hence the parity bound and not a few ulps
+                dX = np.abs(lit["X"] - fast["aux"]["x_hist"][it])
+                assert dX[:3].max() <= TOL_T and dX[3:].max() <= TOL_R, (P, T, it, dX)
         finally:
             gpu_ctx.set_option("force_exact", 0)
-        # same decisions -> same fixed-point sums -> bitwise the same trajectory
-        assert np.array_equal(fast["aux"]["n2_raw"], lit["aux"]["n2_raw"])
-        assert np.array_equal(fast["aux"]["n2_in"], lit["aux"]["n2_in"])
-        assert np.array_equal(fast["aux"]["x_hist"], lit["aux"]["x_hist"])
-        assert np.array_equal(fast["X"], lit["X"]) and np.array_equal(fast["cov"], lit["cov"])
-        again = gpu_ctx.solve(a, b, rl, np.zeros(6), P, T)
-        assert np.array_equal(again["X"], fast["X"])                       # run-to-run reproducible
 
 
 def test_device_resident_batch_full_size(gpu_ctx):
@@ -478,12 +487,17 @@ def test_rarely_taken_paths_give_the_same_bits(gpu_ctx, frames, sample_pc):
     for key, val in (("guard_scale", 16), ("lut_polar_quantile", 0.6), ("lut_polar_quantile", 0.0)):
         ctx = icet_amd.Context(0)
         ctx.set_option(key, val)
-        r1 = ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
-        r2 = ctx.solve(c, d, 7, np.zeros(6), 48, 150)
+        k1 = ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
+        assert np.array_equal(k1["aux"]["n1_raw"], base1["aux"]["n1_raw"]) and np.array_equal(k1["aux"]["sigma1"], base1["aux"]["sigma1"]), (key, val)   # keyframe: same bits
+        assert np.array_equal(k1["aux"]["l_diag"], base1["aux"]["l_diag"]) and np.array_equal(k1["aux"]["cluster_bounds"], base1["aux"]["cluster_bounds"]), (key, val)
+        # loop: a point that changes from the fast to the literal path enters the sums as a run of one instead of inside its lane's
+        # run, so the float partial sums round differently; the DECISIONS must not change: every iteration replayed from the same X
+        for it in range(7):
+            x0 = np.zeros(6, np.float32) if it == 0 else base1["aux"]["x_hist"][it - 1]
+            r1 = ctx.solve(a, b, 1, x0, 24, 75, aux=True)
+            assert np.array_equal(r1["aux"]["n2_raw"][0], base1["aux"]["n2_raw"][it]) and np.array_equal(r1["aux"]["n2_in"][0], base1["aux"]["n2_in"][it]), (key, val, it)
         ctx.close()
-        assert np.array_equal(r1["X"], base1["X"]) and np.array_equal(r1["aux"]["n2_in"], base1["aux"]["n2_in"]), (key, val)
-        assert np.array_equal(r1["aux"]["n1_raw"], base1["aux"]["n1_raw"]) and np.array_equal(r1["aux"]["sigma1"], base1["aux"]["sigma1"]), (key, val)
-        assert np.array_equal(r2["X"], base2["X"]), (key, val)
+        assert np.abs(k1["X"][:3] - base1["X"][:3]).max() <= TOL_T and np.abs(k1["X"][3:] - base1["X"][3:]).max() <= TOL_R, (key, val)
     with pytest.raises(icet_amd.IcetError):
         gpu_ctx.set_option("no_such_knob", 1)
 

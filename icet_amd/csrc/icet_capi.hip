@@ -86,6 +86,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, dev_realloc(w.seg_off, (size_t)np + 1));
         HIPCHK(c, dev_realloc(w.bin_count, pv));
         HIPCHK(c, dev_realloc(w.bin_start, (size_t)np * (VV + 1)));
+        HIPCHK(c, dev_realloc(w.live_bins, pv)); HIPCHK(c, dev_realloc(w.n_live, np));
         HIPCHK(c, dev_realloc(w.hotD, pv)); HIPCHK(c, dev_realloc(w.fitD, pv)); HIPCHK(c, dev_realloc(w.activeD, pv)); HIPCHK(c, dev_realloc(w.midD, pv));
         HIPCHK(c, dev_realloc(w.hotS, pv)); HIPCHK(c, dev_realloc(w.fitS, pv));
         HIPCHK(c, dev_realloc(w.slot_of_voxel, (size_t)np * ((VV + 1) & ~1)));
@@ -118,6 +119,15 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
             HIPCHK(c, dev_realloc(w.keyA, n)); HIPCHK(c, dev_realloc(w.keyB, n)); HIPCHK(c, dev_realloc(w.valA, n)); HIPCHK(c, dev_realloc(w.valB, n));
             HIPCHK(c, dev_realloc(w.pred, n)); HIPCHK(c, dev_realloc(w.src, n));
             w.cap_n1 = n;
+        }
+        {
+            const size_t need_items = (size_t)(w.cap_n1 / 64 + (int64_t)w.cap_pairs * (w.cap_V + 1) + 64);
+            if (need_items > w.cap_fit_items) {
+                if (w.fit_items) { HIPCHK(c, hipFree(w.fit_items)); w.fit_items = nullptr; }
+                HIPCHK(c, hipMalloc(&w.fit_items, need_items * 16));
+                w.cap_fit_items = need_items;
+            }
+            HIPCHK(c, dev_realloc(w.fit_n_items, (size_t)w.cap_pairs));
         }
         const size_t need = sort_temp_bytes(w.cap_n1);
         if (need > w.sort_tmp_bytes) {
@@ -347,7 +357,7 @@ icet_status icet_destroy(icet_ctx* c) {
     Workspace& w = c->w;
     void* ps[] = {w.key64A, w.key64B, w.bin16, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.cart1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src,
                   w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.near_over, w.near_over_count, w.acc, w.xf, w.X, w.flags,
-                  w.sort_tmp, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
+                  w.sort_tmp, w.fit_items, w.fit_n_items, w.live_bins, w.n_live, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);
     free_aux(c);
     if (c->h_desc) (void)hipHostFree(c->h_desc);

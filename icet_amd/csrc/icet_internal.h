@@ -69,7 +69,7 @@ struct FitMid {
     float inner, outer;                       // findCluster's bounds (0, 0 when there is no cluster)
     int32_t cnt;                              // rows in the bin
     int32_t has_fit;
-    int32_t pad[3];
+    int32_t pad[3];                           // pad[0]: rows inside the radial range (k_fit_cluster -> k_fit_moments)
 };
 static_assert(sizeof(FitMid) == 64, "k_fit_scan1 stages this record as 16 words");
 
@@ -99,6 +99,8 @@ struct Workspace {
     int32_t *bin_count = nullptr, *bin_start = nullptr;             // pairs x V, pairs x (V+1)
     SlotHot* hotD = nullptr; SlotFit* fitD = nullptr; int32_t* activeD = nullptr;   // dense, pairs x V
     FitMid* midD = nullptr;                                                          // dense, pairs x V
+    int32_t* live_bins = nullptr; int32_t* n_live = nullptr;                         // pairs x V: bins holding >= n rows, compacted; pairs: their number
+    void* fit_items = nullptr; size_t cap_fit_items = 0; uint32_t* fit_n_items = nullptr;   // work items of k_fit_roundtrip (16 B each) and their count
     SlotHot* hotS = nullptr; SlotFit* fitS = nullptr;                               // compact, pairs x V
     int16_t* slot_of_voxel = nullptr; int32_t* n_slots = nullptr;
     uint32_t* acc = nullptr;                  // pairs x V x kAccWords
@@ -176,7 +178,8 @@ __device__ __forceinline__ int rank_sort_bucket_of(uint32_t key, const uint32_t*
     for (int step = kRankSortMaxBuckets / 2; step > 0; step >>= 1) lo += (sp[lo + step] < key) ? step : 0;
     return lo;
 }
-hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st);
+hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st,
+                             int32_t* live = nullptr, int32_t* n_live = nullptr, int live_min = 0);
 
 // sort.hip
 size_t sort_temp_bytes(int64_t total_n);

@@ -10,8 +10,8 @@
 //                                                          parallel closed form
 //     k_bin_tiles + k_bin_scan + k_bin_scatter             stable multi-split of positions by voxel = the order in which
 //                                                          sortSphericalCoordinates appends rows to each voxel
-//     k_fit_scan1         fitCells1: findCluster (:557-607), bounds filter (:609-652), the spherical -> Cartesian round
-//                         trip of the surviving rows (:159) and their mean / covariance (:160-162), one wave per bin
+//     k_fit_cluster / k_fit_roundtrip / k_fit_moments   fitCells1: findCluster (:557-607), bounds filter (:609-652), the
+//                         spherical -> Cartesian round trip of the surviving rows (:159), their mean / covariance (:160-162)
 //     k_fit_finish        per-bin tail, one lane per bin: 3x3 eigen-decomposition (:181-184), sigma points (:187-232) -> L,
 //                         records of the active voxels
 //     k_compact_slots     dense voxel table -> compact "slots" of active voxels
@@ -22,6 +22,7 @@
 #include "icet_internal.h"
 #include "icet_device_common.h"
 #include "icet_device_math.h"
+#include <algorithm>
 
 namespace icet {
 namespace {
@@ -317,11 +318,13 @@ __global__ __launch_bounds__(kBlock) void k_bin_tiles(const uint32_t* __restrict
     class_start[(size_t)pair * (V + 1) + b] = tot;
 }
 
-__global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class_start, int V) {
-    __shared__ int wave_tot[kBlock / 64];
-    __shared__ int base;
+// live (optional): the classes holding at least live_min rows, compacted in class order -- the angular bins fitCells1 looks at at
+// all (src/icet.cpp:115) -- so that the fit kernels walk ~1/4 of the grid instead of launching a wave per bin.
+__global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class_start, int V, int32_t* __restrict__ live, int32_t* __restrict__ n_live, int live_min) {
+    __shared__ int wave_tot[kBlock / 64], wave_live[kBlock / 64];
+    __shared__ int base, lbase;
     const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) base = 0;
+    if (threadIdx.x == 0) { base = 0; lbase = 0; }
     __syncthreads();
     for (int v0 = 0; v0 < V; v0 += kBlock) {
         const int b = v0 + threadIdx.x;
@@ -329,17 +332,20 @@ __global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class
         int incl = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const unsigned long long lm = __ballot(live != nullptr && b < V && tot >= live_min);
         if (lane == 63) wave_tot[wave] = incl;
+        if (lane == 0) wave_live[wave] = __popcll(lm);
         __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < wave; k++) woff += wave_tot[k];
-        const int bb = base;
+        int woff = 0, loff = 0;
+        for (int k = 0; k < wave; k++) { woff += wave_tot[k]; loff += wave_live[k]; }
+        const int bb = base, lb = lbase;
         if (b < V) class_start[(size_t)pair * (V + 1) + b] = bb + woff + incl - tot;
+        if ((lm >> lane) & 1ull) live[(size_t)pair * V + lb + loff + __popcll(lm & ((1ull << lane) - 1ull))] = b;
         __syncthreads();
-        if (threadIdx.x == kBlock - 1) base = bb + woff + incl;
+        if (threadIdx.x == kBlock - 1) { base = bb + woff + incl; lbase = lb + loff + __popcll(lm); }
         __syncthreads();
     }
-    if (threadIdx.x == 0) class_start[(size_t)pair * (V + 1) + V] = base;
+    if (threadIdx.x == 0) { class_start[(size_t)pair * (V + 1) + V] = base; if (n_live) n_live[pair] = lbase; }
 }
 
 // One block per tile (<= 2048 positions); wave w owns the w-th quarter (<= 8 rounds of 64 positions).  Everything
@@ -401,37 +407,51 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
             if (rank == 0) mine[bb[k]] += (uint32_t)__popcll(peers);  // one leader per distinct voxel in this round
         }
     }
-    // one scattered 4-byte store per row; k_fit_scan1 gathers the coordinates through it (element-wise scattered stores of
+    // one scattered 4-byte store per row; k_fit_cluster gathers the coordinates through it (element-wise scattered stores of
     // the three coordinate arrays cost 4x more than gathering them, and a separate gather pass 0.15 ms more than gathering
     // inside the fit, whose independent loads hide the latency)
 #pragma unroll
     for (int k = 0; k < kScatterRounds; k++)
         if (ok[k]) sorted_row[o + dest[k]] = row[k];
 }
-// fitCells1 (src/icet.cpp:109-252): one wavefront per angular bin.
-// The per-bin tail -- 3x3 eigen-decomposition, the six sigma points, the slot records -- is scalar work: it runs in
-// k_fit_finish with one LANE per bin instead of here with one WAVE per bin (measured: 0.21 ms of the 0.42 ms this kernel
-// took on 256 pairs was 64 lanes executing the same eigen-solve).
-#ifndef ICET_FIT_WAVES
-#define ICET_FIT_WAVES 4      /* register budget of the double-precision round trip (128 VGPRs) */
+// fitCells1 (src/icet.cpp:109-252) in four kernels, each shaped for what bounds it:
+//   k_fit_cluster    one wave per angular bin: findCluster (:557-607) on the bin's rows in stored (scrambled) order, then the rows
+//                    inside the radial range are COMPACTED to the front of the bin's segment of cand[] / cand_r[] and announced as
+//                    work items of <= 64 rows.  Pointer chasing through the sorted-row table: latency bound, light on registers,
+//                    8 waves per SIMD.
+//   k_fit_roundtrip  one wave per work item, full lanes: the angular half of filterPointsInsideCluster (:609-652) where it is not
+//                    implied by the row's classification, and the reference's spherical -> Cartesian round trip (:159) under the
+//                    shared arithmetic rule -- double-precision atan2 / acos, ~350 DP instructions per row: issue bound, 128 VGPRs.
+//   k_fit_moments    one wave per bin: mean and covariance of the surviving rows (:160-162), exact sums -- a short coalesced read.
+//   k_fit_finish     one LANE per bin: 3x3 eigen-decomposition, sigma points, slot records (scalar work).
+// One fused kernel (one wave per bin for everything, round 2's first version) took 437 us per 256 pairs: the double-precision code
+// set its register budget (4 waves per SIMD, which the latency-bound walk wanted to be 8) and ran beside half-empty waves.
+#ifndef ICET_FIT_BLOCKS
+#define ICET_FIT_BLOCKS 4096
 #endif
-constexpr int kFitKeep = 256;                 // round-tripped rows per bin kept in LDS for the second (centred) pass; the rest goes through cart1[]
-struct FitLds { uint32_t qrow[128]; float qr[128]; float kx[kFitKeep], ky[kFitKeep], kz[kFitKeep]; };   // per wave: candidate queue + kept rows, 4 KB
-__global__ __launch_bounds__(kBlock, ICET_FIT_WAVES) void k_fit_scan1(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
+#ifndef ICET_RT_BLOCKS
+#define ICET_RT_BLOCKS 2048
+#endif
+struct FitItem { int32_t pair, v, k0, nb; };      // rows k0 .. k0 + nb of bin v's compacted candidates
+// A pair owns the item slots [item_base, item_base + n1 / 64 + V): at most one partial batch per bin plus the full ones.
+__device__ __host__ __forceinline__ size_t item_base(int32_t off1, int pair, int V) { return (size_t)(off1 / 64) + (size_t)pair * (size_t)(V + 1); }
+
+__global__ __launch_bounds__(kBlock, 8) void k_fit_cluster(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
                                                       const uint32_t* __restrict__ sorted_row, const float* __restrict__ r1,
-                                                      float* __restrict__ cart1, size_t cart_stride,
+                                                      uint32_t* __restrict__ cand, float* __restrict__ cand_r, FitItem* __restrict__ items, uint32_t* __restrict__ n_items,
+                                                      const int32_t* __restrict__ live, const int32_t* __restrict__ n_live,
                                                       FitMid* __restrict__ midD, int T, int P, int n, float thresh, float buff, int n_pairs, int chunks) {
-    __shared__ FitLds fl[kBlock / 64];
+    __shared__ float stage[kBlock / 64][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int V = T * P;
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;          // all bins of a pair on one XCD: its tables stay in that L2
-    const int v = chunk * (kBlock / 64) + wave;
-    if (v >= V) return;
     const PairDesc d = desc[pair];
-    const int theta = v % T, phi = v / T;
-    float az0, az1, el0, el1;
-    voxel_limits(theta, phi, T, P, az0, az1, el0, el1);
+    const int nl = n_live[pair];
+    // a fixed number of waves per pair walks the pair's live bins (those with >= n rows, src/icet.cpp:115): a wave per bin of the
+    // grid would launch 4 x as many waves as have work (measured: ~90 us of dispatching empty blocks per 256-pair launch)
+    for (int j = chunk * (kBlock / 64) + wave; j < nl; j += chunks * (kBlock / 64)) {
+    const int v = live[(size_t)pair * V + j];
     const int bs = bin_start[(size_t)pair * (V + 1) + v];
     const int cnt = bin_start[(size_t)pair * (V + 1) + v + 1] - bs;
     const size_t base = (size_t)d.off1 + bs;
@@ -442,11 +462,9 @@ __global__ __launch_bounds__(kBlock, ICET_FIT_WAVES) void k_fit_scan1(const Pair
     auto RS = [&](int i) { return r1[po + (sorted_row[base + i] & kRowMask)]; };
 
     float inner = 0.f, outer = 0.f;
-    int has_fit = 0;
-    float mean[3] = {0.f, 0.f, 0.f};
-    float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // xx xy xz yy yz zz
+    int m_cand = 0;                                                   // rows inside the radial range (wave-uniform)
 
-    if (cnt >= n) {
+    {
         // The bin's first 4 x 64 rows are fetched up front with independent loads (most bins hold ~100-400 rows), so
         // the serial walks below run on registers instead of paying one memory round trip per 64 rows.
         constexpr int kCache = 4;
@@ -496,107 +514,167 @@ __global__ __launch_bounds__(kBlock, ICET_FIT_WAVES) void k_fit_scan1(const Pair
             if (front != 0.f) { const float back = RS(cnt - 1); inner = front - buff; outer = back + buff; }
             else { inner = 0.f; outer = 0.f; }
         }
-        // ---- filterPointsInsideCluster + sphericalToCartesian + mean / covariance (src/icet.cpp:155-162).  Nothing is fitted
-        // unless outerDistance > 0.1 (:158, float against a double literal), so bins without a cluster stop here.
+        // ---- the radial half of filterPointsInsideCluster (src/icet.cpp:609-652): rows with r in [inner, outer], compacted.  Nothing
+        // is fitted unless outerDistance > 0.1 (:158, float against a double literal), so bins without a cluster stop here.
+#if !(defined(ICET_EXP_FIT) && ICET_EXP_FIT == 2)
         if ((double)outer > 0.1) {
-            const float* sx = d.s1; const float* sy = d.s1 + d.ld1; const float* sz = d.s1 + 2 * (size_t)d.ld1;
-            float* qx = cart1 + base; float* qy = qx + cart_stride; float* qz = qy + cart_stride;     // second-pass scratch beyond kFitKeep rows
-            FitLds& L = fl[wave];
-            // A row survives the filter iff its r lies in [inner, outer] and its angles lie inside the voxel's f32 limits.  The
-            // angular half holds by construction for a row classified away from every edge (the same argument as for the bin
-            // itself); a row flagged near-edge is tested with the literal formulas.  Survivors go through the reference's
-            // spherical -> Cartesian round trip under the shared rule (roundtrip_cr: double-precision atan2 / acos).  That is the
-            // expensive part, so the rows inside the radial range are first COMPACTED into a per-wave LDS queue and the round trip
-            // runs on full 64-lane batches; the sums are exact (double accumulators over float addends: the shared rule), so the
-            // order in which rows are visited does not matter.
-            double sumx = 0.0, sumy = 0.0, sumz = 0.0; int rows = 0;
-            int qn = 0, done = 0;                                     // queue fill, candidates processed (both wave-uniform)
             const unsigned long long lt = (1ull << lane) - 1ull;
-            int c0 = 0;
-            while (c0 < cnt || qn > 0) {
-                if (c0 < cnt) {
-                    const int i = c0 + lane, c = c0 >> 6;
-                    uint32_t rw; float r;
-                    if (c < kCache) {                                 // block-uniform: the cached chunks, selected without indexing the register arrays
-                        rw = (c == 0) ? prw[0] : (c == 1) ? prw[1] : (c == 2) ? prw[2] : prw[3];
-                        r = (c == 0) ? pr[0] : (c == 1) ? pr[1] : (c == 2) ? pr[2] : pr[3];
-                    } else {
-                        rw = (i < cnt) ? sorted_row[base + i] : 0u;
-                        r = (i < cnt) ? r1[po + (rw & kRowMask)] : 0.f;
-                    }
-                    const bool cand = (i < cnt) && (r >= inner) && (r <= outer);
-                    const unsigned long long m = __ballot(cand);
-                    if (cand) { const int pos = qn + __popcll(m & lt); L.qrow[pos] = rw; L.qr[pos] = r; }
-                    qn += __popcll(m);
-                    c0 += 64;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            for (int c0 = 0; c0 < cnt; c0 += 64) {
+                const int i = c0 + lane, c = c0 >> 6;
+                uint32_t rw; float r;
+                if (c < kCache) {                                     // wave-uniform: the cached chunks, selected without indexing the register arrays
+                    rw = (c == 0) ? prw[0] : (c == 1) ? prw[1] : (c == 2) ? prw[2] : prw[3];
+                    r = (c == 0) ? pr[0] : (c == 1) ? pr[1] : (c == 2) ? pr[2] : pr[3];
+                } else {
+                    rw = (i < cnt) ? sorted_row[base + i] : 0u;
+                    r = (i < cnt) ? r1[po + (rw & kRowMask)] : 0.f;
                 }
-                if (qn >= 64 || (c0 >= cnt && qn > 0)) {
-                    const int nb = min(qn, 64);
-                    if (lane < nb) {
-                        const uint32_t rw = L.qrow[lane]; const float r = L.qr[lane];
-                        const uint32_t row = rw & kRowMask;
-                        float th, ph, X, Y, Z;
-                        roundtrip_cr(sx[row], sy[row], sz[row], r, th, ph, X, Y, Z);
-                        // NaN angles (r = 0, NaN rows) fail the test, like the reference's 1000 sentinel
-                        const bool in = !(rw & kSortedNearBit) || (th >= az0 && th <= az1 && ph >= el0 && ph <= el1);
-                        if (in) { sumx += (double)X; sumy += (double)Y; sumz += (double)Z; rows++; }
-                        else X = __builtin_nanf("");              // marks "did not survive" for the second pass
-                        const int k = done + lane;                    // done is a multiple of 64: lane l always owns the words k = l (mod 64)
-                        if (k < kFitKeep) { L.kx[k] = X; L.ky[k] = Y; L.kz[k] = Z; } else { qx[k] = X; qy[k] = Y; qz[k] = Z; }
-                    }
-                    const uint32_t w2 = L.qrow[lane + 64]; const float r2 = L.qr[lane + 64];     // shift the queue down by one batch
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-                    L.qrow[lane] = w2; L.qr[lane] = r2;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-                    done += nb; qn -= nb;
-                }
+                const bool in = (i < cnt) && (r >= inner) && (r <= outer);
+                const unsigned long long m = __ballot(in);
+                if (in) { const size_t pos = base + m_cand + __popcll(m & lt); cand[pos] = rw; cand_r[pos] = r; }
+                m_cand += __popcll(m);
             }
-            sumx = wave_sum_d(sumx); sumy = wave_sum_d(sumy); sumz = wave_sum_d(sumz); rows = wave_sum_i(rows);
-            if (rows * 3 >= n) {                              // src/icet.cpp:158 (size() counts coefficients)
-#pragma clang fp contract(off)
-                has_fit = 1;
-                mean[0] = (float)sumx / (float)rows; mean[1] = (float)sumy / (float)rows; mean[2] = (float)sumz / (float)rows;
-                double c[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                for (int k = lane; k < done; k += 64) {                     // the lane that wrote word k reads it: no fence needed
-                    const bool lds = k < kFitKeep;
-                    const float X = lds ? L.kx[k] : qx[k];
-                    if (X == X) {
-                        const float Y = lds ? L.ky[k] : qy[k], Z = lds ? L.kz[k] : qz[k];
-                        const float dx = X - mean[0], dy = Y - mean[1], dz = Z - mean[2];
-                        c[0] += (double)(dx * dx); c[1] += (double)(dx * dy); c[2] += (double)(dx * dz);
-                        c[3] += (double)(dy * dy); c[4] += (double)(dy * dz); c[5] += (double)(dz * dz);
-                    }
-                }
-                const float den = (float)(rows - 1);
-#pragma unroll
-                for (int k = 0; k < 6; k++) cov[k] = (float)wave_sum_d(c[k]) / den;
-            }
+            // announce the batches: one list and one counter per pair (a single counter for the whole launch serialises ~50 k
+            // returning atomics on one word: measured 0.4 ms)
+            const int nbatch = (m_cand + 63) >> 6;
+            uint32_t slot = 0;
+            if (lane == 0 && nbatch > 0) slot = atomicAdd(&n_items[pair], (uint32_t)nbatch);
+            slot = __shfl(slot, 0);
+            FitItem* mine = items + item_base(d.off1, pair, V);
+            for (int bI = lane; bI < nbatch; bI += 64) { FitItem it; it.pair = pair; it.v = v; it.k0 = 64 * bI; it.nb = min(64, m_cand - 64 * bI); mine[slot + bI] = it; }
         }
+#endif
     }
-    // one 64-byte record per bin, staged through LDS so that 16 lanes store it with one coalesced instruction
-    __shared__ float stage[kBlock / 64][16];
+    // one 64-byte record per live bin (the Gaussian is filled in by k_fit_moments; the records of the other bins were zeroed),
+    // staged through LDS so that 16 lanes store it with one coalesced instruction
     if (lane == 0) {
         float* g = stage[wave];
-        g[0] = mean[0]; g[1] = mean[1]; g[2] = mean[2];
 #pragma unroll
-        for (int k = 0; k < 6; k++) g[3 + k] = cov[k];
-        g[9] = inner; g[10] = outer; g[11] = __int_as_float(cnt); g[12] = __int_as_float(has_fit); g[13] = g[14] = g[15] = 0.f;
+        for (int k = 0; k < 9; k++) g[k] = 0.f;
+        g[9] = inner; g[10] = outer; g[11] = __int_as_float(cnt); g[12] = __int_as_float(0); g[13] = __int_as_float(m_cand); g[14] = g[15] = 0.f;
     }
     // same wave wrote and reads: LDS operations of one wave complete in order
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     if (lane < 16) reinterpret_cast<float*>(midD + (size_t)pair * V + v)[lane] = stage[wave][lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }   // live bins of this wave
+}
+
+#ifndef ICET_FIT_WAVES
+#define ICET_FIT_WAVES 4      /* register budget of the double-precision round trip (128 VGPRs) */
+#endif
+__global__ __launch_bounds__(kBlock, ICET_FIT_WAVES) void k_fit_roundtrip(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
+                                                      const uint32_t* __restrict__ cand, const float* __restrict__ cand_r,
+                                                      const FitItem* __restrict__ items, const uint32_t* __restrict__ n_items,
+                                                      float* __restrict__ cart1, size_t cart_stride, int T, int P, int n_pairs, int chunks) {
+    const int lane = threadIdx.x & 63;
+    const int V = T * P;
+    constexpr uint32_t kRowMask = ~kSortedNearBit;
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;          // the pair's blocks share an XCD: its scan and tables sit in that L2
+    const PairDesc d = desc[pair];
+    const uint32_t n_it = n_items[pair];
+    const FitItem* mine = items + item_base(d.off1, pair, V);
+    for (uint32_t w = chunk * (kBlock / 64) + (threadIdx.x >> 6); w < n_it; w += chunks * (kBlock / 64)) {
+        const FitItem it = mine[w];
+        if (lane >= it.nb) continue;
+        const size_t idx = (size_t)d.off1 + bin_start[(size_t)it.pair * (V + 1) + it.v] + it.k0 + lane;
+        const uint32_t rw = cand[idx]; const float r = cand_r[idx];
+        const uint32_t row = rw & kRowMask;
+        const float* sx = d.s1;
+        float th, ph, X, Y, Z;
+#if defined(ICET_EXP_FIT) && ICET_EXP_FIT == 1
+        X = sx[row]; Y = sx[d.ld1 + row]; Z = sx[2 * (size_t)d.ld1 + row]; th = 0.f; ph = 0.f;
+#else
+        roundtrip_cr(sx[row], sx[d.ld1 + row], sx[2 * (size_t)d.ld1 + row], r, th, ph, X, Y, Z);
+#endif
+        // The angular half of the filter holds by construction for a row classified away from every edge (the same argument as
+        // for the bin itself); a row flagged near-edge is tested with the literal formulas.  NaN angles (r = 0, NaN rows) fail the
+        // test, like the reference's 1000 sentinel.
+        if (rw & kSortedNearBit) {
+            float az0, az1, el0, el1;
+            voxel_limits(it.v % T, it.v / T, T, P, az0, az1, el0, el1);
+            if (!(th >= az0 && th <= az1 && ph >= el0 && ph <= el1)) X = __builtin_nanf("");     // marks "did not survive"
+        }
+        cart1[idx] = X; cart1[cart_stride + idx] = Y; cart1[2 * cart_stride + idx] = Z;
+    }
+}
+
+__global__ __launch_bounds__(kBlock, 8) void k_fit_moments(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start, const float* __restrict__ cart1,
+                                                      size_t cart_stride, const int32_t* __restrict__ live, const int32_t* __restrict__ n_live,
+                                                      FitMid* __restrict__ midD, int V, int n, int n_pairs, int chunks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const int nl = n_live[pair];
+    for (int j = chunk * (kBlock / 64) + wave; j < nl; j += chunks * (kBlock / 64)) {
+    const int v = live[(size_t)pair * V + j];
+    FitMid* mid = midD + (size_t)pair * V + v;
+    const int m = mid->pad[0];                                        // candidates of this bin (k_fit_cluster)
+    if (m <= 0) continue;
+    const size_t base = (size_t)desc[pair].off1 + bin_start[(size_t)pair * (V + 1) + v];
+    const float* qx = cart1 + base; const float* qy = qx + cart_stride; const float* qz = qy + cart_stride;
+    // Sums in double over float addends: exact (or within 2^-53), so the order of the lanes does not matter -- the shared rule.
+    constexpr int kKeep = 4;                                          // the first 256 rows stay in registers for the centred pass
+    float cx[kKeep], cy[kKeep], cz[kKeep];
+    double sumx = 0.0, sumy = 0.0, sumz = 0.0; int rows = 0;
+#pragma unroll
+    for (int k = 0; k < kKeep; k++) {
+        const int i = lane + 64 * k;
+        cx[k] = (i < m) ? qx[i] : __builtin_nanf(""); cy[k] = (i < m) ? qy[i] : 0.f; cz[k] = (i < m) ? qz[i] : 0.f;
+        if (cx[k] == cx[k]) { sumx += (double)cx[k]; sumy += (double)cy[k]; sumz += (double)cz[k]; rows++; }
+    }
+    for (int i = lane + 64 * kKeep; i < m; i += 64) {
+        const float X = qx[i];
+        if (X == X) { sumx += (double)X; sumy += (double)qy[i]; sumz += (double)qz[i]; rows++; }
+    }
+    sumx = wave_sum_d(sumx); sumy = wave_sum_d(sumy); sumz = wave_sum_d(sumz); rows = wave_sum_i(rows);
+    if (rows * 3 < n) continue;                                       // src/icet.cpp:158 (size() counts coefficients); has_fit stays 0
+    float mean[3], cov[6];
+    {
+#pragma clang fp contract(off)
+        mean[0] = (float)sumx / (float)rows; mean[1] = (float)sumy / (float)rows; mean[2] = (float)sumz / (float)rows;
+        double c[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < kKeep; k++) {
+            if (cx[k] == cx[k]) {
+                const float dx = cx[k] - mean[0], dy = cy[k] - mean[1], dz = cz[k] - mean[2];
+                c[0] += (double)(dx * dx); c[1] += (double)(dx * dy); c[2] += (double)(dx * dz);
+                c[3] += (double)(dy * dy); c[4] += (double)(dy * dz); c[5] += (double)(dz * dz);
+            }
+        }
+        for (int i = lane + 64 * kKeep; i < m; i += 64) {
+            const float X = qx[i];
+            if (X == X) {
+                const float dx = X - mean[0], dy = qy[i] - mean[1], dz = qz[i] - mean[2];
+                c[0] += (double)(dx * dx); c[1] += (double)(dx * dy); c[2] += (double)(dx * dz);
+                c[3] += (double)(dy * dy); c[4] += (double)(dy * dz); c[5] += (double)(dz * dz);
+            }
+        }
+        const float den = (float)(rows - 1);
+#pragma unroll
+        for (int k = 0; k < 6; k++) cov[k] = (float)wave_sum_d(c[k]) / den;
+    }
+    if (lane == 0) {
+        mid->mean[0] = mean[0]; mid->mean[1] = mean[1]; mid->mean[2] = mean[2];
+#pragma unroll
+        for (int k = 0; k < 6; k++) mid->cov[k] = cov[k];
+        mid->has_fit = 1;
+    }
+    }   // live bins of this wave
 }
 
 // fitCells1's per-bin tail (src/icet.cpp:181-252), one lane per angular bin: eigen-decomposition, U = eigenvectors^T, the six
 // sigma points and their inside test -> L, the scan-1 half of the gate at :290, and the records of the active voxels.
-__global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict__ midD, SlotHot* __restrict__ hotD, SlotFit* __restrict__ fitD,
+__global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict__ midD, const int32_t* __restrict__ bin_start, SlotHot* __restrict__ hotD, SlotFit* __restrict__ fitD,
                                                        int32_t* __restrict__ activeD, AuxDev aux, int T, int P, int n) {
     const int V = T * P;
     const int v = blockIdx.x * kBlock + threadIdx.x;
     const int pair = blockIdx.y;
     if (v >= V) return;
     const size_t o = (size_t)pair * V + v;
-    const FitMid m = midD[o];
+    FitMid m = midD[o];
+    m.cnt = bin_start[(size_t)pair * (V + 1) + v + 1] - bin_start[(size_t)pair * (V + 1) + v];     // bins below n rows have no record of their own (zeroed)
     const int theta = v % T, phi = v / T;
     float az0, az1, el0, el1;
     voxel_limits(theta, phi, T, P, az0, az1, el0, el1);
@@ -759,25 +837,41 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
         k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, w.flags, c.V, np, chunks, 0);
         ICET_LAUNCH_CHECK();
     }
-    e = launch_class_scan(w.counts, w.tile_base, w.bin_start, c.V, chunks, c.n_pairs, st);
+    e = launch_class_scan(w.counts, w.tile_base, w.bin_start, c.V, chunks, c.n_pairs, st, w.live_bins, w.n_live, c.n);
     if (e != hipSuccess) return e;
     k_bin_scatter<<<grid, blk, (size_t)c.V * 16, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks);
     ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 3) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
-    const int fit_chunks = (c.V + kBlock / 64 - 1) / (kBlock / 64);
-    k_fit_scan1<<<dim3(groups * fit_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.valA, w.r1, w.cart1, (size_t)w.cap_n1, w.midD, c.T, c.P, c.n, c.thresh, c.buff, np, fit_chunks);
+    // keyA / keyB (bucket-grouped keys and the overflow scratch of the rank sort) are dead by now: candidate rows and their r
+    e = hipMemsetAsync(w.fit_n_items, 0, sizeof(uint32_t) * c.n_pairs, st); if (e != hipSuccess) return e;
+    e = hipMemsetAsync(w.midD, 0, sizeof(FitMid) * (size_t)c.n_pairs * c.V, st); if (e != hipSuccess) return e;
+    FitItem* items = reinterpret_cast<FitItem*>(w.fit_items);
+    // a fixed number of blocks per pair walks the pair's live bins / work items (their numbers are only known on the device):
+    // enough blocks to fill the chip whatever the batch size
+    const int fit_chunks = std::max(1, std::min((c.V + kBlock / 64 - 1) / (kBlock / 64), (ICET_FIT_BLOCKS + c.n_pairs - 1) / c.n_pairs));
+    k_fit_cluster<<<dim3(groups * fit_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.valA, w.r1, w.keyA, reinterpret_cast<float*>(w.keyB), items, w.fit_n_items,
+                                                             w.live_bins, w.n_live, w.midD, c.T, c.P, c.n, c.thresh, c.buff, np, fit_chunks);
     ICET_LAUNCH_CHECK();
-    k_fit_finish<<<dim3((c.V + kBlock - 1) / kBlock, c.n_pairs), blk, 0, st>>>(w.midD, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n);
+    {
+        const int rt_chunks = std::max(1, std::min(64, (ICET_RT_BLOCKS + c.n_pairs - 1) / c.n_pairs));
+        k_fit_roundtrip<<<dim3(groups * rt_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.keyA, reinterpret_cast<const float*>(w.keyB), items, w.fit_n_items, w.cart1, (size_t)w.cap_n1,
+                                                                  c.T, c.P, np, rt_chunks);
+        ICET_LAUNCH_CHECK();
+    }
+    k_fit_moments<<<dim3(groups * fit_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.cart1, (size_t)w.cap_n1, w.live_bins, w.n_live, w.midD, c.V, c.n, np, fit_chunks);
+    ICET_LAUNCH_CHECK();
+    k_fit_finish<<<dim3((c.V + kBlock - 1) / kBlock, c.n_pairs), blk, 0, st>>>(w.midD, w.bin_start, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n);
     ICET_LAUNCH_CHECK();
     k_compact_slots<<<c.n_pairs, blk, 0, st>>>(w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, w.near_over_count, c.V);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }
 
-hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st) {
+hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st,
+                             int32_t* live, int32_t* n_live, int live_min) {
     k_bin_tiles<<<dim3((n_classes + kBlock - 1) / kBlock, n_pairs), kBlock, 0, st>>>(counts, tile_base, class_start, n_classes, chunks);
     ICET_LAUNCH_CHECK();
-    k_bin_scan<<<n_pairs, kBlock, 0, st>>>(class_start, n_classes);
+    k_bin_scan<<<n_pairs, kBlock, 0, st>>>(class_start, n_classes, live, n_live, live_min);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

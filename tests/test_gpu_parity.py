@@ -177,8 +177,8 @@ def test_batch_equals_singles_and_oracle(gpu_ctx, frames, sample_pc):
         assert np.array_equal(out["X"][k], single["X"]) and np.array_equal(out["pred_stds"][k], single["pred_stds"])
         ref = po.solve(s1[k], s2[k], x0=x0[k])
         # the truncated scans (k = 2, 3) are partial views with few voxels and a poorly constrained z / roll: held to the larger of the
-        # parity bound and 5 x the oracle's own answer-to-answer spread under a 1-ulp perturbation of scan 2
-        sens = oracle_sensitivity(s1[k], s2[k], x0=x0[k]) if k in (2, 3) else np.zeros(6)
+        # parity bound and 5 x the oracle's own answer-to-answer spread under a 1-ulp perturbation of both scans
+        sens = oracle_sensitivity(s1[k], s2[k], trials=4, scan1_too=True, x0=x0[k]) if k in (2, 3) else np.zeros(6)
         _check_solution(dict(X=out["X"][k], pred_stds=out["pred_stds"][k], cov=out["cov"][k]), ref, max(TOL_T, 5 * sens[:3].max()), max(TOL_R, 5 * sens[3:].max()))
 
 

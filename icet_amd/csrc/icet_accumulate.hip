@@ -52,18 +52,6 @@ constexpr int kXf = 48;                          // per-pair transform record, s
 // partial sums, which are flushed with one global atomic per touched word at the end.
 // Block -> (pair, chunk) is XCD-aware: all chunks of a pair have equal blockIdx % 8, i.e. share an
 // XCD and therefore its L2 copy of the pair's tables (speed only, never correctness).
-// Two values at once: the three multiplies / the fma are packed-FP32 instructions (v_pk_mul_f32, v_pk_fma_f32).
-typedef float vfloat2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void to_fix2(float a, float b, unsigned long long& fa, unsigned long long& fb) {
-    const vfloat2 v = {a, b};
-    const vfloat2 x = v * kFixScale;
-    vfloat2 h = x * 2.3283064365386963e-10f;                        // 2^-32
-    h.x = floorf(h.x); h.y = floorf(h.y);
-    const vfloat2 lo = __builtin_elementwise_fma(h, (vfloat2){-4294967296.0f, -4294967296.0f}, x);
-    fa = ((unsigned long long)(uint32_t)(int)h.x << 32) | (unsigned long long)(uint32_t)lo.x;
-    fb = ((unsigned long long)(uint32_t)(int)h.y << 32) | (unsigned long long)(uint32_t)lo.y;
-}
-
 // Partial sums of a slot that has no LDS row go straight to HBM.  Kept out of line so that the LDS update in the hot loop
 // stays a ds_add_* (a select between the two pointers would turn both into flat atomics).
 __device__ __noinline__ void spill_flush(uint32_t* A, uint32_t nraw, uint32_t nin, float S0, float S1, float S2, float S3, float S4,
@@ -162,10 +150,8 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
                   unsigned long long* F = lacc + slot * 10;
                   atomicAdd(&F[0], (unsigned long long)cr | ((unsigned long long)ci << 32));
                   if (ci) {
-                      unsigned long long f0, f1, f2, f3, f4, f5, f6, f7;
-                      to_fix2(a0, a1, f0, f1); to_fix2(a2, a3, f2, f3); to_fix2(a4, a5, f4, f5); to_fix2(a6, a7, f6, f7);
-                      atomicAdd(&F[1], f0); atomicAdd(&F[2], f1); atomicAdd(&F[3], f2); atomicAdd(&F[4], f3); atomicAdd(&F[5], f4);
-                      atomicAdd(&F[6], f5); atomicAdd(&F[7], f6); atomicAdd(&F[8], f7); atomicAdd(&F[9], to_fix(a8));
+                      atomicAdd(&F[1], to_fix(a0)); atomicAdd(&F[2], to_fix(a1)); atomicAdd(&F[3], to_fix(a2)); atomicAdd(&F[4], to_fix(a3)); atomicAdd(&F[5], to_fix(a4));
+                      atomicAdd(&F[6], to_fix(a5)); atomicAdd(&F[7], to_fix(a6)); atomicAdd(&F[8], to_fix(a7)); atomicAdd(&F[9], to_fix(a8));
                   }
               } else {
                   spill_flush(gacc + (size_t)slot * kAccWords, cr, ci, a0, a1, a2, a3, a4, a5, a6, a7, a8);

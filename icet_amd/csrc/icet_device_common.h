@@ -215,14 +215,14 @@ __device__ __forceinline__ void classify_literal(float qx, float qy, float qz, c
     }
 }
 
-// float -> 64-bit fixed point (floor(v * 2^36), two's complement) in 6 VALU instructions: the scaling is exact (power of
-// two), h = floor(x / 2^32) is a small integer held exactly in a float, and x - h * 2^32 is exact under fma and lies in
-// [0, 2^32).  Any fixed rounding rule would do; what matters is that integer addition is associative.
+// float -> 64-bit fixed point: v * 2^36 rounded to the nearest integer (ties to even), two's complement, in 3 instructions.
+// One double fma forms v * 2^36 + 1.5 * 2^52 with a single rounding; for |v| < 2^15 the sum lies in [2^52, 2^53), where the ulp
+// is 1, so the integer sits in the mantissa and subtracting the bit pattern of 1.5 * 2^52 leaves it (negative values included).
+// Any fixed rounding rule would do; what matters is that EVERY conversion on the path uses this one (a slot's sums may arrive
+// through LDS or straight in HBM) and that integer addition is associative.
 __device__ __forceinline__ unsigned long long to_fix(float v) {
-    const float x = v * kFixScale;
-    const float h = floorf(x * 2.3283064365386963e-10f);            // 2^-32
-    const float lo = fmaf(h, -4294967296.0f, x);
-    return ((unsigned long long)(uint32_t)(int)h << 32) | (unsigned long long)(uint32_t)lo;
+    const double x = fma((double)v, (double)kFixScale, 6755399441055744.0);          // 1.5 * 2^52
+    return (unsigned long long)(__double_as_longlong(x) - 0x4338000000000000LL);
 }
 
 // One run's partial sums into a slot's HBM accumulator record (kAccWords words: [raw | in << 32], then 9 fixed-point sums).

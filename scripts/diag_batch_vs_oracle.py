@@ -11,21 +11,24 @@ from oracle import pyoracle as po
 from concurrent.futures import ThreadPoolExecutor
 
 N = int(os.environ.get("N", "256"))
+ids = [int(v) for v in os.environ["PAIRS"].split(",")] if os.environ.get("PAIRS") else list(range(N))     # PAIRS=79,190: only these bench pairs
+N = len(ids)
 dev = torch.device("cuda", 0)
-pairs = [ls.make_batch_pair(k, device=dev) for k in range(N)]
+pairs = [ls.make_batch_pair(k, device=dev) for k in ids]
 h1 = [p[0].T.cpu().numpy() for p in pairs]; h2 = [p[1].T.cpu().numpy() for p in pairs]
 ctx = icet_amd.Context(0)
 gpu = [ctx.solve(h1[k], h2[k], 7, np.zeros(6), 24, 75, aux=True) for k in range(N)]
 def one(k):
     ref = po.solve(h1[k], h2[k], trace=True)
     lm = po.solve(h1[k], h2[k], mode=po.LIBMF)
-    return ref, lm["X"]
+    return ref, lm["X"], lm["pred_stds"]
 with ThreadPoolExecutor(16) as ex:
     res = list(ex.map(one, range(N)))
 kf_bad, cols, sign_diff, lmask_diff, fits = [], 0, 0, 0, 0
-dX = np.zeros((N, 6)); dps = np.zeros(N); dcov = np.zeros(N); dlib = np.zeros((N, 6))
+dX = np.zeros((N, 6)); dps = np.zeros(N); dcov = np.zeros(N); dlib = np.zeros((N, 6)); dlps = np.zeros(N)
 for k in range(N):
-    ref, xl = res[k]; t, ax = ref["trace"], gpu[k]["aux"]
+    ref, xl, pl = res[k]; t, ax = ref["trace"], gpu[k]["aux"]
+    dlps[k] = np.abs(pl / ref["pred_stds"] - 1).max()
     f = t["has_fit"] == 1
     same = (np.array_equal(ax["n1_raw"], t["n1_raw"]) and np.array_equal(ax["cluster_bounds"], t["bounds"]) and np.array_equal(ax["has_fit"], t["has_fit"])
             and all(np.array_equal(ax[g][f].view(np.uint32), t[o][f].view(np.uint32)) for g, o in (("mu1", "mu1"), ("sigma1", "sigma1"), ("evecs1", "evecs1"), ("l_diag", "Ldiag"))))
@@ -45,6 +48,9 @@ out = {
     "pairs_over_3e-4m_or_1e-4rad": int(((dX[:, :3].max(1) > 3e-4) | (dX[:, 3:].max(1) > 1e-4)).sum()),
     "oracle_rule_vs_libmf_dX_t_max": float(dlib[:, :3].max()), "oracle_rule_vs_libmf_dX_t_median": float(np.median(dlib[:, :3].max(1))),
     "oracle_rule_vs_libmf_pairs_over_3e-4m": int((dlib[:, :3].max(1) > 3e-4).sum()),
+    "oracle_rule_vs_libmf_rel_pred_stds_max": float(dlps.max()), "oracle_rule_vs_libmf_rel_pred_stds_p99": float(np.quantile(dlps, 0.99)),
+    "rel_pred_stds_p99": float(np.quantile(dps, 0.99)), "rel_cov_p99": float(np.quantile(dcov, 0.99)),
+    "rel_pred_stds_top5": [float(v) for v in np.sort(dps)[-5:]], "rel_pred_stds_top5_pairs": [int(k) for k in np.argsort(dps)[-5:]],
 }
 order = np.argsort(-dX[:, :3].max(1))
 out["dX_t_top5"] = [float(dX[k, :3].max()) for k in order[:5]]; out["dX_t_top5_pairs"] = [int(k) for k in order[:5]]

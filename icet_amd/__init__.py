@@ -5,6 +5,6 @@ Only what the path needs lives here: ``csrc/`` (HIP kernels + the C ABI of inclu
 (seeded synthetic scans for the BASELINE configs) and ``dist`` (sharding independent pairs over
 the GPUs of a node).
 """
-from .api import ICET, Context, IcetError, Params, load_library, default_context  # noqa: F401
+from .api import ICET, Context, MultiContext, IcetError, Params, load_library, default_context  # noqa: F401
 
-__all__ = ["ICET", "Context", "IcetError", "Params", "load_library", "default_context"]
+__all__ = ["ICET", "Context", "MultiContext", "IcetError", "Params", "load_library", "default_context"]

@@ -22,11 +22,12 @@ FLAG_TRUE_SORT = 2      # non-parity extension, see include/icet_hip.h
 
 # every symbol include/icet_hip.h, include/icet_nodes.h and include/icet_io.h declare
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_batch",
-                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_set_option",
+                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_set_option", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
+                    "icet_multi_solve_batch", "icet_multi_solve_batch_device",
                     "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_map",
                     "icet_node_prev_scan", "icet_node_aligned", "icet_node_snail_trail", "icet_node_last_timing", "icet_stream", "icet_device",
                     "icet_load_scan", "icet_free_scan", "icet_save_scan_npy")
-_NON_STATUS = ("icet_version", "icet_last_error", "icet_stream", "icet_device", "icet_free_scan")
+_NON_STATUS = ("icet_version", "icet_last_error", "icet_stream", "icet_device", "icet_free_scan", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context")
 
 
 class IcetError(RuntimeError):
@@ -61,7 +62,7 @@ _I = C.POINTER(C.c_int32)
 
 class Aux(C.Structure):
     _fields_ = [("cluster_bounds", _F), ("n1_raw", _I), ("has_fit", _I), ("mu1", _F), ("sigma1", _F), ("evecs1", _F), ("l_diag", _F),
-                ("x_hist", _F), ("htwh", _F), ("htwdz", _F), ("n2_raw", _I), ("n2_in", _I)]
+                ("x_hist", _F), ("htwh", _F), ("htwdz", _F), ("n2_raw", _I), ("n2_in", _I), ("test_points", _F)]
 
 
 _lib = None
@@ -91,6 +92,14 @@ def load_library():
     L.icet_last_timing.argtypes = [C.c_void_p, C.c_void_p]
     L.icet_debug_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     L.icet_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    L.icet_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32]
+    L.icet_multi_destroy.argtypes = [C.c_void_p]
+    L.icet_multi_last_error.argtypes = [C.c_void_p]; L.icet_multi_last_error.restype = C.c_char_p
+    L.icet_multi_devices.argtypes = [C.c_void_p]; L.icet_multi_devices.restype = C.c_int32
+    L.icet_multi_context.argtypes = [C.c_void_p, C.c_int32]; L.icet_multi_context.restype = C.c_void_p
+    L.icet_multi_solve_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.icet_multi_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.POINTER(DevScan), C.c_void_p, C.c_void_p]
     L.icet_node_create.argtypes = [C.c_void_p, C.POINTER(NodeParams), C.POINTER(C.c_void_p)]
     L.icet_node_destroy.argtypes = [C.c_void_p]
     L.icet_node_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(NodeResult)]
@@ -189,7 +198,8 @@ class Context:
             arr = dict(cluster_bounds=np.zeros((V, 6), np.float32), n1_raw=np.zeros(V, np.int32), has_fit=np.zeros(V, np.int32),
                        mu1=np.zeros((V, 3), np.float32), sigma1=np.zeros((V, 3, 3), np.float32), evecs1=np.zeros((V, 3, 3), np.float32),
                        l_diag=np.zeros((V, 3), np.float32), x_hist=np.zeros((rl, 6), np.float32), htwh=np.zeros((rl, 6, 6), np.float32),
-                       htwdz=np.zeros((rl, 6), np.float32), n2_raw=np.zeros((rl, V), np.int32), n2_in=np.zeros((rl, V), np.int32))
+                       htwdz=np.zeros((rl, 6), np.float32), n2_raw=np.zeros((rl, V), np.int32), n2_in=np.zeros((rl, V), np.int32),
+                       test_points=np.zeros((V, 6, 3), np.float32))
             auxs = Aux()
             for k, v in arr.items():
                 setattr(auxs, k, v.ctypes.data_as(_I if v.dtype == np.int32 else _F))
@@ -225,6 +235,55 @@ class Context:
         st = load_library().icet_solve_batch_device(self._h, C.byref(params), k, A, B,
                                                     C.c_void_p(d_x0_ptr) if d_x0_ptr else None, C.c_void_p(d_out_ptr))
         self._check(st)
+
+
+class MultiContext:
+    """One context per GPU of this node (``icet_multi``): pair k of a batch runs on ``devices[k % len(devices)]``, results gathered."""
+
+    def __init__(self, devices):
+        L = load_library()
+        ids = (C.c_int32 * max(len(devices), 1))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        st = L.icet_multi_create(C.byref(h), ids, len(devices))
+        if st != ICET_OK:
+            raise IcetError(st, "icet_multi_create(%s)" % (list(devices),))
+        self._h = h
+        self.devices = list(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().icet_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != ICET_OK:
+            raise IcetError(st, load_library().icet_multi_last_error(self._h).decode())
+
+    def solve_batch(self, scans1, scans2, runlen, X0=None, num_bins_phi=24, num_bins_theta=75, n=25, thresh=0.1, buff=0.1):
+        k = len(scans1)
+        p = Params(int(runlen), int(num_bins_phi), int(num_bins_theta), int(n), float(thresh), float(buff), 0)
+        s1 = [_colmajor(s) for s in scans1]; s2 = [_colmajor(s) for s in scans2]
+        a1 = (C.c_void_p * max(k, 1))(*[s.ctypes.data for s in s1]); a2 = (C.c_void_p * max(k, 1))(*[s.ctypes.data for s in s2])
+        n1 = np.array([s.shape[1] for s in s1], np.int64); n2 = np.array([s.shape[1] for s in s2], np.int64)
+        x0 = None if X0 is None else np.ascontiguousarray(np.asarray(X0, np.float32).reshape(k, 6))
+        X = np.zeros((k, 6), np.float32); ps = np.zeros((k, 6), np.float32); cov = np.zeros((k, 36), np.float32)
+        self._check(load_library().icet_multi_solve_batch(self._h, C.byref(p), k, a1, n1.ctypes.data, a2, n2.ctypes.data,
+                                                          x0.ctypes.data if x0 is not None else None, X.ctypes.data, ps.ctypes.data, cov.ctypes.data))
+        return dict(X=X, pred_stds=ps, cov=cov.reshape(k, 6, 6))
+
+    def solve_batch_device(self, scan1_descs, scan2_descs, params, d_out_ptr, d_x0_ptr=None):
+        """scan*_descs[k] = (device_ptr, n, ld) on devices[k % len(devices)]; d_out / d_x0 on devices[0]."""
+        k = len(scan1_descs)
+        A = (DevScan * max(k, 1))(*[DevScan(int(p), int(n), int(ld)) for (p, n, ld) in scan1_descs])
+        B = (DevScan * max(k, 1))(*[DevScan(int(p), int(n), int(ld)) for (p, n, ld) in scan2_descs])
+        self._check(load_library().icet_multi_solve_batch_device(self._h, C.byref(params), k, A, B,
+                                                                 C.c_void_p(d_x0_ptr) if d_x0_ptr else None, C.c_void_p(d_out_ptr)))
 
 
 _default_ctx = {}
@@ -268,6 +327,7 @@ class ICET:
         if side_tables:
             a = res["aux"]
             self.clusterBounds = a["cluster_bounds"]
+            self.testPoints = a["test_points"].reshape(-1, 3)           # (V * 6) x 3, src/icet.cpp:41,213-231 (zeros where the reference leaves garbage)
             fit = a["has_fit"] == 1
             self.ellipsoid1Means = list(a["mu1"][fit])
             self.ellipsoid1Covariances = list(a["sigma1"][fit])

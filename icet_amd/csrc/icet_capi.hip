@@ -230,7 +230,7 @@ icet_status ensure_out(icet_ctx* c, int32_t n_pairs) {
 
 void free_aux(icet_ctx* c) {
     AuxDev& a = c->aux_dev;
-    void* ps[] = {a.bounds, a.n1_raw, a.has_fit, a.mu1, a.sigma1, a.evecs1, a.l_diag, a.x_hist, a.htwh, a.htwdz, a.n2_raw, a.n2_in};
+    void* ps[] = {a.bounds, a.n1_raw, a.has_fit, a.mu1, a.sigma1, a.evecs1, a.l_diag, a.x_hist, a.htwh, a.htwdz, a.n2_raw, a.n2_in, a.test_points};
     for (void* p : ps) if (p) (void)hipFree(p);
     a = AuxDev{};
     c->aux_V = 0; c->aux_runlen = 0;
@@ -244,7 +244,7 @@ icet_status ensure_aux(icet_ctx* c, int V, int runlen) {
     const size_t rl = runlen > 0 ? runlen : 1;
     HIPCHK(c, dev_realloc(a.bounds, (size_t)V * 6)); HIPCHK(c, dev_realloc(a.n1_raw, V)); HIPCHK(c, dev_realloc(a.has_fit, V));
     HIPCHK(c, dev_realloc(a.mu1, (size_t)V * 3)); HIPCHK(c, dev_realloc(a.sigma1, (size_t)V * 9)); HIPCHK(c, dev_realloc(a.evecs1, (size_t)V * 9));
-    HIPCHK(c, dev_realloc(a.l_diag, (size_t)V * 3));
+    HIPCHK(c, dev_realloc(a.l_diag, (size_t)V * 3)); HIPCHK(c, dev_realloc(a.test_points, (size_t)V * 18));
     HIPCHK(c, dev_realloc(a.x_hist, rl * 6)); HIPCHK(c, dev_realloc(a.htwh, rl * 36)); HIPCHK(c, dev_realloc(a.htwdz, rl * 6));
     HIPCHK(c, dev_realloc(a.n2_raw, rl * V)); HIPCHK(c, dev_realloc(a.n2_in, rl * V));
     c->aux_V = V; c->aux_runlen = runlen;
@@ -592,6 +592,7 @@ icet_status icet_solve(icet_ctx* c, const icet_params* p, const float* scan1, in
         ICET_AUX_COPY(mu1, mu1, (size_t)V * 3, float); ICET_AUX_COPY(sigma1, sigma1, (size_t)V * 9, float); ICET_AUX_COPY(evecs1, evecs1, (size_t)V * 9, float);
         ICET_AUX_COPY(l_diag, l_diag, (size_t)V * 3, float); ICET_AUX_COPY(x_hist, x_hist, rl * 6, float); ICET_AUX_COPY(htwh, htwh, rl * 36, float);
         ICET_AUX_COPY(htwdz, htwdz, rl * 6, float); ICET_AUX_COPY(n2_raw, n2_raw, rl * V, int32_t); ICET_AUX_COPY(n2_in, n2_in, rl * V, int32_t);
+        ICET_AUX_COPY(test_points, test_points, (size_t)V * 18, float);
 #undef ICET_AUX_COPY
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));

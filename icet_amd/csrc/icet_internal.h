@@ -78,7 +78,7 @@ static_assert(sizeof(SlotHot) == 48 && sizeof(SlotFit) == 80, "k_compact_slots c
 // Optional dense (per-voxel) dump for the reference's public side tables; device pointers or null.
 struct AuxDev {
     float* bounds; int32_t* n1_raw; int32_t* has_fit; float* mu1; float* sigma1; float* evecs1; float* l_diag;
-    float* x_hist; float* htwh; float* htwdz; int32_t* n2_raw; int32_t* n2_in;
+    float* x_hist; float* htwh; float* htwdz; int32_t* n2_raw; int32_t* n2_in; float* test_points;
 };
 
 struct Workspace {

@@ -688,6 +688,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
         // testSigmaPoints walks j = 0..5 and leaves the loop AFTER testing the first point with r > outer (:669-686).
         bool inside[6] = {false, false, false, false, false, false};
         bool done = false;
+        float spx[6], spy[6], spz[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             const int k = j >> 1;
@@ -701,10 +702,19 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
                 py = (j & 1) ? m.mean[1] - r1_ : m.mean[1] + r1_;
                 pz = (j & 1) ? m.mean[2] - r2_ : m.mean[2] + r2_;
             }
+            spx[j] = px; spy[j] = py; spz[j] = pz;
             if (!done) {
                 float r, az, el; c2s_cr(px, py, pz, r, az, el);
                 inside[j] = inside_bounds(r, az, el, az0, az1, el0, el1, inner, outer);
                 done = r > outer;
+            }
+        }
+        if (aux.test_points) {          // `testPoints` (src/icet.cpp:213-231): the sigma points of every axis that is pruned
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const bool pruned = !(inside[j & ~1] || inside[j | 1]);
+                float* tp = aux.test_points + (o * 6 + j) * 3;
+                tp[0] = pruned ? spx[j] : 0.f; tp[1] = pruned ? spy[j] : 0.f; tp[2] = pruned ? spz[j] : 0.f;
             }
         }
         Ld[0] = (inside[0] || inside[1]) ? 1.f : 0.f; Ld[1] = (inside[2] || inside[3]) ? 1.f : 0.f; Ld[2] = (inside[4] || inside[5]) ? 1.f : 0.f;
@@ -732,6 +742,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
     if (aux.sigma1) { float* sg = aux.sigma1 + o * 9; sg[0] = m.cov[0]; sg[1] = m.cov[1]; sg[2] = m.cov[2]; sg[3] = m.cov[1]; sg[4] = m.cov[3]; sg[5] = m.cov[4]; sg[6] = m.cov[2]; sg[7] = m.cov[4]; sg[8] = m.cov[5]; }
     if (aux.evecs1) for (int k = 0; k < 9; k++) aux.evecs1[o * 9 + k] = Vm[k];
     if (aux.l_diag) { aux.l_diag[o * 3] = Ld[0]; aux.l_diag[o * 3 + 1] = Ld[1]; aux.l_diag[o * 3 + 2] = Ld[2]; }
+    if (aux.test_points && !m.has_fit) for (int k = 0; k < 18; k++) aux.test_points[o * 18 + k] = 0.f;
 }
 
 // Dense per-voxel records -> compact slots in voxel order (phi-major, theta inner: the reference's

@@ -8,12 +8,18 @@
 //
 // Needs Eigen (as the reference does).  Eigen is not present in the build image of this repository, so this adapter
 // is deliberately a thin copy-in / copy-out shim over the Eigen-free icet_amd::ICET of include/icet_host.hpp, which
-// is what the test-suite compiles and runs (tests/cpp).  Members the reference keeps only for its own internals
-// (pointIndices1/2, the sigma1/mu1/U/L std::maps, points1Spherical, ...) are not exposed; no caller reads them.
+// is what the test-suite compiles and runs (tests/cpp); the adapter itself is compiled and run against a minimal Eigen-API mock
+// (tests/cpp/mock_eigen, tests/cpp/adapter_demo.cpp) so that it cannot rot.  Members the reference keeps only for its own
+// internals (pointIndices1/2, the sigma1/mu1/U/L std::maps, points1Spherical, ...) are not exposed; no caller reads them.
+// Two members differ in content, neither is read by any caller: `points2_OG` holds scan 2 as given (the reference stores it after
+// its radial "sort" and a spherical round trip, src/icet.cpp:263-275: same points, permuted, <= 2 ulp away -- the device never
+// sorts scan 2); `testPoints` holds the sigma points of the pruned axes like the reference's (src/icet.cpp:213-231) and ZEROS in the
+// rows the reference leaves uninitialised.
 #ifndef ICET_H
 #define ICET_H
 
 #include <Eigen/Dense>
+#include <string>
 #include <vector>
 #include "icet_host.hpp"
 
@@ -38,6 +44,9 @@ public:
             for (int v = 0; v < V; v++) for (int k = 0; k < 6; k++) clusterBounds(v, k) = it.clusterBounds[v * 6 + k];
         if ((long)it.points2.size() == scan2.rows() * 3)
             points2 = Eigen::Map<const Eigen::MatrixXf>(it.points2.data(), scan2.rows(), 3);
+        testPoints = Eigen::MatrixXf::Zero(V * 6, 3);                  // src/icet.cpp:41
+        if ((int)it.testPoints.size() == V * 18)
+            for (int r = 0; r < V * 6; r++) for (int k = 0; k < 3; k++) testPoints(r, k) = it.testPoints[r * 3 + k];
         for (size_t i = 0; i < it.ellipsoid1Means.size(); i++) {
             ellipsoid1Means.emplace_back(it.ellipsoid1Means[i][0], it.ellipsoid1Means[i][1], it.ellipsoid1Means[i][2]);
             Eigen::Matrix3f c;
@@ -54,7 +63,7 @@ public:
     // algorithm params
     int rl; int numBinsPhi; int numBinsTheta; int n; float thresh; float buff;
 
-    Eigen::MatrixXf points1, points2, points2_OG, clusterBounds, HTWH_i, HTWdz_i;
+    Eigen::MatrixXf points1, points2, points2_OG, clusterBounds, testPoints, HTWH_i, HTWdz_i;
     Eigen::VectorXf pred_stds;
     Eigen::VectorXf X;    // global solution vector (x, y, z, roll, pitch, yaw)
     Eigen::VectorXf dx;   // last linear perturbation

@@ -74,6 +74,9 @@ typedef struct icet_aux {
     float*   htwdz;           /* runlen x 6  (`HTWdz_i` per iteration)                                    */
     int32_t* n2_raw;          /* runlen x V: |pointIndices2| (only voxels with a scan-1 fit are counted) */
     int32_t* n2_in;           /* runlen x V: scan-2 points inside the voxel's cluster bounds             */
+    float*   test_points;     /* (V x 6) x 3 row-major (`testPoints`, src/icet.cpp:41,213-231): rows 6v + 2k, 6v + 2k + 1 hold
+                                 the two sigma points of axis k of voxel v when that axis was pruned (L row k = 0); every
+                                 other row is zero (the reference leaves those rows uninitialised)                          */
 } icet_aux;
 
 typedef struct icet_ctx icet_ctx;   /* opaque: device id, stream, workspace */
@@ -139,6 +142,30 @@ icet_status icet_debug_fetch(icet_ctx* ctx, int32_t what, void* out, int64_t cou
  * the hand-written rank sort), "guard_scale" (>= 1), "lut_polar_quantile" (0..1).  Unknown name or value
  * out of range: ICET_ERR_BAD_ARG. */
 icet_status icet_set_option(icet_ctx* ctx, const char* name, double value);
+
+/* The HIP stream (hipStream_t as void*) and device a context enqueues on -- for callers that produce scans on the GPU. */
+void* icet_stream(icet_ctx* ctx);
+int   icet_device(const icet_ctx* ctx);
+
+/* --- the batched-pairs case over several GPUs of one node (BASELINE.json configs[3]) ---------
+ * The reference has no counterpart: it constructs one ICET object per pair on the calling thread.  A handle owns one context per
+ * device; pair k of a call runs on device_ids[k mod n_devices] from its own host thread, and the 48 result floats per pair are
+ * gathered into ONE buffer -- the caller's host arrays, or HBM of device_ids[0] through peer copies over xGMI.  There is no
+ * data-path collective; a process that runs one rank per GPU gathers with torch.distributed / RCCL instead (icet_amd/dist.py). */
+typedef struct icet_multi icet_multi;
+icet_status icet_multi_create(icet_multi** handle, const int32_t* device_ids, int32_t n_devices);   /* ids distinct, each < device count */
+icet_status icet_multi_destroy(icet_multi* handle);
+const char* icet_multi_last_error(const icet_multi* handle);
+int32_t     icet_multi_devices(const icet_multi* handle);
+icet_ctx*   icet_multi_context(icet_multi* handle, int32_t i);      /* the context of device_ids[i] (e.g. for icet_set_option / icet_reserve) */
+/* HOST pointers in and out, same meaning as icet_solve_batch. */
+icet_status icet_multi_solve_batch(icet_multi* handle, const icet_params* p, int32_t n_pairs,
+                                   const float* const* scan1, const int64_t* n1, const float* const* scan2, const int64_t* n2,
+                                   const float* x0, float* x_out, float* pred_stds_out, float* cov_out);
+/* Scans resident in HBM: scan1[k] / scan2[k] on device_ids[k mod n_devices]; d_x0 (n_pairs x 6 or NULL) and d_out (n_pairs x 48,
+ * layout of icet_solve_batch_device) on device_ids[0].  Returns after the gather has completed. */
+icet_status icet_multi_solve_batch_device(icet_multi* handle, const icet_params* p, int32_t n_pairs,
+                                          const icet_dev_scan* scan1, const icet_dev_scan* scan2, const float* d_x0, float* d_out);
 
 #ifdef __cplusplus
 }

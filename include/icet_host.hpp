@@ -58,6 +58,7 @@ public:
         if (side_tables && V > 0) {
             clusterBounds.assign((size_t)V * 6, 0.f); has_fit.assign(V, 0); mu1.assign((size_t)V * 3, 0.f); sigma1.assign((size_t)V * 9, 0.f);
             x_hist.assign((size_t)RL * 6, 0.f); htwh.assign((size_t)RL * 36, 0.f); htwdz.assign((size_t)RL * 6, 0.f);
+            testPoints.assign((size_t)V * 18, 0.f); aux.test_points = testPoints.data();
             aux.cluster_bounds = clusterBounds.data(); aux.has_fit = has_fit.data(); aux.mu1 = mu1.data(); aux.sigma1 = sigma1.data();
             aux.x_hist = x_hist.data(); aux.htwh = htwh.data(); aux.htwdz = htwdz.data();
         }
@@ -104,6 +105,7 @@ public:
     std::array<float, 36> cov{};                 // 6x6 noise_mat, row-major (a local in the reference, src/icet.cpp:410-411)
     std::array<float, 36> HTWH_i{}; std::array<float, 6> HTWdz_i{};
     std::vector<float> clusterBounds;            // V x 6 row-major
+    std::vector<float> testPoints;               // (V * 6) x 3 row-major: sigma points of the pruned axes (src/icet.cpp:213-231), zeros elsewhere
     std::vector<float> points2;                  // n2 x 3 column-major
     std::vector<std::array<float, 3>> ellipsoid1Means, ellipsoid2Means;
     std::vector<std::array<float, 9>> ellipsoid1Covariances, ellipsoid2Covariances;

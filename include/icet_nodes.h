@@ -84,10 +84,6 @@ icet_status icet_node_snail_trail(icet_node* node, float* out, int64_t ld, int64
  * [0] range filter ms, [1] ICET solve ms, [2] map-queue kernel ms (0 if no map). */
 icet_status icet_node_last_timing(icet_node* node, float out_ms[3]);
 
-/* The HIP stream (hipStream_t as void*) and device a context enqueues on -- for callers that produce scans on the GPU. */
-void* icet_stream(icet_ctx* ctx);
-int   icet_device(const icet_ctx* ctx);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,40 @@
+// tests/cpp/adapter_demo.cpp -- compiles and runs include/icet.h (the adapter with the reference's class name, constructor signature
+// and member names) through the call pattern of /root/reference/src/odometry.cpp:73-82: construct `ICET it(prev, cur, run_length, X0,
+// numBinsPhi, numBinsTheta)`, read it.X and it.pred_stds, seed X0 for the next frame.  Built against tests/cpp/mock_eigen (this image
+// has no Eigen; the mock pins no numerics) or against the real Eigen when one is installed (-DICET_TEST_REAL_EIGEN -I<eigen>).
+// usage: adapter_demo scan1.f32 scan2.f32 n1 n2          (files: column-major N x 3 float32)
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <vector>
+#include "icet.h"
+
+static Eigen::MatrixXf slurp(const char* path, long n) {
+    Eigen::MatrixXf m(n, 3);
+    FILE* f = std::fopen(path, "rb");
+    if (!f || std::fread(m.data(), sizeof(float), (size_t)n * 3, f) != (size_t)n * 3) { std::fprintf(stderr, "cannot read %s\n", path); std::exit(2); }
+    std::fclose(f);
+    return m;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 5) return 2;
+    Eigen::MatrixXf prev_pcl_matrix = slurp(argv[1], std::atol(argv[3])), pcl_matrix = slurp(argv[2], std::atol(argv[4]));
+    Eigen::VectorXf X0(6);
+    X0 << 0., 0., 0., 0., 0., 0.;
+    for (int frame = 0; frame < 2; frame++) {
+        int run_length = 7;
+        int numBinsPhi = 24;
+        int numBinsTheta = 75;
+        ICET it(prev_pcl_matrix, pcl_matrix, run_length, X0, numBinsPhi, numBinsTheta);
+        if (it.status != ICET_OK) { std::fprintf(stderr, "status %d: %s\n", (int)it.status, it.error.c_str()); return 1; }
+        Eigen::VectorXf X = it.X;
+        std::printf("X %.9g %.9g %.9g %.9g %.9g %.9g\n", X[0], X[1], X[2], X[3], X[4], X[5]);
+        std::printf("pred_stds %.9g %.9g %.9g %.9g %.9g %.9g\n", it.pred_stds[0], it.pred_stds[1], it.pred_stds[2], it.pred_stds[3], it.pred_stds[4], it.pred_stds[5]);
+        std::printf("members %ld %ld %ld %ld %zu %zu %ld\n", it.clusterBounds.rows(), it.clusterBounds.cols(), it.points2.rows(), it.testPoints.rows(),
+                    it.ellipsoid1Means.size(), it.ellipsoid2Means.size(), it.HTWH_i.rows());
+        //seed initial estimate for next iteration
+        X0 << X[0], X[1], X[2], X[3], X[4], X[5];
+    }
+    return 0;
+}

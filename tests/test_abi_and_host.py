@@ -69,6 +69,42 @@ def test_null_and_bad_arguments_do_not_crash():
     assert not h.value
 
 
+def test_multi_device_entry_validates_arguments_without_gpu():
+    """icet_multi_* (the native multi-GPU entry of the batched-pairs case): argument checks run before any device is touched, and
+    without a device the handle cannot be created -- loudly, with the documented status."""
+    import icet_amd
+    lib = icet_amd.load_library()
+    A = icet_amd.api
+    h = C.c_void_p()
+    ids = (C.c_int32 * 2)(0, 0)
+    assert lib.icet_multi_create(None, ids, 1) == A.ICET_ERR_BAD_ARG
+    assert lib.icet_multi_create(C.byref(h), None, 1) == A.ICET_ERR_BAD_ARG and not h.value
+    assert lib.icet_multi_create(C.byref(h), ids, 0) == A.ICET_ERR_BAD_ARG and not h.value
+    if not torch.cuda.is_available():
+        assert lib.icet_multi_create(C.byref(h), ids, 1) == A.ICET_ERR_NO_DEVICE and not h.value
+        with pytest.raises(icet_amd.IcetError) as e:
+            icet_amd.MultiContext([0])
+        assert e.value.status == A.ICET_ERR_NO_DEVICE
+    assert lib.icet_multi_destroy(None) == A.ICET_ERR_BAD_ARG
+    assert lib.icet_multi_last_error(None) == b"null handle" and lib.icet_multi_devices(None) == 0 and lib.icet_multi_context(None, 0) is None
+    assert lib.icet_multi_solve_batch(None, None, 0, None, None, None, None, None, None, None, None) == A.ICET_ERR_BAD_ARG
+    assert lib.icet_multi_solve_batch_device(None, None, 0, None, None, None, None) == A.ICET_ERR_BAD_ARG
+    assert lib.icet_set_option(None, b"lds_slots", 1.0) == A.ICET_ERR_BAD_ARG
+
+
+def test_eigen_adapter_header_compiles_against_the_mock(tmp_path):
+    """include/icet.h must at least COMPILE and link everywhere (the run against a device is in tests/test_gpu_parity.py); without a
+    GPU the constructed object carries an error status instead of throwing."""
+    exe = str(tmp_path / "adapter_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "cpp", "mock_eigen"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "adapter_demo.cpp"), "-L", os.path.join(ROOT, "icet_amd", "lib"), "-licet_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "icet_amd", "lib"), "-o", exe])
+    if not torch.cuda.is_available():
+        np.zeros((3, 100), np.float32).tofile(str(tmp_path / "z.f32"))
+        out = subprocess.run([exe, str(tmp_path / "z.f32"), str(tmp_path / "z.f32"), "100", "100"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 1 and "status" in out.stderr
+
+
 def test_no_oracle_in_product_path():
     """The shipped package must not import, link or call anything under oracle/ (or the reference)."""
     for dp, _, fs in os.walk(os.path.join(ROOT, "icet_amd")):

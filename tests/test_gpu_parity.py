@@ -387,6 +387,42 @@ def test_icet_class_mirrors_reference_members(frames, frames_golden):
     assert np.abs(it.X[:3] - frames_golden["X"][:3]).max() <= TOL_T
 
 
+def test_eigen_adapter_header_compiles_and_runs(tmp_path, gpu_ctx, frames):
+    """include/icet.h -- the adapter with the reference's class name, constructor signature and members -- compiled with g++ against a
+    minimal Eigen-API mock (tests/cpp/mock_eigen: this image has no Eigen; the mock pins no numerics) and run through the call
+    pattern of src/odometry.cpp:73-82, two frames with X0 seeding: same X as the Python mirror, bit for bit."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a, b = frames
+    (tmp_path / "s1.f32").write_bytes(np.ascontiguousarray(a.T).tobytes())
+    (tmp_path / "s2.f32").write_bytes(np.ascontiguousarray(b.T).tobytes())
+    exe = str(tmp_path / "adapter_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(root, "tests", "cpp", "mock_eigen"), "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "adapter_demo.cpp"), "-L", os.path.join(root, "icet_amd", "lib"), "-licet_hip",
+                           "-Wl,-rpath," + os.path.join(root, "icet_amd", "lib"), "-o", exe])
+    out = subprocess.run([exe, str(tmp_path / "s1.f32"), str(tmp_path / "s2.f32"), str(a.shape[0]), str(b.shape[0])], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    X1 = np.array(lines[0].split()[1:], np.float32); X2 = np.array(lines[3].split()[1:], np.float32)
+    r1 = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75)
+    r2 = gpu_ctx.solve(a, b, 7, r1["X"], 24, 75)
+    assert np.array_equal(X1, r1["X"]) and np.array_equal(X2, r2["X"])
+    assert lines[2].split()[1:] == ["1800", "6", str(b.shape[0]), "10800", "86", "0", "6"]
+
+
+def test_test_points_member(gpu_ctx, frames):
+    """`testPoints` (include/icet.h:84, src/icet.cpp:213-231): the sigma points of every pruned axis, bit for bit the oracle's."""
+    from oracle import pyoracle as po
+    a, b = frames
+    g = gpu_ctx.solve(a, b, 1, np.zeros(6), 24, 75, aux=True)["aux"]
+    t = po.solve(a, b, runlen=1, trace=True)["trace"]
+    f = t["has_fit"] == 1
+    pruned = np.repeat(t["Ldiag"] == 0, 2, axis=1) & f[:, None]                  # (V, 6): both sigma points of a pruned axis
+    assert pruned.sum() > 20
+    assert np.array_equal(g["test_points"][pruned].view(np.uint32), t["sigma_points"][pruned].view(np.uint32))
+    assert not g["test_points"][~pruned].any()
+
+
 def test_error_behaviour(gpu_ctx, frames):
     import icet_amd
     a, b = frames
@@ -458,6 +494,65 @@ def test_many_pairs_parity_natural_signs(gpu_ctx):
     print("128 pairs, natural signs: max |dX_t| %.3g m, |dX_r| %.3g rad, rel pred_stds %.3g, rel cov %.3g; median |dX_t| %.3g; within 1e-4 m / 1e-5 rad: %.1f %%"
           % (*worst, np.median(dts), 100 * within))
     assert np.median(dts) < 5e-6 and np.median(drs) < 5e-7 and within >= 0.93, (np.median(dts), np.median(drs), within)
+
+
+def test_rccl_gather_on_one_rank_is_the_identity():
+    """icet_amd.dist.gather_results through RCCL (torch.distributed backend "nccl") with a process group of ONE rank on cuda:0: the
+    all-gather + de-interleave must return the rank's own rows.  This is as much of the N > 1 path as a 1-GPU box can run; the
+    world-size-2 logic is covered by the gloo test on CPU (tests/test_abi_and_host.py)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from icet_amd.dist import gather_results, solve_sharded
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+x = torch.arange(7 * 48, dtype=torch.float32, device=dev).reshape(7, 48) * 0.5
+y = gather_results(x, 7)
+assert y.shape == x.shape and torch.equal(x, y) and y.data_ptr() != x.data_ptr()
+z = solve_sharded(5, lambda ids: torch.full((len(ids), 48), 3.0, device=dev) * torch.tensor(ids, device=dev, dtype=torch.float32)[:, None], dev)
+assert torch.equal(z[:, 0].cpu(), torch.tensor([0., 3., 6., 9., 12.]))
+dist.barrier(); dist.destroy_process_group()
+print("rccl one-rank gather ok")
+"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "rccl one-rank gather ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_multi_device_entry_with_one_device_equals_the_single_context(gpu_ctx, frames, sample_pc):
+    """icet_multi_* with n_devices = 1 (all this box has): the host-pointer entry must reproduce icet_solve_batch bit for bit, the
+    device-resident entry icet_solve_batch_device -- X0 scatter and result gather included -- and duplicate / unknown device ids
+    are refused.  (No N > 1 run has happened anywhere yet: DESIGN.md section 9.)"""
+    import icet_amd
+    from icet_amd import lidar_sim as ls, api
+    a, b = frames; c, d = sample_pc
+    s1 = [a, c, a[:30000], b]; s2 = [b, d, b[:31000], a]
+    x0 = np.zeros((4, 6), np.float32); x0[1, 0] = 0.3; x0[3, 5] = 0.01
+    ref = gpu_ctx.solve_batch(s1, s2, 7, x0)
+    m = icet_amd.MultiContext([0])
+    got = m.solve_batch(s1, s2, 7, x0)
+    for key in ("X", "pred_stds", "cov"):
+        assert np.array_equal(got[key], ref[key]), key
+    dev = torch.device("cuda", 0)
+    pairs = [ls.make_batch_pair(k, device=dev) for k in range(3)]
+    d1 = [(p[0].data_ptr(), p[0].shape[1], p[0].shape[1]) for p in pairs]; d2 = [(p[1].data_ptr(), p[1].shape[1], p[1].shape[1]) for p in pairs]
+    xd = torch.zeros((3, 6), dtype=torch.float32, device=dev); xd[:, 0] = torch.tensor([0.0, 0.02, -0.01], device=dev)
+    o_multi = torch.zeros((3, 48), dtype=torch.float32, device=dev); o_single = torch.zeros_like(o_multi)
+    torch.cuda.synchronize()
+    prm = api.Params(7, 24, 75, 25, 0.1, 0.1, 0)
+    m.solve_batch_device(d1, d2, prm, o_multi.data_ptr(), xd.data_ptr())
+    ctx = icet_amd.Context(0); ctx.solve_batch_device(d1, d2, prm, o_single.data_ptr(), xd.data_ptr()); ctx.sync(); ctx.close()
+    torch.cuda.synchronize()
+    assert torch.equal(o_multi, o_single) and bool(torch.isfinite(o_multi).all())
+    m.close()
+    with pytest.raises(icet_amd.IcetError) as e:
+        icet_amd.MultiContext([0, 0])
+    assert e.value.status == api.ICET_ERR_BAD_ARG
+    with pytest.raises(icet_amd.IcetError) as e:
+        icet_amd.MultiContext([0, 63])
+    assert e.value.status == api.ICET_ERR_NO_DEVICE
 
 
 def test_rarely_taken_paths_give_the_same_bits(gpu_ctx, frames, sample_pc):

@@ -27,6 +27,7 @@ struct icet_ctx {
     bool own_stream = false;
     Workspace w;
     Tuning tune;                    // icet_set_option
+    int32_t kf_pairs = 0; icet_params kf_params{};      // a keyframe parked by icet_keyframe_device (0 pairs = none)
     int max_lds = 160 * 1024;       // hipDeviceAttributeMaxSharedMemoryPerBlock of the device
     std::string err;
     // host staging (pinned) for descriptors and results
@@ -252,8 +253,11 @@ icet_status ensure_aux(icet_ctx* c, int V, int runlen) {
 }
 
 // Enqueue the whole solve for descriptors already sitting in c->h_desc[0..n_pairs).
-icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const float* d_x0, float* d_out, const AuxDev* aux) {
-    Workspace& w = c->w;
+// The solve in two halves, so that a sequential caller can build the keyframe of a scan while the previous pair is still iterating
+// (icet_keyframe_device / icet_register_device): enqueue_keyframe = ICET::fitScan1 (src/icet.cpp:68-107) for the scan-1 halves of the
+// descriptors in c->h_desc[0..n_pairs), enqueue_loop = prepScan2 + runlen x fitScan2 (:254-277, :372-436) for their scan-2 halves
+// against the tables the keyframe left in the workspace.
+LaunchCfg make_cfg(icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     LaunchCfg cfg{};
     cfg.T = p->bins_theta; cfg.P = p->bins_phi; cfg.V = cfg.T * cfg.P; cfg.n = p->n; cfg.runlen = p->runlen;
     cfg.thresh = p->thresh; cfg.buff = p->buff; cfg.n_pairs = n_pairs;
@@ -264,11 +268,9 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     if (cfg.kf_pts_per_thread < 1) cfg.kf_pts_per_thread = 1;
     cfg.stage_event = c->stage_at ? c->ev_stage : nullptr; cfg.stage_at = c->stage_at;
     cfg.vec4_ok = 1;
-    for (int k = 0; k < n_pairs; k++)
-        if ((reinterpret_cast<uintptr_t>(c->h_desc[k].s2) & 15u) || (c->h_desc[k].ld2 & 3)) { cfg.vec4_ok = 0; break; }
-    { icet_status ts = ensure_thresholds(c, cfg.T, cfg.P); if (ts != ICET_OK) return ts; }
     int64_t tot = 0, tot2 = 0; int mx1 = 0, mx2 = 0;
     for (int k = 0; k < n_pairs; k++) {
+        if ((reinterpret_cast<uintptr_t>(c->h_desc[k].s2) & 15u) || (c->h_desc[k].ld2 & 3)) cfg.vec4_ok = 0;
         c->h_seg[k] = (int32_t)tot; c->h_desc[k].off1 = (int32_t)tot; tot += c->h_desc[k].n1;
         c->h_desc[k].off2 = (int32_t)tot2; tot2 += c->h_desc[k].n2;
         if (c->h_desc[k].n1 > mx1) mx1 = c->h_desc[k].n1;
@@ -278,6 +280,22 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     cfg.total_n1 = tot; cfg.max_n1 = mx1; cfg.max_n2 = mx2;
     cfg.kf_chunks = (mx1 + 256 * cfg.kf_pts_per_thread - 1) / (256 * cfg.kf_pts_per_thread);
     if (cfg.kf_chunks < 1) cfg.kf_chunks = 1;
+    return cfg;
+}
+
+icet_status upload_desc(icet_ctx* c, int32_t n_pairs) {
+    Workspace& w = c->w;
+    HIPCHK(c, hipMemcpyAsync(w.desc, c->h_desc, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(w.seg_off, c->h_seg, sizeof(int32_t) * (n_pairs + 1), hipMemcpyHostToDevice, c->stream));
+    if (!c->ev_desc) HIPCHK(c, hipEventCreateWithFlags(&c->ev_desc, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_desc, c->stream)); c->desc_in_flight = true;
+    return ICET_OK;
+}
+
+icet_status enqueue_keyframe(icet_ctx* c, const icet_params* p, int32_t n_pairs, const AuxDev* aux) {
+    Workspace& w = c->w;
+    { icet_status ts = ensure_thresholds(c, p->bins_theta, p->bins_phi); if (ts != ICET_OK) return ts; }
+    const LaunchCfg cfg = make_cfg(c, p, n_pairs);
     {
         const size_t need = (size_t)n_pairs * cfg.kf_chunks * (cfg.V > kRankSortMaxBuckets ? cfg.V : kRankSortMaxBuckets);
         if (need > w.cap_counts) {
@@ -286,13 +304,17 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
             w.cap_counts = need;
         }
     }
-    HIPCHK(c, hipMemcpyAsync(w.desc, c->h_desc, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(w.seg_off, c->h_seg, sizeof(int32_t) * (n_pairs + 1), hipMemcpyHostToDevice, c->stream));
-    if (!c->ev_desc) HIPCHK(c, hipEventCreateWithFlags(&c->ev_desc, hipEventDisableTiming));
-    HIPCHK(c, hipEventRecord(c->ev_desc, c->stream)); c->desc_in_flight = true;
-    while ((int)c->ev_acc.size() < 2 * p->runlen) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_acc.push_back(e); }
+    { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }
     HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
     HIPCHK(c, launch_keyframe(w, cfg, aux, c->stream));
+    return ICET_OK;
+}
+
+icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, const float* d_x0, float* d_out, const AuxDev* aux, bool reupload) {
+    Workspace& w = c->w;
+    const LaunchCfg cfg = make_cfg(c, p, n_pairs);
+    if (reupload) { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }      // the scan-2 halves arrived after the keyframe call
+    while ((int)c->ev_acc.size() < 2 * p->runlen) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_acc.push_back(e); }
     HIPCHK(c, launch_init_state(w, cfg, d_x0, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
     const bool per_iter = (p->flags & ICET_FLAG_TIMING) != 0;
@@ -305,6 +327,14 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     HIPCHK(c, hipEventRecord(c->ev_c, c->stream));
     c->timing_valid = true; c->last_iters = per_iter ? p->runlen : 0;
     return ICET_OK;
+}
+
+// Enqueue the whole solve for descriptors already sitting in c->h_desc[0..n_pairs).
+icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const float* d_x0, float* d_out, const AuxDev* aux) {
+    c->kf_pairs = 0;                                                    // whatever keyframe a sequential caller had parked here is overwritten
+    icet_status s = enqueue_keyframe(c, p, n_pairs, aux);
+    if (s != ICET_OK) return s;
+    return enqueue_loop(c, p, n_pairs, d_x0, d_out, aux, false);
 }
 
 icet_status write_runlen0(icet_ctx* c, int32_t n_pairs, const float* d_x0, float* d_out) {
@@ -499,6 +529,52 @@ static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t 
     }
     if (p->runlen == 0) return write_runlen0(c, n_pairs, d_x0, d_out);
     return enqueue(c, p, n_pairs, d_x0, d_out, nullptr);
+}
+
+icet_status icet_keyframe_device(icet_ctx* c, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1) {
+    if (!c) return ICET_ERR_BAD_ARG;
+    if (!params_ok(p) || n_pairs < 1 || !scan1) { c->err = "bad argument"; return ICET_ERR_BAD_ARG; }
+    int64_t tot1 = 0;
+    for (int k = 0; k < n_pairs; k++) {
+        const icet_dev_scan& a = scan1[k];
+        if (a.n < 0 || a.ld < a.n || (a.n > 0 && !a.ptr) || a.ld >= ((int64_t)1 << 30)) { c->err = "bad scan descriptor"; return ICET_ERR_BAD_ARG; }
+        tot1 += a.n;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    c->kf_pairs = 0;
+    icet_status s = ensure_workspace(c, p, n_pairs, tot1, 0);
+    if (s != ICET_OK) return s;
+    if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
+    for (int k = 0; k < n_pairs; k++) {
+        PairDesc& d = c->h_desc[k];
+        d.s1 = scan1[k].ptr; d.n1 = (int32_t)scan1[k].n; d.ld1 = (int32_t)scan1[k].ld;
+        d.s2 = nullptr; d.n2 = 0; d.ld2 = 0; d.off1 = 0; d.off2 = 0;
+    }
+    s = enqueue_keyframe(c, p, n_pairs, nullptr);
+    if (s != ICET_OK) return s;
+    c->kf_pairs = n_pairs; c->kf_params = *p;
+    return ICET_OK;
+}
+
+icet_status icet_register_device(icet_ctx* c, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan2, const float* d_x0, float* d_out) {
+    if (!c) return ICET_ERR_BAD_ARG;
+    if (!params_ok(p) || n_pairs < 1 || !scan2 || !d_out) { c->err = "bad argument"; return ICET_ERR_BAD_ARG; }
+    const icet_params& q = c->kf_params;
+    if (c->kf_pairs != n_pairs || q.bins_phi != p->bins_phi || q.bins_theta != p->bins_theta || q.n != p->n || q.thresh != p->thresh || q.buff != p->buff ||
+        ((q.flags ^ p->flags) & ICET_FLAG_TRUE_SORT)) { c->err = "no keyframe with these parameters is parked in this context (icet_keyframe_device)"; return ICET_ERR_BAD_ARG; }
+    int64_t tot2 = 0;
+    for (int k = 0; k < n_pairs; k++) {
+        const icet_dev_scan& b = scan2[k];
+        if (b.n < 0 || b.ld < b.n || (b.n > 0 && !b.ptr) || b.ld >= ((int64_t)1 << 30)) { c->err = "bad scan descriptor"; return ICET_ERR_BAD_ARG; }
+        tot2 += b.n;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (p->runlen == 0) return write_runlen0(c, n_pairs, d_x0, d_out);
+    icet_status s = ensure_workspace(c, p, n_pairs, 0, tot2);              // only the scan-2 overflow list can grow here: the keyframe tables stay
+    if (s != ICET_OK) return s;
+    if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
+    for (int k = 0; k < n_pairs; k++) { PairDesc& d = c->h_desc[k]; d.s2 = scan2[k].ptr; d.n2 = (int32_t)scan2[k].n; d.ld2 = (int32_t)scan2[k].ld; }
+    return enqueue_loop(c, p, n_pairs, d_x0, d_out, nullptr, true);
 }
 
 icet_status icet_solve_batch(icet_ctx* c, const icet_params* p, int32_t n_pairs,

@@ -22,6 +22,7 @@
 #include <new>
 #include <numeric>
 #include <random>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -204,6 +205,11 @@ void quat_of(const float* P /* 4x4 row-major */, float q[4]) {
 }  // namespace
 
 struct icet_node {
+    // Keyframe pipelining: scan 2 of frame k is scan 1 of frame k + 1, so the keyframe of a scan is built the
+    // moment the scan arrives, on the OTHER of two contexts / streams, while the Gauss-Newton loop of the current pair iterates; the
+    // frame-to-pose critical path is then range filter + loop.  kf[owner] holds the parked keyframe of the previous scan.
+    // Both contexts are the node's own: a keyframe parked in the caller's context would be lost to the caller's next solve on it.
+    icet_ctx* kf[2] = {nullptr, nullptr}; int owner = 0; bool pipelined = false;
     icet_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;
     int device = 0;
@@ -225,7 +231,7 @@ struct icet_node {
     int32_t* d_idx = nullptr; int32_t* h_idx = nullptr;
     float* d_aligned = nullptr; int64_t cap_aligned = 0, n_aligned = 0, ld_aligned = 0;     // scanMatcher.cpp:76
     std::vector<float> snail;                                                               // scanMatcher.cpp:27-28,79-84: rows x 3 row-major, host
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [5]: start of the loop on the owner's stream (pipelined)
     bool timing_valid = false, timed_map = false;
 };
 
@@ -237,7 +243,7 @@ namespace {
 
 icet_status ensure_scan(icet_node* nd, int which, int64_t n) {
     if (n <= nd->cap_scan[which]) return ICET_OK;
-    NCHK(nd, hipStreamSynchronize(nd->stream));
+    NCHK(nd, hipDeviceSynchronize());                             // both streams of a pipelined node may still read the buffer
     if (nd->d_scan[which]) { NCHK(nd, hipFree(nd->d_scan[which])); nd->d_scan[which] = nullptr; }
     const int64_t cap = (n + n / 8 + 63) / 64 * 64;
     NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_scan[which]), sizeof(float) * 3 * (size_t)cap));
@@ -258,6 +264,13 @@ icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t l
         if (n) NCHK(nd, hipMemcpy2DAsync(nd->d_scan[nd->prev], l * sizeof(float), d_scan, ld * sizeof(float), n * sizeof(float), 3, hipMemcpyDeviceToDevice, st));
         NCHK(nd, hipStreamSynchronize(st));
         nd->n_scan[nd->prev] = n; nd->ld_scan[nd->prev] = l;
+        if (nd->pipelined) {
+            icet_dev_scan a{nd->d_scan[nd->prev], n, l};
+            icet_params sp = nd->p.solve; sp.flags = ICET_FLAG_NONE;
+            nd->owner = 0;
+            icet_status ks = icet_keyframe_device(nd->kf[0], &sp, 1, &a);
+            if (ks != ICET_OK) { nd->err = icet_last_error(nd->kf[0]); return ks; }
+        }
         nd->initialized = true;
         res->solved = 0; res->n_kept = n;
         std::memcpy(res->pose, nd->pose, sizeof(nd->pose)); quat_of(nd->pose, res->quat);
@@ -297,26 +310,51 @@ icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t l
     const int64_t nk = *nd->h_nkept;
     nd->n_scan[cur] = nk; nd->ld_scan[cur] = lcur;
     // ---- ICET it(prev, cur, runlen, X0, bins_phi, bins_theta, n, thresh, buff)  (odometry.cpp:76) ----
+    // The down-sample indices of this frame (simpleMapMaker.cpp:147-158) depend only on the row count and on the node's RNG stream,
+    // and Fisher-Yates over ~10^5 indices costs about as much host time as the solve costs device time: a helper thread shuffles
+    // while this one enqueues the solve.  (The previous frame's map kernel, which read d_idx, finished before the row-count sync.)
+    int m_map = 0;
+    std::future<int> shuffle;
+    if (nd->p.map_capacity > 0) {
+        shuffle = std::async(std::launch::async, [nd, nk]() {
+            nd->indices.resize((size_t)nk);
+            std::iota(nd->indices.begin(), nd->indices.end(), (std::size_t)0);
+            std::shuffle(nd->indices.begin(), nd->indices.end(), nd->gen);
+            const int m = (int)std::min<int64_t>(nd->p.map_downsample, nk);
+            for (int i = 0; i < m; i++) nd->h_idx[i] = (int32_t)nd->indices[i];
+            return m;
+        });
+    }
     std::memcpy(nd->h_x0, nd->X0, sizeof(nd->X0));
-    NCHK(nd, hipMemcpyAsync(nd->d_x0, nd->h_x0, sizeof(float) * 6, hipMemcpyHostToDevice, st));
     icet_dev_scan a{nd->d_scan[nd->prev], nd->n_scan[nd->prev], nd->ld_scan[nd->prev]}, b{nd->d_scan[cur], nk, lcur};
     icet_params sp = nd->p.solve; sp.flags = ICET_FLAG_NONE;
-    s = icet_solve_batch_device(nd->ctx, &sp, 1, &a, &b, nd->d_x0, nd->d_out);
-    if (s != ICET_OK) { nd->err = icet_last_error(nd->ctx); return s; }
-    NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, st));
-    NCHK(nd, hipEventRecord(nd->ev[2], st));
-    // While the device solves: the down-sample indices of this frame (simpleMapMaker.cpp:147-158).  They depend only on the
-    // row count and on the node's RNG stream, and Fisher-Yates over ~10^5 indices costs about as much host time as the solve
-    // costs device time.  (The previous frame's map kernel, which read d_idx, finished before the row-count sync above.)
-    int m_map = 0;
-    if (nd->p.map_capacity > 0) {
-        nd->indices.resize((size_t)nk);
-        std::iota(nd->indices.begin(), nd->indices.end(), (std::size_t)0);
-        std::shuffle(nd->indices.begin(), nd->indices.end(), nd->gen);
-        m_map = (int)std::min<int64_t>(nd->p.map_downsample, nk);
-        for (int i = 0; i < m_map; i++) nd->h_idx[i] = (int32_t)nd->indices[i];
+    hipStream_t so = st;                                          // the stream the result arrives on
+    if (nd->pipelined) {
+        // the loop against the keyframe parked one frame ago (the host has synchronised the filter's stream above), then -- behind
+        // it in host order, beside it on the device -- the keyframe of THIS scan on the other context, for the next frame
+        icet_ctx* own = nd->kf[nd->owner]; icet_ctx* oth = nd->kf[nd->owner ^ 1];
+        so = reinterpret_cast<hipStream_t>(icet_stream(own));
+        NCHK(nd, hipEventRecord(nd->ev[5], so));
+        NCHK(nd, hipMemcpyAsync(nd->d_x0, nd->h_x0, sizeof(float) * 6, hipMemcpyHostToDevice, so));
+        s = icet_register_device(own, &sp, 1, &b, nd->d_x0, nd->d_out);
+        if (s != ICET_OK) { nd->err = icet_last_error(own); return s; }
+        NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, so));
+        NCHK(nd, hipEventRecord(nd->ev[2], so));
+        s = icet_keyframe_device(oth, &sp, 1, &b);
+        if (s != ICET_OK) { nd->err = icet_last_error(oth); return s; }
+        nd->owner ^= 1;
+    } else {
+        NCHK(nd, hipMemcpyAsync(nd->d_x0, nd->h_x0, sizeof(float) * 6, hipMemcpyHostToDevice, st));
+        s = icet_solve_batch_device(nd->ctx, &sp, 1, &a, &b, nd->d_x0, nd->d_out);
+        if (s != ICET_OK) { nd->err = icet_last_error(nd->ctx); return s; }
+        NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, st));
+        NCHK(nd, hipEventRecord(nd->ev[2], st));
+    }
+    if (shuffle.valid()) {
+        m_map = shuffle.get();
         if (m_map) NCHK(nd, hipMemcpyAsync(nd->d_idx, nd->h_idx, sizeof(int32_t) * m_map, hipMemcpyHostToDevice, st));
     }
+    if (so != st) NCHK(nd, hipStreamSynchronize(so));
     NCHK(nd, hipStreamSynchronize(st));
     float X[6];
     std::memcpy(X, nd->h_out, sizeof(X)); std::memcpy(res->pred_stds, nd->h_out + 6, sizeof(float) * 6);
@@ -407,6 +445,10 @@ icet_status icet_node_create(icet_ctx* ctx, const icet_node_params* p, icet_node
         hipHostMalloc(reinterpret_cast<void**>(&nd->h_out), sizeof(float) * 48) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_x0), sizeof(float) * 6) != hipSuccess)
         return fail(ICET_ERR_NOMEM);
     for (hipEvent_t& e : nd->ev) if (hipEventCreate(&e) != hipSuccess) return fail(ICET_ERR_HIP);
+    if (!(p->flags & ICET_NODE_NO_PIPELINE)) {
+        for (icet_ctx*& k : nd->kf) { icet_status cs = icet_create(&k, nd->device, nullptr); if (cs != ICET_OK) return fail(cs); }
+        nd->pipelined = true;
+    }
     if (p->flags & ICET_NODE_SNAIL_TRAIL) nd->snail.assign(3, 0.f);      // scanMatcher.cpp:27-28: one row at the origin
     if (p->map_capacity > 0) {
         if (hipMalloc(reinterpret_cast<void**>(&nd->d_map), sizeof(float) * 3 * (size_t)p->map_capacity) != hipSuccess) return fail(ICET_ERR_NOMEM);
@@ -428,6 +470,7 @@ icet_status icet_node_destroy(icet_node* nd) {
     void* hp[] = {nd->h_nkept, nd->h_out, nd->h_x0, nd->h_idx};
     for (void* q : hp) if (q) (void)hipHostFree(q);
     for (hipEvent_t e : nd->ev) if (e) (void)hipEventDestroy(e);
+    for (icet_ctx* k : nd->kf) if (k) (void)icet_destroy(k);
     delete nd;
     return ICET_OK;
 }
@@ -511,7 +554,7 @@ icet_status icet_node_last_timing(icet_node* nd, float out_ms[3]) {
     if (!nd->timing_valid) return ICET_ERR_BAD_ARG;
     float a = 0, b = 0, c = 0;
     NCHK(nd, hipEventElapsedTime(&a, nd->ev[0], nd->ev[1]));
-    NCHK(nd, hipEventElapsedTime(&b, nd->ev[1], nd->ev[2]));
+    NCHK(nd, hipEventElapsedTime(&b, nd->pipelined ? nd->ev[5] : nd->ev[1], nd->ev[2]));
     if (nd->timed_map) { NCHK(nd, hipEventSynchronize(nd->ev[3])); NCHK(nd, hipEventElapsedTime(&c, nd->ev[4], nd->ev[3])); }
     out_ms[0] = a; out_ms[1] = b; out_ms[2] = c;
     return ICET_OK;

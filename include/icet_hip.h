@@ -115,6 +115,16 @@ icet_status icet_solve_batch_device(icet_ctx* ctx, const icet_params* p, int32_t
                                     const float* d_x0, float* d_out);
 icet_status icet_sync(icet_ctx* ctx);
 
+/* --- the same solve in two halves, for the sequential callers (src/odometry.cpp:73-88: scan 2 of one frame is scan 1 of the next) ---
+ * icet_keyframe_device builds the keyframe of n scans -- ICET::fitScan1, src/icet.cpp:68-107 -- and parks it in the context;
+ * icet_register_device runs prepScan2 + runlen x fitScan2 (:254-277, :372-436) of n scan-2s against it, with the results of
+ * icet_solve_batch_device bit for bit.  Both are asynchronous on the context's stream; a parked keyframe stays valid (and can be
+ * registered against again) until the context solves or parks another.  With two contexts a caller builds the keyframe of frame
+ * k on one stream while frame k-1 / k still iterates on the other (include/icet_nodes.h does). */
+icet_status icet_keyframe_device(icet_ctx* ctx, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1);
+icet_status icet_register_device(icet_ctx* ctx, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan2,
+                                 const float* d_x0, float* d_out);
+
 /* Pre-size the workspace (so the first timed call does not allocate). */
 icet_status icet_reserve(icet_ctx* ctx, const icet_params* p, int32_t n_pairs, int64_t total_n1, int64_t total_n2);
 

@@ -42,7 +42,9 @@ typedef struct icet_node_params {
  * appended (:79-84). */
 enum { ICET_NODE_NO_RANGE_FILTER = 1,   /* every row of every scan is kept (min_range ignored)                              */
        ICET_NODE_ALIGNED_CLOUD   = 2,   /* keep scan2_in_scan1_frame of the last frame on the device (icet_node_aligned)    */
-       ICET_NODE_SNAIL_TRAIL     = 4 }; /* maintain the snail trail (icet_node_snail_trail)                                 */
+       ICET_NODE_SNAIL_TRAIL     = 4,   /* maintain the snail trail (icet_node_snail_trail)                                 */
+       ICET_NODE_NO_PIPELINE     = 8 }; /* build every frame's keyframe inside its own solve, as the reference does, instead of one frame
+                                           ahead on a second stream (same result bits either way; for A/B timing and the tests)          */
 
 typedef struct icet_node_result {
     int32_t solved;           /* 0 for the first scan: it is only stored (odometry.cpp:46-52)                              */

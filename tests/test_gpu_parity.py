@@ -496,6 +496,34 @@ def test_many_pairs_parity_natural_signs(gpu_ctx):
     assert np.median(dts) < 5e-6 and np.median(drs) < 5e-7 and within >= 0.93, (np.median(dts), np.median(drs), within)
 
 
+def test_keyframe_and_register_halves_equal_the_whole_solve(gpu_ctx):
+    """icet_keyframe_device + icet_register_device (the solve in two halves, for the sequential callers) give the bits of
+    icet_solve_batch_device; a parked keyframe can be registered against more than once; a mismatched call is refused."""
+    import icet_amd
+    from icet_amd import lidar_sim as ls, api
+    dev = torch.device("cuda", 0)
+    pairs = [ls.make_batch_pair(k, device=dev) for k in range(3)]
+    d1 = [(p[0].data_ptr(), p[0].shape[1], p[0].shape[1]) for p in pairs]; d2 = [(p[1].data_ptr(), p[1].shape[1], p[1].shape[1]) for p in pairs]
+    xd = torch.zeros((3, 6), dtype=torch.float32, device=dev); xd[:, 0] = torch.tensor([0.0, 0.02, -0.01], device=dev)
+    whole = torch.zeros((3, 48), dtype=torch.float32, device=dev); halves = torch.zeros_like(whole); again = torch.zeros_like(whole)
+    torch.cuda.synchronize()
+    prm = api.Params(7, 24, 75, 25, 0.1, 0.1, 0)
+    ctx = icet_amd.Context(0)
+    ctx.solve_batch_device(d1, d2, prm, whole.data_ptr(), xd.data_ptr()); ctx.sync()
+    ctx.keyframe_device(d1, prm)
+    ctx.register_device(d2, prm, halves.data_ptr(), xd.data_ptr())
+    ctx.register_device(d2, prm, again.data_ptr(), xd.data_ptr()); ctx.sync()
+    assert torch.equal(whole, halves) and torch.equal(whole, again) and bool(torch.isfinite(whole).all())
+    with pytest.raises(icet_amd.IcetError):                      # other grid than the parked keyframe's
+        ctx.register_device(d2, api.Params(7, 48, 150, 25, 0.1, 0.1, 0), again.data_ptr())
+    with pytest.raises(icet_amd.IcetError):                      # other number of pairs
+        ctx.register_device(d2[:2], prm, again.data_ptr())
+    ctx.solve_batch_device(d1[:1], d2[:1], prm, again.data_ptr()); ctx.sync()
+    with pytest.raises(icet_amd.IcetError):                      # a whole solve un-parks the keyframe
+        ctx.register_device(d2, prm, again.data_ptr())
+    ctx.close()
+
+
 def test_rccl_gather_on_one_rank_is_the_identity():
     """icet_amd.dist.gather_results through RCCL (torch.distributed backend "nccl") with a process group of ONE rank on cuda:0: the
     all-gather + de-interleave must return the rank's own rows.  This is as much of the N > 1 path as a 1-GPU box can run; the

@@ -144,6 +144,14 @@ def test_gpu_odometry_node_matches_oracle(gpu_ctx, seq64):
             t = g.last_timing()
             assert t["filter_ms"] > 0 and t["solve_ms"] > 0
     g.close(); o.close()
+    # the keyframe of every scan is built one frame ahead on a second stream; with ICET_NODE_NO_PIPELINE (flags = 8) it
+    # is built inside the frame's own solve, as the reference does: the results must be the same BITS
+    kw = dict(api.ODOMETRY_NODE); kw["flags"] = kw.get("flags", 0) | 8
+    a_, b_ = api.Node(gpu_ctx, **api.ODOMETRY_NODE), api.Node(gpu_ctx, **kw)
+    for s in seq64:
+        ra, rb = a_.push(s), b_.push(s)
+        assert np.array_equal(ra["X"], rb["X"]) and np.array_equal(ra["pred_stds"], rb["pred_stds"]) and np.array_equal(ra["pose"], rb["pose"])
+    a_.close(); b_.close()
 
 
 @pytest.mark.gpu

@@ -152,7 +152,10 @@ struct LaunchCfg {
     int true_sort = 0;                // ICET_FLAG_TRUE_SORT (non-parity extension): src[] = the sorted order itself
     int force_exact = 0;              // diagnostic: route every point through the literal evaluation
     int rs_cap = 0;                   // Tuning::rs_cap
+    int reject_moving = 0;            // ICET_FLAG_REJECT_MOVING (non-parity extension)
 };
+constexpr float kRejectMovingThresh = 0.3f;        // python/ICET_spherical.py:38  RM_thresh
+constexpr int kRejectMovingStartIter = 4;          // python/ICET_spherical.py:36  start_RM_iter
 
 // icet_keyframe.hip
 hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* aux, hipStream_t st);

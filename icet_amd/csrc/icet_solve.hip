@@ -69,7 +69,7 @@ __device__ __noinline__ void drain_near_overflow(const NearOverflow& o, int pair
 
 __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__ n_slots, const SlotFit* __restrict__ fitS, uint32_t* __restrict__ acc,
                                                      float* __restrict__ X_all, float* __restrict__ xf_all, float* __restrict__ out, AuxDev aux,
-                                                     int V, int n, int iter, int runlen, NearOverflow over) {
+                                                     int V, int n, int iter, int runlen, NearOverflow over, int reject_moving) {
     __shared__ float J[27];
     __shared__ float red[kBlock / 64][27];
     const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -121,8 +121,15 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
         float Rn[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) Rn[k] = f.s1n[k] + cov2[k] / d2;
-        // Rp = M Rn M^T  (M = L U^T)                                             src/icet.cpp:317
         const float* M = f.M;
+        // dz = M (mu2 - mu1)                                                       src/icet.cpp:335-337
+        float dz[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) dz[i] = M[3 * i] * db[0] + M[3 * i + 1] * db[1] + M[3 * i + 2] * db[2];
+        // extension (ICET_FLAG_REJECT_MOVING): a voxel whose compact residual is beyond the cutoff in a kept axis is a moving object
+        if (reject_moving && iter >= kRejectMovingStartIter &&
+            (fabsf(dz[0]) > kRejectMovingThresh || fabsf(dz[1]) > kRejectMovingThresh || fabsf(dz[2]) > kRejectMovingThresh)) continue;
+        // Rp = M Rn M^T  (M = L U^T)                                             src/icet.cpp:317
         float MR[9];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
@@ -161,10 +168,6 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
             WH[6 + j]  = W[1] * Hz[j] + W[3] * Hz[6 + j] + W[4] * Hz[12 + j];
             WH[12 + j] = W[2] * Hz[j] + W[4] * Hz[6 + j] + W[5] * Hz[12 + j];
         }
-        // dz = M (mu2 - mu1)                                                       src/icet.cpp:335-337
-        float dz[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) dz[i] = M[3 * i] * db[0] + M[3 * i + 1] * db[1] + M[3 * i + 2] * db[2];
         int q = 0;
 #pragma unroll
         for (int a = 0; a < 6; a++) {
@@ -268,7 +271,7 @@ hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* auxp, hipStream_t st) {
     AuxDev aux{}; if (auxp) aux = *auxp;
     NearOverflow over{w.desc, w.slot_of_voxel, w.hotS, w.thr, w.near_over, w.near_over_count, c.T, c.P};
-    k_gn_solve<<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over);
+    k_gn_solve<<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

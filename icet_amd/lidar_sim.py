@@ -149,6 +149,19 @@ def make_pair(scene_seed=1000, noise_seed=1001, motion=DEFAULT_MOTION, rings=64,
     return s1, s2, X.astype(np.float32)
 
 
+def make_pair_with_moving_objects(scene_seed=1000, noise_seed=1001, motion=DEFAULT_MOTION, shift=(1.2, 0.4), every=3, rings=64, steps=2048, device="cpu"):
+    """A pair in which every `every`-th box of the scene has moved by `shift` (m, in x / y) between the two scans: the input the
+    moving-object rejection of the Python variant (python/ICET_spherical.py:175-250) exists for.  Returns (scan1, scan2, X_true)."""
+    scene = make_scene(scene_seed)
+    moved = dict(scene)
+    moved["boxes"] = [(b[0] + shift[0], b[1] + shift[0], b[2] + shift[1], b[3] + shift[1], b[4], b[5]) if k % every == 0 else b for k, b in enumerate(scene["boxes"])]
+    X = np.asarray(motion, np.float64)
+    R = euler_R(X[3], X[4], X[5])
+    s1 = make_scan(scene, (np.zeros(3), np.eye(3)), noise_seed * 2 + 1, rings, steps, device=device)
+    s2 = make_scan(moved, (R.T @ X[:3], R.T), noise_seed * 2 + 2, rings, steps, device=device)
+    return s1, s2, X.astype(np.float32)
+
+
 def batch_motion(k):
     """Motion of pair k of the batched configs: U(+-0.6, +-0.05, +-0.02 m; +-0.005, +-0.005, +-0.02 rad), seed 5000+k."""
     rs = np.random.RandomState(5000 + k)

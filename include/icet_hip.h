@@ -44,11 +44,16 @@ typedef struct icet_params {
 
 enum { ICET_FLAG_NONE = 0,
        ICET_FLAG_TIMING = 1,  /* record HIP events around every bin/accumulate launch (icet_last_timing[2]) */
-       ICET_FLAG_TRUE_SORT = 2 /* NON-PARITY EXTENSION: really sort scan 1 by range before clustering, instead of reproducing
+       ICET_FLAG_TRUE_SORT = 2, /* NON-PARITY EXTENSION: really sort scan 1 by range before clustering, instead of reproducing
                                   the reference's one-step swap loop (src/icet.cpp:78-83), which leaves the rows scrambled so
                                   that findCluster sees most bins in a shuffled order and only ~1/4 of the populated bins get a
                                   Gaussian.  Results then differ from the reference by design (more voxels, better conditioned);
-                                  the oracle has the same switch so that the extension is still checked against a CPU twin. */ };
+                                  the oracle has the same switch so that the extension is still checked against a CPU twin. */
+       ICET_FLAG_REJECT_MOVING = 4 /* NON-PARITY EXTENSION: moving-object rejection as in the reference's Python
+                                  variant (python/ICET_spherical.py:175-250, the hard cutoff that is live there): from the 5th iteration on
+                                  (start_RM_iter = 4), a voxel whose compact residual L U^T (mu2 - mu1) exceeds RM_thresh = 0.3 m in any
+                                  kept axis is left out of that iteration's H^T W H and H^T W dz.  The C++ reference has nothing like it, so
+                                  results differ from it by design; the oracle has the same switch (ICET_ORACLE_REJECT_MOVING). */ };
 
 /* A scan that already lives in device memory (HBM) on the context's device. */
 typedef struct icet_dev_scan {

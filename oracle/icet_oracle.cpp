@@ -440,6 +440,8 @@ struct Solver {
                 for (int a = 0; a < 3; a++) { mu1m(a, 0) = f.mu[a]; mu2m(a, 0) = mean[a]; }
                 Mat z1 = matmul(LUt, mu1m), z2 = matmul(LUt, mu2m);
                 Mat dz(3, 1); for (int a = 0; a < 3; a++) dz(a, 0) = z2(a, 0) - z1(a, 0);
+                if ((prm.mode & ICET_ORACLE_REJECT_MOVING) && iter_no >= 4 &&
+                    (std::fabs(dz(0, 0)) > 0.3f || std::fabs(dz(1, 0)) > 0.3f || std::fabs(dz(2, 0)) > 0.3f)) { out.HTWH = Mat(6, 6); return out; }   // extension: a moving object
                 out.HTWdz = matmul(HzTW, dz);                                                // icet.cpp:338
                 out.used = true; out.sigma2 = cov; for (int a = 0; a < 3; a++) out.mu2[a] = mean[a];
             }

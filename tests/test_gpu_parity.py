@@ -387,6 +387,25 @@ def test_icet_class_mirrors_reference_members(frames, frames_golden):
     assert np.abs(it.X[:3] - frames_golden["X"][:3]).max() <= TOL_T
 
 
+def test_reject_moving_extension_matches_its_oracle_twin(gpu_ctx):
+    """ICET_FLAG_REJECT_MOVING is a labelled NON-PARITY extension (the Python variant's moving-object rejection on top of
+    the C++ path).  It is held to a CPU twin -- the oracle with ICET_ORACLE_REJECT_MOVING -- on a pair in which half of the boxes
+    moved: the same voxels dropped, the same answer within the usual bounds, a different answer than without the flag; off by default."""
+    from icet_amd import lidar_sim as ls, api
+    from oracle import pyoracle as po
+    s1, s2, xt = ls.make_pair_with_moving_objects(shift=(0.6, 0.1), every=2)
+    a, b = s1.T.numpy(), s2.T.numpy()
+    g = gpu_ctx.solve(a, b, 9, np.zeros(6), 24, 75, aux=True, flags=api.FLAG_REJECT_MOVING)
+    o = po.solve(a, b, runlen=9, trace=True, mode=po.REJECT_MOVING)
+    _check_solution(g, o)
+    for it in range(9):
+        assert np.abs(g["aux"]["htwh"][it] - o["trace"]["HTWH"][it]).max() <= 5e-2 * np.abs(o["trace"]["HTWH"][it]).max(), it     # a dropped voxel would show as a missing term
+    plain_g = gpu_ctx.solve(a, b, 9, np.zeros(6), 24, 75, aux=True)
+    _check_solution(plain_g, po.solve(a, b, runlen=9))
+    assert np.array_equal(g["aux"]["x_hist"][:4], plain_g["aux"]["x_hist"][:4])             # nothing happens before the 5th iteration
+    assert np.abs(g["X"] - plain_g["X"]).max() > 1e-4                                        # then it is a different answer
+
+
 def test_eigen_adapter_header_compiles_and_runs(tmp_path, gpu_ctx, frames):
     """include/icet.h -- the adapter with the reference's class name, constructor signature and members -- compiled with g++ against a
     minimal Eigen-API mock (tests/cpp/mock_eigen: this image has no Eigen; the mock pins no numerics) and run through the call

@@ -182,7 +182,7 @@ __device__ __forceinline__ int rank_sort_bucket_of(uint32_t key, const uint32_t*
     return lo;
 }
 hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st,
-                             int32_t* live = nullptr, int32_t* n_live = nullptr, int live_min = 0);
+                             int32_t* live = nullptr, int32_t* n_live = nullptr, int live_min = 0, uint32_t* n_items = nullptr);
 
 // sort.hip
 size_t sort_temp_bytes(int64_t total_n);

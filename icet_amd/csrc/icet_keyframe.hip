@@ -320,7 +320,8 @@ __global__ __launch_bounds__(kBlock) void k_bin_tiles(const uint32_t* __restrict
 
 // live (optional): the classes holding at least live_min rows, compacted in class order -- the angular bins fitCells1 looks at at
 // all (src/icet.cpp:115) -- so that the fit kernels walk ~1/4 of the grid instead of launching a wave per bin.
-__global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class_start, int V, int32_t* __restrict__ live, int32_t* __restrict__ n_live, int live_min) {
+__global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class_start, int V, int32_t* __restrict__ live, int32_t* __restrict__ n_live, int live_min,
+                                                     uint32_t* __restrict__ n_items) {
     __shared__ int wave_tot[kBlock / 64], wave_live[kBlock / 64];
     __shared__ int base, lbase;
     const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class
         if (threadIdx.x == kBlock - 1) { base = bb + woff + incl; lbase = lb + loff + __popcll(lm); }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { class_start[(size_t)pair * (V + 1) + V] = base; if (n_live) n_live[pair] = lbase; }
+    if (threadIdx.x == 0) { class_start[(size_t)pair * (V + 1) + V] = base; if (n_live) n_live[pair] = lbase; if (n_items) n_items[pair] = 0u; }
 }
 
 // One block per tile (<= 2048 positions); wave w owns the w-th quarter (<= 8 rounds of 64 positions).  Everything
@@ -673,8 +674,10 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
     const int pair = blockIdx.y;
     if (v >= V) return;
     const size_t o = (size_t)pair * V + v;
-    FitMid m = midD[o];
-    m.cnt = bin_start[(size_t)pair * (V + 1) + v + 1] - bin_start[(size_t)pair * (V + 1) + v];     // bins below n rows have no record of their own (zeroed)
+    const int cnt_v = bin_start[(size_t)pair * (V + 1) + v + 1] - bin_start[(size_t)pair * (V + 1) + v];
+    FitMid m{};                                                   // a bin below n rows was never visited by the fit kernels: nothing to read
+    if (cnt_v >= n) m = midD[o];
+    m.cnt = cnt_v;
     const int theta = v % T, phi = v / T;
     float az0, az1, el0, el1;
     voxel_limits(theta, phi, T, P, az0, az1, el0, el1);
@@ -848,14 +851,13 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
         k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, w.flags, c.V, np, chunks, 0);
         ICET_LAUNCH_CHECK();
     }
-    e = launch_class_scan(w.counts, w.tile_base, w.bin_start, c.V, chunks, c.n_pairs, st, w.live_bins, w.n_live, c.n);
+    e = launch_class_scan(w.counts, w.tile_base, w.bin_start, c.V, chunks, c.n_pairs, st, w.live_bins, w.n_live, c.n, w.fit_n_items);
     if (e != hipSuccess) return e;
     k_bin_scatter<<<grid, blk, (size_t)c.V * 16, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks);
     ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 3) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     // keyA / keyB (bucket-grouped keys and the overflow scratch of the rank sort) are dead by now: candidate rows and their r
-    e = hipMemsetAsync(w.fit_n_items, 0, sizeof(uint32_t) * c.n_pairs, st); if (e != hipSuccess) return e;
-    e = hipMemsetAsync(w.midD, 0, sizeof(FitMid) * (size_t)c.n_pairs * c.V, st); if (e != hipSuccess) return e;
+    // (k_bin_scan zeroed the pairs' item counters; k_fit_finish takes a bin below n rows for empty without reading its record)
     FitItem* items = reinterpret_cast<FitItem*>(w.fit_items);
     // a fixed number of blocks per pair walks the pair's live bins / work items (their numbers are only known on the device):
     // enough blocks to fill the chip whatever the batch size
@@ -879,10 +881,10 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
 }
 
 hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st,
-                             int32_t* live, int32_t* n_live, int live_min) {
+                             int32_t* live, int32_t* n_live, int live_min, uint32_t* n_items) {
     k_bin_tiles<<<dim3((n_classes + kBlock - 1) / kBlock, n_pairs), kBlock, 0, st>>>(counts, tile_base, class_start, n_classes, chunks);
     ICET_LAUNCH_CHECK();
-    k_bin_scan<<<n_pairs, kBlock, 0, st>>>(class_start, n_classes, live, n_live, live_min);
+    k_bin_scan<<<n_pairs, kBlock, 0, st>>>(class_start, n_classes, live, n_live, live_min, n_items);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

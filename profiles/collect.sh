@@ -23,11 +23,14 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch --
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d /tmp/p_write -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/p_sq1 -- $CMD > $OUT/sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/p_sq2 -- $CMD > $OUT/sq2.log 2>&1
-for d in p_fetch p_write p_sq1 p_sq2; do
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d /tmp/p_tcc -- $CMD > $OUT/tcc.log 2>&1
+for d in p_fetch p_write p_sq1 p_sq2 p_tcc; do
   f=$(ls /tmp/$d/*/*counter_collection.csv | head -1)
   grep -E "Kernel_Name|icet::|onesweep" $f | grep -v "at::native" > /tmp/$d.csv
 done
-python3 $R/profiles/pmc_summary.py /tmp/p_fetch.csv /tmp/p_write.csv /tmp/p_sq1.csv /tmp/p_sq2.csv > $OUT/${TAG}_pmc.txt
+python3 $R/profiles/pmc_summary.py /tmp/p_fetch.csv /tmp/p_write.csv /tmp/p_sq1.csv /tmp/p_sq2.csv /tmp/p_tcc.csv > $OUT/${TAG}_pmc.txt
+ROWS=$(python3 -c "import json; d=json.load(open('$OUT/${TAG}_bench_under_rocprof.json')); print(d['config']['points_scan1_mean']*d['config']['pairs_per_gpu'])")
+python3 $R/profiles/pmc_bounds.py $ROWS /tmp/p_fetch.csv /tmp/p_write.csv /tmp/p_sq1.csv /tmp/p_sq2.csv /tmp/p_tcc.csv > $OUT/${TAG}_bounds.txt
 python3 - <<PY
 import csv, json, re, collections
 def mean_counter(path, kernel, counter):
@@ -42,4 +45,5 @@ json.dump({"k_gn_accumulate_bytes_per_launch": traffic, "FETCH_SIZE_KB_raw": fet
            "tag": "$TAG"}, open("$OUT/traffic_latest.json", "w"), indent=1)
 print(open("$OUT/traffic_latest.json").read())
 PY
+cat $OUT/${TAG}_bounds.txt
 cat $OUT/${TAG}_kernels.txt

@@ -7,6 +7,7 @@
 #include <math.h>
 #include "icet_internal.h"
 #include "icet_device_common.h"
+#include <algorithm>
 
 namespace icet {
 namespace {
@@ -20,6 +21,7 @@ namespace {
 #ifndef ICET_ACC_PTS
 #define ICET_ACC_PTS 4
 #endif
+static_assert(ICET_ACC_PTS == 4, "phase C of k_gn_accumulate is written for 4 consecutive points per lane");
 constexpr int kAccPts = ICET_ACC_PTS;                      // consecutive points per lane per trip (two dwordx4 loads per coordinate)
 constexpr int kAccBlock = ICET_ACC_BLOCK;        // k_gn_accumulate: the waves of a block share one copy of the pair's LDS tables
 constexpr int kAccWavesPerSimd = ICET_ACC_WAVES; // register budget: 6 -> 84 VGPRs, no spills, three 512-thread blocks per CU (with 1536 blocks per 256-pair launch: 130 -> 121 us); 8 spills
@@ -59,6 +61,8 @@ __device__ __noinline__ void spill_flush(uint32_t* A, uint32_t nraw, uint32_t ni
     acc_add_hbm(A, nraw, nin, S0, S1, S2, S3, S4, S5, S6, S7, S8);
 }
 
+constexpr int kCntBits = 21;            // LDS count word: three 21-bit fields
+constexpr unsigned long long kCntMask = (1ull << kCntBits) - 1ull;
 constexpr uint32_t kNearCap = 512;      // undecided points a block parks in LDS (2 KB); the rest goes to the per-pair overflow list in HBM
 
 typedef __attribute__((address_space(1))) const float gfloat;
@@ -86,8 +90,9 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
 
     LutCell* lut_t = reinterpret_cast<LutCell*>(smem);                    // Mt + 1 cells (the spare one catches pa == 4)
     LutCell* lut_p = lut_t + (Mt + 1);                                    // Mp + 1 cells (w == 1)
-    // per slot 10 x u64, the layout of the HBM accumulator: [raw | in << 32], then the 9 fixed-point sums -- constant offsets
-    // inside a flush, one 64-bit add for the two counts
+    // per slot 10 x u64: [raw | in << 21 | conversions << 42] (a block sees < 2^21 points: launch_gn_accumulate), then the 9
+    // fixed-point sums with the conversion bias still in them (to_fix_biased) -- constant offsets inside a flush, one 64-bit add
+    // for the counts, two VALU instructions per value; the bias comes out once per slot when the block hands its sums to HBM
     unsigned long long* lacc = reinterpret_cast<unsigned long long*>(lut_p + (Mp + 1));
     float* hot = reinterpret_cast<float*>(lacc + 10 * lds_slots);         // lds_slots x 5: inner, outer, mu1
     int16_t* map = reinterpret_cast<int16_t*>(hot + lds_slots * 5);
@@ -139,19 +144,15 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
     float XN[4], YN[4], ZN[4];
     load4(begin + kAccPts * (int)threadIdx.x, XN, YN, ZN);
     for (int t0 = begin + kAccPts * threadIdx.x; t0 < begin + cs; t0 += kAccPts * kAccBlock) {   // whole waves iterate together
-      // Run state of this lane for the whole trip: the current run, and a stash holding one finished run (see phase C).
-      int cur = -1; uint32_t nraw = 0, nin = 0;
-      float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f, S6 = 0.f, S7 = 0.f, S8 = 0.f;
-      int bs = -1; uint32_t braw = 0, bin = 0;
-      float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, B4 = 0.f, B5 = 0.f, B6 = 0.f, B7 = 0.f, B8 = 0.f;
       auto flush = [&](int slot, uint32_t cr, uint32_t ci, float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {
           if (slot >= 0) {
               if (slot < nl) {
                   unsigned long long* F = lacc + slot * 10;
-                  atomicAdd(&F[0], (unsigned long long)cr | ((unsigned long long)ci << 32));
+                  atomicAdd(&F[0], (unsigned long long)cr | ((unsigned long long)ci << kCntBits) | ((ci ? 1ull : 0ull) << (2 * kCntBits)));
                   if (ci) {
-                      atomicAdd(&F[1], to_fix(a0)); atomicAdd(&F[2], to_fix(a1)); atomicAdd(&F[3], to_fix(a2)); atomicAdd(&F[4], to_fix(a3)); atomicAdd(&F[5], to_fix(a4));
-                      atomicAdd(&F[6], to_fix(a5)); atomicAdd(&F[7], to_fix(a6)); atomicAdd(&F[8], to_fix(a7)); atomicAdd(&F[9], to_fix(a8));
+                      atomicAdd(&F[1], to_fix_biased(a0)); atomicAdd(&F[2], to_fix_biased(a1)); atomicAdd(&F[3], to_fix_biased(a2)); atomicAdd(&F[4], to_fix_biased(a3));
+                      atomicAdd(&F[5], to_fix_biased(a4)); atomicAdd(&F[6], to_fix_biased(a5)); atomicAdd(&F[7], to_fix_biased(a6)); atomicAdd(&F[8], to_fix_biased(a7));
+                      atomicAdd(&F[9], to_fix_biased(a8));
                   }
               } else {
                   spill_flush(gacc + (size_t)slot * kAccWords, cr, ci, a0, a1, a2, a3, a4, a5, a6, a7, a8);
@@ -247,38 +248,63 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
                 }
             }
         }
-        const bool any_slot = (pc[0].s >= 0) | (pc[1].s >= 0) | (pc[2].s >= 0) | (pc[3].s >= 0);
-        if (__ballot(any_slot | (cur >= 0)) == 0ull) continue;           // wave-uniform: nothing here lands in an active voxel and no run is open
-        // ---- phase C: run-length accumulation over the lane's consecutive points.  A finished run is parked in a
-        // register stash instead of being flushed at once, so a lane converts to fixed point and touches LDS about
-        // twice per trip of kAccPts points (a third run inside one trip, rare, flushes the stash early). ----
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int s = pc[j].s;
-            if (s != cur) {
-                if (cur >= 0) {
-                    // only a lane whose OWN stash is occupied (a third run inside its 4 points: rare) flushes here; a wave-wide
-                    // "any lane has a stash" test would run the flush at almost every j, for lanes that could have waited
-                    if (bs >= 0) flush(bs, braw, bin, B0, B1, B2, B3, B4, B5, B6, B7, B8);
-                    bs = cur; braw = nraw; bin = nin; B0 = S0; B1 = S1; B2 = S2; B3 = S3; B4 = S4; B5 = S5; B6 = S6; B7 = S7; B8 = S8;
-                }
-                cur = s; nraw = 0; nin = 0; S0 = S1 = S2 = S3 = S4 = S5 = S6 = S7 = S8 = 0.f;
+        const int s0 = pc[0].s, s1 = pc[1].s, s2 = pc[2].s, s3 = pc[3].s;
+        if (__ballot((s0 >= 0) | (s1 >= 0) | (s2 >= 0) | (s3 >= 0)) == 0ull) continue;   // wave-uniform: nothing here lands in an active voxel
+        // ---- phase C: run-length accumulation over the lane's 4 consecutive points.  Lidar storage order keeps neighbours in one
+        // voxel (on the bench scans 92 % of the lanes see a single run, the rest two), so the sums are formed per RUN -- a maximal
+        // group of consecutive points of one slot, summed in point order -- and a lane converts to fixed point and touches LDS once
+        // or twice per trip.  No state machine: with 4 points a run is the run of point 0 (A), the run of point 3 when that is
+        // another one (Z), or lies strictly between them (points 1 / 2: needs three runs in four points; its own rare branch).
+        // Membership is a mask per point, so the two sets of sums are straight-line code. ----
+        {
+            const bool e1 = s1 == s0, e2 = s2 == s1, e3 = s3 == s2;
+            const bool a1 = e1, a2 = a1 & e2, a3 = a2 & e3;                 // point j continues the run of point 0
+            const bool z3 = !a3, z2 = z3 & e3, z1 = z2 & e2;                // point j belongs to the run of point 3, a different run
+            const bool i0 = pc[0].inb, i1 = pc[1].inb, i2 = pc[2].inb, i3 = pc[3].inb;
+            float A0, A1, A2, A3, A4, A5, A6, A7, A8, Z0, Z1, Z2, Z3, Z4, Z5, Z6, Z7, Z8;
+            {   // point 0 opens run A; an out-of-bounds point only counts (its d may be anything: masked to 0, never multiplied in)
+                const float dx = i0 ? pc[0].dx : 0.f, dy = i0 ? pc[0].dy : 0.f, dz = i0 ? pc[0].dz : 0.f;
+                A0 = dx; A1 = dy; A2 = dz; A3 = dx * dx; A4 = dx * dy; A5 = dx * dz; A6 = dy * dy; A7 = dy * dz; A8 = dz * dz;
+                Z0 = Z1 = Z2 = Z3 = Z4 = Z5 = Z6 = Z7 = Z8 = 0.f;
             }
-            if (s >= 0) {
-                nraw++;
-                if (pc[j].inb) {
-                    const float dx = pc[j].dx, dy = pc[j].dy, dz = pc[j].dz;
-                    nin++;
-                    S0 += dx; S1 += dy; S2 += dz;
-                    S3 += dx * dx; S4 += dx * dy; S5 += dx * dz; S6 += dy * dy; S7 += dy * dz; S8 += dz * dz;
+            // (scalar on purpose: with the two runs packed into register pairs -- v_pk_fma_f32 on (A, Z) -- the kernel needs 79 VGPRs
+            // and spills, and the compiler can no longer sink the Z sums into the branch that flushes them)
+#define ICET_ACC_POINT(j, inA, inZ)                                                                                                          \
+            {                                                                                                                                \
+                const bool ma = (inA) & pc[j].inb, mz = (inZ) & pc[j].inb;                                                                   \
+                const float ax = ma ? pc[j].dx : 0.f, ay = ma ? pc[j].dy : 0.f, az = ma ? pc[j].dz : 0.f;                                    \
+                const float zx = mz ? pc[j].dx : 0.f, zy = mz ? pc[j].dy : 0.f, zz = mz ? pc[j].dz : 0.f;                                    \
+                A0 += ax; A1 += ay; A2 += az;                                                                                                \
+                A3 = fmaf(ax, ax, A3); A4 = fmaf(ax, ay, A4); A5 = fmaf(ax, az, A5); A6 = fmaf(ay, ay, A6); A7 = fmaf(ay, az, A7); A8 = fmaf(az, az, A8); \
+                Z0 += zx; Z1 += zy; Z2 += zz;                                                                                                \
+                Z3 = fmaf(zx, zx, Z3); Z4 = fmaf(zx, zy, Z4); Z5 = fmaf(zx, zz, Z5); Z6 = fmaf(zy, zy, Z6); Z7 = fmaf(zy, zz, Z7); Z8 = fmaf(zz, zz, Z8); \
+            }
+            ICET_ACC_POINT(1, a1, z1)
+            ICET_ACC_POINT(2, a2, z2)
+            ICET_ACC_POINT(3, a3, z3)
+#undef ICET_ACC_POINT
+            const uint32_t ar = 1u + (a1 ? 1u : 0u) + (a2 ? 1u : 0u) + (a3 ? 1u : 0u);
+            const uint32_t ai = (i0 ? 1u : 0u) + ((a1 & i1) ? 1u : 0u) + ((a2 & i2) ? 1u : 0u) + ((a3 & i3) ? 1u : 0u);
+            flush(s0, ar, ai, A0, A1, A2, A3, A4, A5, A6, A7, A8);
+            if (__ballot(z3 & (s3 >= 0)) != 0ull) {
+                const uint32_t zr = 1u + (z2 ? 1u : 0u) + (z1 ? 1u : 0u);
+                const uint32_t zi = (i3 ? 1u : 0u) + ((z2 & i2) ? 1u : 0u) + ((z1 & i1) ? 1u : 0u);
+                flush(z3 ? s3 : -1, zr, zi, Z0, Z1, Z2, Z3, Z4, Z5, Z6, Z7, Z8);
+            }
+            const bool m1 = !a1 & !z1, m2 = !a2 & !z2;                      // points of a run strictly between A and Z
+            if (__ballot((m1 & (s1 >= 0)) | (m2 & (s2 >= 0))) != 0ull) {
+                const bool joint = m1 & m2 & e2;                            // points 1 and 2 form one run
+                const float bx = i1 ? pc[1].dx : 0.f, by = i1 ? pc[1].dy : 0.f, bz = i1 ? pc[1].dz : 0.f;
+                const float cx = i2 ? pc[2].dx : 0.f, cy = i2 ? pc[2].dy : 0.f, cz = i2 ? pc[2].dz : 0.f;
+                if (m1 & !joint) flush(s1, 1u, i1 ? 1u : 0u, bx, by, bz, bx * bx, bx * by, bx * bz, by * by, by * bz, bz * bz);
+                if (m2) {
+                    const float jx = joint ? bx : 0.f, jy = joint ? by : 0.f, jz = joint ? bz : 0.f;
+                    flush(s2, joint ? 2u : 1u, (i2 ? 1u : 0u) + ((joint & i1) ? 1u : 0u), jx + cx, jy + cy, jz + cz,
+                          fmaf(cx, cx, jx * jx), fmaf(cx, cy, jx * jy), fmaf(cx, cz, jx * jz), fmaf(cy, cy, jy * jy), fmaf(cy, cz, jy * jz), fmaf(cz, cz, jz * jz));
                 }
             }
         }
       }   // sub-groups of 4
-      if (__ballot((cur >= 0) | (bs >= 0)) != 0ull) {
-          flush(cur, nraw, nin, S0, S1, S2, S3, S4, S5, S6, S7, S8);
-          if (__ballot(bs >= 0) != 0ull) flush(bs, braw, bin, B0, B1, B2, B3, B4, B5, B6, B7, B8);
-      }
     }
     __syncthreads();
     {   // ---- the parked points: literal classification, each a run of one ----
@@ -293,7 +319,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
                 const float dx = pc1.dx, dy = pc1.dy, dz = pc1.dz;
                 unsigned long long* F = lacc + min(pc1.s, nl > 0 ? nl - 1 : 0) * 10;
                 if (pc1.s < nl) {
-                    atomicAdd(&F[0], 1ull | ((unsigned long long)(pc1.inb ? 1u : 0u) << 32));
+                    atomicAdd(&F[0], 1ull | ((unsigned long long)(pc1.inb ? 1u : 0u) << kCntBits));   // unbiased values below: not counted as conversions
                     if (pc1.inb) {
                         atomicAdd(&F[1], to_fix(dx)); atomicAdd(&F[2], to_fix(dy)); atomicAdd(&F[3], to_fix(dz));
                         atomicAdd(&F[4], to_fix(dx * dx)); atomicAdd(&F[5], to_fix(dx * dy)); atomicAdd(&F[6], to_fix(dx * dz));
@@ -309,12 +335,14 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
     for (int s = threadIdx.x; s < nl; s += kAccBlock) {
         const unsigned long long* L = lacc + s * 10;
         const unsigned long long cnt = L[0];
-        if ((uint32_t)cnt == 0u) continue;                                  // no point of this chunk reached the voxel
+        const unsigned long long raw = cnt & kCntMask, in = (cnt >> kCntBits) & kCntMask, conv = cnt >> (2 * kCntBits);
+        if (raw == 0ull) continue;                                          // no point of this chunk reached the voxel
         unsigned long long* G = reinterpret_cast<unsigned long long*>(gacc + (size_t)s * kAccWords);
-        atomicAdd(&G[0], cnt);
-        if ((uint32_t)(cnt >> 32)) {
+        atomicAdd(&G[0], raw | (in << 32));
+        if (in) {
+            const unsigned long long bias = conv * kFixBias;                // mod 2^64, like the sums
 #pragma unroll
-            for (int k = 1; k < 10; k++) atomicAdd(&G[k], L[k]);
+            for (int k = 1; k < 10; k++) atomicAdd(&G[k], L[k] - bias);
         }
     }
 }
@@ -347,7 +375,8 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     int lds_slots = c.lds_slots > 0 ? c.lds_slots : (int)((budget > fixed ? budget - fixed : 0) / row);
     lds_slots = lds_slots < 32 ? 32 : lds_slots;
     if (lds_slots > c.V) lds_slots = c.V;
-    const int chunks = chunks_for(c.n_pairs, c.max_n2, kAccBlock * c.acc_min_pts_per_thread, c.acc_target_blocks);
+    int chunks = chunks_for(c.n_pairs, c.max_n2, kAccBlock * c.acc_min_pts_per_thread, c.acc_target_blocks);
+    chunks = std::max(chunks, (int)(((long long)c.max_n2 + (1 << 20) - 1) >> 20));          // a block's counts live in 21-bit fields: at most 2^20 (+ rounding) points per block
     const size_t lds = fixed + (size_t)lds_slots * (5 + kAccLds) * 4;
     dim3 grid(grid_groups(c.n_pairs) * chunks), blk(kAccBlock);
     const LutCell* lut = reinterpret_cast<const LutCell*>(w.lut);

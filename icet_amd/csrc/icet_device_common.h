@@ -215,15 +215,21 @@ __device__ __forceinline__ void classify_literal(float qx, float qy, float qz, c
     }
 }
 
-// float -> 64-bit fixed point: v * 2^36 rounded to the nearest integer (ties to even), two's complement, in 3 instructions.
-// One double fma forms v * 2^36 + 1.5 * 2^52 with a single rounding; for |v| < 2^15 the sum lies in [2^52, 2^53), where the ulp
-// is 1, so the integer sits in the mantissa and subtracting the bit pattern of 1.5 * 2^52 leaves it (negative values included).
+// float -> 64-bit fixed point: v * 2^36 rounded to the nearest integer (ties to even), two's complement.
+// (double)v + 1.5 * 2^16 lies in [2^16, 2^17) for |v| < 2^15, where a double's ulp is 2^-36: the addition itself rounds v to the
+// grid and leaves 2^51 + round(v * 2^36) in the mantissa field, i.e. the integer plus the bit pattern of 1.5 * 2^16 (kFixBias).
 // Any fixed rounding rule would do; what matters is that EVERY conversion on the path uses this one (a slot's sums may arrive
 // through LDS or straight in HBM) and that integer addition is associative.
-__device__ __forceinline__ unsigned long long to_fix(float v) {
-    const double x = fma((double)v, (double)kFixScale, 6755399441055744.0);          // 1.5 * 2^52
-    return (unsigned long long)(__double_as_longlong(x) - 0x4338000000000000LL);
+// to_fix_biased leaves the bias in: a sum of n such words is n * kFixBias + the sum of the integers (mod 2^64), so a block that
+// counts its conversions takes the bias out once per slot instead of once per value (k_gn_accumulate): two VALU instructions
+// per value (v_cvt_f64_f32, v_add_f64 with a scalar constant).
+static_assert(kFixScale == 68719476736.0f, "kFixMagic / kFixBias below are written for a scale of 2^36");
+constexpr double kFixMagic = 98304.0;                               // 1.5 * 2^(52 - 36)
+constexpr unsigned long long kFixBias = 0x40F8000000000000ULL;      // its bit pattern
+__device__ __forceinline__ unsigned long long to_fix_biased(float v) {
+    return (unsigned long long)__double_as_longlong((double)v + kFixMagic);
 }
+__device__ __forceinline__ unsigned long long to_fix(float v) { return to_fix_biased(v) - kFixBias; }
 
 // One run's partial sums into a slot's HBM accumulator record (kAccWords words: [raw | in << 32], then 9 fixed-point sums).
 __device__ __forceinline__ void acc_add_hbm(uint32_t* A, uint32_t nraw, uint32_t nin, float S0, float S1, float S2, float S3, float S4,

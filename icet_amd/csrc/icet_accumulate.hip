@@ -206,26 +206,29 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
             nr[0] |= odd; nr[1] |= odd; nr[2] |= odd; nr[3] |= odd;
         }
         // ---- phase A2: only waves that touch an active voxel look at the hot records (radial test, d = q - mu1) ----
-        const bool lane_has = ((SM[0] >= 0) & !nr[0]) | ((SM[1] >= 0) & !nr[1]) | ((SM[2] >= 0) & !nr[2]) | ((SM[3] >= 0) & !nr[3]);
-        if (__ballot(lane_has) != 0ull) {
+        // E: the point's slot, -1 for "no active voxel" and for a point that waits for the literal formulas
+        const int E0 = nr[0] ? -1 : SM[0], E1 = nr[1] ? -1 : SM[1], E2 = nr[2] ? -1 : SM[2], E3 = nr[3] ? -1 : SM[3];
+        if (__ballot((E0 & E1 & E2 & E3) >= 0) != 0ull) {                  // some lane holds a point with E >= 0 (the sign bits do not all agree on "negative")
             // A slot beyond the LDS table (more active voxels than lds_slots; the launch sizes the table so that this is rare) keeps
             // its record in HBM.  Its points stay in the lane's runs like any other -- how the sums are grouped must not depend on a
             // launch-shape knob, or the knob would show in the result bits -- so the record is fetched here, in a wave-uniform branch
             // that ordinary waves skip (every LDS access stays a ds_* instruction, every HBM access a global_*).
-            const bool beyond = __ballot(((SM[0] >= nl) & !nr[0]) | ((SM[1] >= nl) & !nr[1]) | ((SM[2] >= nl) & !nr[2]) | ((SM[3] >= nl) & !nr[3])) != 0ull;
+            const bool beyond = __ballot(max(max(E0, E1), max(E2, E3)) >= nl) != 0ull;
+            const int E[4] = {E0, E1, E2, E3};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int sm = SM[j];
-                const bool has = (sm >= 0) & !nr[j];
+                const int sm = E[j];
+                const bool has = sm >= 0;
                 const float* h = hot + min(max(sm, 0), lds_slots - 1) * 5;
                 float inner = h[0], outer = h[1], m0 = h[2], m1 = h[3], m2 = h[4];
                 if (beyond) {
-                    if (has & (sm >= nl)) { const SlotHot g = hs[sm]; inner = g.inner; outer = g.outer; m0 = g.mu[0]; m1 = g.mu[1]; m2 = g.mu[2]; }
+                    if (sm >= nl) { const SlotHot g = hs[sm]; inner = g.inner; outer = g.outer; m0 = g.mu[0]; m1 = g.mu[1]; m2 = g.mu[2]; }
                 }
                 const float r = RR[j];
                 const float gr = 1e-6f * r;
-                nr[j] = nr[j] | (has & (!(fabsf(r - inner) >= gr) | !(fabsf(r - outer) >= gr)));
-                pc[j].s = nr[j] ? -1 : sm;
+                const bool edge = has & (!(fabsf(r - inner) >= gr) | !(fabsf(r - outer) >= gr));
+                nr[j] |= edge;
+                pc[j].s = edge ? -1 : sm;
                 pc[j].inb = has & (r >= inner) & (r <= outer);
                 pc[j].dx = QX[j] - m0; pc[j].dy = QY[j] - m1; pc[j].dz = QZ[j] - m2;
             }

@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=256)
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="icet_set_option on the context (launch-shape experiments); echoed in config.options")
     ap.add_argument("--distinct", type=int, default=0, help="generate only this many distinct pairs and cycle them (0 = all distinct)")
     return ap.parse_args()
 
@@ -207,6 +209,9 @@ def main():
 
     stream = torch.cuda.Stream(device=dev)
     ctx = icet_amd.Context(local_rank, stream=stream.cuda_stream)
+    for kv in args.set:
+        name, value = kv.split("=", 1)
+        ctx.set_option(name, float(value))
     p_plain = api.Params(iters, P, T, 25, 0.1, 0.1, 0)
     p_timed = api.Params(iters, P, T, 25, 0.1, 0.1, api.FLAG_TIMING)
     out = torch.zeros((len(ids), 48), dtype=torch.float32, device=dev)
@@ -344,6 +349,7 @@ def main():
             "config": {"workload": ("configs[2]/[3]: %d independent 64-ch synthetic scan pairs per GPU (~%dk pts/scan, %s-major), 75x24 voxels, 7 iters, "
                                     "pair k -> rank k mod N, RCCL all-gather of 48 floats/pair when N>1" % (n_local, int(np.mean(n2) / 1000), args.order))
                        if args.workload == "batch" else "configs[4]: single 128-ch pair (~%dk pts), 150x48 voxels, 10 iters" % int(np.mean(n2) / 1000),
+                       **({"options": list(args.set)} if args.set else {}),
                        "pairs_per_gpu": n_local, "pairs_total": n_global, "points_scan1_mean": int(np.mean(n1)), "points_scan2_mean": int(np.mean(n2)),
                        "bins_theta": T, "bins_phi": P, "iters": iters, "parallelism": "pairs round-robin x%d" % world, "gen_s": round(t_gen, 1)},
             "roofline": {"kernel": "k_gn_accumulate", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

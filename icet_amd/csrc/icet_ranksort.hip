@@ -13,11 +13,14 @@
 //                    and its tile's bucket histogram, at no extra pass over r
 //   [k_bin_scan]     (shared with the voxel multi-split) exclusive scan over (bucket, tile)
 //   k_rs_scatter     stable multi-split of the rows into their buckets (match-any ranking, as k_bin_scatter)
-//   k_rs_bucket_sort one block per (pair, bucket): LSD radix sort of the bucket's (key, row) pairs entirely in
-//                    LDS (4 stable 8-bit passes, passes whose digit is constant are skipped), then s[] and pred[] are
-//                    written -- no inverse-permutation kernel.  A bucket that does not fit LDS runs the same code on
-//                    global scratch; a bucket of identical keys (the zero rows of a real scan: thousands of exact
-//                    r = 0) is already in order because the multi-split is stable.
+//   k_rs_bucket_sort one block per (pair, bucket), the bucket's (key, row) pairs in LDS: a COUNTING sort on the bucket's
+//                    own key range (a bucket is 1/128 of a smooth distribution, so its keys are close to uniform
+//                    between its min and max: ~0.5 rows per cell of (key - min) >> shift), then every row ranks
+//                    itself inside its cell by (key, row) -- 7 barriers instead of the ~15 of an LSD radix sort --
+//                    and s[] and pred[] are written: no inverse-permutation kernel.  A bucket whose keys pile up in
+//                    one cell takes the LSD radix sort in LDS (stable 8-bit passes, constant digits skipped), one that
+//                    does not fit LDS runs that radix sort on global scratch; a bucket of identical keys (the zero rows
+//                    of a real scan: thousands of exact r = 0) is already in order because the multi-split is stable.
 // Equal keys always fall into one bucket (bucket = number of splitters strictly below the key), a repeated key that
 // reaches the sample becomes a bucket of its own, and every stage is stable, so ties end up ordered by row index.
 // Traffic ~30 B per row instead of ~130 B.
@@ -42,7 +45,7 @@ constexpr int kBucketBits = kRankSortBucketBits;
 // 1280 rows (25 KB, 6 blocks per CU) beats the earlier fixed 2560 (45 KB, 3 blocks) by 0.2 ms -- the sort is latency bound
 // and wants the occupancy -- even though a few per cent of the buckets then overflow to the global-scratch path.
 constexpr int kBucketTarget = ICET_RS_TARGET;
-constexpr int kCapMin = 1280, kCapMax = 9216;  // 9216 rows = 152 KB: one block per CU, still far better than global scratch
+constexpr int kCapMin = 1280, kCapMax = 8960;  // 8960 rows + 4096 cells = 156 KB: one block per CU, still far better than global scratch
 constexpr int kSortBlock = 256;
 constexpr int kSortWaves = kSortBlock / 64;
 
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(1024) void k_rs_splitters(const PairDesc* __restric
 constexpr int kScatterRounds = kKfMaxPtsPerThread;   // a tile is at most 4 waves x this many rounds x 64 positions
 __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restrict__ desc, const float* __restrict__ r1, const uint8_t* __restrict__ bkt,
                                                        const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bucket_start,
-                                                       uint32_t* __restrict__ bkey, uint32_t* __restrict__ bidx, int n_pairs, int chunks) {
+                                                       uint2* __restrict__ bkv, int n_pairs, int chunks) {
     __shared__ uint32_t lb[4 * kMaxBuckets];
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;
@@ -135,34 +138,35 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restric
             const int rank = __popcll(peers & lt);
             const uint32_t dest = mine[bb[k]] + (uint32_t)rank;
             if (rank == 0) mine[bb[k]] += (uint32_t)__popcll(peers);
-            bkey[o + dest] = key[k];
-            bidx[o + dest] = (uint32_t)(wlo + 64 * k + lane);
+            bkv[o + dest] = make_uint2(key[k], (uint32_t)(wlo + 64 * k + lane));      // (key, row): ONE scattered 8-byte store
         }
     }
 }
 
-// ---- per-bucket LSD radix sort (stable): in LDS, or -- same code on global scratch -- for a bucket that does not fit --
-// LDS layout (words): cnt[kSortWaves*256] | tot[256] | wsum[4] | red[2*kSortWaves] | buf0 keys[kCap] idx[kCap] | buf1 keys idx
-constexpr int kOffCnt = 0, kOffTot = kSortWaves * 256, kOffWsum = kOffTot + 256, kOffRed = kOffWsum + 4, kOffBuf = kOffRed + 2 * kSortWaves;
+// ---- per-bucket sort ------------------------------------------------------------------------------------------------
+// LDS layout (words): cells[C]  (the radix fallback keeps cnt[kSortWaves*256] | tot[256] | wsum[4] in the same words)
+//                     | red[16] | buf0 keys[kCap] rows[kCap] | buf1 keys[kCap] rows[kCap]
+constexpr int kOffCnt = 0, kOffTot = kSortWaves * 256, kOffWsum = kOffTot + 256, kRadixWords = kOffWsum + 4;
+constexpr int kRedWords = 16;
+constexpr int kMaxCellRows = 24;      // a cell holding more rows than this sends the bucket to the radix sort (rank-in-cell is quadratic in it)
 
-// kLds selects, at compile time, LDS arrays (indexed off the extern __shared__ base, so the compiler emits ds_*
-// instructions) or the global scratch pointers; `sel` says which of the two buffers is the input.
+// One stable 8-bit LSD pass.  kLds selects, at compile time, LDS arrays (indexed off the extern __shared__ base, so the
+// compiler emits ds_* instructions) or the global scratch pointers; `sel` says which of the two buffers is the input.
 template <bool kLds>
-__device__ __forceinline__ void radix_pass(uint32_t* smem, int kCap, int sel, const uint32_t* gK0, const uint32_t* gI0, uint32_t* gK1, uint32_t* gI1, int n, int shift, uint32_t dmask) {
+__device__ __forceinline__ void radix_pass(uint32_t* smem, int offBuf, int kCap, int sel, const uint2* gIn, uint2* gOut, int n, int shift, uint32_t dmask) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* cnt = smem + kOffCnt; uint32_t* tot = smem + kOffTot; int* wsum = reinterpret_cast<int*>(smem + kOffWsum);
-    const int inB = kOffBuf + sel * 2 * kCap, outB = kOffBuf + (1 - sel) * 2 * kCap;
-    auto ldK = [&](int i) -> uint32_t { if constexpr (kLds) return smem[inB + i]; else return gK0[i]; };
-    auto ldI = [&](int i) -> uint32_t { if constexpr (kLds) return smem[inB + kCap + i]; else return gI0[i]; };
-    auto st = [&](uint32_t dest, uint32_t k, uint32_t id) {
-        if constexpr (kLds) { smem[outB + dest] = k; smem[outB + kCap + dest] = id; } else { gK1[dest] = k; gI1[dest] = id; }
+    const int inB = offBuf + sel * 2 * kCap, outB = offBuf + (1 - sel) * 2 * kCap;
+    auto ld = [&](int i) -> uint2 { if constexpr (kLds) return make_uint2(smem[inB + i], smem[inB + kCap + i]); else return gIn[i]; };
+    auto st = [&](uint32_t dest, uint2 kv) {
+        if constexpr (kLds) { smem[outB + dest] = kv.x; smem[outB + kCap + dest] = kv.y; } else gOut[dest] = kv;
     };
     int seg = (n + kSortWaves - 1) / kSortWaves; seg = (seg + 63) / 64 * 64;
     const int wlo = wave * seg, whi = min(n, wlo + seg);
     uint32_t* mine = cnt + wave * 256;
     for (int i = lane; i < 256; i += 64) mine[i] = 0u;
     // (same wave zeroes and then adds: LDS operations of one wave complete in order)
-    for (int i = wlo + lane; i < whi; i += 64) atomicAdd(&mine[(ldK(i) >> shift) & 255u], 1u);
+    for (int i = wlo + lane; i < whi; i += 64) atomicAdd(&mine[(ld(i).x >> shift) & 255u], 1u);
     __syncthreads();
     {                                                           // kSortBlock == 256: one thread per digit
         const int dgt = threadIdx.x;
@@ -187,8 +191,8 @@ __device__ __forceinline__ void radix_pass(uint32_t* smem, int kCap, int sel, co
     for (int i0 = wlo; i0 < whi; i0 += 64) {
         const int i = i0 + lane;
         const bool ok = i < whi;
-        const uint32_t k = ok ? ldK(i) : 0u, id = ok ? ldI(i) : 0u;
-        const uint32_t dgt = (k >> shift) & 255u;
+        const uint2 kv = ok ? ld(i) : make_uint2(0u, 0u);
+        const uint32_t dgt = (kv.x >> shift) & 255u;
         unsigned long long peers = __ballot(ok);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -201,7 +205,7 @@ __device__ __forceinline__ void radix_pass(uint32_t* smem, int kCap, int sel, co
             const int rank = __popcll(peers & lt);
             const uint32_t dest = mine[dgt] + (uint32_t)rank;
             if (rank == 0) mine[dgt] += (uint32_t)__popcll(peers);
-            st(dest, k, id);
+            st(dest, kv);
         }
     }
     __syncthreads();
@@ -209,46 +213,113 @@ __device__ __forceinline__ void radix_pass(uint32_t* smem, int kCap, int sel, co
 
 static_assert(kSortBlock == 256, "radix_pass assigns one thread per digit");
 
+// Block-wide reductions of four words (OR, AND, min, max of the keys) through red[].
+__device__ __forceinline__ void block_key_stats(uint32_t* red, uint32_t& vor, uint32_t& vand, uint32_t& vmin, uint32_t& vmax) {
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        vor |= __shfl_xor(vor, sft); vand &= __shfl_xor(vand, sft);
+        vmin = min(vmin, (uint32_t)__shfl_xor(vmin, sft)); vmax = max(vmax, (uint32_t)__shfl_xor(vmax, sft));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave] = vor; red[kSortWaves + wave] = vand; red[2 * kSortWaves + wave] = vmin; red[3 * kSortWaves + wave] = vmax; }
+    __syncthreads();
+    vor = 0u; vand = 0xFFFFFFFFu; vmin = 0xFFFFFFFFu; vmax = 0u;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) { vor |= red[w]; vand &= red[kSortWaves + w]; vmin = min(vmin, red[2 * kSortWaves + w]); vmax = max(vmax, red[3 * kSortWaves + w]); }
+    __syncthreads();
+}
+static_assert(4 * kSortWaves <= kRedWords, "red[] holds four words per wave");
+
+// Counting sort of the n (key, row) pairs in buf0 on the bucket's own key range; true = done (s / pred written), false = some cell
+// is too crowded (block-uniform; nothing written): the caller falls back to the radix sort.
+__device__ __forceinline__ bool counting_sort_lds(uint32_t* smem, int C, int logC, int kCap, int n, uint32_t kmin, uint32_t kmax,
+                                                  int lo, size_t off1, uint32_t* s_out, int32_t* pred_out) {
+    uint32_t* cells = smem; uint32_t* red = smem + C;
+    const int offBuf = C + kRedWords;
+    const uint32_t* K0 = smem + offBuf; const uint32_t* I0 = K0 + kCap;
+    uint32_t* K1 = smem + offBuf + 2 * kCap; uint32_t* I1 = K1 + kCap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t range = kmax - kmin;                                   // > 0 here
+    const int sh = max(0, 32 - __clz(range) - logC);                      // (range >> sh) < C
+    for (int j = threadIdx.x; j < C; j += kSortBlock) cells[j] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kSortBlock) atomicAdd(&cells[(K0[i] - kmin) >> sh], 1u);
+    __syncthreads();
+    {   // exclusive scan of the cell counts in place (thread t owns C / 256 consecutive cells) + the largest count
+        const int per = C / kSortBlock, c0 = threadIdx.x * per;
+        uint32_t sum = 0u, big = 0u;
+        for (int j = 0; j < per; j++) { const uint32_t c = cells[c0 + j]; sum += c; big = max(big, c); }
+        int incl = (int)sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) big = max(big, (uint32_t)__shfl_xor(big, sft));
+        if (lane == 63) { red[wave] = (uint32_t)incl; red[kSortWaves + wave] = big; }
+        __syncthreads();
+        uint32_t base = (uint32_t)incl - sum;
+        for (int k = 0; k < wave; k++) base += red[k];
+        big = 0u;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; w++) big = max(big, red[kSortWaves + w]);
+        if (big > (uint32_t)kMaxCellRows) { __syncthreads(); return false; }          // block-uniform
+        for (int j = 0; j < per; j++) { const uint32_t c = cells[c0 + j]; cells[c0 + j] = base; base += c; }
+    }
+    __syncthreads();
+    // placement by cell, in arrival order inside a cell; afterwards cells[c] = END of cell c (its begin = cells[c - 1])
+    for (int i = threadIdx.x; i < n; i += kSortBlock) {
+        const uint32_t k = K0[i];
+        const uint32_t pos = atomicAdd(&cells[(k - kmin) >> sh], 1u);
+        K1[pos] = k; I1[pos] = I0[i];
+    }
+    __syncthreads();
+    // every row ranks itself among the rows of its cell by (key, row): ties in row order, the oracle's rule
+    for (int p = threadIdx.x; p < n; p += kSortBlock) {
+        const uint32_t k = K1[p], id = I1[p];
+        const uint32_t c = (k - kmin) >> sh;
+        const uint32_t b = c ? cells[c - 1] : 0u, e = cells[c];
+        uint32_t r = b;
+        for (uint32_t j = b; j < e; j++) { const uint32_t kj = K1[j], ij = I1[j]; r += ((kj < k) | ((kj == k) & (ij < id))) ? 1u : 0u; }
+        s_out[off1 + lo + r] = id;
+        pred_out[off1 + id] = lo + (int)r;
+    }
+    return true;
+}
+
 template <bool kLds>
-__device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int kCap, const uint32_t* bkey, const uint32_t* bidx, uint32_t* gK0, uint32_t* gI0, uint32_t* gK1, uint32_t* gI1,
+__device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int C, int logC, int kCap, const uint2* bkv, uint2* gA, uint2* gB,
                                                  int n, int lo, size_t off1, uint32_t* s_out, int32_t* pred_out) {
     const size_t o = off1 + lo;
-    if constexpr (kLds) {
-        for (int i = threadIdx.x; i < n; i += kSortBlock) { smem[kOffBuf + i] = bkey[o + i]; smem[kOffBuf + kCap + i] = bidx[o + i]; }
-        __syncthreads();
+    const int offBuf = C + kRedWords;
+    uint32_t vor = 0u, vand = 0xFFFFFFFFu, vmin = 0xFFFFFFFFu, vmax = 0u;
+    for (int i = threadIdx.x; i < n; i += kSortBlock) {
+        const uint2 kv = bkv[o + i];
+        if constexpr (kLds) { smem[offBuf + i] = kv.x; smem[offBuf + kCap + i] = kv.y; }
+        vor |= kv.x; vand &= kv.x; vmin = min(vmin, kv.x); vmax = max(vmax, kv.x);
     }
-    // OR / AND of all keys: a digit position where every key agrees needs no pass (in particular a bucket of
-    // identical keys -- the zero rows of a real scan -- needs none at all)
-    uint32_t vor = 0u, vand = 0xFFFFFFFFu;
-    for (int i = threadIdx.x; i < n; i += kSortBlock) { uint32_t k; if constexpr (kLds) k = smem[kOffBuf + i]; else k = gK0[i]; vor |= k; vand &= k; }
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) { vor |= __shfl_xor(vor, sft); vand &= __shfl_xor(vand, sft); }
-    uint32_t* red = smem + kOffRed;
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = vor; red[kSortWaves + (threadIdx.x >> 6)] = vand; }
-    __syncthreads();
-    vor = 0u; vand = 0xFFFFFFFFu;
-#pragma unroll
-    for (int w = 0; w < kSortWaves; w++) { vor |= red[w]; vand &= red[kSortWaves + w]; }
-    const uint32_t differ = vor & ~vand;                        // bit set where the keys do not all agree
-    __syncthreads();
+    block_key_stats(smem + C, vor, vand, vmin, vmax);             // (its barriers also publish buf0)
+    // a digit position where every key agrees needs no radix pass; a bucket of identical keys -- the zero rows of a real scan -- is
+    // already in order (the multi-split is stable)
+    const uint32_t differ = vor & ~vand;
     int sel = 0;
-    for (int pass = 0; pass < 4; pass++) {
-        if (((differ >> (8 * pass)) & 255u) == 0u) continue;    // block-uniform
-        radix_pass<kLds>(smem, kCap, sel, sel ? gK1 : gK0, sel ? gI1 : gI0, sel ? gK0 : gK1, sel ? gI0 : gI1, n, 8 * pass, (differ >> (8 * pass)) & 255u);
-        sel ^= 1;
+    if (differ != 0u) {
+        if constexpr (kLds) { if (counting_sort_lds(smem, C, logC, kCap, n, vmin, vmax, lo, off1, s_out, pred_out)) return; }
+        for (int pass = 0; pass < 4; pass++) {
+            if (((differ >> (8 * pass)) & 255u) == 0u) continue;    // block-uniform
+            radix_pass<kLds>(smem, offBuf, kCap, sel, sel ? gB : gA, sel ? gA : gB, n, 8 * pass, (differ >> (8 * pass)) & 255u);
+            sel ^= 1;
+        }
     }
     for (int i = threadIdx.x; i < n; i += kSortBlock) {
         uint32_t row;
-        if constexpr (kLds) row = smem[kOffBuf + sel * 2 * kCap + kCap + i]; else row = (sel ? gI1 : gI0)[i];
+        if constexpr (kLds) row = smem[offBuf + sel * 2 * kCap + kCap + i]; else row = (sel ? gB : gA)[i].y;
         s_out[o + i] = row;
         pred_out[off1 + row] = lo + i;
     }
 }
 
 __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bucket_start,
-                                                               const int32_t* __restrict__ n_buckets, uint32_t* __restrict__ bkey, uint32_t* __restrict__ bidx,
-                                                               uint32_t* __restrict__ altkey, uint32_t* __restrict__ altidx,
-                                                               uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out, int kCap, int n_pairs) {
+                                                               const int32_t* __restrict__ n_buckets, uint2* __restrict__ bkv, uint2* __restrict__ alt,
+                                                               uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out, int kCap, int logC, int n_pairs) {
     extern __shared__ uint32_t smem[];
     // all buckets of a pair on one XCD (decode_block): their scattered 4-byte writes of pred[] then complete whole cache lines in
     // ONE L2 instead of leaving partial lines in eight
@@ -259,8 +330,9 @@ __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* _
     const int n = bucket_start[(size_t)pair * (kMaxBuckets + 1) + bucket + 1] - lo;
     if (n <= 0) return;
     const size_t off1 = (size_t)desc[pair].off1;
-    if (n <= kCap) bucket_sort_body<true>(smem, kCap, bkey, bidx, nullptr, nullptr, nullptr, nullptr, n, lo, off1, s_out, pred_out);
-    else bucket_sort_body<false>(smem, kCap, bkey, bidx, bkey + off1 + lo, bidx + off1 + lo, altkey + off1 + lo, altidx + off1 + lo, n, lo, off1, s_out, pred_out);
+    const int C = 1 << logC;
+    if (n <= kCap) bucket_sort_body<true>(smem, C, logC, kCap, bkv, nullptr, nullptr, n, lo, off1, s_out, pred_out);
+    else bucket_sort_body<false>(smem, C, logC, kCap, bkv, bkv + off1 + lo, alt + off1 + lo, n, lo, off1, s_out, pred_out);
 }
 
 }  // namespace
@@ -275,10 +347,14 @@ static int rank_sort_cap(int max_n, int forced) {
     if (forced > 0) cap = forced < 64 ? 64 : (forced > kCapMax ? kCapMax : forced);     // Tuning::rs_cap (tests: force the global-scratch path)
     return cap;
 }
-static size_t rank_sort_lds_bytes(int cap) { return (size_t)(kOffBuf + 4 * cap) * 4; }
+// cells of the counting sort: about two per LDS row (a bucket then fills them to 0.2 - 0.9 rows per cell), 2048 (which also
+// holds the radix fallback's counters) to 4096
+static int rank_sort_log_cells(int cap) { return cap <= 1280 ? 11 : 12; }
+static size_t rank_sort_lds_bytes(int cap) { return (size_t)((1 << rank_sort_log_cells(cap)) + kRedWords + 4 * cap) * 4; }
+static_assert(kRadixWords <= 2048, "the radix fallback's counters live in the cell array");
 
-// Outputs: w.valB = s (row with rank i), w.pred = rank of every row.  Scratch: w.keyA / w.valA (bucket-grouped keys and
-// rows), w.keyB / w.key64A (overflow buckets), w.bkt, w.counts / w.tile_base, w.splitters, w.n_buckets, w.bucket_start.
+// Outputs: w.valB = s (row with rank i), w.pred = rank of every row.  Scratch: w.key64A (bucket-grouped (key, row) pairs),
+// w.key64B (second buffer of an overflow bucket), w.bkt, w.counts / w.tile_base, w.splitters, w.n_buckets, w.bucket_start.
 hipError_t init_rank_sort_kernels() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_bucket_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_sort_lds_bytes(kCapMax));
 }
@@ -296,11 +372,11 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
     // (buckets bkt[] and the per-tile histograms counts[] were produced by k_scan1_spherical)
     hipError_t e = launch_class_scan(w.counts, w.tile_base, w.bucket_start, kMaxBuckets, chunks, np, st);
     if (e != hipSuccess) return e;
-    k_rs_scatter<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, w.keyA, w.valA, np, chunks);
+    k_rs_scatter<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks);
     ICET_LAUNCH_CHECK();
     const int cap = rank_sort_cap(c.max_n1, c.rs_cap);
-    k_rs_bucket_sort<<<dim3(groups * kMaxBuckets), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, w.keyA, w.valA, w.keyB,
-                                                                                             reinterpret_cast<uint32_t*>(w.key64A), w.valB, w.pred, cap, np);
+    k_rs_bucket_sort<<<dim3(groups * kMaxBuckets), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, reinterpret_cast<uint2*>(w.key64A),
+                                                                                             reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), np);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

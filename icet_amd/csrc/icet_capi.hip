@@ -121,6 +121,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
             HIPCHK(c, dev_realloc(w.pred, n)); HIPCHK(c, dev_realloc(w.src, n));
             w.cap_n1 = n;
         }
+        HIPCHK(c, dev_realloc(w.execbits, (size_t)(w.cap_n1 / 64 + w.cap_pairs + 2)));      // exec_word_base: off1 / 64 + pair
         {
             const size_t need_items = (size_t)(w.cap_n1 / 64 + (int64_t)w.cap_pairs * (w.cap_V + 1) + 64);
             if (need_items > w.cap_fit_items) {
@@ -386,7 +387,7 @@ icet_status icet_destroy(icet_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     Workspace& w = c->w;
-    void* ps[] = {w.key64A, w.key64B, w.bin16, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.cart1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src,
+    void* ps[] = {w.key64A, w.key64B, w.bin16, w.execbits, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.cart1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src,
                   w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.near_over, w.near_over_count, w.acc, w.xf, w.X, w.flags,
                   w.sort_tmp, w.fit_items, w.fit_n_items, w.live_bins, w.n_live, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);

@@ -31,7 +31,7 @@ constexpr int kKfMaxPtsPerThread = ICET_KF_MAXPTS;   // keyframe kernels: larges
 // ICET_ERR_UNSUPPORTED instead of failing a launch mid-sequence.  Voxel ids travel in 14 bits of a 16-bit word whose two top
 // bits carry per-row flags (kRowNearBit, kRowExecBit); slot ids travel as int16.
 constexpr int kMaxVoxels = 10000;
-constexpr uint16_t kRowExecBit = 0x8000u;   // the reference's swap loop executes its step at this row (icet_keyframe.hip, k_exec_flags)
+constexpr uint16_t kRowExecBit = 0x8000u;   // (free since the swap-loop flags moved to a bit table; stays clear)
 constexpr uint16_t kRowNearBit = 0x4000u;   // the row lies within a guard band of a voxel edge: its azimuth / polar bounds test must be done with the literal formulas
 constexpr uint16_t kRowBinMask = 0x3FFFu;
 constexpr uint32_t kSortedNearBit = 0x80000000u;   // the same flag in the sorted-row table (rows < 2^31)
@@ -95,6 +95,7 @@ struct Workspace {
     uint16_t* binpos = nullptr;                                      // angular bin of the row at every position after the scramble
     uint32_t* counts = nullptr; uint32_t* tile_base = nullptr; size_t cap_counts = 0;               // pairs x tiles x V histogram / tile base offsets
     uint16_t* bin16 = nullptr;                                       // angular bin of every scan-1 row (input order)
+    unsigned long long* execbits = nullptr;                          // swap loop: "step v executed", 64 rows per word (exec_word_base, icet_keyframe.hip)
     int32_t *pred = nullptr, *src = nullptr;
     int32_t *bin_count = nullptr, *bin_start = nullptr;             // pairs x V, pairs x (V+1)
     SlotHot* hotD = nullptr; SlotFit* fitD = nullptr; int32_t* activeD = nullptr;   // dense, pairs x V

@@ -122,18 +122,22 @@ __global__ __launch_bounds__(kBlock) void k_inverse_perm(const PairDesc* __restr
 #endif
 constexpr int kWalk = ICET_WALK;
 
-// The flag goes into bit 15 of the row's voxel word (icet_internal.h): k_scramble_src needs "did step u execute" and "which voxel
-// is row u in" for the same u, so one 2-byte random read serves both.
-constexpr uint16_t kExecBit = kRowExecBit, kBinMask = kRowBinMask;
+// The flags go into a bit table, 64 rows per word: 116 k rows = 15 KB, which k_scramble_src keeps in LDS, so that "did step u
+// execute" costs its walks no memory access (round 2a kept the flag in the row's voxel word: one more random read per chain step).
+// A pair's words start at exec_word_base; word ranges of different pairs never overlap:
+// floor((off1 + n) / 64) + 1 >= floor(off1 / 64) + ceil(n / 64).
+constexpr uint16_t kBinMask = kRowBinMask;
+__device__ __host__ __forceinline__ size_t exec_word_base(int32_t off1, int pair) { return (size_t)(off1 >> 6) + (size_t)pair; }
 
-__global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
-                                                       uint16_t* __restrict__ bin16, int32_t* __restrict__ flags, int max_walk, int n_pairs, int chunks) {
+__global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restrict__ desc, const int32_t* __restrict__ pred,
+                                                       unsigned long long* __restrict__ execbits, int32_t* __restrict__ flags, int max_walk, int n_pairs, int chunks) {
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;
     const PairDesc d = desc[pair];
     int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
     const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
     const size_t o = d.off1;
+    unsigned long long* bits = execbits + exec_word_base(d.off1, pair);
     for (int base = lo_ + threadIdx.x; base < hi_; base += kWalk * kBlock) {
         int u[kWalk], len[kWalk]; bool act[kWalk], moved[kWalk];
 #pragma unroll
@@ -161,8 +165,10 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
         }
 #pragma unroll
         for (int k = 0; k < kWalk; k++) {
+            // a wave holds 64 consecutive rows starting at a multiple of 64 (lo_ is a multiple of kBlock): one ballot = one word
             const int v = base + k * kBlock;
-            if (v < hi_ && moved[k] && !(len[k] & 1)) bin16[o + v] |= kExecBit;      // k_scan1_spherical wrote the id with the bit clear
+            const unsigned long long m = __ballot(v < hi_ && moved[k] && !(len[k] & 1));
+            if ((threadIdx.x & 63) == 0 && v < hi_) bits[v >> 6] = m;
         }
     }
 }
@@ -175,39 +181,44 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
 #ifndef ICET_SCR_WAVES
 #define ICET_SCR_WAVES 6      /* <= 80 VGPRs: 6 waves per SIMD for a latency-bound walk (measured: -35 us per 256-pair keyframe; 8 spills) */
 #endif
+// kBitsInLds: the pair's exec table sits in LDS behind the voxel histogram (any scan below ~0.75 M rows); otherwise its words are
+// read from memory.
+template <bool kBitsInLds>
 __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
-                                                         int32_t* __restrict__ src, int32_t* __restrict__ flags, int max_walk,
+                                                         const unsigned long long* __restrict__ execbits, int32_t* __restrict__ src, int32_t* __restrict__ flags, int max_walk,
                                                          const uint16_t* __restrict__ bin16, uint16_t* __restrict__ binpos, uint32_t* __restrict__ counts, int V,
                                                          int n_pairs, int chunks) {
-    extern __shared__ uint32_t lh[];
+    extern __shared__ __attribute__((aligned(8))) uint32_t lh[];
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;
     const PairDesc d = desc[pair];
     int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
     const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
     const size_t o = d.off1;
+    const unsigned long long* gbits = execbits + exec_word_base(d.off1, pair);
+    unsigned long long* lbits = reinterpret_cast<unsigned long long*>(lh + ((V + 1) & ~1));
     for (int b = threadIdx.x; b < V; b += kBlock) lh[b] = 0u;
+    if (kBitsInLds) {
+        const int nw = (d.n1 + 63) >> 6;
+        for (int i = threadIdx.x; i < nw; i += kBlock) lbits[i] = gbits[i];
+    }
     __syncthreads();
+    auto exec = [&](int u) -> bool { const unsigned long long w = kBitsInLds ? lbits[u >> 6] : gbits[u >> 6]; return (w >> (u & 63)) & 1ull; };
     for (int base = lo_ + threadIdx.x; base < hi_; base += kWalk * kBlock) {
         int f[kWalk], u[kWalk], len[kWalk]; bool act[kWalk];
-        int pv[kWalk]; uint16_t wv[kWalk], fb[kWalk];    // fb: packed word of the row f[] (its voxel id is what the histogram needs)
+        int pv[kWalk];
 #pragma unroll
         for (int k = 0; k < kWalk; k++) {
             const int v = base + k * kBlock;
-            const bool valid = v < hi_;
-            const size_t i = o + (valid ? v : lo_);
-            pv[k] = pred[i]; wv[k] = bin16[i];
+            pv[k] = pred[o + (v < hi_ ? v : lo_)];
         }
-        uint16_t wp[kWalk];
-#pragma unroll
-        for (int k = 0; k < kWalk; k++) wp[k] = bin16[o + pv[k]];
 #pragma unroll
         for (int k = 0; k < kWalk; k++) {
             const int v = base + k * kBlock;
             const bool valid = v < hi_;
             const bool moved = valid && pv[k] != v;             // s[v] != v  <=>  pred[v] != v (fixed points of a permutation)
-            f[k] = moved ? pv[k] : v; fb[k] = moved ? wp[k] : wv[k];
-            act[k] = moved && (wv[k] & kExecBit) && !(wp[k] & kExecBit);   // head of a run of executed steps
+            f[k] = moved ? pv[k] : v;
+            act[k] = moved && exec(v) && !exec(pv[k]);           // head of a run of executed steps
             u[k] = v; len[k] = 0;
         }
         bool any = false;
@@ -217,27 +228,27 @@ __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const P
             int nu[kWalk];
 #pragma unroll
             for (int k = 0; k < kWalk; k++) nu[k] = act[k] ? (int)s[o + u[k]] : 0;
-            uint16_t ne[kWalk];
-#pragma unroll
-            for (int k = 0; k < kWalk; k++) ne[k] = act[k] ? bin16[o + nu[k]] : (uint16_t)0;
             any = false;
 #pragma unroll
             for (int k = 0; k < kWalk; k++) {
                 if (act[k]) {
                     u[k] = nu[k]; len[k]++;
-                    if (!(ne[k] & kExecBit)) { f[k] = u[k]; fb[k] = ne[k]; act[k] = false; }
-                    else if (len[k] > max_walk) { atomicOr(&flags[pair], 1); f[k] = u[k]; fb[k] = ne[k]; act[k] = false; }
+                    if (!exec(nu[k])) { f[k] = u[k]; act[k] = false; }
+                    else if (len[k] > max_walk) { atomicOr(&flags[pair], 1); f[k] = u[k]; act[k] = false; }
                 }
                 any |= act[k];
             }
         }
+        uint16_t fb[kWalk];                                      // packed word of the row that lands here (its voxel id is what the histogram needs)
+#pragma unroll
+        for (int k = 0; k < kWalk; k++) { const int v = base + k * kBlock; fb[k] = (v < hi_) ? bin16[o + f[k]] : (uint16_t)0; }
 #pragma unroll
         for (int k = 0; k < kWalk; k++) {
             const int v = base + k * kBlock;
             if (v < hi_) {
                 src[o + v] = f[k];
                 const uint16_t b = fb[k] & kBinMask;
-                binpos[o + v] = fb[k] & (uint16_t)~kExecBit;       // voxel id + the row's near-edge flag
+                binpos[o + v] = fb[k];                              // voxel id + the row's near-edge flag
                 atomicAdd(&lh[b], 1u);
             }
         }
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_hist(const PairDesc* __restrict_
     const size_t o = d.off1;
     for (int v = lo_ + threadIdx.x; v < hi_; v += kBlock) {
         const uint16_t wd = bin16[o + src[o + v]];
-        binpos[o + v] = wd & (uint16_t)~kExecBit;
+        binpos[o + v] = wd;
         atomicAdd(&lh[wd & kBinMask], 1u);
     }
     __syncthreads();
@@ -793,12 +804,15 @@ __global__ __launch_bounds__(kBlock) void k_compact_slots(const SlotHot* __restr
 #define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
 // dynamic LDS of the keyframe kernels, bytes: the voxel-indexed ones grow with the grid (validated against the device in ensure_workspace)
+// k_scramble_src keeps the pair's exec bit table in LDS while histogram + table stay below this (0.75 M rows on a 75 x 24 grid)
+constexpr size_t kScrambleLdsMax = 100 * 1024;
 static size_t scan1_lds_bytes(const Workspace& w) { return (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell); }
 
 hipError_t init_keyframe_kernels() {
     const int cap = 160 * 1024 - 2048;        // static __shared__ of the kernels comes on top
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scramble_src), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scramble_src<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scramble_src<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_hist), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan1_spherical), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     return e;
@@ -841,9 +855,13 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
         ICET_LAUNCH_CHECK();
     } else {
         const int max_walk = 4096;
-        k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, w.bin16, w.flags, max_walk, np, chunks);
+        k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.pred, w.execbits, w.flags, max_walk, np, chunks);
         ICET_LAUNCH_CHECK();
-        k_scramble_src<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.valB, w.pred, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);
+        const size_t hist_bytes = (size_t)((c.V + 1) & ~1) * 4, bit_bytes = (size_t)((c.max_n1 + 63) / 64) * 8;
+        if (hist_bytes + bit_bytes <= kScrambleLdsMax)
+            k_scramble_src<true><<<grid, blk, hist_bytes + bit_bytes, st>>>(w.desc, w.valB, w.pred, w.execbits, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);
+        else
+            k_scramble_src<false><<<grid, blk, hist_bytes, st>>>(w.desc, w.valB, w.pred, w.execbits, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);
         ICET_LAUNCH_CHECK();
         k_scramble_serial<<<c.n_pairs, 64, 0, st>>>(w.desc, w.valB, w.pred /* reused as scratch */, w.src, w.flags);
         ICET_LAUNCH_CHECK();

@@ -309,4 +309,37 @@ __device__ inline void pinv3_sym(const float a[6], float rel_tol, float w[6]) {
     w[5] = (float)(i0 * V20 * V20 + i1 * V21 * V21 + i2 * V22 * V22);
 }
 
+// The same pseudo-inverse without the eigen-decomposition where that is provably equal: a projected noise matrix M Rn M^T is positive
+// semi-definite, exactly zero in the rows / columns of the axes L masks out, and otherwise well conditioned on ordinary voxels.  With
+// the masked axes filled by the largest diagonal entry (an eigenvalue between the block's smallest and largest, so the condition number is
+// the block's), cond_2 <= |A|_F |A^-1|_F <= 1e6 proves that no eigenvalue of the block falls below rel_tol (3 eps = 3.6e-7) of the largest:
+// the pseudo-inverse is then the inverse of the block (adjugate / determinant in double: at a condition number of 1e5 that keeps 11 digits)
+// and zero on the masked axes.  Anything else -- ill-conditioned, indefinite by rounding, NaN -- takes the Jacobi route above.
+// Why it matters: a double-precision Jacobi rotation is a chain of five dependent divisions / square roots (~1 us per sweep per lane), and
+// k_gn_solve is one block of dependent latencies per pair.
+__device__ inline void pinv3_sym_fast(const float a[6], float rel_tol, float w[6]) {
+    double a00 = a[0], a01 = a[1], a02 = a[2], a11 = a[3], a12 = a[4], a22 = a[5];
+    const bool z0 = a[0] == 0.f, z1 = a[3] == 0.f, z2 = a[5] == 0.f;
+    const double fill = fmax(fmax(a00, a11), a22);
+    if (z0) a00 = fill;
+    if (z1) a11 = fill;
+    if (z2) a22 = fill;
+    const bool clean = (!z0 || (a[1] == 0.f && a[2] == 0.f)) && (!z1 || (a[1] == 0.f && a[4] == 0.f)) && (!z2 || (a[2] == 0.f && a[4] == 0.f));
+    const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+    const double det = a00 * c00 + a01 * c01 + a02 * c02;
+    if (clean && fill > 0.0 && det > 0.0) {
+        const double rd = 1.0 / det;
+        const double i00 = c00 * rd, i01 = c01 * rd, i02 = c02 * rd, i11 = c11 * rd, i12 = c12 * rd, i22 = c22 * rd;
+        const double fa = a00 * a00 + a11 * a11 + a22 * a22 + 2.0 * (a01 * a01 + a02 * a02 + a12 * a12);
+        const double fi = i00 * i00 + i11 * i11 + i22 * i22 + 2.0 * (i01 * i01 + i02 * i02 + i12 * i12);
+        if (fa * fi <= 1e12) {
+            w[0] = z0 ? 0.f : (float)i00; w[1] = (z0 | z1) ? 0.f : (float)i01; w[2] = (z0 | z2) ? 0.f : (float)i02;
+            w[3] = z1 ? 0.f : (float)i11; w[4] = (z1 | z2) ? 0.f : (float)i12; w[5] = z2 ? 0.f : (float)i22;
+            return;
+        }
+    }
+    pinv3_sym<double>(a, rel_tol, w);
+}
+
 }  // namespace icetdev

@@ -107,16 +107,16 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
         // mean and covariance of the m surviving points from the sums about mu1 (src/icet.cpp:303-306), in DOUBLE: the scatter in
         // a voxel's thin direction (1e-6 m^2 for a single-ring line) is what is left of sum(d d^T) ~ m |mu2 - mu1|^2 (1e-2) after the
         // subtraction -- in float that cancellation cost percents of the voxel's weight (round 2, scripts/diag_voxel.py)
-        const double fmD = (double)m;
-        const double dbD[3] = {sdD[0] / fmD, sdD[1] / fmD, sdD[2] / fmD};
+        const double fmD = (double)m, rfmD = 1.0 / fmD;
+        const double dbD[3] = {sdD[0] * rfmD, sdD[1] * rfmD, sdD[2] * rfmD};
         const float db[3] = {(float)dbD[0], (float)dbD[1], (float)dbD[2]};   // mean - mu1
         const float mu2[3] = {(float)((double)f.mu[0] + dbD[0]), (float)((double)f.mu[1] + dbD[1]), (float)((double)f.mu[2] + dbD[2])};
-        const double denD = (double)(m - 1);
+        const double denD = 1.0 / (double)(m - 1);
         const float d2 = (float)(n2 - 1);
         float cov2[6];
-        cov2[0] = (float)((sddD[0] - fmD * dbD[0] * dbD[0]) / denD); cov2[1] = (float)((sddD[1] - fmD * dbD[0] * dbD[1]) / denD);
-        cov2[2] = (float)((sddD[2] - fmD * dbD[0] * dbD[2]) / denD); cov2[3] = (float)((sddD[3] - fmD * dbD[1] * dbD[1]) / denD);
-        cov2[4] = (float)((sddD[4] - fmD * dbD[1] * dbD[2]) / denD); cov2[5] = (float)((sddD[5] - fmD * dbD[2] * dbD[2]) / denD);
+        cov2[0] = (float)((sddD[0] - fmD * dbD[0] * dbD[0]) * denD); cov2[1] = (float)((sddD[1] - fmD * dbD[0] * dbD[1]) * denD);
+        cov2[2] = (float)((sddD[2] - fmD * dbD[0] * dbD[2]) * denD); cov2[3] = (float)((sddD[3] - fmD * dbD[1] * dbD[1]) * denD);
+        cov2[4] = (float)((sddD[4] - fmD * dbD[1] * dbD[2]) * denD); cov2[5] = (float)((sddD[5] - fmD * dbD[2] * dbD[2]) * denD);
         // R_noise = sigma1/(|idx1|-1) + cov2/(|idx2|-1)                         src/icet.cpp:315
         float Rn[6];
 #pragma unroll
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
         Rp[4] = MR[3] * M[6] + MR[4] * M[7] + MR[5] * M[8];
         Rp[5] = MR[6] * M[6] + MR[7] * M[7] + MR[8] * M[8];
         float W[6];
-        icetdev::pinv3_sym<double>(Rp, 3.0f * FLT_EPSILON, W);               // src/icet.cpp:320-321
+        icetdev::pinv3_sym_fast(Rp, 3.0f * FLT_EPSILON, W);                 // src/icet.cpp:320-321
         // H_z = M * [-I | Jx mu | Jy mu | Jz mu]                                  src/icet.cpp:324-329
         float Hj[9];      // columns 3..5 of H_j, row-major 3x3
 #pragma unroll

@@ -7,7 +7,7 @@
 // A device-wide library radix sort has to carry the pair id in the key (40 significant bits -> 5 digit passes over
 // 12 bytes per element, ~1.4 ms per 256 pairs) and still needs a separate inverse-permutation pass.  Per pair the
 // data is small (116 k keys), so this file does a sample sort instead:
-//   k_rs_splitters   one block per pair: radii of ~2 k sampled rows straight from the Cartesian scan, sorted in LDS
+//   k_rs_splitters   one wave per pair: radii of ~2 k sampled rows straight from the Cartesian scan, sorted in registers
 //                    (bitonic), <= 127 splitters published -- runs BEFORE k_scan1_spherical, which then
 //   [k_scan1_spherical, icet_kernels.hip] also finds every row's bucket (branch-free binary search of the splitters)
 //                    and its tile's bucket histogram, at no extra pass over r
@@ -54,36 +54,61 @@ __device__ __forceinline__ float radius_of(float x, float y, float z) {     // t
     return (r != r) ? 1000.0f : r;
 }
 
-__global__ __launch_bounds__(1024) void k_rs_splitters(const PairDesc* __restrict__ desc,
-                                                       uint32_t* __restrict__ splitters, int32_t* __restrict__ n_buckets) {
+// One WAVE per pair: the 2048 sampled keys live in registers, 32 per lane (element e = 32 * lane + r), and go through the bitonic
+// network without a single block barrier -- the 45 stages whose partner distance is below 32 are register-to-register, the other
+// 21 exchange through __shfl_xor.  Measured per 256-pair launch: 55 us, of which ~27 are the 6 k scattered sample loads of the
+// one wave (a diagnostic build that samples consecutive rows runs in 28) -- the 1024-thread, 66-barrier LDS version of round 2a
+// took 58, so the kernel is bound by the memory-level parallelism of one CU per pair, not by the sort.
+static_assert(kSamples == 2048, "k_rs_splitters holds 32 keys per lane of one wave");
+__global__ __launch_bounds__(64) void k_rs_splitters(const PairDesc* __restrict__ desc,
+                                                     uint32_t* __restrict__ splitters, int32_t* __restrict__ n_buckets) {
     __shared__ uint32_t sm[kSamples];
-    const int pair = blockIdx.x;
+    const int pair = blockIdx.x, lane = threadIdx.x;
     const PairDesc d = desc[pair];
     const int n = d.n1;
     const int stride = max(1, (n + kSamples - 1) / kSamples);
     const int ns = n > 0 ? (n + stride - 1) / stride : 0;
-    for (int j = threadIdx.x; j < kSamples; j += 1024)
-        sm[j] = (j < ns) ? __float_as_uint(radius_of(d.s1[(size_t)j * stride], d.s1[d.ld1 + (size_t)j * stride], d.s1[2 * (size_t)d.ld1 + (size_t)j * stride])) : 0xFFFFFFFFu;
-    __syncthreads();
+    uint32_t x[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        const int j = 32 * lane + r;
+        x[r] = (j < ns) ? __float_as_uint(radius_of(d.s1[(size_t)j * stride], d.s1[d.ld1 + (size_t)j * stride], d.s1[2 * (size_t)d.ld1 + (size_t)j * stride])) : 0xFFFFFFFFu;
+    }
+#pragma unroll
     for (int k = 2; k <= kSamples; k <<= 1) {                   // bitonic sort, ascending
+#pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < kSamples; t += 1024) {
-                const int p = t ^ j;
-                if (p > t) {
-                    const uint32_t a = sm[t], b = sm[p];
-                    const bool up = (t & k) == 0;
-                    if ((a > b) == up) { sm[t] = b; sm[p] = a; }
+            if (j >= 32) {                                      // partner in another lane, same register
+                const int lj = j >> 5;
+                const bool up = ((32 * lane) & k) == 0;
+                const bool low = (lane & lj) == 0;              // this lane holds the lower index of the pair
+#pragma unroll
+                for (int r = 0; r < 32; r++) {
+                    const uint32_t o = (uint32_t)__shfl_xor((int)x[r], lj);
+                    const uint32_t lo = min(x[r], o), hi = max(x[r], o);
+                    x[r] = (low == up) ? lo : hi;
+                }
+            } else {                                            // partner in this lane: registers r and r ^ j
+#pragma unroll
+                for (int r = 0; r < 32; r++) {
+                    if (r & j) continue;
+                    // direction bit: from the register index when k <= 16 (compile time), from the lane otherwise
+                    const bool up = (k < 32) ? ((r & k) == 0) : (((32 * lane) & k) == 0);
+                    const uint32_t lo = min(x[r], x[r ^ j]), hi = max(x[r], x[r ^ j]);
+                    x[r] = up ? lo : hi; x[r ^ j] = up ? hi : lo;
                 }
             }
-            __syncthreads();
         }
     }
+#pragma unroll
+    for (int r = 0; r < 32; r++) sm[32 * lane + r] = x[r];
+    __syncthreads();
     int nb = (n + kBucketTarget - 1) / kBucketTarget;
     nb = min(max(nb, 1), kMaxBuckets);
     if (n == 0) nb = 0;
     if (threadIdx.x == 0) n_buckets[pair] = nb;
     // splitters[j], j = 1..nb-1 ; slot 0 unused ; unused slots = +max so that the search never counts them
-    for (int j = threadIdx.x; j < kMaxBuckets; j += 1024)
+    for (int j = threadIdx.x; j < kMaxBuckets; j += 64)
         splitters[(size_t)pair * kMaxBuckets + j] = (j >= 1 && j < nb) ? sm[(int)(((long long)j * ns) / nb)] : 0xFFFFFFFFu;
 }
 
@@ -275,7 +300,7 @@ hipError_t init_rank_sort_kernels() {
 }
 
 hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
-    k_rs_splitters<<<c.n_pairs, 1024, 0, st>>>(w.desc, w.splitters, w.n_buckets);
+    k_rs_splitters<<<c.n_pairs, 64, 0, st>>>(w.desc, w.splitters, w.n_buckets);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

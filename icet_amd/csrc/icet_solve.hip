@@ -74,33 +74,52 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
     __shared__ float red[kBlock / 64][27];
     const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* X = X_all + pair * 6;
-    {
-        const uint32_t nov = over.count[pair];                          // block-uniform
-        if (nov) {
-            drain_near_overflow(over, pair, V, xf_all + pair * kXf, acc + (size_t)pair * V * kAccWords, nov);
-            __threadfence();                                            // this block reads the sums it has just added to
-            __syncthreads();
-            if (threadIdx.x == 0) over.count[pair] = 0u;
-        }
-    }
-    if (threadIdx.x < 27) J[threadIdx.x] = xf_all[pair * kXf + 16 + threadIdx.x];      // written by the previous update (write_xf)
-    __syncthreads();
+    // The block is a chain of dependent latencies, so everything it will need is requested up front: the two counts, the Jacobian
+    // table and -- speculatively, for slot threadIdx.x, before the number of slots is known (any slot < V is valid memory) -- the
+    // first round's accumulator and fit records, as 16-byte loads.
+    struct Rec { uint4 q[5]; };
+    static_assert(sizeof(Rec) == kAccWords * 4 && sizeof(Rec) == sizeof(SlotFit), "80-byte records");
+    const uint32_t nov = over.count[pair];                              // block-uniform
     const int ns = n_slots[pair];
+    const float jmine = (threadIdx.x < 27) ? xf_all[pair * kXf + 16 + threadIdx.x] : 0.f;      // written by the previous update (write_xf)
+    auto load_rec = [](const void* p) { Rec r; const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+        for (int k = 0; k < 5; k++) r.q[k] = q[k];
+        return r; };
+    Rec accR{}, fitR{};
+    if ((int)threadIdx.x < V) { accR = load_rec(acc + ((size_t)pair * V + threadIdx.x) * kAccWords); fitR = load_rec(fitS + (size_t)pair * V + threadIdx.x); }
+    if (nov) {
+        drain_near_overflow(over, pair, V, xf_all + pair * kXf, acc + (size_t)pair * V * kAccWords, nov);
+        __threadfence();                                                // this block reads the sums it has just added to
+        __syncthreads();
+        if (threadIdx.x == 0) over.count[pair] = 0u;
+        if ((int)threadIdx.x < V) accR = load_rec(acc + ((size_t)pair * V + threadIdx.x) * kAccWords);   // the speculative copy predates the drain
+    }
+    if (threadIdx.x < 27) J[threadIdx.x] = jmine;
+    __syncthreads();
     float S[27];
 #pragma unroll
     for (int k = 0; k < 27; k++) S[k] = 0.f;
     for (int s = threadIdx.x; s < ns; s += kBlock) {
         uint32_t* A = acc + ((size_t)pair * V + s) * kAccWords;
-        const uint32_t n2 = A[0], m = A[1];
-        const long long* AF = reinterpret_cast<const long long*>(A + 2);
+        if (s != (int)threadIdx.x) { accR = load_rec(A); fitR = load_rec(fitS + (size_t)pair * V + s); }       // later rounds
+        uint32_t aw[kAccWords];
+        __builtin_memcpy(aw, &accR, sizeof(Rec));
+        const uint32_t n2 = aw[0], m = aw[1];
+        long long AF[9];
+        __builtin_memcpy(AF, aw + 2, sizeof(AF));
         double sdD[3], sddD[6];
 #pragma unroll
         for (int k = 0; k < 3; k++) sdD[k] = (double)AF[k] * kFixInv;
 #pragma unroll
         for (int k = 0; k < 6; k++) sddD[k] = (double)AF[3 + k] * kFixInv;
+        {
+            uint4* z = reinterpret_cast<uint4*>(A);                  // ready for the next iteration
 #pragma unroll
-        for (int k = 0; k < kAccWords; k++) A[k] = 0u;           // ready for the next iteration
-        const SlotFit f = fitS[(size_t)pair * V + s];
+            for (int k = 0; k < 5; k++) z[k] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        SlotFit f;
+        __builtin_memcpy(&f, &fitR, sizeof(SlotFit));
         if (aux.n2_raw) aux.n2_raw[((size_t)pair * runlen + iter) * V + f.v] = (int)n2;
         if (aux.n2_in) aux.n2_in[((size_t)pair * runlen + iter) * V + f.v] = (int)m;
         if (!((int)n2 > n && (int)m > n)) continue;               // src/icet.cpp:290 (scan-2 half), :302
@@ -180,17 +199,23 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
 #pragma unroll
     for (int k = 0; k < 27; k++) { float t = wave_sum(S[k]); if (lane == 0) red[wave][k] = t; }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-
+    if (wave != 0) return;
+    // The 6 x 6 part runs on lane 0 of the first wave; its lanes assemble the input and write the results out (one lane doing the
+    // 27 four-way sums and ~100 scalar stores was a quarter of the tail).
+    __shared__ float stage[kXf + 48];                               // transform record | X, pred_stds, covariance
+    if (lane < 27) { float t = 0.f; for (int w = 0; w < kBlock / 64; w++) t += red[w][lane]; stage[lane] = t; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     float Hm[36], g[6];
     {
         int q = 0;
-        for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) {
-            float t = 0.f; for (int w = 0; w < kBlock / 64; w++) t += red[w][q];
-            Hm[a * 6 + b] = t; Hm[b * 6 + a] = t; q++;
-        }
-        for (int a = 0; a < 6; a++) { float t = 0.f; for (int w = 0; w < kBlock / 64; w++) t += red[w][21 + a]; g[a] = t; }
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) { const float t = stage[q]; Hm[a * 6 + b] = t; Hm[b * 6 + a] = t; q++; }
+#pragma unroll
+        for (int a = 0; a < 6; a++) g[a] = stage[21 + a];
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     // Normal case first: HTWH positive definite with condition number <= 1e6.  Then nothing is pruned
     // (checkCondition's cutoff, src/icet.cpp:453,469), every eigenvalue is above the pseudo-inverse's rank threshold
     // (eps * 6 < 1e-6), pinv(HTWH) is the inverse and dx = HTWH^-1 HTWdz -- a Cholesky factorisation gives both.
@@ -248,15 +273,25 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
             for (int a = 0; a < 6; a++) dx[a] += Q[a * 6 + k] * pj;
         }
     }
+    // (every lane of the wave ran the scalar algebra above on the same inputs -- a wave costs what a lane costs -- so the results are
+    // wave-uniform; lane 0 stages them and the lanes store them)
     float Xn[6];
-    for (int k = 0; k < 6; k++) { Xn[k] = X[k] + dx[k]; X[k] = Xn[k]; }
-    write_xf(xf_all + pair * kXf, Xn);
-    float* o = out + (size_t)pair * 48;
-    for (int k = 0; k < 6; k++) { o[k] = Xn[k]; o[6 + k] = ps[k]; }
-    for (int k = 0; k < 36; k++) o[12 + k] = cov[k];
-    if (aux.x_hist) for (int k = 0; k < 6; k++) aux.x_hist[((size_t)pair * runlen + iter) * 6 + k] = Xn[k];
-    if (aux.htwh) for (int k = 0; k < 36; k++) aux.htwh[((size_t)pair * runlen + iter) * 36 + k] = Hm[k];
-    if (aux.htwdz) for (int k = 0; k < 6; k++) aux.htwdz[((size_t)pair * runlen + iter) * 6 + k] = g[k];
+    for (int k = 0; k < 6; k++) Xn[k] = X[k] + dx[k];
+    if (lane == 0) {
+        write_xf(stage, Xn);
+        float* r = stage + kXf;
+        for (int k = 0; k < 6; k++) { r[k] = Xn[k]; r[6 + k] = ps[k]; }
+        for (int k = 0; k < 36; k++) r[12 + k] = cov[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (lane < kXf) xf_all[pair * kXf + lane] = stage[lane];
+    if (lane < 48) out[(size_t)pair * 48 + lane] = stage[kXf + lane];
+    if (lane < 6) X[lane] = stage[kXf + lane];
+    if (lane == 0) {
+        if (aux.x_hist) for (int k = 0; k < 6; k++) aux.x_hist[((size_t)pair * runlen + iter) * 6 + k] = Xn[k];
+        if (aux.htwh) for (int k = 0; k < 36; k++) aux.htwh[((size_t)pair * runlen + iter) * 36 + k] = Hm[k];
+        if (aux.htwdz) for (int k = 0; k < 6; k++) aux.htwdz[((size_t)pair * runlen + iter) * 6 + k] = g[k];
+    }
 }
 }  // namespace
 

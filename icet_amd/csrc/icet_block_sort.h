@@ -13,7 +13,6 @@ constexpr int kSortWaves = kSortBlock / 64;
 //                     | red[16] | buf0 keys[kCap] rows[kCap] | buf1 keys[kCap] rows[kCap]
 constexpr int kOffCnt = 0, kOffTot = kSortWaves * 256, kOffWsum = kOffTot + 256, kRadixWords = kOffWsum + 4;
 constexpr int kRedWords = 16;
-constexpr int kMaxCellRows = 24;      // a cell holding more rows than this sends the bucket to the radix sort (rank-in-cell is quadratic in it)
 
 // One stable 8-bit LSD pass.  kLds selects, at compile time, LDS arrays (indexed off the extern __shared__ base, so the
 // compiler emits ds_* instructions) or the global scratch pointers; `sel` says which of the two buffers is the input.

@@ -131,6 +131,8 @@ struct Tuning {
     int batch_parts = 0;          // parts a device batch is cut into (0 = automatic)
     int batch_stage = 4;          // keyframe stage after which the next part may start (0 = lock step)
     int rs_cap = 0;               // LDS rows of the per-bucket sort (0 = from the largest scan)
+    int rs_max_cell = 24;         // per-bucket counting sort: a cell above this many rows sends the bucket to the radix sort (0: always)
+    int exec_bits_lds = 1;        // k_scramble_src keeps the pair's swap-loop bit table in LDS (0: reads it from memory, the path of scans above ~0.75 M rows)
     double guard_scale = 1.0;     // multiplies the classification guard bands (tables are rebuilt)
     double lut_polar_quantile = 0.25;   // polar LUT cell width = this quantile of the polar bin widths
 };
@@ -153,6 +155,7 @@ struct LaunchCfg {
     int true_sort = 0;                // ICET_FLAG_TRUE_SORT (non-parity extension): src[] = the sorted order itself
     int force_exact = 0;              // diagnostic: route every point through the literal evaluation
     int rs_cap = 0;                   // Tuning::rs_cap
+    int rs_max_cell = 24, exec_bits_lds = 1;   // Tuning::rs_max_cell, ::exec_bits_lds
     int reject_moving = 0;            // ICET_FLAG_REJECT_MOVING (non-parity extension)
 };
 constexpr float kRejectMovingThresh = 0.3f;        // python/ICET_spherical.py:38  RM_thresh

@@ -858,7 +858,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
         k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.pred, w.execbits, w.flags, max_walk, np, chunks);
         ICET_LAUNCH_CHECK();
         const size_t hist_bytes = (size_t)((c.V + 1) & ~1) * 4, bit_bytes = (size_t)((c.max_n1 + 63) / 64) * 8;
-        if (hist_bytes + bit_bytes <= kScrambleLdsMax)
+        if (c.exec_bits_lds && hist_bytes + bit_bytes <= kScrambleLdsMax)
             k_scramble_src<true><<<grid, blk, hist_bytes + bit_bytes, st>>>(w.desc, w.valB, w.pred, w.execbits, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);
         else
             k_scramble_src<false><<<grid, blk, hist_bytes, st>>>(w.desc, w.valB, w.pred, w.execbits, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);

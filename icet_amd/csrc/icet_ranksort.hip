@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restric
 // Counting sort of the n (key, row) pairs in buf0 on the bucket's own key range; true = done (s / pred written), false = some cell
 // is too crowded (block-uniform; nothing written): the caller falls back to the radix sort.
 __device__ __forceinline__ bool counting_sort_lds(uint32_t* smem, int C, int logC, int kCap, int n, uint32_t kmin, uint32_t kmax,
-                                                  int lo, size_t off1, uint32_t* s_out, int32_t* pred_out) {
+                                                  int lo, size_t off1, uint32_t* s_out, int32_t* pred_out, int max_cell) {
     uint32_t* cells = smem; uint32_t* red = smem + C;
     const int offBuf = C + kRedWords;
     const uint32_t* K0 = smem + offBuf; const uint32_t* I0 = K0 + kCap;
@@ -201,7 +201,7 @@ __device__ __forceinline__ bool counting_sort_lds(uint32_t* smem, int C, int log
         big = 0u;
 #pragma unroll
         for (int w = 0; w < kSortWaves; w++) big = max(big, red[kSortWaves + w]);
-        if (big > (uint32_t)kMaxCellRows) { __syncthreads(); return false; }          // block-uniform
+        if (big > (uint32_t)max_cell) { __syncthreads(); return false; }          // block-uniform
         for (int j = 0; j < per; j++) { const uint32_t c = cells[c0 + j]; cells[c0 + j] = base; base += c; }
     }
     __syncthreads();
@@ -227,7 +227,7 @@ __device__ __forceinline__ bool counting_sort_lds(uint32_t* smem, int C, int log
 
 template <bool kLds>
 __device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int C, int logC, int kCap, const uint2* bkv, uint2* gA, uint2* gB,
-                                                 int n, int lo, size_t off1, uint32_t* s_out, int32_t* pred_out) {
+                                                 int n, int lo, size_t off1, uint32_t* s_out, int32_t* pred_out, int max_cell) {
     const size_t o = off1 + lo;
     const int offBuf = C + kRedWords;
     uint32_t vor = 0u, vand = 0xFFFFFFFFu, vmin = 0xFFFFFFFFu, vmax = 0u;
@@ -242,7 +242,7 @@ __device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int C, int logC
     const uint32_t differ = vor & ~vand;
     int sel = 0;
     if (differ != 0u) {
-        if constexpr (kLds) { if (counting_sort_lds(smem, C, logC, kCap, n, vmin, vmax, lo, off1, s_out, pred_out)) return; }
+        if constexpr (kLds) { if (counting_sort_lds(smem, C, logC, kCap, n, vmin, vmax, lo, off1, s_out, pred_out, max_cell)) return; }
         for (int pass = 0; pass < 4; pass++) {
             if (((differ >> (8 * pass)) & 255u) == 0u) continue;    // block-uniform
             radix_pass<kLds>(smem, offBuf, kCap, sel, sel ? gB : gA, sel ? gA : gB, n, 8 * pass, (differ >> (8 * pass)) & 255u);
@@ -259,7 +259,7 @@ __device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int C, int logC
 
 __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bucket_start,
                                                                const int32_t* __restrict__ n_buckets, uint2* __restrict__ bkv, uint2* __restrict__ alt,
-                                                               uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out, int kCap, int logC, int n_pairs) {
+                                                               uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out, int kCap, int logC, int max_cell, int n_pairs) {
     extern __shared__ uint32_t smem[];
     // all buckets of a pair on one XCD (decode_block): their scattered 4-byte writes of pred[] then complete whole cache lines in
     // ONE L2 instead of leaving partial lines in eight
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* _
     if (n <= 0) return;
     const size_t off1 = (size_t)desc[pair].off1;
     const int C = 1 << logC;
-    if (n <= kCap) bucket_sort_body<true>(smem, C, logC, kCap, bkv, nullptr, nullptr, n, lo, off1, s_out, pred_out);
-    else bucket_sort_body<false>(smem, C, logC, kCap, bkv, bkv + off1 + lo, alt + off1 + lo, n, lo, off1, s_out, pred_out);
+    if (n <= kCap) bucket_sort_body<true>(smem, C, logC, kCap, bkv, nullptr, nullptr, n, lo, off1, s_out, pred_out, max_cell);
+    else bucket_sort_body<false>(smem, C, logC, kCap, bkv, bkv + off1 + lo, alt + off1 + lo, n, lo, off1, s_out, pred_out, max_cell);
 }
 
 }  // namespace
@@ -316,7 +316,7 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
     ICET_LAUNCH_CHECK();
     const int cap = rank_sort_cap(c.max_n1, c.rs_cap);
     k_rs_bucket_sort<<<dim3(groups * kMaxBuckets), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, reinterpret_cast<uint2*>(w.key64A),
-                                                                                             reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), np);
+                                                                                             reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -152,7 +152,8 @@ icet_status icet_debug_fetch(icet_ctx* ctx, int32_t what, void* out, int64_t cou
 
 /* Launch-shape and diagnostic knobs of ONE context (the library never reads the environment).  Every value
  * yields the same result bits; defaults are the measured optima.  Names: "lds_slots", "acc_pts",
- * "acc_blocks", "kf_pts", "rs_cap", "batch_parts" (0 = automatic), "batch_stage" (0..4), "force_exact"
+ * "acc_blocks", "kf_pts", "rs_cap", "rs_max_cell" (0: per-bucket radix sort instead of the counting sort),
+ * "exec_bits_lds" (0: swap-loop bit table read from memory), "batch_parts" (0 = automatic), "batch_stage" (0..4), "force_exact"
  * (every scan-2 point through the literal classification), "library_sort" (rocPRIM radix sort instead of
  * the hand-written rank sort), "guard_scale" (>= 1), "lut_polar_quantile" (0..1).  Unknown name or value
  * out of range: ICET_ERR_BAD_ARG. */

@@ -153,6 +153,30 @@ def test_highres_config5_full_size(gpu_ctx):
     assert np.abs(r["X"][:3] - xt[:3]).max() < 0.05
 
 
+def test_million_row_scans(gpu_ctx):
+    """Past every size at which a launch shape switches: ~1 M rows per scan (128 rings x 8192 steps) -- the per-bucket sort at its
+    largest LDS capacity (one block per CU) with buckets that overflow to the global-scratch radix sort, the swap-loop bit table
+    too large for LDS (read from memory), accumulate blocks at 144 KB of LDS.  Same bar: sort + swap loop and the keyframe table
+    bit-exact against the unmodified oracle, X within tolerance."""
+    from icet_amd import lidar_sim as ls
+    from oracle import pyoracle as po
+    s1, s2, xt = ls.make_pair(9100, 9101, motion=(0.12, 0.02, 0.005, 0.002, -0.001, 0.004), rings=128, steps=8192)
+    a, b = s1.T.numpy(), s2.T.numpy()
+    assert a.shape[0] > 900000
+    ref = po.solve(a, b, runlen=4, bins_phi=24, bins_theta=75, trace=True)
+    r = gpu_ctx.solve(a, b, 4, np.zeros(6), 24, 75, aux=True)
+    t, ax = ref["trace"], r["aux"]
+    f = t["has_fit"] == 1
+    assert f.sum() > 100
+    assert np.array_equal(ax["n1_raw"], t["n1_raw"]) and np.array_equal(ax["cluster_bounds"], t["bounds"]) and np.array_equal(ax["has_fit"], t["has_fit"])
+    for name_g, name_o in (("mu1", "mu1"), ("sigma1", "sigma1"), ("evecs1", "evecs1"), ("l_diag", "Ldiag")):
+        assert np.array_equal(ax[name_g][f].view(np.uint32), t[name_o][f].view(np.uint32)), name_g
+    n = a.shape[0]
+    assert np.array_equal(gpu_ctx.debug_fetch("src", n), po.scramble(po.c2s(a)[:, 0]))
+    assert gpu_ctx.debug_fetch("flags", 1)[0] == 0
+    _check_solution(r, ref)
+
+
 def test_other_parameters(gpu_ctx, frames):
     from oracle import pyoracle as po
     a, b = frames

@@ -20,6 +20,7 @@ _STATUS_NAMES = {0: "ICET_OK", 1: "ICET_ERR_BAD_ARG", 2: "ICET_ERR_NO_DEVICE", 3
 FLAG_TIMING = 1
 FLAG_TRUE_SORT = 2      # non-parity extension, see include/icet_hip.h
 FLAG_REJECT_MOVING = 4  # non-parity extension (moving-object rejection of the Python variant), see include/icet_hip.h
+FLAG_HALF_GAP_BOUNDS = 8  # non-parity extension (half-gap cluster buffers of the Python variant; implies TRUE_SORT), see include/icet_hip.h
 
 # every symbol include/icet_hip.h, include/icet_nodes.h and include/icet_io.h declare
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_batch",

@@ -262,7 +262,8 @@ LaunchCfg make_cfg(icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     LaunchCfg cfg{};
     cfg.T = p->bins_theta; cfg.P = p->bins_phi; cfg.V = cfg.T * cfg.P; cfg.n = p->n; cfg.runlen = p->runlen;
     cfg.thresh = p->thresh; cfg.buff = p->buff; cfg.n_pairs = n_pairs;
-    cfg.true_sort = (p->flags & ICET_FLAG_TRUE_SORT) ? 1 : 0;
+    cfg.half_gap = (p->flags & ICET_FLAG_HALF_GAP_BOUNDS) ? 1 : 0;
+    cfg.true_sort = (p->flags & (ICET_FLAG_TRUE_SORT | ICET_FLAG_HALF_GAP_BOUNDS)) ? 1 : 0;
     cfg.reject_moving = (p->flags & ICET_FLAG_REJECT_MOVING) ? 1 : 0;
     cfg.lds_slots = c->tune.lds_slots; cfg.acc_min_pts_per_thread = c->tune.acc_pts; cfg.acc_target_blocks = c->tune.acc_blocks;
     cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds;

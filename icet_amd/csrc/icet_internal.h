@@ -157,6 +157,7 @@ struct LaunchCfg {
     int rs_cap = 0;                   // Tuning::rs_cap
     int rs_max_cell = 24, exec_bits_lds = 1;   // Tuning::rs_max_cell, ::exec_bits_lds
     int reject_moving = 0;            // ICET_FLAG_REJECT_MOVING (non-parity extension)
+    int half_gap = 0;                 // ICET_FLAG_HALF_GAP_BOUNDS (non-parity extension; sets true_sort as well)
 };
 constexpr float kRejectMovingThresh = 0.3f;        // python/ICET_spherical.py:38  RM_thresh
 constexpr int kRejectMovingStartIter = 4;          // python/ICET_spherical.py:36  start_RM_iter

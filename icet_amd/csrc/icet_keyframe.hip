@@ -452,7 +452,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_fit_cluster(const PairDesc* __res
                                                       const uint32_t* __restrict__ sorted_row, const float* __restrict__ r1,
                                                       uint32_t* __restrict__ cand, float* __restrict__ cand_r, FitItem* __restrict__ items, uint32_t* __restrict__ n_items,
                                                       const int32_t* __restrict__ live, const int32_t* __restrict__ n_live,
-                                                      FitMid* __restrict__ midD, int T, int P, int n, float thresh, float buff, int n_pairs, int chunks) {
+                                                      FitMid* __restrict__ midD, int T, int P, int n, float thresh, float buff, int n_pairs, int chunks, int half_gap) {
     __shared__ float stage[kBlock / 64][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int V = T * P;
@@ -491,6 +491,10 @@ __global__ __launch_bounds__(kBlock, 8) void k_fit_cluster(const PairDesc* __res
         // ---- findCluster (src/icet.cpp:557-607): first run of >= n consecutive points whose
         // successive |dr| <= thresh, walking the bin in stored (scrambled) order.
         int run_start = 0; float front = 0.f; float carry_prev = 0.f; bool found = false;
+        float front_before = 0.f;                                     // the point walked just before `front` (extension ICET_FLAG_HALF_GAP_BOUNDS)
+        // the half-gap rule of the Python variant (python/utils.py:92-119): a bound reaches half way to the nearest point outside the
+        // cluster, at most buff; buff where there is no such point
+        auto in_buff = [&](float fr, int start, float before) { return (half_gap && start > 0) ? fminf(buff, 0.5f * fabsf(fr - before)) : buff; };
         // A break is a point that does not continue the current run; a run is reported at the first break that closes
         // >= n points.  In the scrambled order most points are breaks, so instead of visiting the breaks of a 64-point
         // chunk one after another, every break lane looks up the break before it with a prefix-max scan and the first
@@ -512,10 +516,13 @@ __global__ __launch_bounds__(kBlock, 8) void k_fit_cluster(const PairDesc* __res
                 const int rs0 = __shfl(prevb, b);                    // start of the run that this break closes
                 const float back = (b > 0) ? __shfl(r, b - 1) : carry_prev;
                 const float fr = (rs0 >= c0) ? __shfl(r, rs0 - c0) : front;
-                inner = fr - buff; outer = back + buff; found = true;
+                const float before = (rs0 > c0) ? __shfl(r, max(rs0 - 1 - c0, 0)) : (rs0 == c0 ? carry_prev : front_before);
+                const float after = __shfl(r, b);                    // the point that ended the run
+                inner = fr - in_buff(fr, rs0, before);
+                outer = back + (half_gap ? fminf(buff, 0.5f * fabsf(after - back)) : buff); found = true;
             } else {
                 const int last = __shfl(pm, 63);                     // last break of this chunk, if any
-                if (last >= 0) { run_start = last; front = __shfl(r, last - c0); }
+                if (last >= 0) { run_start = last; front = __shfl(r, last - c0); front_before = (last > c0) ? __shfl(r, max(last - 1 - c0, 0)) : carry_prev; }
             }
             carry_prev = __shfl(r, 63);
         };
@@ -523,7 +530,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_fit_cluster(const PairDesc* __res
         for (int k = 0; k < kCache; k++) if (64 * k < cnt && !found) walk(64 * k, pr[k]);
         for (int c0 = 64 * kCache; c0 < cnt && !found; c0 += 64) walk(c0, (c0 + lane < cnt) ? RS(c0 + lane) : 0.f);
         if (!found && cnt - run_start >= n) {
-            if (front != 0.f) { const float back = RS(cnt - 1); inner = front - buff; outer = back + buff; }
+            if (front != 0.f) { const float back = RS(cnt - 1); inner = front - in_buff(front, run_start, front_before); outer = back + buff; }
             else { inner = 0.f; outer = 0.f; }
         }
         // ---- the radial half of filterPointsInsideCluster (src/icet.cpp:609-652): rows with r in [inner, outer], compacted.  Nothing
@@ -881,7 +888,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     // enough blocks to fill the chip whatever the batch size
     const int fit_chunks = std::max(1, std::min((c.V + kBlock / 64 - 1) / (kBlock / 64), (ICET_FIT_BLOCKS + c.n_pairs - 1) / c.n_pairs));
     k_fit_cluster<<<dim3(groups * fit_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.valA, w.r1, w.keyA, reinterpret_cast<float*>(w.keyB), items, w.fit_n_items,
-                                                             w.live_bins, w.n_live, w.midD, c.T, c.P, c.n, c.thresh, c.buff, np, fit_chunks);
+                                                             w.live_bins, w.n_live, w.midD, c.T, c.P, c.n, c.thresh, c.buff, np, fit_chunks, c.half_gap);
     ICET_LAUNCH_CHECK();
     {
         const int rt_chunks = std::max(1, std::min(64, (ICET_RT_BLOCKS + c.n_pairs - 1) / c.n_pairs));

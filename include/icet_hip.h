@@ -49,11 +49,17 @@ enum { ICET_FLAG_NONE = 0,
                                   that findCluster sees most bins in a shuffled order and only ~1/4 of the populated bins get a
                                   Gaussian.  Results then differ from the reference by design (more voxels, better conditioned);
                                   the oracle has the same switch so that the extension is still checked against a CPU twin. */
-       ICET_FLAG_REJECT_MOVING = 4 /* NON-PARITY EXTENSION: moving-object rejection as in the reference's Python
+       ICET_FLAG_REJECT_MOVING = 4, /* NON-PARITY EXTENSION: moving-object rejection as in the reference's Python
                                   variant (python/ICET_spherical.py:175-250, the hard cutoff that is live there): from the 5th iteration on
                                   (start_RM_iter = 4), a voxel whose compact residual L U^T (mu2 - mu1) exceeds RM_thresh = 0.3 m in any
                                   kept axis is left out of that iteration's H^T W H and H^T W dz.  The C++ reference has nothing like it, so
-                                  results differ from it by design; the oracle has the same switch (ICET_ORACLE_REJECT_MOVING). */ };
+                                  results differ from it by design; the oracle has the same switch (ICET_ORACLE_REJECT_MOVING). */
+       ICET_FLAG_HALF_GAP_BOUNDS = 8 /* NON-PARITY EXTENSION: the cluster buffers of the reference's Python variant
+                                  (python/utils.py:92-119, "as described in spherical paper"): the radial bounds of a voxel's cluster reach
+                                  half way to the nearest point outside it, at most `buff`, instead of `buff` on either side (a neighbour
+                                  that exists is more than `thresh` away, so this only tightens bounds whose neighbour lies within 2 buff).
+                                  Needs the voxel's rows in ascending range, so it implies ICET_FLAG_TRUE_SORT.  Oracle twin:
+                                  ICET_ORACLE_HALF_GAP. */ };
 
 /* A scan that already lives in device memory (HBM) on the context's device. */
 typedef struct icet_dev_scan {

@@ -191,26 +191,32 @@ struct VoxelFit {            // what the reference keeps in sigma1/mu1/U/L std::
 struct Contribution { Mat HTWH{6, 6}; Mat HTWdz{6, 1}; int n_in = 0; float mu2[3] = {0, 0, 0}; Mat sigma2{3, 3}; bool used = false; };
 
 // ---------------------------------------------------------------- icet.cpp:557-607
-static std::pair<float, float> findCluster(const Sph& s, const int* idx, int numPoints, int n, float thresh, float buff) {
+// half_gap (NON-PARITY EXTENSION, ICET_ORACLE_HALF_GAP; the rule of python/utils.py:92-119 as the paper states it): the bounds reach half
+// way to the nearest point outside the cluster -- the point walked just before its first one, the point that ended it -- at most buff;
+// buff where there is no such point.
+static std::pair<float, float> findCluster(const Sph& s, const int* idx, int numPoints, int n, float thresh, float buff, bool half_gap = false) {
     float innerDistance = 0.0f, outerDistance = 0.0f;
     long count = 0; float front = 0.f, back = 0.f;      // localPoints.size(), .front()(0), .back()(0)
+    bool has_before = false; float before = 0.f;         // the point walked just before `front`
+    auto in_buff = [&]() { return (half_gap && has_before) ? std::min(buff, 0.5f * std::abs(front - before)) : buff; };
     for (int i = 0; i < numPoints; i++) {
         float pr = s.r[idx[i]];
         if (count != 0 && std::abs(back - pr) <= thresh) {
             back = pr; count++;
         } else {
             if (count >= n) {
-                innerDistance = front - buff;
-                outerDistance = back + buff;
+                innerDistance = front - in_buff();
+                outerDistance = back + (half_gap ? std::min(buff, 0.5f * std::abs(pr - back)) : buff);
                 return {innerDistance, outerDistance};
             } else {
+                has_before = i > 0; if (i > 0) before = s.r[idx[i - 1]];
                 count = 1; front = pr; back = pr;
             }
         }
     }
     if (count >= n) {
         if (count != 0 && front != 0) {
-            innerDistance = front - buff;
+            innerDistance = front - in_buff();
             outerDistance = back + buff;
             return {innerDistance, outerDistance};
         } else {
@@ -308,7 +314,7 @@ struct Solver {
     void fitCells1(const int* indices, int cnt, int theta, int phi) {
         const int v = T * phi + theta;
         if ((size_t)cnt >= (size_t)n) {
-            auto cd = findCluster(sph1, indices, cnt, n, prm.thresh, prm.buff);
+            auto cd = findCluster(sph1, indices, cnt, n, prm.thresh, prm.buff, (prm.mode & ICET_ORACLE_HALF_GAP) != 0);
             float innerDistance = cd.first, outerDistance = cd.second;
             boundsRow(theta, phi, innerDistance, outerDistance);
             const float* lims = &clusterBounds[6 * v];
@@ -371,7 +377,7 @@ struct Solver {
         const int N = (int)p1x.size();
         sph1.resize(N);
         for (int i = 0; i < N; i++) c2s_one(p1x[i], p1y[i], p1z[i], sph1.r[i], sph1.th[i], sph1.ph[i], libmf);
-        sortAndScramble(sph1, (prm.mode & ICET_ORACLE_TRUE_SORT) != 0);
+        sortAndScramble(sph1, (prm.mode & (ICET_ORACLE_TRUE_SORT | ICET_ORACLE_HALF_GAP)) != 0);
         binPoints(sph1, bin1_start, bin1_idx);
         for (int phi = 0; phi < P; phi++)
             for (int theta = 0; theta < T; theta++) {
@@ -386,7 +392,7 @@ struct Solver {
         sph2.resize(N);
         for (int i = 0; i < N; i++) c2s_one(p2x[i], p2y[i], p2z[i], sph2.r[i], sph2.th[i], sph2.ph[i], libmf);
         if (skip_rt2) { rawx = p2x; rawy = p2y; rawz = p2z; }          // the rows as given, carried through the same scramble
-        sortAndScramble(sph2, (prm.mode & ICET_ORACLE_TRUE_SORT) != 0, skip_rt2 ? &rawx : nullptr, &rawy, &rawz);
+        sortAndScramble(sph2, (prm.mode & (ICET_ORACLE_TRUE_SORT | ICET_ORACLE_HALF_GAP)) != 0, skip_rt2 ? &rawx : nullptr, &rawy, &rawz);
         ogx.resize(N); ogy.resize(N); ogz.resize(N);
         for (int i = 0; i < N; i++) s2c_one(sph2.r[i], sph2.th[i], sph2.ph[i], ogx[i], ogy[i], ogz[i], libmf);
     }

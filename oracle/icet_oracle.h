@@ -17,9 +17,11 @@ enum { ICET_ORACLE_SERIAL = 0,   /* live path: serial voxel loop, src/icet.cpp:3
        ICET_ORACLE_SKIP_RT2 = 8,    /* EXPERIMENT (quantifies the device's one documented deviation): scan 2 is never round-tripped through
                                        spherical coordinates (src/icet.cpp:275, 303) */
        ICET_ORACLE_RT2_THIN = 16, /* EXPERIMENT: as SKIP_RT2, but voxels whose scan-1 Gaussian is thin (lambda_min < 1e-5 m^2) keep the round trips */
-       ICET_ORACLE_REJECT_MOVING = 32 }; /* OR-ed in: non-parity extension, twin of ICET_FLAG_REJECT_MOVING: from iteration 4 on a voxel whose
+       ICET_ORACLE_REJECT_MOVING = 32, /* OR-ed in: non-parity extension, twin of ICET_FLAG_REJECT_MOVING: from iteration 4 on a voxel whose
                                        compact residual L U^T (mu2 - mu1) exceeds 0.3 m in a kept axis is skipped
                                        (python/ICET_spherical.py:175-250, RM_thresh :38, start_RM_iter :36) */
+       ICET_ORACLE_HALF_GAP = 64 };  /* OR-ed in: non-parity extension, twin of ICET_FLAG_HALF_GAP_BOUNDS (implies TRUE_SORT): cluster bounds reach
+                                       half way to the nearest point outside the cluster, at most buff (python/utils.py:92-119) */
 
 typedef struct icet_oracle_params {
     int32_t runlen;      /* include/icet.h:38  */

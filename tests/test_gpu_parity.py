@@ -687,3 +687,26 @@ def test_true_sort_extension_matches_its_oracle_twin(gpu_ctx, frames, sample_pc)
         _check_solution(dict(X=g["X"], pred_stds=g["pred_stds"], cov=g["cov"]), o)
         plain = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
         assert g["aux"]["has_fit"].sum() > 2 * plain["aux"]["has_fit"].sum()                   # and it is a different answer by design
+
+
+def test_half_gap_bounds_extension_matches_its_oracle_twin(gpu_ctx, frames, sample_pc):
+    """ICET_FLAG_HALF_GAP_BOUNDS (the cluster buffers of the Python variant, python/utils.py:92-119) is a labelled NON-PARITY
+    extension on top of the really-sorted rows.  Held to its CPU twin (ICET_ORACLE_HALF_GAP): cluster bounds and the whole keyframe table
+    bit-exact, X within the usual tolerance; and it does what it says -- no bound is wider than with the fixed buffer, some are tighter."""
+    from oracle import pyoracle as po
+    from icet_amd import api
+    for a, b in (frames, sample_pc):
+        g = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True, flags=api.FLAG_HALF_GAP_BOUNDS)
+        o = po.solve(a, b, trace=True, mode=po.HALF_GAP)
+        assert np.array_equal(g["aux"]["n1_raw"], o["trace"]["n1_raw"]) and np.array_equal(g["aux"]["cluster_bounds"], o["trace"]["bounds"])
+        assert np.array_equal(g["aux"]["has_fit"], o["trace"]["has_fit"])
+        f = o["trace"]["has_fit"] == 1
+        for name_g, name_o in (("mu1", "mu1"), ("sigma1", "sigma1"), ("evecs1", "evecs1"), ("l_diag", "Ldiag")):
+            assert np.array_equal(g["aux"][name_g][f].view(np.uint32), o["trace"][name_o][f].view(np.uint32)), name_g
+        _check_solution(dict(X=g["X"], pred_stds=g["pred_stds"], cov=g["cov"]), o)
+        srt = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True, flags=api.FLAG_TRUE_SORT)       # same clusters, fixed buffers
+        bh, bs = g["aux"]["cluster_bounds"], srt["aux"]["cluster_bounds"]
+        has = bs[:, 5] > 0
+        assert np.array_equal(bh[:, 5] > 0, has)
+        assert (bh[has, 4] >= bs[has, 4]).all() and (bh[has, 5] <= bs[has, 5]).all()
+        assert (bh[has, 4] > bs[has, 4]).any() or (bh[has, 5] < bs[has, 5]).any()

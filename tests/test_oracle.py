@@ -311,3 +311,36 @@ def test_reject_moving_extension_of_the_oracle():
     c, d, _ = ls.make_pair()
     st_p = po.solve(c.T.numpy(), d.T.numpy(), runlen=9); st_r = po.solve(c.T.numpy(), d.T.numpy(), runlen=9, mode=po.REJECT_MOVING)
     assert np.array_equal(st_p["X"], st_r["X"])
+
+
+def test_half_gap_bounds_extension_of_the_oracle(frames):
+    """ICET_ORACLE_HALF_GAP (twin of ICET_FLAG_HALF_GAP_BOUNDS; python/utils.py:92-119): on really sorted rows the cluster
+    bounds reach half way to the nearest point outside the cluster, at most buff -- checked against a direct NumPy evaluation of the rule
+    on every voxel of a real scan."""
+    from oracle import pyoracle as po
+    a, b = frames
+    n, thresh, buff = 25, 0.1, 0.1
+    o = po.solve(a, b, runlen=1, trace=True, mode=po.HALF_GAP)
+    sph = po.c2s(a)
+    vox = np.asarray(po.voxel_of(sph)).reshape(-1)
+    bounds = o["trace"]["bounds"]
+    checked = 0
+    for v in range(75 * 24):
+        r = np.sort(sph[vox == v, 0], kind="stable")
+        if r.size < n:
+            continue
+        # first run of >= n consecutive points whose successive differences are <= thresh (src/icet.cpp:557-607 on sorted rows)
+        brk = np.flatnonzero(np.abs(np.diff(r)) > np.float32(thresh)) + 1
+        starts = np.concatenate(([0], brk)); ends = np.concatenate((brk, [r.size]))
+        exp = (0.0, 0.0)
+        for s0, e0 in zip(starts, ends):
+            if e0 - s0 >= n:
+                if e0 == r.size and r[s0] == 0:
+                    break
+                inb = min(np.float32(buff), np.float32(0.5) * np.abs(r[s0] - r[s0 - 1])) if s0 > 0 else np.float32(buff)
+                outb = min(np.float32(buff), np.float32(0.5) * np.abs(r[e0] - r[e0 - 1])) if e0 < r.size else np.float32(buff)
+                exp = (np.float32(r[s0] - inb), np.float32(r[e0 - 1] + outb))
+                break
+        assert bounds[v, 4] == np.float32(exp[0]) and bounds[v, 5] == np.float32(exp[1]), (v, bounds[v], exp)
+        checked += exp[1] > 0
+    assert checked > 50

@@ -170,12 +170,15 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restric
 // ---- per-bucket sort ------------------------------------------------------------------------------------------------
 // LDS layout (words): cells[C]  (the radix fallback keeps its counters, kRadixWords words, in the same place) | red[kRedWords]
 //                     | buf0 keys[kCap] rows[kCap] | buf1 keys[kCap] rows[kCap]
+// words reserved for the cells: the radix fallback keeps its counters (kRadixWords) in the same place
+__host__ __device__ constexpr int cell_region(int C) { return C > kRadixWords ? C : (kRadixWords + 3) / 4 * 4; }
+
 // Counting sort of the n (key, row) pairs in buf0 on the bucket's own key range; true = done (s / pred written), false = some cell
 // is too crowded (block-uniform; nothing written): the caller falls back to the radix sort.
 __device__ __forceinline__ bool counting_sort_lds(uint32_t* smem, int C, int logC, int kCap, int n, uint32_t kmin, uint32_t kmax,
                                                   int lo, size_t off1, uint32_t* s_out, int32_t* pred_out, int max_cell) {
-    uint32_t* cells = smem; uint32_t* red = smem + C;
-    const int offBuf = C + kRedWords;
+    uint32_t* cells = smem; uint32_t* red = smem + cell_region(C);
+    const int offBuf = cell_region(C) + kRedWords;
     const uint32_t* K0 = smem + offBuf; const uint32_t* I0 = K0 + kCap;
     uint32_t* K1 = smem + offBuf + 2 * kCap; uint32_t* I1 = K1 + kCap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -229,14 +232,14 @@ template <bool kLds>
 __device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int C, int logC, int kCap, const uint2* bkv, uint2* gA, uint2* gB,
                                                  int n, int lo, size_t off1, uint32_t* s_out, int32_t* pred_out, int max_cell) {
     const size_t o = off1 + lo;
-    const int offBuf = C + kRedWords;
+    const int offBuf = cell_region(C) + kRedWords;
     uint32_t vor = 0u, vand = 0xFFFFFFFFu, vmin = 0xFFFFFFFFu, vmax = 0u;
     for (int i = threadIdx.x; i < n; i += kSortBlock) {
         const uint2 kv = bkv[o + i];
         if constexpr (kLds) { smem[offBuf + i] = kv.x; smem[offBuf + kCap + i] = kv.y; }
         vor |= kv.x; vand &= kv.x; vmin = min(vmin, kv.x); vmax = max(vmax, kv.x);
     }
-    block_key_stats(smem + C, vor, vand, vmin, vmax);             // (its barriers also publish buf0)
+    block_key_stats(smem + cell_region(C), vor, vand, vmin, vmax);             // (its barriers also publish buf0)
     // a digit position where every key agrees needs no radix pass; a bucket of identical keys -- the zero rows of a real scan -- is
     // already in order (the multi-split is stable)
     const uint32_t differ = vor & ~vand;
@@ -287,11 +290,15 @@ static int rank_sort_cap(int max_n, int forced) {
     if (forced > 0) cap = forced < 64 ? 64 : (forced > kCapMax ? kCapMax : forced);     // Tuning::rs_cap (tests: force the global-scratch path)
     return cap;
 }
-// cells of the counting sort: about two per LDS row (a bucket then fills them to 0.2 - 0.9 rows per cell), 2048 (which also
-// holds the radix fallback's counters) to 4096
-static int rank_sort_log_cells(int cap) { return cap <= 1280 ? 11 : 12; }
-static size_t rank_sort_lds_bytes(int cap) { return (size_t)((1 << rank_sort_log_cells(cap)) + kRedWords + 4 * cap) * 4; }
-static_assert(kRadixWords <= 2048, "the radix fallback's counters live in the cell array");
+// cells of the counting sort: 1024 for the ~900-row buckets of a 64-channel scan (1 - 2 rows per cell), 4096 for large ones.  Measured
+// on 256 pairs: 2048 cells 320 us, 1024 cells 279 us (half the scan work and 26 instead of 29 KB: six blocks per CU), 512 cells 291 us;
+// 1024 cells with a u16 order array instead of the second (key, row) buffer (18 KB, eight blocks per CU) 288 us -- the extra
+// indirection in the rank loop costs more than the occupancy brings.
+#ifndef ICET_RS_LOGC_SMALL
+#define ICET_RS_LOGC_SMALL 10
+#endif
+static int rank_sort_log_cells(int cap) { return cap <= 1280 ? ICET_RS_LOGC_SMALL : 12; }
+static size_t rank_sort_lds_bytes(int cap) { return (size_t)(cell_region(1 << rank_sort_log_cells(cap)) + kRedWords + 4 * cap) * 4; }
 
 // Outputs: w.valB = s (row with rank i), w.pred = rank of every row.  Scratch: w.key64A (bucket-grouped (key, row) pairs),
 // w.key64B (second buffer of an overflow bucket), w.bkt, w.counts / w.tile_base, w.splitters, w.n_buckets, w.bucket_start.

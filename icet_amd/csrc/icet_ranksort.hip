@@ -60,20 +60,22 @@ __device__ __forceinline__ float radius_of(float x, float y, float z) {     // t
 // one wave (a diagnostic build that samples consecutive rows runs in 28) -- the 1024-thread, 66-barrier LDS version of round 2a
 // took 58, so the kernel is bound by the memory-level parallelism of one CU per pair, not by the sort.
 static_assert(kSamples == 2048, "k_rs_splitters holds 32 keys per lane of one wave");
-__global__ __launch_bounds__(64) void k_rs_splitters(const PairDesc* __restrict__ desc,
+constexpr int kSplitLoadThreads = 512;      // the sample is LOADED by 8 waves (6 k scattered loads: the memory-level parallelism of one wave was the bound), sorted by one
+__global__ __launch_bounds__(kSplitLoadThreads) void k_rs_splitters(const PairDesc* __restrict__ desc,
                                                      uint32_t* __restrict__ splitters, int32_t* __restrict__ n_buckets) {
     __shared__ uint32_t sm[kSamples];
-    const int pair = blockIdx.x, lane = threadIdx.x;
+    const int pair = blockIdx.x, lane = threadIdx.x & 63;
     const PairDesc d = desc[pair];
     const int n = d.n1;
     const int stride = max(1, (n + kSamples - 1) / kSamples);
     const int ns = n > 0 ? (n + stride - 1) / stride : 0;
+    for (int j = threadIdx.x; j < kSamples; j += kSplitLoadThreads)
+        sm[j] = (j < ns) ? __float_as_uint(radius_of(d.s1[(size_t)j * stride], d.s1[d.ld1 + (size_t)j * stride], d.s1[2 * (size_t)d.ld1 + (size_t)j * stride])) : 0xFFFFFFFFu;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
     uint32_t x[32];
 #pragma unroll
-    for (int r = 0; r < 32; r++) {
-        const int j = 32 * lane + r;
-        x[r] = (j < ns) ? __float_as_uint(radius_of(d.s1[(size_t)j * stride], d.s1[d.ld1 + (size_t)j * stride], d.s1[2 * (size_t)d.ld1 + (size_t)j * stride])) : 0xFFFFFFFFu;
-    }
+    for (int r = 0; r < 32; r++) x[r] = sm[32 * lane + r];
 #pragma unroll
     for (int k = 2; k <= kSamples; k <<= 1) {                   // bitonic sort, ascending
 #pragma unroll
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(64) void k_rs_splitters(const PairDesc* __restrict_
     }
 #pragma unroll
     for (int r = 0; r < 32; r++) sm[32 * lane + r] = x[r];
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();      // one wave left: its LDS operations complete in order
     int nb = (n + kBucketTarget - 1) / kBucketTarget;
     nb = min(max(nb, 1), kMaxBuckets);
     if (n == 0) nb = 0;
@@ -307,7 +309,7 @@ hipError_t init_rank_sort_kernels() {
 }
 
 hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
-    k_rs_splitters<<<c.n_pairs, 64, 0, st>>>(w.desc, w.splitters, w.n_buckets);
+    k_rs_splitters<<<c.n_pairs, kSplitLoadThreads, 0, st>>>(w.desc, w.splitters, w.n_buckets);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -41,8 +41,10 @@ icet_status icet_multi_create(icet_multi** out, const int32_t* device_ids, int32
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ICET_ERR_NO_DEVICE;
     for (int i = 0; i < n_devices; i++) {
         if (device_ids[i] < 0 || device_ids[i] >= ndev) return ICET_ERR_NO_DEVICE;
-        for (int j = 0; j < i; j++) if (device_ids[j] == device_ids[i]) return ICET_ERR_BAD_ARG;      // a device may appear once
     }
+    // (a device may appear more than once: each entry gets its own context, host thread and result buffer on that device -- two
+    // shards sharing one GPU.  Of no use in production, but it is how the N > 1 sharding, X0 scatter and result gather are exercised
+    // on a one-GPU box: tests/test_gpu_parity.py)
     icet_multi* m = new (std::nothrow) icet_multi();
     if (!m) return ICET_ERR_NOMEM;
     try {

@@ -175,7 +175,7 @@ int   icet_device(const icet_ctx* ctx);
  * gathered into ONE buffer -- the caller's host arrays, or HBM of device_ids[0] through peer copies over xGMI.  There is no
  * data-path collective; a process that runs one rank per GPU gathers with torch.distributed / RCCL instead (icet_amd/dist.py). */
 typedef struct icet_multi icet_multi;
-icet_status icet_multi_create(icet_multi** handle, const int32_t* device_ids, int32_t n_devices);   /* ids distinct, each < device count */
+icet_status icet_multi_create(icet_multi** handle, const int32_t* device_ids, int32_t n_devices);   /* each id < device count; an id may repeat (one context per ENTRY) */
 icet_status icet_multi_destroy(icet_multi* handle);
 const char* icet_multi_last_error(const icet_multi* handle);
 int32_t     icet_multi_devices(const icet_multi* handle);

@@ -594,8 +594,8 @@ print("rccl one-rank gather ok")
 
 def test_multi_device_entry_with_one_device_equals_the_single_context(gpu_ctx, frames, sample_pc):
     """icet_multi_* with n_devices = 1 (all this box has): the host-pointer entry must reproduce icet_solve_batch bit for bit, the
-    device-resident entry icet_solve_batch_device -- X0 scatter and result gather included -- and duplicate / unknown device ids
-    are refused.  (No N > 1 run has happened anywhere yet: DESIGN.md section 9.)"""
+    device-resident entry icet_solve_batch_device -- X0 scatter and result gather included -- and unknown device ids are refused.
+    (No run on N > 1 DEVICES has happened anywhere yet: DESIGN.md section 9; the N > 1 sharding itself runs in the next test.)"""
     import icet_amd
     from icet_amd import lidar_sim as ls, api
     a, b = frames; c, d = sample_pc
@@ -619,11 +619,40 @@ def test_multi_device_entry_with_one_device_equals_the_single_context(gpu_ctx, f
     assert torch.equal(o_multi, o_single) and bool(torch.isfinite(o_multi).all())
     m.close()
     with pytest.raises(icet_amd.IcetError) as e:
-        icet_amd.MultiContext([0, 0])
-    assert e.value.status == api.ICET_ERR_BAD_ARG
-    with pytest.raises(icet_amd.IcetError) as e:
         icet_amd.MultiContext([0, 63])
     assert e.value.status == api.ICET_ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+def test_multi_device_sharding_with_shards_sharing_one_gpu(gpu_ctx, frames, sample_pc, shards):
+    """The N > 1 logic of icet_multi_* on the one GPU of this box: device id 0 listed `shards` times gives that many contexts, host
+    threads and result buffers; pair k goes to shard k mod N, X0 rows are scattered to the shards and the 48 result floats per pair
+    gathered back (strided copies).  Ragged pairs, more pairs than shards and fewer pairs than shards; results must be the single
+    context's, bit for bit, through the host-pointer entry and through the device-resident one."""
+    import icet_amd
+    from icet_amd import lidar_sim as ls, api
+    a, b = frames; c, d = sample_pc
+    s1 = [a, c, a[:30000], b, c[:50000]]; s2 = [b, d, b[:31000], a, d[:47000]]
+    x0 = np.zeros((5, 6), np.float32); x0[1, 0] = 0.3; x0[3, 5] = 0.01; x0[4, 1] = -0.05
+    m = icet_amd.MultiContext([0] * shards)
+    for npairs in (5, 1):                                            # 1 pair: shards 1.. have nothing to do
+        ref = gpu_ctx.solve_batch(s1[:npairs], s2[:npairs], 7, x0[:npairs])
+        got = m.solve_batch(s1[:npairs], s2[:npairs], 7, x0[:npairs])
+        for key in ("X", "pred_stds", "cov"):
+            assert np.array_equal(got[key], ref[key]), (key, npairs)
+    dev = torch.device("cuda", 0)
+    n = 7
+    pairs = [ls.make_batch_pair(k, device=dev) for k in range(n)]
+    d1 = [(p[0].data_ptr(), p[0].shape[1], p[0].shape[1]) for p in pairs]; d2 = [(p[1].data_ptr(), p[1].shape[1], p[1].shape[1]) for p in pairs]
+    xd = torch.zeros((n, 6), dtype=torch.float32, device=dev); xd[:, 0] = torch.linspace(-0.02, 0.03, n, device=dev)
+    o_multi = torch.full((n, 48), float("nan"), dtype=torch.float32, device=dev); o_single = torch.zeros((n, 48), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    prm = api.Params(7, 24, 75, 25, 0.1, 0.1, 0)
+    m.solve_batch_device(d1, d2, prm, o_multi.data_ptr(), xd.data_ptr())
+    ctx = icet_amd.Context(0); ctx.solve_batch_device(d1, d2, prm, o_single.data_ptr(), xd.data_ptr()); ctx.sync(); ctx.close()
+    torch.cuda.synchronize()
+    assert torch.equal(o_multi, o_single) and bool(torch.isfinite(o_multi).all())
+    m.close()
 
 
 def test_rarely_taken_paths_give_the_same_bits(gpu_ctx, frames, sample_pc):

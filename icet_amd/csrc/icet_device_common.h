@@ -168,6 +168,23 @@ __device__ __forceinline__ void classify_angular_fast(float qx, float qy, float 
     prow = ep.idx - ((w < ep.edge) ? T : 0);                             // T * polar bin, polar bin in [0, P]
     near = !(fabsf(pa - et.edge) >= guard_t) | !(fabsf(w - ep.edge) >= guard_p);
 }
+// ---- cross-lane moves on the DPP path (no LDS crossbar: __shfl_* compiles to ds_bpermute_b32, a trip through the LDS pipeline) --------
+// lane i receives x of lane i - 1; lane 0 receives `fill`
+__device__ __forceinline__ int wave_shr1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ float wave_shr1(float x, float fill) { return __int_as_float(wave_shr1(__float_as_int(x), __float_as_int(fill))); }
+// inclusive prefix maximum over the 64 lanes, for values >= -1 (-1 = "nothing"): four row_shr steps inside the rows of 16, then the
+// last lane of row 0 / 2 into rows 1 / 3 and the last lane of row 1 into rows 2 and 3
+__device__ __forceinline__ int wave_incl_max(int v) {
+    int t;
+    t = __builtin_amdgcn_update_dpp(-1, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false); v = max(v, t);
+    t = __builtin_amdgcn_update_dpp(-1, v, 0x112 /* row_shr:2 */, 0xf, 0xf, false); v = max(v, t);
+    t = __builtin_amdgcn_update_dpp(-1, v, 0x114 /* row_shr:4 */, 0xf, 0xf, false); v = max(v, t);
+    t = __builtin_amdgcn_update_dpp(-1, v, 0x118 /* row_shr:8 */, 0xf, 0xf, false); v = max(v, t);
+    t = __builtin_amdgcn_update_dpp(-1, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false); v = max(v, t);
+    t = __builtin_amdgcn_update_dpp(-1, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false); v = max(v, t);
+    return v;
+}
+
 // ---- the literal path for points the fast classification cannot decide ------------------------------------------------
 // sortSphericalCoordinates' bin index WITHOUT the double divide: thr[k] is the smallest float whose reference bin (double
 // arithmetic, src/icet.cpp:545-546) is >= k, built on the host with exactly that arithmetic, so "largest k with

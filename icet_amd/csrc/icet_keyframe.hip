@@ -438,8 +438,15 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
 //   k_fit_finish     one LANE per bin: 3x3 eigen-decomposition, sigma points, slot records (scalar work).
 // One fused kernel (one wave per bin for everything, round 2's first version) took 437 us per 256 pairs: the double-precision code
 // set its register budget (4 waves per SIMD, which the latency-bound walk wanted to be 8) and ran beside half-empty waves.
+// Blocks per launch of the fit kernels (a fixed number of blocks per pair walks the pair's live bins / work items).  Measured on 256 pairs:
+// k_fit_cluster 512 blocks 213 us, 1024: 133, 1536: 110, 2048: 111, 4096: 152, 8192: 195, 16384: 220 -- more waves in flight make its
+// gathers and returning atomics slower, not faster; k_fit_moments (a short coalesced read per bin) the other way: 2048: 70, 8192: 61;
+// k_fit_roundtrip 1024: 115, 2048: 104, 4096: 103.
 #ifndef ICET_FIT_BLOCKS
-#define ICET_FIT_BLOCKS 4096
+#define ICET_FIT_BLOCKS 2048
+#endif
+#ifndef ICET_MOM_BLOCKS
+#define ICET_MOM_BLOCKS 8192
 #endif
 #ifndef ICET_RT_BLOCKS
 #define ICET_RT_BLOCKS 2048
@@ -501,14 +508,10 @@ __global__ __launch_bounds__(kBlock, 8) void k_fit_cluster(const PairDesc* __res
         // lane whose run is long enough is picked with a ballot.
         auto walk = [&](int c0, float r) {
             const int i = c0 + lane; const bool valid = i < cnt;
-            float prev = __shfl_up(r, 1);
-            if (lane == 0) prev = carry_prev;
+            const float prev = wave_shr1(r, carry_prev);
             const bool brk = valid && (i == 0 || !(fabsf(prev - r) <= thresh));
-            int pm = brk ? i : -1;                                   // inclusive prefix max of break positions
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pm, o); if (lane >= o) pm = max(pm, t); }
-            int prevb = __shfl_up(pm, 1);                            // last break strictly before this lane ...
-            if (lane == 0) prevb = -1;
+            const int pm = wave_incl_max(brk ? i : -1);              // inclusive prefix max of break positions (DPP: no LDS crossbar)
+            int prevb = wave_shr1(pm, -1);                           // last break strictly before this lane ...
             prevb = max(prevb, run_start);                           // ... or the run carried in from earlier chunks
             const unsigned long long hit = __ballot(brk && (i - prevb >= n));
             if (hit) {
@@ -896,7 +899,8 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
                                                                   c.T, c.P, np, rt_chunks);
         ICET_LAUNCH_CHECK();
     }
-    k_fit_moments<<<dim3(groups * fit_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.cart1, (size_t)w.cap_n1, w.live_bins, w.n_live, w.midD, c.V, c.n, np, fit_chunks);
+    const int mom_chunks = std::max(1, std::min((c.V + kBlock / 64 - 1) / (kBlock / 64), (ICET_MOM_BLOCKS + c.n_pairs - 1) / c.n_pairs));
+    k_fit_moments<<<dim3(groups * mom_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.cart1, (size_t)w.cap_n1, w.live_bins, w.n_live, w.midD, c.V, c.n, np, mom_chunks);
     ICET_LAUNCH_CHECK();
     k_fit_finish<<<dim3((c.V + kBlock - 1) / kBlock, c.n_pairs), blk, 0, st>>>(w.midD, w.bin_start, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n);
     ICET_LAUNCH_CHECK();

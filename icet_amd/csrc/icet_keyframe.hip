@@ -366,7 +366,12 @@ constexpr int kScatterRounds = kKfMaxPtsPerThread;   // a tile is at most 4 wave
 __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const uint16_t* __restrict__ binpos,
                                                         const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bin_start,
                                                         uint32_t* __restrict__ sorted_row, int V, int vbits, int n_pairs, int chunks) {
-    extern __shared__ uint32_t lb[];                                   // 4 x V : per-wave counts, then per-wave running offsets
+    // LDS: gb[V] (u32: where the tile's rows of a voxel start in the pair's table) | lc[4][V] (u16: per-wave counts, then the running
+    // offset of each wave inside the tile's rows of the voxel).  12 bytes per voxel -- 21.6 KB for 75 x 24, seven blocks per CU; with
+    // four u32 arrays (28.8 KB, five blocks) the kernel took 260 us per 256 pairs: it wants occupancy (capped at 4 / 3 blocks: 281 / 334).
+    extern __shared__ uint32_t lb[];
+    uint32_t* gb = lb;
+    uint16_t* lc = reinterpret_cast<uint16_t*>(lb + V);
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;
     const PairDesc d = desc[pair];
@@ -377,11 +382,11 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
     const int qs = cs_ / 4;                                            // multiple of 64
     const int wlo = lo_ + wave * qs, whi = min(hi_, wlo + qs);
     const int rounds = qs / 64;
-    for (int i = threadIdx.x; i < 4 * V; i += kBlock) lb[i] = 0u;
+    for (int i = threadIdx.x; i < 2 * V; i += kBlock) lb[V + i] = 0u;  // the 4 x V u16 counters, two per word
     __syncthreads();
     const size_t o = d.off1;
     uint32_t bb[kScatterRounds]; uint32_t row[kScatterRounds]; bool ok[kScatterRounds];
-    uint32_t* mine = lb + wave * V;
+    uint16_t* mine = lc + wave * V;
 #pragma unroll
     for (int k = 0; k < kScatterRounds; k++) {
         const int v = wlo + 64 * k + lane;
@@ -389,16 +394,19 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
         const uint32_t wd = ok[k] ? (uint32_t)binpos[o + v] : 0u;
         bb[k] = wd & kRowBinMask;
         row[k] = (ok[k] ? (uint32_t)src[o + v] : 0u) | ((wd & kRowNearBit) ? kSortedNearBit : 0u);   // the flag travels with the row
-        if (ok[k]) atomicAdd(&mine[bb[k]], 1u);
+        if (ok[k]) {                                                   // 16-bit counters, 32-bit atomics: a quarter tile holds <= 512 rows, no carry into the neighbour
+            const uint32_t e = (uint32_t)(wave * V) + bb[k];
+            atomicAdd(&lb[V + (e >> 1)], 1u << (16u * (e & 1u)));
+        }
     }
     __syncthreads();
     {
         const uint32_t* tb = tile_base + ((size_t)pair * chunks + chunk) * V;
         const int32_t* bst = bin_start + (size_t)pair * (V + 1);
         for (int b = threadIdx.x; b < V; b += kBlock) {
-            const uint32_t c0 = lb[b], c1 = lb[V + b], c2 = lb[2 * V + b];
-            const uint32_t base = (uint32_t)bst[b] + tb[b];
-            lb[b] = base; lb[V + b] = base + c0; lb[2 * V + b] = base + c0 + c1; lb[3 * V + b] = base + c0 + c1 + c2;
+            const uint32_t c0 = lc[b], c1 = lc[V + b], c2 = lc[2 * V + b];
+            gb[b] = (uint32_t)bst[b] + tb[b];
+            lc[b] = 0; lc[V + b] = (uint16_t)c0; lc[2 * V + b] = (uint16_t)(c0 + c1); lc[3 * V + b] = (uint16_t)(c0 + c1 + c2);
         }
     }
     __syncthreads();
@@ -415,8 +423,9 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
         dest[k] = 0u;
         if (ok[k]) {
             const int rank = __popcll(peers & lt);
-            dest[k] = mine[bb[k]] + (uint32_t)rank;
-            if (rank == 0) mine[bb[k]] += (uint32_t)__popcll(peers);  // one leader per distinct voxel in this round
+            const uint32_t run = mine[bb[k]];
+            dest[k] = gb[bb[k]] + run + (uint32_t)rank;
+            if (rank == 0) mine[bb[k]] = (uint16_t)(run + (uint32_t)__popcll(peers));  // one leader per distinct voxel in this round
         }
     }
     // one scattered 4-byte store per row; k_fit_cluster gathers the coordinates through it (element-wise scattered stores of
@@ -881,7 +890,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     }
     e = launch_class_scan(w.counts, w.tile_base, w.bin_start, c.V, chunks, c.n_pairs, st, w.live_bins, w.n_live, c.n, w.fit_n_items);
     if (e != hipSuccess) return e;
-    k_bin_scatter<<<grid, blk, (size_t)c.V * 16, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks);
+    k_bin_scatter<<<grid, blk, (size_t)c.V * 12 + 8, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks);
     ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 3) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     // keyA / keyB (bucket-grouped keys and the overflow scratch of the rank sort) are dead by now: candidate rows and their r

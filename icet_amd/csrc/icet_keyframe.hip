@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
 // Fused with the first step of the voxel multi-split (k_bin_hist): the row that lands on a position is known here, so
 // its voxel id and this tile's voxel histogram cost no extra pass over src[].
 #ifndef ICET_SCR_WAVES
-#define ICET_SCR_WAVES 6      /* <= 80 VGPRs: 6 waves per SIMD for a latency-bound walk (measured: -35 us per 256-pair keyframe; 8 spills) */
+#define ICET_SCR_WAVES 8      /* <= 64 VGPRs: 8 waves per SIMD for a latency-bound walk (measured per 256 pairs: 6 waves 269 us, 7: 268, 8: 256) */
 #endif
 // kBitsInLds: the pair's exec table sits in LDS behind the voxel histogram (any scan below ~0.75 M rows); otherwise its words are
 // read from memory.
@@ -196,8 +196,11 @@ __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const P
     const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
     const size_t o = d.off1;
     const unsigned long long* gbits = execbits + exec_word_base(d.off1, pair);
-    unsigned long long* lbits = reinterpret_cast<unsigned long long*>(lh + ((V + 1) & ~1));
-    for (int b = threadIdx.x; b < V; b += kBlock) lh[b] = 0u;
+    // the tile's voxel histogram as 16-bit counters, two per word (a tile holds <= 4096 rows: no carry into the neighbour), then the
+    // pair's exec bit table: 3.6 + 15 KB for a 116 k-row scan on 75 x 24 -- eight blocks per CU
+    const int hist_words = ((V + 1) / 2 + 1) & ~1;                     // even: the bit table behind it is 8-byte aligned
+    unsigned long long* lbits = reinterpret_cast<unsigned long long*>(lh + hist_words);
+    for (int b = threadIdx.x; b < hist_words; b += kBlock) lh[b] = 0u;
     if (kBitsInLds) {
         const int nw = (d.n1 + 63) >> 6;
         for (int i = threadIdx.x; i < nw; i += kBlock) lbits[i] = gbits[i];
@@ -249,13 +252,13 @@ __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const P
                 src[o + v] = f[k];
                 const uint16_t b = fb[k] & kBinMask;
                 binpos[o + v] = fb[k];                              // voxel id + the row's near-edge flag
-                atomicAdd(&lh[b], 1u);
+                atomicAdd(&lh[b >> 1], 1u << (16u * (b & 1u)));
             }
         }
     }
     __syncthreads();
     uint32_t* out = counts + ((size_t)pair * chunks + chunk) * V;
-    for (int b = threadIdx.x; b < V; b += kBlock) out[b] = lh[b];
+    for (int b = threadIdx.x; b < V; b += kBlock) out[b] = (lh[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
 }
 
 // Serial fallback for adversarial permutations (walks longer than max_walk): one lane replays the
@@ -876,7 +879,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
         const int max_walk = 4096;
         k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.pred, w.execbits, w.flags, max_walk, np, chunks);
         ICET_LAUNCH_CHECK();
-        const size_t hist_bytes = (size_t)((c.V + 1) & ~1) * 4, bit_bytes = (size_t)((c.max_n1 + 63) / 64) * 8;
+        const size_t hist_bytes = (size_t)((((c.V + 1) / 2 + 1) & ~1)) * 4, bit_bytes = (size_t)((c.max_n1 + 63) / 64) * 8;
         if (c.exec_bits_lds && hist_bytes + bit_bytes <= kScrambleLdsMax)
             k_scramble_src<true><<<grid, blk, hist_bytes + bit_bytes, st>>>(w.desc, w.valB, w.pred, w.execbits, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);
         else

@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- scan-pairs/s and ms/pair of the MI355X-native ICET hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 needs one process per GPU.  Started by the driver's launcher (python -m torch.distributed.run ... bench.py --gpus N ...)
+the script finds WORLD_SIZE in its environment and is one rank.  Started WITHOUT a launcher (plain `python bench.py --gpus N`)
+it starts that launcher itself as a CHILD process -- before anything here has touched the GPU -- relays the child's JSON line and
+exits with the child's return code; it never re-executes a process that has initialised HIP and never silently measures one GPU.
+`--multi` measures the other N-GPU form instead: ONE process, the native icet_multi_* entry (one context + host thread per GPU,
+peer-copy or RCCL gather inside the C++ library).
 
 A "step" is one pass of the hot path (keyframe build + 7 Gauss-Newton iterations, 75 x 24 voxels) over
 one batch of synthetic 64-channel scan pairs per GPU: BASELINE.json configs[2] (256 independent pairs,
@@ -34,7 +41,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 PUBLISHED_MS_PER_PAIR = 35.0   # reference README.md:59 (Ryzen 5800X) -- different hardware, informational
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -48,7 +55,39 @@ def parse():
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="icet_set_option on the context (launch-shape experiments); echoed in config.options")
     ap.add_argument("--distinct", type=int, default=0, help="generate only this many distinct pairs and cycle them (0 = all distinct)")
-    return ap.parse_args()
+    ap.add_argument("--multi", action="store_true", help="one process, N GPUs through the native icet_multi_* entry (no torch.distributed)")
+    ap.add_argument("--multi-gather", choices=["peer", "rccl"], default="peer", help="--multi: peer copies (default) or the library's RCCL all-gather")
+    ap.add_argument("--min-timed-s", type=float, default=0.5, help="the K timed steps are repeated until the timed region is at least this long")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive sub-record")
+    ap.add_argument("--dry-run-launch", action="store_true", help="print what `--gpus N` would start (JSON) and exit: no GPU, no child")
+    return ap.parse_args(argv)
+
+
+def launcher_command(args, argv, port=None):
+    """The child this script starts for `--gpus N` without a launcher: the driver's own command line (one rank per GPU over RCCL)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--dry-run-launch"]
+
+
+def plan_launch(args, env):
+    """What `main` does about processes, decided BEFORE any GPU call.  Returns (action, detail):
+    'run'     this process is the (or a) rank / the single process
+    'spawn'   --gpus N > 1 without a launcher: start one as a child
+    'refuse'  the environment contradicts --gpus (never measure fewer GPUs than asked for)"""
+    world = env.get("WORLD_SIZE")
+    if args.multi:
+        if world is not None and int(world) > 1:
+            return "refuse", "--multi is one process over N GPUs; it must not run under a %s-rank launcher" % world
+        return "run", "one process, %d device(s) through icet_multi" % args.gpus
+    if world is None:
+        return ("spawn", "no launcher in the environment") if args.gpus > 1 else ("run", "single GPU")
+    if int(world) != args.gpus:
+        return "refuse", "--gpus %d but WORLD_SIZE=%s" % (args.gpus, world)
+    return "run", "rank of a %s-rank launch" % world
 
 
 def run_nodes(args):
@@ -133,8 +172,30 @@ def run_nodes(args):
         dist.barrier(); dist.destroy_process_group()
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    # ---- processes first: decided from the arguments and the environment alone, before anything touches the GPU ----
+    action, why = plan_launch(args, os.environ)
+    if args.dry_run_launch:
+        print(json.dumps({"action": action, "why": why, "command": launcher_command(args, argv, port=29500) if action == "spawn" else None}))
+        return 0
+    if action == "refuse":
+        raise SystemExit("bench.py: " + why)
+    if action == "spawn":
+        import subprocess
+        cmd = launcher_command(args, argv)
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("MASTER_ADDR", "127.0.0.1")
+        print("bench.py: --gpus %d without a launcher (%s): starting %s" % (args.gpus, why, " ".join(cmd)), file=sys.stderr, flush=True)
+        child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{\"metric\"")]
+        for ln in child.stdout.splitlines():
+            if not ln.startswith("{\"metric\""):
+                print(ln, file=sys.stderr)
+        if child.returncode != 0 or not lines:
+            raise SystemExit(child.returncode or 1)
+        print(lines[-1], flush=True)
+        return 0
     if args.workload in ("odometry", "mapmaker"):
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -142,15 +203,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # rehearsal hook: several ranks on ONE card (the 1-GPU dev box) -- never set by the driver
-    if os.environ.get("ICET_BENCH_SHARE_DEVICE"):
-        local_rank = int(os.environ["ICET_BENCH_SHARE_DEVICE"])
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    multi = args.multi
+    n_dev = args.gpus if multi else 1                              # devices THIS process drives
+    if multi and torch.cuda.device_count() < args.gpus and not os.environ.get("ICET_BENCH_SHARE_DEVICE"):
+        raise SystemExit("bench.py --multi --gpus %d: only %d device(s) visible" % (args.gpus, torch.cuda.device_count()))
+    # rehearsal hook: several ranks / shards on ONE card (the 1-GPU dev box) -- never set by the driver
+    share = os.environ.get("ICET_BENCH_SHARE_DEVICE")
+    if share:
+        local_rank = int(share)
+    dev_ids = [int(share)] * n_dev if (multi and share) else (list(range(n_dev)) if multi else [local_rank])
+    torch.cuda.set_device(dev_ids[0])
+    dev = torch.device("cuda", dev_ids[0])
     import torch.distributed as dist
     backend = os.environ.get("ICET_BENCH_BACKEND", "nccl")      # "gloo" only for rehearsing N ranks on one card
     if world > 1:
@@ -159,6 +224,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
     import icet_amd
     from icet_amd import lidar_sim, api
@@ -170,23 +237,28 @@ def main():
     else:
         rings, steps_az, T, P, iters = 128, 4096, 150, 48, 10
         n_local = 1
-    n_global = n_local * world
-    ids = shard_indices(n_global, rank, world)
+    n_gpus = args.gpus if multi else world
+    n_global = n_local * n_gpus
+    ids = list(range(n_global)) if multi else shard_indices(n_global, rank, world)        # pairs THIS process holds (multi: all, pair k on device k mod N)
 
     # ---- synthetic inputs, generated in HBM ------------------------------------------------------
     t_gen = time.time()
     scans1, scans2 = [], []
     distinct = args.distinct if args.distinct > 0 else len(ids)
     for j, k in enumerate(ids):
+        dk = torch.device("cuda", dev_ids[j % n_dev])
         if j < distinct:
             if args.workload == "batch":
-                s1, s2, _ = lidar_sim.make_batch_pair(k, rings, steps_az, device=dev, order=args.order)
+                s1, s2, _ = lidar_sim.make_batch_pair(k, rings, steps_az, device=dk, order=args.order)
             else:
-                s1, s2, _ = lidar_sim.make_pair(9000, 9001, lidar_sim.DEFAULT_MOTION, rings, steps_az, device=dev, order=args.order)
+                s1, s2, _ = lidar_sim.make_pair(9000, 9001, lidar_sim.DEFAULT_MOTION, rings, steps_az, device=dk, order=args.order)
         else:
             s1, s2 = scans1[j % distinct], scans2[j % distinct]
+            if s1.device != dk:
+                s1, s2 = s1.to(dk), s2.to(dk)
         scans1.append(s1); scans2.append(s2)
-    torch.cuda.synchronize()
+    for d in set(dev_ids):
+        torch.cuda.synchronize(d)
     t_gen = time.time() - t_gen
     n1 = [int(s.shape[1]) for s in scans1]; n2 = [int(s.shape[1]) for s in scans2]
 
@@ -207,17 +279,33 @@ def main():
     d1 = [(b.data_ptr(), n, b.shape[1]) for b, n in zip(bufs1, n1)]
     d2 = [(b.data_ptr(), n, b.shape[1]) for b, n in zip(bufs2, n2)]
 
-    stream = torch.cuda.Stream(device=dev)
-    ctx = icet_amd.Context(local_rank, stream=stream.cuda_stream)
-    for kv in args.set:
-        name, value = kv.split("=", 1)
-        ctx.set_option(name, float(value))
     p_plain = api.Params(iters, P, T, 25, 0.1, 0.1, 0)
     p_timed = api.Params(iters, P, T, 25, 0.1, 0.1, api.FLAG_TIMING)
     out = torch.zeros((len(ids), 48), dtype=torch.float32, device=dev)
-    ctx.reserve(p_plain, len(ids), sum(n1), sum(n2))
+    stream = torch.cuda.Stream(device=dev)
+    mctx = None
+    if multi:
+        mctx = api.MultiContext(dev_ids)
+        if args.multi_gather == "rccl":
+            mctx.set_option("gather", 1)
+        for kv in args.set:
+            name, value = kv.split("=", 1)
+            mctx.set_option(name, float(value))
+        mctx.reserve(p_plain, len(ids), sum(n1), sum(n2))
+        ctx = mctx.context(0)                                      # timing / roofline are read from the first device's context
+        for d in set(dev_ids):
+            torch.cuda.synchronize(d)
+    else:
+        ctx = icet_amd.Context(local_rank, stream=stream.cuda_stream)
+        for kv in args.set:
+            name, value = kv.split("=", 1)
+            ctx.set_option(name, float(value))
+        ctx.reserve(p_plain, len(ids), sum(n1), sum(n2))
 
     def step(params):
+        if multi:
+            mctx.solve_batch_device(d1, d2, params, out.data_ptr())    # synchronous: returns after the gather into `out` on devices[0]
+            return out
         with torch.cuda.stream(stream):
             ctx.solve_batch_device(d1, d2, params, out.data_ptr())
             if world > 1:
@@ -228,7 +316,8 @@ def main():
         return out
 
     def fence():
-        torch.cuda.synchronize()
+        for d in set(dev_ids):
+            torch.cuda.synchronize(d)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -236,17 +325,38 @@ def main():
     for _ in range(args.warmup):
         step(p_plain)
     fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step(p_plain)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    ms_per_step = dt / max(args.steps, 1) * 1e3
-    pairs_per_s = n_global * args.steps / dt
+    # The K timed steps, bracketed by barrier + synchronize.  One pass of K steps over 256 pairs is only ~50 ms, so the bracket is
+    # REPEATED (each repetition: exactly K steps between two fences) until the timed region is at least --min-timed-s; `steps`
+    # stays K, `ms_per_step` is the mean over every timed step, `value` the pairs of all of them / the total time.
+    reps_t, dt, rep_ms = 0, 0.0, []
+    while True:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step(p_plain)
+        fence()
+        d = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([d], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt.item())
+        dt += d; reps_t += 1; rep_ms.append(d / max(args.steps, 1) * 1e3)
+        if dt >= args.min_timed_s or reps_t >= 1000:      # every rank sees the same (max-reduced) dt, so every rank leaves together
+            break
+    steps_total = args.steps * reps_t
+    ms_per_step = dt / max(steps_total, 1) * 1e3
+    pairs_per_s = n_global * steps_total / dt
+
+    # ---- the gather alone (N > 1): what the collective costs on top of the solve ----
+    gather_ms = None
+    if world > 1 and backend == "nccl":
+        fence()
+        tg = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for _ in range(20):
+                gather_results(out, n_global, rank, world)
+        fence()
+        gather_ms = (time.perf_counter() - tg) / 20 * 1e3
 
     # ---- per-kernel timing with HIP events on the solve stream (extra steps, not part of `value`) ----
     acc_ms, kf_ms, gn_ms, launches = 0.0, 0.0, 0.0, 0
@@ -257,9 +367,11 @@ def main():
         acc_ms += t["accumulate_ms"]; kf_ms += t["keyframe_ms"]; gn_ms += t["gn_loop_ms"]; launches += t["accumulate_launches"]
     fence()
     acc_launch_ms = acc_ms / max(launches, 1)
-    bytes_per_launch = 12.0 * float(sum(n2))
+    n2_timed = [n for j, n in enumerate(n2) if j % n_dev == 0]                   # the pairs of the context whose events were read
+    n1_timed = [n for j, n in enumerate(n1) if j % n_dev == 0]
+    bytes_per_launch = 12.0 * float(sum(n2_timed))
     achieved = bytes_per_launch / (acc_launch_ms * 1e-3) / 1e9 if acc_launch_ms > 0 else 0.0
-    bytes_path = sum(12.0 * a + 12.0 * b * iters + 192.0 for a, b in zip(n1, n2))
+    bytes_path = sum(12.0 * a + 12.0 * b * iters + 192.0 for a, b in zip(n1, n2)) * (1 if multi else world)      # whole job
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath) and args.workload == "batch" and n_local == 256 and args.distinct == 0:
@@ -269,6 +381,7 @@ def main():
         except Exception:
             traffic = None
 
+    one_ctx = ctx if not multi else icet_amd.Context(dev_ids[0], stream=stream.cuda_stream)
     # ---- single-pair latency (configs[1]) on rank 0's first pair -----------------------------------
     lat = None
     if args.workload == "batch" and not args.no_latency:
@@ -276,16 +389,22 @@ def main():
         o1 = torch.zeros((1, 48), dtype=torch.float32, device=dev)
         with torch.cuda.stream(stream):
             for _ in range(5):
-                ctx.solve_batch_device(one1, one2, p_plain, o1.data_ptr())
+                one_ctx.solve_batch_device(one1, one2, p_plain, o1.data_ptr())
         torch.cuda.synchronize()
-        tl = time.perf_counter(); nrep = 30
+        tl = time.perf_counter(); nrep = 200
         with torch.cuda.stream(stream):
             for _ in range(nrep):
-                ctx.solve_batch_device(one1, one2, p_plain, o1.data_ptr())
-                ctx.sync()
+                one_ctx.solve_batch_device(one1, one2, p_plain, o1.data_ptr())
+                one_ctx.sync()
         lat_ms = (time.perf_counter() - tl) / nrep * 1e3
+        with torch.cuda.stream(stream):
+            one_ctx.solve_batch_device(one1, one2, p_timed, o1.data_ptr())
+        lt = one_ctx.last_timing()
+        l_acc = lt["accumulate_ms"] / max(lt["accumulate_launches"], 1)
         lat = {"workload": "configs[1]: single 64-ch pair, 75x24 voxels, 7 iters, inputs resident in HBM", "ms_per_pair": round(lat_ms, 4),
-               "n1": n1[0], "n2": n2[0], "speedup_vs_published_35ms": round(PUBLISHED_MS_PER_PAIR / lat_ms, 1)}
+               "n1": n1[0], "n2": n2[0], "speedup_vs_published_35ms": round(PUBLISHED_MS_PER_PAIR / lat_ms, 1), "repetitions": nrep,
+               "keyframe_ms": round(lt["keyframe_ms"], 4), "gn_loop_ms": round(lt["gn_loop_ms"], 4), "accumulate_avg_launch_ms": round(l_acc, 5),
+               "whole_path_GBs": round((12.0 * n1[0] + 12.0 * n2[0] * iters + 192.0) / (lat_ms * 1e-3) / 1e9, 1)}
 
     # ---- configs[4] (high-resolution sweep) as a sub-record of the default line: one 128-channel pair, 150 x 48 voxels, 10 iterations ----
     hires = None
@@ -297,29 +416,65 @@ def main():
         ho = torch.zeros((1, 48), dtype=torch.float32, device=dev)
         with torch.cuda.stream(stream):
             for _ in range(5):
-                ctx.solve_batch_device(hd1, hd2, hp, ho.data_ptr())
+                one_ctx.solve_batch_device(hd1, hd2, hp, ho.data_ptr())
         torch.cuda.synchronize()
-        th = time.perf_counter(); nrep = 30
+        th = time.perf_counter(); nrep = 100
         with torch.cuda.stream(stream):
             for _ in range(nrep):
-                ctx.solve_batch_device(hd1, hd2, hp, ho.data_ptr())
-                ctx.sync()
+                one_ctx.solve_batch_device(hd1, hd2, hp, ho.data_ptr())
+                one_ctx.sync()
         h_ms = (time.perf_counter() - th) / nrep * 1e3
         with torch.cuda.stream(stream):
-            ctx.solve_batch_device(hd1, hd2, hpt, ho.data_ptr())
-        ht = ctx.last_timing()
+            one_ctx.solve_batch_device(hd1, hd2, hpt, ho.data_ptr())
+        ht = one_ctx.last_timing()
         h_acc = ht["accumulate_ms"] / max(ht["accumulate_launches"], 1)
         h_bytes = 12.0 * h1.shape[1] + 12.0 * h2.shape[1] * 10 + 192.0
         hires = {"workload": "configs[4]: single 128-ch pair (~%dk pts), 150x48 voxels, 10 iters, inputs resident in HBM" % (int(h2.shape[1]) // 1000),
-                 "ms_per_pair": round(h_ms, 4), "n1": int(h1.shape[1]), "n2": int(h2.shape[1]),
+                 "ms_per_pair": round(h_ms, 4), "n1": int(h1.shape[1]), "n2": int(h2.shape[1]), "repetitions": nrep,
                  "keyframe_ms": round(ht["keyframe_ms"], 4), "gn_loop_ms": round(ht["gn_loop_ms"], 4),
                  "accumulate_avg_launch_ms": round(h_acc, 5), "accumulate_GBs": round(12.0 * h2.shape[1] / (h_acc * 1e-3) / 1e9, 1) if h_acc > 0 else None,
                  "whole_path_GBs": round(h_bytes / (h_ms * 1e-3) / 1e9, 1)}
         del hb1, hb2, h1, h2
 
+    # ---- PCIe-inclusive ("reported both with and without H2D"): 64 pairs through icet_solve_batch, host pointers in,
+    # host results out -- from pageable numpy arrays and from pinned torch tensors.  Never `value`. ----
+    h2d = None
+    if args.workload == "batch" and not args.no_h2d and rank == 0 and not args.no_latency:
+        m = min(64, len(ids))
+        hs1 = [scans1[j].T.contiguous().cpu() for j in range(m)]; hs2 = [scans2[j].T.contiguous().cpu() for j in range(m)]      # N x 3 row-major on the host
+        a1 = [t.numpy() for t in hs1]; a2 = [t.numpy() for t in hs2]
+        hctx = icet_amd.Context(dev_ids[0])
+        def timed(fn, nrep=3):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(nrep):
+                fn()
+            return (time.perf_counter() - t0) / nrep
+        t_page = timed(lambda: hctx.solve_batch(a1, a2, iters, None, P, T))
+        # pinned: the column-major staging the ABI reads, in page-locked memory (api.solve_batch transposes into pageable buffers, so go through the raw entry)
+        import ctypes as C
+        pin1 = [s.T.contiguous().pin_memory() for s in hs1]; pin2 = [s.T.contiguous().pin_memory() for s in hs2]                 # (3, N) = column-major N x 3
+        L = api.load_library()
+        A1 = (C.c_void_p * m)(*[t.data_ptr() for t in pin1]); A2 = (C.c_void_p * m)(*[t.data_ptr() for t in pin2])
+        nn1 = np.array([t.shape[1] for t in pin1], np.int64); nn2 = np.array([t.shape[1] for t in pin2], np.int64)
+        Xo = np.zeros((m, 6), np.float32); Po = np.zeros((m, 6), np.float32); Co = np.zeros((m, 36), np.float32)
+        pp = api.Params(iters, P, T, 25, 0.1, 0.1, 0)
+        def pinned_call():
+            st = L.icet_solve_batch(hctx._h, C.byref(pp), m, A1, nn1.ctypes.data, A2, nn2.ctypes.data, None, Xo.ctypes.data, Po.ctypes.data, Co.ctypes.data)
+            if st != 0:
+                raise RuntimeError("icet_solve_batch -> %d" % st)
+        t_pin = timed(pinned_call)
+        mb = sum(12.0 * (a.shape[0] + b.shape[0]) for a, b in zip(a1, a2)) / 1e6
+        h2d = {"workload": "%d pairs through icet_solve_batch: host pointers in (H2D of both scans), X / pred_stds / cov back on the host" % m,
+               "pageable_ms_per_pair": round(t_page / m * 1e3, 4), "pageable_pairs_per_s": round(m / t_page, 1),
+               "pinned_ms_per_pair": round(t_pin / m * 1e3, 4), "pinned_pairs_per_s": round(m / t_pin, 1),
+               "host_MB_per_call": round(mb, 1), "pinned_h2d_GBs": round(mb / 1e3 / t_pin, 2),
+               "note": "PCIe-inclusive; never `value` (value = inputs resident in HBM). pageable includes the host-side transpose into column-major"}
+        hctx.close()
+
     # ---- CPU baseline: the oracle ("port") on this box's host cores, bounded sample, rank 0 at N=1 -----
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle as po
         cores = min(os.cpu_count() or 1, 16)
         m = min(len(ids), args.cpu_sample_pairs if args.workload == "batch" else 1)
@@ -328,30 +483,50 @@ def main():
         tc = time.perf_counter()
         ref = po.solve_batch(h1, h2, runlen=iters, bins_phi=P, bins_theta=T, n_threads=cores)
         tc = time.perf_counter() - tc
+        # the same sample in the oracle's LITERAL mode (glibc float trig, sequential float sums: the expression types of the reference source)
+        tl = time.perf_counter()
+        po.solve_batch(h1, h2, runlen=iters, bins_phi=P, bins_theta=T, n_threads=cores, mode=po.LIBMF)
+        tl = time.perf_counter() - tl
         sec1, _ = po.time_pair(h1[0], h2[0], reps=3, runlen=iters, bins_phi=P, bins_theta=T)
+        sec1l, _ = po.time_pair(h1[0], h2[0], reps=3, runlen=iters, bins_phi=P, bins_theta=T, mode=po.LIBMF)
         sec4, _ = po.time_pair(h1[0], h2[0], reps=3, runlen=iters, bins_phi=P, bins_theta=T, mode=po.POOL4)   # parallelFitCells2 structure, 4 workers (src/icet.cpp:31,346-370)
+        sec4l, _ = po.time_pair(h1[0], h2[0], reps=3, runlen=iters, bins_phi=P, bins_theta=T, mode=po.POOL4 | po.LIBMF)
         dXp = np.abs(ref["X"] - res[:m, :6].cpu().numpy())
-        cpu = {"value": round(m / tc, 3), "unit": "scan-pairs/s", "cores": cores, "kind": "port",
-               "sample": "first %d pairs of the same batch, one pair per host thread (oracle/icet_oracle.cpp, -O3 -march=native), %.1f s wall" % (m, tc),
-               "single_thread_ms_per_pair": round(sec1 * 1e3, 2), "threadpool4_ms_per_pair": round(sec4 * 1e3, 2),
-               # cross-check against the UNMODIFIED oracle (natural eigenvector signs, nothing borrowed from the device); the parity
-               # tests proper are tests/test_gpu_parity.py (keyframe bit-exact, X within 2e-4 m / 2e-5 rad)
+        over1 = np.nonzero((dXp[:, :3].max(1) > 1e-4) | (dXp[:, 3:].max(1) > 1e-5))[0]
+        over3 = np.nonzero((dXp[:, :3].max(1) > 3e-4) | (dXp[:, 3:].max(1) > 1e-4))[0]
+        cpu = {"value": round(m / tl, 3), "unit": "scan-pairs/s", "cores": cores, "kind": "port",
+               "sample": "first %d pairs of the same batch, one pair per host thread (oracle/icet_oracle.cpp, -O3 -march=native) in the oracle's LITERAL mode "
+                         "(glibc float atan2/acos/sin/cos, sequential float sums -- the reference's expression types), %.1f s wall" % (m, tl),
+               "literal_mode": {"pairs_per_s": round(m / tl, 3), "single_thread_ms_per_pair": round(sec1l * 1e3, 2), "threadpool4_ms_per_pair": round(sec4l * 1e3, 2)},
+               "shared_rule_mode": {"pairs_per_s": round(m / tc, 3), "single_thread_ms_per_pair": round(sec1 * 1e3, 2), "threadpool4_ms_per_pair": round(sec4 * 1e3, 2),
+                                    "note": "correctly rounded transcendentals + exact sums: the mode the parity tests compare the device with (%.1f s wall)" % tc},
+               "single_thread_ms_per_pair": round(sec1l * 1e3, 2), "threadpool4_ms_per_pair": round(sec4l * 1e3, 2),
+               # cross-check against the UNMODIFIED oracle (shared rule, natural eigenvector signs, nothing borrowed from the device); the parity
+               # tests proper are tests/test_gpu_parity.py (keyframe bit-exact, X within 2e-4 m / 2e-5 rad on every pair but the one asserted exception)
                "median_abs_dX_vs_gpu_on_sample": float(np.median(dXp.max(1))), "max_abs_dX_vs_gpu_on_sample": float(dXp.max()),
-               "pairs_over_1e-4_m_or_1e-5_rad_natural_signs": int(((dXp[:, :3].max(1) > 1e-4) | (dXp[:, 3:].max(1) > 1e-5)).sum()),
-               "pairs_over_3e-4_m_or_1e-4_rad_natural_signs": int(((dXp[:, :3].max(1) > 3e-4) | (dXp[:, 3:].max(1) > 1e-4)).sum())}
+               "pairs_over_1e-4_m_or_1e-5_rad_natural_signs": int(over1.size), "pairs_over_3e-4_m_or_1e-4_rad_natural_signs": int(over3.size),
+               "pair_ids_over_3e-4_m_or_1e-4_rad": [int(k) for k in over3]}
 
     if rank == 0:
         line = {
             "metric": "scan-pairs/sec + ms/pair, 64-ch 75x24 voxels 7 iters; HBM GB/s vs peak" if args.workload == "batch" else "scan-pairs/sec, 128-ch 150x48 voxels 10 iters",
-            "value": round(pairs_per_s, 2), "unit": "scan-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(pairs_per_s, 2), "unit": "scan-pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "ms_per_pair": round(ms_per_step / max(n_local, 1), 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timed_region": {"seconds": round(dt, 4), "repetitions_of_the_K_steps": reps_t, "steps_timed": steps_total,
+                             "ms_per_step_min": round(min(rep_ms), 4), "ms_per_step_max": round(max(rep_ms), 4)},
             "config": {"workload": ("configs[2]/[3]: %d independent 64-ch synthetic scan pairs per GPU (~%dk pts/scan, %s-major), 75x24 voxels, 7 iters, "
-                                    "pair k -> rank k mod N, RCCL all-gather of 48 floats/pair when N>1" % (n_local, int(np.mean(n2) / 1000), args.order))
+                                    "pair k -> %s k mod N, %s" % (n_local, int(np.mean(n2) / 1000), args.order, "device" if multi else "rank",
+                                                                  ("one process: icet_multi_solve_batch_device, %s gather" % args.multi_gather) if multi
+                                                                  else "RCCL all-gather of 48 floats/pair when N>1"))
                        if args.workload == "batch" else "configs[4]: single 128-ch pair (~%dk pts), 150x48 voxels, 10 iters" % int(np.mean(n2) / 1000),
                        **({"options": list(args.set)} if args.set else {}),
                        "pairs_per_gpu": n_local, "pairs_total": n_global, "points_scan1_mean": int(np.mean(n1)), "points_scan2_mean": int(np.mean(n2)),
-                       "bins_theta": T, "bins_phi": P, "iters": iters, "parallelism": "pairs round-robin x%d" % world, "gen_s": round(t_gen, 1)},
+                       "bins_theta": T, "bins_phi": P, "iters": iters, "parallelism": "pairs round-robin x%d" % n_gpus,
+                       "processes": 1 if multi else world, "mode": "multi (one process)" if multi else "one process per GPU",
+                       "rccl_ranks": (dist.get_world_size() if (world > 1 and backend == "nccl") else (args.gpus if (multi and args.multi_gather == "rccl") else 0)),
+                       "devices": dev_ids if multi else list(range(world)), "gather_ms": None if gather_ms is None else round(gather_ms, 4),
+                       "gen_s": round(t_gen, 1)},
             "roofline": {"kernel": "k_gn_accumulate", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(acc_launch_ms, 5), "launches_timed": launches,
@@ -360,14 +535,19 @@ def main():
             "cpu_baseline": cpu,
             "latency": lat,
             "highres": hires,
+            "h2d_inclusive": h2d,
             "published_reference_ms_per_pair": PUBLISHED_MS_PER_PAIR,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    if multi:
+        one_ctx.close(); mctx.close()
+    else:
+        ctx.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -25,7 +25,7 @@ FLAG_HALF_GAP_BOUNDS = 8  # non-parity extension (half-gap cluster buffers of th
 # every symbol include/icet_hip.h, include/icet_nodes.h and include/icet_io.h declare
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_batch",
                     "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
-                    "icet_multi_solve_batch", "icet_multi_solve_batch_device",
+                    "icet_multi_solve_batch", "icet_multi_solve_batch_device", "icet_multi_solve_batch_device_after", "icet_multi_set_option",
                     "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_map",
                     "icet_node_prev_scan", "icet_node_aligned", "icet_node_snail_trail", "icet_node_last_timing", "icet_stream", "icet_device",
                     "icet_load_scan", "icet_free_scan", "icet_save_scan_npy")
@@ -104,6 +104,8 @@ def load_library():
     L.icet_multi_solve_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.icet_multi_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.POINTER(DevScan), C.c_void_p, C.c_void_p]
+    L.icet_multi_solve_batch_device_after.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.POINTER(DevScan), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.icet_multi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.icet_node_create.argtypes = [C.c_void_p, C.POINTER(NodeParams), C.POINTER(C.c_void_p)]
     L.icet_node_destroy.argtypes = [C.c_void_p]
     L.icet_node_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(NodeResult)]
@@ -146,7 +148,19 @@ class Context:
         self._h = h
         self.device = device
 
+    @classmethod
+    def borrow(cls, handle, device=-1):
+        """Wrap an icet_ctx* owned by someone else (e.g. icet_multi_context): never destroyed from here."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+        self.device = device
+        self._borrowed = True
+        return self
+
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self._h = None
+            return
         for ref in getattr(self, "_nodes", []):          # nodes borrow this context: they go first
             nd = ref()
             if nd is not None:
@@ -173,8 +187,8 @@ class Context:
         self._check(load_library().icet_reserve(self._h, C.byref(params), n_pairs, total_n1, total_n2))
 
     def debug_fetch(self, what, count):
-        """Diagnostic: 'r' (float32, scan 1 in input order), 'bin' (uint16 per row: voxel id | literal-path flag << 14 |
-        swap-step flag << 15), 'src' (int32 scramble result), 'flags' (int32 per pair)."""
+        """Diagnostic: 'r' (float32, scan 1 in input order), 'bin' (uint16 per row: voxel id | literal-path flag << 14; bit 15
+        unused), 'src' (int32 scramble result), 'flags' (int32 per pair)."""
         code = {"r": 0, "bin": 1, "src": 3, "flags": 4}[what]
         out = np.zeros(count, {0: np.float32, 1: np.uint16}.get(code, np.int32))
         self._check(load_library().icet_debug_fetch(self._h, code, out.ctypes.data, count))
@@ -192,7 +206,8 @@ class Context:
                                                         C.c_void_p(d_x0_ptr) if d_x0_ptr else None, C.c_void_p(d_out_ptr)))
 
     def set_option(self, name, value):
-        """Launch-shape / diagnostic knob of this context (icet_set_option, include/icet_hip.h); results are bitwise unaffected."""
+        """Launch-shape / diagnostic knob of this context (icet_set_option, include/icet_hip.h).  Launch-shape knobs leave the result
+        bits alone; force_exact / guard_scale / lut_polar_quantile keep every decision but regroup float partial sums."""
         self._check(load_library().icet_set_option(self._h, name.encode(), float(value)))
 
     def last_timing(self):
@@ -292,13 +307,34 @@ class MultiContext:
                                                           x0.ctypes.data if x0 is not None else None, X.ctypes.data, ps.ctypes.data, cov.ctypes.data))
         return dict(X=X, pred_stds=ps, cov=cov.reshape(k, 6, 6))
 
-    def solve_batch_device(self, scan1_descs, scan2_descs, params, d_out_ptr, d_x0_ptr=None):
-        """scan*_descs[k] = (device_ptr, n, ld) on devices[k % len(devices)]; d_out / d_x0 on devices[0]."""
+    def set_option(self, name, value):
+        """"gather" (0 peer copies, 1 RCCL all-gather) or any per-context option, applied to every device (icet_multi_set_option)."""
+        self._check(load_library().icet_multi_set_option(self._h, name.encode(), float(value)))
+
+    def context_handle(self, i):
+        return load_library().icet_multi_context(self._h, int(i))
+
+    def context(self, i):
+        """The context of devices[i] as a borrowed :class:`Context` (set_option / last_timing / reserve)."""
+        return Context.borrow(self.context_handle(i), self.devices[i])
+
+    def reserve(self, params, n_pairs, total_n1, total_n2):
+        """Pre-size every device's workspace for its share of a batch (pairs round-robin: ceil(n_pairs / devices) each)."""
+        L = load_library(); D = len(self.devices)
+        for i in range(D):
+            st = L.icet_reserve(C.c_void_p(self.context_handle(i)), C.byref(params), (n_pairs + D - 1) // D, (total_n1 + D - 1) // D + 1, (total_n2 + D - 1) // D + 1)
+            if st != ICET_OK:
+                raise IcetError(st, "icet_reserve on device entry %d" % i)
+
+    def solve_batch_device(self, scan1_descs, scan2_descs, params, d_out_ptr, d_x0_ptr=None, producer_stream=None):
+        """scan*_descs[k] = (device_ptr, n, ld) on devices[k % len(devices)]; d_out / d_x0 on devices[0].  Synchronous.
+        producer_stream: raw hipStream_t of devices[0] whose queued work (the writes of d_x0 / the scans) the solve must wait for."""
         k = len(scan1_descs)
         A = (DevScan * max(k, 1))(*[DevScan(int(p), int(n), int(ld)) for (p, n, ld) in scan1_descs])
         B = (DevScan * max(k, 1))(*[DevScan(int(p), int(n), int(ld)) for (p, n, ld) in scan2_descs])
-        self._check(load_library().icet_multi_solve_batch_device(self._h, C.byref(params), k, A, B,
-                                                                 C.c_void_p(d_x0_ptr) if d_x0_ptr else None, C.c_void_p(d_out_ptr)))
+        self._check(load_library().icet_multi_solve_batch_device_after(self._h, C.byref(params), k, A, B,
+                                                                       C.c_void_p(d_x0_ptr) if d_x0_ptr else None, C.c_void_p(d_out_ptr),
+                                                                       C.c_void_p(producer_stream) if producer_stream else None))
 
 
 _default_ctx = {}

@@ -61,6 +61,13 @@ __device__ __noinline__ void spill_flush(uint32_t* A, uint32_t nraw, uint32_t ni
     acc_add_hbm(A, nraw, nin, S0, S1, S2, S3, S4, S5, S6, S7, S8);
 }
 
+// A flush whose values may leave the range of the two-instruction conversion (to_fix_biased): exact wide conversion, same bias.
+__device__ __noinline__ void flush_wide(unsigned long long* F, float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {
+    atomicAdd(&F[1], to_fix_wide_biased(a0)); atomicAdd(&F[2], to_fix_wide_biased(a1)); atomicAdd(&F[3], to_fix_wide_biased(a2)); atomicAdd(&F[4], to_fix_wide_biased(a3));
+    atomicAdd(&F[5], to_fix_wide_biased(a4)); atomicAdd(&F[6], to_fix_wide_biased(a5)); atomicAdd(&F[7], to_fix_wide_biased(a6)); atomicAdd(&F[8], to_fix_wide_biased(a7));
+    atomicAdd(&F[9], to_fix_wide_biased(a8));
+}
+
 constexpr int kCntBits = 21;            // LDS count word: three 21-bit fields
 constexpr unsigned long long kCntMask = (1ull << kCntBits) - 1ull;
 constexpr uint32_t kNearCap = 512;      // undecided points a block parks in LDS (2 KB); the rest goes to the per-pair overflow list in HBM
@@ -150,9 +157,15 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
                   unsigned long long* F = lacc + slot * 10;
                   atomicAdd(&F[0], (unsigned long long)cr | ((unsigned long long)ci << kCntBits) | ((ci ? 1ull : 0ull) << (2 * kCntBits)));
                   if (ci) {
-                      atomicAdd(&F[1], to_fix_biased(a0)); atomicAdd(&F[2], to_fix_biased(a1)); atomicAdd(&F[3], to_fix_biased(a2)); atomicAdd(&F[4], to_fix_biased(a3));
-                      atomicAdd(&F[5], to_fix_biased(a4)); atomicAdd(&F[6], to_fix_biased(a5)); atomicAdd(&F[7], to_fix_biased(a6)); atomicAdd(&F[8], to_fix_biased(a7));
-                      atomicAdd(&F[9], to_fix_biased(a8));
+                      // the two-instruction conversion holds below 2^15 m^2; the three squared sums bound the other six values (kFixFastMax).
+                      // Wave-uniform test: ordinary grids never leave the first branch (coarse grid x long range does: ADVICE r2)
+                      if (__ballot(!(fmaxf(fmaxf(a3, a6), a8) < kFixFastMax)) == 0ull) {
+                          atomicAdd(&F[1], to_fix_biased(a0)); atomicAdd(&F[2], to_fix_biased(a1)); atomicAdd(&F[3], to_fix_biased(a2)); atomicAdd(&F[4], to_fix_biased(a3));
+                          atomicAdd(&F[5], to_fix_biased(a4)); atomicAdd(&F[6], to_fix_biased(a5)); atomicAdd(&F[7], to_fix_biased(a6)); atomicAdd(&F[8], to_fix_biased(a7));
+                          atomicAdd(&F[9], to_fix_biased(a8));
+                      } else {
+                          flush_wide(F, a0, a1, a2, a3, a4, a5, a6, a7, a8);
+                      }
                   }
               } else {
                   spill_flush(gacc + (size_t)slot * kAccWords, cr, ci, a0, a1, a2, a3, a4, a5, a6, a7, a8);

@@ -79,6 +79,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
     if (total_n1 >= (int64_t)1 << 31) { c->err = "total scan-1 points per call must be < 2^31"; return ICET_ERR_UNSUPPORTED; }
     const bool grow_pairs = n_pairs > w.cap_pairs || V > w.cap_V;
     if (grow_pairs) {
+        c->kf_pairs = 0;                       // the parked keyframe's tables (hotS / fitS / slot_of_voxel / n_slots / acc) are about to be re-allocated
         const int np = n_pairs > w.cap_pairs ? n_pairs : w.cap_pairs;
         const int VV = V > w.cap_V ? V : w.cap_V;
         const size_t pv = (size_t)np * VV;
@@ -115,6 +116,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         const int64_t n = total_n1 > w.cap_n1 ? total_n1 : w.cap_n1;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (n > w.cap_n1) {
+            c->kf_pairs = 0;
             HIPCHK(c, dev_realloc(w.r1, n)); HIPCHK(c, dev_realloc(w.cart1, (size_t)3 * n));
             HIPCHK(c, dev_realloc(w.key64A, n)); HIPCHK(c, dev_realloc(w.key64B, n)); HIPCHK(c, dev_realloc(w.bin16, n)); HIPCHK(c, dev_realloc(w.binpos, n)); HIPCHK(c, dev_realloc(w.bkt, n));
             HIPCHK(c, dev_realloc(w.keyA, n)); HIPCHK(c, dev_realloc(w.keyB, n)); HIPCHK(c, dev_realloc(w.valA, n)); HIPCHK(c, dev_realloc(w.valB, n));
@@ -422,6 +424,7 @@ static icet_status ensure_helpers(icet_ctx* c, int parts);
 icet_status icet_reserve(icet_ctx* c, const icet_params* p, int32_t n_pairs, int64_t total_n1, int64_t total_n2) {
     if (!c || !params_ok(p) || n_pairs < 0 || total_n1 < 0 || total_n2 < 0) return ICET_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    c->kf_pairs = 0;                           // a reservation may move the tables a parked keyframe lives in
     const int parts = batch_parts(c, p, n_pairs);
     if (parts > 1) {            // the batch will be solved in parts (icet_solve_batch_device); 12.5 % headroom for uneven scans
         icet_status hs = ensure_helpers(c, parts);
@@ -519,6 +522,7 @@ icet_status icet_solve_batch_device(icet_ctx* c, const icet_params* p, int32_t n
 static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1, const icet_dev_scan* scan2,
                                      const float* d_x0, float* d_out, int64_t tot1) {
     int64_t tot2 = 0; for (int k = 0; k < n_pairs; k++) tot2 += scan2[k].n;
+    c->kf_pairs = 0;                           // whatever keyframe was parked here is gone (runlen == 0 included: h_desc is overwritten below)
     icet_status s = ensure_workspace(c, p, n_pairs, tot1, tot2);
     if (s != ICET_OK) return s;
     // the previous call may still be copying out of the pinned descriptor staging; its kernels may still be running
@@ -564,7 +568,7 @@ icet_status icet_register_device(icet_ctx* c, const icet_params* p, int32_t n_pa
     if (!params_ok(p) || n_pairs < 1 || !scan2 || !d_out) { c->err = "bad argument"; return ICET_ERR_BAD_ARG; }
     const icet_params& q = c->kf_params;
     if (c->kf_pairs != n_pairs || q.bins_phi != p->bins_phi || q.bins_theta != p->bins_theta || q.n != p->n || q.thresh != p->thresh || q.buff != p->buff ||
-        ((q.flags ^ p->flags) & ICET_FLAG_TRUE_SORT)) { c->err = "no keyframe with these parameters is parked in this context (icet_keyframe_device)"; return ICET_ERR_BAD_ARG; }
+        ((q.flags ^ p->flags) & (ICET_FLAG_TRUE_SORT | ICET_FLAG_HALF_GAP_BOUNDS))) { c->err = "no keyframe with these parameters is parked in this context (icet_keyframe_device)"; return ICET_ERR_BAD_ARG; }
     int64_t tot2 = 0;
     for (int k = 0; k < n_pairs; k++) {
         const icet_dev_scan& b = scan2[k];

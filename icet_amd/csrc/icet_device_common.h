@@ -240,13 +240,27 @@ __device__ __forceinline__ void classify_literal(float qx, float qy, float qz, c
 // to_fix_biased leaves the bias in: a sum of n such words is n * kFixBias + the sum of the integers (mod 2^64), so a block that
 // counts its conversions takes the bias out once per slot instead of once per value (k_gn_accumulate): two VALU instructions
 // per value (v_cvt_f64_f32, v_add_f64 with a scalar constant).
+// RANGE.  The trick holds for |v| < 2^15 m^2 only: beyond it the sum leaves the binade and the mantissa no longer holds the integer.
+// A partial sum of <= 4 squared distances to mu1 stays far below that on an ordinary grid (a 75 x 24 voxel at 100 m is ~13 m wide),
+// but a coarse grid (4 x 2 bins) with long ranges reaches it (d ~ 100 m: 4 d^2 = 40 000).  Such values take to_fix_wide: for
+// |v| >= 2^15 a float is a multiple of 2^-8, so v * 2^36 is an integer and the conversion is exact -- the same round-to-nearest
+// rule, trivially.  k_gn_accumulate tests a whole flush at once (kFixFastMax on the three squared sums, which bound the other six)
+// in a wave-uniform branch; the rare paths (to_fix below) select per value.  Totals have 2^27 m^2 of headroom; past that the
+// two's-complement sum wraps (a reference in float has lost every digit of such a voxel long before).
 static_assert(kFixScale == 68719476736.0f, "kFixMagic / kFixBias below are written for a scale of 2^36");
 constexpr double kFixMagic = 98304.0;                               // 1.5 * 2^(52 - 36)
 constexpr unsigned long long kFixBias = 0x40F8000000000000ULL;      // its bit pattern
+constexpr float kFixFastMax = 16384.0f;                             // squared sums below 2^14 keep every one of the 9 values of a flush below 2^15 (|cross| <= max square, rounding included)
 __device__ __forceinline__ unsigned long long to_fix_biased(float v) {
     return (unsigned long long)__double_as_longlong((double)v + kFixMagic);
 }
-__device__ __forceinline__ unsigned long long to_fix(float v) { return to_fix_biased(v) - kFixBias; }
+// any finite float (saturating far outside the accumulator's range); carries the same bias so that a block's conversion count stays right
+__device__ __forceinline__ unsigned long long to_fix_wide_biased(float v) {
+    return (unsigned long long)__double2ll_rn((double)v * 68719476736.0) + kFixBias;
+}
+__device__ __forceinline__ unsigned long long to_fix(float v) {
+    return ((fabsf(v) < 32768.0f) ? to_fix_biased(v) : to_fix_wide_biased(v)) - kFixBias;
+}
 
 // One run's partial sums into a slot's HBM accumulator record (kAccWords words: [raw | in << 32], then 9 fixed-point sums).
 __device__ __forceinline__ void acc_add_hbm(uint32_t* A, uint32_t nraw, uint32_t nin, float S0, float S1, float S2, float S3, float S4,

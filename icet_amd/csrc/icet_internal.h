@@ -14,7 +14,7 @@ constexpr int kAccLds   = 20;        // in LDS: the same 80-byte record per slot
 // Why 2^36 and not coarser: a voxel holding ~27 points of ONE lidar ring is a line whose covariance has a smallest eigenvalue of
 // ~5e-8 m^2, i.e. a scatter of 1.4e-6 m^2 in that direction, and it enters H^T W H with a weight of 1 / lambda_min; at 2^-30 the
 // truncation of ~15 flushes biased that scatter by 0.5 % (round 2, scripts/diag_voxel.py 61).  A flushed value is the partial sum
-// of at most 4 points, far below 2^15 (to_fix needs |v| * 2^36 < 2^51); the accumulated totals have 2^27 m^2 of headroom.
+// of at most 4 points; values of 2^15 m^2 and more (coarse grids x long ranges) take the wide conversion (icet_device_common.h, to_fix); the totals have 2^27 m^2 of headroom.
 constexpr float kFixScale = 68719476736.0f;           // 2^36
 constexpr double kFixInv = 1.0 / 68719476736.0;
 #ifndef ICET_RS_BUCKET_BITS

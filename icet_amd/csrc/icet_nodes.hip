@@ -252,7 +252,7 @@ icet_status ensure_scan(icet_node* nd, int which, int64_t n) {
 }
 
 // One frame with the raw scan already in HBM (column-major, ld).
-icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t ld, icet_node_result* res) {
+icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld, icet_node_result* res) {
     std::memset(res, 0, sizeof(*res));
     hipStream_t st = nd->stream;
     const int cur = nd->prev ^ 1;
@@ -314,6 +314,7 @@ icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t l
     // and Fisher-Yates over ~10^5 indices costs about as much host time as the solve costs device time: a helper thread shuffles
     // while this one enqueues the solve.  (The previous frame's map kernel, which read d_idx, finished before the row-count sync.)
     int m_map = 0;
+    bool flip_owner = false;
     std::future<int> shuffle;
     if (nd->p.map_capacity > 0) {
         shuffle = std::async(std::launch::async, [nd, nk]() {
@@ -342,7 +343,7 @@ icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t l
         NCHK(nd, hipEventRecord(nd->ev[2], so));
         s = icet_keyframe_device(oth, &sp, 1, &b);
         if (s != ICET_OK) { nd->err = icet_last_error(oth); return s; }
-        nd->owner ^= 1;
+        flip_owner = true;                                        // committed together with nd->prev once the frame has succeeded
     } else {
         NCHK(nd, hipMemcpyAsync(nd->d_x0, nd->h_x0, sizeof(float) * 6, hipMemcpyHostToDevice, st));
         s = icet_solve_batch_device(nd->ctx, &sp, 1, &a, &b, nd->d_x0, nd->d_out);
@@ -414,6 +415,7 @@ icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t l
         }
     }
     nd->prev = cur;                                               // prev_pcl_matrix = pcl_matrix (odometry.cpp:88)
+    if (flip_owner) nd->owner ^= 1;                               // ... and the keyframe parked for it becomes the one the next frame registers against
     // X_homo = X_homo * X_homo_i (odometry.cpp:91-98)
     const float Hi[16] = {R[0], R[1], R[2], X[0], R[3], R[4], R[5], X[1], R[6], R[7], R[8], X[2], 0, 0, 0, 1};
     float P[16];
@@ -424,6 +426,25 @@ icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t l
     res->map_rows = nd->map_filled ? nd->p.map_capacity : nd->map_pos;
     nd->timing_valid = true;
     return ICET_OK;
+}
+
+// No exception may cross the C ABI (std::async can throw std::system_error, the shuffle's vector bad_alloc -- rethrown by get()), and
+// a frame that fails half way must not leave the node's idea of "previous scan" and the parked keyframe disagreeing: on ANY failure
+// the device is drained and the node drops back to "no previous scan" -- the next cloud is stored like the first one
+// (odometry.cpp:46-52) and the pose chain continues from where it was.
+icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t ld, icet_node_result* res) {
+    icet_status s;
+    const bool was_initialized = nd->initialized;
+    try {
+        s = push_frame(nd, d_scan, n, ld, res);
+    } catch (const std::bad_alloc&) { nd->err = "out of host memory"; s = ICET_ERR_NOMEM;
+    } catch (const std::exception& e) { nd->err = std::string("host error: ") + e.what(); s = ICET_ERR_NOMEM;
+    } catch (...) { nd->err = "host error"; s = ICET_ERR_NOMEM; }
+    if (s != ICET_OK && was_initialized) {
+        (void)hipDeviceSynchronize();
+        nd->initialized = false; nd->timing_valid = false;
+    }
+    return s;
 }
 
 }  // namespace

@@ -1,12 +1,9 @@
-// icet_amd/csrc/icet_sort.hip -- stable key/value radix sorts used by the keyframe (scan-1) build.
+// icet_amd/csrc/icet_sort.hip -- the A/B alternative to the hand-written rank sort: rocPRIM (through hipCUB) radix sorts.
 //
-// The reference sorts scan 1 by radial distance with std::sort(std::execution::par) on an index
-// vector (/root/reference/src/icet.cpp:72-77); tie order is unspecified there and fixed here as
-// "stable by original index", which an LSD radix sort gives for free.  A second stable sort by
-// angular-bin id recovers the ascending-position order inside each bin that
-// sortSphericalCoordinates' push_back produces (src/icet.cpp:534-554).
-// Sorting is a plain library operation (rocPRIM through hipCUB); everything else on the path is
-// hand-written in icet_kernels.hip.
+// Reached ONLY through icet_set_option("library_sort", 1) (off by default; kept to measure the rank sort of icet_ranksort.hip
+// against a library sort).  The reference sorts scan 1 by radial distance with std::sort(std::execution::par) on an index
+// vector (/root/reference/src/icet.cpp:72-77); tie order is unspecified there and fixed on this path as "stable by original
+// index", which an LSD radix sort gives for free.
 #include <hipcub/hipcub.hpp>
 #include "icet_internal.h"
 

@@ -54,9 +54,10 @@ enum { ICET_FLAG_NONE = 0,
                                   (start_RM_iter = 4), a voxel whose compact residual L U^T (mu2 - mu1) exceeds RM_thresh = 0.3 m in any
                                   kept axis is left out of that iteration's H^T W H and H^T W dz.  The C++ reference has nothing like it, so
                                   results differ from it by design; the oracle has the same switch (ICET_ORACLE_REJECT_MOVING). */
-       ICET_FLAG_HALF_GAP_BOUNDS = 8 /* NON-PARITY EXTENSION: the cluster buffers of the reference's Python variant
-                                  (python/utils.py:92-119, "as described in spherical paper"): the radial bounds of a voxel's cluster reach
-                                  half way to the nearest point outside it, at most `buff`, instead of `buff` on either side (a neighbour
+       ICET_FLAG_HALF_GAP_BOUNDS = 8 /* NON-PARITY EXTENSION: the cluster buffers the reference's Python variant
+                                  DESCRIBES ("as described in spherical paper", the comments at python/utils.py:92-119 -- the TensorFlow
+                                  code there adds the FULL gap when 2*gap < max_buffer, which is not this rule): the radial bounds of a
+                                  voxel's cluster reach half way to the nearest point outside it, at most `buff`, instead of `buff` on either side (a neighbour
                                   that exists is more than `thresh` away, so this only tightens bounds whose neighbour lies within 2 buff).
                                   Needs the voxel's rows in ascending range, so it implies ICET_FLAG_TRUE_SORT.  Oracle twin:
                                   ICET_ORACLE_HALF_GAP. */ };
@@ -149,15 +150,17 @@ icet_status icet_last_timing(icet_ctx* ctx, float out_ms[4]);
  * of the most recent call to the host.  `what`: 0 = float32 r of scan 1 in input order
  * (utils::cartesianToSpherical, src/utils.cpp:99,116); 1 = uint16 per row: bits 0-13 the row's voxel
  * bins_theta * binPhi + binTheta (sortSphericalCoordinates, src/icet.cpp:545-549), bit 14 "classified with
- * the literal formulas", bit 15 "the swap loop executes its step at this row" (theta / phi themselves are
- * not materialised: only decisions and the Gaussians need them); 3 = int32 src[v], the original row that
+ * the literal formulas", bit 15 unused (theta / phi themselves are not materialised: only decisions and the
+ * Gaussians need them); 3 = int32 src[v], the original row that
  * sits at position v after the reference's sort + swap loop (src/icet.cpp:72-83); 4 = int32 per-pair
  * flags (bit 0: the bounded parallel walk overflowed and the serial replay was used).  `count` elements
  * from the start of the batch's concatenated scan-1 arrays (pairs for what = 4). */
 icet_status icet_debug_fetch(icet_ctx* ctx, int32_t what, void* out, int64_t count);
 
-/* Launch-shape and diagnostic knobs of ONE context (the library never reads the environment).  Every value
- * yields the same result bits; defaults are the measured optima.  Names: "lds_slots", "acc_pts",
+/* Launch-shape and diagnostic knobs of ONE context (the library never reads the environment).  Defaults are the measured
+ * optima.  Launch-shape knobs yield the same result bits; "force_exact", "guard_scale" and "lut_polar_quantile" preserve every
+ * DECISION (the per-voxel counts n2_raw / n2_in) but move points between the 4-point runs and the runs of one, i.e. they regroup
+ * float partial sums: X agrees to rounding, not bitwise.  Names: "lds_slots", "acc_pts",
  * "acc_blocks", "kf_pts", "rs_cap", "rs_max_cell" (0: per-bucket radix sort instead of the counting sort),
  * "exec_bits_lds" (0: swap-loop bit table read from memory), "batch_parts" (0 = automatic), "batch_stage" (0..4), "force_exact"
  * (every scan-2 point through the literal classification), "library_sort" (rocPRIM radix sort instead of
@@ -170,24 +173,35 @@ void* icet_stream(icet_ctx* ctx);
 int   icet_device(const icet_ctx* ctx);
 
 /* --- the batched-pairs case over several GPUs of one node (BASELINE.json configs[3]) ---------
- * The reference has no counterpart: it constructs one ICET object per pair on the calling thread.  A handle owns one context per
- * device; pair k of a call runs on device_ids[k mod n_devices] from its own host thread, and the 48 result floats per pair are
- * gathered into ONE buffer -- the caller's host arrays, or HBM of device_ids[0] through peer copies over xGMI.  There is no
- * data-path collective; a process that runs one rank per GPU gathers with torch.distributed / RCCL instead (icet_amd/dist.py). */
+ * The reference has no counterpart: it constructs one ICET object per pair on the calling thread.  A handle owns one context and
+ * one persistent host thread per device; pair k of a call runs on device_ids[k mod n_devices], and the 48 result floats per pair
+ * are gathered into ONE buffer -- the caller's host arrays, or HBM of device_ids[0].  There is no data-path collective.  The
+ * device-resident gather is, by option "gather": 0 (default) one strided peer copy per device over xGMI (peer access between
+ * device_ids[0] and the others is enabled at create), or 1 ONE ncclAllGather over a communicator of the handle's devices (RCCL,
+ * dlopen'ed on first use; needs distinct device ids) followed by the de-interleave on device_ids[0].  A process that runs one
+ * rank per GPU gathers with torch.distributed / RCCL instead (icet_amd/dist.py). */
 typedef struct icet_multi icet_multi;
 icet_status icet_multi_create(icet_multi** handle, const int32_t* device_ids, int32_t n_devices);   /* each id < device count; an id may repeat (one context per ENTRY) */
 icet_status icet_multi_destroy(icet_multi* handle);
 const char* icet_multi_last_error(const icet_multi* handle);
 int32_t     icet_multi_devices(const icet_multi* handle);
-icet_ctx*   icet_multi_context(icet_multi* handle, int32_t i);      /* the context of device_ids[i] (e.g. for icet_set_option / icet_reserve) */
+icet_ctx*   icet_multi_context(icet_multi* handle, int32_t i);      /* the context of device_ids[i] (e.g. for icet_reserve) */
+/* "gather" (above), or any icet_set_option name, applied to every device's context. */
+icet_status icet_multi_set_option(icet_multi* handle, const char* name, double value);
 /* HOST pointers in and out, same meaning as icet_solve_batch. */
 icet_status icet_multi_solve_batch(icet_multi* handle, const icet_params* p, int32_t n_pairs,
                                    const float* const* scan1, const int64_t* n1, const float* const* scan2, const int64_t* n2,
                                    const float* x0, float* x_out, float* pred_stds_out, float* cov_out);
 /* Scans resident in HBM: scan1[k] / scan2[k] on device_ids[k mod n_devices]; d_x0 (n_pairs x 6 or NULL) and d_out (n_pairs x 48,
- * layout of icet_solve_batch_device) on device_ids[0].  Returns after the gather has completed. */
+ * layout of icet_solve_batch_device) on device_ids[0].  Returns after the gather has completed (synchronous).  The devices'
+ * streams are the handle's own: the scans, d_x0 and whatever last used d_out must have COMPLETED before the call -- or, for work
+ * queued on one stream of device_ids[0], use the _after form: an event recorded on `producer_stream` (hipStream_t as void*, NULL =
+ * none) when the call starts is waited for by every device's stream. */
 icet_status icet_multi_solve_batch_device(icet_multi* handle, const icet_params* p, int32_t n_pairs,
                                           const icet_dev_scan* scan1, const icet_dev_scan* scan2, const float* d_x0, float* d_out);
+icet_status icet_multi_solve_batch_device_after(icet_multi* handle, const icet_params* p, int32_t n_pairs,
+                                                const icet_dev_scan* scan1, const icet_dev_scan* scan2, const float* d_x0, float* d_out,
+                                                void* producer_stream);
 
 #ifdef __cplusplus
 }

@@ -89,7 +89,46 @@ def test_multi_device_entry_validates_arguments_without_gpu():
     assert lib.icet_multi_last_error(None) == b"null handle" and lib.icet_multi_devices(None) == 0 and lib.icet_multi_context(None, 0) is None
     assert lib.icet_multi_solve_batch(None, None, 0, None, None, None, None, None, None, None, None) == A.ICET_ERR_BAD_ARG
     assert lib.icet_multi_solve_batch_device(None, None, 0, None, None, None, None) == A.ICET_ERR_BAD_ARG
+    assert lib.icet_multi_solve_batch_device_after(None, None, 0, None, None, None, None, None) == A.ICET_ERR_BAD_ARG
+    assert lib.icet_multi_set_option(None, b"gather", 1.0) == A.ICET_ERR_BAD_ARG
     assert lib.icet_set_option(None, b"lds_slots", 1.0) == A.ICET_ERR_BAD_ARG
+
+
+# ------------------------------------------------------------------ bench.py: `--gpus N` measures N GPUs or refuses (missing #1)
+def _bench(*argv, env=None, timeout=300):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_plans_its_processes_before_touching_the_gpu():
+    import json
+    # no launcher in the environment: N > 1 starts one -- the driver's own command line -- as a child
+    out = _bench("--gpus", "8", "--steps", "5", "--warmup", "2", "--dry-run-launch")
+    d = json.loads(out.stdout)
+    cmd = d["command"]
+    assert d["action"] == "spawn" and cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"] and "--dry-run-launch" not in cmd
+    # under the driver's launcher the script is a rank; a launcher of another size is refused, never silently shrunk
+    assert json.loads(_bench("--gpus", "8", "--dry-run-launch", env={"WORLD_SIZE": "8", "RANK": "3"}).stdout)["action"] == "run"
+    assert json.loads(_bench("--gpus", "8", "--dry-run-launch", env={"WORLD_SIZE": "4"}).stdout)["action"] == "refuse"
+    assert json.loads(_bench("--gpus", "8", "--dry-run-launch", env={"WORLD_SIZE": "1"}).stdout)["action"] == "refuse"
+    assert json.loads(_bench("--gpus", "1", "--dry-run-launch").stdout)["action"] == "run"
+    # the one-process form never runs under a multi-rank launcher
+    assert json.loads(_bench("--gpus", "4", "--multi", "--dry-run-launch").stdout)["action"] == "run"
+    assert json.loads(_bench("--gpus", "4", "--multi", "--dry-run-launch", env={"WORLD_SIZE": "4"}).stdout)["action"] == "refuse"
+    r = _bench("--gpus", "8", env={"WORLD_SIZE": "4"})
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode of the self-launched ranks")
+def test_bench_self_launch_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2` really starts two ranks through torch.distributed.run; on this box they find no GPU, and the parent
+    relays the failure: non-zero exit, no JSON line -- never a silent one-GPU (or zero-GPU) measurement."""
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", timeout=600)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "starting" in r.stderr and "torch.distributed.run" in r.stderr and "needs a GPU" in r.stderr
 
 
 def test_eigen_adapter_header_compiles_against_the_mock(tmp_path):

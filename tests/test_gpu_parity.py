@@ -7,16 +7,16 @@ against the UNMODIFIED oracle -- natural eigenvector signs, nothing borrowed fro
   * the whole keyframe table is bit-exact: per-row r and voxel, the scramble, per-bin counts, cluster bounds, has_fit,
     mu1, sigma1, the eigenvectors (signs included) and the L masks;
   * the Gauss-Newton loop differs in two documented places -- the device does not round-trip scan 2 through spherical
-    coordinates (<= 2 ulp per point) and reduces the per-voxel terms in another order -- so X, pred_stds and cov agree to
-    float tolerance.  MEASURED over the 256-pair bench batch (scripts/diag_batch_vs_oracle.py, profiles/r02_parity_batch.json):
-    |dX_t| median 9.7e-7 m, p99 4.3e-4, max 7.6e-4; |dX_r| median 9.0e-8 rad, max 4.4e-5; pred_stds 1.5 % and cov 3.0 %
-    relative at most; 248 of 256 pairs within SURVEY 8(c)'s starting values (1e-4 m, 1e-5 rad).  The tail is one kind of
-    voxel: ~27 points of a single lidar ring, a LINE whose scan-2 covariance has a smallest eigenvalue of ~5e-8 m^2 made of
-    rounding alone; kept by all three axes of L it carries up to 20 % of H^T W H with a weight of 1/lambda_min, and the
-    oracle's spherical round trip of scan 2 (1e-6 m per point) moves that eigenvalue by several per cent
-    (scripts/diag_voxel.py 61).  The same oracle run with glibc's float functions instead of the shared rule moves further
-    (11 pairs beyond 3e-4 m, max 0.2 m).  The bounds below are 2x the measured maxima -- no sign alignment, no outliers
-    allowed -- and test_many_pairs_parity_natural_signs also holds the DISTRIBUTION (median, share within the starting values).
+    coordinates (<= 2 ulp per point) and forms the per-voxel moments in one pass about mu1 -- so X, pred_stds and cov agree to
+    float tolerance.  MEASURED over the whole 256-pair bench batch (scripts/diag_batch_vs_oracle.py -> profiles/r03_parity_batch.txt,
+    scripts/diag_rt2_all.py -> profiles/r03_diag_rt2_all.txt): |dX_t| median 4.4e-7 m, p99 7.5e-5; 255 of 256 pairs within SURVEY
+    8(c)'s starting values (1e-4 m, 1e-5 rad), max 9.6e-5 m / 4.7e-6 rad among them; pred_stds within 1.2 %, cov within 2.5 %.
+    What is left on those 255 pairs IS the skipped round trip: against the oracle run with the same skip (ICET_ORACLE_SKIP_RT2) the
+    six worst pairs drop from 6e-5..1e-4 m to 6e-8..4e-6 m, and the pred_stds outlier (pair 39, 1.2 %) disappears.  The one
+    exception, pair 232 (9.2e-4 m), is not explained by it (1.1e-3 m against the skipping oracle): the oracle's own answer on that
+    pair moves by 1.8e-3 m under a 1-ulp perturbation of scan 2.  The bounds below are 2x the measured maxima -- no sign alignment --
+    and test_many_pairs_parity_natural_signs holds them on EVERY pair of the batch, allowing at most one exception, which must lie
+    within 1x the oracle's own 1-ulp sensitivity computed in the test.
 """
 import os
 import numpy as np
@@ -507,36 +507,52 @@ def test_cpp_host_class_demo(tmp_path, gpu_ctx, frames, frames_golden):
 
 
 def test_many_pairs_parity_natural_signs(gpu_ctx):
-    """The first 128 pairs of the bench batch against the UNMODIFIED oracle.  The reference's result depends on the signs of the
-    scan-1 eigenvectors (rows-of-V sigma points; `L*U^T` with U = V^T applies V, Q8 -- one 27-point far voxel of pair
-    159 changes its 6x6 contribution 18-fold under a flip), and on near-degenerate covariances the QR iteration's signs turn on
-    the last bits of sigma1.  With one arithmetic rule on both sides those bits are the same, so nothing is borrowed from the
-    device: the keyframe table must be bit-exact on EVERY pair, X / pred_stds / cov must lie within the stated bounds on EVERY
-    pair (no outliers allowed), and the distribution must be the measured one: median below 5e-6 m, at least 93 % of the pairs
-    within SURVEY 8(c)'s starting values of 1e-4 m / 1e-5 rad."""
+    """ALL 256 pairs of the headline batch (BASELINE configs[2]) against the UNMODIFIED oracle.  The reference's result depends on
+    the signs of the scan-1 eigenvectors (rows-of-V sigma points; `L*U^T` with U = V^T applies V, Q8 -- one 27-point far
+    voxel of pair 159 changes its 6x6 contribution 18-fold under a flip), and on near-degenerate covariances the QR iteration's
+    signs turn on the last bits of sigma1.  With one arithmetic rule on both sides those bits are the same, so nothing is borrowed
+    from the device: the keyframe table must be bit-exact on EVERY pair; X / pred_stds / cov must lie within the stated bounds on
+    every pair with AT MOST ONE exception (measured: pair 232), and the exception must lie within 1x the oracle's own sensitivity to
+    a 1-ulp perturbation of scan 2, computed here; the distribution must be the measured one: median below 5e-6 m, at least 97 % of
+    the pairs within SURVEY 8(c)'s starting values of 1e-4 m / 1e-5 rad."""
+    from concurrent.futures import ThreadPoolExecutor
     from icet_amd import lidar_sim as ls
     from oracle import pyoracle as po
     dev = torch.device("cuda", 0)
-    dts, drs, worst = [], [], np.zeros(4)
-    for k in range(128):
-        s1, s2, _ = ls.make_batch_pair(k, device=dev)
-        a, b = s1.T.cpu().numpy(), s2.T.cpu().numpy()
-        g = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
-        ref = po.solve(a, b, trace=True)
-        t, ax = ref["trace"], g["aux"]
-        f = t["has_fit"] == 1
-        assert np.array_equal(ax["n1_raw"], t["n1_raw"]) and np.array_equal(ax["cluster_bounds"], t["bounds"]) and np.array_equal(ax["has_fit"], t["has_fit"]), k
-        for name_g, name_o in (("mu1", "mu1"), ("sigma1", "sigma1"), ("evecs1", "evecs1"), ("l_diag", "Ldiag")):
-            assert np.array_equal(ax[name_g][f].view(np.uint32), t[name_o][f].view(np.uint32)), (k, name_g)
-        _check_solution(g, ref)
-        dts.append(np.abs(g["X"][:3] - ref["X"][:3]).max()); drs.append(np.abs(g["X"][3:] - ref["X"][3:]).max())
-        dd = np.sqrt(np.abs(np.diag(ref["cov"])))
-        worst = np.maximum(worst, [dts[-1], drs[-1], np.abs(g["pred_stds"] / ref["pred_stds"] - 1).max(), (np.abs(g["cov"] - ref["cov"]) / np.outer(dd, dd)).max()])
-    dts, drs = np.array(dts), np.array(drs)
+    N = 256
+    dts, drs, worst, outside = np.zeros(N), np.zeros(N), np.zeros(4), []
+    with ThreadPoolExecutor(min(os.cpu_count() or 1, 16)) as ex:
+        for k0 in range(0, N, 32):                                  # 32 pairs at a time: the oracle runs on the host cores while the device solves
+            ks = list(range(k0, min(k0 + 32, N)))
+            host = []
+            for k in ks:
+                s1, s2, _ = ls.make_batch_pair(k, device=dev)
+                host.append((s1.T.cpu().numpy(), s2.T.cpu().numpy()))
+            futs = [ex.submit(po.solve, a, b, trace=True) for a, b in host]
+            gpus = [gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True) for a, b in host]
+            for k, (a, b), g, fu in zip(ks, host, gpus, futs):
+                ref = fu.result()
+                t, ax = ref["trace"], g["aux"]
+                f = t["has_fit"] == 1
+                assert np.array_equal(ax["n1_raw"], t["n1_raw"]) and np.array_equal(ax["cluster_bounds"], t["bounds"]) and np.array_equal(ax["has_fit"], t["has_fit"]), k
+                for name_g, name_o in (("mu1", "mu1"), ("sigma1", "sigma1"), ("evecs1", "evecs1"), ("l_diag", "Ldiag")):
+                    assert np.array_equal(ax[name_g][f].view(np.uint32), t[name_o][f].view(np.uint32)), (k, name_g)
+                dts[k] = np.abs(g["X"][:3] - ref["X"][:3]).max(); drs[k] = np.abs(g["X"][3:] - ref["X"][3:]).max()
+                try:
+                    _check_solution(g, ref)
+                except AssertionError:
+                    outside.append(k)
+                    sens = oracle_sensitivity(a, b)
+                    print("pair %d outside the bounds: |dX_t| %.3g m, |dX_r| %.3g rad; oracle 1-ulp sensitivity %.3g m / %.3g rad" % (k, dts[k], drs[k], sens[:3].max(), sens[3:].max()))
+                    assert dts[k] <= sens[:3].max() and drs[k] <= max(sens[3:].max(), TOL_R), (k, dts[k], drs[k], sens)
+                    continue
+                dd = np.sqrt(np.abs(np.diag(ref["cov"])))
+                worst = np.maximum(worst, [dts[k], drs[k], np.abs(g["pred_stds"] / ref["pred_stds"] - 1).max(), (np.abs(g["cov"] - ref["cov"]) / np.outer(dd, dd)).max()])
     within = ((dts <= 1e-4) & (drs <= 1e-5)).mean()
-    print("128 pairs, natural signs: max |dX_t| %.3g m, |dX_r| %.3g rad, rel pred_stds %.3g, rel cov %.3g; median |dX_t| %.3g; within 1e-4 m / 1e-5 rad: %.1f %%"
-          % (*worst, np.median(dts), 100 * within))
-    assert np.median(dts) < 5e-6 and np.median(drs) < 5e-7 and within >= 0.93, (np.median(dts), np.median(drs), within)
+    print("%d pairs, natural signs: outside the bounds %s; among the rest max |dX_t| %.3g m, |dX_r| %.3g rad, rel pred_stds %.3g, rel cov %.3g; median |dX_t| %.3g; within 1e-4 m / 1e-5 rad: %.1f %%"
+          % (N, outside, *worst, np.median(dts), 100 * within))
+    assert len(outside) <= 1, outside
+    assert np.median(dts) < 5e-6 and np.median(drs) < 5e-7 and within >= 0.97, (np.median(dts), np.median(drs), within)
 
 
 def test_keyframe_and_register_halves_equal_the_whole_solve(gpu_ctx):
@@ -617,7 +633,28 @@ def test_multi_device_entry_with_one_device_equals_the_single_context(gpu_ctx, f
     ctx = icet_amd.Context(0); ctx.solve_batch_device(d1, d2, prm, o_single.data_ptr(), xd.data_ptr()); ctx.sync(); ctx.close()
     torch.cuda.synchronize()
     assert torch.equal(o_multi, o_single) and bool(torch.isfinite(o_multi).all())
+    # X0 produced on a side stream and handed over as `producer_stream`: the library's streams must wait for it (no host sync here)
+    side = torch.cuda.Stream(device=dev)
+    o_after = torch.zeros_like(o_multi); xs = torch.empty_like(xd)
+    with torch.cuda.stream(side):
+        big = torch.randn(4096, 4096, device=dev); big = big @ big                 # keeps the stream busy for a while
+        xs.copy_(xd + big[0, 0] * 0.0)
+    m.solve_batch_device(d1, d2, prm, o_after.data_ptr(), xs.data_ptr(), producer_stream=side.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(o_after, o_single)
+    # the library's own RCCL gather (ncclCommInitAll + ncclAllGather behind icet_multi, north_star's wording) with the one rank this box has
+    m.set_option("gather", 1)
+    o_rccl = torch.full_like(o_multi, float("nan"))
+    m.solve_batch_device(d1, d2, prm, o_rccl.data_ptr(), xd.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(o_rccl, o_single)
+    m.set_option("gather", 0)
     m.close()
+    m2 = icet_amd.MultiContext([0, 0])
+    with pytest.raises(icet_amd.IcetError) as e:                   # one rank per GPU: a repeated device cannot form a communicator
+        m2.set_option("gather", 1)
+    assert e.value.status == api.ICET_ERR_UNSUPPORTED
+    m2.close()
     with pytest.raises(icet_amd.IcetError) as e:
         icet_amd.MultiContext([0, 63])
     assert e.value.status == api.ICET_ERR_NO_DEVICE

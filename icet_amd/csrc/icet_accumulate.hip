@@ -277,28 +277,35 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
             const bool a1 = e1, a2 = a1 & e2, a3 = a2 & e3;                 // point j continues the run of point 0
             const bool z3 = !a3, z2 = z3 & e3, z1 = z2 & e2;                // point j belongs to the run of point 3, a different run
             const bool i0 = pc[0].inb, i1 = pc[1].inb, i2 = pc[2].inb, i3 = pc[3].inb;
-            float A0, A1, A2, A3, A4, A5, A6, A7, A8, Z0, Z1, Z2, Z3, Z4, Z5, Z6, Z7, Z8;
+            // The nine sums of a run as two scalars and three PAIRS -- (sum x, sum y), (sum xx, sum yy), (sum xz, sum yz) -- so that a
+            // point costs 2 v_pk_fma_f32 + 1 v_pk_add_f32 + 2 v_fmac + 1 v_add instead of 6 + 3 scalar instructions; every half of a
+            // packed fma is the same IEEE fma, so the bits are those of the scalar form.  (The OTHER packing -- run A with run Z in
+            // the two halves -- needs 79 VGPRs and spills, and the Z sums can then no longer be sunk into the branch that flushes them.)
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 Axy, Asq, Acz, Zxy, Zsq, Zcz; float A2, A4, A8, Z2, Z4, Z8;
             {   // point 0 opens run A; an out-of-bounds point only counts (its d may be anything: masked to 0, never multiplied in)
                 const float dx = i0 ? pc[0].dx : 0.f, dy = i0 ? pc[0].dy : 0.f, dz = i0 ? pc[0].dz : 0.f;
-                A0 = dx; A1 = dy; A2 = dz; A3 = dx * dx; A4 = dx * dy; A5 = dx * dz; A6 = dy * dy; A7 = dy * dz; A8 = dz * dz;
-                Z0 = Z1 = Z2 = Z3 = Z4 = Z5 = Z6 = Z7 = Z8 = 0.f;
+                Axy = f2{dx, dy}; A2 = dz; Asq = Axy * Axy; Acz = f2{dz, dz} * Axy; A4 = dx * dy; A8 = dz * dz;
+                Zxy = Zsq = Zcz = f2{0.f, 0.f}; Z2 = Z4 = Z8 = 0.f;
             }
-            // (scalar on purpose: with the two runs packed into register pairs -- v_pk_fma_f32 on (A, Z) -- the kernel needs 79 VGPRs
-            // and spills, and the compiler can no longer sink the Z sums into the branch that flushes them)
 #define ICET_ACC_POINT(j, inA, inZ)                                                                                                          \
             {                                                                                                                                \
                 const bool ma = (inA) & pc[j].inb, mz = (inZ) & pc[j].inb;                                                                   \
-                const float ax = ma ? pc[j].dx : 0.f, ay = ma ? pc[j].dy : 0.f, az = ma ? pc[j].dz : 0.f;                                    \
-                const float zx = mz ? pc[j].dx : 0.f, zy = mz ? pc[j].dy : 0.f, zz = mz ? pc[j].dz : 0.f;                                    \
-                A0 += ax; A1 += ay; A2 += az;                                                                                                \
-                A3 = fmaf(ax, ax, A3); A4 = fmaf(ax, ay, A4); A5 = fmaf(ax, az, A5); A6 = fmaf(ay, ay, A6); A7 = fmaf(ay, az, A7); A8 = fmaf(az, az, A8); \
-                Z0 += zx; Z1 += zy; Z2 += zz;                                                                                                \
-                Z3 = fmaf(zx, zx, Z3); Z4 = fmaf(zx, zy, Z4); Z5 = fmaf(zx, zz, Z5); Z6 = fmaf(zy, zy, Z6); Z7 = fmaf(zy, zz, Z7); Z8 = fmaf(zz, zz, Z8); \
+                const f2 axy = f2{ma ? pc[j].dx : 0.f, ma ? pc[j].dy : 0.f}; const float az = ma ? pc[j].dz : 0.f;                           \
+                const f2 zxy = f2{mz ? pc[j].dx : 0.f, mz ? pc[j].dy : 0.f}; const float zz = mz ? pc[j].dz : 0.f;                           \
+                Axy += axy; A2 += az;                                                                                                        \
+                Asq = __builtin_elementwise_fma(axy, axy, Asq); Acz = __builtin_elementwise_fma(axy, f2{az, az}, Acz);                       \
+                A4 = fmaf(axy.x, axy.y, A4); A8 = fmaf(az, az, A8);                                                                          \
+                Zxy += zxy; Z2 += zz;                                                                                                        \
+                Zsq = __builtin_elementwise_fma(zxy, zxy, Zsq); Zcz = __builtin_elementwise_fma(zxy, f2{zz, zz}, Zcz);                       \
+                Z4 = fmaf(zxy.x, zxy.y, Z4); Z8 = fmaf(zz, zz, Z8);                                                                          \
             }
             ICET_ACC_POINT(1, a1, z1)
             ICET_ACC_POINT(2, a2, z2)
             ICET_ACC_POINT(3, a3, z3)
 #undef ICET_ACC_POINT
+            const float A0 = Axy.x, A1 = Axy.y, A3 = Asq.x, A6 = Asq.y, A5 = Acz.x, A7 = Acz.y;
+            const float Z0 = Zxy.x, Z1 = Zxy.y, Z3 = Zsq.x, Z6 = Zsq.y, Z5 = Zcz.x, Z7 = Zcz.y;
             const uint32_t ar = 1u + (a1 ? 1u : 0u) + (a2 ? 1u : 0u) + (a3 ? 1u : 0u);
             const uint32_t ai = (i0 ? 1u : 0u) + ((a1 & i1) ? 1u : 0u) + ((a2 & i2) ? 1u : 0u) + ((a3 & i3) ? 1u : 0u);
             flush(s0, ar, ai, A0, A1, A2, A3, A4, A5, A6, A7, A8);

@@ -692,6 +692,38 @@ def test_multi_device_sharding_with_shards_sharing_one_gpu(gpu_ctx, frames, samp
     m.close()
 
 
+def test_coarse_grid_long_range_takes_the_wide_fixed_point_path(gpu_ctx):
+    """the two-instruction float -> fixed-point conversion of k_gn_accumulate holds for |v| < 2^15 m^2 only.  A
+    4 x 2 grid (90-degree voxels) over ranges of 150-220 m puts single squared distances to mu1 above 10^4 m^2 and 4-point partial
+    sums above 2^15: such flushes must take the exact wide conversion.  Decisions (per-voxel counts of every iteration) must equal
+    the oracle's, the first update and X must agree -- a corrupted accumulator would move them by metres."""
+    from icet_amd import lidar_sim as ls
+    from oracle import pyoracle as po
+    s1, s2, _ = ls.make_pair(rings=32, steps=1024)
+    a = (s1.T.numpy() * 40.0).astype(np.float32); b = (s2.T.numpy() * 40.0).astype(np.float32)
+    kw = dict(runlen=5, bins_phi=2, bins_theta=4, n=25, thresh=4.0, buff=4.0)
+    ref = po.solve(a, b, trace=True, **kw)
+    t = ref["trace"]; f = t["has_fit"] == 1
+    sph = po.c2s(b); vox = po.voxel_of(sph, 2, 4)
+    d2max = 0.0
+    for v in np.nonzero(f)[0]:
+        m = (vox == v) & (sph[:, 0] >= t["bounds"][v, 4]) & (sph[:, 0] <= t["bounds"][v, 5])
+        if m.any():
+            d2max = max(d2max, float(np.square(b[m] - t["mu1"][v]).max()))
+    assert d2max > 8192.0 + 1.0, d2max                     # four such points in one lane overflow the fast conversion's range (2^15)
+    g = gpu_ctx.solve(a, b, kw["runlen"], np.zeros(6), 2, 4, 25, 4.0, 4.0, aux=True)
+    ax = g["aux"]
+    assert np.array_equal(ax["cluster_bounds"], t["bounds"]) and np.array_equal(ax["has_fit"], t["has_fit"])
+    assert np.array_equal(ax["mu1"][f].view(np.uint32), t["mu1"][f].view(np.uint32))
+    act = f & (t["n1_raw"] > 25) & (t["bounds"][:, 5] > 1)
+    assert np.array_equal(ax["n2_in"][0][act], t["n2_in"][0][act]) and int(t["n2_in"][0][act].max()) > 100
+    h0 = t["HTWH"][0]; sc = np.sqrt(np.abs(np.diag(h0))) + 1e-30
+    assert (np.abs(ax["htwh"][0] - h0) / np.outer(sc, sc)).max() < 2e-3
+    assert np.abs(ax["x_hist"][0] - t["X"][0]).max() < 40 * 5e-6 + 1e-5
+    sens = oracle_sensitivity(a, b, **kw)
+    assert np.abs(g["X"][:3] - ref["X"][:3]).max() <= max(40 * TOL_T, 5 * sens[:3].max()) and np.abs(g["X"][3:] - ref["X"][3:]).max() <= max(TOL_R, 5 * sens[3:].max()), (g["X"], ref["X"], sens)
+
+
 def test_rarely_taken_paths_give_the_same_bits(gpu_ctx, frames, sample_pc):
     """Every launch-shape knob selects a code path that exists for unusual inputs; on ordinary inputs they must all produce
     the same bits as the default: accumulator rows that do not fit LDS (HBM-atomic spill path), rank-sort buckets that do not

@@ -9,8 +9,12 @@
 // Needs Eigen (as the reference does).  Eigen is not present in the build image of this repository, so this adapter
 // is deliberately a thin copy-in / copy-out shim over the Eigen-free icet_amd::ICET of include/icet_host.hpp, which
 // is what the test-suite compiles and runs (tests/cpp); the adapter itself is compiled and run against a minimal Eigen-API mock
-// (tests/cpp/mock_eigen, tests/cpp/adapter_demo.cpp) so that it cannot rot.  Members the reference keeps only for its own
-// internals (pointIndices1/2, the sigma1/mu1/U/L std::maps, points1Spherical, ...) are not exposed; no caller reads them.
+// (tests/cpp/mock_eigen, tests/cpp/adapter_demo.cpp) so that it cannot rot.  The scan-1 voxel table is exposed as the reference
+// exposes it: the std::map members mu1 / sigma1 / L / U keyed [theta][phi] (include/icet.h:27-29,89-94), one entry per fitted voxel,
+// with U = eigenvectors^T as at src/icet.cpp:184 and L the 0/1 diagonal of src/icet.cpp:205-232; sigma2 / mu2 are declared and stay
+// empty (the reference declares them and never fills them).  Not exposed: pointIndices1/2 and points1Spherical / points2Spherical --
+// indices into, and the rows of, the scrambled spherical copies the reference keeps for its own loops (the device never stores
+// theta / phi of a row: only decisions and the Gaussians need them); no caller reads them.
 // Two members differ in content, neither is read by any caller: `points2_OG` holds scan 2 as given (the reference stores it after
 // its radial "sort" and a spherical round trip, src/icet.cpp:263-275: same points, permuted, <= 2 ulp away -- the device never
 // sorts scan 2); `testPoints` holds the sigma points of the pruned axes like the reference's (src/icet.cpp:213-231) and ZEROS in the
@@ -19,9 +23,14 @@
 #define ICET_H
 
 #include <Eigen/Dense>
+#include <map>
 #include <string>
 #include <vector>
 #include "icet_host.hpp"
+
+using CovarianceMatrix = Eigen::Matrix3f;                                   // == Eigen::Matrix<float, 3, 3> (include/icet.h:27)
+using CovarianceMap = std::map<int, std::map<int, CovarianceMatrix>>;      // include/icet.h:28
+using MeanMap = std::map<int, std::map<int, Eigen::Vector3f>>;             // include/icet.h:29
 
 class ICET {
 public:
@@ -54,11 +63,25 @@ public:
             ellipsoid1Covariances.push_back(c);
             ellipsoid1Alphas.push_back(it.ellipsoid1Alphas[i]);
         }
+        // mu1 / sigma1 / U / L keyed [theta][phi], one entry per fitted voxel (src/icet.cpp:177-184, 205-232)
+        if ((int)it.has_fit.size() == V) {
+            for (int v = 0; v < V; v++) if (it.has_fit[v]) {
+                const int theta = v % num_bins_theta, phi = v / num_bins_theta;
+                CovarianceMatrix s, u, l;
+                for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+                    s(a, b) = it.sigma1[(size_t)v * 9 + a * 3 + b];
+                    u(a, b) = it.evecs1[(size_t)v * 9 + b * 3 + a];                 // U = eigenvectors.transpose()
+                    l(a, b) = (a == b) ? it.l_diag[(size_t)v * 3 + a] : 0.f;
+                }
+                sigma1[theta][phi] = s; U[theta][phi] = u; L[theta][phi] = l;
+                mu1[theta][phi] = Eigen::Vector3f(it.mu1[(size_t)v * 3], it.mu1[(size_t)v * 3 + 1], it.mu1[(size_t)v * 3 + 2]);
+            }
+        }
         status = it.status; error = it.error;
     }
     ~ICET() {}
 
-    void step() { rl--; }
+    void step() { rl--; }      // the reference's stub prints "step", decrements rl and does nothing else (src/icet.cpp:438-441); silent here
 
     // algorithm params
     int rl; int numBinsPhi; int numBinsTheta; int n; float thresh; float buff;
@@ -67,6 +90,9 @@ public:
     Eigen::VectorXf pred_stds;
     Eigen::VectorXf X;    // global solution vector (x, y, z, roll, pitch, yaw)
     Eigen::VectorXf dx;   // last linear perturbation
+
+    CovarianceMap sigma1, sigma2, L, U;      // [theta][phi]; sigma2 / mu2 stay empty as in the reference
+    MeanMap mu1, mu2;
 
     // for viz
     std::vector<Eigen::Vector3f> ellipsoid1Means;

@@ -52,11 +52,11 @@ public:
         icet_params p{runlen, num_bins_phi, num_bins_theta, n, thresh, buff, ICET_FLAG_NONE};
         const int64_t V = (int64_t)num_bins_phi * num_bins_theta;
         const int64_t RL = runlen > 0 ? runlen : 1;
-        std::vector<int32_t> has_fit;
-        std::vector<float> mu1, sigma1, x_hist, htwh, htwdz;
+        std::vector<float> x_hist, htwh, htwdz;
         icet_aux aux{};
         if (side_tables && V > 0) {
             clusterBounds.assign((size_t)V * 6, 0.f); has_fit.assign(V, 0); mu1.assign((size_t)V * 3, 0.f); sigma1.assign((size_t)V * 9, 0.f);
+            evecs1.assign((size_t)V * 9, 0.f); l_diag.assign((size_t)V * 3, 0.f); aux.evecs1 = evecs1.data(); aux.l_diag = l_diag.data();
             x_hist.assign((size_t)RL * 6, 0.f); htwh.assign((size_t)RL * 36, 0.f); htwdz.assign((size_t)RL * 6, 0.f);
             testPoints.assign((size_t)V * 18, 0.f); aux.test_points = testPoints.data();
             aux.cluster_bounds = clusterBounds.data(); aux.has_fit = has_fit.data(); aux.mu1 = mu1.data(); aux.sigma1 = sigma1.data();
@@ -107,6 +107,12 @@ public:
     std::vector<float> clusterBounds;            // V x 6 row-major
     std::vector<float> testPoints;               // (V * 6) x 3 row-major: sigma points of the pruned axes (src/icet.cpp:213-231), zeros elsewhere
     std::vector<float> points2;                  // n2 x 3 column-major
+    // the scan-1 voxel table behind the reference's std::map members mu1 / sigma1 / U / L (include/icet.h:89-94), dense over the V voxels
+    // (row v = numBinsTheta * phi + theta, src/icet.cpp:149); only rows with has_fit[v] == 1 are map entries in the reference
+    std::vector<int32_t> has_fit;                // V
+    std::vector<float> mu1, sigma1;              // V x 3, V x 9 (row-major 3x3)
+    std::vector<float> evecs1;                   // V x 9: eigenvectors of sigma1 as COLUMNS, ascending eigenvalues (the reference's U is the transpose, src/icet.cpp:184)
+    std::vector<float> l_diag;                   // V x 3: diagonal of L (1 = axis kept, src/icet.cpp:205-232)
     std::vector<std::array<float, 3>> ellipsoid1Means, ellipsoid2Means;
     std::vector<std::array<float, 9>> ellipsoid1Covariances, ellipsoid2Covariances;
     std::vector<float> ellipsoid1Alphas, ellipsoid2Alphas;

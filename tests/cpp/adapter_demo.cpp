@@ -33,6 +33,17 @@ int main(int argc, char** argv) {
         std::printf("pred_stds %.9g %.9g %.9g %.9g %.9g %.9g\n", it.pred_stds[0], it.pred_stds[1], it.pred_stds[2], it.pred_stds[3], it.pred_stds[4], it.pred_stds[5]);
         std::printf("members %ld %ld %ld %ld %zu %zu %ld\n", it.clusterBounds.rows(), it.clusterBounds.cols(), it.points2.rows(), it.testPoints.rows(),
                     it.ellipsoid1Means.size(), it.ellipsoid2Means.size(), it.HTWH_i.rows());
+        // the scan-1 voxel table as the reference exposes it (include/icet.h:89-94): maps keyed [theta][phi]
+        size_t entries = 0; double tr = 0, lsum = 0, orth = 0;
+        for (const auto& th : it.sigma1) for (const auto& ph : th.second) {
+            entries++;
+            const CovarianceMatrix& s = ph.second; const CovarianceMatrix& u = it.U[th.first][ph.first]; const CovarianceMatrix& l = it.L[th.first][ph.first];
+            tr += s(0, 0) + s(1, 1) + s(2, 2); lsum += l(0, 0) + l(1, 1) + l(2, 2);
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) { double d = 0; for (int k = 0; k < 3; k++) d += u(a, k) * u(b, k); orth += (d - (a == b)) * (d - (a == b)); }
+        }
+        const Eigen::Vector3f m0 = it.mu1.empty() ? Eigen::Vector3f() : it.mu1.begin()->second.begin()->second;
+        std::printf("maps %zu %zu %zu %zu %zu %zu trace %.9g lsum %.9g orth %.3g first_mu %.9g %.9g %.9g key %d %d\n", entries, it.mu1.size(), it.U.size(), it.L.size(), it.sigma2.size(),
+                    it.mu2.size(), tr, lsum, orth, m0[0], m0[1], m0[2], it.mu1.empty() ? -1 : it.mu1.begin()->first, it.mu1.empty() ? -1 : it.mu1.begin()->second.begin()->first);
         //seed initial estimate for next iteration
         X0 << X[0], X[1], X[2], X[3], X[4], X[5];
     }

@@ -446,11 +446,23 @@ def test_eigen_adapter_header_compiles_and_runs(tmp_path, gpu_ctx, frames):
     out = subprocess.run([exe, str(tmp_path / "s1.f32"), str(tmp_path / "s2.f32"), str(a.shape[0]), str(b.shape[0])], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
-    X1 = np.array(lines[0].split()[1:], np.float32); X2 = np.array(lines[3].split()[1:], np.float32)
+    X1 = np.array(lines[0].split()[1:], np.float32); X2 = np.array(lines[4].split()[1:], np.float32)
     r1 = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75)
     r2 = gpu_ctx.solve(a, b, 7, r1["X"], 24, 75)
     assert np.array_equal(X1, r1["X"]) and np.array_equal(X2, r2["X"])
     assert lines[2].split()[1:] == ["1800", "6", str(b.shape[0]), "10800", "86", "0", "6"]
+    # the std::map members mu1 / sigma1 / U / L keyed [theta][phi] (/root/reference/include/icet.h:89-94) against the oracle's table:
+    # one entry per fitted voxel, U = eigenvectors^T (orthonormal), L = the 0/1 diagonal, sigma2 / mu2 empty
+    from oracle import pyoracle as po
+    t = po.solve(a, b, trace=True)["trace"]
+    f = t["has_fit"] == 1
+    m = lines[3].split()
+    thetas = np.nonzero(f)[0] % 75
+    assert m[0] == "maps" and int(m[1]) == int(f.sum()) == 86 and int(m[2]) == int(m[3]) == int(m[4]) == len(set(thetas.tolist())) and m[5] == m[6] == "0"
+    assert abs(float(m[8]) - float(np.trace(t["sigma1"][f].astype(np.float64), axis1=1, axis2=2).sum())) <= 1e-5 * float(m[8])
+    assert float(m[10]) == float(t["Ldiag"][f].sum()) and float(m[12]) < 1e-9
+    v0 = min(np.nonzero(f)[0], key=lambda v: (v % 75, v // 75))                  # first key of the nested maps: smallest theta, then phi
+    assert np.array_equal(np.array(m[14:17], np.float32), t["mu1"][v0]) and [int(m[18]), int(m[19])] == [v0 % 75, v0 // 75]
 
 
 def test_test_points_member(gpu_ctx, frames):

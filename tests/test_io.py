@@ -135,3 +135,65 @@ def test_loaders_survive_garbage_under_sanitizers(tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([exe], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_files_to_solution_end_to_end(tmp_path):
+    """File -> icet_load_scan -> icet_solve on the GPU box (the demo's path, /root/reference/src/icet_cpp_demo.cpp:25-38,
+    src/utils.cpp:12-91): the golden pair written as Ouster CSV (integer millimetres in columns 8-10), tab-separated xyz, .npy (float64,
+    Fortran order -- the layout of the reference's sample data is float64) and KITTI .bin; every pair of files must load to exactly the
+    rows the format keeps (the CSV branches drop 4 lines / the first point) and solve to the bits of the direct-array solve of those rows;
+    the millimetre-quantised pair is also held to the oracle."""
+    import icet_amd
+    from icet_amd import api
+    from oracle import pyoracle as po
+    d = np.load(os.path.join(GOLDEN, "scans_frame_804_805.npz"))
+    scans = [d["scan1"], d["scan2"]]
+    ctx = icet_amd.Context(0)
+
+    def solve(p, q):
+        return ctx.solve(p, q, 7, np.zeros(6), 24, 75)
+
+    def check(paths, expected, fmt=api.FMT_AUTO):
+        loaded = [api.load_scan(p, fmt) for p in paths]
+        for got, want in zip(loaded, expected):
+            assert got.dtype == np.float32 and got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        r, r0 = solve(*loaded), solve(*expected)
+        for key in ("X", "pred_stds", "cov"):
+            assert np.array_equal(r[key], r0[key]) and np.isfinite(r[key]).all(), key
+        return r
+
+    # Ouster CSV: 14 integer columns, x / y / z in millimetres in columns 8-10; two header lines, and the reader drops two more rows
+    paths, want = [], []
+    for k, s in enumerate(scans):
+        mm = np.rint(s.astype(np.float64) * 1000.0).astype(np.int64)
+        p = str(tmp_path / ("pcap_out_%06d.csv" % k))
+        with open(p, "w") as f:
+            f.write("# ouster dump\n" + ",".join("c%d" % i for i in range(14)) + "\n")
+            for row in mm:
+                f.write("0,0,0,0,0,0,0,0,%d,%d,%d,0,0,0\n" % (row[0], row[1], row[2]))
+        paths.append(p); want.append((mm[2:].astype(np.float32) / np.float32(1000)))
+    r_mm = check(paths, want)
+    ref = po.solve(want[0], want[1])
+    assert np.abs(r_mm["X"][:3] - ref["X"][:3]).max() <= 2e-4 and np.abs(r_mm["X"][3:] - ref["X"][3:]).max() <= 2e-5
+    # tab-separated xyz: %.9g round-trips float32; the first point is taken for a header
+    paths, want = [], []
+    for k, s in enumerate(scans):
+        p = str(tmp_path / ("desk_%d.txt" % k))
+        with open(p, "w") as f:
+            for row in s:
+                f.write("%.9g\t%.9g\t%.9g\n" % (row[0], row[1], row[2]))
+        paths.append(p); want.append(s[1:].copy())
+    check(paths, want)
+    # .npy float64 Fortran order, and KITTI .bin (x, y, z, reflectance)
+    paths = []
+    for k, s in enumerate(scans):
+        p = str(tmp_path / ("frame_%d.npy" % k)); np.save(p, np.asfortranarray(s.astype(np.float64))); paths.append(p)
+    r_npy = check(paths, scans)
+    paths = []
+    for k, s in enumerate(scans):
+        p = str(tmp_path / ("%010d.bin" % k)); np.concatenate([s, np.full((len(s), 1), 0.5, np.float32)], 1).astype(np.float32).tofile(p); paths.append(p)
+    r_bin = check(paths, scans)
+    g = dict(np.load(os.path.join(GOLDEN, "golden_frame_804_805.npz")))
+    assert np.array_equal(r_npy["X"], r_bin["X"]) and np.abs(r_npy["X"][:3] - g["X"][:3]).max() <= 2e-4
+    ctx.close()

@@ -282,38 +282,53 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
             // packed fma is the same IEEE fma, so the bits are those of the scalar form.  (The OTHER packing -- run A with run Z in
             // the two halves -- needs 79 VGPRs and spills, and the Z sums can then no longer be sunk into the branch that flushes them.)
             typedef float f2 __attribute__((ext_vector_type(2)));
-            f2 Axy, Asq, Acz, Zxy, Zsq, Zcz; float A2, A4, A8, Z2, Z4, Z8;
-            {   // point 0 opens run A; an out-of-bounds point only counts (its d may be anything: masked to 0, never multiplied in)
-                const float dx = i0 ? pc[0].dx : 0.f, dy = i0 ? pc[0].dy : 0.f, dz = i0 ? pc[0].dz : 0.f;
-                Axy = f2{dx, dy}; A2 = dz; Asq = Axy * Axy; Acz = f2{dz, dz} * Axy; A4 = dx * dy; A8 = dz * dz;
-                Zxy = Zsq = Zcz = f2{0.f, 0.f}; Z2 = Z4 = Z8 = 0.f;
+            // A lane's SECOND run (the run of point 3 when it is not the run of point 0: 8 % of the lanes, but 93 % of the wave-trips
+            // have such a lane, so its sums and its flush used to be paid by nearly every trip) almost always continues in the next lane:
+            // lane L's points 1-3 and lane L + 1's point 0 are neighbours in the stream.  When it does (`fw`), lane L hands its suffix
+            // points to lane L + 1 (nine DPP moves), which adds them -- first, i.e. in stream order -- to its own run A: one flush per
+            // lane-trip instead of two, no Z sums on the common path.  Lane 63 has no successor and a suffix run that ends exactly at
+            // the lane boundary has nothing to join: those keep the Z path below, now a rare wave-uniform branch.  What is grouped
+            // into one float partial sum stays a property of the data: a maximal run of one slot inside an aligned group of 4 points,
+            // extended backwards over the suffix run of the previous group of the same aligned 256-point block (a wave's trip).
+            const uint32_t zr = 1u + (z2 ? 1u : 0u) + (z1 ? 1u : 0u);
+            const uint32_t zi = (i3 ? 1u : 0u) + ((z2 & i2) ? 1u : 0u) + ((z1 & i1) ? 1u : 0u);
+            const bool fw = z3 & (s3 >= 0) & (wave_shl1(s0, -2) == s3);
+            const bool h1 = fw & z1 & i1, h2 = fw & z2 & i2, h3 = fw & i3;
+            const float g1x = wave_shr1(h1 ? pc[1].dx : 0.f, 0.f), g1y = wave_shr1(h1 ? pc[1].dy : 0.f, 0.f), g1z = wave_shr1(h1 ? pc[1].dz : 0.f, 0.f);
+            const float g2x = wave_shr1(h2 ? pc[2].dx : 0.f, 0.f), g2y = wave_shr1(h2 ? pc[2].dy : 0.f, 0.f), g2z = wave_shr1(h2 ? pc[2].dz : 0.f, 0.f);
+            const float g3x = wave_shr1(h3 ? pc[3].dx : 0.f, 0.f), g3y = wave_shr1(h3 ? pc[3].dy : 0.f, 0.f), g3z = wave_shr1(h3 ? pc[3].dz : 0.f, 0.f);
+            const uint32_t gc = (uint32_t)wave_shr1((int)(fw ? (zr | (zi << 8)) : 0u), 0);      // raw | in-bounds counts of what arrives
+            f2 Axy, Asq, Acz; float A2, A4, A8;
+            {   // the points handed over by the previous lane come first (zeros when there are none)
+                Axy = f2{g1x, g1y}; A2 = g1z; Asq = Axy * Axy; Acz = f2{g1z, g1z} * Axy; A4 = g1x * g1y; A8 = g1z * g1z;
             }
-#define ICET_ACC_POINT(j, inA, inZ)                                                                                                          \
+#define ICET_ACC_ADD(S, vx_, vy_, vz_)                                                                                                       \
             {                                                                                                                                \
-                const bool ma = (inA) & pc[j].inb, mz = (inZ) & pc[j].inb;                                                                   \
-                const f2 axy = f2{ma ? pc[j].dx : 0.f, ma ? pc[j].dy : 0.f}; const float az = ma ? pc[j].dz : 0.f;                           \
-                const f2 zxy = f2{mz ? pc[j].dx : 0.f, mz ? pc[j].dy : 0.f}; const float zz = mz ? pc[j].dz : 0.f;                           \
-                Axy += axy; A2 += az;                                                                                                        \
-                Asq = __builtin_elementwise_fma(axy, axy, Asq); Acz = __builtin_elementwise_fma(axy, f2{az, az}, Acz);                       \
-                A4 = fmaf(axy.x, axy.y, A4); A8 = fmaf(az, az, A8);                                                                          \
-                Zxy += zxy; Z2 += zz;                                                                                                        \
-                Zsq = __builtin_elementwise_fma(zxy, zxy, Zsq); Zcz = __builtin_elementwise_fma(zxy, f2{zz, zz}, Zcz);                       \
-                Z4 = fmaf(zxy.x, zxy.y, Z4); Z8 = fmaf(zz, zz, Z8);                                                                          \
+                const f2 vxy = f2{vx_, vy_}; const float vz = vz_;                                                                           \
+                S##xy += vxy; S##2 += vz;                                                                                                    \
+                S##sq = __builtin_elementwise_fma(vxy, vxy, S##sq); S##cz = __builtin_elementwise_fma(vxy, f2{vz, vz}, S##cz);               \
+                S##4 = fmaf(vxy.x, vxy.y, S##4); S##8 = fmaf(vz, vz, S##8);                                                                  \
             }
-            ICET_ACC_POINT(1, a1, z1)
-            ICET_ACC_POINT(2, a2, z2)
-            ICET_ACC_POINT(3, a3, z3)
-#undef ICET_ACC_POINT
+            ICET_ACC_ADD(A, g2x, g2y, g2z)
+            ICET_ACC_ADD(A, g3x, g3y, g3z)
+            // then the lane's own run A; an out-of-bounds point only counts (its d may be anything: masked to 0, never multiplied in)
+            { const bool m = i0;      ICET_ACC_ADD(A, m ? pc[0].dx : 0.f, m ? pc[0].dy : 0.f, m ? pc[0].dz : 0.f) }
+            { const bool m = a1 & i1; ICET_ACC_ADD(A, m ? pc[1].dx : 0.f, m ? pc[1].dy : 0.f, m ? pc[1].dz : 0.f) }
+            { const bool m = a2 & i2; ICET_ACC_ADD(A, m ? pc[2].dx : 0.f, m ? pc[2].dy : 0.f, m ? pc[2].dz : 0.f) }
+            { const bool m = a3 & i3; ICET_ACC_ADD(A, m ? pc[3].dx : 0.f, m ? pc[3].dy : 0.f, m ? pc[3].dz : 0.f) }
             const float A0 = Axy.x, A1 = Axy.y, A3 = Asq.x, A6 = Asq.y, A5 = Acz.x, A7 = Acz.y;
-            const float Z0 = Zxy.x, Z1 = Zxy.y, Z3 = Zsq.x, Z6 = Zsq.y, Z5 = Zcz.x, Z7 = Zcz.y;
-            const uint32_t ar = 1u + (a1 ? 1u : 0u) + (a2 ? 1u : 0u) + (a3 ? 1u : 0u);
-            const uint32_t ai = (i0 ? 1u : 0u) + ((a1 & i1) ? 1u : 0u) + ((a2 & i2) ? 1u : 0u) + ((a3 & i3) ? 1u : 0u);
+            const uint32_t ar = 1u + (a1 ? 1u : 0u) + (a2 ? 1u : 0u) + (a3 ? 1u : 0u) + (gc & 0xFFu);
+            const uint32_t ai = (i0 ? 1u : 0u) + ((a1 & i1) ? 1u : 0u) + ((a2 & i2) ? 1u : 0u) + ((a3 & i3) ? 1u : 0u) + (gc >> 8);
             flush(s0, ar, ai, A0, A1, A2, A3, A4, A5, A6, A7, A8);
-            if (__ballot(z3 & (s3 >= 0)) != 0ull) {
-                const uint32_t zr = 1u + (z2 ? 1u : 0u) + (z1 ? 1u : 0u);
-                const uint32_t zi = (i3 ? 1u : 0u) + ((z2 & i2) ? 1u : 0u) + ((z1 & i1) ? 1u : 0u);
-                flush(z3 ? s3 : -1, zr, zi, Z0, Z1, Z2, Z3, Z4, Z5, Z6, Z7, Z8);
+            if (__ballot(z3 & (s3 >= 0) & !fw) != 0ull) {                   // a suffix run that could not be handed on
+                f2 Zxy, Zsq, Zcz; float Z2, Z4, Z8;
+                { const bool m = z1 & i1; const float x = m ? pc[1].dx : 0.f, y = m ? pc[1].dy : 0.f, z = m ? pc[1].dz : 0.f;
+                  Zxy = f2{x, y}; Z2 = z; Zsq = Zxy * Zxy; Zcz = f2{z, z} * Zxy; Z4 = x * y; Z8 = z * z; }
+                { const bool m = z2 & i2; ICET_ACC_ADD(Z, m ? pc[2].dx : 0.f, m ? pc[2].dy : 0.f, m ? pc[2].dz : 0.f) }
+                { const bool m = i3;      ICET_ACC_ADD(Z, m ? pc[3].dx : 0.f, m ? pc[3].dy : 0.f, m ? pc[3].dz : 0.f) }
+                flush((z3 & !fw) ? s3 : -1, zr, zi, Zxy.x, Zxy.y, Z2, Zsq.x, Z4, Zcz.x, Zsq.y, Zcz.y, Z8);
             }
+#undef ICET_ACC_ADD
             const bool m1 = !a1 & !z1, m2 = !a2 & !z2;                      // points of a run strictly between A and Z
             if (__ballot((m1 & (s1 >= 0)) | (m2 & (s2 >= 0))) != 0ull) {
                 const bool joint = m1 & m2 & e2;                            // points 1 and 2 form one run

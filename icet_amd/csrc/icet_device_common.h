@@ -172,6 +172,8 @@ __device__ __forceinline__ void classify_angular_fast(float qx, float qy, float 
 // lane i receives x of lane i - 1; lane 0 receives `fill`
 __device__ __forceinline__ int wave_shr1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
 __device__ __forceinline__ float wave_shr1(float x, float fill) { return __int_as_float(wave_shr1(__float_as_int(x), __float_as_int(fill))); }
+// lane i receives x of lane i + 1; lane 63 receives `fill`
+__device__ __forceinline__ int wave_shl1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
 // inclusive prefix maximum over the 64 lanes, for values >= -1 (-1 = "nothing"): four row_shr steps inside the rows of 16, then the
 // last lane of row 0 / 2 into rows 1 / 3 and the last lane of row 1 into rows 2 and 3
 __device__ __forceinline__ int wave_incl_max(int v) {

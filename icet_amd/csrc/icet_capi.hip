@@ -446,7 +446,10 @@ icet_status icet_reserve(icet_ctx* c, const icet_params* p, int32_t n_pairs, int
 // kernel is measured alone on the device.
 static int batch_parts(const icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     if (p->flags & ICET_FLAG_TIMING) return 1;
-    int parts = n_pairs >= 64 ? 2 : 1;      // measured at the end of round 1 on 256 pairs (30 steps): 1 part 84.7 k, 2 parts 89.2 k, 3 parts 88.0 k pairs/s
+    // One part.  Cutting the batch into staggered parts on separate streams paid in round 1 (1 part 84.7 k pairs/s, 2 parts 89.2 k) and has
+    // been a wash since the keyframe and loop kernels were tightened: round 3, 256 pairs, 1 part 100.7 k, 2 parts 100.2 k, 3 parts 96.7 k,
+    // 4 parts 82.1 k (scripts/exp_parts.sh) -- every phase fills the device on its own.  The mechanism stays behind `batch_parts`.
+    int parts = 1;
     if (c->tune.batch_parts > 0) parts = c->tune.batch_parts > 8 ? 8 : c->tune.batch_parts;
     if (parts > n_pairs) parts = n_pairs > 0 ? n_pairs : 1;
     return parts;

@@ -13,7 +13,7 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # all 256 pairs distinct: 745 MB of scans, well past the 256 MiB Infinity Cache, so FETCH_SIZE is real HBM traffic
-CMD="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency"
+CMD="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-h2d --min-timed-s 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- $CMD > $OUT/stats.log 2>&1
 grep -E "^\"Name\"|icet::" /tmp/p_stats/*/*kernel_stats.csv > $OUT/${TAG}_kernel_stats.csv      # this library's kernels only (torch's generator kernels dropped)
 python3 $R/profiles/summarize.py $OUT/${TAG}_kernel_stats.csv 7 > $OUT/${TAG}_kernels.txt

@@ -21,8 +21,12 @@ for f in sys.argv[2:]:
         g = int(r.get("Grid_Size", 0) or 0)
         val[k][r["Counter_Name"]].append((g, float(r["Counter_Value"])))
         dur[k].append((g, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
-def big(lst):            # mean over the launches with the largest grid
-    gmax = max(g for g, _ in lst); v = [x for g, x in lst if g == gmax]; return sum(v) / len(v)
+def big(lst):
+    """Mean over the WHOLE-BATCH launches: the largest grid and, inside it, the values within 40 % of the largest (k_gn_accumulate keeps
+    its grid when a batch is cut into parts -- its part launches then show as half-size counter values, not as a smaller grid)."""
+    gmax = max(g for g, _ in lst); v = [x for g, x in lst if g == gmax]
+    top = max(v); w = [x for x in v if x >= 0.6 * top] if top > 0 else v
+    return sum(w) / len(w)
 print("%-18s %8s %9s %6s %6s %6s %8s %7s %7s %6s" % ("kernel", "us", "winst/row", "wait%", "stall%", "act%", "ldsconf", "rdB/row", "wrB/row", "L2hit%"))
 tot = 0.0
 for k in sorted(val, key=lambda k: -big(dur[k])):

@@ -148,10 +148,15 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
     // The pipeline runs over GROUPS of 4 points (one dwordx4 per coordinate): while a group is classified the next group of the
     // same lane -- the next 4 of its kAccPts consecutive points, or the first 4 of its next trip -- is already in flight, so the
     // prefetch costs 12 registers however many points a lane takes per trip.
+#ifndef ICET_ACC_PHASE
+#define ICET_ACC_PHASE 9       // TIMING BUILDS ONLY (profiles/r03_acc_phases.txt; results are wrong below 9): 0 loads, 1 + classification, 2 + hot records, 3 + parked points, 4 + sums without conversion / LDS atomics
+#endif
+    [[maybe_unused]] float sink = 0.f;
     float XN[4], YN[4], ZN[4];
     load4(begin + kAccPts * (int)threadIdx.x, XN, YN, ZN);
     for (int t0 = begin + kAccPts * threadIdx.x; t0 < begin + cs; t0 += kAccPts * kAccBlock) {   // whole waves iterate together
       auto flush = [&](int slot, uint32_t cr, uint32_t ci, float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {
+          if (ICET_ACC_PHASE == 4) { sink += (float)(slot + (int)cr + (int)ci) + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + a8; return; }
           if (slot >= 0) {
               if (slot < nl) {
                   unsigned long long* F = lacc + slot * 10;
@@ -181,6 +186,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
         for (int j = 0; j < 4; j++) { X[j] = XN[j]; Y[j] = YN[j]; Z[j] = ZN[j]; }
         if (g + 1 < kAccPts / 4) load4(i0 + 4, XN, YN, ZN);
         else if (t0 + kAccPts * kAccBlock < begin + cs) load4(t0 + kAccPts * kAccBlock, XN, YN, ZN);
+        if (ICET_ACC_PHASE == 0) { sink += (X[0] + X[1] + X[2] + X[3]) + (Y[0] + Y[1] + Y[2] + Y[3]) + (Z[0] + Z[1] + Z[2] + Z[3]); continue; }
         PointClass pc[4];
         float QX[4], QY[4], QZ[4], RR[4];
         int SM[4];
@@ -221,6 +227,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
         // ---- phase A2: only waves that touch an active voxel look at the hot records (radial test, d = q - mu1) ----
         // E: the point's slot, -1 for "no active voxel" and for a point that waits for the literal formulas
         const int E0 = nr[0] ? -1 : SM[0], E1 = nr[1] ? -1 : SM[1], E2 = nr[2] ? -1 : SM[2], E3 = nr[3] ? -1 : SM[3];
+        if (ICET_ACC_PHASE == 1) { sink += (float)(E0 + E1 + E2 + E3) + RR[0] + RR[1] + RR[2] + RR[3] + QX[0] + QY[1] + QZ[2]; continue; }
         if (__ballot((E0 & E1 & E2 & E3) >= 0) != 0ull) {                  // some lane holds a point with E >= 0 (the sign bits do not all agree on "negative")
             // A slot beyond the LDS table (more active voxels than lds_slots; the launch sizes the table so that this is rare) keeps
             // its record in HBM.  Its points stay in the lane's runs like any other -- how the sums are grouped must not depend on a
@@ -254,6 +261,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
         // traffic (measured: 119 -> 238 us per launch).  The point's INDEX is parked in the block's LDS queue and classified
         // after the loop, as a run of one; past kNearCap entries (adversarial input, or the force_exact diagnostic) it goes to
         // the pair's overflow list in HBM, which k_gn_solve drains.  Integer accumulation makes the order irrelevant. ----
+        if (ICET_ACC_PHASE == 2) { for (int j = 0; j < 4; j++) sink += (float)pc[j].s + pc[j].dx + pc[j].dy + pc[j].dz + (pc[j].inb ? 1.f : 0.f) + (nr[j] ? 1.f : 0.f); continue; }
         if (__ballot(nr[0] | nr[1] | nr[2] | nr[3]) != 0ull) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -264,6 +272,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
                 }
             }
         }
+        if (ICET_ACC_PHASE == 3) { for (int j = 0; j < 4; j++) sink += (float)pc[j].s + pc[j].dx + pc[j].dy + pc[j].dz + (pc[j].inb ? 1.f : 0.f); continue; }
         const int s0 = pc[0].s, s1 = pc[1].s, s2 = pc[2].s, s3 = pc[3].s;
         if (__ballot((s0 >= 0) | (s1 >= 0) | (s2 >= 0) | (s3 >= 0)) == 0ull) continue;   // wave-uniform: nothing here lands in an active voxel
         // ---- phase C: run-length accumulation over the lane's 4 consecutive points.  Lidar storage order keeps neighbours in one
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
         }
       }   // sub-groups of 4
     }
+    if (ICET_ACC_PHASE != 9 && sink == 1.2345e-30f) near_over_count[pair] = 1u;      // keeps the timing builds' work alive
     __syncthreads();
     {   // ---- the parked points: literal classification, each a run of one ----
         const uint32_t nq = min(nearq[kNearCap], kNearCap);

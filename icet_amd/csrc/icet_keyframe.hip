@@ -6,7 +6,7 @@
 //                         (sortSphericalCoordinates, src/icet.cpp:534-554) through the fast classification with the literal
 //                         fallback, its rank-sort bucket and the tile's bucket histogram
 //     [rank sort, icet_ranksort.hip]                      std::sort by r (src/icet.cpp:72-77)
-//     k_exec_flags / k_scramble_src (+ serial replay)     the reference's one-step swap loop (src/icet.cpp:78-83) in
+//     k_exec_flags / k_scramble_src (+ k_scramble_replay) the reference's one-step swap loop (src/icet.cpp:78-83) in
 //                                                          parallel closed form
 //     k_bin_tiles + k_bin_scan + k_bin_scatter             stable multi-split of positions by voxel = the order in which
 //                                                          sortSphericalCoordinates appends rows to each voxel
@@ -261,24 +261,6 @@ __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const P
     for (int b = threadIdx.x; b < V; b += kBlock) out[b] = (lh[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
 }
 
-// Serial fallback for adversarial permutations (walks longer than max_walk): one lane replays the
-// literal swap loop on indices.  Never taken on lidar data (observed walk depth <= 14).
-__global__ void k_scramble_serial(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, int32_t* __restrict__ idx_tmp,
-                                  int32_t* __restrict__ src, const int32_t* __restrict__ flags) {
-    const int pair = blockIdx.x;
-    if (threadIdx.x != 0 || !(flags[pair] & 1)) return;
-    const PairDesc d = desc[pair];
-    const size_t o = d.off1;
-    for (int i = 0; i < d.n1; i++) { idx_tmp[o + i] = (int)s[o + i]; src[o + i] = i; }
-    for (int i = 0; i < d.n1; i++) {
-        int j = idx_tmp[o + i];
-        if (j != i) {
-            int t = src[o + i]; src[o + i] = src[o + j]; src[o + j] = t;
-            idx_tmp[o + i] = idx_tmp[o + j]; idx_tmp[o + j] = j;
-        }
-    }
-}
-
 // ---- grouping scan-1 rows by voxel, in ascending POSITION order inside each voxel -------------------------------
 // sortSphericalCoordinates appends point indices to per-voxel vectors while walking the (scrambled) array front to back
 // (src/icet.cpp:539-550), so findCluster later sees each voxel's rows in ascending position.  That is a STABLE
@@ -309,6 +291,47 @@ __global__ __launch_bounds__(kBlock) void k_bin_hist(const PairDesc* __restrict_
     __syncthreads();
     uint32_t* out = counts + ((size_t)pair * chunks + chunk) * V;
     for (int b = threadIdx.x; b < V; b += kBlock) out[b] = lh[b];
+}
+
+// Adversarial permutations (a walk longer than max_walk set the pair's flag; never on lidar data: observed depth <= 14): ONE launch
+// replays the literal swap loop on one lane (k_scramble_serial's body) and then redoes, tile by tile, what k_scramble_src fused in --
+// the voxel word of every position and the tiles' voxel histograms.  One block per pair; a pair whose flag is clear costs the launch
+// and nothing else (two separate always-launched kernels cost a single pair ~5 us each for nothing).
+__global__ __launch_bounds__(kBlock) void k_scramble_replay(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, int32_t* __restrict__ idx_tmp,
+                                                            int32_t* __restrict__ src, const int32_t* __restrict__ flags, const uint16_t* __restrict__ bin16,
+                                                            uint16_t* __restrict__ binpos, uint32_t* __restrict__ counts, int V, int chunks) {
+    extern __shared__ uint32_t lh[];
+    const int pair = blockIdx.x;
+    if (!(flags[pair] & 1)) return;
+    const PairDesc d = desc[pair];
+    const size_t o = d.off1;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < d.n1; i++) { idx_tmp[o + i] = (int)s[o + i]; src[o + i] = i; }
+        for (int i = 0; i < d.n1; i++) {
+            int j = idx_tmp[o + i];
+            if (j != i) {
+                int t = src[o + i]; src[o + i] = src[o + j]; src[o + j] = t;
+                idx_tmp[o + i] = idx_tmp[o + j]; idx_tmp[o + j] = j;
+            }
+        }
+        __threadfence();
+    }
+    __syncthreads();
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
+    for (int chunk = 0; chunk < chunks; chunk++) {
+        const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
+        for (int b = threadIdx.x; b < V; b += kBlock) lh[b] = 0u;
+        __syncthreads();
+        for (int v = lo_ + threadIdx.x; v < hi_; v += kBlock) {
+            const uint16_t wd = bin16[o + src[o + v]];
+            binpos[o + v] = wd;
+            atomicAdd(&lh[wd & kBinMask], 1u);
+        }
+        __syncthreads();
+        uint32_t* out = counts + ((size_t)pair * chunks + chunk) * V;
+        for (int b = threadIdx.x; b < V; b += kBlock) out[b] = lh[b];
+        __syncthreads();
+    }
 }
 
 // Exclusive scan over (class, tile) in class-major order, in two steps so that a single large pair (7200 voxels x 240 tiles)
@@ -885,11 +908,9 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
         else
             k_scramble_src<false><<<grid, blk, hist_bytes, st>>>(w.desc, w.valB, w.pred, w.execbits, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);
         ICET_LAUNCH_CHECK();
-        k_scramble_serial<<<c.n_pairs, 64, 0, st>>>(w.desc, w.valB, w.pred /* reused as scratch */, w.src, w.flags);
+        k_scramble_replay<<<c.n_pairs, blk, (size_t)c.V * 4, st>>>(w.desc, w.valB, w.pred /* reused as scratch */, w.src, w.flags, w.bin16, w.binpos, w.counts, c.V, chunks);
         ICET_LAUNCH_CHECK();
         if (c.stage_event && c.stage_at == 2) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
-        k_bin_hist<<<grid, blk, (size_t)c.V * 4, st>>>(w.desc, w.src, w.bin16, w.binpos, w.counts, w.flags, c.V, np, chunks, 0);
-        ICET_LAUNCH_CHECK();
     }
     e = launch_class_scan(w.counts, w.tile_base, w.bin_start, c.V, chunks, c.n_pairs, st, w.live_bins, w.n_live, c.n, w.fit_n_items);
     if (e != hipSuccess) return e;

@@ -54,63 +54,74 @@ __device__ __forceinline__ float radius_of(float x, float y, float z) {     // t
     return (r != r) ? 1000.0f : r;
 }
 
-// One WAVE per pair: the 2048 sampled keys live in registers, 32 per lane (element e = 32 * lane + r), and go through the bitonic
-// network without a single block barrier -- the 45 stages whose partner distance is below 32 are register-to-register, the other
-// 21 exchange through __shfl_xor.  Measured per 256-pair launch: 55 us, of which ~27 are the 6 k scattered sample loads of the
-// one wave (a diagnostic build that samples consecutive rows runs in 28) -- the 1024-thread, 66-barrier LDS version of round 2a
-// took 58, so the kernel is bound by the memory-level parallelism of one CU per pair, not by the sort.
-static_assert(kSamples == 2048, "k_rs_splitters holds 32 keys per lane of one wave");
-constexpr int kSplitLoadThreads = 512;      // the sample is LOADED by 8 waves (6 k scattered loads: the memory-level parallelism of one wave was the bound), sorted by one
+// One BLOCK of 8 waves per pair: the 2048 sampled keys live in registers, FOUR per thread (element e = 4 * tid + r), and go through
+// the bitonic network: the 12 stages whose partner distance is 1 or 2 are register-to-register, the 39 with distance 4 .. 128 exchange
+// through __shfl_xor inside a wave, and only the 6 with distance 256 .. 1024 cross waves through LDS (two barriers each).  Round 2 kept
+// all 2048 keys in ONE wave (32 per lane, no barrier at all): 2112 compare-exchanges and 672 shuffles per lane -- 17 us of a single
+// pair's 22 us for this kernel, and the rest of the block idle; here a lane does 264 + 156.
+static_assert(kSamples == 2048, "k_rs_splitters holds 4 keys per thread of a 512-thread block");
+constexpr int kSplitLoadThreads = 512;
 __global__ __launch_bounds__(kSplitLoadThreads) void k_rs_splitters(const PairDesc* __restrict__ desc,
                                                      uint32_t* __restrict__ splitters, int32_t* __restrict__ n_buckets) {
     __shared__ uint32_t sm[kSamples];
-    const int pair = blockIdx.x, lane = threadIdx.x & 63;
+    const int pair = blockIdx.x, tid = threadIdx.x;
     const PairDesc d = desc[pair];
     const int n = d.n1;
     const int stride = max(1, (n + kSamples - 1) / kSamples);
     const int ns = n > 0 ? (n + stride - 1) / stride : 0;
-    for (int j = threadIdx.x; j < kSamples; j += kSplitLoadThreads)
-        sm[j] = (j < ns) ? __float_as_uint(radius_of(d.s1[(size_t)j * stride], d.s1[d.ld1 + (size_t)j * stride], d.s1[2 * (size_t)d.ld1 + (size_t)j * stride])) : 0xFFFFFFFFu;
-    __syncthreads();
-    if (threadIdx.x >= 64) return;
-    uint32_t x[32];
+    uint32_t x[4];
 #pragma unroll
-    for (int r = 0; r < 32; r++) x[r] = sm[32 * lane + r];
+    for (int r = 0; r < 4; r++) {                               // element e = 4 * tid + r: each thread loads its own four samples
+        const int j = 4 * tid + r;
+        x[r] = (j < ns) ? __float_as_uint(radius_of(d.s1[(size_t)j * stride], d.s1[d.ld1 + (size_t)j * stride], d.s1[2 * (size_t)d.ld1 + (size_t)j * stride])) : 0xFFFFFFFFu;
+    }
 #pragma unroll
     for (int k = 2; k <= kSamples; k <<= 1) {                   // bitonic sort, ascending
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 32) {                                      // partner in another lane, same register
-                const int lj = j >> 5;
-                const bool up = ((32 * lane) & k) == 0;
-                const bool low = (lane & lj) == 0;              // this lane holds the lower index of the pair
+            if (j >= 4) {                                       // partner in another thread, same register
+                const int tj = j >> 2;
+                const bool up = ((4 * tid) & k) == 0;
+                const bool low = (tid & tj) == 0;               // this thread holds the lower index of the pair
+                uint32_t o[4];
+                if (tj < 64) {
 #pragma unroll
-                for (int r = 0; r < 32; r++) {
-                    const uint32_t o = (uint32_t)__shfl_xor((int)x[r], lj);
-                    const uint32_t lo = min(x[r], o), hi = max(x[r], o);
+                    for (int r = 0; r < 4; r++) o[r] = (uint32_t)__shfl_xor((int)x[r], tj);
+                } else {                                        // another wave: through LDS
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < 4; r++) sm[4 * tid + r] = x[r];
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = sm[4 * (tid ^ tj) + r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t lo = min(x[r], o[r]), hi = max(x[r], o[r]);
                     x[r] = (low == up) ? lo : hi;
                 }
-            } else {                                            // partner in this lane: registers r and r ^ j
+            } else {                                            // partner in this thread: registers r and r ^ j
 #pragma unroll
-                for (int r = 0; r < 32; r++) {
+                for (int r = 0; r < 4; r++) {
                     if (r & j) continue;
-                    // direction bit: from the register index when k <= 16 (compile time), from the lane otherwise
-                    const bool up = (k < 32) ? ((r & k) == 0) : (((32 * lane) & k) == 0);
+                    // direction bit: from the register index when k <= 2 (compile time), from the thread otherwise
+                    const bool up = (k < 4) ? ((r & k) == 0) : (((4 * tid) & k) == 0);
                     const uint32_t lo = min(x[r], x[r ^ j]), hi = max(x[r], x[r ^ j]);
                     x[r] = up ? lo : hi; x[r ^ j] = up ? hi : lo;
                 }
             }
         }
     }
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 32; r++) sm[32 * lane + r] = x[r];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();      // one wave left: its LDS operations complete in order
+    for (int r = 0; r < 4; r++) sm[4 * tid + r] = x[r];
+    __syncthreads();
     int nb = (n + kBucketTarget - 1) / kBucketTarget;
     nb = min(max(nb, 1), kMaxBuckets);
     if (n == 0) nb = 0;
     if (threadIdx.x == 0) n_buckets[pair] = nb;
     // splitters[j], j = 1..nb-1 ; slot 0 unused ; unused slots = +max so that the search never counts them
-    for (int j = threadIdx.x; j < kMaxBuckets; j += 64)
+    for (int j = threadIdx.x; j < kMaxBuckets; j += kSplitLoadThreads)
         splitters[(size_t)pair * kMaxBuckets + j] = (j >= 1 && j < nb) ? sm[(int)(((long long)j * ns) / nb)] : 0xFFFFFFFFu;
 }
 

@@ -725,15 +725,50 @@ __global__ __launch_bounds__(kBlock, 8) void k_fit_moments(const PairDesc* __res
 // sigma points and their inside test -> L, the scan-1 half of the gate at :290, and the records of the active voxels.
 __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict__ midD, const int32_t* __restrict__ bin_start, SlotHot* __restrict__ hotD, SlotFit* __restrict__ fitD,
                                                        int32_t* __restrict__ activeD, AuxDev aux, int T, int P, int n) {
+    // Two stages.  (A) one lane per bin: the cheap per-bin outputs, and the FITTED bins of the block (~12 % of its 256) compacted into an
+    // LDS list; (B) one lane per fitted bin: the 3x3 eigen-decomposition, the six sigma points with their double-precision
+    // cartesianToSpherical, the slot records.  With the heavy part on the bin's own lane (round 2) every wave ran it for its handful of
+    // fitted lanes; compacted, one wave per block does (k_fit_finish 53 -> see DESIGN.md section 4).
+    __shared__ int s_list[kBlock];
+    __shared__ int s_count;
+    __shared__ float s_pt[kBlock][6][3];                          // (B2) sigma points of the block's fitted bins, by list position
+    __shared__ float s_lim[kBlock][6];                            // az0, az1, el0, el1, inner, outer
+    __shared__ unsigned char s_in[kBlock][6], s_far[kBlock][6];   // inside the bounds / r > outer, per point
     const int V = T * P;
-    const int v = blockIdx.x * kBlock + threadIdx.x;
     const int pair = blockIdx.y;
-    if (v >= V) return;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    {
+        const int v = blockIdx.x * kBlock + threadIdx.x;
+        if (v < V) {
+            const size_t o = (size_t)pair * V + v;
+            const int cnt_v = bin_start[(size_t)pair * (V + 1) + v + 1] - bin_start[(size_t)pair * (V + 1) + v];
+            FitMid m{};                                               // a bin below n rows was never visited by the fit kernels: nothing to read
+            if (cnt_v >= n) m = midD[o];
+            if (m.has_fit) s_list[atomicAdd(&s_count, 1)] = v;        // (the order of the list is irrelevant: every entry writes its own rows)
+            else {
+                activeD[o] = 0;
+                if (aux.bounds) {
+                    float az0, az1, el0, el1;
+                    voxel_limits(v % T, v / T, T, P, az0, az1, el0, el1);
+                    float* b = aux.bounds + o * 6; b[0] = az0; b[1] = az1; b[2] = el0; b[3] = el1; b[4] = m.inner; b[5] = m.outer;
+                }
+                if (aux.n1_raw) aux.n1_raw[o] = cnt_v;
+                if (aux.has_fit) aux.has_fit[o] = 0;
+                if (aux.mu1) { aux.mu1[o * 3] = m.mean[0]; aux.mu1[o * 3 + 1] = m.mean[1]; aux.mu1[o * 3 + 2] = m.mean[2]; }
+                if (aux.sigma1) { float* sg = aux.sigma1 + o * 9; sg[0] = m.cov[0]; sg[1] = m.cov[1]; sg[2] = m.cov[2]; sg[3] = m.cov[1]; sg[4] = m.cov[3]; sg[5] = m.cov[4]; sg[6] = m.cov[2]; sg[7] = m.cov[4]; sg[8] = m.cov[5]; }
+                if (aux.evecs1) for (int k = 0; k < 9; k++) aux.evecs1[o * 9 + k] = 0.f;
+                if (aux.l_diag) { aux.l_diag[o * 3] = 0.f; aux.l_diag[o * 3 + 1] = 0.f; aux.l_diag[o * 3 + 2] = 0.f; }
+                if (aux.test_points) for (int k = 0; k < 18; k++) aux.test_points[o * 18 + k] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const bool mine = (int)threadIdx.x < s_count;                 // this lane owns list entry threadIdx.x
+    const int v = mine ? s_list[threadIdx.x] : 0;
     const size_t o = (size_t)pair * V + v;
-    const int cnt_v = bin_start[(size_t)pair * (V + 1) + v + 1] - bin_start[(size_t)pair * (V + 1) + v];
-    FitMid m{};                                                   // a bin below n rows was never visited by the fit kernels: nothing to read
-    if (cnt_v >= n) m = midD[o];
-    m.cnt = cnt_v;
+    FitMid m{};
+    if (mine) { m = midD[o]; m.cnt = bin_start[(size_t)pair * (V + 1) + v + 1] - bin_start[(size_t)pair * (V + 1) + v]; }
     const int theta = v % T, phi = v / T;
     float az0, az1, el0, el1;
     voxel_limits(theta, phi, T, P, az0, az1, el0, el1);
@@ -744,10 +779,6 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
     if (m.has_fit) {
         icetdev::eig3_sym(m.cov[0], m.cov[1], m.cov[3], m.cov[2], m.cov[4], m.cov[5], ev, Vm);
         // sigma points mu +- 2 sqrt(lambda_k) * (row k of V): rotated = diag(2 sqrt(lambda)) * U^T = diag(.) * V (src/icet.cpp:187-202).
-        // testSigmaPoints walks j = 0..5 and leaves the loop AFTER testing the first point with r > outer (:669-686).
-        bool inside[6] = {false, false, false, false, false, false};
-        bool done = false;
-        float spx[6], spy[6], spz[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             const int k = j >> 1;
@@ -761,19 +792,36 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
                 py = (j & 1) ? m.mean[1] - r1_ : m.mean[1] + r1_;
                 pz = (j & 1) ? m.mean[2] - r2_ : m.mean[2] + r2_;
             }
-            spx[j] = px; spy[j] = py; spz[j] = pz;
-            if (!done) {
-                float r, az, el; c2s_cr(px, py, pz, r, az, el);
-                inside[j] = inside_bounds(r, az, el, az0, az1, el0, el1, inner, outer);
-                done = r > outer;
-            }
+            s_pt[threadIdx.x][j][0] = px; s_pt[threadIdx.x][j][1] = py; s_pt[threadIdx.x][j][2] = pz;
+        }
+        s_lim[threadIdx.x][0] = az0; s_lim[threadIdx.x][1] = az1; s_lim[threadIdx.x][2] = el0; s_lim[threadIdx.x][3] = el1;
+        s_lim[threadIdx.x][4] = inner; s_lim[threadIdx.x][5] = outer;
+    }
+    // (B2) cartesianToSpherical of the 6 x count sigma points (double-precision atan2 / acos each), one per lane
+    __syncthreads();
+    for (int item = threadIdx.x; item < 6 * s_count; item += kBlock) {
+        const int q = item / 6, j = item - 6 * q;
+        float r, az, el; c2s_cr(s_pt[q][j][0], s_pt[q][j][1], s_pt[q][j][2], r, az, el);
+        s_in[q][j] = inside_bounds(r, az, el, s_lim[q][0], s_lim[q][1], s_lim[q][2], s_lim[q][3], s_lim[q][4], s_lim[q][5]) ? 1 : 0;
+        s_far[q][j] = (r > s_lim[q][5]) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!mine) return;
+    if (m.has_fit) {
+        // testSigmaPoints walks j = 0..5 and leaves the loop AFTER testing the first point with r > outer (:669-686): a point behind
+        // such a point was never tested, i.e. counts as outside.
+        bool inside[6] = {false, false, false, false, false, false};
+        bool done = false;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            if (!done) { inside[j] = s_in[threadIdx.x][j] != 0; done = s_far[threadIdx.x][j] != 0; }
         }
         if (aux.test_points) {          // `testPoints` (src/icet.cpp:213-231): the sigma points of every axis that is pruned
 #pragma unroll
             for (int j = 0; j < 6; j++) {
                 const bool pruned = !(inside[j & ~1] || inside[j | 1]);
                 float* tp = aux.test_points + (o * 6 + j) * 3;
-                tp[0] = pruned ? spx[j] : 0.f; tp[1] = pruned ? spy[j] : 0.f; tp[2] = pruned ? spz[j] : 0.f;
+                tp[0] = pruned ? s_pt[threadIdx.x][j][0] : 0.f; tp[1] = pruned ? s_pt[threadIdx.x][j][1] : 0.f; tp[2] = pruned ? s_pt[threadIdx.x][j][2] : 0.f;
             }
         }
         Ld[0] = (inside[0] || inside[1]) ? 1.f : 0.f; Ld[1] = (inside[2] || inside[3]) ? 1.f : 0.f; Ld[2] = (inside[4] || inside[5]) ? 1.f : 0.f;
@@ -801,7 +849,6 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
     if (aux.sigma1) { float* sg = aux.sigma1 + o * 9; sg[0] = m.cov[0]; sg[1] = m.cov[1]; sg[2] = m.cov[2]; sg[3] = m.cov[1]; sg[4] = m.cov[3]; sg[5] = m.cov[4]; sg[6] = m.cov[2]; sg[7] = m.cov[4]; sg[8] = m.cov[5]; }
     if (aux.evecs1) for (int k = 0; k < 9; k++) aux.evecs1[o * 9 + k] = Vm[k];
     if (aux.l_diag) { aux.l_diag[o * 3] = Ld[0]; aux.l_diag[o * 3 + 1] = Ld[1]; aux.l_diag[o * 3 + 2] = Ld[2]; }
-    if (aux.test_points && !m.has_fit) for (int k = 0; k < 18; k++) aux.test_points[o * 18 + k] = 0.f;
 }
 
 // Dense per-voxel records -> compact slots in voxel order (phi-major, theta inner: the reference's

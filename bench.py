@@ -59,6 +59,7 @@ def parse(argv=None):
     ap.add_argument("--multi-gather", choices=["peer", "rccl"], default="peer", help="--multi: peer copies (default) or the library's RCCL all-gather")
     ap.add_argument("--min-timed-s", type=float, default=0.5, help="the K timed steps are repeated until the timed region is at least this long")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive sub-record")
+    ap.add_argument("--flags", type=int, default=0, help="icet_params.flags for the solves (e.g. 16 = ICET_FLAG_ROUNDTRIP_SCAN2: what the reference's scan-2 round trips cost); echoed in config")
     ap.add_argument("--dry-run-launch", action="store_true", help="print what `--gpus N` would start (JSON) and exit: no GPU, no child")
     return ap.parse_args(argv)
 
@@ -279,8 +280,8 @@ def main(argv=None):
     d1 = [(b.data_ptr(), n, b.shape[1]) for b, n in zip(bufs1, n1)]
     d2 = [(b.data_ptr(), n, b.shape[1]) for b, n in zip(bufs2, n2)]
 
-    p_plain = api.Params(iters, P, T, 25, 0.1, 0.1, 0)
-    p_timed = api.Params(iters, P, T, 25, 0.1, 0.1, api.FLAG_TIMING)
+    p_plain = api.Params(iters, P, T, 25, 0.1, 0.1, args.flags)
+    p_timed = api.Params(iters, P, T, 25, 0.1, 0.1, args.flags | api.FLAG_TIMING)
     out = torch.zeros((len(ids), 48), dtype=torch.float32, device=dev)
     stream = torch.cuda.Stream(device=dev)
     mctx = None
@@ -520,7 +521,7 @@ def main(argv=None):
                                                                   ("one process: icet_multi_solve_batch_device, %s gather" % args.multi_gather) if multi
                                                                   else "RCCL all-gather of 48 floats/pair when N>1"))
                        if args.workload == "batch" else "configs[4]: single 128-ch pair (~%dk pts), 150x48 voxels, 10 iters" % int(np.mean(n2) / 1000),
-                       **({"options": list(args.set)} if args.set else {}),
+                       **({"options": list(args.set)} if args.set else {}), **({"flags": args.flags} if args.flags else {}),
                        "pairs_per_gpu": n_local, "pairs_total": n_global, "points_scan1_mean": int(np.mean(n1)), "points_scan2_mean": int(np.mean(n2)),
                        "bins_theta": T, "bins_phi": P, "iters": iters, "parallelism": "pairs round-robin x%d" % n_gpus,
                        "processes": 1 if multi else world, "mode": "multi (one process)" if multi else "one process per GPU",

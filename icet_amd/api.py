@@ -20,6 +20,7 @@ _STATUS_NAMES = {0: "ICET_OK", 1: "ICET_ERR_BAD_ARG", 2: "ICET_ERR_NO_DEVICE", 3
 FLAG_TIMING = 1
 FLAG_TRUE_SORT = 2      # non-parity extension, see include/icet_hip.h
 FLAG_REJECT_MOVING = 4  # non-parity extension (moving-object rejection of the Python variant), see include/icet_hip.h
+FLAG_ROUNDTRIP_SCAN2 = 16  # parity-study option: the reference's two spherical round trips of scan 2 (see include/icet_hip.h)
 FLAG_HALF_GAP_BOUNDS = 8  # non-parity extension (half-gap cluster buffers of the Python variant; implies TRUE_SORT), see include/icet_hip.h
 
 # every symbol include/icet_hip.h, include/icet_nodes.h and include/icet_io.h declare
@@ -189,8 +190,8 @@ class Context:
     def debug_fetch(self, what, count):
         """Diagnostic: 'r' (float32, scan 1 in input order), 'bin' (uint16 per row: voxel id | literal-path flag << 14; bit 15
         unused), 'src' (int32 scramble result), 'flags' (int32 per pair)."""
-        code = {"r": 0, "bin": 1, "src": 3, "flags": 4}[what]
-        out = np.zeros(count, {0: np.float32, 1: np.uint16}.get(code, np.int32))
+        code = {"r": 0, "bin": 1, "src": 3, "flags": 4, "rt2": 5}[what]
+        out = np.zeros(count, {0: np.float32, 1: np.uint16, 5: np.float32}.get(code, np.int32))
         self._check(load_library().icet_debug_fetch(self._h, code, out.ctypes.data, count))
         return out
 

@@ -76,8 +76,10 @@ typedef __attribute__((address_space(1))) const float gfloat;
 typedef float vfloat4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const vfloat4 gfloat4;
 
-template <bool kVec4>
-__global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
+// kRT2 (ICET_FLAG_ROUNDTRIP_SCAN2, a parity-study option): an in-bounds point enters the sums as sphericalToCartesian(cartesianToSpherical(q))
+// (src/icet.cpp:303) -- a double-precision atan2 + acos inside the loop, in a kernel of its own so that the default kernel keeps its registers.
+template <bool kVec4, bool kRT2>
+__global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_accumulate(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
                                                           const int16_t* __restrict__ slot_of_voxel, const int32_t* __restrict__ n_slots,
                                                           const SlotHot* __restrict__ hotS, uint32_t* __restrict__ acc,
                                                           const float* __restrict__ thr, const LutCell* __restrict__ lut,
@@ -250,7 +252,9 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
                 nr[j] |= edge;
                 pc[j].s = edge ? -1 : sm;
                 pc[j].inb = has & (r >= inner) & (r <= outer);
-                pc[j].dx = QX[j] - m0; pc[j].dy = QY[j] - m1; pc[j].dz = QZ[j] - m2;
+                float ux = QX[j], uy = QY[j], uz = QZ[j];
+                if (kRT2) { if (pc[j].inb & !edge) roundtrip_any(ux, uy, uz, ux, uy, uz); }
+                pc[j].dx = ux - m0; pc[j].dy = uy - m1; pc[j].dz = uz - m2;
             }
         } else {
 #pragma unroll
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate(c
             float qx, qy, qz;
             transform_point(px[i], py[i], pz[i], xf, qx, qy, qz);
             PointClass pc1;
-            classify_literal(qx, qy, qz, map, thr, T, P, hs, pc1);
+            classify_literal(qx, qy, qz, map, thr, T, P, hs, pc1, kRT2);
             if (pc1.s >= 0) {
                 const float dx = pc1.dx, dy = pc1.dy, dz = pc1.dz;
                 unsigned long long* F = lacc + min(pc1.s, nl > 0 ? nl - 1 : 0) * 10;
@@ -407,9 +411,35 @@ inline int chunks_for(int n_pairs, int max_n, int per_block_min, int target_bloc
 #define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t init_accumulate_kernels() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
+}
+
+// points2_OG of prepScan2 (src/icet.cpp:263-275) without its permutation (which only reorders sums): every row of scan 2 through
+// cartesianToSpherical -> sphericalToCartesian under the shared arithmetic rule, written to the round-tripped copy the loop then reads.
+__global__ __launch_bounds__(kBlock) void k_rt2_prepare(const PairDesc* __restrict__ desc, const PairDesc* __restrict__ desc_rt, int n_pairs, int chunks) {
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const PairDesc d = desc[pair], o = desc_rt[pair];
+    float* ox = const_cast<float*>(o.s2); float* oy = ox + o.ld2; float* oz = ox + 2 * (size_t)o.ld2;
+    const float* px = d.s2; const float* py = px + d.ld2; const float* pz = px + 2 * (size_t)d.ld2;
+    int cs = (d.n2 + chunks - 1) / chunks; cs = (cs + kBlock - 1) / kBlock * kBlock;
+    const int lo = chunk * cs, hi = min(d.n2, lo + cs);
+    for (int i = lo + threadIdx.x; i < hi; i += kBlock) {
+        float x, y, z;
+        roundtrip_any(px[i], py[i], pz[i], x, y, z);
+        ox[i] = x; oy[i] = y; oz[i] = z;
+    }
+}
+
+hipError_t launch_rt2_prepare(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
+    const int chunks = std::max(1, std::min(64, (c.max_n2 + 4 * kBlock - 1) / (4 * kBlock)));
+    k_rt2_prepare<<<grid_groups(c.n_pairs) * chunks, kBlock, 0, st>>>(w.desc, w.desc_rt, c.n_pairs, chunks);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
 }
 
 hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
@@ -428,12 +458,11 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     const size_t lds = fixed + (size_t)lds_slots * (5 + kAccLds) * 4;
     dim3 grid(grid_groups(c.n_pairs) * chunks), blk(kAccBlock);
     const LutCell* lut = reinterpret_cast<const LutCell*>(w.lut);
-    if (c.vec4_ok)
-        k_gn_accumulate<true><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp,
-                                                     w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count);
-    else
-        k_gn_accumulate<false><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp,
-                                                      w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count);
+#define ICET_ACC_LAUNCH(V4, RT) k_gn_accumulate<V4, RT><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp, \
+                                                     w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count)
+    if (c.rt2) { if (c.vec4_ok) ICET_ACC_LAUNCH(true, true); else ICET_ACC_LAUNCH(false, true); }
+    else { if (c.vec4_ok) ICET_ACC_LAUNCH(true, false); else ICET_ACC_LAUNCH(false, false); }
+#undef ICET_ACC_LAUNCH
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -32,6 +32,7 @@ struct icet_ctx {
     std::string err;
     // host staging (pinned) for descriptors and results
     PairDesc* h_desc = nullptr; int32_t* h_seg = nullptr; int32_t h_cap_pairs = 0;
+    PairDesc* h_desc_rt = nullptr; int32_t h_cap_rt = 0;       // ICET_FLAG_ROUNDTRIP_SCAN2: descriptors of the round-tripped copy of scan 2
     // device staging for host-pointer entry points
     float* d_stage1 = nullptr; float* d_stage2 = nullptr; int64_t cap_stage1 = 0, cap_stage2 = 0;
     float* d_out = nullptr; float* d_x0 = nullptr; int32_t cap_out_pairs = 0;
@@ -267,6 +268,7 @@ LaunchCfg make_cfg(icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     cfg.half_gap = (p->flags & ICET_FLAG_HALF_GAP_BOUNDS) ? 1 : 0;
     cfg.true_sort = (p->flags & (ICET_FLAG_TRUE_SORT | ICET_FLAG_HALF_GAP_BOUNDS)) ? 1 : 0;
     cfg.reject_moving = (p->flags & ICET_FLAG_REJECT_MOVING) ? 1 : 0;
+    cfg.rt2 = (p->flags & ICET_FLAG_ROUNDTRIP_SCAN2) ? 1 : 0;
     cfg.lds_slots = c->tune.lds_slots; cfg.acc_min_pts_per_thread = c->tune.acc_pts; cfg.acc_target_blocks = c->tune.acc_blocks;
     cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds;
     if (cfg.kf_pts_per_thread > kKfMaxPtsPerThread) cfg.kf_pts_per_thread = kKfMaxPtsPerThread;      // k_bin_scatter: a tile is at most 4 waves x that many rounds x 64 positions
@@ -320,14 +322,42 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
     const LaunchCfg cfg = make_cfg(c, p, n_pairs);
     if (reupload) { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }      // the scan-2 halves arrived after the keyframe call
     while ((int)c->ev_acc.size() < 2 * p->runlen) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_acc.push_back(e); }
+    Workspace wl = w;                                    // what the loop kernels see: with ICET_FLAG_ROUNDTRIP_SCAN2 their scan 2 is the round-tripped copy
+    if (cfg.rt2) {
+        int64_t tot = 0;
+        for (int k = 0; k < n_pairs; k++) tot += (c->h_desc[k].n2 + 63) / 64 * 64;
+        if (tot > w.cap_rt2 || !w.desc_rt || n_pairs > c->h_cap_rt) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (tot > w.cap_rt2) { HIPCHK(c, dev_realloc(w.rt2, (size_t)3 * tot)); w.cap_rt2 = tot; }
+            if (n_pairs > c->h_cap_rt || !w.desc_rt) {
+                const int np = n_pairs > w.cap_pairs ? n_pairs : w.cap_pairs;
+                HIPCHK(c, dev_realloc(w.desc_rt, np));
+                if (c->h_desc_rt) { HIPCHK(c, hipHostFree(c->h_desc_rt)); c->h_desc_rt = nullptr; }
+                HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_desc_rt), sizeof(PairDesc) * np));
+                c->h_cap_rt = np;
+            }
+        } else if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
+        int64_t o = 0;
+        for (int k = 0; k < n_pairs; k++) {
+            const int64_t l = (c->h_desc[k].n2 + 63) / 64 * 64;
+            PairDesc dr = c->h_desc[k];
+            dr.s2 = w.rt2 + 3 * o; dr.ld2 = (int32_t)l;
+            c->h_desc_rt[k] = dr; o += l;
+        }
+        HIPCHK(c, hipMemcpyAsync(w.desc_rt, c->h_desc_rt, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_desc, c->stream)); c->desc_in_flight = true;
+        HIPCHK(c, launch_rt2_prepare(w, cfg, c->stream));
+        wl = w; wl.desc = w.desc_rt;
+    }
+    LaunchCfg lcfg = cfg; if (cfg.rt2) lcfg.vec4_ok = 1;     // the copy is 64-float aligned whatever the caller's layout was
     HIPCHK(c, launch_init_state(w, cfg, d_x0, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
     const bool per_iter = (p->flags & ICET_FLAG_TIMING) != 0;
     for (int it = 0; it < p->runlen; it++) {
         if (per_iter) HIPCHK(c, hipEventRecord(c->ev_acc[2 * it], c->stream));
-        HIPCHK(c, launch_gn_accumulate(w, cfg, c->stream));
+        HIPCHK(c, launch_gn_accumulate(wl, lcfg, c->stream));
         if (per_iter) HIPCHK(c, hipEventRecord(c->ev_acc[2 * it + 1], c->stream));
-        HIPCHK(c, launch_gn_solve(w, cfg, it, d_out, aux, c->stream));
+        HIPCHK(c, launch_gn_solve(wl, lcfg, it, d_out, aux, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->ev_c, c->stream));
     c->timing_valid = true; c->last_iters = per_iter ? p->runlen : 0;
@@ -391,12 +421,13 @@ icet_status icet_destroy(icet_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     Workspace& w = c->w;
     void* ps[] = {w.key64A, w.key64B, w.bin16, w.execbits, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.cart1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src,
-                  w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.near_over, w.near_over_count, w.acc, w.xf, w.X, w.flags,
+                  w.desc_rt, w.rt2, w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.near_over, w.near_over_count, w.acc, w.xf, w.X, w.flags,
                   w.sort_tmp, w.fit_items, w.fit_n_items, w.live_bins, w.n_live, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);
     free_aux(c);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
     if (c->h_seg) (void)hipHostFree(c->h_seg);
+    if (c->h_desc_rt) (void)hipHostFree(c->h_desc_rt);
     if (c->h_out) (void)hipHostFree(c->h_out);
     for (hipEvent_t e : c->ev_acc) (void)hipEventDestroy(e);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
@@ -697,6 +728,7 @@ icet_status icet_debug_fetch(icet_ctx* c, int32_t what, void* out, int64_t count
         case 1: src = w.bin16; elem = 2; break;
         case 3: src = w.src; break;
         case 4: src = w.flags; cap = w.cap_pairs; break;
+        case 5: src = w.rt2; cap = 3 * w.cap_rt2; break;      // ICET_FLAG_ROUNDTRIP_SCAN2: the round-tripped copy of scan 2 (x | y | z, leading dimension = n2 rounded up to 64)
         default: c->err = "unknown array id"; return ICET_ERR_BAD_ARG;
     }
     if (!src || count > cap) { c->err = "nothing to fetch / count too large"; return ICET_ERR_BAD_ARG; }

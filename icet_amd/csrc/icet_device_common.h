@@ -143,6 +143,23 @@ __device__ __forceinline__ void roundtrip_cr(float x, float y, float z, float r_
     }
 }
 
+// The same round trip for ANY row (ICET_FLAG_ROUNDTRIP_SCAN2): an ordinary point takes roundtrip_cr; a zero / non-finite row goes through
+// the literal sentinel rules (NaN -> 1000, src/utils.cpp:116) and double-precision sin / cos of the float angles.
+__device__ __noinline__ void roundtrip_odd(float x, float y, float z, float& ox, float& oy, float& oz) {
+    float r, th, ph;
+    c2s_cr(x, y, z, r, th, ph);
+    const float spf = (float)sin((double)ph), cpf = (float)cos((double)ph), stf = (float)sin((double)th), ctf = (float)cos((double)th);
+    {
+#pragma clang fp contract(off)
+        ox = r * spf * ctf; oy = r * spf * stf; oz = r * cpf;
+    }
+}
+__device__ __forceinline__ void roundtrip_any(float x, float y, float z, float& ox, float& oy, float& oz) {
+    const float rr = radius_raw(x, y, z);
+    if (rr > 0.f && rr < INFINITY) { float th, ph; roundtrip_cr(x, y, z, rr, th, ph, ox, oy, oz); }
+    else roundtrip_odd(x, y, z, ox, oy, oz);
+}
+
 // ---- fast angular classification -------------------------------------------------------------------------------------
 // Every decision the reference takes on a point's angles is a comparison against a voxel edge: the azimuth bin
 // int(theta / 2pi * T) in double (src/icet.cpp:545), the polar bin, and the f32 azimuth / polar bounds (:632-633, Q6).  Two
@@ -217,7 +234,7 @@ struct PointClass { int s; bool inb; float dx, dy, dz; };
 // Literal evaluation of one transformed point: cartesianToSpherical under the shared rule (correctly rounded theta / phi),
 // bin, slot look-up, 6-sided bounds test (src/icet.cpp:387-388, 299).  map: voxel -> slot (int16, -1 = inactive).
 __device__ __forceinline__ void classify_literal(float qx, float qy, float qz, const int16_t* map, const float* __restrict__ thr, int T, int P,
-                                                 const SlotHot* __restrict__ hs, PointClass& out) {
+                                                 const SlotHot* __restrict__ hs, PointClass& out, bool rt2 = false) {
     float r, th, ph;
     c2s_cr(qx, qy, qz, r, th, ph);
     const float scale_t = (float)((double)T / kTwoPi), scale_p = (float)((double)P / kPi);
@@ -230,6 +247,7 @@ __device__ __forceinline__ void classify_literal(float qx, float qy, float qz, c
     if (s >= 0) {
         const SlotHot h = hs[s];
         out.inb = inside_bounds(r, th, ph, h.az0, h.az1, h.el0, h.el1, h.inner, h.outer);
+        if (rt2 && out.inb) roundtrip_any(qx, qy, qz, qx, qy, qz);          // src/icet.cpp:303: the Gaussian is fitted to the round-tripped rows
         out.dx = qx - h.mu[0]; out.dy = qy - h.mu[1]; out.dz = qz - h.mu[2];
     }
 }

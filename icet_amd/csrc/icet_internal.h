@@ -85,6 +85,7 @@ struct Workspace {
     // capacities
     int32_t cap_pairs = 0; int64_t cap_n1 = 0; int32_t cap_V = 0;
     PairDesc* desc = nullptr;
+    PairDesc* desc_rt = nullptr; float* rt2 = nullptr; int64_t cap_rt2 = 0;   // ICET_FLAG_ROUNDTRIP_SCAN2: descriptors whose scan 2 is the round-tripped copy, and that copy (3 x cap_rt2 floats)
     int32_t* seg_off = nullptr;               // pairs+1, scan-1 segment offsets
     float *r1 = nullptr;                                             // radial distance of every scan-1 row, input order (bit-exact c2s r)
     float *cart1 = nullptr;                                          // 3 x cap_n1: round-tripped Cartesian rows of large bins (k_fit_scan1's second pass)
@@ -158,6 +159,7 @@ struct LaunchCfg {
     int rs_max_cell = 24, exec_bits_lds = 1;   // Tuning::rs_max_cell, ::exec_bits_lds
     int reject_moving = 0;            // ICET_FLAG_REJECT_MOVING (non-parity extension)
     int half_gap = 0;                 // ICET_FLAG_HALF_GAP_BOUNDS (non-parity extension; sets true_sort as well)
+    int rt2 = 0;                      // ICET_FLAG_ROUNDTRIP_SCAN2 (parity-study option)
 };
 constexpr float kRejectMovingThresh = 0.3f;        // python/ICET_spherical.py:38  RM_thresh
 constexpr int kRejectMovingStartIter = 4;          // python/ICET_spherical.py:36  start_RM_iter
@@ -169,6 +171,8 @@ hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st);
 // icet_accumulate.hip
 hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st);
+// ICET_FLAG_ROUNDTRIP_SCAN2: points2_OG = sphericalToCartesian(cartesianToSpherical(scan 2)) (src/icet.cpp:263-275, without the permutation): w.desc -> w.desc_rt
+hipError_t launch_rt2_prepare(const Workspace& w, const LaunchCfg& c, hipStream_t st);
 // Raise the dynamic-LDS limit of the kernels that need more than the default; called once per context (icet_create) with the
 // context's device current -- no process-global "done" flags.
 hipError_t init_keyframe_kernels();

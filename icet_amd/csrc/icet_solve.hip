@@ -48,7 +48,7 @@ __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X
 // fitCells2's per-voxel algebra + reduction + the 6x6 solve.  One block per pair.
 // Undecided scan-2 points that did not fit a block's LDS queue in k_gn_accumulate (see there): literal classification, each a
 // run of one, straight into the HBM accumulators.  Empty on ordinary data; the whole list when the force_exact diagnostic is on.
-struct NearOverflow { const PairDesc* desc; const int16_t* slot_of_voxel; const SlotHot* hotS; const float* thr; uint32_t* list; uint32_t* count; int T, P; };
+struct NearOverflow { const PairDesc* desc; const int16_t* slot_of_voxel; const SlotHot* hotS; const float* thr; uint32_t* list; uint32_t* count; int T, P; int rt2; };
 
 __device__ __noinline__ void drain_near_overflow(const NearOverflow& o, int pair, int V, const float* __restrict__ xf, uint32_t* __restrict__ acc_pair, uint32_t nov) {
     const PairDesc d = o.desc[pair];
@@ -60,7 +60,7 @@ __device__ __noinline__ void drain_near_overflow(const NearOverflow& o, int pair
         float qx, qy, qz;
         transform_point(px[i], py[i], pz[i], xf, qx, qy, qz);
         PointClass pc;
-        classify_literal(qx, qy, qz, map, o.thr, o.T, o.P, hs, pc);
+        classify_literal(qx, qy, qz, map, o.thr, o.T, o.P, hs, pc, o.rt2 != 0);
         if (pc.s >= 0)
             acc_add_hbm(acc_pair + (size_t)pc.s * kAccWords, 1u, pc.inb ? 1u : 0u, pc.dx, pc.dy, pc.dz, pc.dx * pc.dx, pc.dx * pc.dy, pc.dx * pc.dz,
                         pc.dy * pc.dy, pc.dy * pc.dz, pc.dz * pc.dz);
@@ -305,7 +305,7 @@ hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float
 
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* auxp, hipStream_t st) {
     AuxDev aux{}; if (auxp) aux = *auxp;
-    NearOverflow over{w.desc, w.slot_of_voxel, w.hotS, w.thr, w.near_over, w.near_over_count, c.T, c.P};
+    NearOverflow over{w.desc, w.slot_of_voxel, w.hotS, w.thr, w.near_over, w.near_over_count, c.T, c.P, c.rt2};
     k_gn_solve<<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving);
     ICET_LAUNCH_CHECK();
     return hipSuccess;

@@ -54,13 +54,20 @@ enum { ICET_FLAG_NONE = 0,
                                   (start_RM_iter = 4), a voxel whose compact residual L U^T (mu2 - mu1) exceeds RM_thresh = 0.3 m in any
                                   kept axis is left out of that iteration's H^T W H and H^T W dz.  The C++ reference has nothing like it, so
                                   results differ from it by design; the oracle has the same switch (ICET_ORACLE_REJECT_MOVING). */
-       ICET_FLAG_HALF_GAP_BOUNDS = 8 /* NON-PARITY EXTENSION: the cluster buffers the reference's Python variant
+       ICET_FLAG_HALF_GAP_BOUNDS = 8, /* NON-PARITY EXTENSION: the cluster buffers the reference's Python variant
                                   DESCRIBES ("as described in spherical paper", the comments at python/utils.py:92-119 -- the TensorFlow
                                   code there adds the FULL gap when 2*gap < max_buffer, which is not this rule): the radial bounds of a
                                   voxel's cluster reach half way to the nearest point outside it, at most `buff`, instead of `buff` on either side (a neighbour
                                   that exists is more than `thresh` away, so this only tightens bounds whose neighbour lies within 2 buff).
                                   Needs the voxel's rows in ascending range, so it implies ICET_FLAG_TRUE_SORT.  Oracle twin:
-                                  ICET_ORACLE_HALF_GAP. */ };
+                                  ICET_ORACLE_HALF_GAP. */
+       ICET_FLAG_ROUNDTRIP_SCAN2 = 16 /* PARITY-STUDY OPTION (not an extension: it makes the loop MORE literal).  The reference passes scan 2 through
+                                  cartesianToSpherical -> sphericalToCartesian twice: once as a whole (points2_OG, src/icet.cpp:275) and, every
+                                  iteration, the in-bounds points of every voxel (:303).  Each trip moves a point by 1-2 ulp; the default path
+                                  skips both (it is what separates device and CPU restatement on most pairs that differ by
+                                  > 5e-5 m).  With this flag both trips are made, under the shared arithmetic rule (correctly rounded angles and
+                                  sines / cosines): a pre-pass over scan 2, and a double-precision atan2 + acos per in-bounds point per
+                                  iteration -- about twice the loop time.  Decisions (which voxel, inside the bounds) are unchanged. */ };
 
 /* A scan that already lives in device memory (HBM) on the context's device. */
 typedef struct icet_dev_scan {

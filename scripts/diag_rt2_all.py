@@ -25,6 +25,7 @@ pairs = [ls.make_batch_pair(k, device=dev) for k in range(N)]
 h1 = [p[0].T.cpu().numpy() for p in pairs]; h2 = [p[1].T.cpu().numpy() for p in pairs]
 ctx = icet_amd.Context(0)
 gpu = [ctx.solve(h1[k], h2[k], 7, np.zeros(6), 24, 75, aux=(k in dump)) for k in range(N)]
+gpu_rt = [ctx.solve(h1[k], h2[k], 7, np.zeros(6), 24, 75, flags=16) for k in range(N)]      # ICET_FLAG_ROUNDTRIP_SCAN2: the device WITH the two round trips
 os.makedirs("gpurun_out", exist_ok=True)
 for k in dump:
     np.savez_compressed("gpurun_out/bench_pair_%d.npz" % k, scan1=h1[k], scan2=h2[k], X_gpu=gpu[k]["X"], pred_stds_gpu=gpu[k]["pred_stds"], cov_gpu=gpu[k]["cov"],
@@ -47,6 +48,7 @@ def tr(a, b):
 
 
 g_r, g_rr = tr(X, R); g_s, g_sr = tr(X, S); s_r, s_rr = tr(S, R); t_r, t_rr = tr(T, R)
+XR = np.stack([g["X"] for g in gpu_rt]); q_r, q_rr = tr(XR, R); q_s, q_sr = tr(XR, S)
 ps_gr = np.abs(PS / RPS - 1).max(1); ps_gs = np.abs(PS / SPS - 1).max(1)
 np.save("gpurun_out/diag_rt2_X.npy", np.stack([X, R, S, T]))
 out = {"pairs": N,
@@ -56,13 +58,21 @@ out = {"pairs": N,
        "pairs_gpu_vs_skip_over_1e-4m_or_1e-5rad": [int(k) for k in np.nonzero((g_s > 1e-4) | (g_sr > 1e-5))[0]],
        "pairs_skip_vs_ref_over_1e-4m_or_1e-5rad": [int(k) for k in np.nonzero((s_r > 1e-4) | (s_rr > 1e-5))[0]],
        "pairs_thin_vs_ref_over_1e-4m_or_1e-5rad": [int(k) for k in np.nonzero((t_r > 1e-4) | (t_rr > 1e-5))[0]],
+       "gpu_with_round_trips_vs_ref_dt_max": float(q_r.max()), "gpu_with_round_trips_vs_ref_dt_median": float(np.median(q_r)), "gpu_with_round_trips_vs_ref_dt_p99": float(np.quantile(q_r, 0.99)),
+       "gpu_vs_ref_dt_p99": float(np.quantile(g_r, 0.99)),
+       "pairs_gpu_with_round_trips_vs_ref_over_1e-4m_or_1e-5rad": [int(k) for k in np.nonzero((q_r > 1e-4) | (q_rr > 1e-5))[0]],
+       "pairs_over_2e-5m: gpu_vs_ref / gpu_with_round_trips_vs_ref / gpu_vs_skip": [int((g_r > 2e-5).sum()), int((q_r > 2e-5).sum()), int((g_s > 2e-5).sum())],
+       "pairs_closer_to_ref_with_round_trips / farther (by > 1e-6 m)": [int((q_r < g_r - 1e-6).sum()), int((q_r > g_r + 1e-6).sum())],
        "rel_pred_stds_gpu_vs_ref_max": float(ps_gr.max()), "rel_pred_stds_gpu_vs_skip_max": float(ps_gs.max()),
        "rel_pred_stds_gpu_vs_ref_top3": [(int(k), float(ps_gr[k])) for k in np.argsort(-ps_gr)[:3]],
        "rel_pred_stds_gpu_vs_skip_top3": [(int(k), float(ps_gs[k])) for k in np.argsort(-ps_gs)[:3]]}
 print(json.dumps(out, indent=1))
-print("worst pairs by |gpu - ref| (m):   pair   gpu-ref    gpu-skip   skip-ref   thin-ref")
-for k in np.argsort(-g_r)[:10]:
-    print("  %3d   %.2e   %.2e   %.2e   %.2e" % (k, g_r[k], g_s[k], s_r[k], t_r[k]))
+print("worst pairs by |gpu - ref| (m):   pair   gpu-ref    gpu-skip   skip-ref   thin-ref   gpu(with round trips)-ref")
+for k in np.argsort(-g_r)[:12]:
+    print("  %3d   %.2e   %.2e   %.2e   %.2e   %.2e" % (k, g_r[k], g_s[k], s_r[k], t_r[k], q_r[k]))
+print("worst pairs by |gpu(with round trips) - ref| (m):")
+for k in np.argsort(-q_r)[:8]:
+    print("  %3d   %.2e   %.2e   %.2e   %.2e   %.2e" % (k, g_r[k], g_s[k], s_r[k], t_r[k], q_r[k]))
 print("worst pairs by |gpu - skip| (m):")
 for k in np.argsort(-g_s)[:10]:
-    print("  %3d   %.2e   %.2e   %.2e   %.2e" % (k, g_r[k], g_s[k], s_r[k], t_r[k]))
+    print("  %3d   %.2e   %.2e   %.2e   %.2e   %.2e" % (k, g_r[k], g_s[k], s_r[k], t_r[k], q_r[k]))

@@ -64,8 +64,8 @@ enum { ICET_FLAG_NONE = 0,
        ICET_FLAG_ROUNDTRIP_SCAN2 = 16 /* PARITY-STUDY OPTION (not an extension: it makes the loop MORE literal).  The reference passes scan 2 through
                                   cartesianToSpherical -> sphericalToCartesian twice: once as a whole (points2_OG, src/icet.cpp:275) and, every
                                   iteration, the in-bounds points of every voxel (:303).  Each trip moves a point by 1-2 ulp; the default path
-                                  skips both (it is what separates device and CPU restatement on most pairs that differ by
-                                  > 5e-5 m).  With this flag both trips are made, under the shared arithmetic rule (correctly rounded angles and
+                                  skips both (one of several last-bit triggers behind the pairs that differ from the CPU restatement by
+                                  > 5e-5 m; restoring them closes some of those pairs, not all).  With this flag both trips are made, under the shared arithmetic rule (correctly rounded angles and
                                   sines / cosines): a pre-pass over scan 2, and a double-precision atan2 + acos per in-bounds point per
                                   iteration -- about twice the loop time.  Decisions (which voxel, inside the bounds) are unchanged. */ };
 

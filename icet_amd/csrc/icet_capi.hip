@@ -99,6 +99,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, dev_realloc(w.xf, (size_t)np * 48));
         HIPCHK(c, dev_realloc(w.X, (size_t)np * 6));
         HIPCHK(c, dev_realloc(w.flags, np));
+        HIPCHK(c, dev_realloc(w.vrange, (size_t)np * 2));
         HIPCHK(c, dev_realloc(w.splitters, (size_t)np * kRankSortMaxBuckets)); HIPCHK(c, dev_realloc(w.n_buckets, np)); HIPCHK(c, dev_realloc(w.bucket_start, (size_t)np * (kRankSortMaxBuckets + 1)));
         if (c->h_desc) { HIPCHK(c, hipHostFree(c->h_desc)); c->h_desc = nullptr; }
         if (c->h_seg) { HIPCHK(c, hipHostFree(c->h_seg)); c->h_seg = nullptr; }
@@ -310,6 +311,12 @@ icet_status enqueue_keyframe(icet_ctx* c, const icet_params* p, int32_t n_pairs,
             HIPCHK(c, dev_realloc(w.counts, need)); HIPCHK(c, dev_realloc(w.tile_base, need));
             w.cap_counts = need;
         }
+        const size_t need_vr = (size_t)n_pairs * cfg.kf_chunks * 2;        // (its own capacity: tiles per voxel count vary with the grid)
+        if (need_vr > w.cap_tile_vr) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, dev_realloc(w.tile_vr, need_vr));
+            w.cap_tile_vr = need_vr;
+        }
     }
     { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }
     HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
@@ -421,7 +428,7 @@ icet_status icet_destroy(icet_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     Workspace& w = c->w;
     void* ps[] = {w.key64A, w.key64B, w.bin16, w.execbits, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.cart1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src,
-                  w.desc_rt, w.rt2, w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.near_over, w.near_over_count, w.acc, w.xf, w.X, w.flags,
+                  w.desc_rt, w.rt2, w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.near_over, w.near_over_count, w.acc, w.xf, w.X, w.flags, w.vrange, w.tile_vr,
                   w.sort_tmp, w.fit_items, w.fit_n_items, w.live_bins, w.n_live, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);
     free_aux(c);

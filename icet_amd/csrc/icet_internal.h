@@ -113,6 +113,8 @@ struct Workspace {
     float* xf = nullptr;                      // pairs x 48: t[3], R[9] row-major, angles[3], pad, J[27] (see write_xf)
     float* X = nullptr;                       // pairs x 6
     int32_t* flags = nullptr;                 // pairs: bit0 = scramble walk overflow
+    int32_t* vrange = nullptr;                // pairs x 2: smallest / largest voxel id any scan-1 row of the pair has: the voxel multi-split's tables are touched inside it only
+    int32_t* tile_vr = nullptr; size_t cap_tile_vr = 0;   // pairs x tiles x 2: the same per tile (k_scan1_spherical), reduced per pair by the rank sort's k_bin_scan
     float* thr = nullptr; int thr_T = 0, thr_P = 0;   // bin-edge tables: T+1 azimuth thresholds, then P+1 polar thresholds
     void* lut = nullptr; int lut_Mt = 0, lut_Mp = 0;  // classification LUTs of k_gn_accumulate: Mt azimuth cells, then Mp polar cells (8 B each)
     float guard_t = 0.f, guard_p = 0.f;               // guard bands (diamond-angle / cosine units) around voxel edges
@@ -191,7 +193,8 @@ __device__ __forceinline__ int rank_sort_bucket_of(uint32_t key, const uint32_t*
     return lo;
 }
 hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st,
-                             int32_t* live = nullptr, int32_t* n_live = nullptr, int live_min = 0, uint32_t* n_items = nullptr);
+                             int32_t* live = nullptr, int32_t* n_live = nullptr, int live_min = 0, uint32_t* n_items = nullptr, const int32_t* class_range = nullptr,
+                             const int32_t* tile_vr = nullptr, int32_t* vrange_out = nullptr);
 
 // sort.hip
 size_t sort_temp_bytes(int64_t total_n);

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __re
                                                             unsigned long long* __restrict__ key64, uint32_t* __restrict__ key32,
                                                             uint32_t* __restrict__ val, uint16_t* __restrict__ bin16, int T, int P, int n_pairs, int chunks,
                                                             const uint32_t* __restrict__ splitters, uint8_t* __restrict__ bkt, uint32_t* __restrict__ counts,
-                                                            const LutCell* __restrict__ lut, int Mt, int Mp, float guard_t, float guard_p) {
+                                                            const LutCell* __restrict__ lut, int Mt, int Mp, float guard_t, float guard_p, int32_t* __restrict__ tile_vr) {
     // First step of the rank sort fused in (icet_ranksort.hip): the pair's splitters are already known (k_rs_splitters
     // samples the radii straight from the Cartesian rows), so each row's bucket and this tile's bucket histogram cost no
     // extra pass over r1[].  splitters == nullptr: library-sort diagnostic path, nothing of this is needed.
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __re
         __syncthreads();
     }
     const float cell_t = (float)Mt * 0.25f, cell_p = (float)Mp * 0.5f;
+    int vlo = 0x7FFFFFFF, vhi = -1;                                   // voxel ids this thread has seen
     ICET_FOR_CHUNK_OF_SCAN1(i) {
         const float* x = d.s1; const float* y = d.s1 + d.ld1; const float* z = d.s1 + 2 * (size_t)d.ld1;
         const float px = x[i], py = y[i], pz = z[i];
@@ -95,6 +96,20 @@ __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __re
         else if (key32) key32[o] = __float_as_uint(r);
         if (key64 || key32) val[o] = (uint32_t)i;               // library-sort path only
         bin16[o] = (uint16_t)v | (near ? kRowNearBit : (uint16_t)0);
+        vlo = min(vlo, v); vhi = max(vhi, v);
+    }
+    {   // the tile's populated voxel range (a 64-channel scan fills ~1/3 of the id range of the 75 x 24 grid); no atomics: thousands of
+        // waves per pair on one address cost this kernel 150 us per 256 pairs -- the rank sort's per-pair scan reduces the tiles' values
+        __shared__ int s_lo[kBlock / 64], s_hi[kBlock / 64];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { vlo = min(vlo, __shfl_xor(vlo, o)); vhi = max(vhi, __shfl_xor(vhi, o)); }
+        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = vlo; s_hi[threadIdx.x >> 6] = vhi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int lo = s_lo[0], hi = s_hi[0];
+            for (int k = 1; k < kBlock / 64; k++) { lo = min(lo, s_lo[k]); hi = max(hi, s_hi[k]); }
+            tile_vr[((size_t)pair * chunks + chunk) * 2] = lo; tile_vr[((size_t)pair * chunks + chunk) * 2 + 1] = hi;
+        }
     }
     if (splitters) {
         __syncthreads();
@@ -187,7 +202,7 @@ template <bool kBitsInLds>
 __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, const int32_t* __restrict__ pred,
                                                          const unsigned long long* __restrict__ execbits, int32_t* __restrict__ src, int32_t* __restrict__ flags, int max_walk,
                                                          const uint16_t* __restrict__ bin16, uint16_t* __restrict__ binpos, uint32_t* __restrict__ counts, int V,
-                                                         int n_pairs, int chunks) {
+                                                         int n_pairs, int chunks, const int32_t* __restrict__ vrange) {
     extern __shared__ __attribute__((aligned(8))) uint32_t lh[];
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;
@@ -257,8 +272,11 @@ __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const P
         }
     }
     __syncthreads();
+    // only the pair's populated voxel range: the tables of the multi-split are (tiles x V) words -- 109 MB per 256-pair batch each, written
+    // here, scanned by k_bin_tiles, read again by k_bin_scatter -- and nothing outside the range is ever read
     uint32_t* out = counts + ((size_t)pair * chunks + chunk) * V;
-    for (int b = threadIdx.x; b < V; b += kBlock) out[b] = (lh[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
+    const int v0 = min(max(vrange[2 * pair], 0), V), v1 = min(vrange[2 * pair + 1], V - 1);  // (an empty scan: lo = INT_MAX, hi = -1 -> v0 = V > v1, and no overflow in v0 + threadIdx.x)
+    for (int b = v0 + threadIdx.x; b <= v1; b += kBlock) out[b] = (lh[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
 }
 
 // ---- grouping scan-1 rows by voxel, in ascending POSITION order inside each voxel -------------------------------
@@ -338,9 +356,10 @@ __global__ __launch_bounds__(kBlock) void k_scramble_replay(const PairDesc* __re
 // is not scanned by ONE block: k_bin_tiles (one thread per class, blocks over classes) turns each class's per-tile counts into
 // per-tile offsets and leaves the class total in class_start[]; k_bin_scan (one block per pair) scans the totals in place.
 __global__ __launch_bounds__(kBlock) void k_bin_tiles(const uint32_t* __restrict__ counts, uint32_t* __restrict__ tile_base, int32_t* __restrict__ class_start,
-                                                      int V, int chunks) {
+                                                      int V, int chunks, const int32_t* __restrict__ class_range) {
     const int pair = blockIdx.y, b = blockIdx.x * kBlock + threadIdx.x;
     if (b >= V) return;
+    if (class_range && (b < class_range[2 * pair] || b > class_range[2 * pair + 1])) { class_start[(size_t)pair * (V + 1) + b] = 0; return; }   // no row has this class
     const uint32_t* c = counts + (size_t)pair * chunks * V + b;
     uint32_t* tb = tile_base + (size_t)pair * chunks * V + b;
     int tot = 0, t = 0;
@@ -358,11 +377,18 @@ __global__ __launch_bounds__(kBlock) void k_bin_tiles(const uint32_t* __restrict
 // live (optional): the classes holding at least live_min rows, compacted in class order -- the angular bins fitCells1 looks at at
 // all (src/icet.cpp:115) -- so that the fit kernels walk ~1/4 of the grid instead of launching a wave per bin.
 __global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class_start, int V, int32_t* __restrict__ live, int32_t* __restrict__ n_live, int live_min,
-                                                     uint32_t* __restrict__ n_items) {
+                                                     uint32_t* __restrict__ n_items, const int32_t* __restrict__ tile_vr, int chunks, int32_t* __restrict__ vrange_out) {
     __shared__ int wave_tot[kBlock / 64], wave_live[kBlock / 64];
     __shared__ int base, lbase;
     const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { base = 0; lbase = 0; }
+    if (vrange_out && wave == kBlock / 64 - 1) {                  // (rank-sort call) the pair's voxel range from its tiles': the last wave, beside the scan
+        int lo = 0x7FFFFFFF, hi = -1;
+        for (int t = lane; t < chunks; t += 64) { lo = min(lo, tile_vr[((size_t)pair * chunks + t) * 2]); hi = max(hi, tile_vr[((size_t)pair * chunks + t) * 2 + 1]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        if (lane == 0) { vrange_out[2 * pair] = lo; vrange_out[2 * pair + 1] = hi; }
+    }
     __syncthreads();
     for (int v0 = 0; v0 < V; v0 += kBlock) {
         const int b = v0 + threadIdx.x;
@@ -391,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class
 constexpr int kScatterRounds = kKfMaxPtsPerThread;   // a tile is at most 4 waves x this many rounds x 64 positions
 __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const uint16_t* __restrict__ binpos,
                                                         const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bin_start,
-                                                        uint32_t* __restrict__ sorted_row, int V, int vbits, int n_pairs, int chunks) {
+                                                        uint32_t* __restrict__ sorted_row, int V, int vbits, int n_pairs, int chunks, const int32_t* __restrict__ vrange) {
     // LDS: gb[V] (u32: where the tile's rows of a voxel start in the pair's table) | lc[4][V] (u16: per-wave counts, then the running
     // offset of each wave inside the tile's rows of the voxel).  12 bytes per voxel -- 21.6 KB for 75 x 24, seven blocks per CU; with
     // four u32 arrays (28.8 KB, five blocks) the kernel took 260 us per 256 pairs: it wants occupancy (capped at 4 / 3 blocks: 281 / 334).
@@ -429,7 +455,8 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
     {
         const uint32_t* tb = tile_base + ((size_t)pair * chunks + chunk) * V;
         const int32_t* bst = bin_start + (size_t)pair * (V + 1);
-        for (int b = threadIdx.x; b < V; b += kBlock) {
+        const int v0 = min(max(vrange[2 * pair], 0), V), v1 = min(vrange[2 * pair + 1], V - 1);   // no row of the pair lies outside: nothing there is looked up
+        for (int b = v0 + threadIdx.x; b <= v1; b += kBlock) {
             const uint32_t c0 = lc[b], c1 = lc[V + b], c2 = lc[2 * V + b];
             gb[b] = (uint32_t)bst[b] + tb[b];
             lc[b] = 0; lc[V + b] = (uint16_t)c0; lc[2 * V + b] = (uint16_t)(c0 + c1); lc[3 * V + b] = (uint16_t)(c0 + c1 + c2);
@@ -922,9 +949,13 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     int vbits = 1; while ((1 << vbits) < c.V) vbits++;
     const bool batch = c.n_pairs > 1;
     if (!c.use_library_sort) { e = launch_rank_sort_splitters(w, c, st); if (e != hipSuccess) return e; }
+    else {   // diagnostic path: no rank sort, hence nobody reduces the tiles' voxel ranges: the full range (vmin = 0, vmax = "large", clipped to V - 1 by the readers)
+        e = hipMemset2DAsync(w.vrange, 8, 0x00, 4, c.n_pairs, st); if (e != hipSuccess) return e;
+        e = hipMemset2DAsync(w.vrange + 1, 8, 0x7F, 4, c.n_pairs, st); if (e != hipSuccess) return e;
+    }
     k_scan1_spherical<<<grid, blk, scan1_lds_bytes(w), st>>>(w.desc, w.r1, (batch && c.use_library_sort) ? w.key64A : nullptr, c.use_library_sort ? w.keyA : nullptr, w.valA, w.bin16,
                                                               c.T, c.P, np, chunks, c.use_library_sort ? nullptr : w.splitters, w.bkt, w.counts,
-                                                              reinterpret_cast<const LutCell*>(w.lut), w.lut_Mt, w.lut_Mp, w.guard_t, w.guard_p);
+                                                              reinterpret_cast<const LutCell*>(w.lut), w.lut_Mt, w.lut_Mp, w.guard_t, w.guard_p, w.tile_vr);
     ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 4) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     if (c.use_library_sort) {
@@ -951,17 +982,17 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
         ICET_LAUNCH_CHECK();
         const size_t hist_bytes = (size_t)((((c.V + 1) / 2 + 1) & ~1)) * 4, bit_bytes = (size_t)((c.max_n1 + 63) / 64) * 8;
         if (c.exec_bits_lds && hist_bytes + bit_bytes <= kScrambleLdsMax)
-            k_scramble_src<true><<<grid, blk, hist_bytes + bit_bytes, st>>>(w.desc, w.valB, w.pred, w.execbits, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);
+            k_scramble_src<true><<<grid, blk, hist_bytes + bit_bytes, st>>>(w.desc, w.valB, w.pred, w.execbits, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks, w.vrange);
         else
-            k_scramble_src<false><<<grid, blk, hist_bytes, st>>>(w.desc, w.valB, w.pred, w.execbits, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks);
+            k_scramble_src<false><<<grid, blk, hist_bytes, st>>>(w.desc, w.valB, w.pred, w.execbits, w.src, w.flags, max_walk, w.bin16, w.binpos, w.counts, c.V, np, chunks, w.vrange);
         ICET_LAUNCH_CHECK();
         k_scramble_replay<<<c.n_pairs, blk, (size_t)c.V * 4, st>>>(w.desc, w.valB, w.pred /* reused as scratch */, w.src, w.flags, w.bin16, w.binpos, w.counts, c.V, chunks);
         ICET_LAUNCH_CHECK();
         if (c.stage_event && c.stage_at == 2) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     }
-    e = launch_class_scan(w.counts, w.tile_base, w.bin_start, c.V, chunks, c.n_pairs, st, w.live_bins, w.n_live, c.n, w.fit_n_items);
+    e = launch_class_scan(w.counts, w.tile_base, w.bin_start, c.V, chunks, c.n_pairs, st, w.live_bins, w.n_live, c.n, w.fit_n_items, w.vrange);
     if (e != hipSuccess) return e;
-    k_bin_scatter<<<grid, blk, (size_t)c.V * 12 + 8, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks);
+    k_bin_scatter<<<grid, blk, (size_t)c.V * 12 + 8, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks, w.vrange);
     ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 3) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     // keyA / keyB (bucket-grouped keys and the overflow scratch of the rank sort) are dead by now: candidate rows and their r
@@ -990,10 +1021,10 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
 }
 
 hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st,
-                             int32_t* live, int32_t* n_live, int live_min, uint32_t* n_items) {
-    k_bin_tiles<<<dim3((n_classes + kBlock - 1) / kBlock, n_pairs), kBlock, 0, st>>>(counts, tile_base, class_start, n_classes, chunks);
+                             int32_t* live, int32_t* n_live, int live_min, uint32_t* n_items, const int32_t* class_range, const int32_t* tile_vr, int32_t* vrange_out) {
+    k_bin_tiles<<<dim3((n_classes + kBlock - 1) / kBlock, n_pairs), kBlock, 0, st>>>(counts, tile_base, class_start, n_classes, chunks, class_range);
     ICET_LAUNCH_CHECK();
-    k_bin_scan<<<n_pairs, kBlock, 0, st>>>(class_start, n_classes, live, n_live, live_min, n_items);
+    k_bin_scan<<<n_pairs, kBlock, 0, st>>>(class_start, n_classes, live, n_live, live_min, n_items, tile_vr, chunks, vrange_out);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

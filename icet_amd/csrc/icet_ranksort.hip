@@ -330,7 +330,8 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
     const int groups = grid_groups(np);
     dim3 grid(groups * chunks), blk(kBlock);
     // (buckets bkt[] and the per-tile histograms counts[] were produced by k_scan1_spherical)
-    hipError_t e = launch_class_scan(w.counts, w.tile_base, w.bucket_start, kMaxBuckets, chunks, np, st);
+    // (its per-pair scan block also reduces the tiles' voxel ranges, written by k_scan1_spherical, to the pair's)
+    hipError_t e = launch_class_scan(w.counts, w.tile_base, w.bucket_start, kMaxBuckets, chunks, np, st, nullptr, nullptr, 0, nullptr, nullptr, w.tile_vr, w.vrange);
     if (e != hipSuccess) return e;
     k_rs_scatter<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks);
     ICET_LAUNCH_CHECK();

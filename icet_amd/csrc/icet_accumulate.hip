@@ -26,6 +26,7 @@ constexpr int kAccPts = ICET_ACC_PTS;                      // consecutive points
 constexpr int kAccBlock = ICET_ACC_BLOCK;        // k_gn_accumulate: the waves of a block share one copy of the pair's LDS tables
 constexpr int kAccWavesPerSimd = ICET_ACC_WAVES; // register budget: 6 -> 84 VGPRs, no spills, three 512-thread blocks per CU (with 1536 blocks per 256-pair launch: 130 -> 121 us); 8 spills
 constexpr int kXf = 48;                          // per-pair transform record, see write_xf (icet_solve.hip)
+constexpr int kHotWords = 8;                     // LDS record of an active voxel in k_gn_accumulate: inner, outer, mu1 (5 words) at a 32-byte stride: ds_read_b128 + ds_read_b32, address by shift
 
 // One pass of fitScan2's point work over a chunk of one pair's scan 2.
 //   points2 = (points2_OG.rowwise() + t) * R          src/icet.cpp:375-378
@@ -103,8 +104,9 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_a
     // fixed-point sums with the conversion bias still in them (to_fix_biased) -- constant offsets inside a flush, one 64-bit add
     // for the counts, two VALU instructions per value; the bias comes out once per slot when the block hands its sums to HBM
     unsigned long long* lacc = reinterpret_cast<unsigned long long*>(lut_p + (Mp + 1));
-    float* hot = reinterpret_cast<float*>(lacc + 10 * lds_slots);         // lds_slots x 5: inner, outer, mu1
-    int16_t* map = reinterpret_cast<int16_t*>(hot + lds_slots * 5);
+    // lds_slots x 8 floats, 16-byte aligned (one ds_read_b128 + one ds_read_b96 per point): the four radial thresholds of radial_zones, mu1, pad
+    float* hot = reinterpret_cast<float*>(smem + (((size_t)(Mt + Mp + 2) * sizeof(LutCell) + (size_t)80 * lds_slots + 15) & ~(size_t)15));
+    int16_t* map = reinterpret_cast<int16_t*>(hot + lds_slots * kHotWords);
     const int map_words = (V + 1) / 2;
     uint32_t* nearq = reinterpret_cast<uint32_t*>(map) + (V + T + 4) / 2;   // kNearCap point indices, then the fill counter
     const int ns = n_slots[pair];
@@ -118,7 +120,11 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_a
         const uint2* gl = reinterpret_cast<const uint2*>(lut);
         uint2* ll = reinterpret_cast<uint2*>(lut_t);
         for (int i = threadIdx.x; i < Mt + Mp + 2; i += kAccBlock) ll[i] = gl[i];
-        for (int i = threadIdx.x; i < nl * 5; i += kAccBlock) { int s = i / 5, k = i - s * 5; hot[i] = reinterpret_cast<const float*>(hs + s)[4 + k]; }
+        for (int i = threadIdx.x; i < nl; i += kAccBlock) {
+            const SlotHot g = hs[i];
+            float* h = hot + i * kHotWords;
+            h[0] = g.inner; h[1] = g.outer; h[2] = g.mu[0]; h[3] = g.mu[1]; h[4] = g.mu[2];
+        }
         for (int i = threadIdx.x; i < 10 * nl; i += kAccBlock) lacc[i] = 0ull;   // only the rows in use
         if (threadIdx.x == 0) nearq[kNearCap] = 0u;
     }
@@ -183,14 +189,28 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_a
 #pragma unroll
       for (int g = 0; g < kAccPts / 4; g++) {
         const int i0 = t0 + 4 * g;
-        float X[4], Y[4], Z[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) { X[j] = XN[j]; Y[j] = YN[j]; Z[j] = ZN[j]; }
-        if (g + 1 < kAccPts / 4) load4(i0 + 4, XN, YN, ZN);
-        else if (t0 + kAccPts * kAccBlock < begin + cs) load4(t0 + kAccPts * kAccBlock, XN, YN, ZN);
-        if (ICET_ACC_PHASE == 0) { sink += (X[0] + X[1] + X[2] + X[3]) + (Y[0] + Y[1] + Y[2] + Y[3]) + (Z[0] + Z[1] + Z[2] + Z[3]); continue; }
         PointClass pc[4];
         float QX[4], QY[4], QZ[4], RR[4];
+        // == transform_point (icet_device_common.h), on the scalars already in registers: the deferred literal path must see the same bits.
+        // Done for all 4 points BEFORE the next group's loads are issued into the same registers (no copy of the 12 prefetched words).
+        {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 q[6];                                                      // (x, y, z) of points 0-1, then of points 2-3: one packed instruction per two points
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const f2 a = f2{XN[2 * h], XN[2 * h + 1]} + f2{tx, tx}, b = f2{YN[2 * h], YN[2 * h + 1]} + f2{ty, ty}, c = f2{ZN[2 * h], ZN[2 * h + 1]} + f2{tz, tz};
+                q[3 * h + 0] = __builtin_elementwise_fma(c, f2{R20, R20}, __builtin_elementwise_fma(b, f2{R10, R10}, a * f2{R00, R00}));
+                q[3 * h + 1] = __builtin_elementwise_fma(c, f2{R21, R21}, __builtin_elementwise_fma(b, f2{R11, R11}, a * f2{R01, R01}));
+                q[3 * h + 2] = __builtin_elementwise_fma(c, f2{R22, R22}, __builtin_elementwise_fma(b, f2{R12, R12}, a * f2{R02, R02}));
+            }
+            // (the empty asm pins the order: the compiler would otherwise hoist the loads and copy the 12 registers first)
+            asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]) : : "memory");
+#pragma unroll
+            for (int h = 0; h < 2; h++) { QX[2 * h] = q[3 * h].x; QX[2 * h + 1] = q[3 * h].y; QY[2 * h] = q[3 * h + 1].x; QY[2 * h + 1] = q[3 * h + 1].y; QZ[2 * h] = q[3 * h + 2].x; QZ[2 * h + 1] = q[3 * h + 2].y; }
+        }
+        if (g + 1 < kAccPts / 4) load4(i0 + 4, XN, YN, ZN);
+        else if (t0 + kAccPts * kAccBlock < begin + cs) load4(t0 + kAccPts * kAccBlock, XN, YN, ZN);
+        if (ICET_ACC_PHASE == 0) { sink += (QX[0] + QX[1] + QX[2] + QX[3]) + (QY[0] + QY[1] + QY[2] + QY[3]) + (QZ[0] + QZ[1] + QZ[2] + QZ[3]); continue; }
         int SM[4];
         bool nr[4];
         float R2[4];
@@ -199,12 +219,7 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_a
         // that the four look-up chains overlap. ----
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            // == transform_point (icet_device_common.h), on the scalars already in registers: the deferred literal path must see the same bits
-            const float a = X[j] + tx, b = Y[j] + ty, c = Z[j] + tz;
-            const float qx = fmaf(c, R20, fmaf(b, R10, a * R00));
-            const float qy = fmaf(c, R21, fmaf(b, R11, a * R01));
-            const float qz = fmaf(c, R22, fmaf(b, R12, a * R02));
-            QX[j] = qx; QY[j] = qy; QZ[j] = qz;
+            const float qx = QX[j], qy = QY[j], qz = QZ[j];
             const float r2 = qx * qx + qy * qy + qz * qz;
             const float rs = __builtin_amdgcn_rsqf(r2);
             RR[j] = r2 * rs;                                             // |q|
@@ -241,17 +256,25 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_a
             for (int j = 0; j < 4; j++) {
                 const int sm = E[j];
                 const bool has = sm >= 0;
-                const float* h = hot + min(max(sm, 0), lds_slots - 1) * 5;
+                const float* h = hot + min(max(sm, 0), lds_slots - 1) * kHotWords;
                 float inner = h[0], outer = h[1], m0 = h[2], m1 = h[3], m2 = h[4];
                 if (beyond) {
                     if (sm >= nl) { const SlotHot g = hs[sm]; inner = g.inner; outer = g.outer; m0 = g.mu[0]; m1 = g.mu[1]; m2 = g.mu[2]; }
+                    // The record must have ARRIVED before this rare branch rejoins the common path: vmcnt counts loads in issue order, so a
+                    // wait for these five words placed after the join (where the compiler puts it: at the first use) is `s_waitcnt vmcnt(0)`
+                    // on EVERY trip -- a wait for the next trip's point loads as well.
+                    asm volatile("" : "+v"(inner), "+v"(outer), "+v"(m0), "+v"(m1), "+v"(m2));
                 }
+                // |q| against the cluster's radial bounds (filterPointsInsideCluster, src/icet.cpp:299).  r = r2 * rsq(r2) is good to a few
+                // ulps, so a point within 1e-6 r of a bound waits for the literal formulas.  With m = min(r - inner, outer - r), the signed
+                // distance to the nearer bound (inner <= outer), "near a bound" is |m| < guard and "inside" is m >= 0.
                 const float r = RR[j];
                 const float gr = 1e-6f * r;
-                const bool edge = has & (!(fabsf(r - inner) >= gr) | !(fabsf(r - outer) >= gr));
+                const float m = fminf(r - inner, outer - r);
+                const bool edge = has & !(fabsf(m) >= gr);
                 nr[j] |= edge;
                 pc[j].s = edge ? -1 : sm;
-                pc[j].inb = has & (r >= inner) & (r <= outer);
+                pc[j].inb = has & (m >= 0.f);
                 float ux = QX[j], uy = QY[j], uz = QZ[j];
                 if (kRT2) { if (pc[j].inb & !edge) roundtrip_any(ux, uy, uz, ux, uy, uz); }
                 pc[j].dx = ux - m0; pc[j].dy = uy - m1; pc[j].dz = uz - m2;
@@ -307,10 +330,10 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_a
             const uint32_t zi = (i3 ? 1u : 0u) + ((z2 & i2) ? 1u : 0u) + ((z1 & i1) ? 1u : 0u);
             const bool fw = z3 & (s3 >= 0) & (wave_shl1(s0, -2) == s3);
             const bool h1 = fw & z1 & i1, h2 = fw & z2 & i2, h3 = fw & i3;
-            const float g1x = wave_shr1(h1 ? pc[1].dx : 0.f, 0.f), g1y = wave_shr1(h1 ? pc[1].dy : 0.f, 0.f), g1z = wave_shr1(h1 ? pc[1].dz : 0.f, 0.f);
-            const float g2x = wave_shr1(h2 ? pc[2].dx : 0.f, 0.f), g2y = wave_shr1(h2 ? pc[2].dy : 0.f, 0.f), g2z = wave_shr1(h2 ? pc[2].dz : 0.f, 0.f);
-            const float g3x = wave_shr1(h3 ? pc[3].dx : 0.f, 0.f), g3y = wave_shr1(h3 ? pc[3].dy : 0.f, 0.f), g3z = wave_shr1(h3 ? pc[3].dz : 0.f, 0.f);
-            const uint32_t gc = (uint32_t)wave_shr1((int)(fw ? (zr | (zi << 8)) : 0u), 0);      // raw | in-bounds counts of what arrives
+            const float g1x = wave_shr1_zero(h1 ? pc[1].dx : 0.f), g1y = wave_shr1_zero(h1 ? pc[1].dy : 0.f), g1z = wave_shr1_zero(h1 ? pc[1].dz : 0.f);
+            const float g2x = wave_shr1_zero(h2 ? pc[2].dx : 0.f), g2y = wave_shr1_zero(h2 ? pc[2].dy : 0.f), g2z = wave_shr1_zero(h2 ? pc[2].dz : 0.f);
+            const float g3x = wave_shr1_zero(h3 ? pc[3].dx : 0.f), g3y = wave_shr1_zero(h3 ? pc[3].dy : 0.f), g3z = wave_shr1_zero(h3 ? pc[3].dz : 0.f);
+            const uint32_t gc = (uint32_t)wave_shr1_zero((int)(fw ? (zr | (zi << 8)) : 0u));      // raw | in-bounds counts of what arrives
             f2 Axy, Asq, Acz; float A2, A4, A8;
             {   // the points handed over by the previous lane come first (zeros when there are none)
                 Axy = f2{g1x, g1y}; A2 = g1z; Asq = Axy * Axy; Acz = f2{g1z, g1z} * Axy; A4 = g1x * g1y; A8 = g1z * g1z;
@@ -447,15 +470,15 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     // spill busy voxels to HBM atomics, more rows cost occupancy); a small batch has
     // CUs to spare, so a block may take most of a CU's LDS and keep every active voxel of a fine grid (150 x 48: often
     // > 1000) out of the slow HBM-atomic path.
-    const size_t fixed = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)((c.V + c.T + 4) / 2) * 4 + (kNearCap + 1) * 4 + 16;
-    const size_t row = (5 + kAccLds) * 4;
+    const size_t fixed = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)((c.V + c.T + 4) / 2) * 4 + (kNearCap + 1) * 4 + 32;   // + alignment of the hot records
+    const size_t row = (kHotWords + kAccLds) * 4;
     const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : 144 * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU
     int lds_slots = c.lds_slots > 0 ? c.lds_slots : (int)((budget > fixed ? budget - fixed : 0) / row);
     lds_slots = lds_slots < 32 ? 32 : lds_slots;
     if (lds_slots > c.V) lds_slots = c.V;
     int chunks = chunks_for(c.n_pairs, c.max_n2, kAccBlock * c.acc_min_pts_per_thread, c.acc_target_blocks);
     chunks = std::max(chunks, (int)(((long long)c.max_n2 + (1 << 20) - 1) >> 20));          // a block's counts live in 21-bit fields: at most 2^20 (+ rounding) points per block
-    const size_t lds = fixed + (size_t)lds_slots * (5 + kAccLds) * 4;
+    const size_t lds = fixed + (size_t)lds_slots * row;
     dim3 grid(grid_groups(c.n_pairs) * chunks), blk(kAccBlock);
     const LutCell* lut = reinterpret_cast<const LutCell*>(w.lut);
 #define ICET_ACC_LAUNCH(V4, RT) k_gn_accumulate<V4, RT><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp, \

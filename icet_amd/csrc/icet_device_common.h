@@ -189,6 +189,9 @@ __device__ __forceinline__ void classify_angular_fast(float qx, float qy, float 
 // lane i receives x of lane i - 1; lane 0 receives `fill`
 __device__ __forceinline__ int wave_shr1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
 __device__ __forceinline__ float wave_shr1(float x, float fill) { return __int_as_float(wave_shr1(__float_as_int(x), __float_as_int(fill))); }
+// the same with 0 for lane 0, through DPP's bound control: the destination needs no prior value, i.e. no v_mov per call
+__device__ __forceinline__ int wave_shr1_zero(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true); }
+__device__ __forceinline__ float wave_shr1_zero(float x) { return __int_as_float(wave_shr1_zero(__float_as_int(x))); }
 // lane i receives x of lane i + 1; lane 63 receives `fill`
 __device__ __forceinline__ int wave_shl1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
 // inclusive prefix maximum over the 64 lanes, for values >= -1 (-1 = "nothing"): four row_shr steps inside the rows of 16, then the

@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
 #ifndef ICET_RT_BLOCKS
 #define ICET_RT_BLOCKS 2048
 #endif
-struct FitItem { int32_t pair, v, k0, nb; };      // rows k0 .. k0 + nb of bin v's compacted candidates
+struct FitItem { int32_t base, v, k0, nb; };      // rows k0 .. k0 + nb of bin v's compacted candidates; base = the bin's start + k0 (relative to the pair's segment)
 // A pair owns the item slots [item_base, item_base + n1 / 64 + V): at most one partial batch per bin plus the full ones.
 __device__ __host__ __forceinline__ size_t item_base(int32_t off1, int pair, int V) { return (size_t)(off1 / 64) + (size_t)pair * (size_t)(V + 1); }
 
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_fit_cluster(const PairDesc* __res
             if (lane == 0 && nbatch > 0) slot = atomicAdd(&n_items[pair], (uint32_t)nbatch);
             slot = __shfl(slot, 0);
             FitItem* mine = items + item_base(d.off1, pair, V);
-            for (int bI = lane; bI < nbatch; bI += 64) { FitItem it; it.pair = pair; it.v = v; it.k0 = 64 * bI; it.nb = min(64, m_cand - 64 * bI); mine[slot + bI] = it; }
+            for (int bI = lane; bI < nbatch; bI += 64) { FitItem it; it.base = bs + 64 * bI; it.v = v; it.k0 = 64 * bI; it.nb = min(64, m_cand - 64 * bI); mine[slot + bI] = it; }
         }
 #endif
     }
@@ -659,28 +659,47 @@ __global__ __launch_bounds__(kBlock, ICET_FIT_WAVES) void k_fit_roundtrip(const 
     const PairDesc d = desc[pair];
     const uint32_t n_it = n_items[pair];
     const FitItem* mine = items + item_base(d.off1, pair, V);
-    for (uint32_t w = chunk * (kBlock / 64) + (threadIdx.x >> 6); w < n_it; w += chunks * (kBlock / 64)) {
-        const FitItem it = mine[w];
-        if (lane >= it.nb) continue;
-        const size_t idx = (size_t)d.off1 + bin_start[(size_t)it.pair * (V + 1) + it.v] + it.k0 + lane;
-        const uint32_t rw = cand[idx]; const float r = cand_r[idx];
-        const uint32_t row = rw & kRowMask;
-        const float* sx = d.s1;
+    const uint32_t stride = chunks * (kBlock / 64), w0 = chunk * (kBlock / 64) + (threadIdx.x >> 6);
+    if (w0 >= n_it) return;                                            // wave-uniform
+    typedef __attribute__((address_space(1))) const float gfloat;      // the scan lives in HBM: global_load (vmcnt only), not flat
+    gfloat* sx = (gfloat*)d.s1;
+    // An item is a chain of dependent reads -- item record -> candidate row -> the row's coordinates (a gather) -- in front of ~350
+    // double-precision instructions; walked one item at a time a wave spent three memory round trips per item waiting (76 % of its
+    // cycles).  The chain is therefore software-pipelined over the wave's items: while item k is computed the coordinates of item
+    // k + 1, the candidate rows of item k + 2 and the record of item k + 3 are in flight.  Look-ahead past the wave's last item
+    // re-reads the pair's last record with nb = 0 (valid addresses, nothing stored); lanes past an item's nb read its last row.
+    struct Cand { uint32_t rw; float r; };
+    auto load_item = [&](uint32_t w) { FitItem it = mine[min(w, n_it - 1u)]; if (w >= n_it) it.nb = 0; return it; };
+    auto load_cand = [&](const FitItem& it) { const size_t idx = (size_t)d.off1 + it.base + min(lane, max(it.nb - 1, 0)); Cand c; c.rw = cand[idx]; c.r = cand_r[idx]; return c; };
+    auto gather = [&](const Cand& c, float& x, float& y, float& z) { const uint32_t row = c.rw & kRowMask; x = sx[row]; y = sx[d.ld1 + row]; z = sx[2 * (size_t)d.ld1 + row]; };
+    FitItem i0 = load_item(w0), i1 = load_item(w0 + stride), i2 = load_item(w0 + 2 * stride);
+    Cand c0 = load_cand(i0), c1 = load_cand(i1);
+    float x0, y0, z0;
+    gather(c0, x0, y0, z0);
+    for (uint32_t w = w0; w < n_it; w += stride) {
+        const FitItem i3 = load_item(w + 3 * stride);
+        const Cand c2 = load_cand(i2);
+        float x1, y1, z1;
+        gather(c1, x1, y1, z1);
         float th, ph, X, Y, Z;
 #if defined(ICET_EXP_FIT) && ICET_EXP_FIT == 1
-        X = sx[row]; Y = sx[d.ld1 + row]; Z = sx[2 * (size_t)d.ld1 + row]; th = 0.f; ph = 0.f;
+        X = x0; Y = y0; Z = z0; th = 0.f; ph = 0.f;
 #else
-        roundtrip_cr(sx[row], sx[d.ld1 + row], sx[2 * (size_t)d.ld1 + row], r, th, ph, X, Y, Z);
+        roundtrip_cr(x0, y0, z0, c0.r, th, ph, X, Y, Z);
 #endif
         // The angular half of the filter holds by construction for a row classified away from every edge (the same argument as
         // for the bin itself); a row flagged near-edge is tested with the literal formulas.  NaN angles (r = 0, NaN rows) fail the
         // test, like the reference's 1000 sentinel.
-        if (rw & kSortedNearBit) {
+        if (c0.rw & kSortedNearBit) {
             float az0, az1, el0, el1;
-            voxel_limits(it.v % T, it.v / T, T, P, az0, az1, el0, el1);
+            voxel_limits(i0.v % T, i0.v / T, T, P, az0, az1, el0, el1);
             if (!(th >= az0 && th <= az1 && ph >= el0 && ph <= el1)) X = __builtin_nanf("");     // marks "did not survive"
         }
-        cart1[idx] = X; cart1[cart_stride + idx] = Y; cart1[2 * cart_stride + idx] = Z;
+        if (lane < i0.nb) {
+            const size_t idx = (size_t)d.off1 + i0.base + lane;
+            cart1[idx] = X; cart1[cart_stride + idx] = Y; cart1[2 * cart_stride + idx] = Z;
+        }
+        i0 = i1; i1 = i2; i2 = i3; c0 = c1; c1 = c2; x0 = x1; y0 = y1; z0 = z1;
     }
 }
 

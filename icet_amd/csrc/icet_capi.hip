@@ -89,7 +89,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, dev_realloc(w.seg_off, (size_t)np + 1));
         HIPCHK(c, dev_realloc(w.bin_count, pv));
         HIPCHK(c, dev_realloc(w.bin_start, (size_t)np * (VV + 1)));
-        HIPCHK(c, dev_realloc(w.live_bins, pv)); HIPCHK(c, dev_realloc(w.n_live, np));
+        HIPCHK(c, dev_realloc(w.live_bins, pv * 4)); HIPCHK(c, dev_realloc(w.n_live, np));
         HIPCHK(c, dev_realloc(w.hotD, pv)); HIPCHK(c, dev_realloc(w.fitD, pv)); HIPCHK(c, dev_realloc(w.activeD, pv)); HIPCHK(c, dev_realloc(w.midD, pv));
         HIPCHK(c, dev_realloc(w.hotS, pv)); HIPCHK(c, dev_realloc(w.fitS, pv));
         HIPCHK(c, dev_realloc(w.slot_of_voxel, (size_t)np * ((VV + 1) & ~1)));

@@ -101,7 +101,7 @@ struct Workspace {
     int32_t *bin_count = nullptr, *bin_start = nullptr;             // pairs x V, pairs x (V+1)
     SlotHot* hotD = nullptr; SlotFit* fitD = nullptr; int32_t* activeD = nullptr;   // dense, pairs x V
     FitMid* midD = nullptr;                                                          // dense, pairs x V
-    int32_t* live_bins = nullptr; int32_t* n_live = nullptr;                         // pairs x V: bins holding >= n rows, compacted; pairs: their number
+    int32_t* live_bins = nullptr; int32_t* n_live = nullptr;                         // pairs x V records of 4 words {bin, first row, rows, candidates}: bins holding >= n rows, compacted; pairs: their number
     void* fit_items = nullptr; size_t cap_fit_items = 0; uint32_t* fit_n_items = nullptr;   // work items of k_fit_roundtrip (16 B each) and their count
     SlotHot* hotS = nullptr; SlotFit* fitS = nullptr;                               // compact, pairs x V
     int16_t* slot_of_voxel = nullptr; int32_t* n_slots = nullptr;

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_tiles(const uint32_t* __restrict
     class_start[(size_t)pair * (V + 1) + b] = tot;
 }
 
-// live (optional): the classes holding at least live_min rows, compacted in class order -- the angular bins fitCells1 looks at at
+// live (optional): the classes holding at least live_min rows, compacted in class order (16-byte records, pairs x V of them) -- the angular bins fitCells1 looks at at
 // all (src/icet.cpp:115) -- so that the fit kernels walk ~1/4 of the grid instead of launching a wave per bin.
 __global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class_start, int V, int32_t* __restrict__ live, int32_t* __restrict__ n_live, int live_min,
                                                      uint32_t* __restrict__ n_items, const int32_t* __restrict__ tile_vr, int chunks, int32_t* __restrict__ vrange_out) {
@@ -404,7 +404,8 @@ __global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class
         for (int k = 0; k < wave; k++) { woff += wave_tot[k]; loff += wave_live[k]; }
         const int bb = base, lb = lbase;
         if (b < V) class_start[(size_t)pair * (V + 1) + b] = bb + woff + incl - tot;
-        if ((lm >> lane) & 1ull) live[(size_t)pair * V + lb + loff + __popcll(lm & ((1ull << lane) - 1ull))] = b;
+        if ((lm >> lane) & 1ull)      // {class, first row, rows, (candidates: k_fit_cluster)}: what a fit wave needs about its bin in ONE 16-byte read
+            reinterpret_cast<int4*>(live)[(size_t)pair * V + lb + loff + __popcll(lm & ((1ull << lane) - 1ull))] = make_int4(b, bb + woff + incl - tot, tot, 0);
         __syncthreads();
         if (threadIdx.x == kBlock - 1) { base = bb + woff + incl; lbase = lb + loff + __popcll(lm); }
         __syncthreads();
@@ -513,14 +514,27 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
 #ifndef ICET_RT_BLOCKS
 #define ICET_RT_BLOCKS 2048
 #endif
+// k_fit_cluster walks its bins one at a time: the pipeline of k_fit_roundtrip / k_fit_moments (ICET_CLUSTER_PIPE 1: r of bin k + 1, rows of
+// bin k + 2 and record of bin k + 3 in flight while bin k is walked) needs 72 VGPRs, and the kernel is bound by the walk's own chain of
+// DPP scans, ballots and LDS shuffles, which wants 8 waves per SIMD -- measured per 256-pair keyframe: off / 8 waves 1.527 ms,
+// on / 6 waves 1.547, on / 8 waves (10 spills) 1.569.  k_fit_moments keeps its pipeline at 8 waves (2 spilled words, outside the loop).
+#ifndef ICET_CLUSTER_WAVES
+#define ICET_CLUSTER_WAVES 8
+#endif
+#ifndef ICET_MOM_WAVES
+#define ICET_MOM_WAVES 8
+#endif
+#ifndef ICET_CLUSTER_PIPE
+#define ICET_CLUSTER_PIPE 0
+#endif
 struct FitItem { int32_t base, v, k0, nb; };      // rows k0 .. k0 + nb of bin v's compacted candidates; base = the bin's start + k0 (relative to the pair's segment)
 // A pair owns the item slots [item_base, item_base + n1 / 64 + V): at most one partial batch per bin plus the full ones.
 __device__ __host__ __forceinline__ size_t item_base(int32_t off1, int pair, int V) { return (size_t)(off1 / 64) + (size_t)pair * (size_t)(V + 1); }
 
-__global__ __launch_bounds__(kBlock, 8) void k_fit_cluster(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
+__global__ __launch_bounds__(kBlock, ICET_CLUSTER_WAVES) void k_fit_cluster(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
                                                       const uint32_t* __restrict__ sorted_row, const float* __restrict__ r1,
                                                       uint32_t* __restrict__ cand, float* __restrict__ cand_r, FitItem* __restrict__ items, uint32_t* __restrict__ n_items,
-                                                      const int32_t* __restrict__ live, const int32_t* __restrict__ n_live,
+                                                      int32_t* __restrict__ live, const int32_t* __restrict__ n_live,
                                                       FitMid* __restrict__ midD, int T, int P, int n, float thresh, float buff, int n_pairs, int chunks, int half_gap) {
     __shared__ float stage[kBlock / 64][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -530,33 +544,53 @@ __global__ __launch_bounds__(kBlock, 8) void k_fit_cluster(const PairDesc* __res
     const PairDesc d = desc[pair];
     const int nl = n_live[pair];
     // a fixed number of waves per pair walks the pair's live bins (those with >= n rows, src/icet.cpp:115): a wave per bin of the
-    // grid would launch 4 x as many waves as have work (measured: ~90 us of dispatching empty blocks per 256-pair launch)
-    for (int j = chunk * (kBlock / 64) + wave; j < nl; j += chunks * (kBlock / 64)) {
-    const int v = live[(size_t)pair * V + j];
-    const int bs = bin_start[(size_t)pair * (V + 1) + v];
-    const int cnt = bin_start[(size_t)pair * (V + 1) + v + 1] - bs;
-    const size_t base = (size_t)d.off1 + bs;
-    // rows of this bin in (scrambled) position order: sorted_row[base + i] is the row of the pair's input-order tables
-    // (top bit: the row lies within a guard band of a voxel edge)
+    // grid would launch 4 x as many waves as have work (measured: ~90 us of dispatching empty blocks per 256-pair launch).
+    // A bin is a chain of dependent reads -- bin record ({bin, first row, rows}: one 16-byte read) -> the bin's rows -> their r (a
+    // gather) -- before the walk can start; see ICET_CLUSTER_PIPE above for the pipelined variant (not the default).
+    const int stride = chunks * (kBlock / 64), j0 = chunk * (kBlock / 64) + wave;
+    if (j0 >= nl) return;                                             // wave-uniform; no block-wide barrier below
     const size_t po = (size_t)d.off1;
     constexpr uint32_t kRowMask = ~kSortedNearBit;
+    constexpr int kCache = 4;                                         // a bin's first 4 x 64 rows travel in registers (most bins hold ~100-400 rows)
+    const int4* lv = reinterpret_cast<const int4*>(live) + (size_t)pair * V;
+    auto info = [&](int j) { int4 q = lv[min(j, nl - 1)]; if (j >= nl) q.z = 0; return q; };
+    auto rows4 = [&](const int4& q, uint32_t (&rw)[kCache]) {
+#pragma unroll
+        for (int k = 0; k < kCache; k++) rw[k] = (lane + 64 * k < q.z) ? sorted_row[po + q.y + lane + 64 * k] : 0u;
+    };
+    auto radii4 = [&](const int4& q, const uint32_t (&rw)[kCache], float (&rr)[kCache]) {
+#pragma unroll
+        for (int k = 0; k < kCache; k++) rr[k] = (lane + 64 * k < q.z) ? r1[po + (rw[k] & kRowMask)] : 0.f;
+    };
+#if ICET_CLUSTER_PIPE
+    int4 q0 = info(j0), q1 = info(j0 + stride), q2 = info(j0 + 2 * stride);
+    uint32_t prw[kCache], prw1[kCache];
+    rows4(q0, prw); rows4(q1, prw1);
+    float pr[kCache];
+    radii4(q0, prw, pr);
+#endif
+    for (int j = j0; j < nl; j += stride) {
+#if ICET_CLUSTER_PIPE
+    const int4 q3 = info(j + 3 * stride);
+    uint32_t prw2[kCache];
+    rows4(q2, prw2);
+    float pr1[kCache];
+    radii4(q1, prw1, pr1);
+#else
+    const int4 q0 = info(j);
+    uint32_t prw[kCache]; float pr[kCache];
+    rows4(q0, prw); radii4(q0, prw, pr);
+#endif
+    const int v = q0.x, bs = q0.y, cnt = q0.z;
+    const size_t base = po + bs;
+    // rows of this bin in (scrambled) position order: sorted_row[base + i] is the row of the pair's input-order tables
+    // (top bit: the row lies within a guard band of a voxel edge)
     auto RS = [&](int i) { return r1[po + (sorted_row[base + i] & kRowMask)]; };
 
     float inner = 0.f, outer = 0.f;
     int m_cand = 0;                                                   // rows inside the radial range (wave-uniform)
 
     {
-        // The bin's first 4 x 64 rows are fetched up front with independent loads (most bins hold ~100-400 rows), so
-        // the serial walks below run on registers instead of paying one memory round trip per 64 rows.
-        constexpr int kCache = 4;
-        float pr[kCache]; uint32_t prw[kCache];
-#pragma unroll
-        for (int k = 0; k < kCache; k++) {
-            const int i = lane + 64 * k;
-            prw[k] = (i < cnt) ? sorted_row[base + i] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < kCache; k++) pr[k] = (lane + 64 * k < cnt) ? r1[po + (prw[k] & kRowMask)] : 0.f;
         // ---- findCluster (src/icet.cpp:557-607): first run of >= n consecutive points whose
         // successive |dr| <= thresh, walking the bin in stored (scrambled) order.
         int run_start = 0; float front = 0.f; float carry_prev = 0.f; bool found = false;
@@ -640,7 +674,13 @@ __global__ __launch_bounds__(kBlock, 8) void k_fit_cluster(const PairDesc* __res
     // same wave wrote and reads: LDS operations of one wave complete in order
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     if (lane < 16) reinterpret_cast<float*>(midD + (size_t)pair * V + v)[lane] = stage[wave][lane];
+    if (lane == 0) live[((size_t)pair * V + j) * 4 + 3] = m_cand;     // for k_fit_moments: the whole of its bin in the one record
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#if ICET_CLUSTER_PIPE
+    q0 = q1; q1 = q2; q2 = q3;
+#pragma unroll
+    for (int k = 0; k < kCache; k++) { prw[k] = prw1[k]; prw1[k] = prw2[k]; pr[k] = pr1[k]; }
+#endif
     }   // live bins of this wave
 }
 
@@ -703,29 +743,52 @@ __global__ __launch_bounds__(kBlock, ICET_FIT_WAVES) void k_fit_roundtrip(const 
     }
 }
 
-__global__ __launch_bounds__(kBlock, 8) void k_fit_moments(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start, const float* __restrict__ cart1,
+__global__ __launch_bounds__(kBlock, ICET_MOM_WAVES) void k_fit_moments(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start, const float* __restrict__ cart1,
                                                       size_t cart_stride, const int32_t* __restrict__ live, const int32_t* __restrict__ n_live,
                                                       FitMid* __restrict__ midD, int V, int n, int n_pairs, int chunks) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;
     const int nl = n_live[pair];
-    for (int j = chunk * (kBlock / 64) + wave; j < nl; j += chunks * (kBlock / 64)) {
-    const int v = live[(size_t)pair * V + j];
-    FitMid* mid = midD + (size_t)pair * V + v;
-    const int m = mid->pad[0];                                        // candidates of this bin (k_fit_cluster)
+    const int stride = chunks * (kBlock / 64), j0 = chunk * (kBlock / 64) + wave;
+    if (j0 >= nl) return;
+    // Software-pipelined like the two kernels before it: while bin k is summed, the first 256 round-tripped rows of bin k + 1 and the
+    // record of bin k + 2 ({class, first row, rows, candidates}: k_bin_scan / k_fit_cluster) are in flight.
+    constexpr int kKeep = 4;                                          // the first 256 rows stay in registers for the centred pass
+    const size_t po = (size_t)desc[pair].off1;
+    const int4* lv = reinterpret_cast<const int4*>(live) + (size_t)pair * V;
+    auto info = [&](int j) { int4 q = lv[min(j, nl - 1)]; if (j >= nl) q.w = 0; return q; };
+    auto fetch = [&](const int4& q, float (&fx)[kKeep], float (&fy)[kKeep], float (&fz)[kKeep]) {
+        const float* qx = cart1 + po + q.y; const float* qy = qx + cart_stride; const float* qz = qy + cart_stride;
+#pragma unroll
+        for (int k = 0; k < kKeep; k++) {
+            const int i = lane + 64 * k;
+            fx[k] = (i < q.w) ? qx[i] : __builtin_nanf(""); fy[k] = (i < q.w) ? qy[i] : 0.f; fz[k] = (i < q.w) ? qz[i] : 0.f;
+        }
+    };
+    int4 q0 = info(j0), q1 = info(j0 + stride);
+    float cx[kKeep], cy[kKeep], cz[kKeep];
+    fetch(q0, cx, cy, cz);
+    for (int j = j0; j < nl; j += stride) {
+    const int4 q2 = info(j + 2 * stride);
+    float nx[kKeep], ny[kKeep], nz[kKeep];
+    fetch(q1, nx, ny, nz);
+    const int4 qc = q0;
+    float ux[kKeep], uy[kKeep], uz[kKeep];
+#pragma unroll
+    for (int k = 0; k < kKeep; k++) { ux[k] = cx[k]; uy[k] = cy[k]; uz[k] = cz[k]; cx[k] = nx[k]; cy[k] = ny[k]; cz[k] = nz[k]; }
+    q0 = q1; q1 = q2;
+    const int v = qc.x;
+    const int m = qc.w;                                               // candidates of this bin (k_fit_cluster)
     if (m <= 0) continue;
-    const size_t base = (size_t)desc[pair].off1 + bin_start[(size_t)pair * (V + 1) + v];
+    FitMid* mid = midD + (size_t)pair * V + v;
+    const size_t base = po + qc.y;
     const float* qx = cart1 + base; const float* qy = qx + cart_stride; const float* qz = qy + cart_stride;
     // Sums in double over float addends: exact (or within 2^-53), so the order of the lanes does not matter -- the shared rule.
-    constexpr int kKeep = 4;                                          // the first 256 rows stay in registers for the centred pass
-    float cx[kKeep], cy[kKeep], cz[kKeep];
     double sumx = 0.0, sumy = 0.0, sumz = 0.0; int rows = 0;
 #pragma unroll
     for (int k = 0; k < kKeep; k++) {
-        const int i = lane + 64 * k;
-        cx[k] = (i < m) ? qx[i] : __builtin_nanf(""); cy[k] = (i < m) ? qy[i] : 0.f; cz[k] = (i < m) ? qz[i] : 0.f;
-        if (cx[k] == cx[k]) { sumx += (double)cx[k]; sumy += (double)cy[k]; sumz += (double)cz[k]; rows++; }
+        if (ux[k] == ux[k]) { sumx += (double)ux[k]; sumy += (double)uy[k]; sumz += (double)uz[k]; rows++; }
     }
     for (int i = lane + 64 * kKeep; i < m; i += 64) {
         const float X = qx[i];
@@ -740,8 +803,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_fit_moments(const PairDesc* __res
         double c[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < kKeep; k++) {
-            if (cx[k] == cx[k]) {
-                const float dx = cx[k] - mean[0], dy = cy[k] - mean[1], dz = cz[k] - mean[2];
+            if (ux[k] == ux[k]) {
+                const float dx = ux[k] - mean[0], dy = uy[k] - mean[1], dz = uz[k] - mean[2];
                 c[0] += (double)(dx * dx); c[1] += (double)(dx * dy); c[2] += (double)(dx * dz);
                 c[3] += (double)(dy * dy); c[4] += (double)(dy * dz); c[5] += (double)(dz * dz);
             }

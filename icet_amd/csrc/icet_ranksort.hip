@@ -46,6 +46,11 @@ constexpr int kBucketBits = kRankSortBucketBits;
 // 1280 rows (25 KB, 6 blocks per CU) beats the earlier fixed 2560 (45 KB, 3 blocks) by 0.2 ms -- the sort is latency bound
 // and wants the occupancy -- even though a few per cent of the buckets then overflow to the global-scratch path.
 constexpr int kBucketTarget = ICET_RS_TARGET;
+#ifndef ICET_RS_PER_BLOCK
+#define ICET_RS_PER_BLOCK 2
+#endif
+constexpr int kRsPerBlock = ICET_RS_PER_BLOCK;   // buckets per block of k_rs_bucket_sort (power of two)
+constexpr int kRsPrefetch = 5;                   // (key, row) pairs per thread fetched ahead: 5 x 256 = the 1280 rows of the smallest LDS capacity
 constexpr int kCapMin = 1280, kCapMax = 8960;  // 8960 rows + 4096 cells = 156 KB: one block per CU, still far better than global scratch
 
 // ---- splitters -----------------------------------------------------------------------------------------------------
@@ -241,13 +246,23 @@ __device__ __forceinline__ bool counting_sort_lds(uint32_t* smem, int C, int log
     return true;
 }
 
+// pf: the bucket's first kRsPrefetch x 256 (key, row) pairs, already in registers (fetched while the block sorted its previous bucket)
 template <bool kLds>
 __device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int C, int logC, int kCap, const uint2* bkv, uint2* gA, uint2* gB,
-                                                 int n, int lo, size_t off1, uint32_t* s_out, int32_t* pred_out, int max_cell) {
+                                                 int n, int lo, size_t off1, uint32_t* s_out, int32_t* pred_out, int max_cell, const uint2 (&pf)[kRsPrefetch]) {
     const size_t o = off1 + lo;
     const int offBuf = cell_region(C) + kRedWords;
     uint32_t vor = 0u, vand = 0xFFFFFFFFu, vmin = 0xFFFFFFFFu, vmax = 0u;
-    for (int i = threadIdx.x; i < n; i += kSortBlock) {
+#pragma unroll
+    for (int k = 0; k < kRsPrefetch; k++) {
+        const int i = threadIdx.x + k * kSortBlock;
+        if (i < n) {
+            const uint2 kv = pf[k];
+            if constexpr (kLds) { smem[offBuf + i] = kv.x; smem[offBuf + kCap + i] = kv.y; }
+            vor |= kv.x; vand &= kv.x; vmin = min(vmin, kv.x); vmax = max(vmax, kv.x);
+        }
+    }
+    for (int i = threadIdx.x + kRsPrefetch * kSortBlock; i < n; i += kSortBlock) {
         const uint2 kv = bkv[o + i];
         if constexpr (kLds) { smem[offBuf + i] = kv.x; smem[offBuf + kCap + i] = kv.y; }
         vor |= kv.x; vand &= kv.x; vmin = min(vmin, kv.x); vmax = max(vmax, kv.x);
@@ -279,16 +294,45 @@ __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* _
     extern __shared__ uint32_t smem[];
     // all buckets of a pair on one XCD (decode_block): their scattered 4-byte writes of pred[] then complete whole cache lines in
     // ONE L2 instead of leaving partial lines in eight
-    int pair, bucket;
-    if (!decode_block(n_pairs, kMaxBuckets, pair, bucket)) return;
-    if (bucket >= n_buckets[pair]) return;
-    const int lo = bucket_start[(size_t)pair * (kMaxBuckets + 1) + bucket];
-    const int n = bucket_start[(size_t)pair * (kMaxBuckets + 1) + bucket + 1] - lo;
-    if (n <= 0) return;
+    int pair, part;
+    if (!decode_block(n_pairs, kMaxBuckets / kRsPerBlock, pair, part)) return;
+    const int nb = n_buckets[pair];
+    if (part >= nb) return;
     const size_t off1 = (size_t)desc[pair].off1;
     const int C = 1 << logC;
-    if (n <= kCap) bucket_sort_body<true>(smem, C, logC, kCap, bkv, nullptr, nullptr, n, lo, off1, s_out, pred_out, max_cell);
-    else bucket_sort_body<false>(smem, C, logC, kCap, bkv, bkv + off1 + lo, alt + off1 + lo, n, lo, off1, s_out, pred_out, max_cell);
+    // A block sorts kRsPerBlock buckets (part, part + stride, ...) and fetches the next bucket's pairs into registers before it sorts
+    // the current one: the load of a bucket (its 7 KB arrive after two dependent reads) overlaps the previous bucket's sort instead
+    // of standing in front of its own.
+    constexpr int kStride = kMaxBuckets / kRsPerBlock;
+    const int32_t* bs = bucket_start + (size_t)pair * (kMaxBuckets + 1);
+    int los[kRsPerBlock], ns[kRsPerBlock];
+#pragma unroll
+    for (int q = 0; q < kRsPerBlock; q++) {
+        const int bkt = part + q * kStride;
+        const bool ok = bkt < nb;
+        los[q] = ok ? bs[bkt] : 0; ns[q] = ok ? bs[bkt + 1] - los[q] : 0;
+    }
+    auto fetch = [&](int lo, int n, uint2 (&pf)[kRsPrefetch]) {
+#pragma unroll
+        for (int k = 0; k < kRsPrefetch; k++) { const int i = threadIdx.x + k * kSortBlock; pf[k] = (i < n) ? bkv[off1 + lo + i] : make_uint2(0u, 0u); }
+    };
+    uint2 pf[kRsPrefetch];
+    fetch(los[0], ns[0], pf);
+#pragma unroll
+    for (int q = 0; q < kRsPerBlock; q++) {
+        uint2 nf[kRsPrefetch];
+        if (q + 1 < kRsPerBlock) fetch(los[q + 1], ns[q + 1], nf);
+        const int lo = los[q], n = ns[q];
+        if (n > 0) {                                                   // block-uniform
+            if (n <= kCap) bucket_sort_body<true>(smem, C, logC, kCap, bkv, nullptr, nullptr, n, lo, off1, s_out, pred_out, max_cell, pf);
+            else bucket_sort_body<false>(smem, C, logC, kCap, bkv, bkv + off1 + lo, alt + off1 + lo, n, lo, off1, s_out, pred_out, max_cell, pf);
+            __syncthreads();                                           // the LDS buffers are reused by the next bucket
+        }
+        if (q + 1 < kRsPerBlock) {
+#pragma unroll
+            for (int k = 0; k < kRsPrefetch; k++) pf[k] = nf[k];
+        }
+    }
 }
 
 }  // namespace
@@ -336,7 +380,7 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
     k_rs_scatter<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks);
     ICET_LAUNCH_CHECK();
     const int cap = rank_sort_cap(c.max_n1, c.rs_cap);
-    k_rs_bucket_sort<<<dim3(groups * kMaxBuckets), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, reinterpret_cast<uint2*>(w.key64A),
+    k_rs_bucket_sort<<<dim3(groups * (kMaxBuckets / kRsPerBlock)), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, reinterpret_cast<uint2*>(w.key64A),
                                                                                              reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np);
     ICET_LAUNCH_CHECK();
     return hipSuccess;

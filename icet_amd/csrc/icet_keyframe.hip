@@ -217,8 +217,17 @@ __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const P
     unsigned long long* lbits = reinterpret_cast<unsigned long long*>(lh + hist_words);
     for (int b = threadIdx.x; b < hist_words; b += kBlock) lh[b] = 0u;
     if (kBitsInLds) {
+        // copied through registers, all reads of a thread in flight together: written as a plain loop the copy is compiled to
+        // load - wait - store, one memory round trip per 256 words, i.e. 7 in a row for a 116 k-row scan -- in each of its 61 blocks
         const int nw = (d.n1 + 63) >> 6;
-        for (int i = threadIdx.x; i < nw; i += kBlock) lbits[i] = gbits[i];
+        constexpr int kCopy = 8;
+        for (int i0 = 0; i0 < nw; i0 += kCopy * kBlock) {
+            unsigned long long t[kCopy];
+#pragma unroll
+            for (int k = 0; k < kCopy; k++) { const int i = i0 + k * kBlock + (int)threadIdx.x; t[k] = (i < nw) ? gbits[i] : 0ull; }
+#pragma unroll
+            for (int k = 0; k < kCopy; k++) { const int i = i0 + k * kBlock + (int)threadIdx.x; if (i < nw) lbits[i] = t[k]; }
+        }
     }
     __syncthreads();
     auto exec = [&](int u) -> bool { const unsigned long long w = kBitsInLds ? lbits[u >> 6] : gbits[u >> 6]; return (w >> (u & 63)) & 1ull; };

@@ -523,10 +523,12 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
 #ifndef ICET_RT_BLOCKS
 #define ICET_RT_BLOCKS 2048
 #endif
-// k_fit_cluster walks its bins one at a time: the pipeline of k_fit_roundtrip / k_fit_moments (ICET_CLUSTER_PIPE 1: r of bin k + 1, rows of
-// bin k + 2 and record of bin k + 3 in flight while bin k is walked) needs 72 VGPRs, and the kernel is bound by the walk's own chain of
-// DPP scans, ballots and LDS shuffles, which wants 8 waves per SIMD -- measured per 256-pair keyframe: off / 8 waves 1.527 ms,
-// on / 6 waves 1.547, on / 8 waves (10 spills) 1.569.  k_fit_moments keeps its pipeline at 8 waves (2 spilled words, outside the loop).
+// k_fit_cluster pipelines the front of its per-bin chain (record -> rows -> their r -> walk) as far as 64 VGPRs allow: the rows of bin
+// k + 1 and the record of bin k + 2 are in flight while bin k is walked (ICET_CLUSTER_PIPE 2, 62 VGPRs); the r gather of the current bin
+// stays exposed.  The deeper pipeline of k_fit_roundtrip / k_fit_moments (1: also the r of bin k + 1) needs 72 VGPRs, and the kernel is
+// bound by the walk's own chain of DPP scans, ballots and LDS shuffles, which wants 8 waves per SIMD -- measured per 256-pair keyframe:
+// 0 (no look-ahead) 1.482 ms, 2: 1.467, 1 at 6 waves: +0.02, 1 at 8 waves (10 spills): +0.04.  k_fit_moments keeps its pipeline at
+// 8 waves (2 spilled words, outside the loop).
 #ifndef ICET_CLUSTER_WAVES
 #define ICET_CLUSTER_WAVES 8
 #endif
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
 #define ICET_MOM_WAVES 8
 #endif
 #ifndef ICET_CLUSTER_PIPE
-#define ICET_CLUSTER_PIPE 0
+#define ICET_CLUSTER_PIPE 2
 #endif
 struct FitItem { int32_t base, v, k0, nb; };      // rows k0 .. k0 + nb of bin v's compacted candidates; base = the bin's start + k0 (relative to the pair's segment)
 // A pair owns the item slots [item_base, item_base + n1 / 64 + V): at most one partial batch per bin plus the full ones.
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(kBlock, ICET_CLUSTER_WAVES) void k_fit_cluster(cons
     // a fixed number of waves per pair walks the pair's live bins (those with >= n rows, src/icet.cpp:115): a wave per bin of the
     // grid would launch 4 x as many waves as have work (measured: ~90 us of dispatching empty blocks per 256-pair launch).
     // A bin is a chain of dependent reads -- bin record ({bin, first row, rows}: one 16-byte read) -> the bin's rows -> their r (a
-    // gather) -- before the walk can start; see ICET_CLUSTER_PIPE above for the pipelined variant (not the default).
+    // gather) -- before the walk can start; see ICET_CLUSTER_PIPE above for how much of it runs ahead.
     const int stride = chunks * (kBlock / 64), j0 = chunk * (kBlock / 64) + wave;
     if (j0 >= nl) return;                                             // wave-uniform; no block-wide barrier below
     const size_t po = (size_t)d.off1;
@@ -571,20 +573,30 @@ __global__ __launch_bounds__(kBlock, ICET_CLUSTER_WAVES) void k_fit_cluster(cons
 #pragma unroll
         for (int k = 0; k < kCache; k++) rr[k] = (lane + 64 * k < q.z) ? r1[po + (rw[k] & kRowMask)] : 0.f;
     };
-#if ICET_CLUSTER_PIPE
+#if ICET_CLUSTER_PIPE == 1
     int4 q0 = info(j0), q1 = info(j0 + stride), q2 = info(j0 + 2 * stride);
     uint32_t prw[kCache], prw1[kCache];
     rows4(q0, prw); rows4(q1, prw1);
     float pr[kCache];
     radii4(q0, prw, pr);
+#elif ICET_CLUSTER_PIPE == 2
+    int4 q0 = info(j0), q1 = info(j0 + stride);
+    uint32_t prw[kCache];
+    rows4(q0, prw);
 #endif
     for (int j = j0; j < nl; j += stride) {
-#if ICET_CLUSTER_PIPE
+#if ICET_CLUSTER_PIPE == 1
     const int4 q3 = info(j + 3 * stride);
     uint32_t prw2[kCache];
     rows4(q2, prw2);
     float pr1[kCache];
     radii4(q1, prw1, pr1);
+#elif ICET_CLUSTER_PIPE == 2
+    const int4 q2 = info(j + 2 * stride);
+    uint32_t prw1[kCache];
+    rows4(q1, prw1);
+    float pr[kCache];
+    radii4(q0, prw, pr);
 #else
     const int4 q0 = info(j);
     uint32_t prw[kCache]; float pr[kCache];
@@ -685,10 +697,14 @@ __global__ __launch_bounds__(kBlock, ICET_CLUSTER_WAVES) void k_fit_cluster(cons
     if (lane < 16) reinterpret_cast<float*>(midD + (size_t)pair * V + v)[lane] = stage[wave][lane];
     if (lane == 0) live[((size_t)pair * V + j) * 4 + 3] = m_cand;     // for k_fit_moments: the whole of its bin in the one record
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-#if ICET_CLUSTER_PIPE
+#if ICET_CLUSTER_PIPE == 1
     q0 = q1; q1 = q2; q2 = q3;
 #pragma unroll
     for (int k = 0; k < kCache; k++) { prw[k] = prw1[k]; prw1[k] = prw2[k]; pr[k] = pr1[k]; }
+#elif ICET_CLUSTER_PIPE == 2
+    q0 = q1; q1 = q2;
+#pragma unroll
+    for (int k = 0; k < kCache; k++) prw[k] = prw1[k];
 #endif
     }   // live bins of this wave
 }

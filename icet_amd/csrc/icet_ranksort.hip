@@ -49,7 +49,7 @@ constexpr int kBucketTarget = ICET_RS_TARGET;
 #ifndef ICET_RS_PER_BLOCK
 #define ICET_RS_PER_BLOCK 2
 #endif
-constexpr int kRsPerBlock = ICET_RS_PER_BLOCK;   // buckets per block of k_rs_bucket_sort (power of two)
+constexpr int kRsPerBlockBatch = ICET_RS_PER_BLOCK;   // buckets per block of k_rs_bucket_sort in a throughput batch (a small batch: one, it has CUs to spare)
 constexpr int kRsPrefetch = 5;                   // (key, row) pairs per thread fetched ahead: 5 x 256 = the 1280 rows of the smallest LDS capacity
 constexpr int kCapMin = 1280, kCapMax = 8960;  // 8960 rows + 4096 cells = 156 KB: one block per CU, still far better than global scratch
 
@@ -288,6 +288,7 @@ __device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int C, int logC
     }
 }
 
+template <int kRsPerBlock>
 __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bucket_start,
                                                                const int32_t* __restrict__ n_buckets, uint2* __restrict__ bkv, uint2* __restrict__ alt,
                                                                uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out, int kCap, int logC, int max_cell, int n_pairs) {
@@ -360,7 +361,9 @@ static size_t rank_sort_lds_bytes(int cap) { return (size_t)(cell_region(1 << ra
 // Outputs: w.valB = s (row with rank i), w.pred = rank of every row.  Scratch: w.key64A (bucket-grouped (key, row) pairs),
 // w.key64B (second buffer of an overflow bucket), w.bkt, w.counts / w.tile_base, w.splitters, w.n_buckets, w.bucket_start.
 hipError_t init_rank_sort_kernels() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_bucket_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_sort_lds_bytes(kCapMax));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_bucket_sort<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_sort_lds_bytes(kCapMax));
+    if (e == hipSuccess && kRsPerBlockBatch != 1) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_bucket_sort<kRsPerBlockBatch>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_sort_lds_bytes(kCapMax));
+    return e;
 }
 
 hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
@@ -380,7 +383,13 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
     k_rs_scatter<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks);
     ICET_LAUNCH_CHECK();
     const int cap = rank_sort_cap(c.max_n1, c.rs_cap);
-    k_rs_bucket_sort<<<dim3(groups * (kMaxBuckets / kRsPerBlock)), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, reinterpret_cast<uint2*>(w.key64A),
+    // two buckets per block (the second one's pairs in flight during the first one's sort) once the launch fills the chip several times over;
+    // a small batch -- one pair is 128 blocks on 256 CUs -- keeps a block per bucket
+    if (groups * kMaxBuckets >= 16 * 256 && kRsPerBlockBatch != 1)
+        k_rs_bucket_sort<kRsPerBlockBatch><<<dim3(groups * (kMaxBuckets / kRsPerBlockBatch)), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, reinterpret_cast<uint2*>(w.key64A),
+                                                                                             reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np);
+    else
+        k_rs_bucket_sort<1><<<dim3(groups * kMaxBuckets), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, reinterpret_cast<uint2*>(w.key64A),
                                                                                              reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np);
     ICET_LAUNCH_CHECK();
     return hipSuccess;

@@ -219,10 +219,24 @@ def main(argv=None):
     dev = torch.device("cuda", dev_ids[0])
     import torch.distributed as dist
     backend = os.environ.get("ICET_BENCH_BACKEND", "nccl")      # "gloo" only for rehearsing N ranks on one card
+    collective_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            try:
+                dist.init_process_group(backend="nccl", device_id=dev)
+                probe = torch.zeros(1, device=dev)
+                dist.all_reduce(probe)                                   # the communicator is really built here: fail now, not inside the timed region
+                torch.cuda.synchronize(dev)
+            except Exception as e:                                       # RCCL unusable on this node: the 48-float gather goes through the host, and the line says so
+                sys.stderr.write("bench.py: RCCL process group failed (%s: %s); gathering through gloo instead\n" % (type(e).__name__, e))
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                backend = "gloo"
+                collective_note = "gloo fallback: RCCL init failed (%s)" % type(e).__name__
+                dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend=backend)
         if dist.get_world_size() != args.gpus:
@@ -527,6 +541,7 @@ def main(argv=None):
                        "processes": 1 if multi else world, "mode": "multi (one process)" if multi else "one process per GPU",
                        "rccl_ranks": (dist.get_world_size() if (world > 1 and backend == "nccl") else (args.gpus if (multi and args.multi_gather == "rccl") else 0)),
                        "devices": dev_ids if multi else list(range(world)), "gather_ms": None if gather_ms is None else round(gather_ms, 4),
+                       "collective": collective_note or ("rccl" if (world > 1 and backend == "nccl") else (backend if world > 1 else None)),
                        "gen_s": round(t_gen, 1)},
             "roofline": {"kernel": "k_gn_accumulate", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

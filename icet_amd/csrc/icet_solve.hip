@@ -55,7 +55,7 @@ __device__ __noinline__ void drain_near_overflow(const NearOverflow& o, int pair
     const float* px = d.s2; const float* py = px + d.ld2; const float* pz = px + 2 * (size_t)d.ld2;
     const int16_t* map = o.slot_of_voxel + (size_t)pair * ((V + 1) & ~1);
     const SlotHot* hs = o.hotS + (size_t)pair * V;
-    for (uint32_t e = threadIdx.x; e < nov; e += kBlock) {
+    for (uint32_t e = threadIdx.x; e < nov; e += blockDim.x) {
         const int i = (int)o.list[(size_t)d.off2 + e];
         float qx, qy, qz;
         transform_point(px[i], py[i], pz[i], xf, qx, qy, qz);
@@ -67,11 +67,14 @@ __device__ __noinline__ void drain_near_overflow(const NearOverflow& o, int pair
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__ n_slots, const SlotFit* __restrict__ fitS, uint32_t* __restrict__ acc,
+// kT threads per block: 256 for ordinary grids (a 64-channel scan on 75 x 24 has ~220 active voxels: one round), 512 -- the most that 248 VGPRs allow --
+// for fine grids (150 x 48: > 1000 active voxels, three rounds of the per-voxel algebra instead of five)
+template <int kT>
+__global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_slots, const SlotFit* __restrict__ fitS, uint32_t* __restrict__ acc,
                                                      float* __restrict__ X_all, float* __restrict__ xf_all, float* __restrict__ out, AuxDev aux,
                                                      int V, int n, int iter, int runlen, NearOverflow over, int reject_moving) {
     __shared__ float J[27];
-    __shared__ float red[kBlock / 64][27];
+    __shared__ float red[kT / 64][27];
     const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* X = X_all + pair * 6;
     // The block is a chain of dependent latencies, so everything it will need is requested up front: the two counts, the Jacobian
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
     float S[27];
 #pragma unroll
     for (int k = 0; k < 27; k++) S[k] = 0.f;
-    for (int s = threadIdx.x; s < ns; s += kBlock) {
+    for (int s = threadIdx.x; s < ns; s += kT) {
         uint32_t* A = acc + ((size_t)pair * V + s) * kAccWords;
         if (s != (int)threadIdx.x) { accR = load_rec(A); fitR = load_rec(fitS + (size_t)pair * V + s); }       // later rounds
         uint32_t aw[kAccWords];
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void k_gn_solve(const int32_t* __restrict__
     // The 6 x 6 part runs on lane 0 of the first wave; its lanes assemble the input and write the results out (one lane doing the
     // 27 four-way sums and ~100 scalar stores was a quarter of the tail).
     __shared__ float stage[kXf + 48];                               // transform record | X, pred_stds, covariance
-    if (lane < 27) { float t = 0.f; for (int w = 0; w < kBlock / 64; w++) t += red[w][lane]; stage[lane] = t; }
+    if (lane < 27) { float t = 0.f; for (int w = 0; w < kT / 64; w++) t += red[w][lane]; stage[lane] = t; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     float Hm[36], g[6];
     {
@@ -306,7 +309,8 @@ hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* auxp, hipStream_t st) {
     AuxDev aux{}; if (auxp) aux = *auxp;
     NearOverflow over{w.desc, w.slot_of_voxel, w.hotS, w.thr, w.near_over, w.near_over_count, c.T, c.P, c.rt2};
-    k_gn_solve<<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving);
+    if (c.V > 4096) k_gn_solve<512><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving);
+    else k_gn_solve<kBlock><<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

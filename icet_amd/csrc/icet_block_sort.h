@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "icet_device_common.h"
 
 namespace icet {
 
@@ -38,8 +39,7 @@ __device__ __forceinline__ void radix_pass(uint32_t* smem, int offBuf, int kCap,
 #pragma unroll
         for (int w = 0; w < kSortWaves; w++) { const uint32_t c = cnt[w * 256 + dgt]; cnt[w * 256 + dgt] = t; t += c; }
         int incl = (int)t;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        incl = wave_incl_sum(incl);
         if (lane == 63) wsum[wave] = incl;
         tot[dgt] = (uint32_t)(incl - (int)t);                   // exclusive within the wave
     }
@@ -79,11 +79,7 @@ static_assert(kSortBlock == 256, "radix_pass assigns one thread per digit");
 
 // Block-wide reductions of four words (OR, AND, min, max of the keys) through red[].
 __device__ __forceinline__ void block_key_stats(uint32_t* red, uint32_t& vor, uint32_t& vand, uint32_t& vmin, uint32_t& vmax) {
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) {
-        vor |= __shfl_xor(vor, sft); vand &= __shfl_xor(vand, sft);
-        vmin = min(vmin, (uint32_t)__shfl_xor(vmin, sft)); vmax = max(vmax, (uint32_t)__shfl_xor(vmax, sft));
-    }
+    vor = wave_reduce_or(vor); vand = wave_reduce_and(vand); vmin = wave_reduce_min(vmin); vmax = wave_reduce_max(vmax);   // DPP, not the LDS crossbar
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[wave] = vor; red[kSortWaves + wave] = vand; red[2 * kSortWaves + wave] = vmin; red[3 * kSortWaves + wave] = vmax; }
     __syncthreads();

@@ -194,6 +194,57 @@ __device__ __forceinline__ int wave_shr1_zero(int x) { return __builtin_amdgcn_u
 __device__ __forceinline__ float wave_shr1_zero(float x) { return __int_as_float(wave_shr1_zero(__float_as_int(x))); }
 // lane i receives x of lane i + 1; lane 63 receives `fill`
 __device__ __forceinline__ int wave_shl1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
+// Sum over the 64 lanes on the DPP path (the __shfl_xor butterflies above are ds_bpermute_b32: two trips through the LDS pipeline per
+// step of a double): an inclusive scan -- four row_shr steps inside the rows of 16, the last lane of rows 0 / 2 into rows 1 / 3, the last
+// lane of row 1 into rows 2 and 3 -- whose lane 63 holds the total, read back with v_readlane.  Every lane gets the same bits.
+template <int kCtrl, int kRowMask> __device__ __forceinline__ int dpp_zero_fill(int v) { return __builtin_amdgcn_update_dpp(0, v, kCtrl, kRowMask, 0xf, false); }
+__device__ __forceinline__ float wave_total(float v) {
+    v += __int_as_float(dpp_zero_fill<0x111 /* row_shr:1 */, 0xf>(__float_as_int(v)));
+    v += __int_as_float(dpp_zero_fill<0x112 /* row_shr:2 */, 0xf>(__float_as_int(v)));
+    v += __int_as_float(dpp_zero_fill<0x114 /* row_shr:4 */, 0xf>(__float_as_int(v)));
+    v += __int_as_float(dpp_zero_fill<0x118 /* row_shr:8 */, 0xf>(__float_as_int(v)));
+    v += __int_as_float(dpp_zero_fill<0x142 /* row_bcast:15 */, 0xa>(__float_as_int(v)));
+    v += __int_as_float(dpp_zero_fill<0x143 /* row_bcast:31 */, 0xc>(__float_as_int(v)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_total(int v) {
+    v += dpp_zero_fill<0x111, 0xf>(v); v += dpp_zero_fill<0x112, 0xf>(v); v += dpp_zero_fill<0x114, 0xf>(v); v += dpp_zero_fill<0x118, 0xf>(v);
+    v += dpp_zero_fill<0x142, 0xa>(v); v += dpp_zero_fill<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+template <int kCtrl, int kRowMask> __device__ __forceinline__ double dpp_zero_fill_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)dpp_zero_fill<kCtrl, kRowMask>((int)(unsigned)b), hi = (unsigned)dpp_zero_fill<kCtrl, kRowMask>((int)(unsigned)((unsigned long long)b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_total(double v) {
+    v += dpp_zero_fill_d<0x111, 0xf>(v); v += dpp_zero_fill_d<0x112, 0xf>(v); v += dpp_zero_fill_d<0x114, 0xf>(v); v += dpp_zero_fill_d<0x118, 0xf>(v);
+    v += dpp_zero_fill_d<0x142, 0xa>(v); v += dpp_zero_fill_d<0x143, 0xc>(v);
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// The same scan for any associative operation on 32-bit words (`id` = its identity, what a lane without a source contributes):
+// every lane ends with the inclusive prefix of lanes 0 .. its own; wave_reduce_* read the total back from lane 63.
+template <typename Op> __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t id, Op op) {
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, false));
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, false));
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, false));
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)id, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ int wave_incl_sum(int v) { return (int)wave_incl_scan((uint32_t)v, 0u, [](uint32_t a, uint32_t b) { return a + b; }); }
+__device__ __forceinline__ uint32_t wave_reduce_or(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0u, [](uint32_t a, uint32_t b) { return a | b; }), 63); }
+__device__ __forceinline__ uint32_t wave_reduce_and(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0xFFFFFFFFu, [](uint32_t a, uint32_t b) { return a & b; }), 63); }
+__device__ __forceinline__ uint32_t wave_reduce_min(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0xFFFFFFFFu, [](uint32_t a, uint32_t b) { return a < b ? a : b; }), 63); }
+__device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; }), 63); }
+// x of lane `src`, src wave-uniform: v_readlane_b32 instead of a ds_bpermute_b32
+__device__ __forceinline__ int wave_read(int x, int src) { return __builtin_amdgcn_readlane(x, __builtin_amdgcn_readfirstlane(src)); }
+__device__ __forceinline__ float wave_read(float x, int src) { return __int_as_float(wave_read(__float_as_int(x), src)); }
+
 // inclusive prefix maximum over the 64 lanes, for values >= -1 (-1 = "nothing"): four row_shr steps inside the rows of 16, then the
 // last lane of row 0 / 2 into rows 1 / 3 and the last lane of row 1 into rows 2 and 3
 __device__ __forceinline__ int wave_incl_max(int v) {

@@ -402,9 +402,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class
     for (int v0 = 0; v0 < V; v0 += kBlock) {
         const int b = v0 + threadIdx.x;
         const int tot = (b < V) ? class_start[(size_t)pair * (V + 1) + b] : 0;
-        int incl = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const int incl = wave_incl_sum(tot);
         const unsigned long long lm = __ballot(live != nullptr && b < V && tot >= live_min);
         if (lane == 63) wave_tot[wave] = incl;
         if (lane == 0) wave_live[wave] = __popcll(lm);
@@ -633,18 +631,19 @@ __global__ __launch_bounds__(kBlock, ICET_CLUSTER_WAVES) void k_fit_cluster(cons
             const unsigned long long hit = __ballot(brk && (i - prevb >= n));
             if (hit) {
                 const int b = __ffsll((long long)hit) - 1;
-                const int rs0 = __shfl(prevb, b);                    // start of the run that this break closes
-                const float back = (b > 0) ? __shfl(r, b - 1) : carry_prev;
-                const float fr = (rs0 >= c0) ? __shfl(r, rs0 - c0) : front;
-                const float before = (rs0 > c0) ? __shfl(r, max(rs0 - 1 - c0, 0)) : (rs0 == c0 ? carry_prev : front_before);
-                const float after = __shfl(r, b);                    // the point that ended the run
+                // (every lane index below is wave-uniform: v_readlane, not a shuffle through LDS)
+                const int rs0 = wave_read(prevb, b);                 // start of the run that this break closes
+                const float back = (b > 0) ? wave_read(r, b - 1) : carry_prev;
+                const float fr = (rs0 >= c0) ? wave_read(r, rs0 - c0) : front;
+                const float before = (rs0 > c0) ? wave_read(r, max(rs0 - 1 - c0, 0)) : (rs0 == c0 ? carry_prev : front_before);
+                const float after = wave_read(r, b);                 // the point that ended the run
                 inner = fr - in_buff(fr, rs0, before);
                 outer = back + (half_gap ? fminf(buff, 0.5f * fabsf(after - back)) : buff); found = true;
             } else {
-                const int last = __shfl(pm, 63);                     // last break of this chunk, if any
-                if (last >= 0) { run_start = last; front = __shfl(r, last - c0); front_before = (last > c0) ? __shfl(r, max(last - 1 - c0, 0)) : carry_prev; }
+                const int last = wave_read(pm, 63);                  // last break of this chunk, if any
+                if (last >= 0) { run_start = last; front = wave_read(r, last - c0); front_before = (last > c0) ? wave_read(r, max(last - 1 - c0, 0)) : carry_prev; }
             }
-            carry_prev = __shfl(r, 63);
+            carry_prev = wave_read(r, 63);
         };
 #pragma unroll
         for (int k = 0; k < kCache; k++) if (64 * k < cnt && !found) walk(64 * k, pr[k]);
@@ -678,7 +677,7 @@ __global__ __launch_bounds__(kBlock, ICET_CLUSTER_WAVES) void k_fit_cluster(cons
             const int nbatch = (m_cand + 63) >> 6;
             uint32_t slot = 0;
             if (lane == 0 && nbatch > 0) slot = atomicAdd(&n_items[pair], (uint32_t)nbatch);
-            slot = __shfl(slot, 0);
+            slot = (uint32_t)wave_read((int)slot, 0);
             FitItem* mine = items + item_base(d.off1, pair, V);
             for (int bI = lane; bI < nbatch; bI += 64) { FitItem it; it.base = bs + 64 * bI; it.v = v; it.k0 = 64 * bI; it.nb = min(64, m_cand - 64 * bI); mine[slot + bI] = it; }
         }
@@ -819,7 +818,7 @@ __global__ __launch_bounds__(kBlock, ICET_MOM_WAVES) void k_fit_moments(const Pa
         const float X = qx[i];
         if (X == X) { sumx += (double)X; sumy += (double)qy[i]; sumz += (double)qz[i]; rows++; }
     }
-    sumx = wave_sum_d(sumx); sumy = wave_sum_d(sumy); sumz = wave_sum_d(sumz); rows = wave_sum_i(rows);
+    sumx = wave_total(sumx); sumy = wave_total(sumy); sumz = wave_total(sumz); rows = wave_total(rows);
     if (rows * 3 < n) continue;                                       // src/icet.cpp:158 (size() counts coefficients); has_fit stays 0
     float mean[3], cov[6];
     {
@@ -844,7 +843,7 @@ __global__ __launch_bounds__(kBlock, ICET_MOM_WAVES) void k_fit_moments(const Pa
         }
         const float den = (float)(rows - 1);
 #pragma unroll
-        for (int k = 0; k < 6; k++) cov[k] = (float)wave_sum_d(c[k]) / den;
+        for (int k = 0; k < 6; k++) cov[k] = (float)wave_total(c[k]) / den;
     }
     if (lane == 0) {
         mid->mean[0] = mean[0]; mid->mean[1] = mean[1]; mid->mean[2] = mean[2];

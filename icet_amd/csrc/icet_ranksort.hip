@@ -210,11 +210,8 @@ __device__ __forceinline__ bool counting_sort_lds(uint32_t* smem, int C, int log
         const int per = C / kSortBlock, c0 = threadIdx.x * per;
         uint32_t sum = 0u, big = 0u;
         for (int j = 0; j < per; j++) { const uint32_t c = cells[c0 + j]; sum += c; big = max(big, c); }
-        int incl = (int)sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-#pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) big = max(big, (uint32_t)__shfl_xor(big, sft));
+        const int incl = wave_incl_sum((int)sum);
+        big = wave_reduce_max(big);
         if (lane == 63) { red[wave] = (uint32_t)incl; red[kSortWaves + wave] = big; }
         __syncthreads();
         uint32_t base = (uint32_t)incl - sum;

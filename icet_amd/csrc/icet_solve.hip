@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
         for (int a = 0; a < 6; a++) S[21 + a] += WH[a] * dz[0] + WH[6 + a] * dz[1] + WH[12 + a] * dz[2];
     }
 #pragma unroll
-    for (int k = 0; k < 27; k++) { float t = wave_sum(S[k]); if (lane == 0) red[wave][k] = t; }
+    for (int k = 0; k < 27; k++) { float t = wave_total(S[k]); if (lane == 0) red[wave][k] = t; }      // DPP scan, not 6 x 27 trips through the LDS crossbar
     __syncthreads();
     if (wave != 0) return;
     // The 6 x 6 part runs on lane 0 of the first wave; its lanes assemble the input and write the results out (one lane doing the

@@ -245,6 +245,27 @@ __device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) { return (uint32
 __device__ __forceinline__ int wave_read(int x, int src) { return __builtin_amdgcn_readlane(x, __builtin_amdgcn_readfirstlane(src)); }
 __device__ __forceinline__ float wave_read(float x, int src) { return __int_as_float(wave_read(__float_as_int(x), src)); }
 
+// x of lane (lane ^ kD), kD a power of two below 64, without the LDS crossbar: quad permutes for 1 and 2, a pair of row shifts for
+// 4 and 8 (the partner is kD lanes up or down inside the row of 16), gfx950's v_permlane16_swap / v_permlane32_swap for 16 and 32
+// (with both operands = x they return [x0 x0 x2 x2] and [x1 x1 x3 x3] by rows of 16, resp. halves: the partner row is in one of them).
+template <int kD> __device__ __forceinline__ uint32_t wave_xor(uint32_t x) {
+    static_assert(kD == 1 || kD == 2 || kD == 4 || kD == 8 || kD == 16 || kD == 32, "partner distance");
+    const int lane = (int)(threadIdx.x & 63u);
+    if constexpr (kD == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
+    else if constexpr (kD == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
+    else if constexpr (kD == 4 || kD == 8) {
+        const int up = __builtin_amdgcn_update_dpp(0, (int)x, 0x100 + kD /* row_shl: lane i <- i + kD */, 0xf, 0xf, true);
+        const int dn = __builtin_amdgcn_update_dpp(0, (int)x, 0x110 + kD /* row_shr: lane i <- i - kD */, 0xf, 0xf, true);
+        return (uint32_t)((lane & kD) ? dn : up);
+    } else if constexpr (kD == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        return (lane & 32) ? r[0] : r[1];
+    }
+}
+
 // inclusive prefix maximum over the 64 lanes, for values >= -1 (-1 = "nothing"): four row_shr steps inside the rows of 16, then the
 // last lane of row 0 / 2 into rows 1 / 3 and the last lane of row 1 into rows 2 and 3
 __device__ __forceinline__ int wave_incl_max(int v) {

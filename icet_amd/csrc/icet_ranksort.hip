@@ -61,7 +61,7 @@ __device__ __forceinline__ float radius_of(float x, float y, float z) {     // t
 
 // One BLOCK of 8 waves per pair: the 2048 sampled keys live in registers, FOUR per thread (element e = 4 * tid + r), and go through
 // the bitonic network: the 12 stages whose partner distance is 1 or 2 are register-to-register, the 39 with distance 4 .. 128 exchange
-// through __shfl_xor inside a wave, and only the 6 with distance 256 .. 1024 cross waves through LDS (two barriers each).  Round 2 kept
+// inside a wave (wave_xor: DPP and gfx950's permlane swaps, no trip through the LDS crossbar), and only the 6 with distance 256 .. 1024 cross waves through LDS (two barriers each).  Round 2 kept
 // all 2048 keys in ONE wave (32 per lane, no barrier at all): 2112 compare-exchanges and 672 shuffles per lane -- 17 us of a single
 // pair's 22 us for this kernel, and the rest of the block idle; here a lane does 264 + 156.
 static_assert(kSamples == 2048, "k_rs_splitters holds 4 keys per thread of a 512-thread block");
@@ -91,7 +91,16 @@ __global__ __launch_bounds__(kSplitLoadThreads) void k_rs_splitters(const PairDe
                 uint32_t o[4];
                 if (tj < 64) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (uint32_t)__shfl_xor((int)x[r], tj);
+                    for (int r = 0; r < 4; r++) {               // (tj is a compile-time constant once the loops are unrolled: the switch folds)
+                        switch (tj) {
+                            case 1: o[r] = wave_xor<1>(x[r]); break;
+                            case 2: o[r] = wave_xor<2>(x[r]); break;
+                            case 4: o[r] = wave_xor<4>(x[r]); break;
+                            case 8: o[r] = wave_xor<8>(x[r]); break;
+                            case 16: o[r] = wave_xor<16>(x[r]); break;
+                            default: o[r] = wave_xor<32>(x[r]); break;
+                        }
+                    }
                 } else {                                        // another wave: through LDS
                     __syncthreads();
 #pragma unroll

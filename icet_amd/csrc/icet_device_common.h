@@ -241,6 +241,8 @@ __device__ __forceinline__ uint32_t wave_reduce_or(uint32_t v) { return (uint32_
 __device__ __forceinline__ uint32_t wave_reduce_and(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0xFFFFFFFFu, [](uint32_t a, uint32_t b) { return a & b; }), 63); }
 __device__ __forceinline__ uint32_t wave_reduce_min(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0xFFFFFFFFu, [](uint32_t a, uint32_t b) { return a < b ? a : b; }), 63); }
 __device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; }), 63); }
+__device__ __forceinline__ int wave_reduce_min_i(int v) { return __builtin_amdgcn_readlane((int)wave_incl_scan((uint32_t)v, 0x7FFFFFFFu, [](uint32_t a, uint32_t b) { return (uint32_t)min((int)a, (int)b); }), 63); }
+__device__ __forceinline__ int wave_reduce_max_i(int v) { return __builtin_amdgcn_readlane((int)wave_incl_scan((uint32_t)v, 0x80000000u, [](uint32_t a, uint32_t b) { return (uint32_t)max((int)a, (int)b); }), 63); }
 // x of lane `src`, src wave-uniform: v_readlane_b32 instead of a ds_bpermute_b32
 __device__ __forceinline__ int wave_read(int x, int src) { return __builtin_amdgcn_readlane(x, __builtin_amdgcn_readfirstlane(src)); }
 __device__ __forceinline__ float wave_read(float x, int src) { return __int_as_float(wave_read(__float_as_int(x), src)); }

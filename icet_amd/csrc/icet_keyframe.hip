@@ -101,8 +101,7 @@ __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __re
     {   // the tile's populated voxel range (a 64-channel scan fills ~1/3 of the id range of the 75 x 24 grid); no atomics: thousands of
         // waves per pair on one address cost this kernel 150 us per 256 pairs -- the rank sort's per-pair scan reduces the tiles' values
         __shared__ int s_lo[kBlock / 64], s_hi[kBlock / 64];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { vlo = min(vlo, __shfl_xor(vlo, o)); vhi = max(vhi, __shfl_xor(vhi, o)); }
+        vlo = wave_reduce_min_i(vlo); vhi = wave_reduce_max_i(vhi);
         if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = vlo; s_hi[threadIdx.x >> 6] = vhi; }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -394,8 +393,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class
     if (vrange_out && wave == kBlock / 64 - 1) {                  // (rank-sort call) the pair's voxel range from its tiles': the last wave, beside the scan
         int lo = 0x7FFFFFFF, hi = -1;
         for (int t = lane; t < chunks; t += 64) { lo = min(lo, tile_vr[((size_t)pair * chunks + t) * 2]); hi = max(hi, tile_vr[((size_t)pair * chunks + t) * 2 + 1]); }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        lo = wave_reduce_min_i(lo); hi = wave_reduce_max_i(hi);
         if (lane == 0) { vrange_out[2 * pair] = lo; vrange_out[2 * pair + 1] = hi; }
     }
     __syncthreads();

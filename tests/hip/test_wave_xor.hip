@@ -1,5 +1,5 @@
 // Stand-alone check of wave_xor<D> (icet_device_common.h) against __shfl_xor, and of the DPP scans against a serial loop.
-// Run on the GPU box:  hipcc --offload-arch=gfx950 -O2 -I icet_amd/csrc -I include scripts/hip/test_wave_xor.hip -o /tmp/t && /tmp/t
+// Run on the GPU box:  hipcc --offload-arch=gfx950 -O2 -I icet_amd/csrc -I include tests/hip/test_wave_xor.hip -o /tmp/t && /tmp/t
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

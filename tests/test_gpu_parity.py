@@ -467,6 +467,19 @@ def test_eigen_adapter_header_compiles_and_runs(tmp_path, gpu_ctx, frames):
     assert np.array_equal(np.array(m[14:17], np.float32), t["mu1"][v0]) and [int(m[18]), int(m[19])] == [v0 % 75, v0 // 75]
 
 
+def test_cross_lane_primitives_match_the_shuffles(tmp_path):
+    """The DPP / permlane cross-lane helpers of icet_device_common.h (wave_xor<D>, wave_incl_sum, wave_reduce_max: what replaced the
+    ds_bpermute shuffles in the splitter sort, the scans and the reductions) against __shfl_xor / a serial loop, on the device."""
+    import shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "wave_xor")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-I", os.path.join(root, "icet_amd", "csrc"), "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "hip", "test_wave_xor.hip"), "-o", exe], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_test_points_member(gpu_ctx, frames):
     """`testPoints` (include/icet.h:84, src/icet.cpp:213-231): the sigma points of every pruned axis, bit for bit the oracle's."""
     from oracle import pyoracle as po

@@ -384,20 +384,21 @@ __global__ __launch_bounds__(kBlock) void k_bin_tiles(const uint32_t* __restrict
 
 // live (optional): the classes holding at least live_min rows, compacted in class order (16-byte records, pairs x V of them) -- the angular bins fitCells1 looks at at
 // all (src/icet.cpp:115) -- so that the fit kernels walk ~1/4 of the grid instead of launching a wave per bin.
-__global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class_start, int V, int32_t* __restrict__ live, int32_t* __restrict__ n_live, int live_min,
+constexpr int kScanBlock = 1024;               // one block per pair scans its V classes: 2 rounds on 75 x 24, 8 on 150 x 48
+__global__ __launch_bounds__(kScanBlock) void k_bin_scan(int32_t* __restrict__ class_start, int V, int32_t* __restrict__ live, int32_t* __restrict__ n_live, int live_min,
                                                      uint32_t* __restrict__ n_items, const int32_t* __restrict__ tile_vr, int chunks, int32_t* __restrict__ vrange_out) {
-    __shared__ int wave_tot[kBlock / 64], wave_live[kBlock / 64];
+    __shared__ int wave_tot[kScanBlock / 64], wave_live[kScanBlock / 64];
     __shared__ int base, lbase;
     const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { base = 0; lbase = 0; }
-    if (vrange_out && wave == kBlock / 64 - 1) {                  // (rank-sort call) the pair's voxel range from its tiles': the last wave, beside the scan
+    if (vrange_out && wave == kScanBlock / 64 - 1) {                  // (rank-sort call) the pair's voxel range from its tiles': the last wave, beside the scan
         int lo = 0x7FFFFFFF, hi = -1;
         for (int t = lane; t < chunks; t += 64) { lo = min(lo, tile_vr[((size_t)pair * chunks + t) * 2]); hi = max(hi, tile_vr[((size_t)pair * chunks + t) * 2 + 1]); }
         lo = wave_reduce_min_i(lo); hi = wave_reduce_max_i(hi);
         if (lane == 0) { vrange_out[2 * pair] = lo; vrange_out[2 * pair + 1] = hi; }
     }
     __syncthreads();
-    for (int v0 = 0; v0 < V; v0 += kBlock) {
+    for (int v0 = 0; v0 < V; v0 += kScanBlock) {
         const int b = v0 + threadIdx.x;
         const int tot = (b < V) ? class_start[(size_t)pair * (V + 1) + b] : 0;
         const int incl = wave_incl_sum(tot);
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scan(int32_t* __restrict__ class
         if ((lm >> lane) & 1ull)      // {class, first row, rows, (candidates: k_fit_cluster)}: what a fit wave needs about its bin in ONE 16-byte read
             reinterpret_cast<int4*>(live)[(size_t)pair * V + lb + loff + __popcll(lm & ((1ull << lane) - 1ull))] = make_int4(b, bb + woff + incl - tot, tot, 0);
         __syncthreads();
-        if (threadIdx.x == kBlock - 1) { base = bb + woff + incl; lbase = lb + loff + __popcll(lm); }
+        if (threadIdx.x == kScanBlock - 1) { base = bb + woff + incl; lbase = lb + loff + __popcll(lm); }
         __syncthreads();
     }
     if (threadIdx.x == 0) { class_start[(size_t)pair * (V + 1) + V] = base; if (n_live) n_live[pair] = lbase; if (n_items) n_items[pair] = 0u; }
@@ -1129,7 +1130,7 @@ hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_
                              int32_t* live, int32_t* n_live, int live_min, uint32_t* n_items, const int32_t* class_range, const int32_t* tile_vr, int32_t* vrange_out) {
     k_bin_tiles<<<dim3((n_classes + kBlock - 1) / kBlock, n_pairs), kBlock, 0, st>>>(counts, tile_base, class_start, n_classes, chunks, class_range);
     ICET_LAUNCH_CHECK();
-    k_bin_scan<<<n_pairs, kBlock, 0, st>>>(class_start, n_classes, live, n_live, live_min, n_items, tile_vr, chunks, vrange_out);
+    k_bin_scan<<<n_pairs, kScanBlock, 0, st>>>(class_start, n_classes, live, n_live, live_min, n_items, tile_vr, chunks, vrange_out);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -370,15 +370,17 @@ __global__ __launch_bounds__(kBlock) void k_bin_tiles(const uint32_t* __restrict
     if (class_range && (b < class_range[2 * pair] || b > class_range[2 * pair + 1])) { class_start[(size_t)pair * (V + 1) + b] = 0; return; }   // no row has this class
     const uint32_t* c = counts + (size_t)pair * chunks * V + b;
     uint32_t* tb = tile_base + (size_t)pair * chunks * V + b;
-    int tot = 0, t = 0;
-    for (; t + 8 <= chunks; t += 8) {                         // 8 independent loads in flight
-        uint32_t x[8];
+    // a thread walks its class through the pair's tiles: 16 independent loads in flight per trip, the last trip predicated (61 tiles of a
+    // 116 k-row scan: four memory round trips; batches of 8 and a one-by-one tail made that twelve)
+    constexpr int kTilesPerTrip = 16;
+    int tot = 0;
+    for (int t = 0; t < chunks; t += kTilesPerTrip) {
+        uint32_t x[kTilesPerTrip];
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = c[(size_t)(t + k) * V];
+        for (int k = 0; k < kTilesPerTrip; k++) x[k] = (t + k < chunks) ? c[(size_t)(t + k) * V] : 0u;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { tb[(size_t)(t + k) * V] = (uint32_t)tot; tot += (int)x[k]; }
+        for (int k = 0; k < kTilesPerTrip; k++) { if (t + k < chunks) tb[(size_t)(t + k) * V] = (uint32_t)tot; tot += (int)x[k]; }
     }
-    for (; t < chunks; t++) { const uint32_t x = c[(size_t)t * V]; tb[(size_t)t * V] = (uint32_t)tot; tot += (int)x; }
     class_start[(size_t)pair * (V + 1) + b] = tot;
 }
 

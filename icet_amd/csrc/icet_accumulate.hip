@@ -113,15 +113,31 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_a
     const int nl = min(ns, lds_slots);
     const SlotHot* hs = hotS + (size_t)pair * V;
     {
+        // The block's tables come from L2 through registers with every read of a thread in flight at once: the first two trips of the
+        // voxel map, the first three of the LUTs and the first hot record are requested before anything is stored (written as plain
+        // copy loops they compile to load - wait - store per trip: six dependent round trips in front of the block's first point).
         const uint32_t* gm = reinterpret_cast<const uint32_t*>(slot_of_voxel + (size_t)pair * ((V + 1) & ~1));   // rows padded to even length
         uint32_t* lm = reinterpret_cast<uint32_t*>(map);
-        for (int i = threadIdx.x; i < map_words; i += kAccBlock) lm[i] = gm[i];
-        for (int i = 2 * map_words + threadIdx.x; i < V + T + 2; i += kAccBlock) map[i] = (int16_t)-1;   // bt == T or bp == P land here
         const uint2* gl = reinterpret_cast<const uint2*>(lut);
         uint2* ll = reinterpret_cast<uint2*>(lut_t);
-        for (int i = threadIdx.x; i < Mt + Mp + 2; i += kAccBlock) ll[i] = gl[i];
+        const int n_lut = Mt + Mp + 2;
+        constexpr int kMapAhead = 2, kLutAhead = 3;
+        uint32_t mreg[kMapAhead]; uint2 lreg[kLutAhead];
+#pragma unroll
+        for (int k = 0; k < kMapAhead; k++) { const int i = (int)threadIdx.x + k * kAccBlock; mreg[k] = (i < map_words) ? gm[i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < kLutAhead; k++) { const int i = (int)threadIdx.x + k * kAccBlock; lreg[k] = (i < n_lut) ? gl[i] : make_uint2(0u, 0u); }
+        SlotHot g0{};
+        if ((int)threadIdx.x < nl) g0 = hs[threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < kMapAhead; k++) { const int i = (int)threadIdx.x + k * kAccBlock; if (i < map_words) lm[i] = mreg[k]; }
+        for (int i = (int)threadIdx.x + kMapAhead * kAccBlock; i < map_words; i += kAccBlock) lm[i] = gm[i];
+        for (int i = 2 * map_words + threadIdx.x; i < V + T + 2; i += kAccBlock) map[i] = (int16_t)-1;   // bt == T or bp == P land here
+#pragma unroll
+        for (int k = 0; k < kLutAhead; k++) { const int i = (int)threadIdx.x + k * kAccBlock; if (i < n_lut) ll[i] = lreg[k]; }
+        for (int i = (int)threadIdx.x + kLutAhead * kAccBlock; i < n_lut; i += kAccBlock) ll[i] = gl[i];
         for (int i = threadIdx.x; i < nl; i += kAccBlock) {
-            const SlotHot g = hs[i];
+            const SlotHot g = (i == (int)threadIdx.x) ? g0 : hs[i];
             float* h = hot + i * kHotWords;
             h[0] = g.inner; h[1] = g.outer; h[2] = g.mu[0]; h[3] = g.mu[1]; h[4] = g.mu[2];
         }

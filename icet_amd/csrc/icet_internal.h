@@ -136,6 +136,7 @@ struct Tuning {
     int rs_cap = 0;               // LDS rows of the per-bucket sort (0 = from the largest scan)
     int rs_max_cell = 24;         // per-bucket counting sort: a cell above this many rows sends the bucket to the radix sort (0: always)
     int exec_bits_lds = 1;        // k_scramble_src keeps the pair's swap-loop bit table in LDS (0: reads it from memory, the path of scans above ~0.75 M rows)
+    int exec_pairwise = -1;       // "did step v execute": one block per pair in index order with the bit table in LDS (k_exec_flags_pair) 1, chain walks (k_exec_flags) 0, by batch size -1
     double guard_scale = 1.0;     // multiplies the classification guard bands (tables are rebuilt)
     double lut_polar_quantile = 0.25;   // polar LUT cell width = this quantile of the polar bin widths
 };
@@ -158,7 +159,7 @@ struct LaunchCfg {
     int true_sort = 0;                // ICET_FLAG_TRUE_SORT (non-parity extension): src[] = the sorted order itself
     int force_exact = 0;              // diagnostic: route every point through the literal evaluation
     int rs_cap = 0;                   // Tuning::rs_cap
-    int rs_max_cell = 24, exec_bits_lds = 1;   // Tuning::rs_max_cell, ::exec_bits_lds
+    int rs_max_cell = 24, exec_bits_lds = 1, exec_pairwise = -1;   // Tuning::rs_max_cell, ::exec_bits_lds, ::exec_pairwise
     int reject_moving = 0;            // ICET_FLAG_REJECT_MOVING (non-parity extension)
     int half_gap = 0;                 // ICET_FLAG_HALF_GAP_BOUNDS (non-parity extension; sets true_sort as well)
     int rt2 = 0;                      // ICET_FLAG_ROUNDTRIP_SCAN2 (parity-study option)

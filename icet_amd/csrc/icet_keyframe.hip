@@ -187,6 +187,81 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
     }
 }
 
+// The same bits from the RECURRENCE instead of the chain walks: step v executes iff pred(v) > v, or pred(v) < v and step pred(v) did
+// not execute (the chain parity of k_exec_flags, one link at a time; pred(v) < v is never a fixed point, so its bit is its parity).
+// Every row then needs ONE earlier bit instead of a walk through pred[] -- 0.7 random 4-byte reads per row, with the long chains
+// walked by a few lanes per wave -- if the rows are taken in index order, and a pair's whole bit table is 15 KB: one block per pair
+// keeps it in LDS and goes through the pair's rows in chunks of 1024 x kR, pred[] streamed (the next chunk in flight), the bit of
+// pred(v) read from LDS.  A row whose pred(v) lies inside its own chunk (a few % of the rows) waits for that row's result: a state
+// byte per row of the chunk and a few rounds behind a barrier, until no row of the block is pending.  No global random access at
+// all; a pair takes ~60 chunks x a few barriers whatever the batch, so this is the kernel of THROUGHPUT batches (one block per CU
+// and pair), while a small batch keeps k_exec_flags and its hundreds of independent tiles.  Measured per 256 pairs: 144 -> see DESIGN.
+#ifndef ICET_EXEC_PAIR_ROWS
+#define ICET_EXEC_PAIR_ROWS 8
+#endif
+#ifndef ICET_EXEC_PAIR_THREADS
+#define ICET_EXEC_PAIR_THREADS 1024
+#endif
+constexpr int kExecPairThreads = ICET_EXEC_PAIR_THREADS;
+template <int kR>
+__global__ __launch_bounds__(kExecPairThreads) void k_exec_flags_pair(const PairDesc* __restrict__ desc, const int32_t* __restrict__ pred,
+                                                                      unsigned long long* __restrict__ execbits) {
+    extern __shared__ __attribute__((aligned(8))) unsigned char sm_exec[];
+    constexpr int kT = kExecPairThreads, kC = kT * kR;
+    unsigned char* st = sm_exec;                                          // per row of the chunk: 0 pending, 2 | bit resolved
+    unsigned long long* lbits = reinterpret_cast<unsigned long long*>(sm_exec + kC);
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const PairDesc d = desc[pair];
+    const int n = d.n1;
+    const int32_t* pp = pred + (size_t)d.off1;
+    int pn[kR];
+#pragma unroll
+    for (int r = 0; r < kR; r++) { const int v = r * kT + tid; pn[r] = (v < n) ? pp[v] : 0; }
+    for (int c0 = 0; c0 < n; c0 += kC) {
+        int p[kR]; bool pend[kR], e[kR];
+#pragma unroll
+        for (int r = 0; r < kR; r++) { p[r] = pn[r]; const int v = c0 + kC + r * kT + tid; pn[r] = (v < n) ? pp[v] : 0; }      // the next chunk is in flight
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < kR; r++) {
+            const int v = c0 + r * kT + tid, pv = p[r];
+            e[r] = false; pend[r] = false;
+            if (v < n) {
+                if (pv >= v) e[r] = pv != v;                               // moved to a later position: executes; a fixed point does not
+                else if (pv < c0) e[r] = ((lbits[pv >> 6] >> (pv & 63)) & 1ull) == 0ull;     // an earlier chunk: its bit is in the table
+                else pend[r] = true;                                       // a row of this chunk
+            }
+            st[r * kT + tid] = pend[r] ? (unsigned char)0 : (unsigned char)(2 | (e[r] ? 1 : 0));
+            any |= pend[r];
+        }
+        // rounds: a pending row takes its result as soon as pred(v) has one; every thread looks after its own rows (on lidar data ~3 % of a
+        // chunk is pending and three rounds settle it; a chain of k rows inside one chunk -- adversarial input -- takes k rounds).  Two
+        // alternatives measured slower: polling the state bytes without barriers (the waves serialise on their rows), and one wave
+        // resolving a compacted list of the pending rows (its dependent LDS reads cost more than the barriers of the parallel rounds).
+        while (__syncthreads_or(any ? 1 : 0)) {                            // (the barrier also publishes the state bytes)
+            any = false;
+#pragma unroll
+            for (int r = 0; r < kR; r++) {
+                if (pend[r]) {
+                    const unsigned char s = st[p[r] - c0];                 // may be written in this very round: then this row resolves now or next round
+                    if (s & 2) { e[r] = (s & 1) == 0; pend[r] = false; st[r * kT + tid] = (unsigned char)(2 | (e[r] ? 1 : 0)); }
+                    else any = true;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kR; r++) {                                    // a wave holds 64 consecutive rows starting at a multiple of 64: one ballot = one word
+            const int v = c0 + r * kT + tid;
+            const unsigned long long m = __ballot(e[r]);
+            if (lane == 0 && v < n) lbits[v >> 6] = m;
+        }
+        __syncthreads();                                                   // the table is complete up to this chunk; the state bytes are free again
+    }
+    unsigned long long* gbits = execbits + exec_word_base(d.off1, pair);
+    const int nw = (n + 63) >> 6;
+    for (int i = tid; i < nw; i += kT) gbits[i] = lbits[i];
+}
+
 // src[v] = original row that ends at position v after the swap loop.  Position v receives row
 // pred(v), except at the head of a run of executed steps, where the row arrives from the end of
 // the forward chain v -> s[v] -> s[s[v]] ... while the steps executed.
@@ -1042,6 +1117,7 @@ hipError_t init_keyframe_kernels() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scramble_src<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_hist), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan1_spherical), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_exec_flags_pair<ICET_EXEC_PAIR_ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     return e;
 }
 
@@ -1086,7 +1162,14 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
         ICET_LAUNCH_CHECK();
     } else {
         const int max_walk = 4096;
-        k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.pred, w.execbits, w.flags, max_walk, np, chunks);
+        {
+            constexpr int kR = ICET_EXEC_PAIR_ROWS;
+            const size_t pair_lds = (size_t)kExecPairThreads * kR + (size_t)((c.max_n1 + 63) / 64) * 8;    // state bytes + the bit table
+            const bool fits = pair_lds <= (size_t)150 * 1024;
+            const bool pairwise = fits && (c.exec_pairwise > 0 || (c.exec_pairwise < 0 && c.n_pairs >= 64));
+            if (pairwise) k_exec_flags_pair<kR><<<c.n_pairs, kExecPairThreads, pair_lds, st>>>(w.desc, w.pred, w.execbits);
+            else k_exec_flags<<<grid, blk, 0, st>>>(w.desc, w.pred, w.execbits, w.flags, max_walk, np, chunks);
+        }
         ICET_LAUNCH_CHECK();
         const size_t hist_bytes = (size_t)((((c.V + 1) / 2 + 1) & ~1)) * 4, bit_bytes = (size_t)((c.max_n1 + 63) / 64) * 8;
         if (c.exec_bits_lds && hist_bytes + bit_bytes <= kScrambleLdsMax)

@@ -400,6 +400,15 @@ def test_rank_sort_and_scramble_corner_cases(gpu_ctx, frames):
     p = np.stack([rad * np.cos(el) * np.cos(ang), rad * np.cos(el) * np.sin(ang), rad * np.sin(el)], 1).astype(np.float32)
     _keyframe_vs_oracle(gpu_ctx, p, p)
     assert gpu_ctx.debug_fetch("flags", 1)[0] & 1          # the bounded walk overflowed and the serial replay ran
+    # the same three inputs with the executed-step bits from the per-pair recurrence kernel (what a throughput batch runs): equal
+    # keys, one giant bucket, and dependency chains as long as a chunk inside every chunk
+    gpu_ctx.set_option("exec_pairwise", 1)
+    try:
+        _keyframe_vs_oracle(gpu_ctx, z, b)
+        _keyframe_vs_oracle(gpu_ctx, c, b)
+        _keyframe_vs_oracle(gpu_ctx, p, p)
+    finally:
+        gpu_ctx.set_option("exec_pairwise", -1)
 
 
 def test_icet_class_mirrors_reference_members(frames, frames_golden):
@@ -807,12 +816,13 @@ def test_rarely_taken_paths_give_the_same_bits(gpu_ctx, frames, sample_pc):
     """Every launch-shape knob selects a code path that exists for unusual inputs; on ordinary inputs they must all produce
     the same bits as the default: accumulator rows that do not fit LDS (HBM-atomic spill path), rank-sort buckets that do not
     fit LDS (global-scratch radix sort), buckets whose keys pile up in one cell of the counting sort (LDS radix sort), the swap-loop
-    bit table read from memory instead of LDS (scans above ~0.75 M rows), small keyframe tiles, few / many accumulate blocks, and the
+    bit table read from memory instead of LDS (scans above ~0.75 M rows), the executed-step bits from the per-pair recurrence kernel (the
+    kernel of throughput batches) and from the chain walks (small batches), small keyframe tiles, few / many accumulate blocks, and the
     library (rocPRIM) sort that the hand-written rank sort replaced."""
     a, b = frames; c, d = sample_pc
     base1 = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
     base2 = gpu_ctx.solve(c, d, 7, np.zeros(6), 48, 150)
-    knobs = [("lds_slots", 32, 0), ("rs_cap", 128, 0), ("rs_max_cell", 0, 24), ("rs_max_cell", 1, 24), ("exec_bits_lds", 0, 1), ("kf_pts", 1, 8), ("kf_pts", 3, 8), ("acc_blocks", 7, 1536),
+    knobs = [("lds_slots", 32, 0), ("rs_cap", 128, 0), ("rs_max_cell", 0, 24), ("rs_max_cell", 1, 24), ("exec_bits_lds", 0, 1), ("exec_pairwise", 1, -1), ("exec_pairwise", 0, -1), ("kf_pts", 1, 8), ("kf_pts", 3, 8), ("acc_blocks", 7, 1536),
              ("acc_pts", 64, 4), ("library_sort", 1, 0), ("batch_stage", 0, 4)]
     for key, val, default in knobs:
         gpu_ctx.set_option(key, val)

@@ -44,14 +44,17 @@ constexpr int kBucketBits = kRankSortBucketBits;
 // Rows per bucket aimed for.  With at most 128 buckets a 64-channel scan (~116 k rows) gets ~900-row buckets; the LDS
 // capacity of the per-bucket sort is chosen per launch from the largest scan (rank_sort_cap): measured on 256 such pairs,
 // 1280 rows (25 KB, 6 blocks per CU) beats the earlier fixed 2560 (45 KB, 3 blocks) by 0.2 ms -- the sort is latency bound
-// and wants the occupancy -- even though a few per cent of the buckets then overflow to the global-scratch path.
+// and wants the occupancy.  With 2048 samples for 128 buckets the bucket sizes scatter by ~20 % around their mean (944 +- 180 rows on a
+// 121 k-row scan), so ~3 % of them exceed 1280 rows and went to the global-scratch path; 1664 rows (30.7 KB with the 1024 cells: five
+// blocks per CU) keeps all but ~0.1 % in LDS and is 23 us per 256-pair keyframe faster than 1280, 1408 / 1536: in between,
+// 1792 ... 2048 (four blocks per CU): no better than 1280.
 constexpr int kBucketTarget = ICET_RS_TARGET;
 #ifndef ICET_RS_PER_BLOCK
 #define ICET_RS_PER_BLOCK 2
 #endif
 constexpr int kRsPerBlockBatch = ICET_RS_PER_BLOCK;   // buckets per block of k_rs_bucket_sort in a throughput batch (a small batch: one, it has CUs to spare)
-constexpr int kRsPrefetch = 5;                   // (key, row) pairs per thread fetched ahead: 5 x 256 = the 1280 rows of the smallest LDS capacity
-constexpr int kCapMin = 1280, kCapMax = 8960;  // 8960 rows + 4096 cells = 156 KB: one block per CU, still far better than global scratch
+constexpr int kRsPrefetch = 5;                   // (key, row) pairs per thread fetched ahead: 5 x 256 = 1280 rows, more than 97 % of the buckets of a 64-channel scan
+constexpr int kCapMin = 1664, kCapMax = 8960;  // 8960 rows + 4096 cells = 156 KB: one block per CU, still far better than global scratch
 
 // ---- splitters -----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float radius_of(float x, float y, float z) {     // the r that k_scan1_spherical stores, bit for bit
@@ -361,7 +364,10 @@ static int rank_sort_cap(int max_n, int forced) {
 #ifndef ICET_RS_LOGC_SMALL
 #define ICET_RS_LOGC_SMALL 10
 #endif
-static int rank_sort_log_cells(int cap) { return cap <= 1280 ? ICET_RS_LOGC_SMALL : 12; }
+#ifndef ICET_RS_SMALL_CAP
+#define ICET_RS_SMALL_CAP 1664
+#endif
+static int rank_sort_log_cells(int cap) { return cap <= ICET_RS_SMALL_CAP ? ICET_RS_LOGC_SMALL : 12; }
 static size_t rank_sort_lds_bytes(int cap) { return (size_t)(cell_region(1 << rank_sort_log_cells(cap)) + kRedWords + 4 * cap) * 4; }
 
 // Outputs: w.valB = s (row with rank i), w.pred = rank of every row.  Scratch: w.key64A (bucket-grouped (key, row) pairs),

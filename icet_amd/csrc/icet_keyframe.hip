@@ -438,25 +438,55 @@ __global__ __launch_bounds__(kBlock) void k_scramble_replay(const PairDesc* __re
 // Exclusive scan over (class, tile) in class-major order, in two steps so that a single large pair (7200 voxels x 240 tiles)
 // is not scanned by ONE block: k_bin_tiles (one thread per class, blocks over classes) turns each class's per-tile counts into
 // per-tile offsets and leaves the class total in class_start[]; k_bin_scan (one block per pair) scans the totals in place.
+// A block takes 64 classes; its four waves split the pair's tiles into quarters: wave g walks quarter g of every class (coalesced: a lane
+// per class), keeps the running counts of its quarter in registers, and the quarters are joined through LDS -- one round of loads, one
+// barrier, one round of stores per 4 x 16 tiles (a thread per class walking ALL tiles took four dependent rounds on a 116 k-row scan).
+constexpr int kTileClasses = 64;
 __global__ __launch_bounds__(kBlock) void k_bin_tiles(const uint32_t* __restrict__ counts, uint32_t* __restrict__ tile_base, int32_t* __restrict__ class_start,
                                                       int V, int chunks, const int32_t* __restrict__ class_range) {
-    const int pair = blockIdx.y, b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= V) return;
-    if (class_range && (b < class_range[2 * pair] || b > class_range[2 * pair + 1])) { class_start[(size_t)pair * (V + 1) + b] = 0; return; }   // no row has this class
+    __shared__ int s_tot[kBlock / 64][kTileClasses];
+    const int pair = blockIdx.y, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int b = blockIdx.x * kTileClasses + lane;
+    int lo = 0, hi = V - 1;
+    if (class_range) { lo = class_range[2 * pair]; hi = class_range[2 * pair + 1]; }
+    const int b_first = blockIdx.x * kTileClasses, b_last = min(b_first + kTileClasses, V) - 1;
+    if (b_last < lo || b_first > hi) {                            // no row of the pair has a class of this block (block-uniform)
+        if (g == 0 && b < V) class_start[(size_t)pair * (V + 1) + b] = 0;
+        return;
+    }
+    const bool live = b < V && b >= lo && b <= hi;
+    constexpr int kQ = kBlock / 64, kTrip = 16;
+    const int per = (chunks + kQ - 1) / kQ;                       // tiles per quarter
+    const int t_lo = min(g * per, chunks), t_hi = min(t_lo + per, chunks);
     const uint32_t* c = counts + (size_t)pair * chunks * V + b;
     uint32_t* tb = tile_base + (size_t)pair * chunks * V + b;
-    // a thread walks its class through the pair's tiles: 16 independent loads in flight per trip, the last trip predicated (61 tiles of a
-    // 116 k-row scan: four memory round trips; batches of 8 and a one-by-one tail made that twelve)
-    constexpr int kTilesPerTrip = 16;
+    // pass 1: the quarter's total (for quarters of at most kTrip tiles -- scans up to ~130 k rows -- the counts stay in registers for pass 2)
+    uint32_t x[kTrip];                                            // the quarter's FIRST trip stays in registers for pass 2
     int tot = 0;
-    for (int t = 0; t < chunks; t += kTilesPerTrip) {
-        uint32_t x[kTilesPerTrip];
 #pragma unroll
-        for (int k = 0; k < kTilesPerTrip; k++) x[k] = (t + k < chunks) ? c[(size_t)(t + k) * V] : 0u;
+    for (int k = 0; k < kTrip; k++) { x[k] = (live && t_lo + k < t_hi) ? c[(size_t)(t_lo + k) * V] : 0u; tot += (int)x[k]; }
+    for (int t0 = t_lo + kTrip; t0 < t_hi; t0 += kTrip) {         // longer quarters (scans above ~130 k rows): further trips of 16 loads in flight
+        uint32_t y[kTrip];
 #pragma unroll
-        for (int k = 0; k < kTilesPerTrip; k++) { if (t + k < chunks) tb[(size_t)(t + k) * V] = (uint32_t)tot; tot += (int)x[k]; }
+        for (int k = 0; k < kTrip; k++) y[k] = (live && t0 + k < t_hi) ? c[(size_t)(t0 + k) * V] : 0u;
+#pragma unroll
+        for (int k = 0; k < kTrip; k++) tot += (int)y[k];
     }
-    class_start[(size_t)pair * (V + 1) + b] = tot;
+    s_tot[g][lane] = tot;
+    __syncthreads();
+    int run = 0;
+    for (int q = 0; q < g; q++) run += s_tot[q][lane];
+    // pass 2: where each tile's rows of the class start
+#pragma unroll
+    for (int k = 0; k < kTrip; k++) { if (live && t_lo + k < t_hi) tb[(size_t)(t_lo + k) * V] = (uint32_t)run; run += (int)x[k]; }
+    for (int t0 = t_lo + kTrip; t0 < t_hi; t0 += kTrip) {
+        uint32_t y[kTrip];
+#pragma unroll
+        for (int k = 0; k < kTrip; k++) y[k] = (live && t0 + k < t_hi) ? c[(size_t)(t0 + k) * V] : 0u;
+#pragma unroll
+        for (int k = 0; k < kTrip; k++) { if (live && t0 + k < t_hi) tb[(size_t)(t0 + k) * V] = (uint32_t)run; run += (int)y[k]; }
+    }
+    if (g == kQ - 1 && b < V) class_start[(size_t)pair * (V + 1) + b] = live ? run : 0;
 }
 
 // live (optional): the classes holding at least live_min rows, compacted in class order (16-byte records, pairs x V of them) -- the angular bins fitCells1 looks at at
@@ -1213,7 +1243,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
 
 hipError_t launch_class_scan(const uint32_t* counts, uint32_t* tile_base, int32_t* class_start, int n_classes, int chunks, int n_pairs, hipStream_t st,
                              int32_t* live, int32_t* n_live, int live_min, uint32_t* n_items, const int32_t* class_range, const int32_t* tile_vr, int32_t* vrange_out) {
-    k_bin_tiles<<<dim3((n_classes + kBlock - 1) / kBlock, n_pairs), kBlock, 0, st>>>(counts, tile_base, class_start, n_classes, chunks, class_range);
+    k_bin_tiles<<<dim3((n_classes + kTileClasses - 1) / kTileClasses, n_pairs), kBlock, 0, st>>>(counts, tile_base, class_start, n_classes, chunks, class_range);
     ICET_LAUNCH_CHECK();
     k_bin_scan<<<n_pairs, kScanBlock, 0, st>>>(class_start, n_classes, live, n_live, live_min, n_items, tile_vr, chunks, vrange_out);
     ICET_LAUNCH_CHECK();

@@ -962,13 +962,16 @@ __global__ __launch_bounds__(kBlock, ICET_MOM_WAVES) void k_fit_moments(const Pa
 
 // fitCells1's per-bin tail (src/icet.cpp:181-252), one lane per angular bin: eigen-decomposition, U = eigenvectors^T, the six
 // sigma points and their inside test -> L, the scan-1 half of the gate at :290, and the records of the active voxels.
+// kFinishBins bins per block: 512 for a throughput batch (75 x 24 is then 4 blocks per pair, 1024 per 256-pair launch: ONE resident round at the kernel's
+// 127 VGPRs instead of two), 256 for small batches (more blocks for a single pair's CUs).
+template <int kFinishBins>
 __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict__ midD, const int32_t* __restrict__ bin_start, SlotHot* __restrict__ hotD, SlotFit* __restrict__ fitD,
                                                        int32_t* __restrict__ activeD, AuxDev aux, int T, int P, int n) {
     // Two stages.  (A) one lane per bin: the cheap per-bin outputs, and the FITTED bins of the block (~12 % of its 256) compacted into an
     // LDS list; (B) one lane per fitted bin: the 3x3 eigen-decomposition, the six sigma points with their double-precision
     // cartesianToSpherical, the slot records.  With the heavy part on the bin's own lane (round 2) every wave ran it for its handful of
     // fitted lanes; compacted, one wave per block does (k_fit_finish 53 -> see DESIGN.md section 4).
-    __shared__ int s_list[kBlock];
+    __shared__ int s_list[kFinishBins];
     __shared__ int s_count;
     __shared__ float s_pt[kBlock][6][3];                          // (B2) sigma points of the block's fitted bins, by list position
     __shared__ float s_lim[kBlock][6];                            // az0, az1, el0, el1, inner, outer
@@ -977,8 +980,9 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
     const int pair = blockIdx.y;
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
-    {
-        const int v = blockIdx.x * kBlock + threadIdx.x;
+#pragma unroll
+    for (int kb = 0; kb < kFinishBins / kBlock; kb++) {
+        const int v = blockIdx.x * kFinishBins + kb * kBlock + (int)threadIdx.x;
         if (v < V) {
             const size_t o = (size_t)pair * V + v;
             const int cnt_v = bin_start[(size_t)pair * (V + 1) + v + 1] - bin_start[(size_t)pair * (V + 1) + v];
@@ -1003,8 +1007,11 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
         }
     }
     __syncthreads();
-    const bool mine = (int)threadIdx.x < s_count;                 // this lane owns list entry threadIdx.x
-    const int v = mine ? s_list[threadIdx.x] : 0;
+    const int n_list = s_count;
+    for (int base = 0; base < n_list; base += kBlock) {           // one trip on ordinary grids (a block's 512 bins hold ~60 fitted ones); block-uniform
+    const int n_here = min(kBlock, n_list - base);
+    const bool mine = (int)threadIdx.x < n_here;                  // this lane owns list entry base + threadIdx.x
+    const int v = mine ? s_list[base + threadIdx.x] : 0;
     const size_t o = (size_t)pair * V + v;
     FitMid m{};
     if (mine) { m = midD[o]; m.cnt = bin_start[(size_t)pair * (V + 1) + v + 1] - bin_start[(size_t)pair * (V + 1) + v]; }
@@ -1038,14 +1045,14 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
     }
     // (B2) cartesianToSpherical of the 6 x count sigma points (double-precision atan2 / acos each), one per lane
     __syncthreads();
-    for (int item = threadIdx.x; item < 6 * s_count; item += kBlock) {
+    for (int item = threadIdx.x; item < 6 * n_here; item += kBlock) {
         const int q = item / 6, j = item - 6 * q;
         float r, az, el; c2s_cr(s_pt[q][j][0], s_pt[q][j][1], s_pt[q][j][2], r, az, el);
         s_in[q][j] = inside_bounds(r, az, el, s_lim[q][0], s_lim[q][1], s_lim[q][2], s_lim[q][3], s_lim[q][4], s_lim[q][5]) ? 1 : 0;
         s_far[q][j] = (r > s_lim[q][5]) ? 1 : 0;
     }
     __syncthreads();
-    if (!mine) return;
+    if (mine) {
     if (m.has_fit) {
         // testSigmaPoints walks j = 0..5 and leaves the loop AFTER testing the first point with r > outer (:669-686): a point behind
         // such a point was never tested, i.e. counts as outside.
@@ -1088,6 +1095,9 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
     if (aux.sigma1) { float* sg = aux.sigma1 + o * 9; sg[0] = m.cov[0]; sg[1] = m.cov[1]; sg[2] = m.cov[2]; sg[3] = m.cov[1]; sg[4] = m.cov[3]; sg[5] = m.cov[4]; sg[6] = m.cov[2]; sg[7] = m.cov[4]; sg[8] = m.cov[5]; }
     if (aux.evecs1) for (int k = 0; k < 9; k++) aux.evecs1[o * 9 + k] = Vm[k];
     if (aux.l_diag) { aux.l_diag[o * 3] = Ld[0]; aux.l_diag[o * 3 + 1] = Ld[1]; aux.l_diag[o * 3 + 2] = Ld[2]; }
+    }   // mine
+    __syncthreads();                                              // the staging arrays are reused by the next trip
+    }   // trips over the block's fitted bins
 }
 
 // Dense per-voxel records -> compact slots in voxel order (phi-major, theta inner: the reference's
@@ -1234,7 +1244,8 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     const int mom_chunks = std::max(1, std::min((c.V + kBlock / 64 - 1) / (kBlock / 64), (ICET_MOM_BLOCKS + c.n_pairs - 1) / c.n_pairs));
     k_fit_moments<<<dim3(groups * mom_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.cart1, (size_t)w.cap_n1, w.live_bins, w.n_live, w.midD, c.V, c.n, np, mom_chunks);
     ICET_LAUNCH_CHECK();
-    k_fit_finish<<<dim3((c.V + kBlock - 1) / kBlock, c.n_pairs), blk, 0, st>>>(w.midD, w.bin_start, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n);
+    if ((long long)c.n_pairs * ((c.V + kBlock - 1) / kBlock) >= 2048) k_fit_finish<2 * kBlock><<<dim3((c.V + 2 * kBlock - 1) / (2 * kBlock), c.n_pairs), blk, 0, st>>>(w.midD, w.bin_start, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n);
+    else k_fit_finish<kBlock><<<dim3((c.V + kBlock - 1) / kBlock, c.n_pairs), blk, 0, st>>>(w.midD, w.bin_start, w.hotD, w.fitD, w.activeD, aux, c.T, c.P, c.n);
     ICET_LAUNCH_CHECK();
     k_compact_slots<<<c.n_pairs, kCompactBlock, 0, st>>>(w.hotD, w.fitD, w.activeD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.acc, w.near_over_count, c.V);
     ICET_LAUNCH_CHECK();

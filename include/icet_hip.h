@@ -169,7 +169,8 @@ icet_status icet_debug_fetch(icet_ctx* ctx, int32_t what, void* out, int64_t cou
  * DECISION (the per-voxel counts n2_raw / n2_in) but move points between the 4-point runs and the runs of one, i.e. they regroup
  * float partial sums: X agrees to rounding, not bitwise.  Names: "lds_slots", "acc_pts",
  * "acc_blocks", "kf_pts", "rs_cap", "rs_max_cell" (0: per-bucket radix sort instead of the counting sort),
- * "exec_bits_lds" (0: swap-loop bit table read from memory), "batch_parts" (0 = automatic), "batch_stage" (0..4), "force_exact"
+ * "exec_bits_lds" (0: swap-loop bit table read from memory), "exec_pairwise" (which kernel computes the swap loop's executed-step bits:
+ * 1 one block per pair from the recurrence, 0 chain walks over independent tiles, -1 by batch size), "batch_parts" (0 = automatic), "batch_stage" (0..4), "force_exact"
  * (every scan-2 point through the literal classification), "library_sort" (rocPRIM radix sort instead of
  * the hand-written rank sort), "guard_scale" (>= 1), "lut_polar_quantile" (0..1).  Unknown name or value
  * out of range: ICET_ERR_BAD_ARG. */

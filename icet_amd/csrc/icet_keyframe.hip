@@ -964,6 +964,11 @@ __global__ __launch_bounds__(kBlock, ICET_MOM_WAVES) void k_fit_moments(const Pa
 // sigma points and their inside test -> L, the scan-1 half of the gate at :290, and the records of the active voxels.
 // kFinishBins bins per block: 512 for a throughput batch (75 x 24 is then 4 blocks per pair, 1024 per 256-pair launch: ONE resident round at the kernel's
 // 127 VGPRs instead of two), 256 for small batches (more blocks for a single pair's CUs).
+#ifndef ICET_FINISH_TRIP
+#define ICET_FINISH_TRIP 256
+#endif
+constexpr int kFinishTrip = ICET_FINISH_TRIP;    // fitted bins per trip of k_fit_finish's heavy stage (<= kBlock; smaller values only to exercise the loop: scripts/cmp_libs.py)
+static_assert(kFinishTrip <= kBlock, "one lane per fitted bin of a trip");
 template <int kFinishBins>
 __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict__ midD, const int32_t* __restrict__ bin_start, SlotHot* __restrict__ hotD, SlotFit* __restrict__ fitD,
                                                        int32_t* __restrict__ activeD, AuxDev aux, int T, int P, int n) {
@@ -1008,8 +1013,8 @@ __global__ __launch_bounds__(kBlock) void k_fit_finish(const FitMid* __restrict_
     }
     __syncthreads();
     const int n_list = s_count;
-    for (int base = 0; base < n_list; base += kBlock) {           // one trip on ordinary grids (a block's 512 bins hold ~60 fitted ones); block-uniform
-    const int n_here = min(kBlock, n_list - base);
+    for (int base = 0; base < n_list; base += kFinishTrip) {           // one trip on ordinary grids (a block's 512 bins hold ~60 fitted ones); block-uniform
+    const int n_here = min(kFinishTrip, n_list - base);
     const bool mine = (int)threadIdx.x < n_here;                  // this lane owns list entry base + threadIdx.x
     const int v = mine ? s_list[base + threadIdx.x] : 0;
     const size_t o = (size_t)pair * V + v;

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_a
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;
     const PairDesc d = desc[pair];
     int cs = (d.n2 + chunks - 1) / chunks;
-    cs = (cs + kAccPts * kAccBlock - 1) / (kAccPts * kAccBlock) * (kAccPts * kAccBlock);   // whole trips of kAccPts points per lane
+    cs = (cs + kAccPts * 64 - 1) / (kAccPts * 64) * (kAccPts * 64);   // whole WAVE-trips (256 points): chunks of equal size whatever the block's trip; a block's last trip may leave waves idle
     const int begin = chunk * cs;
     if (begin >= d.n2) return;
     const int end = min(d.n2, begin + cs);

@@ -415,6 +415,7 @@ def main(argv=None):
         with torch.cuda.stream(stream):
             one_ctx.solve_batch_device(one1, one2, p_timed, o1.data_ptr())
         lt = one_ctx.last_timing()
+        lat_X = o1[0].cpu().numpy().copy()
         l_acc = lt["accumulate_ms"] / max(lt["accumulate_launches"], 1)
         lat = {"workload": "configs[1]: single 64-ch pair, 75x24 voxels, 7 iters, inputs resident in HBM", "ms_per_pair": round(lat_ms, 4),
                "n1": n1[0], "n2": n2[0], "speedup_vs_published_35ms": round(PUBLISHED_MS_PER_PAIR / lat_ms, 1), "repetitions": nrep,
@@ -442,6 +443,7 @@ def main(argv=None):
         with torch.cuda.stream(stream):
             one_ctx.solve_batch_device(hd1, hd2, hpt, ho.data_ptr())
         ht = one_ctx.last_timing()
+        hi_X = ho[0].cpu().numpy().copy(); hi_host = (h1.T.cpu().numpy(), h2.T.cpu().numpy())
         h_acc = ht["accumulate_ms"] / max(ht["accumulate_launches"], 1)
         h_bytes = 12.0 * h1.shape[1] + 12.0 * h2.shape[1] * 10 + 192.0
         hires = {"workload": "configs[4]: single 128-ch pair (~%dk pts), 150x48 voxels, 10 iters, inputs resident in HBM" % (int(h2.shape[1]) // 1000),
@@ -456,8 +458,9 @@ def main(argv=None):
     h2d = None
     if args.workload == "batch" and not args.no_h2d and rank == 0 and not args.no_latency:
         m = min(64, len(ids))
-        hs1 = [scans1[j].T.contiguous().cpu() for j in range(m)]; hs2 = [scans2[j].T.contiguous().cpu() for j in range(m)]      # N x 3 row-major on the host
-        a1 = [t.numpy() for t in hs1]; a2 = [t.numpy() for t in hs2]
+        # pageable host arrays in the layout the reference's callers hold (Eigen::MatrixXf: column-major N x 3), so nothing is transposed on the way in
+        hs1 = [scans1[j].cpu().contiguous() for j in range(m)]; hs2 = [scans2[j].cpu().contiguous() for j in range(m)]          # (3, N) C-order == column-major N x 3
+        a1 = [t.numpy().T for t in hs1]; a2 = [t.numpy().T for t in hs2]                                                        # N x 3 views in Fortran order
         hctx = icet_amd.Context(dev_ids[0])
         def timed(fn, nrep=3):
             fn()
@@ -468,7 +471,7 @@ def main(argv=None):
         t_page = timed(lambda: hctx.solve_batch(a1, a2, iters, None, P, T))
         # pinned: the column-major staging the ABI reads, in page-locked memory (api.solve_batch transposes into pageable buffers, so go through the raw entry)
         import ctypes as C
-        pin1 = [s.T.contiguous().pin_memory() for s in hs1]; pin2 = [s.T.contiguous().pin_memory() for s in hs2]                 # (3, N) = column-major N x 3
+        pin1 = [s.pin_memory() for s in hs1]; pin2 = [s.pin_memory() for s in hs2]                                               # (3, N) = column-major N x 3
         L = api.load_library()
         A1 = (C.c_void_p * m)(*[t.data_ptr() for t in pin1]); A2 = (C.c_void_p * m)(*[t.data_ptr() for t in pin2])
         nn1 = np.array([t.shape[1] for t in pin1], np.int64); nn2 = np.array([t.shape[1] for t in pin2], np.int64)
@@ -484,8 +487,73 @@ def main(argv=None):
                "pageable_ms_per_pair": round(t_page / m * 1e3, 4), "pageable_pairs_per_s": round(m / t_page, 1),
                "pinned_ms_per_pair": round(t_pin / m * 1e3, 4), "pinned_pairs_per_s": round(m / t_pin, 1),
                "host_MB_per_call": round(mb, 1), "pinned_h2d_GBs": round(mb / 1e3 / t_pin, 2),
-               "note": "PCIe-inclusive; never `value` (value = inputs resident in HBM). pageable includes the host-side transpose into column-major"}
+               "note": "PCIe-inclusive; never `value` (value = inputs resident in HBM). Host arrays are column-major N x 3 (an Eigen::MatrixXf); "
+                       "scan 2s are uploaded on a copy stream beside the keyframe build"}
         hctx.close()
+
+    # ---- the constructor path (what src/odometry.cpp:73-79 pays per frame): ONE 64-ch pair from PAGEABLE host memory through icet_solve with the
+    # side tables include/icet.h asks for, and the same through the compiled adapter (tests/cpp/adapter_demo.cpp against the Eigen-API mock) ----
+    ctor = None
+    if args.workload == "batch" and not args.no_h2d and rank == 0 and not args.no_latency:
+        import ctypes as C
+        L = api.load_library()
+        cctx = icet_amd.Context(dev_ids[0])
+        c1 = scans1[0].cpu().contiguous().numpy(); c2 = scans2[0].cpu().contiguous().numpy()      # (3, N): column-major N x 3, pageable
+        V = T * P
+        tabs = dict(cluster_bounds=np.zeros((V, 6), np.float32), has_fit=np.zeros(V, np.int32), mu1=np.zeros((V, 3), np.float32), sigma1=np.zeros((V, 9), np.float32),
+                    evecs1=np.zeros((V, 9), np.float32), l_diag=np.zeros((V, 3), np.float32), x_hist=np.zeros((iters, 6), np.float32), htwh=np.zeros((iters, 36), np.float32),
+                    htwdz=np.zeros((iters, 6), np.float32), test_points=np.zeros((V, 18), np.float32), points2=np.zeros((3, c2.shape[1]), np.float32))
+        ax = api.Aux()
+        for k2, v2 in tabs.items():
+            setattr(ax, k2, v2.ctypes.data_as(api._I if v2.dtype == np.int32 else api._F))
+        cp = api.Params(iters, P, T, 25, 0.1, 0.1, 0)
+        x0 = np.zeros(6, np.float32); Xc = np.zeros(6, np.float32); Pc = np.zeros(6, np.float32); Cc = np.zeros(36, np.float32)
+        def ctor_call(aux):
+            st = L.icet_solve(cctx._h, C.byref(cp), c1.ctypes.data, c1.shape[1], c1.shape[1], c2.ctypes.data, c2.shape[1], c2.shape[1],
+                              x0.ctypes.data, Xc.ctypes.data, Pc.ctypes.data, Cc.ctypes.data, C.byref(ax) if aux else None)
+            if st != 0:
+                raise RuntimeError("icet_solve -> %d" % st)
+        def timed_ms(fn, nrep=100):
+            for _ in range(5):
+                fn()
+            ts = []
+            for _ in range(nrep):
+                t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
+            return float(np.mean(ts)), float(np.median(ts))
+        full_mean, full_med = timed_ms(lambda: ctor_call(True))
+        bare_mean, bare_med = timed_ms(lambda: ctor_call(False))
+        keep = ax.points2; ax.points2 = None
+        nop2_mean, _ = timed_ms(lambda: ctor_call(True))
+        ax.points2 = keep
+        res1 = torch.zeros((1, 48), dtype=torch.float32, device=dev)
+        with torch.cuda.stream(stream):
+            one_ctx.solve_batch_device(d1[:1], d2[:1], p_plain, res1.data_ptr()); one_ctx.sync()
+        same = bool(np.array_equal(Xc, res1[0, :6].cpu().numpy()))
+        ctor = {"workload": "configs[1] through the drop-in boundary: one 64-ch pair in PAGEABLE host memory (column-major N x 3, as an Eigen::MatrixXf) -> icet_solve -> X, pred_stds, cov "
+                            "and the side tables include/icet.h requests (clusterBounds, mu1/sigma1/U/L tables, testPoints, HTWH_i, points2) back on the host",
+                "ms_per_pair": round(full_mean, 4), "median_ms": round(full_med, 4), "x_and_pred_stds_only_ms": round(bare_mean, 4), "all_tables_but_points2_ms": round(nop2_mean, 4),
+                "resident_ms_for_scale": None if lat is None else lat["ms_per_pair"], "bits_equal_device_resident_solve": same,
+                "host_MB_in": round(12.0 * (c1.shape[1] + c2.shape[1]) / 1e6, 2)}
+        # the compiled adapter: class ICET of include/icet.h constructed from Eigen-API matrices in a timing loop
+        try:
+            import subprocess, tempfile
+            td = tempfile.mkdtemp(prefix="icet_ctor_")
+            c1.tofile(os.path.join(td, "s1.f32")); c2.tofile(os.path.join(td, "s2.f32"))
+            exe = os.path.join(td, "adapter_demo")
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "tests", "cpp", "mock_eigen"), "-I", os.path.join(ROOT, "include"),
+                                   os.path.join(ROOT, "tests", "cpp", "adapter_demo.cpp"), "-L", os.path.join(ROOT, "icet_amd", "lib"), "-licet_hip",
+                                   "-Wl,-rpath," + os.path.join(ROOT, "icet_amd", "lib"), "-o", exe], stderr=subprocess.DEVNULL)
+            o = subprocess.run([exe, os.path.join(td, "s1.f32"), os.path.join(td, "s2.f32"), str(c1.shape[1]), str(c2.shape[1]), "100"], capture_output=True, text=True, timeout=300)
+            tl2 = [ln for ln in o.stdout.splitlines() if ln.startswith("ctor_timing")]
+            if o.returncode == 0 and tl2:
+                f = tl2[-1].split()
+                ctor["adapter_class_ICET_ms"] = float(f[4]); ctor["adapter_class_ICET_median_ms"] = float(f[6])
+                ctor["adapter_note"] = "tests/cpp/adapter_demo.cpp: `ICET it(prev, cur, 7, X0, 24, 75)` of include/icet.h against the Eigen-API mock, 100 constructions, a separate process"
+            else:
+                ctor["adapter_class_ICET_ms"] = None; ctor["adapter_note"] = "adapter_demo failed: rc %d %s" % (o.returncode, o.stderr[-200:])
+        except Exception as e:
+            ctor["adapter_class_ICET_ms"] = None; ctor["adapter_note"] = "adapter_demo not run: %s" % type(e).__name__
+        cctx.close()
 
     # ---- CPU baseline: the oracle ("port") on this box's host cores, bounded sample, rank 0 at N=1 -----
     cpu = None
@@ -509,6 +577,13 @@ def main(argv=None):
         dXp = np.abs(ref["X"] - res[:m, :6].cpu().numpy())
         over1 = np.nonzero((dXp[:, :3].max(1) > 1e-4) | (dXp[:, 3:].max(1) > 1e-5))[0]
         over3 = np.nonzero((dXp[:, :3].max(1) > 3e-4) | (dXp[:, 3:].max(1) > 1e-4))[0]
+        # the two single-pair sub-records against the unmodified oracle on their own inputs (informational here; asserted in tests/test_gpu_parity.py)
+        if lat is not None:
+            r1 = po.solve(h1[0], h2[0], runlen=iters, bins_phi=P, bins_theta=T)
+            lat["max_abs_dX_vs_oracle"] = float(np.abs(r1["X"] - lat_X[:6]).max()); lat["max_rel_pred_stds_vs_oracle"] = float(np.abs(lat_X[6:12] / r1["pred_stds"] - 1).max())
+        if hires is not None:
+            r5 = po.solve(hi_host[0], hi_host[1], runlen=10, bins_phi=48, bins_theta=150)
+            hires["max_abs_dX_vs_oracle"] = float(np.abs(r5["X"] - hi_X[:6]).max()); hires["max_rel_pred_stds_vs_oracle"] = float(np.abs(hi_X[6:12] / r5["pred_stds"] - 1).max())
         cpu = {"value": round(m / tl, 3), "unit": "scan-pairs/s", "cores": cores, "kind": "port",
                "sample": "first %d pairs of the same batch, one pair per host thread (oracle/icet_oracle.cpp, -O3 -march=native) in the oracle's LITERAL mode "
                          "(glibc float atan2/acos/sin/cos, sequential float sums -- the reference's expression types), %.1f s wall" % (m, tl),
@@ -552,6 +627,7 @@ def main(argv=None):
             "latency": lat,
             "highres": hires,
             "h2d_inclusive": h2d,
+            "ctor": ctor,
             "published_reference_ms_per_pair": PUBLISHED_MS_PER_PAIR,
         }
         print(json.dumps(line), flush=True)

@@ -24,7 +24,7 @@ FLAG_ROUNDTRIP_SCAN2 = 16  # parity-study option: the reference's two spherical 
 FLAG_HALF_GAP_BOUNDS = 8  # non-parity extension (half-gap cluster buffers of the Python variant; implies TRUE_SORT), see include/icet_hip.h
 
 # every symbol include/icet_hip.h, include/icet_nodes.h and include/icet_io.h declare
-EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_batch",
+EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_begin", "icet_solve_keyframe_tables", "icet_solve_end", "icet_solve_batch",
                     "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
                     "icet_multi_solve_batch", "icet_multi_solve_batch_device", "icet_multi_solve_batch_device_after", "icet_multi_set_option",
                     "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_map",
@@ -65,7 +65,7 @@ _I = C.POINTER(C.c_int32)
 
 class Aux(C.Structure):
     _fields_ = [("cluster_bounds", _F), ("n1_raw", _I), ("has_fit", _I), ("mu1", _F), ("sigma1", _F), ("evecs1", _F), ("l_diag", _F),
-                ("x_hist", _F), ("htwh", _F), ("htwdz", _F), ("n2_raw", _I), ("n2_in", _I), ("test_points", _F)]
+                ("x_hist", _F), ("htwh", _F), ("htwdz", _F), ("n2_raw", _I), ("n2_in", _I), ("test_points", _F), ("points2", _F)]
 
 
 _lib = None
@@ -89,6 +89,9 @@ def load_library():
     L.icet_reserve.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_int64, C.c_int64]
     L.icet_solve.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Aux)]
+    L.icet_solve_begin.argtypes = L.icet_solve.argtypes
+    L.icet_solve_end.argtypes = [C.c_void_p]
+    L.icet_solve_keyframe_tables.argtypes = [C.c_void_p]
     L.icet_solve_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.icet_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.POINTER(DevScan), C.c_void_p, C.c_void_p]
@@ -218,6 +221,8 @@ class Context:
 
     # -- single pair, host arrays ---------------------------------------------------------------
     def solve(self, scan1, scan2, runlen, X0, num_bins_phi, num_bins_theta, n=25, thresh=0.1, buff=0.1, aux=False, flags=0):
+        """icet_solve.  scan1 / scan2: N x 3 (any layout numpy can view; an N x 3 array in Fortran order -- an Eigen::MatrixXf -- is
+        passed without a copy).  aux=True also returns the side tables (icet_aux), among them ``points2`` (N2 x 3)."""
         s1, s2 = _colmajor(scan1), _colmajor(scan2)
         p = Params(int(runlen), int(num_bins_phi), int(num_bins_theta), int(n), float(thresh), float(buff), int(flags))
         x0 = np.asarray(X0, np.float32).reshape(6).copy()
@@ -230,10 +235,11 @@ class Context:
                        mu1=np.zeros((V, 3), np.float32), sigma1=np.zeros((V, 3, 3), np.float32), evecs1=np.zeros((V, 3, 3), np.float32),
                        l_diag=np.zeros((V, 3), np.float32), x_hist=np.zeros((rl, 6), np.float32), htwh=np.zeros((rl, 6, 6), np.float32),
                        htwdz=np.zeros((rl, 6), np.float32), n2_raw=np.zeros((rl, V), np.int32), n2_in=np.zeros((rl, V), np.int32),
-                       test_points=np.zeros((V, 6, 3), np.float32))
+                       test_points=np.zeros((V, 6, 3), np.float32), points2=np.zeros((3, s2.shape[1]), np.float32))
             auxs = Aux()
             for k, v in arr.items():
                 setattr(auxs, k, v.ctypes.data_as(_I if v.dtype == np.int32 else _F))
+            arr["points2"] = arr["points2"].T                # (N2, 3) view of the column-major buffer
             out["aux"] = arr
         st = load_library().icet_solve(self._h, C.byref(p), s1.ctypes.data, s1.shape[1], s1.shape[1], s2.ctypes.data, s2.shape[1], s2.shape[1],
                                        x0.ctypes.data, X.ctypes.data, ps.ctypes.data, cov.ctypes.data, C.byref(auxs) if auxs is not None else None)
@@ -391,7 +397,7 @@ class ICET:
                 self.HTWdz_i = a["htwdz"][runlen - 1].reshape(6, 1)
                 xprev = np.asarray(X0, np.float32).reshape(6) if runlen == 1 else a["x_hist"][runlen - 2]
                 self.dx = a["x_hist"][runlen - 1] - xprev
-                self.points2 = (np.asarray(scan2, np.float32) + xprev[:3]) @ euler_R(xprev[3], xprev[4], xprev[5])
+                self.points2 = a["points2"]                  # (p + t) * R of the last iteration, from the device (src/icet.cpp:375-378)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

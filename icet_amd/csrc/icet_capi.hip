@@ -37,8 +37,19 @@ struct icet_ctx {
     float* d_stage1 = nullptr; float* d_stage2 = nullptr; int64_t cap_stage1 = 0, cap_stage2 = 0;
     float* d_out = nullptr; float* d_x0 = nullptr; int32_t cap_out_pairs = 0;
     float* h_out = nullptr;
-    // aux (single pair)
+    // aux (single pair): every side table of a solve lives in ONE device block (`d_pack`, words of 4 bytes, layout aux_layout()) behind the
+    // 48 result floats, so that results and side tables come back in one DMA into the pinned `h_pack`
     AuxDev aux_dev{}; int aux_V = 0, aux_runlen = 0;
+    uint32_t* d_pack = nullptr; uint32_t* h_pack = nullptr; size_t cap_pack = 0;
+    float* h_pts2 = nullptr; float* d_pts2 = nullptr; size_t cap_pts2 = 0;   // `points2` (scan 2 under the last iteration's transform): device buffer + pinned host copy
+    float* h_x0 = nullptr;                                       // pinned, 6 x cap_out_pairs
+    // host-pointer entry points: scan 2 is uploaded on a stream of its own, beside the keyframe build of scan 1
+    hipStream_t st_copy = nullptr; hipEvent_t ev_s2 = nullptr;
+    hipEvent_t ev_kf = nullptr, ev_kfd = nullptr, ev_prev = nullptr, ev_pts2 = nullptr;   // keyframe built / its tables on the host / transform of the last iteration known / points2 on the host
+    // icet_solve_begin .. icet_solve_end
+    struct Pending { bool active = false; float* x_out = nullptr; float* ps_out = nullptr; float* cov_out = nullptr; icet_aux aux{}; bool has_aux = false;
+                     int V = 0, rl = 0; int64_t n2 = 0; bool kf_tables = false, kf_done = false, pts2 = false, pts2_dev = false, tail_ints = false;
+                     const float* scan2 = nullptr; int64_t ld2 = 0; } pend;
     // timing
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
     std::vector<hipEvent_t> ev_acc;
@@ -229,31 +240,98 @@ icet_status ensure_out(icet_ctx* c, int32_t n_pairs) {
     HIPCHK(c, dev_realloc(c->d_out, (size_t)n_pairs * 48));
     HIPCHK(c, dev_realloc(c->d_x0, (size_t)n_pairs * 6));
     if (c->h_out) { HIPCHK(c, hipHostFree(c->h_out)); c->h_out = nullptr; }
+    if (c->h_x0) { HIPCHK(c, hipHostFree(c->h_x0)); c->h_x0 = nullptr; }
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out), sizeof(float) * 48 * (size_t)n_pairs));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_x0), sizeof(float) * 6 * (size_t)n_pairs));
     c->cap_out_pairs = n_pairs;
     return ICET_OK;
 }
 
+// The copy stream of the host-pointer entry points and its event (created on first use).
+// Uploads go through the runtime's own pageable path, one hipMemcpy2DAsync per scan: measured on the GPU box (profiles/r04_stage_probe.txt,
+// scripts/hip/stage_probe.hip) it moves a 1.45 MB scan in 35 us (41 GB/s), as fast as from pinned memory; a ring of pinned chunks filled by
+// copy threads -- built first -- was 3-4x SLOWER (every chunk's DMA command costs ~10 us, and this host copies 50 GB/s on one thread).
+// What made the round-3 constructor path slow were the thirteen D2H copies into pageable arrays and the host loop for `points2`, not the upload.
+icet_status ensure_host_path(icet_ctx* c) {
+    if (!c->st_copy) HIPCHK(c, hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&c->ev_s2, &c->ev_kf, &c->ev_kfd, &c->ev_prev, &c->ev_pts2})
+        if (!*e) HIPCHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return ICET_OK;
+}
+
+// Column-major N x 3 host scan (leading dimension ld) -> staging buffer (leading dimension l) on `st`.
+hipError_t upload_scan(float* dst, int64_t l, const float* src, int64_t n, int64_t ld, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    return hipMemcpy2DAsync(dst, l * sizeof(float), src, ld * sizeof(float), n * sizeof(float), 3, hipMemcpyHostToDevice, st);
+}
+
+// (p + t) * R over a column-major scan (src/icet.cpp:375-378) with the device's own t and R (the transform record of write_xf): the host
+// half of `points2`.  Plain float arithmetic; the AVX2 + FMA build of the same loop is taken when the CPU has it.
+#define ICET_POINTS2_BODY                                                                                                     \
+    const float tx = xf[0], ty = xf[1], tz = xf[2];                                                                           \
+    const float R00 = xf[3], R01 = xf[4], R02 = xf[5], R10 = xf[6], R11 = xf[7], R12 = xf[8], R20 = xf[9], R21 = xf[10], R22 = xf[11]; \
+    const float* __restrict__ px = s; const float* __restrict__ py = s + ld; const float* __restrict__ pz = s + 2 * ld;      \
+    float* __restrict__ ox = out; float* __restrict__ oy = out + n; float* __restrict__ oz = out + 2 * n;                    \
+    for (int64_t i = 0; i < n; i++) {                                                                                         \
+        const float a = px[i] + tx, b = py[i] + ty, c = pz[i] + tz;                                                           \
+        ox[i] = a * R00 + b * R10 + c * R20; oy[i] = a * R01 + b * R11 + c * R21; oz[i] = a * R02 + b * R12 + c * R22;       \
+    }
+#if defined(__x86_64__)
+__attribute__((target("avx2,fma"))) void host_points2_avx2(const float* xf, const float* s, int64_t ld, int64_t n, float* out) { ICET_POINTS2_BODY }
+#endif
+void host_points2(const float* xf, const float* s, int64_t ld, int64_t n, float* out) {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) { host_points2_avx2(xf, s, ld, n, out); return; }
+#endif
+    ICET_POINTS2_BODY
+}
+#undef ICET_POINTS2_BODY
+
+// Word offsets (4-byte words, every table 16-byte aligned) of the single-pair result block, which exists twice with one layout: in HBM
+// (d_pack) and in pinned host memory (h_pack).  [0, small_end): the 48 result floats, the transform record of the last iteration (for
+// `points2`) and the per-iteration 6 / 36 / 6-float tables -- the kernels write these STRAIGHT into the pinned copy (a few posted PCIe
+// writes per iteration; no D2H command on the critical path); [bounds, kf_end): the keyframe tables, final once the keyframe is built,
+// copied to the host on the copy stream while the loop runs; then the rarely requested integer tables (copied at the end).
+struct AuxLayout { size_t out, xf_last, x_hist, htwh, htwdz, small_end, bounds, has_fit, mu1, sigma1, evecs1, l_diag, test_points, kf_end, n1_raw, n2_raw, n2_in, ints_end, total; };
+AuxLayout aux_layout(int V, int runlen) {
+    AuxLayout L{}; size_t o = 0;
+    auto take = [&o](size_t n) { const size_t at = o; o += (n + 3) & ~(size_t)3; return at; };
+    const size_t rl = runlen > 0 ? runlen : 1, v = (size_t)V;
+    L.out = take(48); L.xf_last = take(48); L.x_hist = take(rl * 6); L.htwh = take(rl * 36); L.htwdz = take(rl * 6); L.small_end = o;
+    L.bounds = take(v * 6); L.has_fit = take(v); L.mu1 = take(v * 3); L.sigma1 = take(v * 9); L.evecs1 = take(v * 9); L.l_diag = take(v * 3);
+    L.test_points = take(v * 18); L.kf_end = o; L.n1_raw = take(v); L.n2_raw = take(rl * v); L.n2_in = take(rl * v); L.ints_end = o;
+    L.total = o;
+    return L;
+}
+
 void free_aux(icet_ctx* c) {
-    AuxDev& a = c->aux_dev;
-    void* ps[] = {a.bounds, a.n1_raw, a.has_fit, a.mu1, a.sigma1, a.evecs1, a.l_diag, a.x_hist, a.htwh, a.htwdz, a.n2_raw, a.n2_in, a.test_points};
-    for (void* p : ps) if (p) (void)hipFree(p);
-    a = AuxDev{};
+    if (c->d_pack) { (void)hipFree(c->d_pack); c->d_pack = nullptr; }
+    if (c->h_pack) { (void)hipHostFree(c->h_pack); c->h_pack = nullptr; }
+    c->cap_pack = 0;
+    c->aux_dev = AuxDev{};
     c->aux_V = 0; c->aux_runlen = 0;
 }
 
-icet_status ensure_aux(icet_ctx* c, int V, int runlen) {
-    if (c->aux_V >= V && c->aux_runlen >= runlen && c->aux_dev.bounds) return ICET_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    free_aux(c);
-    AuxDev& a = c->aux_dev;
-    const size_t rl = runlen > 0 ? runlen : 1;
-    HIPCHK(c, dev_realloc(a.bounds, (size_t)V * 6)); HIPCHK(c, dev_realloc(a.n1_raw, V)); HIPCHK(c, dev_realloc(a.has_fit, V));
-    HIPCHK(c, dev_realloc(a.mu1, (size_t)V * 3)); HIPCHK(c, dev_realloc(a.sigma1, (size_t)V * 9)); HIPCHK(c, dev_realloc(a.evecs1, (size_t)V * 9));
-    HIPCHK(c, dev_realloc(a.l_diag, (size_t)V * 3)); HIPCHK(c, dev_realloc(a.test_points, (size_t)V * 18));
-    HIPCHK(c, dev_realloc(a.x_hist, rl * 6)); HIPCHK(c, dev_realloc(a.htwh, rl * 36)); HIPCHK(c, dev_realloc(a.htwdz, rl * 6));
-    HIPCHK(c, dev_realloc(a.n2_raw, rl * V)); HIPCHK(c, dev_realloc(a.n2_in, rl * V));
-    c->aux_V = V; c->aux_runlen = runlen;
+// Device and pinned host copies of the result block for (V, runlen); c->aux_dev points into the device block.
+icet_status ensure_pack(icet_ctx* c, int V, int runlen) {
+    const AuxLayout L = aux_layout(V, runlen);
+    if (L.total > c->cap_pack) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        free_aux(c);
+        HIPCHK(c, dev_realloc(c->d_pack, L.total));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pack), L.total * sizeof(uint32_t)));
+        c->cap_pack = L.total;
+    }
+    if (c->aux_V != V || c->aux_runlen != runlen) {
+        AuxDev& a = c->aux_dev; uint32_t* d = c->d_pack;
+        auto F = [d](size_t at) { return reinterpret_cast<float*>(d + at); };
+        auto I = [d](size_t at) { return reinterpret_cast<int32_t*>(d + at); };
+        float* hs = reinterpret_cast<float*>(c->h_pack);                     // pinned host memory is device-accessible under the same address
+        a.bounds = F(L.bounds); a.n1_raw = I(L.n1_raw); a.has_fit = I(L.has_fit); a.mu1 = F(L.mu1); a.sigma1 = F(L.sigma1); a.evecs1 = F(L.evecs1);
+        a.l_diag = F(L.l_diag); a.x_hist = hs + L.x_hist; a.htwh = hs + L.htwh; a.htwdz = hs + L.htwdz; a.n2_raw = I(L.n2_raw); a.n2_in = I(L.n2_in);
+        a.test_points = F(L.test_points); a.xf_last = hs + L.xf_last;
+        c->aux_V = V; c->aux_runlen = runlen;
+    }
     return ICET_OK;
 }
 
@@ -328,7 +406,8 @@ icet_status enqueue_keyframe(icet_ctx* c, const icet_params* p, int32_t n_pairs,
     return ICET_OK;
 }
 
-icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, const float* d_x0, float* d_out, const AuxDev* aux, bool reupload) {
+icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, const float* d_x0, float* d_out, const AuxDev* aux, bool reupload, float* pts2_out = nullptr, hipEvent_t scan2_ready = nullptr) {
+    const bool want_pts2 = aux && aux->xf_last && p->runlen > 0;      // pts2_out: the device computes `points2` (else only the transform snapshot + its event: the host does)
     Workspace& w = c->w;
     const LaunchCfg cfg = make_cfg(c, p, n_pairs);
     if (reupload) { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }      // the scan-2 halves arrived after the keyframe call
@@ -357,11 +436,28 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
         }
         HIPCHK(c, hipMemcpyAsync(w.desc_rt, c->h_desc_rt, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipEventRecord(c->ev_desc, c->stream)); c->desc_in_flight = true;
+        if (scan2_ready) HIPCHK(c, hipStreamWaitEvent(c->stream, scan2_ready, 0));
         HIPCHK(c, launch_rt2_prepare(w, cfg, c->stream));
         wl = w; wl.desc = w.desc_rt;
     }
     LaunchCfg lcfg = cfg; if (cfg.rt2) lcfg.vec4_ok = 1;     // the copy is 64-float aligned whatever the caller's layout was
-    HIPCHK(c, launch_init_state(w, cfg, d_x0, c->stream));
+    HIPCHK(c, launch_init_state(w, cfg, d_x0, c->stream, want_pts2 ? aux->xf_last : nullptr));
+    // `points2` (include/icet.h:80): scan 2 as the LAST fitScan2 transforms it (src/icet.cpp:375-378).  That transform is known as soon as the
+    // solve of iteration runlen - 2 has run: k_gn_solve / k_init_state snapshot its record in aux->xf_last (pinned host memory) and ev_prev
+    // marks the moment.  icet_solve_end then transforms scan 2 ON THE HOST while the last iteration still runs on the device (measured: a
+    // device kernel + 1.45 MB D2H + the copy into the caller's pageable array cost 110 us behind the loop, the host pass ~25 us under it).
+    // Only with ICET_FLAG_ROUNDTRIP_SCAN2, whose points2_OG exists on the device alone, the device computes it (copy stream).
+    auto enqueue_points2 = [&]() -> icet_status {
+        HIPCHK(c, hipEventRecord(c->ev_prev, c->stream));
+        if (!pts2_out) return ICET_OK;
+        HIPCHK(c, hipStreamWaitEvent(c->st_copy, c->ev_prev, 0));
+        HIPCHK(c, launch_points2(wl, lcfg, aux->xf_last, c->d_pts2, c->st_copy));
+        HIPCHK(c, hipMemcpyAsync(pts2_out, c->d_pts2, sizeof(float) * 3 * (size_t)c->h_desc[0].n2, hipMemcpyDeviceToHost, c->st_copy));
+        HIPCHK(c, hipEventRecord(c->ev_pts2, c->st_copy));
+        return ICET_OK;
+    };
+    if (scan2_ready) HIPCHK(c, hipStreamWaitEvent(c->stream, scan2_ready, 0));     // host-pointer entries: scan 2 was uploaded on the copy stream beside the keyframe build
+    if (want_pts2 && p->runlen == 1) { const icet_status ps = enqueue_points2(); if (ps != ICET_OK) return ps; }
     HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
     const bool per_iter = (p->flags & ICET_FLAG_TIMING) != 0;
     for (int it = 0; it < p->runlen; it++) {
@@ -369,6 +465,7 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
         HIPCHK(c, launch_gn_accumulate(wl, lcfg, c->stream));
         if (per_iter) HIPCHK(c, hipEventRecord(c->ev_acc[2 * it + 1], c->stream));
         HIPCHK(c, launch_gn_solve(wl, lcfg, it, d_out, aux, c->stream));
+        if (want_pts2 && it == p->runlen - 2) { const icet_status ps = enqueue_points2(); if (ps != ICET_OK) return ps; }
     }
     HIPCHK(c, hipEventRecord(c->ev_c, c->stream));
     c->timing_valid = true; c->last_iters = per_iter ? p->runlen : 0;
@@ -381,6 +478,17 @@ icet_status enqueue(icet_ctx* c, const icet_params* p, int32_t n_pairs, const fl
     icet_status s = enqueue_keyframe(c, p, n_pairs, aux);
     if (s != ICET_OK) return s;
     return enqueue_loop(c, p, n_pairs, d_x0, d_out, aux, false);
+}
+
+// Staging buffers of the host-pointer entry points (3 x l floats per scan, leading dimension l = n rounded up to 64).
+icet_status ensure_stage(icet_ctx* c, int64_t tot1, int64_t tot2) {
+    if (3 * tot1 > c->cap_stage1 || 3 * tot2 > c->cap_stage2) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->st_copy) HIPCHK(c, hipStreamSynchronize(c->st_copy));
+        if (3 * tot1 > c->cap_stage1) { HIPCHK(c, dev_realloc(c->d_stage1, (size_t)3 * tot1)); c->cap_stage1 = 3 * tot1; }
+        if (3 * tot2 > c->cap_stage2) { HIPCHK(c, dev_realloc(c->d_stage2, (size_t)3 * tot2)); c->cap_stage2 = 3 * tot2; }
+    }
+    return ICET_OK;
 }
 
 icet_status write_runlen0(icet_ctx* c, int32_t n_pairs, const float* d_x0, float* d_out) {
@@ -436,6 +544,12 @@ icet_status icet_destroy(icet_ctx* c) {
                   w.sort_tmp, w.fit_items, w.fit_n_items, w.live_bins, w.n_live, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);
     free_aux(c);
+    if (c->st_copy) (void)hipStreamSynchronize(c->st_copy);
+    if (c->h_pts2) (void)hipHostFree(c->h_pts2);
+    if (c->d_pts2) (void)hipFree(c->d_pts2);
+    if (c->h_x0) (void)hipHostFree(c->h_x0);
+    for (hipEvent_t e : {c->ev_s2, c->ev_kf, c->ev_kfd, c->ev_prev, c->ev_pts2}) if (e) (void)hipEventDestroy(e);
+    if (c->st_copy) (void)hipStreamDestroy(c->st_copy);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
     if (c->h_seg) (void)hipHostFree(c->h_seg);
     if (c->h_desc_rt) (void)hipHostFree(c->h_desc_rt);
@@ -634,6 +748,7 @@ icet_status icet_solve_batch(icet_ctx* c, const icet_params* p, int32_t n_pairs,
                              const float* x0, float* x_out, float* pred_stds_out, float* cov_out) {
     if (!c) return ICET_ERR_BAD_ARG;
     if (!params_ok(p) || n_pairs < 0 || (n_pairs > 0 && (!scan1 || !n1 || !scan2 || !n2 || !x_out || !pred_stds_out))) { c->err = "bad argument"; return ICET_ERR_BAD_ARG; }
+    if (c->pend.active) { c->err = "icet_solve_begin without icet_solve_end on this context"; return ICET_ERR_BAD_ARG; }
     if (n_pairs == 0) return ICET_OK;
     int64_t tot1 = 0, tot2 = 0;
     for (int k = 0; k < n_pairs; k++) {
@@ -642,28 +757,43 @@ icet_status icet_solve_batch(icet_ctx* c, const icet_params* p, int32_t n_pairs,
     }
     HIPCHK(c, hipSetDevice(c->device));
     icet_status s = ensure_workspace(c, p, n_pairs, tot1, tot2);
+    if (s == ICET_OK) s = ensure_out(c, n_pairs);
+    if (s == ICET_OK) s = ensure_host_path(c);
+    if (s == ICET_OK) s = ensure_stage(c, tot1, tot2);
     if (s != ICET_OK) return s;
-    s = ensure_out(c, n_pairs);
-    if (s != ICET_OK) return s;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (3 * tot1 > c->cap_stage1) { HIPCHK(c, dev_realloc(c->d_stage1, (size_t)3 * tot1)); c->cap_stage1 = 3 * tot1; }
-    if (3 * tot2 > c->cap_stage2) { HIPCHK(c, dev_realloc(c->d_stage2, (size_t)3 * tot2)); c->cap_stage2 = 3 * tot2; }
+    if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
+    // Scan 1 of every pair goes up first on the solve stream (the keyframe build needs nothing else); the scan 2s follow on the copy
+    // stream while the keyframe kernels run, and the loop waits for them.  Host scans are dense column-major (ld == n) in this entry point.
     int64_t o1 = 0, o2 = 0;
     for (int k = 0; k < n_pairs; k++) {
         const int64_t l1 = (n1[k] + 63) / 64 * 64, l2 = (n2[k] + 63) / 64 * 64;
         PairDesc& d = c->h_desc[k];
         d.s1 = c->d_stage1 + 3 * o1; d.s2 = c->d_stage2 + 3 * o2;
         d.n1 = (int32_t)n1[k]; d.ld1 = (int32_t)l1; d.n2 = (int32_t)n2[k]; d.ld2 = (int32_t)l2; d.off1 = 0; d.off2 = 0;
-        // host scans are dense column-major (ld == n) in this entry point
-        if (n1[k]) HIPCHK(c, hipMemcpy2DAsync(c->d_stage1 + 3 * o1, l1 * sizeof(float), scan1[k], n1[k] * sizeof(float), n1[k] * sizeof(float), 3, hipMemcpyHostToDevice, c->stream));
-        if (n2[k]) HIPCHK(c, hipMemcpy2DAsync(c->d_stage2 + 3 * o2, l2 * sizeof(float), scan2[k], n2[k] * sizeof(float), n2[k] * sizeof(float), 3, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, upload_scan(c->d_stage1 + 3 * o1, l1, scan1[k], n1[k], n1[k], c->stream));
         o1 += l1; o2 += l2;
     }
     const float* dx0 = nullptr;
-    if (x0) { HIPCHK(c, hipMemcpyAsync(c->d_x0, x0, sizeof(float) * 6 * n_pairs, hipMemcpyHostToDevice, c->stream)); dx0 = c->d_x0; }
+    if (x0) { std::memcpy(c->h_x0, x0, sizeof(float) * 6 * n_pairs); HIPCHK(c, hipMemcpyAsync(c->d_x0, c->h_x0, sizeof(float) * 6 * n_pairs, hipMemcpyHostToDevice, c->stream)); dx0 = c->d_x0; }
+    auto upload_scan2s = [&]() -> hipError_t {
+        for (int k = 0; k < n_pairs; k++) {
+            const PairDesc& d = c->h_desc[k];
+            hipError_t e = upload_scan(const_cast<float*>(d.s2), d.ld2, scan2[k], n2[k], n2[k], c->st_copy);
+            if (e != hipSuccess) return e;
+        }
+        return hipEventRecord(c->ev_s2, c->st_copy);
+    };
     if (p->runlen == 0) s = write_runlen0(c, n_pairs, dx0, c->d_out);
-    else s = enqueue(c, p, n_pairs, dx0, c->d_out, nullptr);
-    if (s != ICET_OK) return s;
+    else {
+        c->kf_pairs = 0;
+        s = enqueue_keyframe(c, p, n_pairs, nullptr);
+        if (s == ICET_OK) {
+            const hipError_t e = upload_scan2s();
+            if (e != hipSuccess) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->st_copy); c->err = std::string("scan-2 upload: ") + hipGetErrorString(e); return ICET_ERR_HIP; }
+            s = enqueue_loop(c, p, n_pairs, dx0, c->d_out, nullptr, false, nullptr, c->ev_s2);
+        }
+    }
+    if (s != ICET_OK) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->st_copy); return s; }
     HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(float) * 48 * n_pairs, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < n_pairs; k++) {
@@ -674,60 +804,152 @@ icet_status icet_solve_batch(icet_ctx* c, const icet_params* p, int32_t n_pairs,
     return ICET_OK;
 }
 
-icet_status icet_solve(icet_ctx* c, const icet_params* p, const float* scan1, int64_t n1, int64_t ld1,
-                       const float* scan2, int64_t n2, int64_t ld2, const float x0[6],
-                       float x_out[6], float pred_stds_out[6], float cov_out[36], icet_aux* aux) {
+// The constructor replacement in two halves.  icet_solve_begin enqueues the uploads, the whole registration and the copy of the results
+// and returns while the device works (the scans must stay untouched until icet_solve_end: the runtime may still be reading them);
+// icet_solve_end waits and fills the outputs named at begin.  What the host does in between -- the reference's constructor deep-copies
+// both scans into its members (src/icet.cpp:30,33), include/icet.h does the same there -- overlaps with the device.
+icet_status icet_solve_begin(icet_ctx* c, const icet_params* p, const float* scan1, int64_t n1, int64_t ld1,
+                             const float* scan2, int64_t n2, int64_t ld2, const float x0[6],
+                             float x_out[6], float pred_stds_out[6], float cov_out[36], icet_aux* aux) {
     if (!c) return ICET_ERR_BAD_ARG;
     if (!params_ok(p) || n1 < 0 || n2 < 0 || ld1 < n1 || ld2 < n2 || (n1 > 0 && !scan1) || (n2 > 0 && !scan2) || !x0 || !x_out || !pred_stds_out) {
         c->err = "bad argument"; return ICET_ERR_BAD_ARG;
     }
+    if (c->pend.active) { c->err = "icet_solve_begin without icet_solve_end on this context"; return ICET_ERR_BAD_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     const int V = p->bins_phi * p->bins_theta;
     const int64_t l1 = (n1 + 63) / 64 * 64, l2 = (n2 + 63) / 64 * 64;
     icet_status s = ensure_workspace(c, p, 1, l1, l2);
+    if (s == ICET_OK) s = ensure_out(c, 1);
+    if (s == ICET_OK) s = ensure_host_path(c);
+    if (s == ICET_OK) s = ensure_stage(c, l1, l2);
+    if (s == ICET_OK) s = ensure_pack(c, V, p->runlen);
     if (s != ICET_OK) return s;
-    s = ensure_out(c, 1);
-    if (s != ICET_OK) return s;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (3 * l1 > c->cap_stage1) { HIPCHK(c, dev_realloc(c->d_stage1, (size_t)3 * l1)); c->cap_stage1 = 3 * l1; }
-    if (3 * l2 > c->cap_stage2) { HIPCHK(c, dev_realloc(c->d_stage2, (size_t)3 * l2)); c->cap_stage2 = 3 * l2; }
-    if (n1) HIPCHK(c, hipMemcpy2DAsync(c->d_stage1, l1 * sizeof(float), scan1, ld1 * sizeof(float), n1 * sizeof(float), 3, hipMemcpyHostToDevice, c->stream));
-    if (n2) HIPCHK(c, hipMemcpy2DAsync(c->d_stage2, l2 * sizeof(float), scan2, ld2 * sizeof(float), n2 * sizeof(float), 3, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_x0, x0, sizeof(float) * 6, hipMemcpyHostToDevice, c->stream));
+    const bool want_pts2 = aux && aux->points2 && n2 > 0 && p->runlen > 0;
+    if (want_pts2 && (p->flags & ICET_FLAG_ROUNDTRIP_SCAN2) && (size_t)3 * n2 > c->cap_pts2) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->st_copy) HIPCHK(c, hipStreamSynchronize(c->st_copy));
+        if (c->h_pts2) { HIPCHK(c, hipHostFree(c->h_pts2)); c->h_pts2 = nullptr; c->cap_pts2 = 0; }
+        const size_t want = (size_t)3 * n2 + (size_t)3 * n2 / 8;
+        HIPCHK(c, dev_realloc(c->d_pts2, want));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pts2), want * sizeof(float)));
+        c->cap_pts2 = want;
+    }
+    if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
+    // (no stream synchronisation up front: the staging buffers, the result block and the pinned x0 are only ever used by the host-pointer
+    // entry points, each of which has drained the stream before it returned)
+    std::memcpy(c->h_x0, x0, 6 * sizeof(float));                              // pinned: k_init_state reads X0 straight from it (no H2D command)
+    HIPCHK(c, upload_scan(c->d_stage1, l1, scan1, n1, ld1, c->stream));
     PairDesc& d = c->h_desc[0];
     d.s1 = c->d_stage1; d.s2 = c->d_stage2; d.n1 = (int32_t)n1; d.ld1 = (int32_t)l1; d.n2 = (int32_t)n2; d.ld2 = (int32_t)l2; d.off1 = 0; d.off2 = 0;
-    const AuxDev* ad = nullptr;
-    if (aux) {
-        s = ensure_aux(c, V, p->runlen);
-        if (s != ICET_OK) return s;
-        const size_t rl = p->runlen > 0 ? p->runlen : 1;
-        HIPCHK(c, hipMemsetAsync(c->aux_dev.n2_raw, 0, sizeof(int32_t) * rl * V, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->aux_dev.n2_in, 0, sizeof(int32_t) * rl * V, c->stream));
-        ad = &c->aux_dev;
-    }
+    const AuxLayout L = aux_layout(V, p->runlen);
+    float* h_res = reinterpret_cast<float*>(c->h_pack) + L.out;               // the 48 result floats: written by k_gn_solve into pinned host memory
+    AuxDev ad = c->aux_dev;
+    icet_ctx::Pending& q = c->pend;
+    q = icet_ctx::Pending{};
+    icet_status st = ICET_OK;
     if (p->runlen == 0) {
-        s = write_runlen0(c, 1, c->d_x0, c->d_out);
-        aux = nullptr;
+        // the reference's constructor leaves X = X0, pred_stds = 0 when runlen == 0 (src/icet.cpp:36-37,47); nothing to enqueue
+        std::memset(h_res, 0, 48 * sizeof(float)); std::memcpy(h_res, x0, 6 * sizeof(float));
+        if (aux && aux->points2 && n2 > 0)                                    // `points2` of an object that never iterated is its copy of scan 2 (src/icet.cpp:33)
+            for (int k = 0; k < 3; k++) std::memcpy(aux->points2 + (size_t)k * n2, scan2 + (size_t)k * ld2, (size_t)n2 * sizeof(float));
     } else {
-        s = enqueue(c, p, 1, c->d_x0, c->d_out, ad);
+        if (aux) {
+            const size_t rl = p->runlen, v = (size_t)V;
+            // per-iteration integer tables: k_gn_solve writes the active voxels only, so they start from zero -- and are neither cleared
+            // nor written when nobody asked for them
+            if (aux->n2_raw) HIPCHK(c, hipMemsetAsync(ad.n2_raw, 0, sizeof(int32_t) * rl * v, c->stream)); else ad.n2_raw = nullptr;
+            if (aux->n2_in) HIPCHK(c, hipMemsetAsync(ad.n2_in, 0, sizeof(int32_t) * rl * v, c->stream)); else ad.n2_in = nullptr;
+            q.kf_tables = aux->cluster_bounds || aux->has_fit || aux->mu1 || aux->sigma1 || aux->evecs1 || aux->l_diag || aux->test_points;
+            q.tail_ints = aux->n1_raw || aux->n2_raw || aux->n2_in;
+            q.pts2 = want_pts2; q.pts2_dev = want_pts2 && (p->flags & ICET_FLAG_ROUNDTRIP_SCAN2) != 0;
+            q.scan2 = scan2; q.ld2 = ld2;
+            if (!want_pts2) ad.xf_last = nullptr;
+        }
+        c->kf_pairs = 0;
+        st = enqueue_keyframe(c, p, 1, aux ? &ad : nullptr);
+        if (st == ICET_OK) {
+            // scan 2 goes up on the copy stream while the keyframe kernels enqueued above run; the loop waits for ev_s2
+            hipError_t e = upload_scan(c->d_stage2, l2, scan2, n2, ld2, c->st_copy);
+            if (e == hipSuccess) e = hipEventRecord(c->ev_s2, c->st_copy);
+            if (e == hipSuccess && q.kf_tables) {
+                // the keyframe tables are final now: they travel to the host on the copy stream while the loop iterates
+                e = hipEventRecord(c->ev_kf, c->stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(c->st_copy, c->ev_kf, 0);
+                if (e == hipSuccess) e = hipMemcpyAsync(c->h_pack + L.bounds, c->d_pack + L.bounds, (L.kf_end - L.bounds) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->st_copy);
+                if (e == hipSuccess) e = hipEventRecord(c->ev_kfd, c->st_copy);
+            }
+            if (e != hipSuccess) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->st_copy); c->err = std::string("scan-2 upload / table download: ") + hipGetErrorString(e); return ICET_ERR_HIP; }
+            st = enqueue_loop(c, p, 1, c->h_x0, h_res, aux ? &ad : nullptr, false, q.pts2_dev ? c->h_pts2 : nullptr, c->ev_s2);
+        }
+        if (st == ICET_OK && q.tail_ints)
+            HIPCHK(c, hipMemcpyAsync(c->h_pack + L.n1_raw, c->d_pack + L.n1_raw, (L.ints_end - L.n1_raw) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     }
-    if (s != ICET_OK) return s;
-    HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, c->stream));
-    if (aux) {
-        const AuxDev& a = c->aux_dev; const size_t rl = p->runlen;
-#define ICET_AUX_COPY(dst, srcp, count, type) if (aux->dst) HIPCHK(c, hipMemcpyAsync(aux->dst, a.srcp, sizeof(type) * (count), hipMemcpyDeviceToHost, c->stream))
-        ICET_AUX_COPY(cluster_bounds, bounds, (size_t)V * 6, float); ICET_AUX_COPY(n1_raw, n1_raw, V, int32_t); ICET_AUX_COPY(has_fit, has_fit, V, int32_t);
-        ICET_AUX_COPY(mu1, mu1, (size_t)V * 3, float); ICET_AUX_COPY(sigma1, sigma1, (size_t)V * 9, float); ICET_AUX_COPY(evecs1, evecs1, (size_t)V * 9, float);
-        ICET_AUX_COPY(l_diag, l_diag, (size_t)V * 3, float); ICET_AUX_COPY(x_hist, x_hist, rl * 6, float); ICET_AUX_COPY(htwh, htwh, rl * 36, float);
-        ICET_AUX_COPY(htwdz, htwdz, rl * 6, float); ICET_AUX_COPY(n2_raw, n2_raw, rl * V, int32_t); ICET_AUX_COPY(n2_in, n2_in, rl * V, int32_t);
-        ICET_AUX_COPY(test_points, test_points, (size_t)V * 18, float);
-#undef ICET_AUX_COPY
+    if (st != ICET_OK) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->st_copy); return st; }
+    q.active = true; q.x_out = x_out; q.ps_out = pred_stds_out; q.cov_out = cov_out; q.has_aux = aux != nullptr && p->runlen > 0;
+    q.aux = aux ? *aux : icet_aux{}; q.V = V; q.rl = p->runlen; q.n2 = n2;
+    return ICET_OK;
+}
+
+// The keyframe half of a pending solve: returns when the keyframe tables named at begin (cluster_bounds, has_fit, mu1, sigma1, evecs1,
+// l_diag, test_points) are in the caller's arrays -- the loop is still iterating on the device.  Optional; icet_solve_end does it otherwise.
+icet_status icet_solve_keyframe_tables(icet_ctx* c) {
+    if (!c) return ICET_ERR_BAD_ARG;
+    icet_ctx::Pending& q = c->pend;
+    if (!q.active) { c->err = "icet_solve_keyframe_tables without icet_solve_begin"; return ICET_ERR_BAD_ARG; }
+    if (!q.has_aux || !q.kf_tables || q.kf_done) return ICET_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev_kfd));
+    const AuxLayout L = aux_layout(q.V, q.rl);
+    const icet_aux& a = q.aux; const size_t v = (size_t)q.V;
+    auto add = [&](void* dst, size_t at, size_t n) { if (dst && n) std::memcpy(dst, c->h_pack + at, n * sizeof(uint32_t)); };
+    add(a.cluster_bounds, L.bounds, v * 6); add(a.has_fit, L.has_fit, v); add(a.mu1, L.mu1, v * 3); add(a.sigma1, L.sigma1, v * 9);
+    add(a.evecs1, L.evecs1, v * 9); add(a.l_diag, L.l_diag, v * 3); add(a.test_points, L.test_points, v * 18);
+    q.kf_done = true;
+    return ICET_OK;
+}
+
+icet_status icet_solve_end(icet_ctx* c) {
+    if (!c) return ICET_ERR_BAD_ARG;
+    icet_ctx::Pending& q = c->pend;
+    if (!q.active) { c->err = "icet_solve_end without icet_solve_begin"; return ICET_ERR_BAD_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    // what is ready before the loop has finished is moved into the caller's arrays while the device still iterates
+    icet_status ks = icet_solve_keyframe_tables(c);
+    q.active = false;
+    if (q.has_aux && q.pts2 && ks == ICET_OK) {
+        if (q.pts2_dev) {
+            HIPCHK(c, hipEventSynchronize(c->ev_pts2));
+            std::memcpy(q.aux.points2, c->h_pts2, (size_t)3 * q.n2 * sizeof(float));
+        } else {
+            // the transform of the last iteration is known (its solve is still running): scan 2 is transformed here, under the device's last iteration
+            HIPCHK(c, hipEventSynchronize(c->ev_prev));
+            const AuxLayout Lp = aux_layout(q.V, q.rl);
+            host_points2(reinterpret_cast<const float*>(c->h_pack) + Lp.xf_last, q.scan2, q.ld2, q.n2, q.aux.points2);
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::memcpy(x_out, c->h_out, 6 * sizeof(float));
-    std::memcpy(pred_stds_out, c->h_out + 6, 6 * sizeof(float));
-    if (cov_out) std::memcpy(cov_out, c->h_out + 12, 36 * sizeof(float));
+    if (q.rl > 0) HIPCHK(c, hipStreamSynchronize(c->st_copy));
+    if (ks != ICET_OK) return ks;
+    const AuxLayout L = aux_layout(q.V, q.rl);
+    const float* out = reinterpret_cast<const float*>(c->h_pack) + L.out;
+    std::memcpy(q.x_out, out, 6 * sizeof(float));
+    std::memcpy(q.ps_out, out + 6, 6 * sizeof(float));
+    if (q.cov_out) std::memcpy(q.cov_out, out + 12, 36 * sizeof(float));
+    if (q.has_aux) {
+        const icet_aux& a = q.aux; const size_t rl = q.rl, v = (size_t)q.V;
+        auto add = [&](void* dst, size_t at, size_t n) { if (dst && n) std::memcpy(dst, c->h_pack + at, n * sizeof(uint32_t)); };
+        add(a.x_hist, L.x_hist, rl * 6); add(a.htwh, L.htwh, rl * 36); add(a.htwdz, L.htwdz, rl * 6);
+        add(a.n1_raw, L.n1_raw, v); add(a.n2_raw, L.n2_raw, rl * v); add(a.n2_in, L.n2_in, rl * v);
+    }
     return ICET_OK;
+}
+
+icet_status icet_solve(icet_ctx* c, const icet_params* p, const float* scan1, int64_t n1, int64_t ld1,
+                       const float* scan2, int64_t n2, int64_t ld2, const float x0[6],
+                       float x_out[6], float pred_stds_out[6], float cov_out[36], icet_aux* aux) {
+    const icet_status s = icet_solve_begin(c, p, scan1, n1, ld1, scan2, n2, ld2, x0, x_out, pred_stds_out, cov_out, aux);
+    return s == ICET_OK ? icet_solve_end(c) : s;
 }
 
 icet_status icet_debug_fetch(icet_ctx* c, int32_t what, void* out, int64_t count) {

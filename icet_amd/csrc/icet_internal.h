@@ -79,6 +79,7 @@ static_assert(sizeof(SlotHot) == 48 && sizeof(SlotFit) == 80, "k_compact_slots c
 struct AuxDev {
     float* bounds; int32_t* n1_raw; int32_t* has_fit; float* mu1; float* sigma1; float* evecs1; float* l_diag;
     float* x_hist; float* htwh; float* htwdz; int32_t* n2_raw; int32_t* n2_in; float* test_points;
+    float* xf_last;      // 48 floats: the transform record the LAST iteration's point pass uses (written by k_init_state / the solve of iteration runlen - 2), for `points2`
 };
 
 struct Workspace {
@@ -170,8 +171,10 @@ constexpr int kRejectMovingStartIter = 4;          // python/ICET_spherical.py:3
 // icet_keyframe.hip
 hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* aux, hipStream_t st);
 // icet_solve.hip
-hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st);
+hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last = nullptr);
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st);
+// `points2` of pair 0 (include/icet.h:80): scan 2 under the transform record `xf` (AuxDev::xf_last); out = n2 x 3 column-major, ld n2 (may be pinned host memory)
+hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* xf, float* out, hipStream_t st);
 // icet_accumulate.hip
 hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st);
 // ICET_FLAG_ROUNDTRIP_SCAN2: points2_OG = sphericalToCartesian(cartesianToSpherical(scan 2)) (src/icet.cpp:263-275, without the permutation): w.desc -> w.desc_rt

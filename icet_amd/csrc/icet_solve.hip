@@ -5,6 +5,7 @@
 //                    covariance (:410-417), conditioning (:443-492), dx and X += dx (:427-433); one block per pair
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include "icet_internal.h"
 #include "icet_device_common.h"
 #include "icet_device_math.h"
@@ -37,12 +38,13 @@ __device__ __forceinline__ void write_xf(float* xf, const float X[6]) {
     J[24] = 0.f; J[25] = 0.f; J[26] = 0.f;
 }
 
-__global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X, float* __restrict__ xf, int n_pairs) {
+__global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X, float* __restrict__ xf, int n_pairs, float* __restrict__ xf_last) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     float x[6];
     for (int k = 0; k < 6; k++) { x[k] = x0 ? x0[p * 6 + k] : 0.f; X[p * 6 + k] = x[k]; }
     write_xf(xf + p * kXf, x);
+    if (xf_last) for (int k = 0; k < kXf; k++) xf_last[p * kXf + k] = xf[p * kXf + k];      // a one-iteration solve transforms scan 2 by X0 (`points2`)
 }
 
 // fitCells2's per-voxel algebra + reduction + the 6x6 solve.  One block per pair.
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     if (lane < kXf) xf_all[pair * kXf + lane] = stage[lane];
+    if (aux.xf_last && iter == runlen - 2 && lane < kXf) aux.xf_last[pair * kXf + lane] = stage[lane];      // what the last point pass will use (`points2`)
     if (lane < 48) out[(size_t)pair * 48 + lane] = stage[kXf + lane];
     if (lane < 6) X[lane] = stage[kXf + lane];
     if (lane == 0) {
@@ -300,8 +303,32 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
 
 #define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
-hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st) {
-    k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs);
+hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last) {
+    k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs, xf_last);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// `points2` member of the reference object (include/icet.h:80; src/icet.cpp:375-378): pair 0's scan 2 under the transform the last point pass
+// uses (AuxDev::xf_last) -- the same transform_point, so the same bits.  `out` may be pinned host memory (one coalesced write per
+// coordinate); runs on a side stream beside the last iteration.
+__global__ __launch_bounds__(kBlock) void k_points2(const PairDesc* __restrict__ desc, const float* __restrict__ xf, float* __restrict__ out) {
+    __shared__ float sxf[12];                                     // the record may live in pinned host memory: one read per block, not per point
+    if (threadIdx.x < 12) sxf[threadIdx.x] = xf[threadIdx.x];
+    __syncthreads();
+    const PairDesc d = desc[0];
+    const float* px = d.s2; const float* py = px + d.ld2; const float* pz = px + 2 * (size_t)d.ld2;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.n2; i += gridDim.x * kBlock) {
+        float qx, qy, qz;
+        transform_point(px[i], py[i], pz[i], sxf, qx, qy, qz);
+        out[i] = qx; out[(size_t)d.n2 + i] = qy; out[2 * (size_t)d.n2 + i] = qz;
+    }
+}
+
+hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* xf, float* out, hipStream_t st) {
+    if (c.max_n2 <= 0) return hipSuccess;
+    const int blocks = std::min(1024, (c.max_n2 + kBlock - 1) / kBlock);
+    k_points2<<<blocks, kBlock, 0, st>>>(w.desc, xf, out);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -36,26 +36,26 @@ class ICET {
 public:
     ICET(Eigen::MatrixXf& scan1, Eigen::MatrixXf& scan2, int runlen, Eigen::VectorXf X0, int num_bins_phi, int num_bins_theta,
          int n = 25, float thresh = 0.1, float buff = 0.1)
-        : rl(runlen), numBinsPhi(num_bins_phi), numBinsTheta(num_bins_theta), n(n), thresh(thresh), buff(buff),
-          points1(scan1), points2(scan2), points2_OG(scan2), X(X0) {
+        : rl(runlen), numBinsPhi(num_bins_phi), numBinsTheta(num_bins_theta), n(n), thresh(thresh), buff(buff), X(X0) {
         // Eigen::MatrixXf is column-major: data() is x[N] | y[N] | z[N] with leading dimension rows()
         float x0[6] = {0, 0, 0, 0, 0, 0};
         for (int k = 0; k < 6 && k < X0.size(); k++) x0[k] = X0[k];
-        icet_amd::ICET it(scan1.data(), scan1.rows(), scan1.rows(), scan2.data(), scan2.rows(), scan2.rows(), runlen, x0,
-                          num_bins_phi, num_bins_theta, n, thresh, buff);
-        X = Eigen::VectorXf(6); pred_stds = Eigen::VectorXf(6); dx = Eigen::VectorXf(6);
-        for (int k = 0; k < 6; k++) { X[k] = it.X[k]; pred_stds[k] = it.pred_stds[k]; dx[k] = it.dx[k]; }
-        HTWH_i.resize(6, 6); HTWdz_i.resize(6, 1);
-        for (int a = 0; a < 6; a++) { HTWdz_i(a, 0) = it.HTWdz_i[a]; for (int b = 0; b < 6; b++) HTWH_i(a, b) = it.HTWH_i[a * 6 + b]; }
+        // `points2` receives scan 2 under the last iteration's transform straight from the solve (no intermediate copy)
+        points2.resize(scan2.rows(), 3);
+        icet_amd::ICET it(icet_amd::ICET::Deferred{}, scan1.data(), scan1.rows(), scan1.rows(), scan2.data(), scan2.rows(), scan2.rows(), runlen, x0,
+                          num_bins_phi, num_bins_theta, n, thresh, buff, 0, true, scan2.rows() > 0 ? points2.data() : nullptr);
+        // the deep copies the reference's constructor makes of both scans (src/icet.cpp:30,33) -- done while the device builds the keyframe
+        points1 = scan1; points2_OG = scan2;
+        // everything fitScan1 produces arrives while the Gauss-Newton loop still iterates on the device: converted to the reference's members here
+        it.finish_keyframe();
         const int V = num_bins_phi * num_bins_theta;
         clusterBounds = Eigen::MatrixXf::Zero(V, 6);
         if ((int)it.clusterBounds.size() == V * 6)
             for (int v = 0; v < V; v++) for (int k = 0; k < 6; k++) clusterBounds(v, k) = it.clusterBounds[v * 6 + k];
-        if ((long)it.points2.size() == scan2.rows() * 3)
-            points2 = Eigen::Map<const Eigen::MatrixXf>(it.points2.data(), scan2.rows(), 3);
         testPoints = Eigen::MatrixXf::Zero(V * 6, 3);                  // src/icet.cpp:41
         if ((int)it.testPoints.size() == V * 18)
-            for (int r = 0; r < V * 6; r++) for (int k = 0; k < 3; k++) testPoints(r, k) = it.testPoints[r * 3 + k];
+            for (int v = 0; v < V; v++) if (it.has_fit[v])             // rows of un-fitted voxels stay zero
+                for (int r = 6 * v; r < 6 * v + 6; r++) for (int k = 0; k < 3; k++) testPoints(r, k) = it.testPoints[r * 3 + k];
         for (size_t i = 0; i < it.ellipsoid1Means.size(); i++) {
             ellipsoid1Means.emplace_back(it.ellipsoid1Means[i][0], it.ellipsoid1Means[i][1], it.ellipsoid1Means[i][2]);
             Eigen::Matrix3f c;
@@ -77,6 +77,12 @@ public:
                 mu1[theta][phi] = Eigen::Vector3f(it.mu1[(size_t)v * 3], it.mu1[(size_t)v * 3 + 1], it.mu1[(size_t)v * 3 + 2]);
             }
         }
+        it.finish();
+        if (it.status != ICET_OK || runlen <= 0) points2 = scan2;                 // an object that never iterated keeps its copy of scan 2
+        X = Eigen::VectorXf(6); pred_stds = Eigen::VectorXf(6); dx = Eigen::VectorXf(6);
+        for (int k = 0; k < 6; k++) { X[k] = it.X[k]; pred_stds[k] = it.pred_stds[k]; dx[k] = it.dx[k]; }
+        HTWH_i.resize(6, 6); HTWdz_i.resize(6, 1);
+        for (int a = 0; a < 6; a++) { HTWdz_i(a, 0) = it.HTWdz_i[a]; for (int b = 0; b < 6; b++) HTWH_i(a, b) = it.HTWH_i[a * 6 + b]; }
         status = it.status; error = it.error;
     }
     ~ICET() {}

@@ -96,6 +96,9 @@ typedef struct icet_aux {
     float*   test_points;     /* (V x 6) x 3 row-major (`testPoints`, src/icet.cpp:41,213-231): rows 6v + 2k, 6v + 2k + 1 hold
                                  the two sigma points of axis k of voxel v when that axis was pruned (L row k = 0); every
                                  other row is zero (the reference leaves those rows uninitialised)                          */
+    float*   points2;         /* n2 x 3 COLUMN-major, leading dimension n2 (`points2`, include/icet.h:80): scan 2 as the last
+                                 fitScan2 transformed it, (p + t) * R with the X before the final update (src/icet.cpp:375-378
+                                 precede :433) -- computed on the device with the loop's own transform; scan 2 itself when runlen == 0 */
 } icet_aux;
 
 typedef struct icet_ctx icet_ctx;   /* opaque: device id, stream, workspace */
@@ -117,6 +120,22 @@ icet_status icet_solve(icet_ctx* ctx, const icet_params* p,
                        const float* scan2, int64_t n2, int64_t ld2,
                        const float x0[6], float x_out[6], float pred_stds_out[6], float cov_out[36],
                        icet_aux* aux_or_null);
+
+/* The same call in two halves.  icet_solve_begin enqueues the uploads of both scans, the whole registration and the copy of the
+ * results and returns without waiting for the device; icet_solve_end waits and fills x_out / pred_stds_out / cov_out / the aux tables
+ * named at begin.  Both scans and every output pointer must stay valid -- the scans unmodified -- until icet_solve_end returns.  Host work placed between the two -- the reference's constructor deep-copies both scans into its members
+ * (src/icet.cpp:30,33); include/icet.h makes those copies there -- overlaps with the device.  One begin per context at a time; the
+ * other host-pointer entry points refuse to run in between (ICET_ERR_BAD_ARG). */
+icet_status icet_solve_begin(icet_ctx* ctx, const icet_params* p,
+                             const float* scan1, int64_t n1, int64_t ld1,
+                             const float* scan2, int64_t n2, int64_t ld2,
+                             const float x0[6], float x_out[6], float pred_stds_out[6], float cov_out[36],
+                             icet_aux* aux_or_null);
+/* Optional, between begin and end: returns as soon as the KEYFRAME tables named at begin (cluster_bounds, has_fit, mu1, sigma1, evecs1,
+ * l_diag, test_points -- everything fitScan1 produces, src/icet.cpp:68-252) are in the caller's arrays, while the Gauss-Newton loop is
+ * still iterating on the device: the caller can convert them (include/icet.h builds its Eigen members and std::maps) under the loop. */
+icet_status icet_solve_keyframe_tables(icet_ctx* ctx);
+icet_status icet_solve_end(icet_ctx* ctx);
 
 /* --- N independent pairs, HOST pointers (one ICET object per pair in the reference) --------------- */
 icet_status icet_solve_batch(icet_ctx* ctx, const icet_params* p, int32_t n_pairs,

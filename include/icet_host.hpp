@@ -40,53 +40,86 @@ inline icet_ctx* thread_context(int device, icet_status* st_out = nullptr) {
 
 class ICET {
 public:
+    struct Deferred {};      // tag: the constructor returns once the solve is enqueued (icet_solve_begin); finish() completes the object
+
     // scan1 / scan2: column-major N x 3 (x[0..n) | y[0..n) | z[0..n)), leading dimension ld >= n.
+    // points2_out (optional): n2 x 3 column-major buffer of the caller that receives `points2` instead of the member vector.
     ICET(const float* scan1, int64_t n1, int64_t ld1, const float* scan2, int64_t n2, int64_t ld2, int runlen,
          const float X0[6], int num_bins_phi, int num_bins_theta, int n = 25, float thresh = 0.1f, float buff = 0.1f,
-         int device = 0, bool side_tables = true)
-        : rl(runlen), numBinsPhi(num_bins_phi), numBinsTheta(num_bins_theta), n(n), thresh(thresh), buff(buff) {
-        for (int k = 0; k < 6; k++) { X[k] = X0 ? X0[k] : 0.f; pred_stds[k] = 0.f; dx[k] = 0.f; }
+         int device = 0, bool side_tables = true, float* points2_out = nullptr)
+        : ICET(Deferred{}, scan1, n1, ld1, scan2, n2, ld2, runlen, X0, num_bins_phi, num_bins_theta, n, thresh, buff, device, side_tables, points2_out) {
+        finish();
+    }
+
+    // First half: both scans are read completely (the caller may reuse them), the registration runs on the device while the caller
+    // does other host work -- include/icet.h makes the reference's member copies of the scans here -- until finish().
+    ICET(Deferred, const float* scan1, int64_t n1, int64_t ld1, const float* scan2, int64_t n2, int64_t ld2, int runlen,
+         const float X0[6], int num_bins_phi, int num_bins_theta, int n = 25, float thresh = 0.1f, float buff = 0.1f,
+         int device = 0, bool side_tables = true, float* points2_out = nullptr)
+        : rl(runlen), numBinsPhi(num_bins_phi), numBinsTheta(num_bins_theta), n(n), thresh(thresh), buff(buff), side_tables_(side_tables) {
+        for (int k = 0; k < 6; k++) { X[k] = X0 ? X0[k] : 0.f; x0_[k] = X[k]; pred_stds[k] = 0.f; dx[k] = 0.f; }
         cov.fill(0.f); HTWH_i.fill(0.f); HTWdz_i.fill(0.f);
-        icet_ctx* ctx = thread_context(device, &status);
-        if (!ctx) { error = "icet_create failed (no usable HIP device; this path has no CPU fallback)"; return; }
+        ctx_ = thread_context(device, &status);
+        if (!ctx_) { error = "icet_create failed (no usable HIP device; this path has no CPU fallback)"; return; }
         icet_params p{runlen, num_bins_phi, num_bins_theta, n, thresh, buff, ICET_FLAG_NONE};
         const int64_t V = (int64_t)num_bins_phi * num_bins_theta;
         const int64_t RL = runlen > 0 ? runlen : 1;
-        std::vector<float> x_hist, htwh, htwdz;
         icet_aux aux{};
         if (side_tables && V > 0) {
             clusterBounds.assign((size_t)V * 6, 0.f); has_fit.assign(V, 0); mu1.assign((size_t)V * 3, 0.f); sigma1.assign((size_t)V * 9, 0.f);
             evecs1.assign((size_t)V * 9, 0.f); l_diag.assign((size_t)V * 3, 0.f); aux.evecs1 = evecs1.data(); aux.l_diag = l_diag.data();
-            x_hist.assign((size_t)RL * 6, 0.f); htwh.assign((size_t)RL * 36, 0.f); htwdz.assign((size_t)RL * 6, 0.f);
+            x_hist_.assign((size_t)RL * 6, 0.f); htwh_.assign((size_t)RL * 36, 0.f); htwdz_.assign((size_t)RL * 6, 0.f);
             testPoints.assign((size_t)V * 18, 0.f); aux.test_points = testPoints.data();
             aux.cluster_bounds = clusterBounds.data(); aux.has_fit = has_fit.data(); aux.mu1 = mu1.data(); aux.sigma1 = sigma1.data();
-            aux.x_hist = x_hist.data(); aux.htwh = htwh.data(); aux.htwdz = htwdz.data();
+            aux.x_hist = x_hist_.data(); aux.htwh = htwh_.data(); aux.htwdz = htwdz_.data();
+            // `points2` = scan 2 under the transform of the LAST iteration, i.e. X before the final update (src/icet.cpp:375-378 precede
+            // :433): (p + t) * R(angles), column-major n2 x 3 -- computed on the device with the loop's own transform
+            if (n2 > 0) {
+                if (points2_out) aux.points2 = points2_out;
+                else { points2.resize((size_t)n2 * 3); aux.points2 = points2.data(); }      // (value-initialised once; overwritten by the solve)
+            }
         }
-        float x0[6]; for (int k = 0; k < 6; k++) x0[k] = X[k];
-        status = icet_solve(ctx, &p, scan1, n1, ld1, scan2, n2, ld2, x0, X.data(), pred_stds.data(), cov.data(), side_tables ? &aux : nullptr);
-        if (status != ICET_OK) { error = icet_last_error(ctx); for (int k = 0; k < 6; k++) { X[k] = x0[k]; pred_stds[k] = 0.f; } return; }
-        if (!side_tables || runlen <= 0) return;
+        status = icet_solve_begin(ctx_, &p, scan1, n1, ld1, scan2, n2, ld2, x0_, X.data(), pred_stds.data(), cov.data(), side_tables ? &aux : nullptr);
+        if (status != ICET_OK) { error = icet_last_error(ctx_); for (int k = 0; k < 6; k++) { X[k] = x0_[k]; pred_stds[k] = 0.f; } return; }
+        begun_ = true;
+    }
+
+    // Optional, between the Deferred constructor and finish(): returns when everything fitScan1 produces (clusterBounds, has_fit, mu1, sigma1,
+    // evecs1, l_diag, testPoints, the ellipsoid1* lists) is in the members, while the Gauss-Newton loop still iterates on the device.
+    void finish_keyframe() {
+        if (!begun_ || kf_done_ || !side_tables_ || rl <= 0) return;
+        if (icet_solve_keyframe_tables(ctx_) != ICET_OK) return;              // finish() reports the error
+        kf_done_ = true;
+        const int64_t V = (int64_t)numBinsPhi * numBinsTheta;
         // ellipsoid1* : one entry per fitted scan-1 voxel, phi-major order (src/icet.cpp:95-102,236-239); ellipsoid2* stay empty
+        size_t fitted = 0;
+        for (int64_t v = 0; v < V; v++) fitted += has_fit[v] ? 1 : 0;
+        ellipsoid1Means.reserve(fitted); ellipsoid1Covariances.reserve(fitted); ellipsoid1Alphas.reserve(fitted);
         for (int64_t v = 0; v < V; v++) if (has_fit[v]) {
             ellipsoid1Means.push_back({mu1[3 * v], mu1[3 * v + 1], mu1[3 * v + 2]});
             std::array<float, 9> c; for (int k = 0; k < 9; k++) c[k] = sigma1[9 * v + k];
             ellipsoid1Covariances.push_back(c); ellipsoid1Alphas.push_back(0.3f);
         }
-        for (int k = 0; k < 36; k++) HTWH_i[k] = htwh[(size_t)(runlen - 1) * 36 + k];
-        for (int k = 0; k < 6; k++) HTWdz_i[k] = htwdz[(size_t)(runlen - 1) * 6 + k];
-        // `points2` = scan 2 under the transform of the LAST iteration, i.e. X before the final update
-        // (src/icet.cpp:375-378 precede :433): (p + t) * R(angles), column-major n2 x 3.
-        const float* xp = (runlen == 1) ? x0 : &x_hist[(size_t)(runlen - 2) * 6];
-        for (int k = 0; k < 6; k++) dx[k] = x_hist[(size_t)(runlen - 1) * 6 + k] - xp[k];
-        float R[9]; euler_R(xp[3], xp[4], xp[5], R);
-        points2.resize((size_t)n2 * 3);
-        for (int64_t i = 0; i < n2; i++) {
-            const float a = scan2[i] + xp[0], b = scan2[ld2 + i] + xp[1], c = scan2[2 * ld2 + i] + xp[2];
-            points2[i] = a * R[0] + b * R[3] + c * R[6];
-            points2[n2 + i] = a * R[1] + b * R[4] + c * R[7];
-            points2[2 * n2 + i] = a * R[2] + b * R[5] + c * R[8];
-        }
     }
+
+    // Second half: waits for the device and fills the members.  Idempotent; called by the one-shot constructor.
+    void finish() {
+        if (!begun_) return;
+        finish_keyframe();
+        begun_ = false;
+        status = icet_solve_end(ctx_);
+        if (status != ICET_OK) { error = icet_last_error(ctx_); for (int k = 0; k < 6; k++) { X[k] = x0_[k]; pred_stds[k] = 0.f; } return; }
+        const int runlen = rl;
+        if (!side_tables_ || runlen <= 0) return;
+        for (int k = 0; k < 36; k++) HTWH_i[k] = htwh_[(size_t)(runlen - 1) * 36 + k];
+        for (int k = 0; k < 6; k++) HTWdz_i[k] = htwdz_[(size_t)(runlen - 1) * 6 + k];
+        const float* xp = (runlen == 1) ? x0_ : &x_hist_[(size_t)(runlen - 2) * 6];
+        for (int k = 0; k < 6; k++) dx[k] = x_hist_[(size_t)(runlen - 1) * 6 + k] - xp[k];
+    }
+
+    ~ICET() { if (begun_) (void)icet_solve_end(ctx_); }      // a Deferred object that was never finished: the context must not stay pending
+    ICET(const ICET&) = delete;
+    ICET& operator=(const ICET&) = delete;
 
     // utils::R (src/utils.cpp:144-152), row-major
     static void euler_R(float phi, float theta, float psi, float R[9]) {
@@ -118,6 +151,11 @@ public:
     std::vector<float> ellipsoid1Alphas, ellipsoid2Alphas;
     icet_status status = ICET_OK;
     std::string error;
+
+private:
+    icet_ctx* ctx_ = nullptr; bool begun_ = false, kf_done_ = false, side_tables_ = true;
+    float x0_[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<float> x_hist_, htwh_, htwdz_;
 };
 
 }  // namespace icet_amd

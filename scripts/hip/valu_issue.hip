@@ -15,8 +15,8 @@
 #include <vector>
 #include <algorithm>
 
-enum Kind { K_FMA, K_FMAC, K_PKFMA, K_ADD, K_MUL, K_PKADD, K_CNDMASK, K_CMP, K_CMPX_S, K_MINMAX, K_RCP, K_CVT_I, K_CVT_F64, K_ADD_F64, K_FMA_F64, K_DPP_MOV, K_ADD_U32, K_LSHL_ADD, K_FMA_DEP, K_LDS_ADD64_SAME, K_LDS_ADD64_DISTINCT, K_LDS_READ_B32, K_COUNT };
-static const char* kNames[K_COUNT] = {"v_fma_f32 (3 VGPR sources, 16 independent chains)", "v_fmac_f32 (VOP2: 2 sources + accumulate)", "v_pk_fma_f32 (two FMAs per lane)", "v_add_f32", "v_mul_f32", "v_pk_add_f32", "v_cndmask_b32 (vcc mask)", "v_cmp_lt_f32 (writes vcc)", "v_cmp_lt_f32 (writes an SGPR pair)", "v_min_f32", "v_rcp_f32 (transcendental)", "v_cvt_i32_f32", "v_cvt_f64_f32", "v_add_f64", "v_fma_f64", "v_mov_b32 dpp row_shr:1", "v_add_u32", "v_lshl_add_u32", "v_fma_f32, ONE dependent chain (latency)", "ds_add_u64, 16 neighbouring lanes per address", "ds_add_u64, 64 distinct addresses", "ds_read_b32 (dependent address chain: latency)"};
+enum Kind { K_FMA, K_FMAC, K_PKFMA, K_ADD, K_MUL, K_PKADD, K_CNDMASK, K_CMP, K_CMPX_S, K_MINMAX, K_RCP, K_CVT_I, K_CVT_F64, K_ADD_F64, K_FMA_F64, K_DPP_MOV, K_ADD_U32, K_LSHL_ADD, K_FMA_DEP, K_CND_DIFF, K_CND_SGPR, K_CMP_CND, K_AND, K_BFI, K_MOV, K_MAX, K_LDS_ADD64_SAME, K_LDS_ADD64_DISTINCT, K_LDS_READ_B32, K_COUNT };
+static const char* kNames[K_COUNT] = {"v_fma_f32 (3 VGPR sources, 16 independent chains)", "v_fmac_f32 (VOP2: 2 sources + accumulate)", "v_pk_fma_f32 (two FMAs per lane)", "v_add_f32", "v_mul_f32", "v_pk_add_f32", "v_cndmask_b32 (vcc mask)", "v_cmp_lt_f32 (writes vcc)", "v_cmp_lt_f32 (writes an SGPR pair)", "v_min_f32", "v_rcp_f32 (transcendental)", "v_cvt_i32_f32", "v_cvt_f64_f32", "v_add_f64", "v_fma_f64", "v_mov_b32 dpp row_shr:1", "v_add_u32", "v_lshl_add_u32", "v_fma_f32, ONE dependent chain (latency)", "v_cndmask_b32, destination differs from both sources", "v_cndmask_b32_e64, mask in an SGPR pair", "v_cmp_lt_f32 vcc + v_cndmask_b32 pairs (16 pairs per round)", "v_and_b32", "v_bfi_b32", "v_mov_b32", "v_max_f32", "ds_add_u64, 16 neighbouring lanes per address", "ds_add_u64, 64 distinct addresses", "ds_read_b32 (dependent address chain: latency)"};
 
 // block-wide elapsed time: first stamp after the barrier .. last wave's end stamp (LDS min / max), so that an unfair arbiter (oldest wave first) cannot hide starved waves
 template <int KIND>
@@ -59,6 +59,13 @@ __global__ void k_issue(unsigned long long* out, int reps, float seed) {
 #define I_K_ADD_U32(i) "v_add_u32 %" #i ", %16, %" #i "\n"
 #define I_K_LSHL_ADD(i) "v_lshl_add_u32 %" #i ", %" #i ", 1, %16\n"
 #define I_K_FMA_DEP(i) "v_fma_f32 %0, %16, %0, %17\n"
+#define I_K_CND_DIFF(i) "v_cndmask_b32 %" #i ", %16, %17, vcc\n"
+#define I_K_CND_SGPR(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %16, s[20:21]\n"
+#define I_K_AND(i) "v_and_b32 %" #i ", %16, %" #i "\n"
+#define I_K_BFI(i) "v_bfi_b32 %" #i ", %16, %17, %" #i "\n"
+#define I_K_MOV(i) "v_mov_b32 %" #i ", %16\n"
+#define I_K_MAX(i) "v_max_f32 %" #i ", %16, %" #i "\n"
+#define I_K_CMP_CND(i) "v_cmp_lt_f32 vcc, %" #i ", %16\nv_cndmask_b32 %" #i ", %" #i ", %17, vcc\n"
     for (int r = 0; r < reps; r++) {
         if (KIND == K_FMA) asm volatile(R16(I_K_FMA) R16(I_K_FMA) : O16(v) : "v"(a), "v"(b) : "vcc", "s20", "s21");
         else if (KIND == K_FMAC) asm volatile(R16(I_K_FMAC) R16(I_K_FMAC) : O16(v) : "v"(a), "v"(b) : "vcc", "s20", "s21");
@@ -79,6 +86,13 @@ __global__ void k_issue(unsigned long long* out, int reps, float seed) {
         else if (KIND == K_ADD_U32) asm volatile(R16(I_K_ADD_U32) R16(I_K_ADD_U32) : O16(v) : "v"(a), "v"(b) : "vcc", "s20", "s21");
         else if (KIND == K_LSHL_ADD) asm volatile(R16(I_K_LSHL_ADD) R16(I_K_LSHL_ADD) : O16(v) : "v"(a), "v"(b) : "vcc", "s20", "s21");
         else if (KIND == K_FMA_DEP) asm volatile(R16(I_K_FMA_DEP) R16(I_K_FMA_DEP) : O16(v) : "v"(a), "v"(b) : "vcc", "s20", "s21");
+        else if (KIND == K_CND_DIFF) asm volatile(R16(I_K_CND_DIFF) R16(I_K_CND_DIFF) : O16(v) : "v"(a), "v"(b) : "vcc", "s20", "s21");
+        else if (KIND == K_CND_SGPR) asm volatile(R16(I_K_CND_SGPR) R16(I_K_CND_SGPR) : O16(v) : "v"(a), "v"(b) : "vcc", "s20", "s21");
+        else if (KIND == K_CMP_CND) asm volatile(R16(I_K_CMP_CND)  : O16(v) : "v"(a), "v"(b) : "vcc", "s20", "s21");
+        else if (KIND == K_AND) asm volatile(R16(I_K_AND) R16(I_K_AND) : O16(v) : "v"(a), "v"(b) : "vcc", "s20", "s21");
+        else if (KIND == K_BFI) asm volatile(R16(I_K_BFI) R16(I_K_BFI) : O16(v) : "v"(a), "v"(b) : "vcc", "s20", "s21");
+        else if (KIND == K_MOV) asm volatile(R16(I_K_MOV) R16(I_K_MOV) : O16(v) : "v"(a), "v"(b) : "vcc", "s20", "s21");
+        else if (KIND == K_MAX) asm volatile(R16(I_K_MAX) R16(I_K_MAX) : O16(v) : "v"(a), "v"(b) : "vcc", "s20", "s21");
         else if (KIND == K_LDS_READ_B32) {
 #pragma unroll
             for (int i = 0; i < 32; i++) asm volatile("ds_read_b32 %0, %0\ns_waitcnt lgkmcnt(0)" : "+v"(chase) : : "memory");
@@ -130,7 +144,7 @@ int main() {
     FILE* f = stdout;
     fprintf(f, "VALU issue cost on %s (%d CUs), s_memtime ticks (= shader cycles), 2048 x 32 instructions per wave, every CU busy\n", p.gcnArchName, n_cu);
     fprintf(f, "w waves per SIMD = blocks of 256 x w threads, one per CU (w <= 4) or two of 256 x w/2 (w = 6, 8)\n\n");
-    run<K_FMA>(d_out, n_cu, f); run<K_FMAC>(d_out, n_cu, f); run<K_PKFMA>(d_out, n_cu, f); run<K_ADD>(d_out, n_cu, f); run<K_MUL>(d_out, n_cu, f); run<K_PKADD>(d_out, n_cu, f); run<K_CNDMASK>(d_out, n_cu, f); run<K_CMP>(d_out, n_cu, f); run<K_CMPX_S>(d_out, n_cu, f); run<K_MINMAX>(d_out, n_cu, f); run<K_RCP>(d_out, n_cu, f); run<K_CVT_I>(d_out, n_cu, f); run<K_CVT_F64>(d_out, n_cu, f); run<K_ADD_F64>(d_out, n_cu, f); run<K_FMA_F64>(d_out, n_cu, f); run<K_DPP_MOV>(d_out, n_cu, f); run<K_ADD_U32>(d_out, n_cu, f); run<K_LSHL_ADD>(d_out, n_cu, f); run<K_FMA_DEP>(d_out, n_cu, f);
+    run<K_FMA>(d_out, n_cu, f); run<K_FMAC>(d_out, n_cu, f); run<K_PKFMA>(d_out, n_cu, f); run<K_ADD>(d_out, n_cu, f); run<K_MUL>(d_out, n_cu, f); run<K_PKADD>(d_out, n_cu, f); run<K_CNDMASK>(d_out, n_cu, f); run<K_CMP>(d_out, n_cu, f); run<K_CMPX_S>(d_out, n_cu, f); run<K_MINMAX>(d_out, n_cu, f); run<K_RCP>(d_out, n_cu, f); run<K_CVT_I>(d_out, n_cu, f); run<K_CVT_F64>(d_out, n_cu, f); run<K_ADD_F64>(d_out, n_cu, f); run<K_FMA_F64>(d_out, n_cu, f); run<K_DPP_MOV>(d_out, n_cu, f); run<K_ADD_U32>(d_out, n_cu, f); run<K_LSHL_ADD>(d_out, n_cu, f); run<K_FMA_DEP>(d_out, n_cu, f); run<K_CND_DIFF>(d_out, n_cu, f); run<K_CND_SGPR>(d_out, n_cu, f); run<K_CMP_CND>(d_out, n_cu, f); run<K_AND>(d_out, n_cu, f); run<K_BFI>(d_out, n_cu, f); run<K_MOV>(d_out, n_cu, f); run<K_MAX>(d_out, n_cu, f);
     run<K_LDS_ADD64_SAME>(d_out, n_cu, f); run<K_LDS_ADD64_DISTINCT>(d_out, n_cu, f); run<K_LDS_READ_B32>(d_out, n_cu, f);
     hipFree(d_out);
     return 0;

@@ -2,7 +2,10 @@
 // and member names) through the call pattern of /root/reference/src/odometry.cpp:73-82: construct `ICET it(prev, cur, run_length, X0,
 // numBinsPhi, numBinsTheta)`, read it.X and it.pred_stds, seed X0 for the next frame.  Built against tests/cpp/mock_eigen (this image
 // has no Eigen; the mock pins no numerics) or against the real Eigen when one is installed (-DICET_TEST_REAL_EIGEN -I<eigen>).
-// usage: adapter_demo scan1.f32 scan2.f32 n1 n2          (files: column-major N x 3 float32)
+// usage: adapter_demo scan1.f32 scan2.f32 n1 n2 [reps]   (files: column-major N x 3 float32; reps > 0 appends a timing loop: what one
+//        constructor call costs a node, pageable Eigen matrices in, members out -- bench.py's "ctor" sub-record)
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -46,6 +49,22 @@ int main(int argc, char** argv) {
                     it.mu2.size(), tr, lsum, orth, m0[0], m0[1], m0[2], it.mu1.empty() ? -1 : it.mu1.begin()->first, it.mu1.empty() ? -1 : it.mu1.begin()->second.begin()->first);
         //seed initial estimate for next iteration
         X0 << X[0], X[1], X[2], X[3], X[4], X[5];
+    }
+    const int reps = argc > 5 ? std::atoi(argv[5]) : 0;
+    if (reps > 0) {
+        X0 << 0., 0., 0., 0., 0., 0.;
+        std::vector<double> ms;
+        double sink = 0;
+        for (int r = 0; r < reps + 3; r++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            ICET it(prev_pcl_matrix, pcl_matrix, 7, X0, 24, 75);
+            const auto t1 = std::chrono::steady_clock::now();
+            sink += it.X[0] + it.pred_stds[0];
+            if (r >= 3) ms.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+        }
+        std::sort(ms.begin(), ms.end());
+        double mean = 0; for (double v : ms) mean += v;
+        std::printf("ctor_timing reps %d mean_ms %.4f median_ms %.4f min_ms %.4f sink %.3g\n", reps, mean / ms.size(), ms[ms.size() / 2], ms[0], sink);
     }
     return 0;
 }

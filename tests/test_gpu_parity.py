@@ -28,7 +28,34 @@ import torch
 pytestmark = pytest.mark.gpu
 
 TOL_T, TOL_R = 2e-4, 2e-5              # 2 x (8.1e-5 m, 9.7e-6 rad): measured maxima over the 256-pair batch without its one sensitivity-explained pair
-RTOL_STD, RTOL_COV = 2.5e-2, 5e-2       # 2 x (1.2 %, 2.5 %)
+RTOL_STD_LOOSE, RTOL_COV_LOOSE = 2.5e-2, 5e-2   # NAMED exception only: bench pair 39 (1.2 % / 2.5 %: the last bit of a single-ring voxel's mean)
+RTOL_STD, RTOL_COV = 2e-3, 4e-3         # everything else: 2 x the largest value measured over EVERY _check_solution call of this file outside pair 39
+                                        # (0.10 % / 0.20 %; gpurun_out/parity_margins.txt of round 4) -- the blanket 2.5 % / 5 % of round 3 is gone (review r3, weak 1e)
+RTOL_STD_P99, RTOL_COV_P99 = 1.5e-3, 3e-3      # the 256 bench pairs: 2 x their p99 (0.07 % / 0.14 %, profiles/r03_parity_batch.txt)
+
+_MARGINS = []                           # (test, |dX_t|, |dX_r|, rel pred_stds, rel cov) of every _check_solution call: written to gpurun_out/parity_margins.txt at exit
+
+
+def _record(tag, res, ref):
+    try:
+        d = np.sqrt(np.abs(np.diag(ref["cov"]))) + 1e-30
+        with np.errstate(all="ignore"):
+            rs = float(np.nanmax(np.abs(res["pred_stds"] / np.where(ref["pred_stds"] == 0, np.nan, ref["pred_stds"]) - 1))) if np.any(ref["pred_stds"] != 0) else 0.0
+        _MARGINS.append((tag, float(np.abs(res["X"][:3] - ref["X"][:3]).max()), float(np.abs(res["X"][3:] - ref["X"][3:]).max()), rs,
+                         float((np.abs(res["cov"] - ref["cov"]) / np.outer(d, d)).max())))
+    except Exception:
+        pass
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_margins():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if _MARGINS and os.path.isdir(out):
+        with open(os.path.join(out, "parity_margins.txt"), "w") as f:
+            f.write("# test  |dX_t| m  |dX_r| rad  rel pred_stds  rel cov (every _check_solution call of tests/test_gpu_parity.py; bounds: %g m %g rad %g %g)\n" % (TOL_T, TOL_R, RTOL_STD, RTOL_COV))
+            for m in _MARGINS:
+                f.write("%s %.3g %.3g %.3g %.3g\n" % m)
 
 
 def oracle_sensitivity(a, b, trials=3, scan1_too=False, **kw):
@@ -48,13 +75,15 @@ def oracle_sensitivity(a, b, trials=3, scan1_too=False, **kw):
     return dev
 
 
-def _check_solution(res, ref, tol_t=TOL_T, tol_r=TOL_R):
+def _check_solution(res, ref, tol_t=TOL_T, tol_r=TOL_R, rtol_std=RTOL_STD, rtol_cov=RTOL_COV):
+    import inspect
+    _record(inspect.stack()[1].function, res, ref)
     assert np.isfinite(res["X"]).all()
     assert np.abs(res["X"][:3] - ref["X"][:3]).max() <= tol_t, (res["X"], ref["X"])
     assert np.abs(res["X"][3:] - ref["X"][3:]).max() <= tol_r, (res["X"], ref["X"])
-    assert np.allclose(res["pred_stds"], ref["pred_stds"], rtol=RTOL_STD, atol=1e-7)
+    assert np.allclose(res["pred_stds"], ref["pred_stds"], rtol=rtol_std, atol=1e-7)
     d = np.sqrt(np.abs(np.diag(ref["cov"])))
-    assert (np.abs(res["cov"] - ref["cov"]) <= RTOL_COV * np.outer(d, d) + 1e-12).all()
+    assert (np.abs(res["cov"] - ref["cov"]) <= rtol_cov * np.outer(d, d) + 1e-12).all()
 
 
 @pytest.mark.parametrize("name", ["frame_804_805", "sample_pc_1_2"])
@@ -153,6 +182,58 @@ def test_highres_config5_full_size(gpu_ctx):
     assert np.array_equal(gpu_ctx.debug_fetch("src", n), po.scramble(po.c2s(a)[:, 0]))
     _check_solution(r, ref)
     assert np.abs(r["X"][:3] - xt[:3]).max() < 0.05
+
+
+def test_highres_config5_exactly_as_bench_times_it(gpu_ctx):
+    """BASELINE configs[4] EXACTLY as bench.py's `highres` sub-record generates it (review r3, next 1(i)): make_pair(9000, 9001,
+    DEFAULT_MOTION, 128, 4096) generated ON THE DEVICE (torch's device generator draws other noise than the CPU's), 150 x 48 voxels,
+    10 iterations, X0 = 0.  On this grid (2.4-degree voxels) the loop does not reach the true 0.5 m motion from X0 = 0 -- device and
+    oracle both settle at x = 0.133 m -- but they settle at the SAME point: measured 1.1e-5 m apart (scripts/diag_highres.py ->
+    profiles/r04_highres_parity.txt; DESIGN.md's 1.6e-3 m of round 3 was a CPU-generated pair whose loop ends in a limit cycle).
+    Asserted: the keyframe table and the sort + swap loop bit for bit; every iteration REPLAYED from the oracle's own state (one
+    Gauss-Newton step from the same X: no accumulated divergence) within the parity bound with at most a handful of voxels counting
+    differently; the free-running result within the parity bound AND within 2 x the oracle's own sensitivity to a 1-ulp perturbation
+    of scan 2 computed here (floored at 2e-5 m); pred_stds / cov within 2 x the batch p99."""
+    from icet_amd import lidar_sim as ls
+    from oracle import pyoracle as po
+    P, T, RL = 48, 150, 10
+    dev = torch.device("cuda", 0)
+    s1, s2, xt = ls.make_pair(9000, 9001, ls.DEFAULT_MOTION, 128, 4096, device=dev)
+    a, b = s1.T.cpu().numpy(), s2.T.cpu().numpy()
+    assert a.shape[0] > 450000
+    ref = po.solve(a, b, runlen=RL, bins_phi=P, bins_theta=T, trace=True)
+    g = gpu_ctx.solve(a, b, RL, np.zeros(6), P, T, aux=True)
+    t, ax = ref["trace"], g["aux"]
+    f = t["has_fit"] == 1
+    assert f.sum() > 500
+    assert np.array_equal(ax["n1_raw"], t["n1_raw"]) and np.array_equal(ax["cluster_bounds"], t["bounds"]) and np.array_equal(ax["has_fit"], t["has_fit"])
+    for name_g, name_o in (("mu1", "mu1"), ("sigma1", "sigma1"), ("evecs1", "evecs1"), ("l_diag", "Ldiag")):
+        assert np.array_equal(ax[name_g][f].view(np.uint32), t[name_o][f].view(np.uint32)), name_g
+    assert np.array_equal(gpu_ctx.debug_fetch("src", a.shape[0]), po.scramble(po.c2s(a)[:, 0]))
+    act = f & (t["n1_raw"] > 25) & (t["bounds"][:, 5] > 1)
+    first = None
+    for it in range(RL):
+        x0 = np.zeros(6, np.float32) if it == 0 else t["X"][it - 1]
+        rp = gpu_ctx.solve(a, b, 1, x0, P, T, aux=True)
+        d = np.abs(rp["X"] - t["X"][it])
+        flips = int((rp["aux"]["n2_raw"][0][act] != t["n2_raw"][it][act]).sum())
+        assert d[:3].max() <= TOL_T and d[3:].max() <= TOL_R and flips <= 8, (it, d, flips)
+        free = np.abs(ax["x_hist"][it] - t["X"][it])
+        nd = int((ax["n2_raw"][it][act] != t["n2_raw"][it][act]).sum() + (ax["n2_in"][it][act] != np.maximum(t["n2_in"][it][act], 0)).sum())
+        if first is None and nd:
+            first = it
+        print("iter %d: free-running |dX| %.2e m %.2e rad, %d voxel counts differ; replayed from the oracle's X: %.2e m %.2e rad, %d raw counts differ"
+              % (it, free[:3].max(), free[3:].max(), nd, d[:3].max(), d[3:].max(), flips))
+    print("first iteration with a differing decision: %s" % first)
+    rng = np.random.default_rng(123)
+    sens = np.zeros(6)
+    for _ in range(4):
+        bp = (b.astype(np.float64) * (1.0 + rng.uniform(-1e-7, 1e-7, b.shape))).astype(np.float32)
+        sens = np.maximum(sens, np.abs(po.solve(a, bp, runlen=RL, bins_phi=P, bins_theta=T)["X"] - ref["X"]))
+    dX = np.abs(g["X"] - ref["X"])
+    print("configs[4] as benchmarked: |dX_t| %.3g m, |dX_r| %.3g rad; oracle 1-ulp sensitivity %.3g m / %.3g rad" % (dX[:3].max(), dX[3:].max(), sens[:3].max(), sens[3:].max()))
+    _check_solution(g, ref, rtol_std=RTOL_STD_P99, rtol_cov=RTOL_COV_P99)
+    assert dX[:3].max() <= max(2 * sens[:3].max(), 2e-5) and dX[3:].max() <= max(2 * sens[3:].max(), 2e-6), (dX, sens)
 
 
 def test_million_row_scans(gpu_ctx):
@@ -502,6 +583,59 @@ def test_test_points_member(gpu_ctx, frames):
     assert not g["test_points"][~pruned].any()
 
 
+def test_constructor_path_from_pageable_host_memory(gpu_ctx, frames):
+    """The drop-in path (icet_solve: pageable host scans in, members out) since round 4: scan 2 uploaded on a copy stream beside the
+    keyframe build, results + side tables in ONE block and one D2H copy, `points2` from the device, and the call in two halves
+    (icet_solve_begin / icet_solve_end).  None of it may show in the bits: a padded leading dimension and the two-halves form give the
+    result of the plain call; `points2` is scan 2 under the transform of the last iteration (src/icet.cpp:375-378 with the X BEFORE the
+    final update); a second begin and the other host entry points are refused while a begin is pending."""
+    import ctypes as C
+    import icet_amd
+    from icet_amd import api
+    a, b = frames
+    base = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
+    xprev = base["aux"]["x_hist"][5].astype(np.float64)
+    exp = (b.astype(np.float64) + xprev[:3]) @ api.euler_R(*xprev[3:]).astype(np.float64)
+    assert base["aux"]["points2"].shape == b.shape and np.abs(base["aux"]["points2"] - exp).max() < 3e-5       # float products / FMAs against float64: a few ulp of ~100 m
+    r1 = gpu_ctx.solve(a, b, 1, np.zeros(6), 24, 75, aux=True)
+    assert np.array_equal(r1["aux"]["points2"], b)                                                                # one iteration: transformed by X0 = 0
+    L = api.load_library()
+    ctx = icet_amd.Context(0)
+    p = api.Params(7, 24, 75, 25, 0.1, 0.1, 0)
+    n1, n2 = a.shape[0], b.shape[0]
+    ld1, ld2 = n1 + 37, n2 + 5                                             # leading dimensions that are neither n nor multiples of 4
+    A = np.full((3, ld1), np.nan, np.float32); A[:, :n1] = a.T
+    B = np.full((3, ld2), np.nan, np.float32); B[:, :n2] = b.T
+    x0 = np.zeros(6, np.float32)
+
+    def call(fn, aux=None):
+        X = np.zeros(6, np.float32); ps = np.zeros(6, np.float32); cov = np.zeros(36, np.float32)
+        st = fn(ctx._h, C.byref(p), A.ctypes.data, n1, ld1, B.ctypes.data, n2, ld2, x0.ctypes.data, X.ctypes.data, ps.ctypes.data, cov.ctypes.data, aux)
+        return st, X, ps, cov
+
+    st, X, ps, cov = call(L.icet_solve)
+    assert st == 0 and np.array_equal(X, base["X"]) and np.array_equal(ps, base["pred_stds"]) and np.array_equal(cov.reshape(6, 6), base["cov"])
+    # two halves: outputs arrive at end (the scans stay untouched until then)
+    pts2 = np.zeros((3, n2), np.float32); bounds = np.zeros((24 * 75, 6), np.float32)
+    ax = api.Aux(); ax.points2 = pts2.ctypes.data_as(api._F); ax.cluster_bounds = bounds.ctypes.data_as(api._F)
+    st, X, ps, cov = call(L.icet_solve_begin, C.byref(ax))
+    assert st == 0
+    assert call(L.icet_solve_begin)[0] == api.ICET_ERR_BAD_ARG             # one begin at a time
+    assert call(L.icet_solve)[0] == api.ICET_ERR_BAD_ARG
+    with pytest.raises(icet_amd.IcetError):
+        ctx.solve_batch([a], [b], 7)
+    assert L.icet_solve_end(ctx._h) == 0
+    assert np.array_equal(X, base["X"]) and np.array_equal(ps, base["pred_stds"])
+    assert np.array_equal(pts2.T, base["aux"]["points2"]) and np.array_equal(bounds, base["aux"]["cluster_bounds"])
+    assert L.icet_solve_end(ctx._h) == api.ICET_ERR_BAD_ARG                # nothing pending any more
+    A[:] = 0; B[:] = 0                                                      # (the next call must not see the old uploads)
+    # the batch entry through the same ring: ragged pairs, bitwise the single solves
+    got = ctx.solve_batch([a, b[:40000], a], [b, a[:41000], b], 7)
+    assert np.array_equal(got["X"][0], base["X"]) and np.array_equal(got["X"][2], base["X"])
+    assert np.array_equal(got["X"][1], gpu_ctx.solve(b[:40000], a[:41000], 7, np.zeros(6), 24, 75)["X"])
+    ctx.close()
+
+
 def test_error_behaviour(gpu_ctx, frames):
     import icet_amd
     a, b = frames
@@ -542,28 +676,43 @@ def test_cpp_host_class_demo(tmp_path, gpu_ctx, frames, frames_golden):
     assert lines["ellipsoids"].split()[0] == "86" and lines["bad_status"].strip() == "1"
 
 
+# Named exceptions of the 256-pair headline batch (review r3, weak 1c / 1e): measured in profiles/r03_parity_batch.txt, r03_pair232.txt.
+#   232: corridor scene, lambda_min(HtWH) 100x below the next eigenvalue; 9.2e-4 m from the oracle = 0.32 sigma of its own predicted std; held to
+#        1x the oracle's own sensitivity to a 1-ulp perturbation of scan 2, computed in the test (1.8e-3 m measured).
+#   39:  pred_stds 1.2 % / cov 2.5 % off while X agrees (a single-ring voxel's last bit): held to RTOL_STD_LOOSE / RTOL_COV_LOOSE.
+BATCH_EXCEPTIONS_X = (232,)
+BATCH_EXCEPTIONS_STD = (39, 232)
+
+
 def test_many_pairs_parity_natural_signs(gpu_ctx):
-    """ALL 256 pairs of the headline batch (BASELINE configs[2]) against the UNMODIFIED oracle.  The reference's result depends on
-    the signs of the scan-1 eigenvectors (rows-of-V sigma points; `L*U^T` with U = V^T applies V, Q8 -- one 27-point far
-    voxel of pair 159 changes its 6x6 contribution 18-fold under a flip), and on near-degenerate covariances the QR iteration's
-    signs turn on the last bits of sigma1.  With one arithmetic rule on both sides those bits are the same, so nothing is borrowed
-    from the device: the keyframe table must be bit-exact on EVERY pair; X / pred_stds / cov must lie within the stated bounds on
-    every pair with AT MOST ONE exception (measured: pair 232), and the exception must lie within 1x the oracle's own sensitivity to
-    a 1-ulp perturbation of scan 2, computed here; the distribution must be the measured one: median below 5e-6 m, at least 97 % of
-    the pairs within SURVEY 8(c)'s starting values of 1e-4 m / 1e-5 rad."""
+    """ALL 256 DISTINCT pairs of the headline batch (BASELINE configs[2]) pushed through ONE icet_solve_batch_device call -- the call
+    bench.py times -- and THAT output compared with the UNMODIFIED oracle (review r3, next 1(ii)); every pair is also solved alone
+    through icet_solve for the keyframe tables, and must give the batch's bits.  The reference's result depends on the signs of the
+    scan-1 eigenvectors (rows-of-V sigma points; `L*U^T` with U = V^T applies V, Q8), and on near-degenerate covariances
+    the QR iteration's signs turn on the last bits of sigma1; with one arithmetic rule on both sides those bits are the same, so nothing
+    is borrowed from the device.  Asserted: keyframe table bit-exact on EVERY pair; X within 2e-4 m / 2e-5 rad, pred_stds / cov within
+    2 x their measured p99 (0.15 % / 0.3 %) on every pair but the NAMED exceptions above -- which are held to their own stated bounds
+    (232: 1x the oracle's 1-ulp sensitivity computed here; 39: 2.5 % / 5 %) -- and the distribution: median below 5e-6 m,
+    at least 97 % of the pairs within SURVEY 8(c)'s starting values of 1e-4 m / 1e-5 rad."""
     from concurrent.futures import ThreadPoolExecutor
-    from icet_amd import lidar_sim as ls
+    import icet_amd
+    from icet_amd import lidar_sim as ls, api
     from oracle import pyoracle as po
     dev = torch.device("cuda", 0)
     N = 256
+    pairs = [ls.make_batch_pair(k, device=dev) for k in range(N)]
+    d1 = [(p[0].data_ptr(), p[0].shape[1], p[0].shape[1]) for p in pairs]; d2 = [(p[1].data_ptr(), p[1].shape[1], p[1].shape[1]) for p in pairs]
+    out = torch.zeros((N, 48), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    bctx = icet_amd.Context(0)
+    bctx.solve_batch_device(d1, d2, api.Params(7, 24, 75, 25, 0.1, 0.1, 0), out.data_ptr()); bctx.sync()
+    batch = out.cpu().numpy()
+    bctx.close()
     dts, drs, worst, outside = np.zeros(N), np.zeros(N), np.zeros(4), []
     with ThreadPoolExecutor(min(os.cpu_count() or 1, 16)) as ex:
         for k0 in range(0, N, 32):                                  # 32 pairs at a time: the oracle runs on the host cores while the device solves
             ks = list(range(k0, min(k0 + 32, N)))
-            host = []
-            for k in ks:
-                s1, s2, _ = ls.make_batch_pair(k, device=dev)
-                host.append((s1.T.cpu().numpy(), s2.T.cpu().numpy()))
+            host = [(pairs[k][0].T.cpu().numpy(), pairs[k][1].T.cpu().numpy()) for k in ks]
             futs = [ex.submit(po.solve, a, b, trace=True) for a, b in host]
             gpus = [gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True) for a, b in host]
             for k, (a, b), g, fu in zip(ks, host, gpus, futs):
@@ -573,21 +722,25 @@ def test_many_pairs_parity_natural_signs(gpu_ctx):
                 assert np.array_equal(ax["n1_raw"], t["n1_raw"]) and np.array_equal(ax["cluster_bounds"], t["bounds"]) and np.array_equal(ax["has_fit"], t["has_fit"]), k
                 for name_g, name_o in (("mu1", "mu1"), ("sigma1", "sigma1"), ("evecs1", "evecs1"), ("l_diag", "Ldiag")):
                     assert np.array_equal(ax[name_g][f].view(np.uint32), t[name_o][f].view(np.uint32)), (k, name_g)
-                dts[k] = np.abs(g["X"][:3] - ref["X"][:3]).max(); drs[k] = np.abs(g["X"][3:] - ref["X"][3:]).max()
-                try:
-                    _check_solution(g, ref)
-                except AssertionError:
-                    outside.append(k)
+                # the pair inside the 256-pair call is bit for bit the pair solved alone (integer accumulation)
+                assert np.array_equal(batch[k, :6], g["X"]) and np.array_equal(batch[k, 6:12], g["pred_stds"]) and np.array_equal(batch[k, 12:], g["cov"].reshape(36)), k
+                gb = dict(X=batch[k, :6], pred_stds=batch[k, 6:12], cov=batch[k, 12:].reshape(6, 6))       # what the batch entry returned
+                dts[k] = np.abs(gb["X"][:3] - ref["X"][:3]).max(); drs[k] = np.abs(gb["X"][3:] - ref["X"][3:]).max()
+                if k in BATCH_EXCEPTIONS_X:
                     sens = oracle_sensitivity(a, b)
-                    print("pair %d outside the bounds: |dX_t| %.3g m, |dX_r| %.3g rad; oracle 1-ulp sensitivity %.3g m / %.3g rad" % (k, dts[k], drs[k], sens[:3].max(), sens[3:].max()))
-                    assert dts[k] <= sens[:3].max() and drs[k] <= max(sens[3:].max(), TOL_R), (k, dts[k], drs[k], sens)
+                    print("pair %d (named exception): |dX_t| %.3g m, |dX_r| %.3g rad; oracle 1-ulp sensitivity %.3g m / %.3g rad" % (k, dts[k], drs[k], sens[:3].max(), sens[3:].max()))
+                    if dts[k] > TOL_T or drs[k] > TOL_R:
+                        outside.append(k)
+                    assert dts[k] <= max(sens[:3].max(), TOL_T) and drs[k] <= max(sens[3:].max(), TOL_R), (k, dts[k], drs[k], sens)
                     continue
-                dd = np.sqrt(np.abs(np.diag(ref["cov"])))
-                worst = np.maximum(worst, [dts[k], drs[k], np.abs(g["pred_stds"] / ref["pred_stds"] - 1).max(), (np.abs(g["cov"] - ref["cov"]) / np.outer(dd, dd)).max()])
+                loose = k in BATCH_EXCEPTIONS_STD
+                _check_solution(gb, ref, rtol_std=RTOL_STD_LOOSE if loose else RTOL_STD_P99, rtol_cov=RTOL_COV_LOOSE if loose else RTOL_COV_P99)
+                if not loose:
+                    dd = np.sqrt(np.abs(np.diag(ref["cov"])))
+                    worst = np.maximum(worst, [dts[k], drs[k], np.abs(gb["pred_stds"] / ref["pred_stds"] - 1).max(), (np.abs(gb["cov"] - ref["cov"]) / np.outer(dd, dd)).max()])
     within = ((dts <= 1e-4) & (drs <= 1e-5)).mean()
-    print("%d pairs, natural signs: outside the bounds %s; among the rest max |dX_t| %.3g m, |dX_r| %.3g rad, rel pred_stds %.3g, rel cov %.3g; median |dX_t| %.3g; within 1e-4 m / 1e-5 rad: %.1f %%"
+    print("%d pairs through one icet_solve_batch_device call, natural signs: outside 2e-4 m / 2e-5 rad: %s; among the unexceptional pairs max |dX_t| %.3g m, |dX_r| %.3g rad, rel pred_stds %.3g, rel cov %.3g; median |dX_t| %.3g; within 1e-4 m / 1e-5 rad: %.1f %%"
           % (N, outside, *worst, np.median(dts), 100 * within))
-    assert len(outside) <= 1, outside
     assert np.median(dts) < 5e-6 and np.median(drs) < 5e-7 and within >= 0.97, (np.median(dts), np.median(drs), within)
 
 
@@ -808,7 +961,8 @@ def test_scan2_round_trip_option(gpu_ctx, frames):
         pa, pb = p[0].T.cpu().numpy(), p[1].T.cpu().numpy()
         one = ctx.solve(pa, pb, 7, np.zeros(6), 24, 75, flags=api.FLAG_ROUNDTRIP_SCAN2)
         assert np.array_equal(out[j, :6].cpu().numpy(), one["X"])
-        _check_solution(one, po.solve(pa, pb))
+        loose = j == 1                                       # bench pair 39: the named pred_stds / cov exception
+        _check_solution(one, po.solve(pa, pb), rtol_std=RTOL_STD_LOOSE if loose else RTOL_STD, rtol_cov=RTOL_COV_LOOSE if loose else RTOL_COV)
     ctx.close()
 
 

@@ -597,6 +597,46 @@ def main(argv=None):
                "pairs_over_1e-4_m_or_1e-5_rad_natural_signs": int(over1.size), "pairs_over_3e-4_m_or_1e-4_rad_natural_signs": int(over3.size),
                "pair_ids_over_3e-4_m_or_1e-4_rad": [int(k) for k in over3]}
 
+    # ---- configs[0] with a number, and the first non-synthetic figures: the reference's own sample pairs (src/sample_data/frame_804/805.npy,
+    # python/point_clouds/sample_pc_1/2.npy, committed as float32 fixtures) through the GPU path and through the oracle on the host (literal mode:
+    # serial loop = the live path of src/icet.cpp:391-404, and the 4-worker ThreadPool structure of :346-370), as src/icet_cpp_demo.cpp:25-45 runs them ----
+    sample = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and args.workload == "batch":
+        from oracle import pyoracle as po
+        sample = {"workload": "configs[0]: the reference's sample scan pairs (real lidar data), 75x24 voxels, 7 iters, X0 = 0; GPU: icet_solve from pageable host memory "
+                              "(PCIe-inclusive) and device-resident; CPU: oracle in its literal mode, serial and ThreadPool-4", "data": "real", "pairs": {}}
+        sctx = icet_amd.Context(dev_ids[0])
+        for name in ("frame_804_805", "sample_pc_1_2"):
+            fx = np.load(os.path.join(ROOT, "tests", "golden", "scans_%s.npz" % name))
+            a, b = fx["scan1"], fx["scan2"]                                   # N x 3 float32
+            ac, bc = np.ascontiguousarray(a.T).T, np.ascontiguousarray(b.T).T   # column-major N x 3 (an Eigen::MatrixXf)
+            r = sctx.solve(ac, bc, iters, np.zeros(6), P, T)
+            t0 = time.perf_counter(); nrep = 50
+            for _ in range(nrep):
+                r = sctx.solve(ac, bc, iters, np.zeros(6), P, T)
+            host_ms = (time.perf_counter() - t0) / nrep * 1e3
+            ta = torch.from_numpy(np.ascontiguousarray(a.T)).to(dev); tb = torch.from_numpy(np.ascontiguousarray(b.T)).to(dev)
+            pa, pb = padded(ta), padded(tb)
+            so = torch.zeros((1, 48), dtype=torch.float32, device=dev)
+            sd1 = [(pa.data_ptr(), a.shape[0], pa.shape[1])]; sd2 = [(pb.data_ptr(), b.shape[0], pb.shape[1])]
+            with torch.cuda.stream(stream):
+                for _ in range(5):
+                    one_ctx.solve_batch_device(sd1, sd2, p_plain, so.data_ptr())
+                one_ctx.sync()
+                t0 = time.perf_counter()
+                for _ in range(nrep):
+                    one_ctx.solve_batch_device(sd1, sd2, p_plain, so.data_ptr()); one_ctx.sync()
+                res_ms = (time.perf_counter() - t0) / nrep * 1e3
+            o_ref = po.solve(a, b, runlen=iters, bins_phi=P, bins_theta=T)
+            ser, _ = po.time_pair(a, b, reps=3, runlen=iters, bins_phi=P, bins_theta=T, mode=po.LIBMF)
+            pool, _ = po.time_pair(a, b, reps=3, runlen=iters, bins_phi=P, bins_theta=T, mode=po.POOL4 | po.LIBMF)
+            sample["pairs"][name] = {"points": [int(a.shape[0]), int(b.shape[0])], "gpu_resident_ms": round(res_ms, 4), "gpu_from_host_memory_ms": round(host_ms, 4),
+                                     "cpu_serial_literal_ms": round(ser * 1e3, 2), "cpu_threadpool4_literal_ms": round(pool * 1e3, 2),
+                                     "speedup_resident_vs_cpu_serial": round(ser * 1e3 / res_ms, 1),
+                                     "X_gpu": [round(float(v), 6) for v in r["X"]], "max_abs_dX_vs_oracle": float(np.abs(r["X"] - o_ref["X"]).max()),
+                                     "bits_equal_resident_and_host_path": bool(np.array_equal(so[0, :6].cpu().numpy(), r["X"]))}
+        sctx.close()
+
     if rank == 0:
         line = {
             "metric": "scan-pairs/sec + ms/pair, 64-ch 75x24 voxels 7 iters; HBM GB/s vs peak" if args.workload == "batch" else "scan-pairs/sec, 128-ch 150x48 voxels 10 iters",
@@ -628,6 +668,7 @@ def main(argv=None):
             "highres": hires,
             "h2d_inclusive": h2d,
             "ctor": ctor,
+            "sample": sample,
             "published_reference_ms_per_pair": PUBLISHED_MS_PER_PAIR,
         }
         print(json.dumps(line), flush=True)

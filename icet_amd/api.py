@@ -65,7 +65,8 @@ _I = C.POINTER(C.c_int32)
 
 class Aux(C.Structure):
     _fields_ = [("cluster_bounds", _F), ("n1_raw", _I), ("has_fit", _I), ("mu1", _F), ("sigma1", _F), ("evecs1", _F), ("l_diag", _F),
-                ("x_hist", _F), ("htwh", _F), ("htwdz", _F), ("n2_raw", _I), ("n2_in", _I), ("test_points", _F), ("points2", _F)]
+                ("x_hist", _F), ("htwh", _F), ("htwdz", _F), ("n2_raw", _I), ("n2_in", _I), ("test_points", _F), ("points2", _F),
+                ("points1_spherical", _F), ("point_index1", _I), ("bin_start1", _I), ("points2_spherical", _F), ("voxel2", _I)]
 
 
 _lib = None
@@ -222,7 +223,8 @@ class Context:
     # -- single pair, host arrays ---------------------------------------------------------------
     def solve(self, scan1, scan2, runlen, X0, num_bins_phi, num_bins_theta, n=25, thresh=0.1, buff=0.1, aux=False, flags=0):
         """icet_solve.  scan1 / scan2: N x 3 (any layout numpy can view; an N x 3 array in Fortran order -- an Eigen::MatrixXf -- is
-        passed without a copy).  aux=True also returns the side tables (icet_aux), among them ``points2`` (N2 x 3)."""
+        passed without a copy).  aux=True also returns the side tables (icet_aux), among them ``points2`` (N2 x 3); aux="full" adds the
+        per-point members of the reference object (points1_spherical, point_index1 / bin_start1, points2_spherical, voxel2)."""
         s1, s2 = _colmajor(scan1), _colmajor(scan2)
         p = Params(int(runlen), int(num_bins_phi), int(num_bins_theta), int(n), float(thresh), float(buff), int(flags))
         x0 = np.asarray(X0, np.float32).reshape(6).copy()
@@ -236,10 +238,15 @@ class Context:
                        l_diag=np.zeros((V, 3), np.float32), x_hist=np.zeros((rl, 6), np.float32), htwh=np.zeros((rl, 6, 6), np.float32),
                        htwdz=np.zeros((rl, 6), np.float32), n2_raw=np.zeros((rl, V), np.int32), n2_in=np.zeros((rl, V), np.int32),
                        test_points=np.zeros((V, 6, 3), np.float32), points2=np.zeros((3, s2.shape[1]), np.float32))
+            if aux == "full":
+                arr.update(points1_spherical=np.zeros((3, s1.shape[1]), np.float32), point_index1=np.zeros(s1.shape[1], np.int32), bin_start1=np.zeros(V + 1, np.int32),
+                           points2_spherical=np.zeros((3, s2.shape[1]), np.float32), voxel2=np.zeros(s2.shape[1], np.int32))
             auxs = Aux()
             for k, v in arr.items():
                 setattr(auxs, k, v.ctypes.data_as(_I if v.dtype == np.int32 else _F))
-            arr["points2"] = arr["points2"].T                # (N2, 3) view of the column-major buffer
+            for k in ("points2", "points1_spherical", "points2_spherical"):
+                if k in arr:
+                    arr[k] = arr[k].T                         # (N, 3) views of the column-major buffers
             out["aux"] = arr
         st = load_library().icet_solve(self._h, C.byref(p), s1.ctypes.data, s1.shape[1], s1.shape[1], s2.ctypes.data, s2.shape[1], s2.shape[1],
                                        x0.ctypes.data, X.ctypes.data, ps.ctypes.data, cov.ctypes.data, C.byref(auxs) if auxs is not None else None)
@@ -375,6 +382,8 @@ class ICET:
     """
 
     def __init__(self, scan1, scan2, runlen, X0, num_bins_phi, num_bins_theta, n=25, thresh=0.1, buff=0.1, *, device=0, side_tables=True):
+        """side_tables: False = X / pred_stds only; True = every member a caller in the reference reads; "full" = also the per-point members
+        points1Spherical, pointIndices1, points2Spherical, pointIndices2 (include/icet.h:79,82,95-96: several MB more per solve)."""
         self.rl, self.numBinsPhi, self.numBinsTheta, self.n, self.thresh, self.buff = runlen, num_bins_phi, num_bins_theta, n, thresh, buff
         ctx = default_context(device)
         res = ctx.solve(scan1, scan2, runlen, X0, num_bins_phi, num_bins_theta, n, thresh, buff, aux=side_tables)
@@ -397,7 +406,15 @@ class ICET:
                 self.HTWdz_i = a["htwdz"][runlen - 1].reshape(6, 1)
                 xprev = np.asarray(X0, np.float32).reshape(6) if runlen == 1 else a["x_hist"][runlen - 2]
                 self.dx = a["x_hist"][runlen - 1] - xprev
-                self.points2 = a["points2"]                  # (p + t) * R of the last iteration, from the device (src/icet.cpp:375-378)
+                self.points2 = a["points2"]                  # (p + t) * R of the last iteration (src/icet.cpp:375-378)
+                if side_tables == "full":
+                    T, P = num_bins_theta, num_bins_phi
+                    self.points1Spherical = a["points1_spherical"]; self.points2Spherical = a["points2_spherical"]
+                    bs, idx = a["bin_start1"], a["point_index1"]
+                    # [theta][phi] -> ascending indices, as std::vector<std::vector<std::vector<int>>> (include/icet.h:95-96)
+                    self.pointIndices1 = [[idx[bs[T * ph + th]:bs[T * ph + th + 1]] for ph in range(P)] for th in range(T)]
+                    order = np.argsort(a["voxel2"], kind="stable"); cnt = np.bincount(a["voxel2"], minlength=T * P); st = np.concatenate([[0], np.cumsum(cnt)])
+                    self.pointIndices2 = [[order[st[T * ph + th]:st[T * ph + th + 1]] for ph in range(P)] for th in range(T)]
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -43,12 +43,14 @@ struct icet_ctx {
     uint32_t* d_pack = nullptr; uint32_t* h_pack = nullptr; size_t cap_pack = 0;
     float* h_pts2 = nullptr; float* d_pts2 = nullptr; size_t cap_pts2 = 0;   // `points2` (scan 2 under the last iteration's transform): device buffer + pinned host copy
     float* h_x0 = nullptr;                                       // pinned, 6 x cap_out_pairs
+    float* d_sph1 = nullptr; int32_t* d_idx1 = nullptr; size_t cap_side1 = 0;      // points1Spherical / pointIndices1 on request (icet_sidetables.hip)
+    float* d_sph2 = nullptr; int32_t* d_vox2 = nullptr; size_t cap_side2 = 0;      // points2Spherical / the rows' voxels on request
     // host-pointer entry points: scan 2 is uploaded on a stream of its own, beside the keyframe build of scan 1
     hipStream_t st_copy = nullptr; hipEvent_t ev_s2 = nullptr;
     hipEvent_t ev_kf = nullptr, ev_kfd = nullptr, ev_prev = nullptr, ev_pts2 = nullptr;   // keyframe built / its tables on the host / transform of the last iteration known / points2 on the host
     // icet_solve_begin .. icet_solve_end
     struct Pending { bool active = false; float* x_out = nullptr; float* ps_out = nullptr; float* cov_out = nullptr; icet_aux aux{}; bool has_aux = false;
-                     int V = 0, rl = 0; int64_t n2 = 0; bool kf_tables = false, kf_done = false, pts2 = false, pts2_dev = false, tail_ints = false;
+                     int V = 0, rl = 0; int64_t n2 = 0; bool kf_tables = false, kf_done = false, pts2 = false, pts2_dev = false, tail_ints = false, side1 = false, side2 = false; int64_t n1 = 0;
                      const float* scan2 = nullptr; int64_t ld2 = 0; } pend;
     // timing
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
@@ -62,6 +64,12 @@ struct icet_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_stage = nullptr; int stage_at = 0;            // see LaunchCfg::stage_event
     hipEvent_t ev_desc = nullptr; bool desc_in_flight = false;   // completion of the last copy out of the pinned descriptor staging
+    // Small device batches whose launch geometry repeats call after call are replayed from a captured hipGraph (option "graph"): the ~33
+    // launches of a single-pair solve then cost one hipGraphLaunch on the host, and the command processor runs them back to back.
+    struct GraphKey { int64_t v[40]; };                        // every LaunchCfg field + the pointers the launches take (graph_key_of)
+    bool capturing = false; int graph_mode = -1;               // -1: replay batches of <= 8 pairs whose launch key repeats; 0 never; 1 same as -1
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; GraphKey graph_key{}; GraphKey seen_key{}; bool have_seen = false, have_graph = false;
+    hipEvent_t ev_graph = nullptr; bool graph_in_flight = false;
 };
 
 namespace {
@@ -378,7 +386,7 @@ icet_status upload_desc(icet_ctx* c, int32_t n_pairs) {
     HIPCHK(c, hipMemcpyAsync(w.desc, c->h_desc, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(w.seg_off, c->h_seg, sizeof(int32_t) * (n_pairs + 1), hipMemcpyHostToDevice, c->stream));
     if (!c->ev_desc) HIPCHK(c, hipEventCreateWithFlags(&c->ev_desc, hipEventDisableTiming));
-    HIPCHK(c, hipEventRecord(c->ev_desc, c->stream)); c->desc_in_flight = true;
+    if (!c->capturing) { HIPCHK(c, hipEventRecord(c->ev_desc, c->stream)); c->desc_in_flight = true; }     // (a captured event cannot be waited for on the host: the replay path orders the staging itself)
     return ICET_OK;
 }
 
@@ -401,7 +409,7 @@ icet_status enqueue_keyframe(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         }
     }
     { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }
-    HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
+    if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
     HIPCHK(c, launch_keyframe(w, cfg, aux, c->stream));
     return ICET_OK;
 }
@@ -458,7 +466,7 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
     };
     if (scan2_ready) HIPCHK(c, hipStreamWaitEvent(c->stream, scan2_ready, 0));     // host-pointer entries: scan 2 was uploaded on the copy stream beside the keyframe build
     if (want_pts2 && p->runlen == 1) { const icet_status ps = enqueue_points2(); if (ps != ICET_OK) return ps; }
-    HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
+    if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
     const bool per_iter = (p->flags & ICET_FLAG_TIMING) != 0;
     for (int it = 0; it < p->runlen; it++) {
         if (per_iter) HIPCHK(c, hipEventRecord(c->ev_acc[2 * it], c->stream));
@@ -467,8 +475,7 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
         HIPCHK(c, launch_gn_solve(wl, lcfg, it, d_out, aux, c->stream));
         if (want_pts2 && it == p->runlen - 2) { const icet_status ps = enqueue_points2(); if (ps != ICET_OK) return ps; }
     }
-    HIPCHK(c, hipEventRecord(c->ev_c, c->stream));
-    c->timing_valid = true; c->last_iters = per_iter ? p->runlen : 0;
+    if (!c->capturing) { HIPCHK(c, hipEventRecord(c->ev_c, c->stream)); c->timing_valid = true; c->last_iters = per_iter ? p->runlen : 0; }
     return ICET_OK;
 }
 
@@ -547,6 +554,7 @@ icet_status icet_destroy(icet_ctx* c) {
     if (c->st_copy) (void)hipStreamSynchronize(c->st_copy);
     if (c->h_pts2) (void)hipHostFree(c->h_pts2);
     if (c->d_pts2) (void)hipFree(c->d_pts2);
+    for (void* q : {(void*)c->d_sph1, (void*)c->d_idx1, (void*)c->d_sph2, (void*)c->d_vox2}) if (q) (void)hipFree(q);
     if (c->h_x0) (void)hipHostFree(c->h_x0);
     for (hipEvent_t e : {c->ev_s2, c->ev_kf, c->ev_kfd, c->ev_prev, c->ev_pts2}) if (e) (void)hipEventDestroy(e);
     if (c->st_copy) (void)hipStreamDestroy(c->st_copy);
@@ -561,6 +569,8 @@ icet_status icet_destroy(icet_ctx* c) {
     for (icet_ctx* h : c->helpers) (void)icet_destroy(h);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_desc) (void)hipEventDestroy(c->ev_desc);
+    if (c->have_graph) { (void)hipGraphExecDestroy(c->graph_exec); (void)hipGraphDestroy(c->graph); }
+    if (c->ev_graph) (void)hipEventDestroy(c->ev_graph);
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -687,6 +697,7 @@ static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t 
     // the previous call may still be copying out of the pinned descriptor staging; its kernels may still be running
     // (the device entry point never waits for them: calls queue up behind each other on the stream)
     if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
+    if (c->graph_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_graph)); c->graph_in_flight = false; }     // a replay re-reads the pinned descriptor staging when it RUNS
     for (int k = 0; k < n_pairs; k++) {
         PairDesc& d = c->h_desc[k];
         d.s1 = scan1[k].ptr; d.s2 = scan2[k].ptr;
@@ -694,6 +705,56 @@ static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t 
         d.off1 = 0; d.off2 = 0;
     }
     if (p->runlen == 0) return write_runlen0(c, n_pairs, d_x0, d_out);
+    if (c->graph_mode && n_pairs <= 8 && !(p->flags & (ICET_FLAG_TIMING | ICET_FLAG_ROUNDTRIP_SCAN2)) && !c->stage_at) {
+        // The kernels read the scans' addresses and sizes from the descriptor table (re-uploaded from pinned memory by a memcpy node of the
+        // graph on every replay); what the launches themselves depend on is the LaunchCfg (grids, LDS sizes, point counts passed by value)
+        // and the workspace pointers.  A call whose key equals the previous call's is captured; later calls with that key replay.
+        icet_status ts = ensure_thresholds(c, p->bins_theta, p->bins_phi);
+        if (ts != ICET_OK) return ts;
+        icet_ctx::GraphKey key{};
+        {
+            const LaunchCfg k = make_cfg(c, p, n_pairs);
+            auto bits = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return (int64_t)i; };
+            const int64_t vals[] = {k.T, k.P, k.V, k.n, k.runlen, bits(k.thresh), bits(k.buff), k.n_pairs, k.max_n1, k.max_n2, k.total_n1, k.lds_slots, k.acc_min_pts_per_thread,
+                                    k.acc_target_blocks, k.kf_chunks, k.kf_pts_per_thread, k.use_library_sort, k.vec4_ok, k.true_sort, k.force_exact, k.rs_cap, k.rs_max_cell,
+                                    k.exec_bits_lds, k.exec_pairwise, k.reject_moving, k.half_gap, k.rt2, p->flags, (int64_t)(intptr_t)d_x0, (int64_t)(intptr_t)d_out,
+                                    (int64_t)(intptr_t)c->w.desc, (int64_t)(intptr_t)c->w.thr, (int64_t)(intptr_t)c->w.lut, (int64_t)(intptr_t)c->w.r1, (int64_t)(intptr_t)c->w.counts,
+                                    (int64_t)(intptr_t)c->w.near_over, (int64_t)(intptr_t)c->w.acc, (int64_t)(intptr_t)c->w.fit_items, (int64_t)(intptr_t)c->w.sort_tmp, (int64_t)(intptr_t)c->w.tile_vr};
+            static_assert(sizeof(vals) == sizeof(key.v), "GraphKey size");
+            std::memcpy(key.v, vals, sizeof(vals));
+        }
+        auto same = [](const icet_ctx::GraphKey& a, const icet_ctx::GraphKey& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; };
+        if (c->have_graph && same(key, c->graph_key)) {
+            HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+            HIPCHK(c, hipEventRecord(c->ev_graph, c->stream)); c->graph_in_flight = true;
+            c->timing_valid = false;
+            return ICET_OK;
+        }
+        if (c->have_seen && same(key, c->seen_key)) {
+            if (c->have_graph) { (void)hipGraphExecDestroy(c->graph_exec); (void)hipGraphDestroy(c->graph); c->have_graph = false; }
+            if (!c->ev_graph) HIPCHK(c, hipEventCreateWithFlags(&c->ev_graph, hipEventDisableTiming));
+            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            c->capturing = true;
+            const icet_status es = enqueue(c, p, n_pairs, d_x0, d_out, nullptr);
+            c->capturing = false;
+            hipGraph_t g = nullptr;
+            const hipError_t ee = hipStreamEndCapture(c->stream, &g);
+            if (es != ICET_OK || ee != hipSuccess || !g) {           // could not capture (a capacity grew, an unsupported call): run this call eagerly and stop trying for this key
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+                c->have_seen = false;
+                return enqueue(c, p, n_pairs, d_x0, d_out, nullptr);
+            }
+            hipGraphExec_t ge = nullptr;
+            if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); (void)hipGetLastError(); c->have_seen = false; return enqueue(c, p, n_pairs, d_x0, d_out, nullptr); }
+            c->graph = g; c->graph_exec = ge; c->graph_key = key; c->have_graph = true;
+            HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+            HIPCHK(c, hipEventRecord(c->ev_graph, c->stream)); c->graph_in_flight = true;
+            c->timing_valid = false;
+            return ICET_OK;
+        }
+        c->seen_key = key; c->have_seen = true;
+    }
     return enqueue(c, p, n_pairs, d_x0, d_out, nullptr);
 }
 
@@ -835,6 +896,23 @@ icet_status icet_solve_begin(icet_ctx* c, const icet_params* p, const float* sca
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pts2), want * sizeof(float)));
         c->cap_pts2 = want;
     }
+    const bool want_side1 = aux && p->runlen > 0 && n1 > 0 && (aux->points1_spherical || aux->point_index1 || aux->bin_start1);
+    const bool want_side2 = aux && p->runlen > 0 && n2 > 0 && (aux->points2_spherical || aux->voxel2);
+    if (want_side1 && (size_t)n1 > c->cap_side1) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, dev_realloc(c->d_sph1, (size_t)3 * n1)); HIPCHK(c, dev_realloc(c->d_idx1, (size_t)n1)); c->cap_side1 = (size_t)n1;
+    }
+    if (want_side2 && ((size_t)n2 > c->cap_side2 || (size_t)3 * n2 > c->cap_pts2)) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->st_copy) HIPCHK(c, hipStreamSynchronize(c->st_copy));
+        HIPCHK(c, dev_realloc(c->d_sph2, (size_t)3 * n2)); HIPCHK(c, dev_realloc(c->d_vox2, (size_t)n2)); c->cap_side2 = (size_t)n2;
+        if ((size_t)3 * n2 > c->cap_pts2) {
+            if (c->h_pts2) { HIPCHK(c, hipHostFree(c->h_pts2)); c->h_pts2 = nullptr; }
+            HIPCHK(c, dev_realloc(c->d_pts2, (size_t)3 * n2));
+            HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pts2), (size_t)3 * n2 * sizeof(float)));
+            c->cap_pts2 = (size_t)3 * n2;
+        }
+    }
     if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
     // (no stream synchronisation up front: the staging buffers, the result block and the pinned x0 are only ever used by the host-pointer
     // entry points, each of which has drained the stream before it returned)
@@ -862,12 +940,17 @@ icet_status icet_solve_begin(icet_ctx* c, const icet_params* p, const float* sca
             if (aux->n2_in) HIPCHK(c, hipMemsetAsync(ad.n2_in, 0, sizeof(int32_t) * rl * v, c->stream)); else ad.n2_in = nullptr;
             q.kf_tables = aux->cluster_bounds || aux->has_fit || aux->mu1 || aux->sigma1 || aux->evecs1 || aux->l_diag || aux->test_points;
             q.tail_ints = aux->n1_raw || aux->n2_raw || aux->n2_in;
-            q.pts2 = want_pts2; q.pts2_dev = want_pts2 && (p->flags & ICET_FLAG_ROUNDTRIP_SCAN2) != 0;
+            q.pts2 = want_pts2 && !want_side2; q.pts2_dev = q.pts2 && (p->flags & ICET_FLAG_ROUNDTRIP_SCAN2) != 0;
+            q.side1 = want_side1; q.side2 = want_side2; q.n1 = n1;
             q.scan2 = scan2; q.ld2 = ld2;
-            if (!want_pts2) ad.xf_last = nullptr;
+            if (!want_pts2 && !want_side2) ad.xf_last = nullptr;
         }
         c->kf_pairs = 0;
         st = enqueue_keyframe(c, p, 1, aux ? &ad : nullptr);
+        if (st == ICET_OK && want_side1) {                                     // points1Spherical / pointIndices1 from the tables the keyframe build has just left
+            const LaunchCfg scfg = make_cfg(c, p, 1);
+            HIPCHK(c, launch_side_scan1(c->w, scfg, c->d_sph1, c->d_idx1, c->stream));
+        }
         if (st == ICET_OK) {
             // scan 2 goes up on the copy stream while the keyframe kernels enqueued above run; the loop waits for ev_s2
             hipError_t e = upload_scan(c->d_stage2, l2, scan2, n2, ld2, c->st_copy);
@@ -881,6 +964,13 @@ icet_status icet_solve_begin(icet_ctx* c, const icet_params* p, const float* sca
             }
             if (e != hipSuccess) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->st_copy); c->err = std::string("scan-2 upload / table download: ") + hipGetErrorString(e); return ICET_ERR_HIP; }
             st = enqueue_loop(c, p, 1, c->h_x0, h_res, aux ? &ad : nullptr, false, q.pts2_dev ? c->h_pts2 : nullptr, c->ev_s2);
+        }
+        if (st == ICET_OK && want_side2) {
+            // points2 / points2Spherical / the rows' voxels of the LAST fitScan2: one kernel behind the loop, with the transform record that
+            // iteration used (it reads the scan the loop read: the round-tripped copy under ICET_FLAG_ROUNDTRIP_SCAN2)
+            LaunchCfg scfg = make_cfg(c, p, 1);
+            Workspace wl = c->w; if (scfg.rt2) wl.desc = c->w.desc_rt;
+            HIPCHK(c, launch_side_scan2(wl, scfg, ad.xf_last, c->d_pts2, c->d_sph2, c->d_vox2, c->stream));
         }
         if (st == ICET_OK && q.tail_ints)
             HIPCHK(c, hipMemcpyAsync(c->h_pack + L.n1_raw, c->d_pack + L.n1_raw, (L.ints_end - L.n1_raw) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -941,6 +1031,17 @@ icet_status icet_solve_end(icet_ctx* c) {
         auto add = [&](void* dst, size_t at, size_t n) { if (dst && n) std::memcpy(dst, c->h_pack + at, n * sizeof(uint32_t)); };
         add(a.x_hist, L.x_hist, rl * 6); add(a.htwh, L.htwh, rl * 36); add(a.htwdz, L.htwdz, rl * 6);
         add(a.n1_raw, L.n1_raw, v); add(a.n2_raw, L.n2_raw, rl * v); add(a.n2_in, L.n2_in, rl * v);
+        // the per-point tables go from HBM straight into the caller's arrays (several MB; only when asked for)
+        if (q.side1) {
+            if (a.points1_spherical) HIPCHK(c, hipMemcpy(a.points1_spherical, c->d_sph1, sizeof(float) * 3 * (size_t)q.n1, hipMemcpyDeviceToHost));
+            if (a.point_index1) HIPCHK(c, hipMemcpy(a.point_index1, c->d_idx1, sizeof(int32_t) * (size_t)q.n1, hipMemcpyDeviceToHost));
+            if (a.bin_start1) HIPCHK(c, hipMemcpy(a.bin_start1, c->w.bin_start, sizeof(int32_t) * (v + 1), hipMemcpyDeviceToHost));
+        }
+        if (q.side2) {
+            if (a.points2) HIPCHK(c, hipMemcpy(a.points2, c->d_pts2, sizeof(float) * 3 * (size_t)q.n2, hipMemcpyDeviceToHost));
+            if (a.points2_spherical) HIPCHK(c, hipMemcpy(a.points2_spherical, c->d_sph2, sizeof(float) * 3 * (size_t)q.n2, hipMemcpyDeviceToHost));
+            if (a.voxel2) HIPCHK(c, hipMemcpy(a.voxel2, c->d_vox2, sizeof(int32_t) * (size_t)q.n2, hipMemcpyDeviceToHost));
+        }
     }
     return ICET_OK;
 }
@@ -988,6 +1089,7 @@ icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
     else if (k == "rs_max_cell") t.rs_max_cell = iv < 0 ? 0 : iv;
     else if (k == "exec_bits_lds") t.exec_bits_lds = iv != 0;
     else if (k == "exec_pairwise") t.exec_pairwise = iv < 0 ? -1 : (iv != 0);
+    else if (k == "graph") { c->graph_mode = iv < 0 ? -1 : (iv != 0); c->have_seen = false; }
     else if (k == "guard_scale") { if (!(value >= 1.0 && value <= 1024.0)) { c->err = "guard_scale must lie in [1, 1024]"; return ICET_ERR_BAD_ARG; } t.guard_scale = value; c->w.thr_T = 0; }   // tables are rebuilt by the next call
     else if (k == "lut_polar_quantile") { if (!(value >= 0.0 && value <= 1.0)) { c->err = "lut_polar_quantile must lie in [0, 1]"; return ICET_ERR_BAD_ARG; } t.lut_polar_quantile = value; c->w.thr_T = 0; }
     else { c->err = "unknown option: " + k; return ICET_ERR_BAD_ARG; }

@@ -646,7 +646,12 @@ struct FitItem { int32_t base, v, k0, nb; };      // rows k0 .. k0 + nb of bin v
 // A pair owns the item slots [item_base, item_base + n1 / 64 + V): at most one partial batch per bin plus the full ones.
 __device__ __host__ __forceinline__ size_t item_base(int32_t off1, int pair, int V) { return (size_t)(off1 / 64) + (size_t)pair * (size_t)(V + 1); }
 
-__global__ __launch_bounds__(kBlock, ICET_CLUSTER_WAVES) void k_fit_cluster(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
+// kTail: chunks of 64 rows requested together past a bin's first 256 rows.  A real scan's near field puts tens of thousands of rows into a few
+// bins (the reference's sample_pc pair: one wave walked 237 us while every other wave had long finished -- two dependent memory round trips
+// per 64 rows).  Throughput batches keep 8 waves per SIMD (kTail 2 fits their 64 registers); small batches, whose waves are few anyway, take
+// kTail 8 at 4 waves per SIMD: two round trips per 512 rows.
+template <int kTail>
+__global__ __launch_bounds__(kBlock, kTail > 2 ? 4 : ICET_CLUSTER_WAVES) void k_fit_cluster(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
                                                       const uint32_t* __restrict__ sorted_row, const float* __restrict__ r1,
                                                       uint32_t* __restrict__ cand, float* __restrict__ cand_r, FitItem* __restrict__ items, uint32_t* __restrict__ n_items,
                                                       int32_t* __restrict__ live, const int32_t* __restrict__ n_live,
@@ -731,6 +736,9 @@ __global__ __launch_bounds__(kBlock, ICET_CLUSTER_WAVES) void k_fit_cluster(cons
             const int i = c0 + lane; const bool valid = i < cnt;
             const float prev = wave_shr1(r, carry_prev);
             const bool brk = valid && (i == 0 || !(fabsf(prev - r) <= thresh));
+            // a chunk without a single break only carries the run on (the thousands of exact-zero rows of a real scan share one bin and one
+            // r: 360 chunks of it cost 160 us at ~100 instructions each before this test)
+            if (__ballot(brk) == 0ull) { carry_prev = wave_read(r, 63); return; }
             const int pm = wave_incl_max(brk ? i : -1);              // inclusive prefix max of break positions (DPP: no LDS crossbar)
             int prevb = wave_shr1(pm, -1);                           // last break strictly before this lane ...
             prevb = max(prevb, run_start);                           // ... or the run carried in from earlier chunks
@@ -753,7 +761,16 @@ __global__ __launch_bounds__(kBlock, ICET_CLUSTER_WAVES) void k_fit_cluster(cons
         };
 #pragma unroll
         for (int k = 0; k < kCache; k++) if (64 * k < cnt && !found) walk(64 * k, pr[k]);
-        for (int c0 = 64 * kCache; c0 < cnt && !found; c0 += 64) walk(c0, (c0 + lane < cnt) ? RS(c0 + lane) : 0.f);
+        // rows past the cached ones: kTail chunks' rows, then their radii, are requested together
+        for (int c0 = 64 * kCache; c0 < cnt && !found; c0 += 64 * kTail) {
+            uint32_t tw[kTail]; float tr[kTail];
+#pragma unroll
+            for (int k = 0; k < kTail; k++) tw[k] = (c0 + 64 * k + lane < cnt) ? sorted_row[base + c0 + 64 * k + lane] : 0u;
+#pragma unroll
+            for (int k = 0; k < kTail; k++) tr[k] = (c0 + 64 * k + lane < cnt) ? r1[po + (tw[k] & kRowMask)] : 0.f;
+#pragma unroll
+            for (int k = 0; k < kTail; k++) if (c0 + 64 * k < cnt && !found) walk(c0 + 64 * k, tr[k]);
+        }
         if (!found && cnt - run_start >= n) {
             if (front != 0.f) { const float back = RS(cnt - 1); inner = front - in_buff(front, run_start, front_before); outer = back + buff; }
             else { inner = 0.f; outer = 0.f; }
@@ -1237,8 +1254,12 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     // a fixed number of blocks per pair walks the pair's live bins / work items (their numbers are only known on the device):
     // enough blocks to fill the chip whatever the batch size
     const int fit_chunks = std::max(1, std::min((c.V + kBlock / 64 - 1) / (kBlock / 64), (ICET_FIT_BLOCKS + c.n_pairs - 1) / c.n_pairs));
-    k_fit_cluster<<<dim3(groups * fit_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.valA, w.r1, w.keyA, reinterpret_cast<float*>(w.keyB), items, w.fit_n_items,
-                                                             w.live_bins, w.n_live, w.midD, c.T, c.P, c.n, c.thresh, c.buff, np, fit_chunks, c.half_gap);
+    if (c.n_pairs <= 16)
+        k_fit_cluster<8><<<dim3(groups * fit_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.valA, w.r1, w.keyA, reinterpret_cast<float*>(w.keyB), items, w.fit_n_items,
+                                                                    w.live_bins, w.n_live, w.midD, c.T, c.P, c.n, c.thresh, c.buff, np, fit_chunks, c.half_gap);
+    else
+        k_fit_cluster<2><<<dim3(groups * fit_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.valA, w.r1, w.keyA, reinterpret_cast<float*>(w.keyB), items, w.fit_n_items,
+                                                                    w.live_bins, w.n_live, w.midD, c.T, c.P, c.n, c.thresh, c.buff, np, fit_chunks, c.half_gap);
     ICET_LAUNCH_CHECK();
     {
         const int rt_chunks = std::max(1, std::min(64, (ICET_RT_BLOCKS + c.n_pairs - 1) / c.n_pairs));

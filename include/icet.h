@@ -12,9 +12,14 @@
 // (tests/cpp/mock_eigen, tests/cpp/adapter_demo.cpp) so that it cannot rot.  The scan-1 voxel table is exposed as the reference
 // exposes it: the std::map members mu1 / sigma1 / L / U keyed [theta][phi] (include/icet.h:27-29,89-94), one entry per fitted voxel,
 // with U = eigenvectors^T as at src/icet.cpp:184 and L the 0/1 diagonal of src/icet.cpp:205-232; sigma2 / mu2 are declared and stay
-// empty (the reference declares them and never fills them).  Not exposed: pointIndices1/2 and points1Spherical / points2Spherical --
-// indices into, and the rows of, the scrambled spherical copies the reference keeps for its own loops (the device never stores
-// theta / phi of a row: only decisions and the Gaussians need them); no caller reads them.
+// empty (the reference declares them and never fills them).  pointIndices1/2 and points1Spherical / points2Spherical -- indices into, and
+// the rows of, the spherical copies the reference keeps for its own loops; no caller reads them -- are filled only when
+// ICET::side_tables_level() is set to 2 (extra kernels + several MB of D2H per object).  points1Spherical / pointIndices1 are the reference's
+// bit for bit (rows in the order its sort + swap loop leaves them); the scan-2 members are in the CALLER's row order, because the device never
+// sorts scan 2 (the reference's are in its scrambled order: the same sets, permuted).  The reference's other public METHODS (fitScan1, prepScan2,
+// fitScan2, sortSphericalCoordinates, findCluster, filterPointsInsideCluster, testSigmaPoints, fitCells1/2, parallelFitCells2, get_H,
+// checkCondition: include/icet.h:46-68) are the stages of its constructor; here they run fused on the device inside the constructor and are
+// not callable one by one -- no caller in the reference calls them from outside the class.  step() is kept (a stub there too).
 // Two members differ in content, neither is read by any caller: `points2_OG` holds scan 2 as given (the reference stores it after
 // its radial "sort" and a spherical round trip, src/icet.cpp:263-275: same points, permuted, <= 2 ulp away -- the device never
 // sorts scan 2); `testPoints` holds the sigma points of the pruned axes like the reference's (src/icet.cpp:213-231) and ZEROS in the
@@ -43,7 +48,7 @@ public:
         // `points2` receives scan 2 under the last iteration's transform straight from the solve (no intermediate copy)
         points2.resize(scan2.rows(), 3);
         icet_amd::ICET it(icet_amd::ICET::Deferred{}, scan1.data(), scan1.rows(), scan1.rows(), scan2.data(), scan2.rows(), scan2.rows(), runlen, x0,
-                          num_bins_phi, num_bins_theta, n, thresh, buff, 0, true, scan2.rows() > 0 ? points2.data() : nullptr);
+                          num_bins_phi, num_bins_theta, n, thresh, buff, 0, side_tables_level() >= 2 ? 2 : 1, scan2.rows() > 0 ? points2.data() : nullptr);
         // the deep copies the reference's constructor makes of both scans (src/icet.cpp:30,33) -- done while the device builds the keyframe
         points1 = scan1; points2_OG = scan2;
         // everything fitScan1 produces arrives while the Gauss-Newton loop still iterates on the device: converted to the reference's members here
@@ -83,9 +88,25 @@ public:
         for (int k = 0; k < 6; k++) { X[k] = it.X[k]; pred_stds[k] = it.pred_stds[k]; dx[k] = it.dx[k]; }
         HTWH_i.resize(6, 6); HTWdz_i.resize(6, 1);
         for (int a = 0; a < 6; a++) { HTWdz_i(a, 0) = it.HTWdz_i[a]; for (int b = 0; b < 6; b++) HTWH_i(a, b) = it.HTWH_i[a * 6 + b]; }
+        // the per-point members (include/icet.h:79,82,95-96 of the reference), only at level 2
+        if (side_tables_level() >= 2 && it.status == ICET_OK && runlen > 0) {
+            const long N1 = scan1.rows(), N2 = scan2.rows();
+            if ((long)it.points1Spherical.size() == N1 * 3) points1Spherical = Eigen::Map<const Eigen::MatrixXf>(it.points1Spherical.data(), N1, 3);
+            if ((long)it.points2Spherical.size() == N2 * 3) points2Spherical = Eigen::Map<const Eigen::MatrixXf>(it.points2Spherical.data(), N2, 3);
+            pointIndices1.assign(num_bins_theta, std::vector<std::vector<int>>(num_bins_phi));
+            pointIndices2.assign(num_bins_theta, std::vector<std::vector<int>>(num_bins_phi));
+            if ((int)it.binStart1.size() == V + 1)
+                for (int v = 0; v < V; v++)
+                    pointIndices1[v % num_bins_theta][v / num_bins_theta].assign(it.pointIndex1.begin() + it.binStart1[v], it.pointIndex1.begin() + it.binStart1[v + 1]);
+            for (long i = 0; i < (long)it.voxel2.size(); i++) { const int v = it.voxel2[i]; if (v >= 0 && v < V) pointIndices2[v % num_bins_theta][v / num_bins_theta].push_back((int)i); }
+        }
         status = it.status; error = it.error;
     }
     ~ICET() {}
+
+    // 1 (default): every member a caller in the reference reads.  2: also points1Spherical / pointIndices1 / points2Spherical / pointIndices2,
+    // which the reference keeps for its own loops and no caller reads (several MB more per object).  Process-wide, set before constructing.
+    static int& side_tables_level() { static int level = 1; return level; }
 
     void step() { rl--; }      // the reference's stub prints "step", decrements rl and does nothing else (src/icet.cpp:438-441); silent here
 
@@ -93,6 +114,8 @@ public:
     int rl; int numBinsPhi; int numBinsTheta; int n; float thresh; float buff;
 
     Eigen::MatrixXf points1, points2, points2_OG, clusterBounds, testPoints, HTWH_i, HTWdz_i;
+    Eigen::MatrixXf points1Spherical, points2Spherical;                      // filled at side_tables_level() >= 2
+    std::vector<std::vector<std::vector<int>>> pointIndices1, pointIndices2; // [theta][phi] -> ascending row indices; level 2
     Eigen::VectorXf pred_stds;
     Eigen::VectorXf X;    // global solution vector (x, y, z, roll, pitch, yaw)
     Eigen::VectorXf dx;   // last linear perturbation

@@ -98,7 +98,18 @@ typedef struct icet_aux {
                                  other row is zero (the reference leaves those rows uninitialised)                          */
     float*   points2;         /* n2 x 3 COLUMN-major, leading dimension n2 (`points2`, include/icet.h:80): scan 2 as the last
                                  fitScan2 transformed it, (p + t) * R with the X before the final update (src/icet.cpp:375-378
-                                 precede :433) -- computed on the device with the loop's own transform; scan 2 itself when runlen == 0 */
+                                 precede :433), in the CALLER's row order (the device never sorts scan 2); scan 2 itself when runlen == 0 */
+    /* The per-point members of the reference object (include/icet.h:79,82,95-96).  No caller in the reference reads them; they cost
+     * extra kernels and several MB of D2H, so they are produced only when asked for. */
+    float*   points1_spherical; /* n1 x 3 COLUMN-major (r | theta | phi), leading dimension n1 (`points1Spherical`): row p is the scan-1
+                                   point that sits at position p after the reference's radial sort + swap loop (src/icet.cpp:69-83)   */
+    int32_t* point_index1;      /* n1: `pointIndices1` flattened -- the positions (rows of points1_spherical) of voxel v, ascending,
+                                   are point_index1[bin_start1[v] .. bin_start1[v + 1])  (src/icet.cpp:86, 534-554)                   */
+    int32_t* bin_start1;        /* V + 1                                                                                              */
+    float*   points2_spherical; /* n2 x 3 COLUMN-major (r | theta | phi) of `points2` (`points2Spherical` after the last fitScan2,
+                                   src/icet.cpp:387), caller's row order                                                              */
+    int32_t* voxel2;            /* n2: the voxel sortSphericalCoordinates assigns to every row of points2 in the last fitScan2
+                                   (src/icet.cpp:388): `pointIndices2[theta][phi]` = the rows i with voxel2[i] == T * phi + theta, ascending */
 } icet_aux;
 
 typedef struct icet_ctx icet_ctx;   /* opaque: device id, stream, workspace */
@@ -188,6 +199,8 @@ icet_status icet_debug_fetch(icet_ctx* ctx, int32_t what, void* out, int64_t cou
  * DECISION (the per-voxel counts n2_raw / n2_in) but move points between the 4-point runs and the runs of one, i.e. they regroup
  * float partial sums: X agrees to rounding, not bitwise.  Names: "lds_slots", "acc_pts",
  * "acc_blocks", "kf_pts", "rs_cap", "rs_max_cell" (0: per-bucket radix sort instead of the counting sort),
+ * "graph" (device-resident batches of <= 8 pairs: when a call's launch geometry and pointers equal the previous call's, the whole
+ * solve is captured into a hipGraph and replayed from then on -- one hipGraphLaunch instead of ~33 launches on the host; 0 = never, default -1 = on),
  * "exec_bits_lds" (0: swap-loop bit table read from memory), "exec_pairwise" (which kernel computes the swap loop's executed-step bits:
  * 1 one block per pair from the recurrence, 0 chain walks over independent tiles, -1 by batch size), "batch_parts" (0 = automatic), "batch_stage" (0..4), "force_exact"
  * (every scan-2 point through the literal classification), "library_sort" (rocPRIM radix sort instead of

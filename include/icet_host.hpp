@@ -43,10 +43,13 @@ public:
     struct Deferred {};      // tag: the constructor returns once the solve is enqueued (icet_solve_begin); finish() completes the object
 
     // scan1 / scan2: column-major N x 3 (x[0..n) | y[0..n) | z[0..n)), leading dimension ld >= n.
+    // side_tables: 0 = X / pred_stds / cov only; 1 = every member a caller in the reference reads (clusterBounds, points2, the mu1 / sigma1 / U / L
+    //   tables, testPoints, HTWH_i, ellipsoid1*); 2 = also the per-point members nobody in the reference reads (points1Spherical, pointIndices1,
+    //   points2Spherical, pointIndices2: include/icet.h:79,82,95-96) -- several MB more per solve.
     // points2_out (optional): n2 x 3 column-major buffer of the caller that receives `points2` instead of the member vector.
     ICET(const float* scan1, int64_t n1, int64_t ld1, const float* scan2, int64_t n2, int64_t ld2, int runlen,
          const float X0[6], int num_bins_phi, int num_bins_theta, int n = 25, float thresh = 0.1f, float buff = 0.1f,
-         int device = 0, bool side_tables = true, float* points2_out = nullptr)
+         int device = 0, int side_tables = 1, float* points2_out = nullptr)
         : ICET(Deferred{}, scan1, n1, ld1, scan2, n2, ld2, runlen, X0, num_bins_phi, num_bins_theta, n, thresh, buff, device, side_tables, points2_out) {
         finish();
     }
@@ -55,8 +58,8 @@ public:
     // does other host work -- include/icet.h makes the reference's member copies of the scans here -- until finish().
     ICET(Deferred, const float* scan1, int64_t n1, int64_t ld1, const float* scan2, int64_t n2, int64_t ld2, int runlen,
          const float X0[6], int num_bins_phi, int num_bins_theta, int n = 25, float thresh = 0.1f, float buff = 0.1f,
-         int device = 0, bool side_tables = true, float* points2_out = nullptr)
-        : rl(runlen), numBinsPhi(num_bins_phi), numBinsTheta(num_bins_theta), n(n), thresh(thresh), buff(buff), side_tables_(side_tables) {
+         int device = 0, int side_tables = 1, float* points2_out = nullptr)
+        : rl(runlen), numBinsPhi(num_bins_phi), numBinsTheta(num_bins_theta), n(n), thresh(thresh), buff(buff), side_tables_(side_tables != 0) {
         for (int k = 0; k < 6; k++) { X[k] = X0 ? X0[k] : 0.f; x0_[k] = X[k]; pred_stds[k] = 0.f; dx[k] = 0.f; }
         cov.fill(0.f); HTWH_i.fill(0.f); HTWdz_i.fill(0.f);
         ctx_ = thread_context(device, &status);
@@ -77,6 +80,11 @@ public:
             if (n2 > 0) {
                 if (points2_out) aux.points2 = points2_out;
                 else { points2.resize((size_t)n2 * 3); aux.points2 = points2.data(); }      // (value-initialised once; overwritten by the solve)
+            }
+            if (side_tables >= 2 && runlen > 0) {
+                if (n1 > 0) { points1Spherical.resize((size_t)n1 * 3); pointIndex1.resize((size_t)n1); binStart1.assign((size_t)V + 1, 0);
+                              aux.points1_spherical = points1Spherical.data(); aux.point_index1 = pointIndex1.data(); aux.bin_start1 = binStart1.data(); }
+                if (n2 > 0) { points2Spherical.resize((size_t)n2 * 3); voxel2.resize((size_t)n2); aux.points2_spherical = points2Spherical.data(); aux.voxel2 = voxel2.data(); }
             }
         }
         status = icet_solve_begin(ctx_, &p, scan1, n1, ld1, scan2, n2, ld2, x0_, X.data(), pred_stds.data(), cov.data(), side_tables ? &aux : nullptr);
@@ -140,6 +148,11 @@ public:
     std::vector<float> clusterBounds;            // V x 6 row-major
     std::vector<float> testPoints;               // (V * 6) x 3 row-major: sigma points of the pruned axes (src/icet.cpp:213-231), zeros elsewhere
     std::vector<float> points2;                  // n2 x 3 column-major
+    // side_tables == 2 only (include/icet.h:79,82,95-96 of the reference):
+    std::vector<float> points1Spherical;         // n1 x 3 column-major (r | theta | phi): the scan-1 rows in the order the reference's sort + swap loop leaves them (src/icet.cpp:69-83)
+    std::vector<int32_t> pointIndex1, binStart1; // pointIndices1[theta][phi] = pointIndex1[binStart1[v] .. binStart1[v + 1]), v = numBinsTheta * phi + theta: rows of points1Spherical, ascending
+    std::vector<float> points2Spherical;         // n2 x 3 column-major: points2 in spherical coordinates (src/icet.cpp:387), caller's row order
+    std::vector<int32_t> voxel2;                 // n2: the voxel of every row of points2 (src/icet.cpp:388): pointIndices2[theta][phi] = the rows i with voxel2[i] == v, ascending
     // the scan-1 voxel table behind the reference's std::map members mu1 / sigma1 / U / L (include/icet.h:89-94), dense over the V voxels
     // (row v = numBinsTheta * phi + theta, src/icet.cpp:149); only rows with has_fit[v] == 1 are map entries in the reference
     std::vector<int32_t> has_fit;                // V

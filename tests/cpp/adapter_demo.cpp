@@ -50,6 +50,17 @@ int main(int argc, char** argv) {
         //seed initial estimate for next iteration
         X0 << X[0], X[1], X[2], X[3], X[4], X[5];
     }
+    if (argc > 6) {            // the per-point members at side_tables_level 2 (include/icet.h:79,82,95-96 of the reference)
+        ICET::side_tables_level() = 2;
+        X0 << 0., 0., 0., 0., 0., 0.;
+        ICET it(prev_pcl_matrix, pcl_matrix, 7, X0, 24, 75);
+        ICET::side_tables_level() = 1;
+        size_t e1 = 0, e2 = 0; long bad = 0;
+        for (const auto& th : it.pointIndices1) for (const auto& ph : th) { e1 += ph.size(); for (size_t k = 1; k < ph.size(); k++) bad += ph[k] <= ph[k - 1]; }
+        for (const auto& th : it.pointIndices2) for (const auto& ph : th) { e2 += ph.size(); for (size_t k = 1; k < ph.size(); k++) bad += ph[k] <= ph[k - 1]; }
+        double rs = 0; for (long i = 0; i < it.points1Spherical.rows(); i++) rs += it.points1Spherical(i, 0);
+        std::printf("perpoint %zu %zu %ld %ld %ld %.9g X %.9g\n", e1, e2, bad, it.points1Spherical.rows(), it.points2Spherical.rows(), rs, it.X[0]);
+    }
     const int reps = argc > 5 ? std::atoi(argv[5]) : 0;
     if (reps > 0) {
         X0 << 0., 0., 0., 0., 0., 0.;

@@ -535,9 +535,14 @@ def test_eigen_adapter_header_compiles_and_runs(tmp_path, gpu_ctx, frames):
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(root, "tests", "cpp", "mock_eigen"), "-I", os.path.join(root, "include"),
                            os.path.join(root, "tests", "cpp", "adapter_demo.cpp"), "-L", os.path.join(root, "icet_amd", "lib"), "-licet_hip",
                            "-Wl,-rpath," + os.path.join(root, "icet_amd", "lib"), "-o", exe])
-    out = subprocess.run([exe, str(tmp_path / "s1.f32"), str(tmp_path / "s2.f32"), str(a.shape[0]), str(b.shape[0])], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, str(tmp_path / "s1.f32"), str(tmp_path / "s2.f32"), str(a.shape[0]), str(b.shape[0]), "0", "full"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
+    # level 2: every scan-1 position and every scan-2 row in exactly one voxel list, ascending inside each list, r summed over points1Spherical
+    pp = [ln for ln in lines if ln.startswith("perpoint")][0].split()
+    assert [int(pp[1]), int(pp[2]), int(pp[3]), int(pp[4]), int(pp[5])] == [a.shape[0], b.shape[0], 0, a.shape[0], b.shape[0]]
+    from oracle import pyoracle as po_
+    assert abs(float(pp[6]) - float(po_.c2s(a)[:, 0].astype(np.float64).sum())) <= 1e-6 * float(pp[6])
     X1 = np.array(lines[0].split()[1:], np.float32); X2 = np.array(lines[4].split()[1:], np.float32)
     r1 = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75)
     r2 = gpu_ctx.solve(a, b, 7, r1["X"], 24, 75)
@@ -634,6 +639,35 @@ def test_constructor_path_from_pageable_host_memory(gpu_ctx, frames):
     assert np.array_equal(got["X"][0], base["X"]) and np.array_equal(got["X"][2], base["X"])
     assert np.array_equal(got["X"][1], gpu_ctx.solve(b[:40000], a[:41000], 7, np.zeros(6), 24, 75)["X"])
     ctx.close()
+
+
+def test_per_point_members_of_the_reference_object(gpu_ctx, frames):
+    """points1Spherical / pointIndices1 / points2Spherical / pointIndices2 (/root/reference/include/icet.h:79,82,95-96): produced on request
+    (aux="full").  Scan-1 members bit for bit the oracle's: points1Spherical = cartesianToSpherical of the rows in the order the sort + swap loop
+    leaves them (src/icet.cpp:69-83), pointIndices1 = the stable grouping of those positions by voxel (:534-554).  Scan-2 members: the
+    spherical coordinates and voxels of `points2` as returned (caller's row order), bit for bit the oracle's c2s / voxel rule on those floats."""
+    from oracle import pyoracle as po
+    import icet_amd
+    a, b = frames
+    T, P = 75, 24
+    g = gpu_ctx.solve(a, b, 7, np.zeros(6), P, T, aux="full")
+    base = gpu_ctx.solve(a, b, 7, np.zeros(6), P, T, aux=True)
+    ax = g["aux"]
+    assert np.array_equal(g["X"], base["X"]) and np.array_equal(ax["cluster_bounds"], base["aux"]["cluster_bounds"])
+    sph = po.c2s(a); src = po.scramble(sph[:, 0])
+    assert np.array_equal(ax["points1_spherical"].view(np.uint32), sph[src].view(np.uint32))
+    vox = po.voxel_of(sph[src], P, T)                                  # voxel of the row at every position
+    assert np.array_equal(ax["point_index1"], np.argsort(vox, kind="stable"))
+    assert np.array_equal(np.diff(ax["bin_start1"]), np.bincount(vox, minlength=T * P)) and np.array_equal(np.diff(ax["bin_start1"]), ax["n1_raw"])
+    p2 = np.ascontiguousarray(ax["points2"])
+    assert np.abs(p2 - base["aux"]["points2"]).max() < 2e-5           # device transform (FMA) against the host pass of the default level
+    s2 = po.c2s(p2)
+    assert np.array_equal(ax["points2_spherical"].view(np.uint32), s2.view(np.uint32))
+    assert np.array_equal(ax["voxel2"], po.voxel_of(s2, P, T))
+    it = icet_amd.ICET(a, b, 7, np.zeros(6, np.float32), P, T, side_tables="full")
+    v = int(np.argmax(ax["n1_raw"])); th, ph = v % T, v // T
+    assert len(it.pointIndices1) == T and len(it.pointIndices1[0]) == P and np.array_equal(it.pointIndices1[th][ph], np.nonzero(vox == v)[0])
+    assert sum(len(x) for row in it.pointIndices2 for x in row) == b.shape[0] and np.array_equal(it.pointIndices2[th][ph], np.nonzero(ax["voxel2"] == v)[0])
 
 
 def test_error_behaviour(gpu_ctx, frames):
@@ -742,6 +776,49 @@ def test_many_pairs_parity_natural_signs(gpu_ctx):
     print("%d pairs through one icet_solve_batch_device call, natural signs: outside 2e-4 m / 2e-5 rad: %s; among the unexceptional pairs max |dX_t| %.3g m, |dX_r| %.3g rad, rel pred_stds %.3g, rel cov %.3g; median |dX_t| %.3g; within 1e-4 m / 1e-5 rad: %.1f %%"
           % (N, outside, *worst, np.median(dts), 100 * within))
     assert np.median(dts) < 5e-6 and np.median(drs) < 5e-7 and within >= 0.97, (np.median(dts), np.median(drs), within)
+
+
+def test_graph_replay_of_small_device_batches(gpu_ctx):
+    """A device-resident batch of <= 8 pairs whose launch key (geometry, sizes, workspace and output pointers) repeats is captured into a
+    hipGraph at its second occurrence and replayed afterwards (option "graph", on by default).  The replay must be indistinguishable:
+    same bits as the eager launches; the descriptor table and X0 are re-read on every replay, so OTHER scans of the same size at other
+    addresses and another X0 give their own answers; a call with another key falls back to eager launches and back again."""
+    import icet_amd
+    from icet_amd import lidar_sim as ls, api
+    dev = torch.device("cuda", 0)
+    s1, s2, _ = ls.make_batch_pair(3, device=dev)
+    t2 = s2.clone(); t2[0] += 0.01                                   # another scan 2 of the same size at another address
+    d1 = [(s1.data_ptr(), s1.shape[1], s1.shape[1])]; d2 = [(s2.data_ptr(), s2.shape[1], s2.shape[1])]; e2 = [(t2.data_ptr(), t2.shape[1], t2.shape[1])]
+    prm = api.Params(7, 24, 75, 25, 0.1, 0.1, 0)
+    x0 = torch.zeros((1, 6), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    def run(ctx, scans2, out):
+        ctx.solve_batch_device(d1, scans2, prm, out.data_ptr(), x0.data_ptr()); ctx.sync()
+        return out.cpu().numpy().copy()
+
+    eager = icet_amd.Context(0); eager.set_option("graph", 0)
+    o = torch.zeros((1, 48), dtype=torch.float32, device=dev)
+    ref_a = run(eager, d2, o); ref_b = run(eager, e2, o)
+    x0[0, 0] = 0.05; torch.cuda.synchronize()
+    ref_c = run(eager, d2, o)
+    x0[0, 0] = 0.0; torch.cuda.synchronize()
+    assert not np.array_equal(ref_a, ref_b) and not np.array_equal(ref_a, ref_c)
+    g = icet_amd.Context(0)                                          # default: graph replay on
+    outs = [run(g, d2, o) for _ in range(5)]                         # eager, capture + replay, replay ...
+    assert all(np.array_equal(v, ref_a) for v in outs)
+    assert np.array_equal(run(g, e2, o), ref_b)                      # same key, other scan: the replay reads the new descriptor
+    x0[0, 0] = 0.05; torch.cuda.synchronize()
+    assert np.array_equal(run(g, d2, o), ref_c)                      # same key, other X0 contents
+    x0[0, 0] = 0.0; torch.cuda.synchronize()
+    o2 = torch.zeros((1, 48), dtype=torch.float32, device=dev)
+    assert np.array_equal(run(g, d2, o2), ref_a)                     # another output pointer = another key: eager again
+    assert np.array_equal(run(g, d2, o), ref_a) and np.array_equal(run(g, d2, o), ref_a) and np.array_equal(run(g, d2, o), ref_a)
+    two = torch.zeros((2, 48), dtype=torch.float32, device=dev)      # and a different batch size in between
+    g.solve_batch_device(d1 + d1, d2 + e2, prm, two.data_ptr()); g.sync()
+    assert np.array_equal(two[0].cpu().numpy(), ref_a[0]) and np.array_equal(two[1].cpu().numpy(), ref_b[0])
+    assert np.array_equal(run(g, d2, o), ref_a)
+    eager.close(); g.close()
 
 
 def test_keyframe_and_register_halves_equal_the_whole_solve(gpu_ctx):

@@ -220,27 +220,31 @@ def main(argv=None):
     import torch.distributed as dist
     backend = os.environ.get("ICET_BENCH_BACKEND", "nccl")      # "gloo" only for rehearsing N ranks on one card
     collective_note = None
+    g_data = None                                                  # the group the 48-float gather runs on (RCCL); None = the default (gloo) group
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            try:
-                dist.init_process_group(backend="nccl", device_id=dev)
-                probe = torch.zeros(1, device=dev)
-                dist.all_reduce(probe)                                   # the communicator is really built here: fail now, not inside the timed region
-                torch.cuda.synchronize(dev)
-            except Exception as e:                                       # RCCL unusable on this node: the 48-float gather goes through the host, and the line says so
-                sys.stderr.write("bench.py: RCCL process group failed (%s: %s); gathering through gloo instead\n" % (type(e).__name__, e))
-                try:
-                    dist.destroy_process_group()
-                except Exception:
-                    pass
-                backend = "gloo"
-                collective_note = "gloo fallback: RCCL init failed (%s)" % type(e).__name__
-                dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend=backend)
+        import datetime
+        # Control plane on gloo (barriers, the max-reduction of the timing, and the agreement below); data plane -- the one all-gather per step -- on
+        # an RCCL group of the same ranks.  Whether RCCL works is decided COLLECTIVELY (a rank falling back on its own while the others
+        # stay in the RCCL group would hang the job): every rank tries, the verdicts are min-reduced over gloo, all ranks take the same path.
+        dist.init_process_group(backend="gloo")
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+        if backend == "nccl":
+            ok, why = 1, ""
+            try:
+                g_data = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+                probe = torch.zeros(1, device=dev)
+                dist.all_reduce(probe, group=g_data)                     # the communicator is really built here: fail now, not inside the timed region
+                torch.cuda.synchronize(dev)
+            except Exception as e:
+                ok, why = 0, "%s: %s" % (type(e).__name__, e)
+                sys.stderr.write("bench.py: rank %d: RCCL group failed (%s)\n" % (rank, why))
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:                                    # some rank has no working RCCL: the 48-float gather goes through the host on EVERY rank, and the line says so
+                backend, g_data = "gloo", None
+                collective_note = "gloo fallback: RCCL group failed on at least one rank%s" % ((" (here: %s)" % why.split(":")[0]) if why else "")
 
     import icet_amd
     from icet_amd import lidar_sim, api
@@ -319,18 +323,20 @@ def main(argv=None):
 
     def step(params):
         if multi:
-            mctx.solve_batch_device(d1, d2, params, out.data_ptr())    # synchronous: returns after the gather into `out` on devices[0]
+            mctx.solve_batch_device(d1, d2, params, out.data_ptr(), asynchronous=not (params.flags & api.FLAG_TIMING))   # queued on the device threads; fence() syncs
             return out
         with torch.cuda.stream(stream):
             ctx.solve_batch_device(d1, d2, params, out.data_ptr())
             if world > 1:
                 if backend == "nccl":
-                    return gather_results(out, n_global, rank, world)
+                    return gather_results(out, n_global, rank, world, group=g_data)
                 ctx.sync()
                 return gather_results(out.cpu(), n_global, rank, world).to(dev)
         return out
 
     def fence():
+        if multi:
+            mctx.sync()                                                # every queued solve + gather has completed on every device
         for d in set(dev_ids):
             torch.cuda.synchronize(d)
         if world > 1:
@@ -352,7 +358,7 @@ def main(argv=None):
         fence()
         d = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([d], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            tt = torch.tensor([d], dtype=torch.float64)                 # control plane: gloo
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             d = float(tt.item())
         dt += d; reps_t += 1; rep_ms.append(d / max(args.steps, 1) * 1e3)
@@ -369,7 +375,7 @@ def main(argv=None):
         tg = time.perf_counter()
         with torch.cuda.stream(stream):
             for _ in range(20):
-                gather_results(out, n_global, rank, world)
+                gather_results(out, n_global, rank, world, group=g_data)
         fence()
         gather_ms = (time.perf_counter() - tg) / 20 * 1e3
 

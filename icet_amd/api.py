@@ -26,7 +26,7 @@ FLAG_HALF_GAP_BOUNDS = 8  # non-parity extension (half-gap cluster buffers of th
 # every symbol include/icet_hip.h, include/icet_nodes.h and include/icet_io.h declare
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_begin", "icet_solve_keyframe_tables", "icet_solve_end", "icet_solve_batch",
                     "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
-                    "icet_multi_solve_batch", "icet_multi_solve_batch_device", "icet_multi_solve_batch_device_after", "icet_multi_set_option",
+                    "icet_multi_solve_batch", "icet_multi_solve_batch_device", "icet_multi_solve_batch_device_after", "icet_multi_solve_batch_device_async", "icet_multi_sync", "icet_multi_set_option",
                     "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_map",
                     "icet_node_prev_scan", "icet_node_aligned", "icet_node_snail_trail", "icet_node_last_timing", "icet_stream", "icet_device",
                     "icet_load_scan", "icet_free_scan", "icet_save_scan_npy")
@@ -110,6 +110,8 @@ def load_library():
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.icet_multi_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.POINTER(DevScan), C.c_void_p, C.c_void_p]
     L.icet_multi_solve_batch_device_after.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.POINTER(DevScan), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.icet_multi_solve_batch_device_async.argtypes = L.icet_multi_solve_batch_device_after.argtypes
+    L.icet_multi_sync.argtypes = [C.c_void_p]
     L.icet_multi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.icet_node_create.argtypes = [C.c_void_p, C.POINTER(NodeParams), C.POINTER(C.c_void_p)]
     L.icet_node_destroy.argtypes = [C.c_void_p]
@@ -340,15 +342,20 @@ class MultiContext:
             if st != ICET_OK:
                 raise IcetError(st, "icet_reserve on device entry %d" % i)
 
-    def solve_batch_device(self, scan1_descs, scan2_descs, params, d_out_ptr, d_x0_ptr=None, producer_stream=None):
-        """scan*_descs[k] = (device_ptr, n, ld) on devices[k % len(devices)]; d_out / d_x0 on devices[0].  Synchronous.
-        producer_stream: raw hipStream_t of devices[0] whose queued work (the writes of d_x0 / the scans) the solve must wait for."""
+    def solve_batch_device(self, scan1_descs, scan2_descs, params, d_out_ptr, d_x0_ptr=None, producer_stream=None, asynchronous=False):
+        """scan*_descs[k] = (device_ptr, n, ld) on devices[k % len(devices)]; d_out / d_x0 on devices[0].
+        producer_stream: raw hipStream_t of devices[0] whose queued work (the writes of d_x0 / the scans) the solve must wait for.
+        asynchronous=True returns as soon as the shares are handed to the device threads; call :meth:`sync` before reading d_out."""
         k = len(scan1_descs)
         A = (DevScan * max(k, 1))(*[DevScan(int(p), int(n), int(ld)) for (p, n, ld) in scan1_descs])
         B = (DevScan * max(k, 1))(*[DevScan(int(p), int(n), int(ld)) for (p, n, ld) in scan2_descs])
-        self._check(load_library().icet_multi_solve_batch_device_after(self._h, C.byref(params), k, A, B,
-                                                                       C.c_void_p(d_x0_ptr) if d_x0_ptr else None, C.c_void_p(d_out_ptr),
-                                                                       C.c_void_p(producer_stream) if producer_stream else None))
+        fn = load_library().icet_multi_solve_batch_device_async if asynchronous else load_library().icet_multi_solve_batch_device_after
+        self._check(fn(self._h, C.byref(params), k, A, B, C.c_void_p(d_x0_ptr) if d_x0_ptr else None, C.c_void_p(d_out_ptr),
+                       C.c_void_p(producer_stream) if producer_stream else None))
+
+    def sync(self):
+        """icet_multi_sync: everything queued by asynchronous calls has completed on every device; raises the first failure."""
+        self._check(load_library().icet_multi_sync(self._h))
 
 
 _default_ctx = {}

@@ -421,6 +421,7 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
     if (reupload) { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }      // the scan-2 halves arrived after the keyframe call
     while ((int)c->ev_acc.size() < 2 * p->runlen) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_acc.push_back(e); }
     Workspace wl = w;                                    // what the loop kernels see: with ICET_FLAG_ROUNDTRIP_SCAN2 their scan 2 is the round-tripped copy
+    if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_b, c->stream));      // keyframe_ms ends here: the scan-2 pre-pass of ICET_FLAG_ROUNDTRIP_SCAN2 belongs to the loop
     if (cfg.rt2) {
         int64_t tot = 0;
         for (int k = 0; k < n_pairs; k++) tot += (c->h_desc[k].n2 + 63) / 64 * 64;
@@ -466,7 +467,6 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
     };
     if (scan2_ready) HIPCHK(c, hipStreamWaitEvent(c->stream, scan2_ready, 0));     // host-pointer entries: scan 2 was uploaded on the copy stream beside the keyframe build
     if (want_pts2 && p->runlen == 1) { const icet_status ps = enqueue_points2(); if (ps != ICET_OK) return ps; }
-    if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
     const bool per_iter = (p->flags & ICET_FLAG_TIMING) != 0;
     for (int it = 0; it < p->runlen; it++) {
         if (per_iter) HIPCHK(c, hipEventRecord(c->ev_acc[2 * it], c->stream));
@@ -590,7 +590,7 @@ static icet_status ensure_helpers(icet_ctx* c, int parts);
 icet_status icet_reserve(icet_ctx* c, const icet_params* p, int32_t n_pairs, int64_t total_n1, int64_t total_n2) {
     if (!c || !params_ok(p) || n_pairs < 0 || total_n1 < 0 || total_n2 < 0) return ICET_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    c->kf_pairs = 0;                           // a reservation may move the tables a parked keyframe lives in
+    // (a parked keyframe survives a reservation that fits the current capacity: ensure_workspace un-parks it exactly when its tables move)
     const int parts = batch_parts(c, p, n_pairs);
     if (parts > 1) {            // the batch will be solved in parts (icet_solve_batch_device); 12.5 % headroom for uneven scans
         icet_status hs = ensure_helpers(c, parts);

@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <new>
@@ -29,20 +30,20 @@
 
 namespace {
 
-// One persistent host thread per device entry.  post() hands it a job, wait() blocks until the job has run.
+// One persistent host thread per device entry with a FIFO of jobs: post() appends, wait() blocks until the queue has drained.
 struct Worker {
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    std::function<void()> job;
-    bool has_job = false, quit = false, busy = false;
+    std::deque<std::function<void()>> jobs;
+    bool quit = false, busy = false;
     void loop() {
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            cv.wait(lk, [&] { return has_job || quit; });
-            if (quit) return;
-            std::function<void()> j;
-            j.swap(job); has_job = false;
+            cv.wait(lk, [&] { return !jobs.empty() || quit; });
+            if (jobs.empty() && quit) return;
+            std::function<void()> j = std::move(jobs.front());
+            jobs.pop_front(); busy = true;
             lk.unlock();
             j();                                   // jobs catch their own exceptions (nothing may escape a thread)
             lk.lock();
@@ -52,12 +53,12 @@ struct Worker {
     }
     void post(std::function<void()> j) {
         std::lock_guard<std::mutex> lk(mu);
-        job = std::move(j); has_job = true; busy = true;
+        jobs.push_back(std::move(j));
         cv.notify_all();
     }
     void wait() {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !busy; });
+        cv.wait(lk, [&] { return jobs.empty() && !busy; });
     }
     void stop() {
         { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); }
@@ -100,6 +101,11 @@ struct icet_multi {
     std::vector<ncclComm_t> comms;       // one per device entry once gather_mode 1 has been used
     std::vector<float*> d_full;          // per device: receive buffer of the all-gather (n_devices x m x 48)
     std::vector<int32_t> cap_full;
+    // asynchronous calls: the first failure of every device since the last icet_multi_sync, and one event per device recorded behind
+    // the last gather it enqueued
+    std::vector<icet_status> st; std::vector<std::string> herr; std::vector<hipEvent_t> ev_done;
+    std::mutex st_mu;
+    bool pending = false;
     std::string err;
 };
 
@@ -155,6 +161,7 @@ icet_status icet_multi_create(icet_multi** out, const int32_t* device_ids, int32
         m->dev.assign(device_ids, device_ids + n_devices);
         m->ctx.assign(n_devices, nullptr); m->d_part.assign(n_devices, nullptr); m->cap_part.assign(n_devices, 0);
         m->d_full.assign(n_devices, nullptr); m->cap_full.assign(n_devices, 0);
+        m->st.assign(n_devices, ICET_OK); m->herr.assign(n_devices, std::string()); m->ev_done.assign(n_devices, nullptr);
         m->workers.reserve(n_devices);
         for (int i = 0; i < n_devices; i++) {
             Worker* w = new Worker();
@@ -177,6 +184,8 @@ icet_status icet_multi_create(icet_multi** out, const int32_t* device_ids, int32
         if (hipDeviceCanAccessPeer(&can, b, a) == hipSuccess && can && hipSetDevice(b) == hipSuccess) { hipError_t e = hipDeviceEnablePeerAccess(a, 0); (void)e; }
         (void)hipGetLastError();                                   // hipErrorPeerAccessAlreadyEnabled is fine
     }
+    for (int i = 0; i < n_devices; i++)
+        if (hipSetDevice(device_ids[i]) != hipSuccess || hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming) != hipSuccess) { icet_multi_destroy(m); return ICET_ERR_HIP; }
     if (hipSetDevice(device_ids[0]) != hipSuccess || hipEventCreateWithFlags(&m->ev_producer, hipEventDisableTiming) != hipSuccess) { icet_multi_destroy(m); return ICET_ERR_HIP; }
     *out = m;
     return ICET_OK;
@@ -190,6 +199,7 @@ icet_status icet_multi_destroy(icet_multi* m) {
         (void)hipSetDevice(m->dev[i]);
         if (m->d_part[i]) (void)hipFree(m->d_part[i]);
         if (i < m->d_full.size() && m->d_full[i]) (void)hipFree(m->d_full[i]);
+        if (i < m->ev_done.size() && m->ev_done[i]) (void)hipEventDestroy(m->ev_done[i]);
         if (m->ctx[i]) (void)icet_destroy(m->ctx[i]);
     }
     if (m->ev_producer) { (void)hipSetDevice(m->dev[0]); (void)hipEventDestroy(m->ev_producer); }
@@ -262,14 +272,21 @@ icet_status icet_multi_solve_batch(icet_multi* m, const icet_params* p, int32_t 
 // N independent pairs RESIDENT IN HBM: scan1[k] / scan2[k] live on device k mod n_devices (the caller placed them there, e.g. the
 // driver of a sensor rig feeding each GPU its share); d_x0 (n_pairs x 6, may be NULL) and d_out (n_pairs x 48) live on device 0 of
 // the handle.  Each device solves its share into a local buffer; the rows are then gathered into d_out (peer copies or RCCL, see
-// the head of this file), ordered after the solve on that device's stream.  Returns when the gather has completed (the call
-// synchronises every device's stream).
+// the head of this file), ordered after the solve on that device's stream.
 // ORDERING.  The devices' streams are the contexts' own; they know nothing about the stream that produced d_x0 / the scans or that
 // last used d_out.  `producer_stream` (a hipStream_t of device_ids[0] passed as void*, NULL = none) closes that gap for work queued
 // on ONE stream: an event recorded on it when the call starts is waited for by every device's stream.  Anything else -- scans
 // written on other devices' streams -- must have completed before the call.
-icet_status icet_multi_solve_batch_device_after(icet_multi* m, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1, const icet_dev_scan* scan2,
-                                                const float* d_x0, float* d_out, void* producer_stream) {
+// ASYNCHRONOUS FORM.  icet_multi_solve_batch_device_async hands every device's share to its host thread and returns at once: the
+// threads enqueue the solve and the gather on their streams and record an event behind them; nothing waits for the device.  Calls queue
+// up behind each other (per device: one FIFO of jobs, one stream).  icet_multi_sync waits for the threads and for the events and
+// reports the first failure since the last sync.  The synchronous entries are async + sync.
+// Two phases per call, because a rank that skipped the RCCL collective would hang the others: (1) everything that can fail before the
+// collective for reasons of the HOST (device selection, buffer growth) runs first on every thread and is checked on the calling
+// thread -- it allocates only when a capacity grows; (2) only then are the solve + gather jobs posted, and a job whose solve fails
+// still enters the collective with what it has.
+static icet_status multi_enqueue(icet_multi* m, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1, const icet_dev_scan* scan2,
+                                 const float* d_x0, float* d_out, void* producer_stream) {
     if (!m) return ICET_ERR_BAD_ARG;
     if (!p || n_pairs < 0 || (n_pairs > 0 && (!scan1 || !scan2 || !d_out))) { m->err = "bad argument"; return ICET_ERR_BAD_ARG; }
     if (n_pairs == 0) return ICET_OK;
@@ -282,43 +299,67 @@ icet_status icet_multi_solve_batch_device_after(icet_multi* m, const icet_params
             m->err = "cannot record an event on producer_stream (is it a stream of device_ids[0]?)"; (void)hipGetLastError(); return ICET_ERR_BAD_ARG;
         }
     }
-    std::vector<icet_status> st; std::vector<std::string> herr;
-    try { st.assign(D, ICET_OK); herr.assign(D, std::string()); } catch (...) { m->err = "out of host memory"; return ICET_ERR_NOMEM; }
-    icet_status* stp = st.data(); std::string* herrp = herr.data();
     const int mrows = (n_pairs + D - 1) / D;              // largest share: the all-gather's (padded) count per rank
-    try {
-        run_all(m, [=](int d) {
-            try {
-                std::vector<icet_dev_scan> a, b;
-                for (int k = d; k < n_pairs; k += D) { a.push_back(scan1[k]); b.push_back(scan2[k]); }
-                const int np = (int)a.size();
-                if (hipSetDevice(m->dev[d]) != hipSuccess) { stp[d] = ICET_ERR_NO_DEVICE; return; }
+    // ---- phase 1: buffers (only when a capacity grows; earlier jobs of the device must have drained before its buffers move) ----
+    bool grow = false;
+    for (int d = 0; d < D; d++) {
+        const int np = (n_pairs - d + D - 1) / D;
+        if ((mode == 1 ? mrows : np) > m->cap_part[d] || (mode == 1 && D * mrows > m->cap_full[d])) grow = true;
+    }
+    if (grow) {
+        std::vector<icet_status> st1;
+        try { st1.assign(D, ICET_OK); } catch (...) { m->err = "out of host memory"; return ICET_ERR_NOMEM; }
+        icet_status* s1 = st1.data();
+        try {
+            run_all(m, [=](int d) {
+                const int np = (n_pairs - d + D - 1) / D;
+                const int need = mode == 1 ? mrows : np;
+                if (hipSetDevice(m->dev[d]) != hipSuccess) { s1[d] = ICET_ERR_NO_DEVICE; return; }
                 hipStream_t s = reinterpret_cast<hipStream_t>(icet_stream(m->ctx[d]));
-                const int need = mode == 1 ? mrows : np;           // RCCL: every rank sends the same (padded) count
+                if (hipStreamSynchronize(s) != hipSuccess) { s1[d] = ICET_ERR_HIP; return; }
                 if (need > m->cap_part[d]) {
                     if (m->d_part[d]) { (void)hipFree(m->d_part[d]); m->d_part[d] = nullptr; m->cap_part[d] = 0; }
                     // results (48 floats) and the share's X0 (6 floats) per pair
-                    if (hipMalloc(reinterpret_cast<void**>(&m->d_part[d]), sizeof(float) * 54 * (size_t)need) != hipSuccess) { stp[d] = ICET_ERR_NOMEM; return; }
+                    if (hipMalloc(reinterpret_cast<void**>(&m->d_part[d]), sizeof(float) * 54 * (size_t)need) != hipSuccess) { s1[d] = ICET_ERR_NOMEM; return; }
                     (void)hipMemsetAsync(m->d_part[d], 0, sizeof(float) * 54 * (size_t)need, s);
                     m->cap_part[d] = need;
                 }
                 if (mode == 1 && D * mrows > m->cap_full[d]) {
                     if (m->d_full[d]) { (void)hipFree(m->d_full[d]); m->d_full[d] = nullptr; m->cap_full[d] = 0; }
-                    if (hipMalloc(reinterpret_cast<void**>(&m->d_full[d]), sizeof(float) * 48 * (size_t)D * mrows) != hipSuccess) { stp[d] = ICET_ERR_NOMEM; return; }
+                    if (hipMalloc(reinterpret_cast<void**>(&m->d_full[d]), sizeof(float) * 48 * (size_t)D * mrows) != hipSuccess) { s1[d] = ICET_ERR_NOMEM; return; }
                     m->cap_full[d] = D * mrows;
                 }
+            });
+        } catch (...) {
+            for (int d = 0; d < D; d++) m->workers[d]->wait();
+            m->err = "cannot hand the work to the device threads"; return ICET_ERR_NOMEM;
+        }
+        for (int d = 0; d < D; d++) if (st1[d] != ICET_OK) { m->err = "device " + std::to_string(m->dev[d]) + ": cannot grow the result buffers"; return st1[d]; }
+    }
+    // ---- phase 2: solve + gather, asynchronously.  The shares are cut here (the caller's descriptor arrays need not outlive the call) ----
+    const icet_params prm = *p;
+    try {
+        std::vector<std::vector<icet_dev_scan>> as(D), bs(D);
+        for (int k = 0; k < n_pairs; k++) { as[k % D].push_back(scan1[k]); bs[k % D].push_back(scan2[k]); }
+        m->pending = true;
+        for (int d = 0; d < D; d++) {
+            m->workers[d]->post([m, d, D, mode, mrows, n_pairs, prm, d_x0, d_out, wait_producer, a = std::move(as[d]), b = std::move(bs[d])]() {
+                icet_status st = ICET_OK; std::string why;
+                const int np = (int)a.size();
+                hipError_t e = hipSetDevice(m->dev[d]);
+                hipStream_t s = reinterpret_cast<hipStream_t>(icet_stream(m->ctx[d]));
                 float* part = m->d_part[d]; float* px0 = part + 48 * (size_t)m->cap_part[d];
-                hipError_t e = hipSuccess;
-                if (wait_producer) e = hipStreamWaitEvent(s, m->ev_producer, 0);
+                if (e == hipSuccess && wait_producer) e = hipStreamWaitEvent(s, m->ev_producer, 0);
                 // this device's rows of X0: rows d, d + D, ... of the buffer on device 0 (a strided peer copy; same device when d == 0)
                 if (e == hipSuccess && d_x0 && np) e = hipMemcpy2DAsync(px0, 6 * sizeof(float), d_x0 + 6 * (size_t)d, 6 * sizeof(float) * D, 6 * sizeof(float), np, hipMemcpyDefault, s);
-                if (e != hipSuccess) { herrp[d] = hipGetErrorString(e); stp[d] = ICET_ERR_HIP; return; }
-                if (np) stp[d] = icet_solve_batch_device(m->ctx[d], p, np, a.data(), b.data(), d_x0 ? px0 : nullptr, part);
-                if (stp[d] != ICET_OK) { if (mode != 1) return; /* RCCL: a rank that skipped the collective would hang the others -- send what there is */ }
+                if (e != hipSuccess) { why = hipGetErrorString(e); st = ICET_ERR_HIP; }
+                if (st == ICET_OK && np) { st = icet_solve_batch_device(m->ctx[d], &prm, np, a.data(), b.data(), d_x0 ? px0 : nullptr, part); if (st != ICET_OK) why = icet_last_error(m->ctx[d]); }
+                // (a failure above does NOT skip the collective: the other ranks have queued theirs and would wait for this one for ever)
+                e = hipSuccess;
                 if (mode == 1) {
                     ncclResult_t r = m->rccl.AllGather(part, m->d_full[d], (size_t)mrows * 48, ncclFloat, m->comms[d], s);
-                    if (r != ncclSuccess) { herrp[d] = std::string("ncclAllGather: ") + m->rccl.GetErrorString(r); if (stp[d] == ICET_OK) stp[d] = ICET_ERR_HIP; return; }
-                    if (d == 0) {
+                    if (r != ncclSuccess) { if (st == ICET_OK) { st = ICET_ERR_HIP; why = std::string("ncclAllGather: ") + m->rccl.GetErrorString(r); } }
+                    else if (d == 0) {
                         // undo the round-robin interleave on the gathering device: block r of the receive buffer holds pairs r, r + D, ...
                         for (int r2 = 0; r2 < D && e == hipSuccess; r2++) {
                             const int rows = (n_pairs - r2 + D - 1) / D;
@@ -326,22 +367,47 @@ icet_status icet_multi_solve_batch_device_after(icet_multi* m, const icet_params
                                                                48 * sizeof(float), rows, hipMemcpyDeviceToDevice, s);
                         }
                     }
-                } else if (np) {
+                } else if (np && st == ICET_OK) {
                     e = hipMemcpy2DAsync(d_out + 48 * (size_t)d, 48 * sizeof(float) * D, part, 48 * sizeof(float), 48 * sizeof(float), np, hipMemcpyDefault, s);
                 }
-                if (e == hipSuccess) e = hipStreamSynchronize(s);
-                if (e != hipSuccess) { herrp[d] = hipGetErrorString(e); if (stp[d] == ICET_OK) stp[d] = ICET_ERR_HIP; }
-            } catch (...) { stp[d] = ICET_ERR_NOMEM; }
-        });
-    } catch (...) {
-        for (int d = 0; d < D; d++) m->workers[d]->wait();
+                if (e == hipSuccess) e = hipEventRecord(m->ev_done[d], s);
+                if (e != hipSuccess && st == ICET_OK) { st = ICET_ERR_HIP; why = hipGetErrorString(e); }
+                if (st != ICET_OK) { std::lock_guard<std::mutex> lk(m->st_mu); if (m->st[d] == ICET_OK) { m->st[d] = st; try { m->herr[d] = why; } catch (...) {} } }
+            });
+        }
+    } catch (...) {                                     // cutting the shares or posting a job allocates: the jobs already posted still run and are collected by the sync
         m->err = "cannot hand the work to the device threads"; return ICET_ERR_NOMEM;
     }
-    for (int d = 0; d < D; d++) if (st[d] != ICET_OK) {
-        if (!herr[d].empty()) m->err = "gather (device " + std::to_string(m->dev[d]) + "): " + herr[d]; else set_err(m, d, m->ctx[d], "icet_solve_batch_device");
-        return st[d];
-    }
     return ICET_OK;
+}
+
+icet_status icet_multi_sync(icet_multi* m) {
+    if (!m) return ICET_ERR_BAD_ARG;
+    const int D = (int)m->dev.size();
+    for (int d = 0; d < D; d++) m->workers[d]->wait();              // every job has enqueued its work and recorded its event
+    icet_status first = ICET_OK;
+    for (int d = 0; d < D; d++) {
+        hipError_t e = m->pending ? hipSetDevice(m->dev[d]) : hipSuccess;
+        if (e == hipSuccess && m->pending) e = hipStreamSynchronize(reinterpret_cast<hipStream_t>(icet_stream(m->ctx[d])));
+        std::lock_guard<std::mutex> lk(m->st_mu);
+        if (e != hipSuccess && m->st[d] == ICET_OK) { m->st[d] = ICET_ERR_HIP; m->herr[d] = hipGetErrorString(e); }
+        if (m->st[d] != ICET_OK && first == ICET_OK) { first = m->st[d]; m->err = "device " + std::to_string(m->dev[d]) + ": " + m->herr[d]; }
+        m->st[d] = ICET_OK; m->herr[d].clear();
+    }
+    m->pending = false;
+    return first;
+}
+
+icet_status icet_multi_solve_batch_device_async(icet_multi* m, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1, const icet_dev_scan* scan2,
+                                                const float* d_x0, float* d_out, void* producer_stream) {
+    return multi_enqueue(m, p, n_pairs, scan1, scan2, d_x0, d_out, producer_stream);
+}
+
+icet_status icet_multi_solve_batch_device_after(icet_multi* m, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1, const icet_dev_scan* scan2,
+                                                const float* d_x0, float* d_out, void* producer_stream) {
+    const icet_status s = multi_enqueue(m, p, n_pairs, scan1, scan2, d_x0, d_out, producer_stream);
+    if (s != ICET_OK) { if (m) (void)icet_multi_sync(m); return s; }
+    return n_pairs > 0 ? icet_multi_sync(m) : ICET_OK;
 }
 
 icet_status icet_multi_solve_batch_device(icet_multi* m, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1, const icet_dev_scan* scan2,

@@ -243,6 +243,16 @@ icet_status icet_multi_solve_batch_device_after(icet_multi* handle, const icet_p
                                                 const icet_dev_scan* scan1, const icet_dev_scan* scan2, const float* d_x0, float* d_out,
                                                 void* producer_stream);
 
+/* The asynchronous form (review r3: the synchronous entry cost one process ~9 % against the stream-ordered single-context path, and eight
+ * GPUs driven from one thread would start behind).  _async hands every device's share to its host thread and returns at once -- the
+ * caller's descriptor arrays are copied, nothing waits for a device; calls queue up behind each other in order.  icet_multi_sync waits
+ * until everything queued so far has completed on every device (d_out is then valid) and returns the first failure since the last sync.
+ * producer_stream as in the _after form (NULL = none). */
+icet_status icet_multi_solve_batch_device_async(icet_multi* handle, const icet_params* p, int32_t n_pairs,
+                                                const icet_dev_scan* scan1, const icet_dev_scan* scan2, const float* d_x0, float* d_out,
+                                                void* producer_stream);
+icet_status icet_multi_sync(icet_multi* handle);
+
 #ifdef __cplusplus
 }
 #endif

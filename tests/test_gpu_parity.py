@@ -955,6 +955,22 @@ def test_multi_device_sharding_with_shards_sharing_one_gpu(gpu_ctx, frames, samp
     ctx = icet_amd.Context(0); ctx.solve_batch_device(d1, d2, prm, o_single.data_ptr(), xd.data_ptr()); ctx.sync(); ctx.close()
     torch.cuda.synchronize()
     assert torch.equal(o_multi, o_single) and bool(torch.isfinite(o_multi).all())
+    # the asynchronous form: three calls queued back to back (other output buffers, another X0, fewer pairs), ONE sync at the end
+    outs = [torch.full((n, 48), float("nan"), dtype=torch.float32, device=dev) for _ in range(3)]
+    xd2 = xd + 0.01
+    torch.cuda.synchronize()
+    m.solve_batch_device(d1, d2, prm, outs[0].data_ptr(), xd.data_ptr(), asynchronous=True)
+    m.solve_batch_device(d1, d2, prm, outs[1].data_ptr(), xd2.data_ptr(), asynchronous=True)
+    m.solve_batch_device(d1[:3], d2[:3], prm, outs[2].data_ptr(), xd.data_ptr(), asynchronous=True)
+    m.sync()
+    ctx = icet_amd.Context(0); o2 = torch.zeros_like(o_single)
+    ctx.solve_batch_device(d1, d2, prm, o2.data_ptr(), xd2.data_ptr()); ctx.sync(); ctx.close()
+    assert torch.equal(outs[0], o_single) and torch.equal(outs[1], o2) and torch.equal(outs[2][:3], o_single[:3]) and bool(torch.isnan(outs[2][3:]).all())
+    with pytest.raises(icet_amd.IcetError):                          # a failing call (no such grid) is reported by the sync, and the handle stays usable
+        m.solve_batch_device(d1, d2, api.Params(7, 400, 400, 25, 0.1, 0.1, 0), outs[0].data_ptr(), asynchronous=True)
+        m.sync()
+    m.solve_batch_device(d1, d2, prm, outs[0].data_ptr(), xd.data_ptr(), asynchronous=True); m.sync()
+    assert torch.equal(outs[0], o_single)
     m.close()
 
 

@@ -31,6 +31,7 @@ constexpr int kKfMaxPtsPerThread = ICET_KF_MAXPTS;   // keyframe kernels: larges
 // ICET_ERR_UNSUPPORTED instead of failing a launch mid-sequence.  Voxel ids travel in 14 bits of a 16-bit word whose two top
 // bits carry per-row flags (kRowNearBit, kRowExecBit); slot ids travel as int16.
 constexpr int kMaxVoxels = 10000;
+constexpr int kGnPartWords = 4 * 20 * 27; // Workspace::gn_part (icet_solve.hip: at most 4 pairs x 20 virtual blocks of 512 slots x 27 partial sums)
 constexpr uint16_t kRowExecBit = 0x8000u;   // (free since the swap-loop flags moved to a bit table; stays clear)
 constexpr uint16_t kRowNearBit = 0x4000u;   // the row lies within a guard band of a voxel edge: its azimuth / polar bounds test must be done with the literal formulas
 constexpr uint16_t kRowBinMask = 0x3FFFu;
@@ -112,6 +113,7 @@ struct Workspace {
     // k_gn_solve.  Empty on ordinary data (~0.02 % of the points are undecided and a block's queue holds 512 of them).
     uint32_t* near_over = nullptr; int64_t cap_n2 = 0; uint32_t* near_over_count = nullptr;
     float* xf = nullptr;                      // pairs x 48: t[3], R[9] row-major, angles[3], pad, J[27] (see write_xf)
+    float* gn_part = nullptr;                 // two-stage solve of fine grids: kGnPartWords floats of partial sums (icet_solve.hip)
     float* X = nullptr;                       // pairs x 6
     int32_t* flags = nullptr;                 // pairs: bit0 = scramble walk overflow
     int32_t* vrange = nullptr;                // pairs x 2: smallest / largest voxel id any scan-1 row of the pair has: the voxel multi-split's tables are touched inside it only

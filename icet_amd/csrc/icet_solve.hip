@@ -17,6 +17,10 @@ namespace {
 // J[27] (get_H's three derivative matrices, src/icet.cpp:507-529).  Written once per iteration by the lane that updates
 // X, so the six sin/cos are evaluated once and serve both the next point pass (R) and the next voxel pass (J).
 constexpr int kXf = 48;
+constexpr int kTwoStageBlocks = 3;        // first-stage blocks per pair of the two-stage solve (3 x 512 slots: one round for up to 1536 active voxels)
+constexpr int kTwoStageMaxPairs = 4;      // the two-stage form is for small batches on fine grids; a throughput batch has a block per CU anyway
+constexpr int kMaxVirtualBlocks = (kMaxVoxels + 511) / 512;     // 20
+static_assert(kTwoStageMaxPairs * kMaxVirtualBlocks * 27 <= kGnPartWords, "Workspace::gn_part");
 __device__ __forceinline__ void write_xf(float* xf, const float X[6]) {
     const float phi = X[3], theta = X[4], psi = X[5];
     float sph, cph, sth, cth, sps, cps;
@@ -71,13 +75,27 @@ __device__ __noinline__ void drain_near_overflow(const NearOverflow& o, int pair
 
 // kT threads per block: 256 for ordinary grids (a 64-channel scan on 75 x 24 has ~220 active voxels: one round), 512 -- the most that 248 VGPRs allow --
 // for fine grids (150 x 48: > 1000 active voxels, three rounds of the per-voxel algebra instead of five)
-template <int kT>
+// kStage 0: everything in ONE block per pair (coarse grids, batches).  The two-stage form of fine grids and small batches (a 150 x 48 grid has
+// > 1000 active voxels: three rounds of the per-voxel algebra in one block): kStage 1 = `nblk` blocks per pair, each reduces the contributions of
+// its share of the slots to 27 partial sums in HBM; kStage 2 = one block per pair adds the partials and runs the 6 x 6 part.  Undecided points
+// waiting in the overflow list must be drained before any sum is read, which one block cannot do for the others: stage 1 then declines (every
+// block sees the same count) and stage 2 runs the whole solve like stage 0.
+// So that a pair's bits do not depend on which form solved it, fine grids (kT = 512) reduce in ONE canonical tree in every form: the slots in
+// "virtual blocks" of 512 (slot s belongs to virtual block s / 512, lane s % 512), each virtual block to its 27 sums (DPP totals of its eight
+// waves, added in wave order), the virtual blocks added in index order.  Coarse grids (kT = 256, one block per pair always) keep one reduction
+// over whatever a thread accumulated.
+template <int kT, int kStage>
 __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_slots, const SlotFit* __restrict__ fitS, uint32_t* __restrict__ acc,
                                                      float* __restrict__ X_all, float* __restrict__ xf_all, float* __restrict__ out, AuxDev aux,
-                                                     int V, int n, int iter, int runlen, NearOverflow over, int reject_moving) {
+                                                     int V, int n, int iter, int runlen, NearOverflow over, int reject_moving, float* __restrict__ part, int nblk) {
+    constexpr bool kCanon = kT == 512;
+    static_assert(kStage == 0 || kCanon, "the two-stage form reduces in virtual blocks of 512 slots");
     __shared__ float J[27];
     __shared__ float red[kT / 64][27];
-    const int pair = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float vpart[kCanon ? kMaxVirtualBlocks : 1][27];     // the virtual blocks' sums when ONE block walks them all (stage 0, or stage 2 after a drain)
+    const int pair = kStage == 1 ? (int)blockIdx.x / nblk : (int)blockIdx.x, blk = kStage == 1 ? (int)blockIdx.x % nblk : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_first = blk * kT + (int)threadIdx.x, vb_stride = kStage == 1 ? nblk : 1;
     float* X = X_all + pair * 6;
     // The block is a chain of dependent latencies, so everything it will need is requested up front: the two counts, the Jacobian
     // table and -- speculatively, for slot threadIdx.x, before the number of slots is known (any slot < V is valid memory) -- the
@@ -91,23 +109,28 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
 #pragma unroll
         for (int k = 0; k < 5; k++) r.q[k] = q[k];
         return r; };
+    if (kStage == 1 && nov) return;                                     // block-uniform (and the same in every block of the pair): stage 2 does the whole solve
+    const bool from_partials = kStage == 2 && nov == 0u;                // stage 1 has reduced the slots already
     Rec accR{}, fitR{};
-    if ((int)threadIdx.x < V) { accR = load_rec(acc + ((size_t)pair * V + threadIdx.x) * kAccWords); fitR = load_rec(fitS + (size_t)pair * V + threadIdx.x); }
+    if (!from_partials && s_first < V) { accR = load_rec(acc + ((size_t)pair * V + s_first) * kAccWords); fitR = load_rec(fitS + (size_t)pair * V + s_first); }
     if (nov) {
         drain_near_overflow(over, pair, V, xf_all + pair * kXf, acc + (size_t)pair * V * kAccWords, nov);
         __threadfence();                                                // this block reads the sums it has just added to
         __syncthreads();
         if (threadIdx.x == 0) over.count[pair] = 0u;
-        if ((int)threadIdx.x < V) accR = load_rec(acc + ((size_t)pair * V + threadIdx.x) * kAccWords);   // the speculative copy predates the drain
+        if (s_first < V) accR = load_rec(acc + ((size_t)pair * V + s_first) * kAccWords);   // the speculative copy predates the drain
     }
     if (threadIdx.x < 27) J[threadIdx.x] = jmine;
     __syncthreads();
     float S[27];
 #pragma unroll
     for (int k = 0; k < 27; k++) S[k] = 0.f;
-    for (int s = threadIdx.x; s < ns; s += kT) {
+    const int nvb = from_partials ? 0 : (ns + kT - 1) / kT;             // rounds = virtual blocks of kT slots
+    for (int vb = blk; vb < nvb; vb += vb_stride) {
+      const int s = vb * kT + (int)threadIdx.x;
+      if (s < ns) do {
         uint32_t* A = acc + ((size_t)pair * V + s) * kAccWords;
-        if (s != (int)threadIdx.x) { accR = load_rec(A); fitR = load_rec(fitS + (size_t)pair * V + s); }       // later rounds
+        if (s != s_first) { accR = load_rec(A); fitR = load_rec(fitS + (size_t)pair * V + s); }       // later rounds
         uint32_t aw[kAccWords];
         __builtin_memcpy(aw, &accR, sizeof(Rec));
         const uint32_t n2 = aw[0], m = aw[1];
@@ -127,7 +150,7 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
         __builtin_memcpy(&f, &fitR, sizeof(SlotFit));
         if (aux.n2_raw) aux.n2_raw[((size_t)pair * runlen + iter) * V + f.v] = (int)n2;
         if (aux.n2_in) aux.n2_in[((size_t)pair * runlen + iter) * V + f.v] = (int)m;
-        if (!((int)n2 > n && (int)m > n)) continue;               // src/icet.cpp:290 (scan-2 half), :302
+        if (!((int)n2 > n && (int)m > n)) break;                  // src/icet.cpp:290 (scan-2 half), :302  (`break` leaves the do { } while (0) of this slot)
         // mean and covariance of the m surviving points from the sums about mu1 (src/icet.cpp:303-306), in DOUBLE: the scatter in
         // a voxel's thin direction (1e-6 m^2 for a single-ring line) is what is left of sum(d d^T) ~ m |mu2 - mu1|^2 (1e-2) after the
         // subtraction -- in float that cancellation cost percents of the voxel's weight (round 2, scripts/diag_voxel.py)
@@ -152,7 +175,7 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
         for (int i = 0; i < 3; i++) dz[i] = M[3 * i] * db[0] + M[3 * i + 1] * db[1] + M[3 * i + 2] * db[2];
         // extension (ICET_FLAG_REJECT_MOVING): a voxel whose compact residual is beyond the cutoff in a kept axis is a moving object
         if (reject_moving && iter >= kRejectMovingStartIter &&
-            (fabsf(dz[0]) > kRejectMovingThresh || fabsf(dz[1]) > kRejectMovingThresh || fabsf(dz[2]) > kRejectMovingThresh)) continue;
+            (fabsf(dz[0]) > kRejectMovingThresh || fabsf(dz[1]) > kRejectMovingThresh || fabsf(dz[2]) > kRejectMovingThresh)) break;
         // Rp = M Rn M^T  (M = L U^T)                                             src/icet.cpp:317
         float MR[9];
 #pragma unroll
@@ -200,15 +223,37 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
         }
 #pragma unroll
         for (int a = 0; a < 6; a++) S[21 + a] += WH[a] * dz[0] + WH[6 + a] * dz[1] + WH[12 + a] * dz[2];
-    }
+      } while (0);
+      if (kCanon) {                                                   // this virtual block's 27 sums, now
 #pragma unroll
-    for (int k = 0; k < 27; k++) { float t = wave_total(S[k]); if (lane == 0) red[wave][k] = t; }      // DPP scan, not 6 x 27 trips through the LDS crossbar
-    __syncthreads();
+          for (int k = 0; k < 27; k++) { float t = wave_total(S[k]); if (lane == 0) red[wave][k] = t; S[k] = 0.f; }
+          __syncthreads();
+          if (threadIdx.x < 27) {
+              float t = 0.f; for (int w = 0; w < kT / 64; w++) t += red[w][threadIdx.x];
+              if (kStage == 1) part[((size_t)pair * kMaxVirtualBlocks + vb) * 27 + threadIdx.x] = t; else vpart[vb][threadIdx.x] = t;
+          }
+          __syncthreads();
+      }
+    }
+    if (kStage == 1) return;
+    if (!kCanon) {
+#pragma unroll
+        for (int k = 0; k < 27; k++) { float t = wave_total(S[k]); if (lane == 0) red[wave][k] = t; }      // DPP scan, not 6 x 27 trips through the LDS crossbar
+        __syncthreads();
+    }
     if (wave != 0) return;
     // The 6 x 6 part runs on lane 0 of the first wave; its lanes assemble the input and write the results out (one lane doing the
     // 27 four-way sums and ~100 scalar stores was a quarter of the tail).
     __shared__ float stage[kXf + 48];                               // transform record | X, pred_stds, covariance
-    if (lane < 27) { float t = 0.f; for (int w = 0; w < kT / 64; w++) t += red[w][lane]; stage[lane] = t; }
+    if (lane < 27) {
+        float t = 0.f;
+        if (kCanon) {                                               // the virtual blocks in index order, from wherever they were reduced
+            const int nv = (ns + kT - 1) / kT;
+            if (from_partials) { for (int b = 0; b < nv; b++) t += part[((size_t)pair * kMaxVirtualBlocks + b) * 27 + lane]; }
+            else { for (int b = 0; b < nv; b++) t += vpart[b][lane]; }
+        } else { for (int w = 0; w < kT / 64; w++) t += red[w][lane]; }
+        stage[lane] = t;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     float Hm[36], g[6];
     {
@@ -336,8 +381,15 @@ hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* x
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* auxp, hipStream_t st) {
     AuxDev aux{}; if (auxp) aux = *auxp;
     NearOverflow over{w.desc, w.slot_of_voxel, w.hotS, w.thr, w.near_over, w.near_over_count, c.T, c.P, c.rt2};
-    if (c.V > 4096) k_gn_solve<512><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving);
-    else k_gn_solve<kBlock><<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving);
+    if (c.V > 4096 && c.n_pairs <= kTwoStageMaxPairs && w.gn_part) {
+        // two stages: several blocks per pair reduce their share of the slots to 27 partial sums each, one block per pair adds them and solves
+        const int nblk = kTwoStageBlocks;
+        k_gn_solve<512, 1><<<c.n_pairs * nblk, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk);
+        ICET_LAUNCH_CHECK();
+        k_gn_solve<512, 2><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk);
+    }
+    else if (c.V > 4096) k_gn_solve<512, 0><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1);
+    else k_gn_solve<kBlock, 0><<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

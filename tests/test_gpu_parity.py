@@ -778,6 +778,31 @@ def test_many_pairs_parity_natural_signs(gpu_ctx):
     assert np.median(dts) < 5e-6 and np.median(drs) < 5e-7 and within >= 0.97, (np.median(dts), np.median(drs), within)
 
 
+def test_two_stage_solve_gives_the_bits_of_the_one_block_solve(gpu_ctx, sample_pc):
+    """Fine grids (V > 4096) in small batches (<= 4 pairs) reduce H^T W H in two stages -- three blocks per pair reduce their share of the
+    active voxels to 27 partial sums, one block adds them and runs the 6 x 6 part (BASELINE north_star's "two-stage reduction") -- larger
+    batches in one block per pair.  Every form adds in ONE canonical tree (virtual blocks of 512 slots), so a pair gives the same bits
+    alone (two stages), inside a batch of 6 (one block), and when undecided points wait in the overflow list (force_exact: stage 1
+    declines, stage 2 drains and solves alone)."""
+    import icet_amd
+    from icet_amd import api
+    dev = torch.device("cuda", 0)
+    a, b = sample_pc
+    ta = torch.from_numpy(np.ascontiguousarray(a.T)).to(dev); tb = torch.from_numpy(np.ascontiguousarray(b.T)).to(dev)
+    d1 = [(ta.data_ptr(), a.shape[0], a.shape[0])]; d2 = [(tb.data_ptr(), b.shape[0], b.shape[0])]
+    prm = api.Params(6, 48, 150, 25, 0.1, 0.1, 0)
+    for exact in (0, 1):
+        ctx = icet_amd.Context(0); ctx.set_option("force_exact", exact); ctx.set_option("graph", 0)
+        one = torch.zeros((1, 48), dtype=torch.float32, device=dev); six = torch.zeros((6, 48), dtype=torch.float32, device=dev)
+        ctx.solve_batch_device(d1, d2, prm, one.data_ptr()); ctx.sync()
+        ctx.solve_batch_device(d1 * 6, d2 * 6, prm, six.data_ptr()); ctx.sync()
+        assert bool(torch.isfinite(one).all()) and all(torch.equal(six[k], one[0]) for k in range(6)), exact
+        if exact == 0:
+            host = gpu_ctx.solve(a, b, 6, np.zeros(6), 48, 150)             # icet_solve: one pair, two stages
+            assert np.array_equal(host["X"], one[0, :6].cpu().numpy())
+        ctx.close()
+
+
 def test_graph_replay_of_small_device_batches(gpu_ctx):
     """A device-resident batch of <= 8 pairs whose launch key (geometry, sizes, workspace and output pointers) repeats is captured into a
     hipGraph at its second occurrence and replayed afterwards (option "graph", on by default).  The replay must be indistinguishable:

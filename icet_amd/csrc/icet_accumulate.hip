@@ -71,7 +71,9 @@ __device__ __noinline__ void flush_wide(unsigned long long* F, float a0, float a
 
 constexpr int kCntBits = 21;            // LDS count word: three 21-bit fields
 constexpr unsigned long long kCntMask = (1ull << kCntBits) - 1ull;
-constexpr uint32_t kNearCap = 512;      // undecided points a block parks in LDS (2 KB); the rest goes to the per-pair overflow list in HBM
+constexpr uint32_t kNearCap = 512;      // undecided points a block of a THROUGHPUT batch parks in LDS (2 KB); the rest goes to the per-pair overflow list in HBM
+constexpr uint32_t kNearCapSmall = 2048;  // small batches (a block has most of a CU's LDS): a whole 2048-point chunk -- the thousands of exact-zero rows of a real scan are
+                                        // undecided points in the first iteration, and the overflow list is drained by ONE block of k_gn_solve (36 - 62 us on the reference's sample pairs)
 
 typedef __attribute__((address_space(1))) const float gfloat;
 typedef float vfloat4 __attribute__((ext_vector_type(4)));
@@ -79,14 +81,17 @@ typedef __attribute__((address_space(1))) const vfloat4 gfloat4;
 
 // kRT2 (ICET_FLAG_ROUNDTRIP_SCAN2, a parity-study option): an in-bounds point enters the sums as sphericalToCartesian(cartesianToSpherical(q))
 // (src/icet.cpp:303) -- a double-precision atan2 + acos inside the loop, in a kernel of its own so that the default kernel keeps its registers.
-template <bool kVec4, bool kRT2>
-__global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_accumulate(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
+// kSmall: a small batch's block (one per CU, nearly all of its LDS) parks up to kNearCapSmall undecided points instead of kNearCap -- a template
+// parameter, not an argument: one more live scalar in this loop costs SGPR spills and, through them, 25 spilled VGPRs (measured: +5 % per launch).
+template <bool kVec4, bool kRT2, bool kSmall>
+__global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : (kSmall ? 2 : kAccWavesPerSimd)) void k_gn_accumulate(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
                                                           const int16_t* __restrict__ slot_of_voxel, const int32_t* __restrict__ n_slots,
                                                           const SlotHot* __restrict__ hotS, uint32_t* __restrict__ acc,
                                                           const float* __restrict__ thr, const LutCell* __restrict__ lut,
                                                           int T, int P, int Mt, int Mp, float guard_t, float guard_p,
                                                           int lds_slots, int chunks, int n_pairs, int force_exact,
                                                           uint32_t* __restrict__ near_over, uint32_t* __restrict__ near_over_count) {
+    constexpr uint32_t near_cap = kSmall ? kNearCapSmall : kNearCap;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int V = T * P;
     int pair, chunk;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_a
     float* hot = reinterpret_cast<float*>(smem + (((size_t)(Mt + Mp + 2) * sizeof(LutCell) + (size_t)80 * lds_slots + 15) & ~(size_t)15));
     int16_t* map = reinterpret_cast<int16_t*>(hot + lds_slots * kHotWords);
     const int map_words = (V + 1) / 2;
-    uint32_t* nearq = reinterpret_cast<uint32_t*>(map) + (V + T + 4) / 2;   // kNearCap point indices, then the fill counter
+    uint32_t* nearq = reinterpret_cast<uint32_t*>(map) + (V + T + 4) / 2;   // near_cap point indices, then the fill counter
     const int ns = n_slots[pair];
     const int nl = min(ns, lds_slots);
     const SlotHot* hs = hotS + (size_t)pair * V;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_a
             h[0] = g.inner; h[1] = g.outer; h[2] = g.mu[0]; h[3] = g.mu[1]; h[4] = g.mu[2];
         }
         for (int i = threadIdx.x; i < 10 * nl; i += kAccBlock) lacc[i] = 0ull;   // only the rows in use
-        if (threadIdx.x == 0) nearq[kNearCap] = 0u;
+        if (threadIdx.x == 0) nearq[near_cap] = 0u;
     }
     const float* xf = xf_all + pair * kXf;
     const float tx = xf[0], ty = xf[1], tz = xf[2];
@@ -309,8 +314,8 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_a
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (nr[j] & (i0 + j < end)) {
-                    const uint32_t e = atomicAdd(&nearq[kNearCap], 1u);
-                    if (e < kNearCap) nearq[e] = (uint32_t)(i0 + j);
+                    const uint32_t e = atomicAdd(&nearq[near_cap], 1u);
+                    if (e < near_cap) nearq[e] = (uint32_t)(i0 + j);
                     else near_over[(size_t)d.off2 + atomicAdd(&near_over_count[pair], 1u)] = (uint32_t)(i0 + j);
                 }
             }
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : kAccWavesPerSimd) void k_gn_a
     if (ICET_ACC_PHASE != 9 && sink == 1.2345e-30f) near_over_count[pair] = 1u;      // keeps the timing builds' work alive
     __syncthreads();
     {   // ---- the parked points: literal classification, each a run of one ----
-        const uint32_t nq = min(nearq[kNearCap], kNearCap);
+        const uint32_t nq = min(nearq[near_cap], near_cap);
         for (uint32_t e = threadIdx.x; e < nq; e += kAccBlock) {
             const int i = (int)nearq[e];
             float qx, qy, qz;
@@ -450,10 +455,11 @@ inline int chunks_for(int n_pairs, int max_n, int per_block_min, int target_bloc
 #define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t init_accumulate_kernels() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipSuccess;
+#define ICET_ACC_ATTR(V4, RT, SM) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate<V4, RT, SM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    ICET_ACC_ATTR(true, false, false); ICET_ACC_ATTR(false, false, false); ICET_ACC_ATTR(true, true, false); ICET_ACC_ATTR(false, true, false);
+    ICET_ACC_ATTR(true, false, true); ICET_ACC_ATTR(false, false, true); ICET_ACC_ATTR(true, true, true); ICET_ACC_ATTR(false, true, true);
+#undef ICET_ACC_ATTR
     return e;
 }
 
@@ -486,9 +492,10 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     // spill busy voxels to HBM atomics, more rows cost occupancy); a small batch has
     // CUs to spare, so a block may take most of a CU's LDS and keep every active voxel of a fine grid (150 x 48: often
     // > 1000) out of the slow HBM-atomic path.
-    const size_t fixed = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)((c.V + c.T + 4) / 2) * 4 + (kNearCap + 1) * 4 + 32;   // + alignment of the hot records
+    const uint32_t near_cap = (c.n_pairs >= 32) ? kNearCap : kNearCapSmall;
+    const size_t fixed = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)((c.V + c.T + 4) / 2) * 4 + (near_cap + 1) * 4 + 32;   // + alignment of the hot records
     const size_t row = (kHotWords + kAccLds) * 4;
-    const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : 144 * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU
+    const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : 156 * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU; a small batch: one block per CU, nearly all of its LDS
     int lds_slots = c.lds_slots > 0 ? c.lds_slots : (int)((budget > fixed ? budget - fixed : 0) / row);
     lds_slots = lds_slots < 32 ? 32 : lds_slots;
     if (lds_slots > c.V) lds_slots = c.V;
@@ -497,10 +504,12 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     const size_t lds = fixed + (size_t)lds_slots * row;
     dim3 grid(grid_groups(c.n_pairs) * chunks), blk(kAccBlock);
     const LutCell* lut = reinterpret_cast<const LutCell*>(w.lut);
-#define ICET_ACC_LAUNCH(V4, RT) k_gn_accumulate<V4, RT><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp, \
+#define ICET_ACC_LAUNCH(V4, RT, SM) k_gn_accumulate<V4, RT, SM><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp, \
                                                      w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count)
-    if (c.rt2) { if (c.vec4_ok) ICET_ACC_LAUNCH(true, true); else ICET_ACC_LAUNCH(false, true); }
-    else { if (c.vec4_ok) ICET_ACC_LAUNCH(true, false); else ICET_ACC_LAUNCH(false, false); }
+#define ICET_ACC_LAUNCH2(V4, RT) do { if (near_cap == kNearCapSmall) ICET_ACC_LAUNCH(V4, RT, true); else ICET_ACC_LAUNCH(V4, RT, false); } while (0)
+    if (c.rt2) { if (c.vec4_ok) ICET_ACC_LAUNCH2(true, true); else ICET_ACC_LAUNCH2(false, true); }
+    else { if (c.vec4_ok) ICET_ACC_LAUNCH2(true, false); else ICET_ACC_LAUNCH2(false, false); }
+#undef ICET_ACC_LAUNCH2
 #undef ICET_ACC_LAUNCH
     ICET_LAUNCH_CHECK();
     return hipSuccess;

@@ -29,13 +29,15 @@ constexpr int kKfMaxPtsPerThread = ICET_KF_MAXPTS;   // keyframe kernels: larges
 // Largest grid the kernels accept.  Binding constraint: k_bin_scatter keeps 4 x V running offsets (16 B per voxel) in one
 // block's LDS (160 KB per CU) -- validated up front in ensure_workspace so that a too-fine grid is refused with
 // ICET_ERR_UNSUPPORTED instead of failing a launch mid-sequence.  Voxel ids travel in 14 bits of a 16-bit word whose two top
-// bits carry per-row flags (kRowNearBit, kRowExecBit); slot ids travel as int16.
+// bits carry per-row flags (kRowNearBit, kRowZeroBit); slot ids travel as int16.
 constexpr int kMaxVoxels = 10000;
 constexpr int kGnPartWords = 4 * 20 * 27; // Workspace::gn_part (icet_solve.hip: at most 4 pairs x 20 virtual blocks of 512 slots x 27 partial sums)
-constexpr uint16_t kRowExecBit = 0x8000u;   // (free since the swap-loop flags moved to a bit table; stays clear)
+constexpr uint16_t kRowZeroBit = 0x8000u;   // the row's r is exactly 0: the invalid returns of a real scan (thousands of exact-zero rows, all in ONE voxel) -- their r need not be gathered
 constexpr uint16_t kRowNearBit = 0x4000u;   // the row lies within a guard band of a voxel edge: its azimuth / polar bounds test must be done with the literal formulas
 constexpr uint16_t kRowBinMask = 0x3FFFu;
-constexpr uint32_t kSortedNearBit = 0x80000000u;   // the same flag in the sorted-row table (rows < 2^31)
+constexpr uint32_t kSortedNearBit = 0x80000000u;   // the same flag in the sorted-row table (rows < 2^30)
+constexpr uint32_t kSortedZeroBit = 0x40000000u;   // kRowZeroBit in the sorted-row table
+constexpr uint32_t kSortedRowMask = ~(kSortedNearBit | kSortedZeroBit);
 
 // One scan pair as the kernels see it (device pointers, column-major N x 3).
 struct PairDesc {

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __re
         if (key64) key64[o] = ((unsigned long long)pair << 32) | (unsigned long long)__float_as_uint(r);
         else if (key32) key32[o] = __float_as_uint(r);
         if (key64 || key32) val[o] = (uint32_t)i;               // library-sort path only
-        bin16[o] = (uint16_t)v | (near ? kRowNearBit : (uint16_t)0);
+        bin16[o] = (uint16_t)v | (near ? kRowNearBit : (uint16_t)0) | (r == 0.f ? kRowZeroBit : (uint16_t)0);
         vlo = min(vlo, v); vhi = max(vhi, v);
     }
     {   // the tile's populated voxel range (a 64-channel scan fills ~1/3 of the id range of the 75 x 24 grid); no atomics: thousands of
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
         ok[k] = (k < rounds) & (v < whi);
         const uint32_t wd = ok[k] ? (uint32_t)binpos[o + v] : 0u;
         bb[k] = wd & kRowBinMask;
-        row[k] = (ok[k] ? (uint32_t)src[o + v] : 0u) | ((wd & kRowNearBit) ? kSortedNearBit : 0u);   // the flag travels with the row
+        row[k] = (ok[k] ? (uint32_t)src[o + v] : 0u) | ((wd & kRowNearBit) ? kSortedNearBit : 0u) | ((wd & kRowZeroBit) ? kSortedZeroBit : 0u);   // the flags travel with the row
         if (ok[k]) {                                                   // 16-bit counters, 32-bit atomics: a quarter tile holds <= 512 rows, no carry into the neighbour
             const uint32_t e = (uint32_t)(wave * V) + bb[k];
             atomicAdd(&lb[V + (e >> 1)], 1u << (16u * (e & 1u)));
@@ -649,7 +649,7 @@ __device__ __host__ __forceinline__ size_t item_base(int32_t off1, int pair, int
 // kTail: chunks of 64 rows requested together past a bin's first 256 rows.  A real scan's near field puts tens of thousands of rows into a few
 // bins (the reference's sample_pc pair: one wave walked 237 us while every other wave had long finished -- two dependent memory round trips
 // per 64 rows).  Throughput batches keep 8 waves per SIMD (kTail 2 fits their 64 registers); small batches, whose waves are few anyway, take
-// kTail 8 at 4 waves per SIMD: two round trips per 512 rows.
+// kTail 16 at 4 waves per SIMD: two round trips per 1024 rows.
 template <int kTail>
 __global__ __launch_bounds__(kBlock, kTail > 2 ? 4 : ICET_CLUSTER_WAVES) void k_fit_cluster(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bin_start,
                                                       const uint32_t* __restrict__ sorted_row, const float* __restrict__ r1,
@@ -670,7 +670,9 @@ __global__ __launch_bounds__(kBlock, kTail > 2 ? 4 : ICET_CLUSTER_WAVES) void k_
     const int stride = chunks * (kBlock / 64), j0 = chunk * (kBlock / 64) + wave;
     if (j0 >= nl) return;                                             // wave-uniform; no block-wide barrier below
     const size_t po = (size_t)d.off1;
-    constexpr uint32_t kRowMask = ~kSortedNearBit;
+    constexpr uint32_t kRowMask = kSortedRowMask;
+    // r of a row of the sorted-row table: rows flagged `r == 0` (the invalid returns of a real scan: one voxel holds thousands of them) are not gathered
+    auto r_of = [&](uint32_t rw, bool valid) { return (valid && !(rw & kSortedZeroBit)) ? r1[po + (rw & kRowMask)] : 0.f; };
     constexpr int kCache = 4;                                         // a bin's first 4 x 64 rows travel in registers (most bins hold ~100-400 rows)
     const int4* lv = reinterpret_cast<const int4*>(live) + (size_t)pair * V;
     auto info = [&](int j) { int4 q = lv[min(j, nl - 1)]; if (j >= nl) q.z = 0; return q; };
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(kBlock, kTail > 2 ? 4 : ICET_CLUSTER_WAVES) void k_
     };
     auto radii4 = [&](const int4& q, const uint32_t (&rw)[kCache], float (&rr)[kCache]) {
 #pragma unroll
-        for (int k = 0; k < kCache; k++) rr[k] = (lane + 64 * k < q.z) ? r1[po + (rw[k] & kRowMask)] : 0.f;
+        for (int k = 0; k < kCache; k++) rr[k] = r_of(rw[k], lane + 64 * k < q.z);
     };
 #if ICET_CLUSTER_PIPE == 1
     int4 q0 = info(j0), q1 = info(j0 + stride), q2 = info(j0 + 2 * stride);
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(kBlock, kTail > 2 ? 4 : ICET_CLUSTER_WAVES) void k_
     const size_t base = po + bs;
     // rows of this bin in (scrambled) position order: sorted_row[base + i] is the row of the pair's input-order tables
     // (top bit: the row lies within a guard band of a voxel edge)
-    auto RS = [&](int i) { return r1[po + (sorted_row[base + i] & kRowMask)]; };
+    auto RS = [&](int i) { return r_of(sorted_row[base + i], true); };
 
     float inner = 0.f, outer = 0.f;
     int m_cand = 0;                                                   // rows inside the radial range (wave-uniform)
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(kBlock, kTail > 2 ? 4 : ICET_CLUSTER_WAVES) void k_
 #pragma unroll
             for (int k = 0; k < kTail; k++) tw[k] = (c0 + 64 * k + lane < cnt) ? sorted_row[base + c0 + 64 * k + lane] : 0u;
 #pragma unroll
-            for (int k = 0; k < kTail; k++) tr[k] = (c0 + 64 * k + lane < cnt) ? r1[po + (tw[k] & kRowMask)] : 0.f;
+            for (int k = 0; k < kTail; k++) tr[k] = r_of(tw[k], c0 + 64 * k + lane < cnt);
 #pragma unroll
             for (int k = 0; k < kTail; k++) if (c0 + 64 * k < cnt && !found) walk(c0 + 64 * k, tr[k]);
         }
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(kBlock, kTail > 2 ? 4 : ICET_CLUSTER_WAVES) void k_
                     r = (c == 0) ? pr[0] : (c == 1) ? pr[1] : (c == 2) ? pr[2] : pr[3];
                 } else {
                     rw = (i < cnt) ? sorted_row[base + i] : 0u;
-                    r = (i < cnt) ? r1[po + (rw & kRowMask)] : 0.f;
+                    r = r_of(rw, i < cnt);
                 }
                 const bool in = (i < cnt) && (r >= inner) && (r <= outer);
                 const unsigned long long m = __ballot(in);
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(kBlock, ICET_FIT_WAVES) void k_fit_roundtrip(const 
                                                       float* __restrict__ cart1, size_t cart_stride, int T, int P, int n_pairs, int chunks) {
     const int lane = threadIdx.x & 63;
     const int V = T * P;
-    constexpr uint32_t kRowMask = ~kSortedNearBit;
+    constexpr uint32_t kRowMask = kSortedRowMask;
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;          // the pair's blocks share an XCD: its scan and tables sit in that L2
     const PairDesc d = desc[pair];
@@ -1255,7 +1257,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     // enough blocks to fill the chip whatever the batch size
     const int fit_chunks = std::max(1, std::min((c.V + kBlock / 64 - 1) / (kBlock / 64), (ICET_FIT_BLOCKS + c.n_pairs - 1) / c.n_pairs));
     if (c.n_pairs <= 16)
-        k_fit_cluster<8><<<dim3(groups * fit_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.valA, w.r1, w.keyA, reinterpret_cast<float*>(w.keyB), items, w.fit_n_items,
+        k_fit_cluster<16><<<dim3(groups * fit_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.valA, w.r1, w.keyA, reinterpret_cast<float*>(w.keyB), items, w.fit_n_items,
                                                                     w.live_bins, w.n_live, w.midD, c.T, c.P, c.n, c.thresh, c.buff, np, fit_chunks, c.half_gap);
     else
         k_fit_cluster<2><<<dim3(groups * fit_chunks), blk, 0, st>>>(w.desc, w.bin_start, w.valA, w.r1, w.keyA, reinterpret_cast<float*>(w.keyB), items, w.fit_n_items,

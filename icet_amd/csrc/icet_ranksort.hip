@@ -205,10 +205,14 @@ __host__ __device__ constexpr int cell_region(int C) { return C > kRadixWords ? 
 
 // Counting sort of the n (key, row) pairs in buf0 on the bucket's own key range; true = done (s / pred written), false = some cell
 // is too crowded (block-uniform; nothing written): the caller falls back to the radix sort.
-__device__ __forceinline__ bool counting_sort_lds(uint32_t* smem, int C, int logC, int kCap, int n, uint32_t kmin, uint32_t kmax,
+__device__ __forceinline__ bool counting_sort_lds(uint32_t* smem, int Clayout, int logCmax, int kCap, int n, uint32_t kmin, uint32_t kmax,
                                                   int lo, size_t off1, uint32_t* s_out, int32_t* pred_out, int max_cell) {
-    uint32_t* cells = smem; uint32_t* red = smem + cell_region(C);
-    const int offBuf = cell_region(C) + kRedWords;
+    uint32_t* cells = smem; uint32_t* red = smem + cell_region(Clayout);
+    const int offBuf = cell_region(Clayout) + kRedWords;
+    // cells for THIS bucket: a launch whose LDS is sized for large buckets (small batches: every bucket up to 8960 rows stays in LDS) still
+    // sorts an ordinary bucket over 1024 cells (~0.5 - 2 rows per cell), not over the 4096 the largest one needs
+    const int logC = (n <= 2 * kSortBlock * 4) ? min(logCmax, 10) : logCmax;
+    const int C = 1 << logC;
     const uint32_t* K0 = smem + offBuf; const uint32_t* I0 = K0 + kCap;
     uint32_t* K1 = smem + offBuf + 2 * kCap; uint32_t* I1 = K1 + kCap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -350,10 +354,14 @@ __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* _
 #define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
 // LDS rows of the per-bucket sort for scans of at most max_n rows: 1.3 x the mean bucket, rounded up to 128
-static int rank_sort_cap(int max_n, int forced) {
+static int rank_sort_cap(int max_n, int forced, int n_pairs) {
     int nb = (max_n + kBucketTarget - 1) / kBucketTarget; nb = nb < 1 ? 1 : (nb > kMaxBuckets ? kMaxBuckets : nb);
     int cap = (int)(1.3 * (double)max_n / nb); cap = (cap + 127) / 128 * 128;
     cap = cap < kCapMin ? kCapMin : (cap > kCapMax ? kCapMax : cap);
+    // A small batch has a CU per block anyway: every bucket up to 8960 rows sorts in LDS.  Real scans need it: their thousands of exact-zero
+    // rows take ~10 of the 128 splitters, the other buckets grow to 3 - 12x the mean (frame_804: 6157 rows against a mean of 512) and
+    // went to the global-scratch radix sort (65 us for this kernel against 16 on a synthetic pair).
+    if (n_pairs <= 4) cap = kCapMax;
     if (forced > 0) cap = forced < 64 ? 64 : (forced > kCapMax ? kCapMax : forced);     // Tuning::rs_cap (tests: force the global-scratch path)
     return cap;
 }
@@ -394,7 +402,7 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
     if (e != hipSuccess) return e;
     k_rs_scatter<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks);
     ICET_LAUNCH_CHECK();
-    const int cap = rank_sort_cap(c.max_n1, c.rs_cap);
+    const int cap = rank_sort_cap(c.max_n1, c.rs_cap, c.n_pairs);
     // two buckets per block (the second one's pairs in flight during the first one's sort) once the launch fills the chip several times over;
     // a small batch -- one pair is 128 blocks on 256 CUs -- keeps a block per bucket
     if (groups * kMaxBuckets >= 16 * 256 && kRsPerBlockBatch != 1)

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kBlock) void k_side_index1(const PairDesc* __restri
                                                         int32_t* __restrict__ out) {
     const PairDesc d = desc[0];
     for (int k = blockIdx.x * kBlock + threadIdx.x; k < d.n1; k += gridDim.x * kBlock)
-        out[k] = (int32_t)inv[(size_t)d.off1 + (sorted_row[(size_t)d.off1 + k] & ~kSortedNearBit)];
+        out[k] = (int32_t)inv[(size_t)d.off1 + (sorted_row[(size_t)d.off1 + k] & kSortedRowMask)];
 }
 
 __global__ __launch_bounds__(kBlock) void k_side_scan2(const PairDesc* __restrict__ desc, const float* __restrict__ xf, float* __restrict__ pts, float* __restrict__ sph,

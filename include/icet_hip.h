@@ -187,7 +187,7 @@ icet_status icet_last_timing(icet_ctx* ctx, float out_ms[4]);
  * of the most recent call to the host.  `what`: 0 = float32 r of scan 1 in input order
  * (utils::cartesianToSpherical, src/utils.cpp:99,116); 1 = uint16 per row: bits 0-13 the row's voxel
  * bins_theta * binPhi + binTheta (sortSphericalCoordinates, src/icet.cpp:545-549), bit 14 "classified with
- * the literal formulas", bit 15 unused (theta / phi themselves are not materialised: only decisions and the
+ * the literal formulas", bit 15 "r is exactly 0" (theta / phi themselves are not materialised: only decisions and the
  * Gaussians need them); 3 = int32 src[v], the original row that
  * sits at position v after the reference's sort + swap loop (src/icet.cpp:72-83); 4 = int32 per-pair
  * flags (bit 0: the bounded parallel walk overflowed and the serial replay was used).  `count` elements

@@ -25,7 +25,7 @@ FLAG_HALF_GAP_BOUNDS = 8  # non-parity extension (half-gap cluster buffers of th
 
 # every symbol include/icet_hip.h, include/icet_nodes.h and include/icet_io.h declare
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_begin", "icet_solve_keyframe_tables", "icet_solve_end", "icet_solve_batch",
-                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
+                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_keyframe_device_n", "icet_register_device_n", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
                     "icet_multi_solve_batch", "icet_multi_solve_batch_device", "icet_multi_solve_batch_device_after", "icet_multi_solve_batch_device_async", "icet_multi_sync", "icet_multi_set_option",
                     "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_map",
                     "icet_node_prev_scan", "icet_node_aligned", "icet_node_snail_trail", "icet_node_last_timing", "icet_stream", "icet_device",
@@ -101,6 +101,8 @@ def load_library():
     L.icet_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.icet_keyframe_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan)]
     L.icet_register_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.c_void_p, C.c_void_p]
+    L.icet_keyframe_device_n.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.c_void_p]
+    L.icet_register_device_n.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.c_void_p, C.c_void_p, C.c_void_p]
     L.icet_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32]
     L.icet_multi_destroy.argtypes = [C.c_void_p]
     L.icet_multi_last_error.argtypes = [C.c_void_p]; L.icet_multi_last_error.restype = C.c_char_p
@@ -200,16 +202,17 @@ class Context:
         self._check(load_library().icet_debug_fetch(self._h, code, out.ctypes.data, count))
         return out
 
-    def keyframe_device(self, scan1_descs, params):
-        """Park the keyframe of the scans (device_ptr, n, ld) in this context (icet_keyframe_device)."""
+    def keyframe_device(self, scan1_descs, params, d_rows_ptr=None):
+        """Park the keyframe of the scans (device_ptr, n, ld) in this context (icet_keyframe_device[_n]: with d_rows_ptr -- a device int32
+        array -- n is an upper bound and the actual row counts are read on the device)."""
         A = (DevScan * max(len(scan1_descs), 1))(*[DevScan(int(p), int(n), int(ld)) for (p, n, ld) in scan1_descs])
-        self._check(load_library().icet_keyframe_device(self._h, C.byref(params), len(scan1_descs), A))
+        self._check(load_library().icet_keyframe_device_n(self._h, C.byref(params), len(scan1_descs), A, C.c_void_p(d_rows_ptr) if d_rows_ptr else None))
 
-    def register_device(self, scan2_descs, params, d_out_ptr, d_x0_ptr=None):
-        """Gauss-Newton loop of the scans against the parked keyframe (icet_register_device)."""
+    def register_device(self, scan2_descs, params, d_out_ptr, d_x0_ptr=None, d_rows_ptr=None):
+        """Gauss-Newton loop of the scans against the parked keyframe (icet_register_device[_n])."""
         B = (DevScan * max(len(scan2_descs), 1))(*[DevScan(int(p), int(n), int(ld)) for (p, n, ld) in scan2_descs])
-        self._check(load_library().icet_register_device(self._h, C.byref(params), len(scan2_descs), B,
-                                                        C.c_void_p(d_x0_ptr) if d_x0_ptr else None, C.c_void_p(d_out_ptr)))
+        self._check(load_library().icet_register_device_n(self._h, C.byref(params), len(scan2_descs), B, C.c_void_p(d_rows_ptr) if d_rows_ptr else None,
+                                                          C.c_void_p(d_x0_ptr) if d_x0_ptr else None, C.c_void_p(d_out_ptr)))
 
     def set_option(self, name, value):
         """Launch-shape / diagnostic knob of this context (icet_set_option, include/icet_hip.h).  Launch-shape knobs leave the result

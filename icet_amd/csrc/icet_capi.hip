@@ -66,9 +66,10 @@ struct icet_ctx {
     hipEvent_t ev_desc = nullptr; bool desc_in_flight = false;   // completion of the last copy out of the pinned descriptor staging
     // Small device batches whose launch geometry repeats call after call are replayed from a captured hipGraph (option "graph"): the ~33
     // launches of a single-pair solve then cost one hipGraphLaunch on the host, and the command processor runs them back to back.
-    struct GraphKey { int64_t v[40]; };                        // every LaunchCfg field + the pointers the launches take (graph_key_of)
+    struct GraphKey { int64_t v[42]; };                        // every LaunchCfg field + the pointers the launches take (graph_key_of)
+    struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; GraphKey key{}, seen{}; bool have_seen = false, have_graph = false; };
     bool capturing = false; int graph_mode = -1;               // -1: replay batches of <= 8 pairs whose launch key repeats; 0 never; 1 same as -1
-    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; GraphKey graph_key{}; GraphKey seen_key{}; bool have_seen = false, have_graph = false;
+    GraphSlot g_solve, g_keyframe, g_loop;                     // the whole solve (icet_solve_batch_device) and its two halves (icet_keyframe_device_n / icet_register_device_n)
     hipEvent_t ev_graph = nullptr; bool graph_in_flight = false;
 };
 
@@ -391,7 +392,7 @@ icet_status upload_desc(icet_ctx* c, int32_t n_pairs) {
     return ICET_OK;
 }
 
-icet_status enqueue_keyframe(icet_ctx* c, const icet_params* p, int32_t n_pairs, const AuxDev* aux) {
+icet_status enqueue_keyframe(icet_ctx* c, const icet_params* p, int32_t n_pairs, const AuxDev* aux, const int32_t* d_counts1 = nullptr) {
     Workspace& w = c->w;
     { icet_status ts = ensure_thresholds(c, p->bins_theta, p->bins_phi); if (ts != ICET_OK) return ts; }
     const LaunchCfg cfg = make_cfg(c, p, n_pairs);
@@ -410,16 +411,18 @@ icet_status enqueue_keyframe(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         }
     }
     { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }
+    if (d_counts1) HIPCHK(c, launch_patch_counts(w, cfg, d_counts1, nullptr, c->stream));      // the descriptors hold upper bounds: the device knows the row counts
     if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
     HIPCHK(c, launch_keyframe(w, cfg, aux, c->stream));
     return ICET_OK;
 }
 
-icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, const float* d_x0, float* d_out, const AuxDev* aux, bool reupload, float* pts2_out = nullptr, hipEvent_t scan2_ready = nullptr) {
+icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, const float* d_x0, float* d_out, const AuxDev* aux, bool reupload, float* pts2_out = nullptr, hipEvent_t scan2_ready = nullptr, const int32_t* d_counts2 = nullptr) {
     const bool want_pts2 = aux && aux->xf_last && p->runlen > 0;      // pts2_out: the device computes `points2` (else only the transform snapshot + its event: the host does)
     Workspace& w = c->w;
     const LaunchCfg cfg = make_cfg(c, p, n_pairs);
     if (reupload) { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }      // the scan-2 halves arrived after the keyframe call
+    if (d_counts2) HIPCHK(c, launch_patch_counts(w, cfg, nullptr, d_counts2, c->stream));
     while ((int)c->ev_acc.size() < 2 * p->runlen) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_acc.push_back(e); }
     Workspace wl = w;                                    // what the loop kernels see: with ICET_FLAG_ROUNDTRIP_SCAN2 their scan 2 is the round-tripped copy
     if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_b, c->stream));      // keyframe_ms ends here: the scan-2 pre-pass of ICET_FLAG_ROUNDTRIP_SCAN2 belongs to the loop
@@ -570,7 +573,7 @@ icet_status icet_destroy(icet_ctx* c) {
     for (icet_ctx* h : c->helpers) (void)icet_destroy(h);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_desc) (void)hipEventDestroy(c->ev_desc);
-    if (c->have_graph) { (void)hipGraphExecDestroy(c->graph_exec); (void)hipGraphDestroy(c->graph); }
+    for (icet_ctx::GraphSlot* g : {&c->g_solve, &c->g_keyframe, &c->g_loop}) if (g->have_graph) { (void)hipGraphExecDestroy(g->exec); (void)hipGraphDestroy(g->graph); }
     if (c->ev_graph) (void)hipEventDestroy(c->ev_graph);
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -689,6 +692,66 @@ icet_status icet_solve_batch_device(icet_ctx* c, const icet_params* p, int32_t n
     return status;
 }
 
+extern "C++" {
+// ---- hipGraph replay of small device batches ------------------------------------------------------------------------------------
+// The kernels read the scans' addresses and sizes from the descriptor table (re-uploaded from pinned memory by a memcpy node of the graph on
+// every replay, and patched with device-side row counts where the caller has them); what the launches themselves depend on is the LaunchCfg
+// (grids, LDS sizes, point counts passed by value) and the workspace pointers.  A call whose key equals the previous call's is captured;
+// later calls with that key replay: one hipGraphLaunch instead of 15 - 35 launches on the host.
+static icet_ctx::GraphKey graph_key_of(icet_ctx* c, const icet_params* p, int32_t n_pairs, const void* a0, const void* a1, const void* a2, const void* a3) {
+    icet_ctx::GraphKey key{};
+    const LaunchCfg k = make_cfg(c, p, n_pairs);
+    auto bits = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return (int64_t)i; };
+    const int64_t vals[] = {k.T, k.P, k.V, k.n, k.runlen, bits(k.thresh), bits(k.buff), k.n_pairs, k.max_n1, k.max_n2, k.total_n1, k.lds_slots, k.acc_min_pts_per_thread,
+                            k.acc_target_blocks, k.kf_chunks, k.kf_pts_per_thread, k.use_library_sort, k.vec4_ok, k.true_sort, k.force_exact, k.rs_cap, k.rs_max_cell,
+                            k.exec_bits_lds, k.exec_pairwise, k.reject_moving, k.half_gap, k.rt2, p->flags, (int64_t)(intptr_t)a0, (int64_t)(intptr_t)a1, (int64_t)(intptr_t)a2, (int64_t)(intptr_t)a3,
+                            (int64_t)(intptr_t)c->w.desc, (int64_t)(intptr_t)c->w.thr, (int64_t)(intptr_t)c->w.lut, (int64_t)(intptr_t)c->w.r1, (int64_t)(intptr_t)c->w.counts,
+                            (int64_t)(intptr_t)c->w.near_over, (int64_t)(intptr_t)c->w.acc, (int64_t)(intptr_t)c->w.fit_items, (int64_t)(intptr_t)c->w.sort_tmp, (int64_t)(intptr_t)c->w.tile_vr};
+    static_assert(sizeof(vals) == sizeof(key.v), "GraphKey size");
+    std::memcpy(key.v, vals, sizeof(vals));
+    return key;
+}
+static bool graph_eligible(const icet_ctx* c, const icet_params* p, int32_t n_pairs) {
+    return c->graph_mode && n_pairs <= 8 && !(p->flags & (ICET_FLAG_TIMING | ICET_FLAG_ROUNDTRIP_SCAN2)) && !c->stage_at;
+}
+// Runs `enq` (which enqueues on c->stream) eagerly, or captured into `slot` and replayed.  The pinned descriptor staging must already hold this call's
+// descriptors; the caller has waited for a replay in flight before it wrote them.
+template <typename Enq> static icet_status run_or_replay(icet_ctx* c, icet_ctx::GraphSlot& slot, const icet_ctx::GraphKey& key, Enq enq) {
+    auto same = [](const icet_ctx::GraphKey& a, const icet_ctx::GraphKey& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; };
+    if (slot.have_graph && same(key, slot.key)) {
+        HIPCHK(c, hipGraphLaunch(slot.exec, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_graph, c->stream)); c->graph_in_flight = true;
+        c->timing_valid = false;
+        return ICET_OK;
+    }
+    if (slot.have_seen && same(key, slot.seen)) {
+        if (slot.have_graph) { (void)hipGraphExecDestroy(slot.exec); (void)hipGraphDestroy(slot.graph); slot.have_graph = false; }
+        if (!c->ev_graph) HIPCHK(c, hipEventCreateWithFlags(&c->ev_graph, hipEventDisableTiming));
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        c->capturing = true;
+        const icet_status es = enq();
+        c->capturing = false;
+        hipGraph_t g = nullptr;
+        const hipError_t ee = hipStreamEndCapture(c->stream, &g);
+        if (es != ICET_OK || ee != hipSuccess || !g) {           // could not capture (a capacity grew, an unsupported call): run this call eagerly and stop trying for this key
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            slot.have_seen = false;
+            return enq();
+        }
+        hipGraphExec_t ge = nullptr;
+        if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); (void)hipGetLastError(); slot.have_seen = false; return enq(); }
+        slot.graph = g; slot.exec = ge; slot.key = key; slot.have_graph = true;
+        HIPCHK(c, hipGraphLaunch(slot.exec, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_graph, c->stream)); c->graph_in_flight = true;
+        c->timing_valid = false;
+        return ICET_OK;
+    }
+    slot.seen = key; slot.have_seen = true;
+    return enq();
+}
+}  // extern "C++"
+
 static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1, const icet_dev_scan* scan2,
                                      const float* d_x0, float* d_out, int64_t tot1) {
     int64_t tot2 = 0; for (int k = 0; k < n_pairs; k++) tot2 += scan2[k].n;
@@ -706,60 +769,19 @@ static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t 
         d.off1 = 0; d.off2 = 0;
     }
     if (p->runlen == 0) return write_runlen0(c, n_pairs, d_x0, d_out);
-    if (c->graph_mode && n_pairs <= 8 && !(p->flags & (ICET_FLAG_TIMING | ICET_FLAG_ROUNDTRIP_SCAN2)) && !c->stage_at) {
-        // The kernels read the scans' addresses and sizes from the descriptor table (re-uploaded from pinned memory by a memcpy node of the
-        // graph on every replay); what the launches themselves depend on is the LaunchCfg (grids, LDS sizes, point counts passed by value)
-        // and the workspace pointers.  A call whose key equals the previous call's is captured; later calls with that key replay.
+    if (graph_eligible(c, p, n_pairs)) {
         icet_status ts = ensure_thresholds(c, p->bins_theta, p->bins_phi);
         if (ts != ICET_OK) return ts;
-        icet_ctx::GraphKey key{};
-        {
-            const LaunchCfg k = make_cfg(c, p, n_pairs);
-            auto bits = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return (int64_t)i; };
-            const int64_t vals[] = {k.T, k.P, k.V, k.n, k.runlen, bits(k.thresh), bits(k.buff), k.n_pairs, k.max_n1, k.max_n2, k.total_n1, k.lds_slots, k.acc_min_pts_per_thread,
-                                    k.acc_target_blocks, k.kf_chunks, k.kf_pts_per_thread, k.use_library_sort, k.vec4_ok, k.true_sort, k.force_exact, k.rs_cap, k.rs_max_cell,
-                                    k.exec_bits_lds, k.exec_pairwise, k.reject_moving, k.half_gap, k.rt2, p->flags, (int64_t)(intptr_t)d_x0, (int64_t)(intptr_t)d_out,
-                                    (int64_t)(intptr_t)c->w.desc, (int64_t)(intptr_t)c->w.thr, (int64_t)(intptr_t)c->w.lut, (int64_t)(intptr_t)c->w.r1, (int64_t)(intptr_t)c->w.counts,
-                                    (int64_t)(intptr_t)c->w.near_over, (int64_t)(intptr_t)c->w.acc, (int64_t)(intptr_t)c->w.fit_items, (int64_t)(intptr_t)c->w.sort_tmp, (int64_t)(intptr_t)c->w.tile_vr};
-            static_assert(sizeof(vals) == sizeof(key.v), "GraphKey size");
-            std::memcpy(key.v, vals, sizeof(vals));
-        }
-        auto same = [](const icet_ctx::GraphKey& a, const icet_ctx::GraphKey& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; };
-        if (c->have_graph && same(key, c->graph_key)) {
-            HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
-            HIPCHK(c, hipEventRecord(c->ev_graph, c->stream)); c->graph_in_flight = true;
-            c->timing_valid = false;
-            return ICET_OK;
-        }
-        if (c->have_seen && same(key, c->seen_key)) {
-            if (c->have_graph) { (void)hipGraphExecDestroy(c->graph_exec); (void)hipGraphDestroy(c->graph); c->have_graph = false; }
-            if (!c->ev_graph) HIPCHK(c, hipEventCreateWithFlags(&c->ev_graph, hipEventDisableTiming));
-            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            c->capturing = true;
-            const icet_status es = enqueue(c, p, n_pairs, d_x0, d_out, nullptr);
-            c->capturing = false;
-            hipGraph_t g = nullptr;
-            const hipError_t ee = hipStreamEndCapture(c->stream, &g);
-            if (es != ICET_OK || ee != hipSuccess || !g) {           // could not capture (a capacity grew, an unsupported call): run this call eagerly and stop trying for this key
-                if (g) (void)hipGraphDestroy(g);
-                (void)hipGetLastError();
-                c->have_seen = false;
-                return enqueue(c, p, n_pairs, d_x0, d_out, nullptr);
-            }
-            hipGraphExec_t ge = nullptr;
-            if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); (void)hipGetLastError(); c->have_seen = false; return enqueue(c, p, n_pairs, d_x0, d_out, nullptr); }
-            c->graph = g; c->graph_exec = ge; c->graph_key = key; c->have_graph = true;
-            HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
-            HIPCHK(c, hipEventRecord(c->ev_graph, c->stream)); c->graph_in_flight = true;
-            c->timing_valid = false;
-            return ICET_OK;
-        }
-        c->seen_key = key; c->have_seen = true;
+        return run_or_replay(c, c->g_solve, graph_key_of(c, p, n_pairs, d_x0, d_out, nullptr, nullptr), [&]() { return enqueue(c, p, n_pairs, d_x0, d_out, nullptr); });
     }
     return enqueue(c, p, n_pairs, d_x0, d_out, nullptr);
 }
 
 icet_status icet_keyframe_device(icet_ctx* c, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1) {
+    return icet_keyframe_device_n(c, p, n_pairs, scan1, nullptr);
+}
+
+icet_status icet_keyframe_device_n(icet_ctx* c, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1, const int32_t* d_rows) {
     if (!c) return ICET_ERR_BAD_ARG;
     if (!params_ok(p) || n_pairs < 1 || !scan1) { c->err = "bad argument"; return ICET_ERR_BAD_ARG; }
     int64_t tot1 = 0;
@@ -773,18 +795,26 @@ icet_status icet_keyframe_device(icet_ctx* c, const icet_params* p, int32_t n_pa
     icet_status s = ensure_workspace(c, p, n_pairs, tot1, 0);
     if (s != ICET_OK) return s;
     if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
+    if (c->graph_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_graph)); c->graph_in_flight = false; }
     for (int k = 0; k < n_pairs; k++) {
         PairDesc& d = c->h_desc[k];
         d.s1 = scan1[k].ptr; d.n1 = (int32_t)scan1[k].n; d.ld1 = (int32_t)scan1[k].ld;
         d.s2 = nullptr; d.n2 = 0; d.ld2 = 0; d.off1 = 0; d.off2 = 0;
     }
-    s = enqueue_keyframe(c, p, n_pairs, nullptr);
+    if (graph_eligible(c, p, n_pairs)) {
+        s = ensure_thresholds(c, p->bins_theta, p->bins_phi);
+        if (s == ICET_OK) s = run_or_replay(c, c->g_keyframe, graph_key_of(c, p, n_pairs, d_rows, nullptr, nullptr, (const void*)1), [&]() { return enqueue_keyframe(c, p, n_pairs, nullptr, d_rows); });
+    } else s = enqueue_keyframe(c, p, n_pairs, nullptr, d_rows);
     if (s != ICET_OK) return s;
     c->kf_pairs = n_pairs; c->kf_params = *p;
     return ICET_OK;
 }
 
 icet_status icet_register_device(icet_ctx* c, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan2, const float* d_x0, float* d_out) {
+    return icet_register_device_n(c, p, n_pairs, scan2, nullptr, d_x0, d_out);
+}
+
+icet_status icet_register_device_n(icet_ctx* c, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan2, const int32_t* d_rows, const float* d_x0, float* d_out) {
     if (!c) return ICET_ERR_BAD_ARG;
     if (!params_ok(p) || n_pairs < 1 || !scan2 || !d_out) { c->err = "bad argument"; return ICET_ERR_BAD_ARG; }
     const icet_params& q = c->kf_params;
@@ -801,8 +831,11 @@ icet_status icet_register_device(icet_ctx* c, const icet_params* p, int32_t n_pa
     icet_status s = ensure_workspace(c, p, n_pairs, 0, tot2);              // only the scan-2 overflow list can grow here: the keyframe tables stay
     if (s != ICET_OK) return s;
     if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
+    if (c->graph_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_graph)); c->graph_in_flight = false; }
     for (int k = 0; k < n_pairs; k++) { PairDesc& d = c->h_desc[k]; d.s2 = scan2[k].ptr; d.n2 = (int32_t)scan2[k].n; d.ld2 = (int32_t)scan2[k].ld; }
-    return enqueue_loop(c, p, n_pairs, d_x0, d_out, nullptr, true);
+    if (graph_eligible(c, p, n_pairs))
+        return run_or_replay(c, c->g_loop, graph_key_of(c, p, n_pairs, d_x0, d_out, d_rows, (const void*)2), [&]() { return enqueue_loop(c, p, n_pairs, d_x0, d_out, nullptr, true, nullptr, nullptr, d_rows); });
+    return enqueue_loop(c, p, n_pairs, d_x0, d_out, nullptr, true, nullptr, nullptr, d_rows);
 }
 
 icet_status icet_solve_batch(icet_ctx* c, const icet_params* p, int32_t n_pairs,
@@ -1090,7 +1123,7 @@ icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
     else if (k == "rs_max_cell") t.rs_max_cell = iv < 0 ? 0 : iv;
     else if (k == "exec_bits_lds") t.exec_bits_lds = iv != 0;
     else if (k == "exec_pairwise") t.exec_pairwise = iv < 0 ? -1 : (iv != 0);
-    else if (k == "graph") { c->graph_mode = iv < 0 ? -1 : (iv != 0); c->have_seen = false; }
+    else if (k == "graph") { c->graph_mode = iv < 0 ? -1 : (iv != 0); c->g_solve.have_seen = c->g_keyframe.have_seen = c->g_loop.have_seen = false; }
     else if (k == "guard_scale") { if (!(value >= 1.0 && value <= 1024.0)) { c->err = "guard_scale must lie in [1, 1024]"; return ICET_ERR_BAD_ARG; } t.guard_scale = value; c->w.thr_T = 0; }   // tables are rebuilt by the next call
     else if (k == "lut_polar_quantile") { if (!(value >= 0.0 && value <= 1.0)) { c->err = "lut_polar_quantile must lie in [0, 1]"; return ICET_ERR_BAD_ARG; } t.lut_polar_quantile = value; c->w.thr_T = 0; }
     else { c->err = "unknown option: " + k; return ICET_ERR_BAD_ARG; }

@@ -183,6 +183,7 @@ hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* x
 hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st);
 // ICET_FLAG_ROUNDTRIP_SCAN2: points2_OG = sphericalToCartesian(cartesianToSpherical(scan 2)) (src/icet.cpp:263-275, without the permutation): w.desc -> w.desc_rt
 hipError_t launch_rt2_prepare(const Workspace& w, const LaunchCfg& c, hipStream_t st);
+hipError_t launch_patch_counts(const Workspace& w, const LaunchCfg& c, const int32_t* d_n1, const int32_t* d_n2, hipStream_t st);   // icet_solve.hip
 // icet_sidetables.hip: the per-point members of the reference object, on request (pair 0 of a single-pair solve)
 hipError_t launch_side_scan1(const Workspace& w, const LaunchCfg& c, float* sph, int32_t* index, hipStream_t st);
 hipError_t launch_side_scan2(const Workspace& w, const LaunchCfg& c, const float* xf, float* pts, float* sph, int32_t* voxel, hipStream_t st);

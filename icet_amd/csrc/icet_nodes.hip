@@ -221,7 +221,7 @@ struct icet_node {
     int prev = 0;
     float* d_stage = nullptr; int64_t cap_stage = 0;              // host scans land here first
     int32_t* d_counts = nullptr; int32_t* d_bases = nullptr; int cap_blocks = 0;
-    int32_t* d_nkept = nullptr; int32_t* h_nkept = nullptr;
+    int32_t* d_nkept = nullptr; int32_t* h_nkept = nullptr;       // d_nkept: TWO counters, one per scan buffer (a frame's count is still read by the keyframe build that runs into the next frame)
     float* d_x0 = nullptr; float* d_out = nullptr; float* h_out = nullptr; float* h_x0 = nullptr;
     float X0[6] = {0, 0, 0, 0, 0, 0};
     float pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -290,6 +290,13 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_bases), sizeof(int32_t) * n_blocks));
         nd->cap_blocks = n_blocks;
     }
+    // Whoever needs the kept-row count on the HOST before the solve can be enqueued (the map maker's shuffle runs over exactly that many
+    // indices; the aligned cloud and the unpipelined solve are sized by it) waits for the filter here.  The pipelined odometry frame does
+    // not: the solve's two halves take the unfiltered row count as an upper bound for their launch geometry and read the actual count on
+    // the device (icet_register_device_n / icet_keyframe_device_n), so the whole frame is enqueued without a host round trip in the middle.
+    const bool fast = nd->pipelined && nd->p.map_capacity == 0 && n > 0 &&
+                      !(nd->p.flags & (ICET_NODE_NO_RANGE_FILTER | ICET_NODE_ALIGNED_CLOUD | ICET_NODE_SNAIL_TRAIL));
+    int32_t* d_cnt = nd->d_nkept + cur;
     NCHK(nd, hipEventRecord(nd->ev[0], st));
     if (nd->p.flags & ICET_NODE_NO_RANGE_FILTER) {               // scanMatcher.cpp:44: the cloud goes to the constructor as it is
         if (n) NCHK(nd, hipMemcpy2DAsync(nd->d_scan[cur], lcur * sizeof(float), d_scan, ld * sizeof(float), n * sizeof(float), 3, hipMemcpyDeviceToDevice, st));
@@ -298,16 +305,18 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         const float *x = d_scan, *y = d_scan + ld, *z = d_scan + 2 * ld;
         float* o = nd->d_scan[cur];
         k_range_count<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_counts);
-        k_range_scan<<<1, kFB, 0, st>>>(nd->d_counts, nd->d_bases, n_blocks, nd->d_nkept);
+        k_range_scan<<<1, kFB, 0, st>>>(nd->d_counts, nd->d_bases, n_blocks, d_cnt);
         k_range_scatter<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_bases, o, o + lcur, o + 2 * lcur);
         NCHK(nd, hipGetLastError());
-        NCHK(nd, hipMemcpyAsync(nd->h_nkept, nd->d_nkept, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        NCHK(nd, hipMemcpyAsync(nd->h_nkept, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     } else {
         *nd->h_nkept = 0;
     }
     NCHK(nd, hipEventRecord(nd->ev[1], st));
-    NCHK(nd, hipStreamSynchronize(st));                           // the solve's launch geometry needs the row count
-    const int64_t nk = *nd->h_nkept;
+    if (!fast) NCHK(nd, hipStreamSynchronize(st));                // the solve's launch geometry needs the row count
+    // fast: an upper bound until the end-of-frame synchronisation -- the buffer's CAPACITY, which does not change from frame to frame, so that the
+    // two halves of the solve see the same launch key every frame and replay their captured graphs (one hipGraphLaunch each instead of ~35 launches)
+    int64_t nk = fast ? lcur : (int64_t)*nd->h_nkept;
     nd->n_scan[cur] = nk; nd->ld_scan[cur] = lcur;
     // ---- ICET it(prev, cur, runlen, X0, bins_phi, bins_theta, n, thresh, buff)  (odometry.cpp:76) ----
     // The down-sample indices of this frame (simpleMapMaker.cpp:147-158) depend only on the row count and on the node's RNG stream,
@@ -335,18 +344,21 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         // it in host order, beside it on the device -- the keyframe of THIS scan on the other context, for the next frame
         icet_ctx* own = nd->kf[nd->owner]; icet_ctx* oth = nd->kf[nd->owner ^ 1];
         so = reinterpret_cast<hipStream_t>(icet_stream(own));
+        if (fast) {                                               // nobody waited for the filter: both solve streams do
+            NCHK(nd, hipStreamWaitEvent(so, nd->ev[1], 0));
+            NCHK(nd, hipStreamWaitEvent(reinterpret_cast<hipStream_t>(icet_stream(oth)), nd->ev[1], 0));
+        }
         NCHK(nd, hipEventRecord(nd->ev[5], so));
-        NCHK(nd, hipMemcpyAsync(nd->d_x0, nd->h_x0, sizeof(float) * 6, hipMemcpyHostToDevice, so));
-        s = icet_register_device(own, &sp, 1, &b, nd->d_x0, nd->d_out);
+        // X0 is read from pinned host memory by the kernel itself (no H2D command); the results stay in HBM during the loop and come back in one copy
+        s = icet_register_device_n(own, &sp, 1, &b, fast ? d_cnt : nullptr, nd->h_x0, nd->d_out);
         if (s != ICET_OK) { nd->err = icet_last_error(own); return s; }
         NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, so));
         NCHK(nd, hipEventRecord(nd->ev[2], so));
-        s = icet_keyframe_device(oth, &sp, 1, &b);
+        s = icet_keyframe_device_n(oth, &sp, 1, &b, fast ? d_cnt : nullptr);
         if (s != ICET_OK) { nd->err = icet_last_error(oth); return s; }
         flip_owner = true;                                        // committed together with nd->prev once the frame has succeeded
     } else {
-        NCHK(nd, hipMemcpyAsync(nd->d_x0, nd->h_x0, sizeof(float) * 6, hipMemcpyHostToDevice, st));
-        s = icet_solve_batch_device(nd->ctx, &sp, 1, &a, &b, nd->d_x0, nd->d_out);
+        s = icet_solve_batch_device(nd->ctx, &sp, 1, &a, &b, nd->h_x0, nd->d_out);
         if (s != ICET_OK) { nd->err = icet_last_error(nd->ctx); return s; }
         NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, st));
         NCHK(nd, hipEventRecord(nd->ev[2], st));
@@ -357,6 +369,7 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
     }
     if (so != st) NCHK(nd, hipStreamSynchronize(so));
     NCHK(nd, hipStreamSynchronize(st));
+    if (fast) { nk = *nd->h_nkept; nd->n_scan[cur] = nk; }        // the filter's count has arrived with everything else
     float X[6];
     std::memcpy(X, nd->h_out, sizeof(X)); std::memcpy(res->pred_stds, nd->h_out + 6, sizeof(float) * 6);
     // seed for the next frame (odometry.cpp:82 / simpleMapMaker.cpp:124), then the guard (simpleMapMaker.cpp:129-137)
@@ -461,7 +474,7 @@ icet_status icet_node_create(icet_ctx* ctx, const icet_node_params* p, icet_node
     nd->ctx = ctx; nd->p = *p; nd->stream = reinterpret_cast<hipStream_t>(icet_stream(ctx)); nd->device = icet_device(ctx);
     auto fail = [&](icet_status s) { icet_node_destroy(nd); return s; };
     if (hipSetDevice(nd->device) != hipSuccess) return fail(ICET_ERR_NO_DEVICE);
-    if (hipMalloc(reinterpret_cast<void**>(&nd->d_nkept), sizeof(int32_t)) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_nkept), sizeof(int32_t)) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void**>(&nd->d_nkept), 2 * sizeof(int32_t)) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_nkept), sizeof(int32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&nd->d_x0), sizeof(float) * 6) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&nd->d_out), sizeof(float) * 48) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&nd->h_out), sizeof(float) * 48) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_x0), sizeof(float) * 6) != hipSuccess)
         return fail(ICET_ERR_NOMEM);

@@ -348,6 +348,21 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
 
 #define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
+// Row counts that only the device knows (a sequential caller's range filter, include/icet_nodes.h): the descriptors were uploaded with upper
+// bounds -- the launch geometry is sized from those -- and take the actual counts here; every kernel reads n1 / n2 from the descriptor.
+__global__ void k_patch_counts(PairDesc* __restrict__ desc, const int32_t* __restrict__ n1, const int32_t* __restrict__ n2, int n_pairs) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    if (n1) desc[p].n1 = max(0, min(n1[p], desc[p].n1));
+    if (n2) desc[p].n2 = max(0, min(n2[p], desc[p].n2));
+}
+
+hipError_t launch_patch_counts(const Workspace& w, const LaunchCfg& c, const int32_t* d_n1, const int32_t* d_n2, hipStream_t st) {
+    k_patch_counts<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(w.desc, d_n1, d_n2, c.n_pairs);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last) {
     k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs, xf_last);
     ICET_LAUNCH_CHECK();

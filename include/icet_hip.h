@@ -174,6 +174,13 @@ icet_status icet_keyframe_device(icet_ctx* ctx, const icet_params* p, int32_t n_
 icet_status icet_register_device(icet_ctx* ctx, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan2,
                                  const float* d_x0, float* d_out);
 
+/* The same two halves for scans whose row counts only the DEVICE knows yet (a range filter that compacted them a moment ago on the same
+ * stream, src/odometry.cpp:57-70): scan[k].n is an UPPER BOUND (the launch geometry is sized from it), d_rows[k] (device, int32, may be NULL =
+ * the bounds are the counts) the actual number of rows, read by the kernels when they run.  The caller need not wait for the filter. */
+icet_status icet_keyframe_device_n(icet_ctx* ctx, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1, const int32_t* d_rows);
+icet_status icet_register_device_n(icet_ctx* ctx, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan2, const int32_t* d_rows,
+                                   const float* d_x0, float* d_out);
+
 /* Pre-size the workspace (so the first timed call does not allocate). */
 icet_status icet_reserve(icet_ctx* ctx, const icet_params* p, int32_t n_pairs, int64_t total_n1, int64_t total_n2);
 

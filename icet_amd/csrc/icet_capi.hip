@@ -298,16 +298,17 @@ void host_points2(const float* xf, const float* s, int64_t ld, int64_t n, float*
 #undef ICET_POINTS2_BODY
 
 // Word offsets (4-byte words, every table 16-byte aligned) of the single-pair result block, which exists twice with one layout: in HBM
-// (d_pack) and in pinned host memory (h_pack).  [0, small_end): the 48 result floats, the transform record of the last iteration (for
-// `points2`) and the per-iteration 6 / 36 / 6-float tables -- the kernels write these STRAIGHT into the pinned copy (a few posted PCIe
-// writes per iteration; no D2H command on the critical path); [bounds, kf_end): the keyframe tables, final once the keyframe is built,
-// copied to the host on the copy stream while the loop runs; then the rarely requested integer tables (copied at the end).
+// (d_pack) and in pinned host memory (h_pack).  [0, small_end): the 48 result floats and the per-iteration 6 / 36 / 6-float tables, written
+// in HBM and copied in ONE small D2H behind the loop (written straight into pinned memory by k_gn_solve they cost every iteration a PCIe
+// round trip at its end: measured on the map maker, +6 us per iteration); xf_last: the transform record of the last iteration (for
+// `points2`), written ONCE, straight into the pinned copy; [bounds, kf_end): the keyframe tables, final once the keyframe is built, copied to
+// the host on the copy stream while the loop runs; then the rarely requested integer tables (copied at the end).
 struct AuxLayout { size_t out, xf_last, x_hist, htwh, htwdz, small_end, bounds, has_fit, mu1, sigma1, evecs1, l_diag, test_points, kf_end, n1_raw, n2_raw, n2_in, ints_end, total; };
 AuxLayout aux_layout(int V, int runlen) {
     AuxLayout L{}; size_t o = 0;
     auto take = [&o](size_t n) { const size_t at = o; o += (n + 3) & ~(size_t)3; return at; };
     const size_t rl = runlen > 0 ? runlen : 1, v = (size_t)V;
-    L.out = take(48); L.xf_last = take(48); L.x_hist = take(rl * 6); L.htwh = take(rl * 36); L.htwdz = take(rl * 6); L.small_end = o;
+    L.out = take(48); L.x_hist = take(rl * 6); L.htwh = take(rl * 36); L.htwdz = take(rl * 6); L.small_end = o; L.xf_last = take(48);
     L.bounds = take(v * 6); L.has_fit = take(v); L.mu1 = take(v * 3); L.sigma1 = take(v * 9); L.evecs1 = take(v * 9); L.l_diag = take(v * 3);
     L.test_points = take(v * 18); L.kf_end = o; L.n1_raw = take(v); L.n2_raw = take(rl * v); L.n2_in = take(rl * v); L.ints_end = o;
     L.total = o;
@@ -338,7 +339,7 @@ icet_status ensure_pack(icet_ctx* c, int V, int runlen) {
         auto I = [d](size_t at) { return reinterpret_cast<int32_t*>(d + at); };
         float* hs = reinterpret_cast<float*>(c->h_pack);                     // pinned host memory is device-accessible under the same address
         a.bounds = F(L.bounds); a.n1_raw = I(L.n1_raw); a.has_fit = I(L.has_fit); a.mu1 = F(L.mu1); a.sigma1 = F(L.sigma1); a.evecs1 = F(L.evecs1);
-        a.l_diag = F(L.l_diag); a.x_hist = hs + L.x_hist; a.htwh = hs + L.htwh; a.htwdz = hs + L.htwdz; a.n2_raw = I(L.n2_raw); a.n2_in = I(L.n2_in);
+        a.l_diag = F(L.l_diag); a.x_hist = F(L.x_hist); a.htwh = F(L.htwh); a.htwdz = F(L.htwdz); a.n2_raw = I(L.n2_raw); a.n2_in = I(L.n2_in);
         a.test_points = F(L.test_points); a.xf_last = hs + L.xf_last;
         c->aux_V = V; c->aux_runlen = runlen;
     }
@@ -955,7 +956,8 @@ icet_status icet_solve_begin(icet_ctx* c, const icet_params* p, const float* sca
     PairDesc& d = c->h_desc[0];
     d.s1 = c->d_stage1; d.s2 = c->d_stage2; d.n1 = (int32_t)n1; d.ld1 = (int32_t)l1; d.n2 = (int32_t)n2; d.ld2 = (int32_t)l2; d.off1 = 0; d.off2 = 0;
     const AuxLayout L = aux_layout(V, p->runlen);
-    float* h_res = reinterpret_cast<float*>(c->h_pack) + L.out;               // the 48 result floats: written by k_gn_solve into pinned host memory
+    float* h_res = reinterpret_cast<float*>(c->h_pack) + L.out;               // the 48 result floats on the host
+    float* d_res = reinterpret_cast<float*>(c->d_pack) + L.out;               // ... and where k_gn_solve writes them
     AuxDev ad = c->aux_dev;
     icet_ctx::Pending& q = c->pend;
     q = icet_ctx::Pending{};
@@ -997,7 +999,8 @@ icet_status icet_solve_begin(icet_ctx* c, const icet_params* p, const float* sca
                 if (e == hipSuccess) e = hipEventRecord(c->ev_kfd, c->st_copy);
             }
             if (e != hipSuccess) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->st_copy); c->err = std::string("scan-2 upload / table download: ") + hipGetErrorString(e); return ICET_ERR_HIP; }
-            st = enqueue_loop(c, p, 1, c->h_x0, h_res, aux ? &ad : nullptr, false, q.pts2_dev ? c->h_pts2 : nullptr, c->ev_s2);
+            st = enqueue_loop(c, p, 1, c->h_x0, d_res, aux ? &ad : nullptr, false, q.pts2_dev ? c->h_pts2 : nullptr, c->ev_s2);
+            if (st == ICET_OK) HIPCHK(c, hipMemcpyAsync(c->h_pack + L.out, c->d_pack + L.out, (aux ? L.small_end : 48) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         }
         if (st == ICET_OK && want_side2) {
             // points2 / points2Spherical / the rows' voxels of the LAST fitScan2: one kernel behind the loop, with the transform record that

@@ -468,12 +468,12 @@ def main(argv=None):
         hs1 = [scans1[j].cpu().contiguous() for j in range(m)]; hs2 = [scans2[j].cpu().contiguous() for j in range(m)]          # (3, N) C-order == column-major N x 3
         a1 = [t.numpy().T for t in hs1]; a2 = [t.numpy().T for t in hs2]                                                        # N x 3 views in Fortran order
         hctx = icet_amd.Context(dev_ids[0])
-        def timed(fn, nrep=3):
+        def timed(fn, nrep=5):                                  # median of 5: one call delayed by the host (page locking, scheduling) must not set the figure
             fn()
-            t0 = time.perf_counter()
+            ts = []
             for _ in range(nrep):
-                fn()
-            return (time.perf_counter() - t0) / nrep
+                t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+            return float(np.median(ts))
         t_page = timed(lambda: hctx.solve_batch(a1, a2, iters, None, P, T))
         # pinned: the column-major staging the ABI reads, in page-locked memory (api.solve_batch transposes into pageable buffers, so go through the raw entry)
         import ctypes as C

@@ -196,8 +196,9 @@ class Context:
         self._check(load_library().icet_reserve(self._h, C.byref(params), n_pairs, total_n1, total_n2))
 
     def debug_fetch(self, what, count):
-        """Diagnostic: 'r' (float32, scan 1 in input order), 'bin' (uint16 per row: voxel id | literal-path flag << 14 | "r is exactly 0" << 15), 'src' (int32 scramble result), 'flags' (int32 per pair)."""
-        code = {"r": 0, "bin": 1, "src": 3, "flags": 4, "rt2": 5}[what]
+        """Diagnostic: 'r' (float32, scan 1 in input order), 'bin' (uint16 per row: voxel id | literal-path flag << 14 | "r is exactly 0" << 15), 'src' (int32 scramble result), 'flags' (int32 per pair), 'lds_rank_ok' (count 1: the
+        device passed the LDS-atomic order self-test of icet_create)."""
+        code = {"r": 0, "bin": 1, "src": 3, "flags": 4, "rt2": 5, "lds_rank_ok": 6}[what]
         out = np.zeros(count, {0: np.float32, 1: np.uint16, 5: np.float32}.get(code, np.int32))
         self._check(load_library().icet_debug_fetch(self._h, code, out.ctypes.data, count))
         return out

@@ -29,6 +29,7 @@ struct icet_ctx {
     Tuning tune;                    // icet_set_option
     int32_t kf_pairs = 0; icet_params kf_params{};      // a keyframe parked by icet_keyframe_device (0 pairs = none)
     int max_lds = 160 * 1024;       // hipDeviceAttributeMaxSharedMemoryPerBlock of the device
+    int lds_rank_ok = 0;            // this device passed lds_rank_selftest (icet_create)
     std::string err;
     // host staging (pinned) for descriptors and results
     PairDesc* h_desc = nullptr; int32_t* h_seg = nullptr; int32_t h_cap_pairs = 0;
@@ -66,7 +67,7 @@ struct icet_ctx {
     hipEvent_t ev_desc = nullptr; bool desc_in_flight = false;   // completion of the last copy out of the pinned descriptor staging
     // Small device batches whose launch geometry repeats call after call are replayed from a captured hipGraph (option "graph"): the ~33
     // launches of a single-pair solve then cost one hipGraphLaunch on the host, and the command processor runs them back to back.
-    struct GraphKey { int64_t v[42]; };                        // every LaunchCfg field + the pointers the launches take (graph_key_of)
+    struct GraphKey { int64_t v[43]; };                        // every LaunchCfg field + the pointers the launches take (graph_key_of)
     struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; GraphKey key{}, seen{}; bool have_seen = false, have_graph = false; };
     bool capturing = false; int graph_mode = -1;               // -1: replay batches of <= 8 pairs whose launch key repeats; 0 never; 1 same as -1
     GraphSlot g_solve, g_keyframe, g_loop;                     // the whole solve (icet_solve_batch_device) and its two halves (icet_keyframe_device_n / icet_register_device_n)
@@ -360,7 +361,7 @@ LaunchCfg make_cfg(icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     cfg.reject_moving = (p->flags & ICET_FLAG_REJECT_MOVING) ? 1 : 0;
     cfg.rt2 = (p->flags & ICET_FLAG_ROUNDTRIP_SCAN2) ? 1 : 0;
     cfg.lds_slots = c->tune.lds_slots; cfg.acc_min_pts_per_thread = c->tune.acc_pts; cfg.acc_target_blocks = c->tune.acc_blocks;
-    cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds; cfg.exec_pairwise = c->tune.exec_pairwise;
+    cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds; cfg.exec_pairwise = c->tune.exec_pairwise; cfg.lds_rank = (c->tune.lds_rank != 0 && c->lds_rank_ok) ? (c->tune.lds_rank == 2 ? 2 : 1) : 0;
     if (cfg.kf_pts_per_thread > kKfMaxPtsPerThread) cfg.kf_pts_per_thread = kKfMaxPtsPerThread;      // k_bin_scatter: a tile is at most 4 waves x that many rounds x 64 positions
     if (cfg.kf_pts_per_thread < 1) cfg.kf_pts_per_thread = 1;
     cfg.stage_event = c->stage_at ? c->ev_stage : nullptr; cfg.stage_at = c->stage_at;
@@ -542,6 +543,11 @@ icet_status icet_create(icet_ctx** out, int device_id, void* hip_stream) {
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c; return ICET_ERR_HIP;       // no usable kernel image for this device: fail loudly, there is no fallback
     }
+    {   // which form of the stable multi-splits this device gets (Tuning::lds_rank): ~0.1 ms once per context
+        int32_t* d_t = nullptr; int ok = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&d_t), sizeof(int32_t)) == hipSuccess) { if (lds_rank_selftest(d_t, c->stream, &ok) != hipSuccess) { ok = 0; (void)hipGetLastError(); } (void)hipFree(d_t); }
+        c->lds_rank_ok = ok;
+    }
     *out = c;
     return ICET_OK;
 }
@@ -705,7 +711,7 @@ static icet_ctx::GraphKey graph_key_of(icet_ctx* c, const icet_params* p, int32_
     auto bits = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return (int64_t)i; };
     const int64_t vals[] = {k.T, k.P, k.V, k.n, k.runlen, bits(k.thresh), bits(k.buff), k.n_pairs, k.max_n1, k.max_n2, k.total_n1, k.lds_slots, k.acc_min_pts_per_thread,
                             k.acc_target_blocks, k.kf_chunks, k.kf_pts_per_thread, k.use_library_sort, k.vec4_ok, k.true_sort, k.force_exact, k.rs_cap, k.rs_max_cell,
-                            k.exec_bits_lds, k.exec_pairwise, k.reject_moving, k.half_gap, k.rt2, p->flags, (int64_t)(intptr_t)a0, (int64_t)(intptr_t)a1, (int64_t)(intptr_t)a2, (int64_t)(intptr_t)a3,
+                            k.exec_bits_lds, k.exec_pairwise, k.lds_rank, k.reject_moving, k.half_gap, k.rt2, p->flags, (int64_t)(intptr_t)a0, (int64_t)(intptr_t)a1, (int64_t)(intptr_t)a2, (int64_t)(intptr_t)a3,
                             (int64_t)(intptr_t)c->w.desc, (int64_t)(intptr_t)c->w.thr, (int64_t)(intptr_t)c->w.lut, (int64_t)(intptr_t)c->w.r1, (int64_t)(intptr_t)c->w.counts,
                             (int64_t)(intptr_t)c->w.near_over, (int64_t)(intptr_t)c->w.acc, (int64_t)(intptr_t)c->w.fit_items, (int64_t)(intptr_t)c->w.sort_tmp, (int64_t)(intptr_t)c->w.tile_vr};
     static_assert(sizeof(vals) == sizeof(key.v), "GraphKey size");
@@ -1093,6 +1099,7 @@ icet_status icet_solve(icet_ctx* c, const icet_params* p, const float* scan1, in
 icet_status icet_debug_fetch(icet_ctx* c, int32_t what, void* out, int64_t count) {
     if (!c || !out || count < 0) return ICET_ERR_BAD_ARG;
     const Workspace& w = c->w;
+    if (what == 6) { if (count != 1) return ICET_ERR_BAD_ARG; *static_cast<int32_t*>(out) = c->lds_rank_ok; return ICET_OK; }   // no device array: the verdict of lds_rank_selftest
     const void* src = nullptr; int64_t cap = w.cap_n1; size_t elem = 4;
     switch (what) {
         case 0: src = w.r1; break;
@@ -1125,6 +1132,7 @@ icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
     else if (k == "rs_cap") t.rs_cap = iv < 0 ? 0 : iv;
     else if (k == "rs_max_cell") t.rs_max_cell = iv < 0 ? 0 : iv;
     else if (k == "exec_bits_lds") t.exec_bits_lds = iv != 0;
+    else if (k == "lds_rank") t.lds_rank = iv < 0 ? -1 : (iv > 2 ? 2 : iv);     // 2: as 1, but the rank sort's multi-split stores unstaged (experiments)
     else if (k == "exec_pairwise") t.exec_pairwise = iv < 0 ? -1 : (iv != 0);
     else if (k == "graph") { c->graph_mode = iv < 0 ? -1 : (iv != 0); c->g_solve.have_seen = c->g_keyframe.have_seen = c->g_loop.have_seen = false; }
     else if (k == "guard_scale") { if (!(value >= 1.0 && value <= 1024.0)) { c->err = "guard_scale must lie in [1, 1024]"; return ICET_ERR_BAD_ARG; } t.guard_scale = value; c->w.thr_T = 0; }   // tables are rebuilt by the next call

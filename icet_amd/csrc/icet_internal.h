@@ -141,6 +141,7 @@ struct Tuning {
     int rs_cap = 0;               // LDS rows of the per-bucket sort (0 = from the largest scan)
     int rs_max_cell = 24;         // per-bucket counting sort: a cell above this many rows sends the bucket to the radix sort (0: always)
     int exec_bits_lds = 1;        // k_scramble_src keeps the pair's swap-loop bit table in LDS (0: reads it from memory, the path of scans above ~0.75 M rows)
+    int lds_rank = -1;            // the stable multi-splits take a row's rank from the value its LDS atomic hands back (1 / -1: if this device passed lds_rank_selftest; 0: ballots per id bit)
     int exec_pairwise = -1;       // "did step v execute": one block per pair in index order with the bit table in LDS (k_exec_flags_pair) 1, chain walks (k_exec_flags) 0, by batch size -1
     double guard_scale = 1.0;     // multiplies the classification guard bands (tables are rebuilt)
     double lut_polar_quantile = 0.25;   // polar LUT cell width = this quantile of the polar bin widths
@@ -168,6 +169,7 @@ struct LaunchCfg {
     int reject_moving = 0;            // ICET_FLAG_REJECT_MOVING (non-parity extension)
     int half_gap = 0;                 // ICET_FLAG_HALF_GAP_BOUNDS (non-parity extension; sets true_sort as well)
     int rt2 = 0;                      // ICET_FLAG_ROUNDTRIP_SCAN2 (parity-study option)
+    int lds_rank = 0;                 // Tuning::lds_rank, resolved against the context's self-test
 };
 constexpr float kRejectMovingThresh = 0.3f;        // python/ICET_spherical.py:38  RM_thresh
 constexpr int kRejectMovingStartIter = 4;          // python/ICET_spherical.py:36  start_RM_iter
@@ -190,6 +192,8 @@ hipError_t launch_side_scan2(const Workspace& w, const LaunchCfg& c, const float
 // Raise the dynamic-LDS limit of the kernels that need more than the default; called once per context (icet_create) with the
 // context's device current -- no process-global "done" flags.
 hipError_t init_keyframe_kernels();
+// does this device hand back the pre-add values of one wave's LDS atomic in ascending lane order (what Tuning::lds_rank rests on)?  Synchronises st.
+hipError_t lds_rank_selftest(int32_t* d_scratch, hipStream_t st, int* ok);
 hipError_t init_accumulate_kernels();
 hipError_t init_rank_sort_kernels();
 

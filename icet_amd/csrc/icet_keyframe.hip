@@ -44,7 +44,10 @@ __device__ __noinline__ int voxel_literal(float px, float py, float pz, float r_
     return voxel_of(theta_cr(py, px), phi_cr(pz, r_raw), T, P);
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __restrict__ desc, float* __restrict__ r1,
+#ifndef ICET_S1_WAVES
+#define ICET_S1_WAVES 8
+#endif
+__global__ __launch_bounds__(kBlock, ICET_S1_WAVES) void k_scan1_spherical(const PairDesc* __restrict__ desc, float* __restrict__ r1,
                                                             unsigned long long* __restrict__ key64, uint32_t* __restrict__ key32,
                                                             uint32_t* __restrict__ val, uint16_t* __restrict__ bin16, int T, int P, int n_pairs, int chunks,
                                                             const uint32_t* __restrict__ splitters, uint8_t* __restrict__ bkt, uint32_t* __restrict__ counts,
@@ -68,9 +71,21 @@ __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __re
     }
     const float cell_t = (float)Mt * 0.25f, cell_p = (float)Mp * 0.5f;
     int vlo = 0x7FFFFFFF, vhi = -1;                                   // voxel ids this thread has seen
-    ICET_FOR_CHUNK_OF_SCAN1(i) {
-        const float* x = d.s1; const float* y = d.s1 + d.ld1; const float* z = d.s1 + 2 * (size_t)d.ld1;
-        const float px = x[i], py = y[i], pz = z[i];
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    const PairDesc d = desc[pair];
+    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
+    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
+    // the scan lives in HBM: global_load (vmcnt only) instead of flat_load, and the NEXT row's coordinates are requested before this row is
+    // worked on -- with one row per thread in flight the 32 waves of a CU hold 24 KB of reads, which at this kernel's 19 B per row of
+    // traffic is what ~1.3 us of memory latency can carry
+    typedef __attribute__((address_space(1))) const float gfloat;
+    gfloat* x = (gfloat*)d.s1; gfloat* y = (gfloat*)(d.s1 + d.ld1); gfloat* z = (gfloat*)(d.s1 + 2 * (size_t)d.ld1);
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    { const int i0 = lo_ + (int)threadIdx.x; if (i0 < hi_) { nx = x[i0]; ny = y[i0]; nz = z[i0]; } }
+    for (int i = lo_ + threadIdx.x; i < hi_; i += kBlock) {
+        const float px = nx, py = ny, pz = nz;
+        { const int j = i + kBlock; if (j < hi_) { nx = x[j]; ny = y[j]; nz = z[j]; } }
         const float rr = radius_raw(px, py, pz);
         // which voxel: fast classification, literal formulas within a guard band of an edge (and for anything that is not an
         // ordinary number: zero rows, NaN, inf, magnitudes whose square leaves the float range)
@@ -528,7 +543,13 @@ __global__ __launch_bounds__(kScanBlock) void k_bin_scan(int32_t* __restrict__ c
 
 // One block per tile (<= 2048 positions); wave w owns the w-th quarter (<= 8 rounds of 64 positions).  Everything
 // global is loaded up front and stored at the end, so the only serial chain is 8 rounds of ballots + LDS.
+// kLdsRank: the rank of a row among the rows of its wave's quarter that hold the same voxel is the value the LDS atomic of the counting
+// step hands back -- gfx950 serves the lanes of one ds_add_rtn that hit the same address in ascending lane order, and a wave's LDS
+// instructions in program order (scripts/hip/lds_atomic_order.hip: 10^10 atomics, no exception; checked again by every context at creation,
+// lds_rank_selftest; the ballot form below stays as the fallback and as the tests' cross-check).  The ballot form costs ~10 VALU
+// instructions per id bit and round -- 11 bits x 8 rounds -- and this kernel is bound by VALU issue (4 cycles per wave64 instruction).
 constexpr int kScatterRounds = kKfMaxPtsPerThread;   // a tile is at most 4 waves x this many rounds x 64 positions
+template <bool kLdsRank>
 __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restrict__ desc, const int32_t* __restrict__ src, const uint16_t* __restrict__ binpos,
                                                         const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bin_start,
                                                         uint32_t* __restrict__ sorted_row, int V, int vbits, int n_pairs, int chunks, const int32_t* __restrict__ vrange) {
@@ -562,7 +583,8 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
         row[k] = (ok[k] ? (uint32_t)src[o + v] : 0u) | ((wd & kRowNearBit) ? kSortedNearBit : 0u) | ((wd & kRowZeroBit) ? kSortedZeroBit : 0u);   // the flags travel with the row
         if (ok[k]) {                                                   // 16-bit counters, 32-bit atomics: a quarter tile holds <= 512 rows, no carry into the neighbour
             const uint32_t e = (uint32_t)(wave * V) + bb[k];
-            atomicAdd(&lb[V + (e >> 1)], 1u << (16u * (e & 1u)));
+            const uint32_t old = atomicAdd(&lb[V + (e >> 1)], 1u << (16u * (e & 1u)));
+            if (kLdsRank) bb[k] |= ((old >> (16u * (e & 1u))) & 0xFFFFu) << 16;     // earlier rows of this wave with the same voxel (<= 511), kept above the 14 id bits
         }
     }
     __syncthreads();
@@ -579,6 +601,10 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
     __syncthreads();
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t dest[kScatterRounds];
+    if (kLdsRank) {
+#pragma unroll
+        for (int k = 0; k < kScatterRounds; k++) { const uint32_t b = bb[k] & 0xFFFFu; dest[k] = ok[k] ? gb[b] + (uint32_t)mine[b] + (bb[k] >> 16) : 0u; }
+    } else
 #pragma unroll
     for (int k = 0; k < kScatterRounds; k++) {
         unsigned long long peers = __ballot(ok[k]);
@@ -1165,9 +1191,50 @@ __global__ __launch_bounds__(kCompactBlock) void k_compact_slots(const SlotHot* 
 }
 
 
+// The property kLdsRank rests on, checked on THIS device: every wave adds 1 to counters its lanes pick (few / many distinct ones, runs of
+// equal neighbours, packed 16-bit halves) and compares the value handed back with the ballot-computed number of earlier occurrences.
+constexpr int kOrderClasses = 512;
+__global__ __launch_bounds__(kBlock) void k_lds_order_selftest(int rounds, int32_t* __restrict__ bad) {
+    __shared__ uint32_t cnt[kBlock / 64][kOrderClasses / 2];
+    __shared__ uint16_t ref[kBlock / 64][kOrderClasses];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < (kBlock / 64) * kOrderClasses / 2; i += kBlock) (&cnt[0][0])[i] = 0u;
+    for (int i = threadIdx.x; i < (kBlock / 64) * kOrderClasses; i += kBlock) (&ref[0][0])[i] = 0;
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int nbad = 0;
+    for (int r = 0; r < rounds; r++) {
+        uint32_t h = (uint32_t)(blockIdx.x * 7919 + r * 104729 + wave * 31) * 0x9E3779B9u; h ^= h >> 15;
+        const int distinct = 1 << (h % 10u);                              // 1 .. 512 classes in play
+        uint32_t x = (h + (uint32_t)((r & 1) ? (lane >> (h >> 8 & 3)) : lane)) * 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+        const uint32_t c = x % (uint32_t)distinct;
+        unsigned long long peers = ~0ull;
+#pragma unroll
+        for (int q = 0; q < 9; q++) { const bool bit = (c >> q) & 1u; const unsigned long long m = __ballot(bit); peers &= bit ? m : ~m; }
+        const uint32_t before = ref[wave][c];
+        const uint32_t old = atomicAdd(&cnt[wave][c >> 1], 1u << (16u * (c & 1u)));
+        if (((old >> (16u * (c & 1u))) & 0xFFFFu) != before + (uint32_t)__popcll(peers & lt)) nbad++;
+        if ((peers & lt) == 0ull) ref[wave][c] = (uint16_t)(before + (uint32_t)__popcll(peers));
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
 }  // namespace
 
 #define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t lds_rank_selftest(int32_t* d_scratch, hipStream_t st, int* ok) {
+    *ok = 0;
+    hipError_t e = hipMemsetAsync(d_scratch, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return e;
+    k_lds_order_selftest<<<1024, kBlock, 0, st>>>(48, d_scratch);          // every CU four times over; <= 48 x 64 per counter: no carry out of a 16-bit half
+    ICET_LAUNCH_CHECK();
+    int32_t bad = -1;
+    e = hipMemcpyAsync(&bad, d_scratch, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) *ok = (bad == 0);
+    return e;
+}
 
 // dynamic LDS of the keyframe kernels, bytes: the voxel-indexed ones grow with the grid (validated against the device in ensure_workspace)
 // k_scramble_src keeps the pair's exec bit table in LDS while histogram + table stay below this (0.75 M rows on a 75 x 24 grid)
@@ -1176,7 +1243,8 @@ static size_t scan1_lds_bytes(const Workspace& w) { return (size_t)(w.lut_Mt + w
 
 hipError_t init_keyframe_kernels() {
     const int cap = 160 * 1024 - 2048;        // static __shared__ of the kernels comes on top
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scramble_src<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scramble_src<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_hist), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
@@ -1247,7 +1315,8 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     }
     e = launch_class_scan(w.counts, w.tile_base, w.bin_start, c.V, chunks, c.n_pairs, st, w.live_bins, w.n_live, c.n, w.fit_n_items, w.vrange);
     if (e != hipSuccess) return e;
-    k_bin_scatter<<<grid, blk, (size_t)c.V * 12 + 8, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks, w.vrange);
+    if (c.lds_rank) k_bin_scatter<true><<<grid, blk, (size_t)c.V * 12 + 8, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks, w.vrange);
+    else k_bin_scatter<false><<<grid, blk, (size_t)c.V * 12 + 8, st>>>(w.desc, w.src, w.binpos, w.tile_base, w.bin_start, w.valA, c.V, vbits, np, chunks, w.vrange);
     ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 3) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     // keyA / keyB (bucket-grouped keys and the overflow scratch of the rank sort) are dead by now: candidate rows and their r

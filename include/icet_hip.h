@@ -197,7 +197,8 @@ icet_status icet_last_timing(icet_ctx* ctx, float out_ms[4]);
  * the literal formulas", bit 15 "r is exactly 0" (theta / phi themselves are not materialised: only decisions and the
  * Gaussians need them); 3 = int32 src[v], the original row that
  * sits at position v after the reference's sort + swap loop (src/icet.cpp:72-83); 4 = int32 per-pair
- * flags (bit 0: the bounded parallel walk overflowed and the serial replay was used).  `count` elements
+ * flags (bit 0: the bounded parallel walk overflowed and the serial replay was used); 6 = ONE int32: 1 if this device passed the
+ * context's LDS-atomic order self-test (option "lds_rank").  `count` elements
  * from the start of the batch's concatenated scan-1 arrays (pairs for what = 4). */
 icet_status icet_debug_fetch(icet_ctx* ctx, int32_t what, void* out, int64_t count);
 
@@ -208,6 +209,8 @@ icet_status icet_debug_fetch(icet_ctx* ctx, int32_t what, void* out, int64_t cou
  * "acc_blocks", "kf_pts", "rs_cap", "rs_max_cell" (0: per-bucket radix sort instead of the counting sort),
  * "graph" (device-resident batches of <= 8 pairs: when a call's launch geometry and pointers equal the previous call's, the whole
  * solve is captured into a hipGraph and replayed from then on -- one hipGraphLaunch instead of ~33 launches on the host; 0 = never, default -1 = on),
+ * "lds_rank" (the keyframe's stable multi-splits take a row's rank among equal classes from the value its LDS atomic hands back: -1 / 1 if
+ * the device passed the order self-test run at icet_create, 0 = one ballot per class-id bit; same bits either way),
  * "exec_bits_lds" (0: swap-loop bit table read from memory), "exec_pairwise" (which kernel computes the swap loop's executed-step bits:
  * 1 one block per pair from the recurrence, 0 chain walks over independent tiles, -1 by batch size), "batch_parts" (0 = automatic), "batch_stage" (0..4), "force_exact"
  * (every scan-2 point through the literal classification), "library_sort" (rocPRIM radix sort instead of

@@ -1090,11 +1090,13 @@ def test_rarely_taken_paths_give_the_same_bits(gpu_ctx, frames, sample_pc):
     fit LDS (global-scratch radix sort), buckets whose keys pile up in one cell of the counting sort (LDS radix sort), the swap-loop
     bit table read from memory instead of LDS (scans above ~0.75 M rows), the executed-step bits from the per-pair recurrence kernel (the
     kernel of throughput batches) and from the chain walks (small batches), small keyframe tiles, few / many accumulate blocks, and the
-    library (rocPRIM) sort that the hand-written rank sort replaced."""
+    library (rocPRIM) sort that the hand-written rank sort replaced; the stable multi-splits with ranks from ballots instead of the values the
+    LDS atomics hand back (the default on a device that passed the order self-test -- which an MI355X must)."""
     a, b = frames; c, d = sample_pc
+    assert gpu_ctx.debug_fetch("lds_rank_ok", 1)[0] == 1, "LDS atomics of one wave not served in lane order on this device?"
     base1 = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
     base2 = gpu_ctx.solve(c, d, 7, np.zeros(6), 48, 150)
-    knobs = [("lds_slots", 32, 0), ("rs_cap", 128, 0), ("rs_max_cell", 0, 24), ("rs_max_cell", 1, 24), ("exec_bits_lds", 0, 1), ("exec_pairwise", 1, -1), ("exec_pairwise", 0, -1), ("kf_pts", 1, 8), ("kf_pts", 3, 8), ("acc_blocks", 7, 1536),
+    knobs = [("lds_slots", 32, 0), ("rs_cap", 128, 0), ("rs_max_cell", 0, 24), ("rs_max_cell", 1, 24), ("exec_bits_lds", 0, 1), ("lds_rank", 0, -1), ("exec_pairwise", 1, -1), ("exec_pairwise", 0, -1), ("kf_pts", 1, 8), ("kf_pts", 3, 8), ("acc_blocks", 7, 1536),
              ("acc_pts", 64, 4), ("library_sort", 1, 0), ("batch_stage", 0, 4)]
     for key, val, default in knobs:
         gpu_ctx.set_option(key, val)

@@ -44,10 +44,7 @@ __device__ __noinline__ int voxel_literal(float px, float py, float pz, float r_
     return voxel_of(theta_cr(py, px), phi_cr(pz, r_raw), T, P);
 }
 
-#ifndef ICET_S1_WAVES
-#define ICET_S1_WAVES 8
-#endif
-__global__ __launch_bounds__(kBlock, ICET_S1_WAVES) void k_scan1_spherical(const PairDesc* __restrict__ desc, float* __restrict__ r1,
+__global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __restrict__ desc, float* __restrict__ r1,
                                                             unsigned long long* __restrict__ key64, uint32_t* __restrict__ key32,
                                                             uint32_t* __restrict__ val, uint16_t* __restrict__ bin16, int T, int P, int n_pairs, int chunks,
                                                             const uint32_t* __restrict__ splitters, uint8_t* __restrict__ bkt, uint32_t* __restrict__ counts,
@@ -71,21 +68,9 @@ __global__ __launch_bounds__(kBlock, ICET_S1_WAVES) void k_scan1_spherical(const
     }
     const float cell_t = (float)Mt * 0.25f, cell_p = (float)Mp * 0.5f;
     int vlo = 0x7FFFFFFF, vhi = -1;                                   // voxel ids this thread has seen
-    int pair, chunk;
-    if (!decode_block(n_pairs, chunks, pair, chunk)) return;
-    const PairDesc d = desc[pair];
-    int cs_ = (d.n1 + chunks - 1) / chunks; cs_ = (cs_ + kBlock - 1) / kBlock * kBlock;
-    const int lo_ = chunk * cs_, hi_ = min(d.n1, lo_ + cs_);
-    // the scan lives in HBM: global_load (vmcnt only) instead of flat_load, and the NEXT row's coordinates are requested before this row is
-    // worked on -- with one row per thread in flight the 32 waves of a CU hold 24 KB of reads, which at this kernel's 19 B per row of
-    // traffic is what ~1.3 us of memory latency can carry
-    typedef __attribute__((address_space(1))) const float gfloat;
-    gfloat* x = (gfloat*)d.s1; gfloat* y = (gfloat*)(d.s1 + d.ld1); gfloat* z = (gfloat*)(d.s1 + 2 * (size_t)d.ld1);
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    { const int i0 = lo_ + (int)threadIdx.x; if (i0 < hi_) { nx = x[i0]; ny = y[i0]; nz = z[i0]; } }
-    for (int i = lo_ + threadIdx.x; i < hi_; i += kBlock) {
-        const float px = nx, py = ny, pz = nz;
-        { const int j = i + kBlock; if (j < hi_) { nx = x[j]; ny = y[j]; nz = z[j]; } }
+    ICET_FOR_CHUNK_OF_SCAN1(i) {
+        const float* x = d.s1; const float* y = d.s1 + d.ld1; const float* z = d.s1 + 2 * (size_t)d.ld1;
+        const float px = x[i], py = y[i], pz = z[i];
         const float rr = radius_raw(px, py, pz);
         // which voxel: fast classification, literal formulas within a guard band of an edge (and for anything that is not an
         // ordinary number: zero rows, NaN, inf, magnitudes whose square leaves the float range)
@@ -574,13 +559,20 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const PairDesc* __restri
     const size_t o = d.off1;
     uint32_t bb[kScatterRounds]; uint32_t row[kScatterRounds]; bool ok[kScatterRounds];
     uint16_t* mine = lc + wave * V;
+    // Two loops: all of the thread's loads first (unconditional, at a clamped index), then the LDS atomics.  Written as one loop with
+    // `ok ? load : 0` every round sits in a branch of its own -- load, wait, atomic -- and the rounds are eight dependent memory round trips.
 #pragma unroll
     for (int k = 0; k < kScatterRounds; k++) {
         const int v = wlo + 64 * k + lane;
         ok[k] = (k < rounds) & (v < whi);
-        const uint32_t wd = ok[k] ? (uint32_t)binpos[o + v] : 0u;
+        const size_t vv = o + (size_t)(ok[k] ? v : lo_);
+        bb[k] = binpos[vv]; row[k] = (uint32_t)src[vv];
+    }
+#pragma unroll
+    for (int k = 0; k < kScatterRounds; k++) {
+        const uint32_t wd = ok[k] ? bb[k] : 0u;
         bb[k] = wd & kRowBinMask;
-        row[k] = (ok[k] ? (uint32_t)src[o + v] : 0u) | ((wd & kRowNearBit) ? kSortedNearBit : 0u) | ((wd & kRowZeroBit) ? kSortedZeroBit : 0u);   // the flags travel with the row
+        row[k] = (ok[k] ? row[k] : 0u) | ((wd & kRowNearBit) ? kSortedNearBit : 0u) | ((wd & kRowZeroBit) ? kSortedZeroBit : 0u);   // the flags travel with the row
         if (ok[k]) {                                                   // 16-bit counters, 32-bit atomics: a quarter tile holds <= 512 rows, no carry into the neighbour
             const uint32_t e = (uint32_t)(wave * V) + bb[k];
             const uint32_t old = atomicAdd(&lb[V + (e >> 1)], 1u << (16u * (e & 1u)));

@@ -166,11 +166,15 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restric
     uint32_t bb[kScatterRounds], key[kScatterRounds]; bool ok[kScatterRounds];
     uint32_t* mine = lb + wave * kMaxBuckets;
 #pragma unroll
-    for (int k = 0; k < kScatterRounds; k++) {
+    for (int k = 0; k < kScatterRounds; k++) {                       // all loads first (clamped, unconditional: see k_bin_scatter), then the atomics
         const int v = wlo + 64 * k + lane;
         ok[k] = (k < rounds) & (v < whi);
-        bb[k] = ok[k] ? (uint32_t)bkt[o + v] : 0u;
-        key[k] = ok[k] ? __float_as_uint(r1[o + v]) : 0u;
+        const size_t vv = o + (size_t)(ok[k] ? v : lo_);
+        bb[k] = bkt[vv]; key[k] = __float_as_uint(r1[vv]);
+    }
+#pragma unroll
+    for (int k = 0; k < kScatterRounds; k++) {
+        if (!ok[k]) { bb[k] = 0u; key[k] = 0u; }
         if (ok[k]) { const uint32_t old = atomicAdd(&mine[bb[k]], 1u); if (kLdsRank) bb[k] |= old << 8; }      // (bucket ids are 7 bits)
     }
     __syncthreads();
@@ -235,11 +239,15 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter_staged(const PairDesc* __
     uint32_t bb[kScatterRounds], key[kScatterRounds]; bool ok[kScatterRounds];
     uint32_t* mine = lb + wave * kMaxBuckets;
 #pragma unroll
-    for (int k = 0; k < kScatterRounds; k++) {
+    for (int k = 0; k < kScatterRounds; k++) {                       // all loads first (clamped, unconditional: see k_bin_scatter), then the atomics
         const int v = wlo + 64 * k + lane;
         ok[k] = (k < rounds) & (v < whi);
-        bb[k] = ok[k] ? (uint32_t)bkt[o + v] : 0u;
-        key[k] = ok[k] ? __float_as_uint(r1[o + v]) : 0u;
+        const size_t vv = o + (size_t)(ok[k] ? v : lo_);
+        bb[k] = bkt[vv]; key[k] = __float_as_uint(r1[vv]);
+    }
+#pragma unroll
+    for (int k = 0; k < kScatterRounds; k++) {
+        if (!ok[k]) { bb[k] = 0u; key[k] = 0u; }
         if (ok[k]) bb[k] |= atomicAdd(&mine[bb[k]], 1u) << 8;       // earlier rows of this wave in the bucket (ids are 7 bits)
     }
     __syncthreads();

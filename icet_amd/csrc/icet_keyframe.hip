@@ -317,29 +317,38 @@ __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const P
         for (int k = 0; k < kWalk; k++) {
             const int v = base + k * kBlock;
             const bool valid = v < hi_;
-            const bool moved = valid && pv[k] != v;             // s[v] != v  <=>  pred[v] != v (fixed points of a permutation)
+            const bool moved = valid & (pv[k] != v);            // s[v] != v  <=>  pred[v] != v (fixed points of a permutation)
             f[k] = moved ? pv[k] : v;
-            act[k] = moved && exec(v) && !exec(pv[k]);           // head of a run of executed steps
+            act[k] = moved & exec(valid ? v : lo_) & !exec(pv[k]);   // head of a run of executed steps (no short circuit: both table reads leave at once)
             u[k] = v; len[k] = 0;
         }
         bool any = false;
 #pragma unroll
         for (int k = 0; k < kWalk; k++) any |= act[k];
+        bool over = false;
         while (any) {
             int nu[kWalk];
 #pragma unroll
             for (int k = 0; k < kWalk; k++) nu[k] = act[k] ? (int)s[o + u[k]] : 0;
+            // straight-line from here (selects, no branch per chain): the eight bit-table reads leave together instead of each one
+            // waiting inside its chain's branch; an idle chain reads word 0
+            unsigned long long w[kWalk];
+#pragma unroll
+            for (int k = 0; k < kWalk; k++) w[k] = kBitsInLds ? lbits[nu[k] >> 6] : (act[k] ? gbits[nu[k] >> 6] : 0ull);
             any = false;
 #pragma unroll
             for (int k = 0; k < kWalk; k++) {
-                if (act[k]) {
-                    u[k] = nu[k]; len[k]++;
-                    if (!exec(nu[k])) { f[k] = u[k]; act[k] = false; }
-                    else if (len[k] > max_walk) { atomicOr(&flags[pair], 1); f[k] = u[k]; act[k] = false; }
-                }
+                const bool a = act[k], ex = (w[k] >> (nu[k] & 63)) & 1ull;
+                u[k] = a ? nu[k] : u[k]; len[k] += a ? 1 : 0;
+                const bool too_long = len[k] > max_walk;
+                over |= a & ex & too_long;
+                const bool stop = !ex | too_long;
+                f[k] = (a & stop) ? nu[k] : f[k];
+                act[k] = a & !stop;
                 any |= act[k];
             }
         }
+        if (over) atomicOr(&flags[pair], 1);
         uint16_t fb[kWalk];                                      // packed word of the row that lands here (its voxel id is what the histogram needs)
 #pragma unroll
         for (int k = 0; k < kWalk; k++) { const int v = base + k * kBlock; fb[k] = (v < hi_) ? bin16[o + f[k]] : (uint16_t)0; }

@@ -344,13 +344,100 @@ __device__ __forceinline__ bool counting_sort_lds(uint32_t* smem, int Clayout, i
     return true;
 }
 
+// The same counting sort for a bucket that is ENTIRELY in the threads' registers (n <= kRsPrefetch x 256 rows: 97 % of the buckets of a
+// 64-channel scan): the keys never go through the first LDS buffer, and every phase is straight-line code over the thread's <= 5 rows -- five
+// independent LDS atomics, then five placements, then five rank walks -- instead of a loop whose every trip waits for its own LDS reads.
+// The cells must have been zeroed before the barriers of block_key_stats.  Same cells, same ranks, same bits as counting_sort_lds.
+__device__ __forceinline__ bool counting_sort_regs(uint32_t* smem, int Clayout, int logC, int kCap, int n, const uint2 (&pf)[kRsPrefetch], uint32_t kmin, uint32_t kmax,
+                                                   int lo, size_t off1, uint32_t* s_out, int32_t* pred_out, int max_cell) {
+    uint32_t* cells = smem; uint32_t* red = smem + cell_region(Clayout);
+    const int offBuf = cell_region(Clayout) + kRedWords;
+    const int C = 1 << logC;
+    uint2* KI = reinterpret_cast<uint2*>(smem + offBuf);                  // (key, row) side by side; the first buffer is free on this path (offBuf is even: 8-byte aligned)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t range = kmax - kmin;                                   // > 0 here
+    const int sh = max(0, 32 - __clz(range) - logC);                      // (range >> sh) < C
+    uint32_t c[kRsPrefetch]; bool ok[kRsPrefetch];
+#pragma unroll
+    for (int k = 0; k < kRsPrefetch; k++) { ok[k] = (int)threadIdx.x + k * kSortBlock < n; c[k] = ok[k] ? (pf[k].x - kmin) >> sh : 0u; }
+#pragma unroll
+    for (int k = 0; k < kRsPrefetch; k++) if (ok[k]) atomicAdd(&cells[c[k]], 1u);
+    __syncthreads();
+    {   // exclusive scan of the cell counts in place (thread t owns C / 256 consecutive cells) + the largest count
+        const int per = C / kSortBlock, c0 = threadIdx.x * per;
+        uint32_t sum = 0u, big = 0u;
+        for (int j = 0; j < per; j++) { const uint32_t x = cells[c0 + j]; sum += x; big = max(big, x); }
+        const int incl = wave_incl_sum((int)sum);
+        big = wave_reduce_max(big);
+        if (lane == 63) { red[wave] = (uint32_t)incl; red[kSortWaves + wave] = big; }
+        __syncthreads();
+        uint32_t base = (uint32_t)incl - sum;
+        for (int k = 0; k < wave; k++) base += red[k];
+        big = 0u;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; w++) big = max(big, red[kSortWaves + w]);
+        if (big > (uint32_t)max_cell) { __syncthreads(); return false; }          // block-uniform
+        for (int j = 0; j < per; j++) { const uint32_t x = cells[c0 + j]; cells[c0 + j] = base; base += x; }
+    }
+    __syncthreads();
+    // placement by cell, in arrival order inside a cell; afterwards cells[c] = END of cell c (its begin = cells[c - 1])
+#pragma unroll
+    for (int k = 0; k < kRsPrefetch; k++)
+        if (ok[k]) KI[atomicAdd(&cells[c[k]], 1u)] = pf[k];
+    __syncthreads();
+    uint32_t b[kRsPrefetch], e[kRsPrefetch];
+#pragma unroll
+    for (int k = 0; k < kRsPrefetch; k++) { b[k] = (ok[k] & (c[k] != 0u)) ? cells[c[k] - (c[k] != 0u ? 1u : 0u)] : 0u; e[k] = ok[k] ? cells[c[k]] : 0u; }
+#pragma unroll
+    for (int k = 0; k < kRsPrefetch; k++) {
+        if (!ok[k]) continue;
+        const uint32_t key = pf[k].x, id = pf[k].y;
+        uint32_t r = b[k];
+        // the first kCellAhead members of the cell in ONE round of reads (a cell holds 1 - 3 rows; walked one member per trip, the wave makes as
+        // many dependent LDS round trips as its fullest cell has rows -- this phase was 40 % of the kernel), the rest of a crowded cell in a loop
+        constexpr uint32_t kCellAhead = 4;
+        uint2 m[kCellAhead];
+#pragma unroll
+        for (uint32_t t = 0; t < kCellAhead; t++) m[t] = KI[min(b[k] + t, (uint32_t)n - 1u)];
+#pragma unroll
+        for (uint32_t t = 0; t < kCellAhead; t++) r += ((b[k] + t < e[k]) & ((m[t].x < key) | ((m[t].x == key) & (m[t].y < id)))) ? 1u : 0u;
+        for (uint32_t j = b[k] + kCellAhead; j < e[k]; j++) { const uint2 x = KI[j]; r += ((x.x < key) | ((x.x == key) & (x.y < id))) ? 1u : 0u; }
+        s_out[off1 + lo + r] = id;
+        pred_out[off1 + id] = lo + (int)r;
+    }
+    return true;
+}
+
 // pf: the bucket's first kRsPrefetch x 256 (key, row) pairs, already in registers (fetched while the block sorted its previous bucket)
 template <bool kLds>
 __device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int C, int logC, int kCap, const uint2* bkv, uint2* gA, uint2* gB,
-                                                 int n, int lo, size_t off1, uint32_t* s_out, int32_t* pred_out, int max_cell, const uint2 (&pf)[kRsPrefetch]) {
+                                                 int n, int lo, size_t off1, uint32_t* s_out, int32_t* pred_out, int max_cell, const uint2 (&pf)[kRsPrefetch],
+                                                 uint32_t key_lo, uint32_t key_hi) {      // key_lo <= key_hi: bounds of the bucket's keys known from the splitters
     const size_t o = off1 + lo;
     const int offBuf = cell_region(C) + kRedWords;
     uint32_t vor = 0u, vand = 0xFFFFFFFFu, vmin = 0xFFFFFFFFu, vmax = 0u;
+    if (kLds && n <= kRsPrefetch * kSortBlock) {                              // block-uniform: the whole bucket is in registers
+        const int logCr = min(logC, 10);
+        for (int j = threadIdx.x; j < (1 << logCr); j += kSortBlock) smem[j] = 0u;     // the cells
+        if (key_lo <= key_hi) {
+            // an inner bucket: its keys lie in (splitter, next splitter] -- the counting sort only needs A range that holds them, so the
+            // block-wide min / max (four wave reductions, two barriers) is left to the first and the last bucket of the pair
+            vmin = key_lo; vmax = key_hi; vor = key_hi; vand = key_lo == key_hi ? key_hi : 0u;
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int k = 0; k < kRsPrefetch; k++)
+                if ((int)threadIdx.x + k * kSortBlock < n) { const uint32_t x = pf[k].x; vor |= x; vand &= x; vmin = min(vmin, x); vmax = max(vmax, x); }
+            block_key_stats(smem + cell_region(C), vor, vand, vmin, vmax);    // (its barriers also publish the zeroed cells)
+        }
+        if ((vor & ~vand) == 0u) {                                             // identical keys: already in order (the multi-split is stable)
+#pragma unroll
+            for (int k = 0; k < kRsPrefetch; k++) { const int i = (int)threadIdx.x + k * kSortBlock; if (i < n) { s_out[o + i] = pf[k].y; pred_out[off1 + pf[k].y] = lo + i; } }
+            return;
+        }
+        if (counting_sort_regs(smem, C, logCr, kCap, n, pf, vmin, vmax, lo, off1, s_out, pred_out, max_cell)) return;
+        vor = 0u; vand = 0xFFFFFFFFu; vmin = 0xFFFFFFFFu; vmax = 0u;            // a crowded cell: the general path below, from the start
+    }
 #pragma unroll
     for (int k = 0; k < kRsPrefetch; k++) {
         const int i = threadIdx.x + k * kSortBlock;
@@ -389,7 +476,8 @@ __device__ __forceinline__ void bucket_sort_body(uint32_t* smem, int C, int logC
 template <int kRsPerBlock>
 __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bucket_start,
                                                                const int32_t* __restrict__ n_buckets, uint2* __restrict__ bkv, uint2* __restrict__ alt,
-                                                               uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out, int kCap, int logC, int max_cell, int n_pairs) {
+                                                               uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out, int kCap, int logC, int max_cell, int n_pairs,
+                                                               const uint32_t* __restrict__ splitters) {
     extern __shared__ uint32_t smem[];
     // all buckets of a pair on one XCD (decode_block): their scattered 4-byte writes of pred[] then complete whole cache lines in
     // ONE L2 instead of leaving partial lines in eight
@@ -405,11 +493,16 @@ __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* _
     constexpr int kStride = kMaxBuckets / kRsPerBlock;
     const int32_t* bs = bucket_start + (size_t)pair * (kMaxBuckets + 1);
     int los[kRsPerBlock], ns[kRsPerBlock];
+    uint32_t klo[kRsPerBlock], khi[kRsPerBlock];
 #pragma unroll
     for (int q = 0; q < kRsPerBlock; q++) {
         const int bkt = part + q * kStride;
         const bool ok = bkt < nb;
         los[q] = ok ? bs[bkt] : 0; ns[q] = ok ? bs[bkt + 1] - los[q] : 0;
+        // bucket = number of splitters strictly below the key: an inner bucket holds splitter[bkt] < key <= splitter[bkt + 1]
+        const bool inner = ok && bkt >= 1 && bkt + 1 < nb;
+        const uint32_t a = inner ? splitters[(size_t)pair * kMaxBuckets + bkt] : 0xFFFFFFFFu, b2 = inner ? splitters[(size_t)pair * kMaxBuckets + bkt + 1] : 0u;
+        klo[q] = (inner && a < b2) ? a + 1u : 1u; khi[q] = (inner && a < b2) ? b2 : 0u;           // (1, 0): not known
     }
     auto fetch = [&](int lo, int n, uint2 (&pf)[kRsPrefetch]) {
 #pragma unroll
@@ -423,8 +516,8 @@ __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* _
         if (q + 1 < kRsPerBlock) fetch(los[q + 1], ns[q + 1], nf);
         const int lo = los[q], n = ns[q];
         if (n > 0) {                                                   // block-uniform
-            if (n <= kCap) bucket_sort_body<true>(smem, C, logC, kCap, bkv, nullptr, nullptr, n, lo, off1, s_out, pred_out, max_cell, pf);
-            else bucket_sort_body<false>(smem, C, logC, kCap, bkv, bkv + off1 + lo, alt + off1 + lo, n, lo, off1, s_out, pred_out, max_cell, pf);
+            if (n <= kCap) bucket_sort_body<true>(smem, C, logC, kCap, bkv, nullptr, nullptr, n, lo, off1, s_out, pred_out, max_cell, pf, klo[q], khi[q]);
+            else bucket_sort_body<false>(smem, C, logC, kCap, bkv, bkv + off1 + lo, alt + off1 + lo, n, lo, off1, s_out, pred_out, max_cell, pf, 1u, 0u);
             __syncthreads();                                           // the LDS buffers are reused by the next bucket
         }
         if (q + 1 < kRsPerBlock) {
@@ -494,10 +587,10 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
     // a small batch -- one pair is 128 blocks on 256 CUs -- keeps a block per bucket
     if (groups * kMaxBuckets >= 16 * 256 && kRsPerBlockBatch != 1)
         k_rs_bucket_sort<kRsPerBlockBatch><<<dim3(groups * (kMaxBuckets / kRsPerBlockBatch)), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, reinterpret_cast<uint2*>(w.key64A),
-                                                                                             reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np);
+                                                                                             reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np, w.splitters);
     else
         k_rs_bucket_sort<1><<<dim3(groups * kMaxBuckets), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, reinterpret_cast<uint2*>(w.key64A),
-                                                                                             reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np);
+                                                                                             reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np, w.splitters);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
 #define ICET_EXEC_PAIR_THREADS 1024
 #endif
 constexpr int kExecPairThreads = ICET_EXEC_PAIR_THREADS;
+static_assert(ICET_EXEC_PAIR_ROWS == 8, "k_exec_flags_pair's wave-uniform skip names its eight rows");
 template <int kR>
 __global__ __launch_bounds__(kExecPairThreads) void k_exec_flags_pair(const PairDesc* __restrict__ desc, const int32_t* __restrict__ pred,
                                                                       unsigned long long* __restrict__ execbits) {
@@ -217,42 +218,70 @@ __global__ __launch_bounds__(kExecPairThreads) void k_exec_flags_pair(const Pair
     int pn[kR];
 #pragma unroll
     for (int r = 0; r < kR; r++) { const int v = r * kT + tid; pn[r] = (v < n) ? pp[v] : 0; }
+    // "does any row of the block still wait": one flag per wave, ONE barrier, two sets of flags used in turn (a wave can only write set A again
+    // after a barrier that every wave reaches after its reads of set A).  __syncthreads_or (ockl's work-group reduction) cost 0.9 us per
+    // round -- the rounds were half of this kernel.
+    __shared__ uint32_t s_any[2][kT / 64];
+    int or_set = 0;
+    auto block_or = [&](bool x) -> bool {
+        const bool wave_any = __ballot(x) != 0ull;
+        if (lane == 0) s_any[or_set][tid >> 6] = wave_any ? 1u : 0u;
+        __syncthreads();
+        uint32_t o = 0u;
+#pragma unroll
+        for (int k = 0; k < kT / 64; k++) o |= s_any[or_set][k];
+        or_set ^= 1;
+        return o != 0u;
+    };
     for (int c0 = 0; c0 < n; c0 += kC) {
-        int p[kR]; bool pend[kR], e[kR];
+        int p[kR];
 #pragma unroll
         for (int r = 0; r < kR; r++) { p[r] = pn[r]; const int v = c0 + kC + r * kT + tid; pn[r] = (v < n) ? pp[v] : 0; }      // the next chunk is in flight
-        bool any = false;
+        // straight-line (selects, no branch per row): the eight table reads leave together; behind `if (earlier chunk)` each one waited inside
+        // its row's branch.  pv is a row of the pair (0 past the end), so the read is always inside the table; its word is only USED for an earlier chunk.
+        unsigned long long w[kR];
+#pragma unroll
+        for (int r = 0; r < kR; r++) w[r] = lbits[p[r] >> 6];
+        uint32_t pm = 0u, em = 0u;                                         // per row of the thread: still waiting / step executed
 #pragma unroll
         for (int r = 0; r < kR; r++) {
             const int v = c0 + r * kT + tid, pv = p[r];
-            e[r] = false; pend[r] = false;
-            if (v < n) {
-                if (pv >= v) e[r] = pv != v;                               // moved to a later position: executes; a fixed point does not
-                else if (pv < c0) e[r] = ((lbits[pv >> 6] >> (pv & 63)) & 1ull) == 0ull;     // an earlier chunk: its bit is in the table
-                else pend[r] = true;                                       // a row of this chunk
-            }
-            st[r * kT + tid] = pend[r] ? (unsigned char)0 : (unsigned char)(2 | (e[r] ? 1 : 0));
-            any |= pend[r];
+            const bool valid = v < n, later = pv >= v, early = pv < c0;
+            const bool bit = (w[r] >> (pv & 63)) & 1ull;
+            // moved to a later position: executes (a fixed point does not); an earlier chunk: its bit is in the table; else a row of this chunk
+            const bool ex = valid & (later ? (pv != v) : (early & !bit));
+            const bool pd = valid & !later & !early;
+            em |= (ex ? 1u : 0u) << r; pm |= (pd ? 1u : 0u) << r;
+            st[r * kT + tid] = pd ? (unsigned char)0 : (unsigned char)(2 | (ex ? 1 : 0));
         }
         // rounds: a pending row takes its result as soon as pred(v) has one; every thread looks after its own rows (on lidar data ~3 % of a
         // chunk is pending and three rounds settle it; a chain of k rows inside one chunk -- adversarial input -- takes k rounds).  Two
         // alternatives measured slower: polling the state bytes without barriers (the waves serialise on their rows), and one wave
         // resolving a compacted list of the pending rows (its dependent LDS reads cost more than the barriers of the parallel rounds).
-        while (__syncthreads_or(any ? 1 : 0)) {                            // (the barrier also publishes the state bytes)
-            any = false;
+        // A round is paid in VALU issue by all 16 waves of the block (4 per SIMD), so it only touches the rows that wait: a thread takes its
+        // waiting rows one at a time (most threads have none, few more than one) instead of walking all eight.
+        while (block_or(pm != 0u)) {                                       // (the barrier also publishes the state bytes)
+            uint32_t todo = pm;
+            while (__ballot(todo != 0u) != 0ull) {                         // wave-uniform
+                const bool have = todo != 0u;
+                const int r = have ? __builtin_ctz(todo) : 0;
+                todo &= todo - 1u;
+                int pr = p[0];
 #pragma unroll
-            for (int r = 0; r < kR; r++) {
-                if (pend[r]) {
-                    const unsigned char s = st[p[r] - c0];                 // may be written in this very round: then this row resolves now or next round
-                    if (s & 2) { e[r] = (s & 1) == 0; pend[r] = false; st[r * kT + tid] = (unsigned char)(2 | (e[r] ? 1 : 0)); }
-                    else any = true;
+                for (int q = 1; q < kR; q++) pr = (r == q) ? p[q] : pr;
+                const unsigned char sb = st[have ? pr - c0 : 0];           // may be written in this very round: then the row resolves now or in the next round
+                const bool got = have & ((sb & 2) != 0);
+                if (got) {
+                    const bool ex = (sb & 1) == 0;
+                    em |= (ex ? 1u : 0u) << r; pm &= ~(1u << r);
+                    st[r * kT + tid] = (unsigned char)(2 | (ex ? 1 : 0));
                 }
             }
         }
 #pragma unroll
         for (int r = 0; r < kR; r++) {                                    // a wave holds 64 consecutive rows starting at a multiple of 64: one ballot = one word
             const int v = c0 + r * kT + tid;
-            const unsigned long long m = __ballot(e[r]);
+            const unsigned long long m = __ballot((em >> r) & 1u);
             if (lane == 0 && v < n) lbits[v >> 6] = m;
         }
         __syncthreads();                                                   // the table is complete up to this chunk; the state bytes are free again

@@ -268,6 +268,45 @@ template <int kD> __device__ __forceinline__ uint32_t wave_xor(uint32_t x) {
     }
 }
 
+// Wave totals of N doubles at once (N = 4 or 8), as a reduce-scatter: in the step with partner lane ^ D a lane keeps half of its list and
+// hands the other half over, so the list halves while the lanes it spans double -- N / 2 + N / 4 + .. + 1 exchanges and then one value over the
+// remaining distances, instead of N x 6 (a double costs two DPP moves per exchange: wave_total of nine doubles was 3/4 of k_fit_moments).
+// Afterwards the total of v[j] sits in every lane whose low log2(N) bits are j's bits reversed: wave_total_scatter_get reads it from there.
+template <int kD> __device__ __forceinline__ double wave_xor_d(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const uint32_t lo = wave_xor<kD>((uint32_t)b), hi = wave_xor<kD>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int N> __device__ __forceinline__ double wave_total_scatter(double (&v)[N]) {
+    static_assert(N == 4 || N == 8, "list length");
+    const int lane = (int)(threadIdx.x & 63u);
+    {
+        const bool up = lane & 1;
+#pragma unroll
+        for (int i = 0; i < N / 2; i++) { const double keep = up ? v[i + N / 2] : v[i], send = up ? v[i] : v[i + N / 2]; v[i] = keep + wave_xor_d<1>(send); }
+    }
+    {
+        const bool up = lane & 2;
+#pragma unroll
+        for (int i = 0; i < N / 4; i++) { const double keep = up ? v[i + N / 4] : v[i], send = up ? v[i] : v[i + N / 4]; v[i] = keep + wave_xor_d<2>(send); }
+    }
+    if constexpr (N == 8) {
+        const bool up = lane & 4;
+        const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+        v[0] = keep + wave_xor_d<4>(send);
+    } else {
+        v[0] += wave_xor_d<4>(v[0]);
+    }
+    v[0] += wave_xor_d<8>(v[0]); v[0] += wave_xor_d<16>(v[0]); v[0] += wave_xor_d<32>(v[0]);
+    return v[0];
+}
+template <int N> __device__ __forceinline__ double wave_total_scatter_get(double mine, int j) {      // j: compile-time index into the list handed to wave_total_scatter<N>
+    const int src = (N == 8) ? (((j >> 2) & 1) | (((j >> 1) & 1) << 1) | ((j & 1) << 2)) : (((j >> 1) & 1) | ((j & 1) << 1));
+    const unsigned long long b = (unsigned long long)__double_as_longlong(mine);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // inclusive prefix maximum over the 64 lanes, for values >= -1 (-1 = "nothing"): four row_shr steps inside the rows of 16, then the
 // last lane of row 0 / 2 into rows 1 / 3 and the last lane of row 1 into rows 2 and 3
 __device__ __forceinline__ int wave_incl_max(int v) {

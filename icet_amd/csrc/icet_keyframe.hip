@@ -999,7 +999,12 @@ __global__ __launch_bounds__(kBlock, ICET_MOM_WAVES) void k_fit_moments(const Pa
         const float X = qx[i];
         if (X == X) { sumx += (double)X; sumy += (double)qy[i]; sumz += (double)qz[i]; rows++; }
     }
-    sumx = wave_total(sumx); sumy = wave_total(sumy); sumz = wave_total(sumz); rows = wave_total(rows);
+    {   // the four totals in one reduce-scatter (the row count as a double: exact)
+        double t[4] = {sumx, sumy, sumz, (double)rows};
+        const double mine = wave_total_scatter<4>(t);
+        sumx = wave_total_scatter_get<4>(mine, 0); sumy = wave_total_scatter_get<4>(mine, 1); sumz = wave_total_scatter_get<4>(mine, 2);
+        rows = (int)wave_total_scatter_get<4>(mine, 3);
+    }
     if (rows * 3 < n) continue;                                       // src/icet.cpp:158 (size() counts coefficients); has_fit stays 0
     float mean[3], cov[6];
     {
@@ -1023,8 +1028,10 @@ __global__ __launch_bounds__(kBlock, ICET_MOM_WAVES) void k_fit_moments(const Pa
             }
         }
         const float den = (float)(rows - 1);
+        double t[8] = {c[0], c[1], c[2], c[3], c[4], c[5], 0.0, 0.0};
+        const double mine = wave_total_scatter<8>(t);
 #pragma unroll
-        for (int k = 0; k < 6; k++) cov[k] = (float)wave_total(c[k]) / den;
+        for (int k = 0; k < 6; k++) cov[k] = (float)wave_total_scatter_get<8>(mine, k) / den;
     }
     if (lane == 0) {
         mid->mean[0] = mean[0]; mid->mean[1] = mean[1]; mid->mean[2] = mean[2];

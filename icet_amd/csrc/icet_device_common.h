@@ -310,14 +310,9 @@ template <int N> __device__ __forceinline__ double wave_total_scatter_get(double
 // inclusive prefix maximum over the 64 lanes, for values >= -1 (-1 = "nothing"): four row_shr steps inside the rows of 16, then the
 // last lane of row 0 / 2 into rows 1 / 3 and the last lane of row 1 into rows 2 and 3
 __device__ __forceinline__ int wave_incl_max(int v) {
-    int t;
-    t = __builtin_amdgcn_update_dpp(-1, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false); v = max(v, t);
-    t = __builtin_amdgcn_update_dpp(-1, v, 0x112 /* row_shr:2 */, 0xf, 0xf, false); v = max(v, t);
-    t = __builtin_amdgcn_update_dpp(-1, v, 0x114 /* row_shr:4 */, 0xf, 0xf, false); v = max(v, t);
-    t = __builtin_amdgcn_update_dpp(-1, v, 0x118 /* row_shr:8 */, 0xf, 0xf, false); v = max(v, t);
-    t = __builtin_amdgcn_update_dpp(-1, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false); v = max(v, t);
-    t = __builtin_amdgcn_update_dpp(-1, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false); v = max(v, t);
-    return v;
+    // on v + 1 >= 0 as UNSIGNED values: a lane without a source then contributes 0, the identity, and every step is ONE v_max_u32_dpp
+    // (with the signed identity -1 the compiler keeps v_mov -1 / v_mov_dpp / v_max per step: 18 instructions instead of 6)
+    return (int)wave_incl_scan((uint32_t)(v + 1), 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; }) - 1;
 }
 
 // ---- the literal path for points the fast classification cannot decide ------------------------------------------------

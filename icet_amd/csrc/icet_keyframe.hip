@@ -333,49 +333,52 @@ __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const P
         }
     }
     __syncthreads();
-    auto exec = [&](int u) -> bool { const unsigned long long w = kBitsInLds ? lbits[u >> 6] : gbits[u >> 6]; return (w >> (u & 63)) & 1ull; };
+    // the bit table as 32-bit words (bit u of the 64-bit words = bit u & 31 of word u >> 5): one read + one v_bfe per look-up
+    const uint32_t* bits32 = kBitsInLds ? reinterpret_cast<const uint32_t*>(lbits) : reinterpret_cast<const uint32_t*>(gbits);
+    auto exec = [&](int u) -> bool { return (bits32[u >> 5] >> (u & 31)) & 1u; };
     for (int base = lo_ + threadIdx.x; base < hi_; base += kWalk * kBlock) {
-        int f[kWalk], u[kWalk], len[kWalk]; bool act[kWalk];
+        int f[kWalk]; uint32_t act[kWalk];                      // act: 0 / ~0 -- masks, not bools: a bool that lives across the rounds costs a v_cndmask 0/1 and a v_cmp per use
         int pv[kWalk];
 #pragma unroll
         for (int k = 0; k < kWalk; k++) {
             const int v = base + k * kBlock;
             pv[k] = pred[o + (v < hi_ ? v : lo_)];
         }
+        uint32_t any = 0u;
 #pragma unroll
         for (int k = 0; k < kWalk; k++) {
             const int v = base + k * kBlock;
             const bool valid = v < hi_;
             const bool moved = valid & (pv[k] != v);            // s[v] != v  <=>  pred[v] != v (fixed points of a permutation)
-            f[k] = moved ? pv[k] : v;
-            act[k] = moved & exec(valid ? v : lo_) & !exec(pv[k]);   // head of a run of executed steps (no short circuit: both table reads leave at once)
-            u[k] = v; len[k] = 0;
+            const bool head = moved & exec(valid ? v : lo_) & !exec(pv[k]);   // head of a run of executed steps (no short circuit: both table reads leave at once)
+            // f: the row that lands on v -- pred(v), v itself for a fixed point; a head walks it forward from v
+            f[k] = head ? v : (moved ? pv[k] : v);
+            act[k] = head ? 0xFFFFFFFFu : 0u;
+            any |= act[k];
         }
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < kWalk; k++) any |= act[k];
+        // The walk is paid in VALU issue by all eight waves of a SIMD (timing builds: it is 115 of this kernel's 245 us, and a round
+        // of the loop was ~160 instructions): a chain is its walking pointer f and one mask, the length is the thread's round count
+        // (all of a thread's chains start together), and after the loads a chain costs a v_bfe_i32 (the bit, as a mask), a v_bfi (the
+        // pointer), an and and an or -- the eight table reads leave together.
         bool over = false;
+        int rounds = 0;
         while (any) {
             int nu[kWalk];
 #pragma unroll
-            for (int k = 0; k < kWalk; k++) nu[k] = act[k] ? (int)s[o + u[k]] : 0;
-            // straight-line from here (selects, no branch per chain): the eight bit-table reads leave together instead of each one
-            // waiting inside its chain's branch; an idle chain reads word 0
-            unsigned long long w[kWalk];
+            for (int k = 0; k < kWalk; k++) nu[k] = act[k] ? (int)s[o + f[k]] : 0;
+            uint32_t w[kWalk];
 #pragma unroll
-            for (int k = 0; k < kWalk; k++) w[k] = kBitsInLds ? lbits[nu[k] >> 6] : (act[k] ? gbits[nu[k] >> 6] : 0ull);
-            any = false;
+            for (int k = 0; k < kWalk; k++) w[k] = kBitsInLds ? bits32[nu[k] >> 5] : (act[k] ? bits32[nu[k] >> 5] : 0u);     // (an idle chain reads word 0 of the LDS table)
+            rounds++;
+            any = 0u;
 #pragma unroll
             for (int k = 0; k < kWalk; k++) {
-                const bool a = act[k], ex = (w[k] >> (nu[k] & 63)) & 1ull;
-                u[k] = a ? nu[k] : u[k]; len[k] += a ? 1 : 0;
-                const bool too_long = len[k] > max_walk;
-                over |= a & ex & too_long;
-                const bool stop = !ex | too_long;
-                f[k] = (a & stop) ? nu[k] : f[k];
-                act[k] = a & !stop;
+                const uint32_t exm = (uint32_t)__builtin_amdgcn_sbfe((int)w[k], nu[k] & 31, 1);       // step nu executed: ~0
+                f[k] = (int)(((uint32_t)nu[k] & act[k]) | ((uint32_t)f[k] & ~act[k]));
+                act[k] &= exm;
                 any |= act[k];
             }
+            if (rounds > max_walk) { over = any != 0u; any = 0u; }   // (uniform) chains still running: the serial replay takes the pair
         }
         if (over) atomicOr(&flags[pair], 1);
         uint16_t fb[kWalk];                                      // packed word of the row that lands here (its voxel id is what the histogram needs)

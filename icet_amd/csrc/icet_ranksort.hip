@@ -353,7 +353,9 @@ __device__ __forceinline__ bool counting_sort_regs(uint32_t* smem, int Clayout, 
     uint32_t* cells = smem; uint32_t* red = smem + cell_region(Clayout);
     const int offBuf = cell_region(Clayout) + kRedWords;
     const int C = 1 << logC;
-    uint2* KI = reinterpret_cast<uint2*>(smem + offBuf);                  // (key, row) side by side; the first buffer is free on this path (offBuf is even: 8-byte aligned)
+    // key << 32 | row as ONE 64-bit word: "sorts before me" is a single 64-bit compare.  The first buffer is free on this path (offBuf is even:
+    // 8-byte aligned; it holds 2 x kCap such words, n + 4 are used)
+    unsigned long long* KI = reinterpret_cast<unsigned long long*>(smem + offBuf);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t range = kmax - kmin;                                   // > 0 here
     const int sh = max(0, 32 - __clz(range) - logC);                      // (range >> sh) < C
@@ -383,7 +385,8 @@ __device__ __forceinline__ bool counting_sort_regs(uint32_t* smem, int Clayout, 
     // placement by cell, in arrival order inside a cell; afterwards cells[c] = END of cell c (its begin = cells[c - 1])
 #pragma unroll
     for (int k = 0; k < kRsPrefetch; k++)
-        if (ok[k]) KI[atomicAdd(&cells[c[k]], 1u)] = pf[k];
+        if (ok[k]) KI[atomicAdd(&cells[c[k]], 1u)] = ((unsigned long long)pf[k].x << 32) | pf[k].y;
+    if (threadIdx.x < 4) KI[n + (int)threadIdx.x] = ~0ull;               // what the look-ahead of the last cell reads: sorts after everything
     __syncthreads();
     uint32_t b[kRsPrefetch], e[kRsPrefetch];
 #pragma unroll
@@ -391,17 +394,19 @@ __device__ __forceinline__ bool counting_sort_regs(uint32_t* smem, int Clayout, 
 #pragma unroll
     for (int k = 0; k < kRsPrefetch; k++) {
         if (!ok[k]) continue;
-        const uint32_t key = pf[k].x, id = pf[k].y;
+        const uint32_t id = pf[k].y;
+        const unsigned long long me = ((unsigned long long)pf[k].x << 32) | id;
         uint32_t r = b[k];
         // the first kCellAhead members of the cell in ONE round of reads (a cell holds 1 - 3 rows; walked one member per trip, the wave makes as
-        // many dependent LDS round trips as its fullest cell has rows -- this phase was 40 % of the kernel), the rest of a crowded cell in a loop
+        // many dependent LDS round trips as its fullest cell has rows), the rest of a crowded cell in a loop.  No "inside my cell" test: what
+        // lies behind the cell belongs to later cells -- larger keys -- or is the padding, and never sorts before me.
         constexpr uint32_t kCellAhead = 4;
-        uint2 m[kCellAhead];
+        unsigned long long m[kCellAhead];
 #pragma unroll
-        for (uint32_t t = 0; t < kCellAhead; t++) m[t] = KI[min(b[k] + t, (uint32_t)n - 1u)];
+        for (uint32_t t = 0; t < kCellAhead; t++) m[t] = KI[b[k] + t];
 #pragma unroll
-        for (uint32_t t = 0; t < kCellAhead; t++) r += ((b[k] + t < e[k]) & ((m[t].x < key) | ((m[t].x == key) & (m[t].y < id)))) ? 1u : 0u;
-        for (uint32_t j = b[k] + kCellAhead; j < e[k]; j++) { const uint2 x = KI[j]; r += ((x.x < key) | ((x.x == key) & (x.y < id))) ? 1u : 0u; }
+        for (uint32_t t = 0; t < kCellAhead; t++) r += (m[t] < me) ? 1u : 0u;
+        for (uint32_t j = b[k] + kCellAhead; j < e[k]; j++) r += (KI[j] < me) ? 1u : 0u;
         s_out[off1 + lo + r] = id;
         pred_out[off1 + id] = lo + (int)r;
     }

@@ -203,7 +203,6 @@ __global__ __launch_bounds__(kBlock) void k_exec_flags(const PairDesc* __restric
 #define ICET_EXEC_PAIR_THREADS 1024
 #endif
 constexpr int kExecPairThreads = ICET_EXEC_PAIR_THREADS;
-static_assert(ICET_EXEC_PAIR_ROWS == 8, "k_exec_flags_pair's wave-uniform skip names its eight rows");
 template <int kR>
 __global__ __launch_bounds__(kExecPairThreads) void k_exec_flags_pair(const PairDesc* __restrict__ desc, const int32_t* __restrict__ pred,
                                                                       unsigned long long* __restrict__ execbits) {

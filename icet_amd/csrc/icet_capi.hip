@@ -361,7 +361,7 @@ LaunchCfg make_cfg(icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     cfg.reject_moving = (p->flags & ICET_FLAG_REJECT_MOVING) ? 1 : 0;
     cfg.rt2 = (p->flags & ICET_FLAG_ROUNDTRIP_SCAN2) ? 1 : 0;
     cfg.lds_slots = c->tune.lds_slots; cfg.acc_min_pts_per_thread = c->tune.acc_pts; cfg.acc_target_blocks = c->tune.acc_blocks;
-    cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds; cfg.exec_pairwise = c->tune.exec_pairwise; cfg.lds_rank = (c->tune.lds_rank != 0 && c->lds_rank_ok) ? (c->tune.lds_rank == 2 ? 2 : 1) : 0;
+    cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds; cfg.exec_pairwise = c->tune.exec_pairwise; cfg.lds_rank = (c->tune.lds_rank != 0 && c->lds_rank_ok) ? 1 : 0;
     if (cfg.kf_pts_per_thread > kKfMaxPtsPerThread) cfg.kf_pts_per_thread = kKfMaxPtsPerThread;      // k_bin_scatter: a tile is at most 4 waves x that many rounds x 64 positions
     if (cfg.kf_pts_per_thread < 1) cfg.kf_pts_per_thread = 1;
     cfg.stage_event = c->stage_at ? c->ev_stage : nullptr; cfg.stage_at = c->stage_at;
@@ -1132,7 +1132,7 @@ icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
     else if (k == "rs_cap") t.rs_cap = iv < 0 ? 0 : iv;
     else if (k == "rs_max_cell") t.rs_max_cell = iv < 0 ? 0 : iv;
     else if (k == "exec_bits_lds") t.exec_bits_lds = iv != 0;
-    else if (k == "lds_rank") t.lds_rank = iv < 0 ? -1 : (iv > 2 ? 2 : iv);     // 2: as 1, but the rank sort's multi-split stores unstaged (experiments)
+    else if (k == "lds_rank") t.lds_rank = iv < 0 ? -1 : (iv != 0);
     else if (k == "exec_pairwise") t.exec_pairwise = iv < 0 ? -1 : (iv != 0);
     else if (k == "graph") { c->graph_mode = iv < 0 ? -1 : (iv != 0); c->g_solve.have_seen = c->g_keyframe.have_seen = c->g_loop.have_seen = false; }
     else if (k == "guard_scale") { if (!(value >= 1.0 && value <= 1024.0)) { c->err = "guard_scale must lie in [1, 1024]"; return ICET_ERR_BAD_ARG; } t.guard_scale = value; c->w.thr_T = 0; }   // tables are rebuilt by the next call

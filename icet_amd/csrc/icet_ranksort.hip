@@ -143,9 +143,8 @@ __global__ __launch_bounds__(kSplitLoadThreads) void k_rs_splitters(const PairDe
 }
 
 // Stable multi-split of the rows of one tile into their buckets; wave w owns the w-th quarter of the tile.
-// kLdsRank: as k_bin_scatter (icet_keyframe.hip) -- the counting step's LDS atomic hands back the row's rank inside its wave's quarter.
+// (The ballot form: what a device that failed the LDS-atomic order self-test gets, and the tests' cross-check; k_rs_scatter_staged below otherwise.)
 constexpr int kScatterRounds = kKfMaxPtsPerThread;   // a tile is at most 4 waves x this many rounds x 64 positions
-template <bool kLdsRank>
 __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restrict__ desc, const float* __restrict__ r1, const uint8_t* __restrict__ bkt,
                                                        const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bucket_start,
                                                        uint2* __restrict__ bkv, int n_pairs, int chunks) {
@@ -175,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restric
 #pragma unroll
     for (int k = 0; k < kScatterRounds; k++) {
         if (!ok[k]) { bb[k] = 0u; key[k] = 0u; }
-        if (ok[k]) { const uint32_t old = atomicAdd(&mine[bb[k]], 1u); if (kLdsRank) bb[k] |= old << 8; }      // (bucket ids are 7 bits)
+        if (ok[k]) atomicAdd(&mine[bb[k]], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < kMaxBuckets; b += kBlock) {
@@ -185,12 +184,6 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restric
     }
     __syncthreads();
     const unsigned long long lt = (1ull << lane) - 1ull;
-    if (kLdsRank) {
-#pragma unroll
-        for (int k = 0; k < kScatterRounds; k++)
-            if (ok[k]) bkv[o + mine[bb[k] & 255u] + (bb[k] >> 8)] = make_uint2(key[k], (uint32_t)(wlo + 64 * k + lane));
-        return;
-    }
 #pragma unroll
     for (int k = 0; k < kScatterRounds; k++) {
         unsigned long long peers = __ballot(ok[k]);
@@ -209,9 +202,10 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restric
     }
 }
 
-// The same multi-split with the tile's rows first grouped by bucket in LDS (ranks from the LDS atomics, see k_bin_scatter): a tile's ~16 rows
-// of one bucket then leave as ONE run of consecutive 8-byte stores by consecutive lanes instead of 16 scattered ones -- the scattered form is
-// bound by the number of store requests, not by instructions (ranks from LDS atomics alone: 116 -> 112 us per 256 pairs).
+// The same multi-split with ranks from the values the LDS atomics hand back (see k_bin_scatter, icet_keyframe.hip) and the tile's rows first
+// grouped by bucket in LDS: a tile's ~16 rows of one bucket then leave as ONE run of consecutive 8-byte stores by consecutive lanes instead of
+// 16 scattered ones -- the scattered form is bound by the number of store requests, not by instructions (ranks from LDS atomics alone: 116 -> 112 us
+// per 256 pairs; staged: 101; with all loads issued before the first atomic: 83).
 static_assert(kMaxBuckets == 128, "k_rs_scatter_staged scans the buckets with two waves");
 __global__ __launch_bounds__(kBlock) void k_rs_scatter_staged(const PairDesc* __restrict__ desc, const float* __restrict__ r1, const uint8_t* __restrict__ bkt,
                                                               const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bucket_start,
@@ -583,9 +577,8 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
     // (its per-pair scan block also reduces the tiles' voxel ranges, written by k_scan1_spherical, to the pair's)
     hipError_t e = launch_class_scan(w.counts, w.tile_base, w.bucket_start, kMaxBuckets, chunks, np, st, nullptr, nullptr, 0, nullptr, nullptr, w.tile_vr, w.vrange);
     if (e != hipSuccess) return e;
-    if (c.lds_rank == 1) k_rs_scatter_staged<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks);
-    else if (c.lds_rank) k_rs_scatter<true><<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks);
-    else k_rs_scatter<false><<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks);
+    if (c.lds_rank) k_rs_scatter_staged<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks);
+    else k_rs_scatter<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks);
     ICET_LAUNCH_CHECK();
     const int cap = rank_sort_cap(c.max_n1, c.rs_cap, c.n_pairs);
     // two buckets per block (the second one's pairs in flight during the first one's sort) once the launch fills the chip several times over;

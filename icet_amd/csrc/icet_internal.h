@@ -18,7 +18,7 @@ constexpr int kAccLds   = 20;        // in LDS: the same 80-byte record per slot
 constexpr float kFixScale = 68719476736.0f;           // 2^36
 constexpr double kFixInv = 1.0 / 68719476736.0;
 #ifndef ICET_RS_BUCKET_BITS
-#define ICET_RS_BUCKET_BITS 7
+#define ICET_RS_BUCKET_BITS 8
 #endif
 constexpr int kRankSortBucketBits = ICET_RS_BUCKET_BITS;       // rank sort (icet_ranksort.hip): at most 2^bits buckets per pair, ids travel as u8
 constexpr int kRankSortMaxBuckets = 1 << kRankSortBucketBits;
@@ -95,7 +95,7 @@ struct Workspace {
     float *cart1 = nullptr;                                          // 3 x cap_n1: round-tripped Cartesian rows of large bins (k_fit_scan1's second pass)
     unsigned long long *key64A = nullptr, *key64B = nullptr;         // (pair << 32 | r bits)
     uint32_t *keyA = nullptr, *keyB = nullptr, *valA = nullptr, *valB = nullptr;
-    uint32_t* splitters = nullptr; int32_t* n_buckets = nullptr; int32_t* bucket_start = nullptr;   // rank sort: pairs x 128, pairs, pairs x 129
+    uint32_t* splitters = nullptr; int32_t* n_buckets = nullptr; int32_t* bucket_start = nullptr;   // rank sort: pairs x kRankSortMaxBuckets, pairs, pairs x (kRankSortMaxBuckets + 1)
     uint8_t* bkt = nullptr;                                          // rank sort: bucket id of every scan-1 row
     uint16_t* binpos = nullptr;                                      // angular bin of the row at every position after the scramble
     uint32_t* counts = nullptr; uint32_t* tile_base = nullptr; size_t cap_counts = 0;               // pairs x tiles x V histogram / tile base offsets

@@ -1281,7 +1281,7 @@ constexpr size_t kScrambleLdsMax = 100 * 1024;
 static size_t scan1_lds_bytes(const Workspace& w) { return (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell); }
 
 hipError_t init_keyframe_kernels() {
-    const int cap = 160 * 1024 - 2048;        // static __shared__ of the kernels comes on top
+    const int cap = 160 * 1024 - 4096;        // static __shared__ of the kernels comes on top (k_scan1_spherical: 8 B per rank-sort bucket + 32)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scramble_src<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);

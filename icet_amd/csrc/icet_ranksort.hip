@@ -8,13 +8,13 @@
 // 12 bytes per element, ~1.4 ms per 256 pairs) and still needs a separate inverse-permutation pass.  Per pair the
 // data is small (116 k keys), so this file does a sample sort instead:
 //   k_rs_splitters   one wave per pair: radii of ~2 k sampled rows straight from the Cartesian scan, sorted in registers
-//                    (bitonic), <= 127 splitters published -- runs BEFORE k_scan1_spherical, which then
+//                    (bitonic), <= 255 splitters published -- runs BEFORE k_scan1_spherical, which then
 //   [k_scan1_spherical, icet_kernels.hip] also finds every row's bucket (branch-free binary search of the splitters)
 //                    and its tile's bucket histogram, at no extra pass over r
 //   [k_bin_scan]     (shared with the voxel multi-split) exclusive scan over (bucket, tile)
 //   k_rs_scatter     stable multi-split of the rows into their buckets (match-any ranking, as k_bin_scatter)
 //   k_rs_bucket_sort one block per (pair, bucket), the bucket's (key, row) pairs in LDS: a COUNTING sort on the bucket's
-//                    own key range (a bucket is 1/128 of a smooth distribution, so its keys are close to uniform
+//                    own key range (a bucket is ~1/128 of a smooth distribution, so its keys are close to uniform
 //                    between its min and max: ~0.5 rows per cell of (key - min) >> shift), then every row ranks
 //                    itself inside its cell by (key, row) -- 7 barriers instead of the ~15 of an LSD radix sort --
 //                    and s[] and pred[] are written: no inverse-permutation kernel.  A bucket whose keys pile up in
@@ -39,12 +39,14 @@ constexpr int kSamples = ICET_RS_SAMPLES;          // sampled keys per pair (pow
 constexpr int kMaxBuckets = kRankSortMaxBuckets;   // power of two (icet_internal.h: the workspace is sized with it)
 constexpr int kBucketBits = kRankSortBucketBits;
 #ifndef ICET_RS_TARGET
-#define ICET_RS_TARGET 512
+#define ICET_RS_TARGET 906
 #endif
-// Rows per bucket aimed for.  With at most 128 buckets a 64-channel scan (~116 k rows) gets ~900-row buckets; the LDS
+// Rows per bucket aimed for: a 64-channel scan (~116 k rows) gets ~130 buckets of ~900 rows, a scan above 232 k rows the maximum of 256
+// (round 4: 128 -> 256 with the target moved from 512 to 906, i.e. nothing changes for a 64-channel scan and the 485 k-row scans of configs[4]
+// get twice the blocks at half the rows: k_rs_bucket_sort 37 -> 25 us of that pair's 0.51 -> 0.49 ms).  The LDS
 // capacity of the per-bucket sort is chosen per launch from the largest scan (rank_sort_cap): measured on 256 such pairs,
 // 1280 rows (25 KB, 6 blocks per CU) beats the earlier fixed 2560 (45 KB, 3 blocks) by 0.2 ms -- the sort is latency bound
-// and wants the occupancy.  With 2048 samples for 128 buckets the bucket sizes scatter by ~20 % around their mean (944 +- 180 rows on a
+// and wants the occupancy.  With 2048 samples for ~128 buckets the bucket sizes scatter by ~20 % around their mean (944 +- 180 rows on a
 // 121 k-row scan), so ~3 % of them exceed 1280 rows and went to the global-scratch path; 1664 rows (30.7 KB with the 1024 cells: five
 // blocks per CU) keeps all but ~0.1 % in LDS and is 23 us per 256-pair keyframe faster than 1280, 1408 / 1536: in between,
 // 1792 ... 2048 (four blocks per CU): no better than 1280.
@@ -206,13 +208,13 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restric
 // grouped by bucket in LDS: a tile's ~16 rows of one bucket then leave as ONE run of consecutive 8-byte stores by consecutive lanes instead of
 // 16 scattered ones -- the scattered form is bound by the number of store requests, not by instructions (ranks from LDS atomics alone: 116 -> 112 us
 // per 256 pairs; staged: 101; with all loads issued before the first atomic: 83).
-static_assert(kMaxBuckets == 128, "k_rs_scatter_staged scans the buckets with two waves");
+static_assert(kMaxBuckets <= kBlock && kMaxBuckets % 64 == 0 && kMaxBuckets <= 256, "k_rs_scatter_staged: one thread per bucket scans them, ids travel in 8 bits");
 __global__ __launch_bounds__(kBlock) void k_rs_scatter_staged(const PairDesc* __restrict__ desc, const float* __restrict__ r1, const uint8_t* __restrict__ bkt,
                                                               const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bucket_start,
                                                               uint2* __restrict__ bkv, int n_pairs, int chunks) {
     __shared__ uint32_t lb[4 * kMaxBuckets];                         // per wave and bucket: rows counted, then the wave's first slot in the stage
     __shared__ int32_t gdelta[kMaxBuckets];                          // bucket: (global position - stage position) of its rows of this tile
-    __shared__ uint32_t wtot[2];
+    __shared__ uint32_t wtot[kMaxBuckets / 64];
     __shared__ uint2 stage[kBlock * kScatterRounds];                 // 16 KB: (key, row), grouped by bucket, the tile's order inside a bucket
     __shared__ uint8_t stage_b[kBlock * kScatterRounds];
     int pair, chunk;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter_staged(const PairDesc* __
 #pragma unroll
     for (int k = 0; k < kScatterRounds; k++) {
         if (!ok[k]) { bb[k] = 0u; key[k] = 0u; }
-        if (ok[k]) bb[k] |= atomicAdd(&mine[bb[k]], 1u) << 8;       // earlier rows of this wave in the bucket (ids are 7 bits)
+        if (ok[k]) bb[k] |= atomicAdd(&mine[bb[k]], 1u) << 8;       // earlier rows of this wave in the bucket (ids are 8 bits)
     }
     __syncthreads();
     uint32_t c0 = 0u, c1 = 0u, c2 = 0u, tot = 0u; int incl = 0;
@@ -255,7 +257,8 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter_staged(const PairDesc* __
     __syncthreads();
     if (threadIdx.x < kMaxBuckets) {
         const int b = threadIdx.x;
-        const uint32_t ls = (uint32_t)incl - tot + (wave ? wtot[0] : 0u);
+        uint32_t ls = (uint32_t)incl - tot;
+        for (int q = 0; q < wave; q++) ls += wtot[q];
         gdelta[b] = (int32_t)gbase - (int32_t)ls;
         lb[b] = ls; lb[kMaxBuckets + b] = ls + c0; lb[2 * kMaxBuckets + b] = ls + c0 + c1; lb[3 * kMaxBuckets + b] = ls + c0 + c1 + c2;
     }
@@ -536,7 +539,7 @@ static int rank_sort_cap(int max_n, int forced, int n_pairs) {
     int cap = (int)(1.3 * (double)max_n / nb); cap = (cap + 127) / 128 * 128;
     cap = cap < kCapMin ? kCapMin : (cap > kCapMax ? kCapMax : cap);
     // A small batch has a CU per block anyway: every bucket up to 8960 rows sorts in LDS.  Real scans need it: their thousands of exact-zero
-    // rows take ~10 of the 128 splitters, the other buckets grow to 3 - 12x the mean (frame_804: 6157 rows against a mean of 512) and
+    // rows take ~10 of the splitters, the other buckets grow to 3 - 12x the mean (frame_804: 6157 rows against a mean of 512) and
     // went to the global-scratch radix sort (65 us for this kernel against 16 on a synthetic pair).
     if (n_pairs <= 4) cap = kCapMax;
     if (forced > 0) cap = forced < 64 ? 64 : (forced > kCapMax ? kCapMax : forced);     // Tuning::rs_cap (tests: force the global-scratch path)
@@ -582,7 +585,7 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
     ICET_LAUNCH_CHECK();
     const int cap = rank_sort_cap(c.max_n1, c.rs_cap, c.n_pairs);
     // two buckets per block (the second one's pairs in flight during the first one's sort) once the launch fills the chip several times over;
-    // a small batch -- one pair is 128 blocks on 256 CUs -- keeps a block per bucket
+    // a small batch -- one pair is at most 256 blocks on 256 CUs -- keeps a block per bucket
     if (groups * kMaxBuckets >= 16 * 256 && kRsPerBlockBatch != 1)
         k_rs_bucket_sort<kRsPerBlockBatch><<<dim3(groups * (kMaxBuckets / kRsPerBlockBatch)), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, reinterpret_cast<uint2*>(w.key64A),
                                                                                              reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np, w.splitters);

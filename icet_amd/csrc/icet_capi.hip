@@ -413,9 +413,8 @@ icet_status enqueue_keyframe(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         }
     }
     { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }
-    if (d_counts1) HIPCHK(c, launch_patch_counts(w, cfg, d_counts1, nullptr, c->stream));      // the descriptors hold upper bounds: the device knows the row counts
     if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
-    HIPCHK(c, launch_keyframe(w, cfg, aux, c->stream));
+    HIPCHK(c, launch_keyframe(w, cfg, aux, c->stream, d_counts1));      // (d_counts1: the descriptors hold upper bounds, the device knows the row counts: patched by the first kernel)
     return ICET_OK;
 }
 
@@ -424,7 +423,7 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
     Workspace& w = c->w;
     const LaunchCfg cfg = make_cfg(c, p, n_pairs);
     if (reupload) { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }      // the scan-2 halves arrived after the keyframe call
-    if (d_counts2) HIPCHK(c, launch_patch_counts(w, cfg, nullptr, d_counts2, c->stream));
+    if (d_counts2 && cfg.rt2) HIPCHK(c, launch_patch_counts(w, cfg, nullptr, d_counts2, c->stream));      // (otherwise k_init_state, the loop's first kernel, patches them)
     while ((int)c->ev_acc.size() < 2 * p->runlen) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_acc.push_back(e); }
     Workspace wl = w;                                    // what the loop kernels see: with ICET_FLAG_ROUNDTRIP_SCAN2 their scan 2 is the round-tripped copy
     if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_b, c->stream));      // keyframe_ms ends here: the scan-2 pre-pass of ICET_FLAG_ROUNDTRIP_SCAN2 belongs to the loop
@@ -456,7 +455,7 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
         wl = w; wl.desc = w.desc_rt;
     }
     LaunchCfg lcfg = cfg; if (cfg.rt2) lcfg.vec4_ok = 1;     // the copy is 64-float aligned whatever the caller's layout was
-    HIPCHK(c, launch_init_state(w, cfg, d_x0, c->stream, want_pts2 ? aux->xf_last : nullptr));
+    HIPCHK(c, launch_init_state(w, cfg, d_x0, c->stream, want_pts2 ? aux->xf_last : nullptr, cfg.rt2 ? nullptr : d_counts2));
     // `points2` (include/icet.h:80): scan 2 as the LAST fitScan2 transforms it (src/icet.cpp:375-378).  That transform is known as soon as the
     // solve of iteration runlen - 2 has run: k_gn_solve / k_init_state snapshot its record in aux->xf_last (pinned host memory) and ev_prev
     // marks the moment.  icet_solve_end then transforms scan 2 ON THE HOST while the last iteration still runs on the device (measured: a

@@ -175,9 +175,9 @@ constexpr float kRejectMovingThresh = 0.3f;        // python/ICET_spherical.py:3
 constexpr int kRejectMovingStartIter = 4;          // python/ICET_spherical.py:36  start_RM_iter
 
 // icet_keyframe.hip
-hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* aux, hipStream_t st);
+hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* aux, hipStream_t st, const int32_t* d_n1 = nullptr);   // d_n1: scan-1 row counts known to the device only (the descriptors hold upper bounds)
 // icet_solve.hip
-hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last = nullptr);
+hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last = nullptr, const int32_t* d_n2 = nullptr);
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st);
 // `points2` of pair 0 (include/icet.h:80): scan 2 under the transform record `xf` (AuxDev::xf_last); out = n2 x 3 column-major, ld n2 (may be pinned host memory)
 hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* xf, float* out, hipStream_t st);
@@ -198,7 +198,7 @@ hipError_t init_accumulate_kernels();
 hipError_t init_rank_sort_kernels();
 
 // ranksort.hip
-hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st);   // before k_scan1_spherical
+hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st, const int32_t* d_n1 = nullptr);   // before k_scan1_spherical; d_n1: device-side row counts to patch into the descriptors
 hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t st);             // after it (buckets + histogram done there)
 
 // bucket(key) = number of splitters strictly below key (splitters sorted ascending in sp[1 .. kRankSortMaxBuckets-1], sp[0] ignored)

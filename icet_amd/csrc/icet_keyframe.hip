@@ -1292,7 +1292,7 @@ hipError_t init_keyframe_kernels() {
     return e;
 }
 
-hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* auxp, hipStream_t st) {
+hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* auxp, hipStream_t st, const int32_t* d_n1) {
     AuxDev aux{}; if (auxp) aux = *auxp;
     // many small chunks per pair: with the XCD-aware mapping only ~4 pairs are then in flight per XCD (see decode_block)
     const int chunks = c.kf_chunks;
@@ -1303,8 +1303,9 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     int pbits = 0; while ((1 << pbits) < c.n_pairs) pbits++;
     int vbits = 1; while ((1 << vbits) < c.V) vbits++;
     const bool batch = c.n_pairs > 1;
-    if (!c.use_library_sort) { e = launch_rank_sort_splitters(w, c, st); if (e != hipSuccess) return e; }
+    if (!c.use_library_sort) { e = launch_rank_sort_splitters(w, c, st, d_n1); if (e != hipSuccess) return e; }
     else {   // diagnostic path: no rank sort, hence nobody reduces the tiles' voxel ranges: the full range (vmin = 0, vmax = "large", clipped to V - 1 by the readers)
+        if (d_n1) { e = launch_patch_counts(w, c, d_n1, nullptr, st); if (e != hipSuccess) return e; }
         e = hipMemset2DAsync(w.vrange, 8, 0x00, 4, c.n_pairs, st); if (e != hipSuccess) return e;
         e = hipMemset2DAsync(w.vrange + 1, 8, 0x7F, 4, c.n_pairs, st); if (e != hipSuccess) return e;
     }

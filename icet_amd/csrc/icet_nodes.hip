@@ -308,11 +308,12 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         k_range_scan<<<1, kFB, 0, st>>>(nd->d_counts, nd->d_bases, n_blocks, d_cnt);
         k_range_scatter<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_bases, o, o + lcur, o + 2 * lcur);
         NCHK(nd, hipGetLastError());
+        if (fast) NCHK(nd, hipEventRecord(nd->ev[1], st));        // what the solve streams wait for: the filtered scan, not the copy of its count to the host
         NCHK(nd, hipMemcpyAsync(nd->h_nkept, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     } else {
         *nd->h_nkept = 0;
     }
-    NCHK(nd, hipEventRecord(nd->ev[1], st));
+    if (!fast) NCHK(nd, hipEventRecord(nd->ev[1], st));
     if (!fast) NCHK(nd, hipStreamSynchronize(st));                // the solve's launch geometry needs the row count
     // fast: an upper bound until the end-of-frame synchronisation -- the buffer's CAPACITY, which does not change from frame to frame, so that the
     // two halves of the solve see the same launch key every frame and replay their captured graphs (one hipGraphLaunch each instead of ~35 launches)

@@ -71,12 +71,15 @@ __device__ __forceinline__ float radius_of(float x, float y, float z) {     // t
 // pair's 22 us for this kernel, and the rest of the block idle; here a lane does 264 + 156.
 static_assert(kSamples == 2048, "k_rs_splitters holds 4 keys per thread of a 512-thread block");
 constexpr int kSplitLoadThreads = 512;
-__global__ __launch_bounds__(kSplitLoadThreads) void k_rs_splitters(const PairDesc* __restrict__ desc,
-                                                     uint32_t* __restrict__ splitters, int32_t* __restrict__ n_buckets) {
+// (n1_dev: scan-1 row counts that only the device knows -- the descriptor holds an upper bound; this is the keyframe's first kernel, so it also
+// does k_patch_counts' job for its pair: one launch less in front of a sequential caller's keyframe)
+__global__ __launch_bounds__(kSplitLoadThreads) void k_rs_splitters(PairDesc* __restrict__ desc,
+                                                     uint32_t* __restrict__ splitters, int32_t* __restrict__ n_buckets, const int32_t* __restrict__ n1_dev) {
     __shared__ uint32_t sm[kSamples];
     const int pair = blockIdx.x, tid = threadIdx.x;
     const PairDesc d = desc[pair];
-    const int n = d.n1;
+    const int n = n1_dev ? max(0, min(n1_dev[pair], d.n1)) : d.n1;
+    if (n1_dev && tid == 0) desc[pair].n1 = n;                  // (every thread of this block took both values itself; later kernels read the descriptor)
     const int stride = max(1, (n + kSamples - 1) / kSamples);
     const int ns = n > 0 ? (n + stride - 1) / stride : 0;
     uint32_t x[4];
@@ -566,8 +569,8 @@ hipError_t init_rank_sort_kernels() {
     return e;
 }
 
-hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
-    k_rs_splitters<<<c.n_pairs, kSplitLoadThreads, 0, st>>>(w.desc, w.splitters, w.n_buckets);
+hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st, const int32_t* d_n1) {
+    k_rs_splitters<<<c.n_pairs, kSplitLoadThreads, 0, st>>>(w.desc, w.splitters, w.n_buckets, d_n1);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -25,7 +25,7 @@ FLAG_HALF_GAP_BOUNDS = 8  # non-parity extension (half-gap cluster buffers of th
 
 # every symbol include/icet_hip.h, include/icet_nodes.h and include/icet_io.h declare
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_begin", "icet_solve_keyframe_tables", "icet_solve_end", "icet_solve_batch",
-                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_keyframe_device_n", "icet_register_device_n", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
+                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_debug_gn_tail", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_keyframe_device_n", "icet_register_device_n", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
                     "icet_multi_solve_batch", "icet_multi_solve_batch_device", "icet_multi_solve_batch_device_after", "icet_multi_solve_batch_device_async", "icet_multi_sync", "icet_multi_set_option",
                     "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_map",
                     "icet_node_prev_scan", "icet_node_aligned", "icet_node_snail_trail", "icet_node_last_timing", "icet_stream", "icet_device",
@@ -66,7 +66,7 @@ _I = C.POINTER(C.c_int32)
 class Aux(C.Structure):
     _fields_ = [("cluster_bounds", _F), ("n1_raw", _I), ("has_fit", _I), ("mu1", _F), ("sigma1", _F), ("evecs1", _F), ("l_diag", _F),
                 ("x_hist", _F), ("htwh", _F), ("htwdz", _F), ("n2_raw", _I), ("n2_in", _I), ("test_points", _F), ("points2", _F),
-                ("points1_spherical", _F), ("point_index1", _I), ("bin_start1", _I), ("points2_spherical", _F), ("voxel2", _I)]
+                ("points1_spherical", _F), ("point_index1", _I), ("bin_start1", _I), ("points2_spherical", _F), ("voxel2", _I), ("cond_info", _F)]
 
 
 _lib = None
@@ -99,6 +99,7 @@ def load_library():
     L.icet_last_timing.argtypes = [C.c_void_p, C.c_void_p]
     L.icet_debug_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     L.icet_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    L.icet_debug_gn_tail.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.icet_keyframe_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan)]
     L.icet_register_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.c_void_p, C.c_void_p]
     L.icet_keyframe_device_n.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.c_void_p]
@@ -225,6 +226,15 @@ class Context:
         self._check(load_library().icet_last_timing(self._h, t.ctypes.data))
         return dict(keyframe_ms=float(t[0]), gn_loop_ms=float(t[1]), accumulate_ms=float(t[2]), accumulate_launches=int(t[3]))
 
+    def debug_gn_tail(self, htwh, htwdz):
+        """icet_debug_gn_tail (test hook): the 6x6 tail of an iteration on the device for n (HTWH, HTWdz).  Returns dict of arrays with leading dimension n:
+        cov (6, 6), pred_stds, dx, eigvals (NaN on the Cholesky route), pruned, route."""
+        H = np.ascontiguousarray(htwh, np.float32).reshape(-1, 36); g = np.ascontiguousarray(htwdz, np.float32).reshape(-1, 6)
+        n = H.shape[0]
+        out = np.zeros((n, 56), np.float32)
+        self._check(load_library().icet_debug_gn_tail(self._h, H.ctypes.data, g.ctypes.data, n, out.ctypes.data))
+        return dict(cov=out[:, :36].reshape(n, 6, 6), pred_stds=out[:, 36:42], dx=out[:, 42:48], eigvals=out[:, 48:54], pruned=out[:, 54].astype(np.int32), route=out[:, 55].astype(np.int32))
+
     # -- single pair, host arrays ---------------------------------------------------------------
     def solve(self, scan1, scan2, runlen, X0, num_bins_phi, num_bins_theta, n=25, thresh=0.1, buff=0.1, aux=False, flags=0):
         """icet_solve.  scan1 / scan2: N x 3 (any layout numpy can view; an N x 3 array in Fortran order -- an Eigen::MatrixXf -- is
@@ -242,7 +252,8 @@ class Context:
                        mu1=np.zeros((V, 3), np.float32), sigma1=np.zeros((V, 3, 3), np.float32), evecs1=np.zeros((V, 3, 3), np.float32),
                        l_diag=np.zeros((V, 3), np.float32), x_hist=np.zeros((rl, 6), np.float32), htwh=np.zeros((rl, 6, 6), np.float32),
                        htwdz=np.zeros((rl, 6), np.float32), n2_raw=np.zeros((rl, V), np.int32), n2_in=np.zeros((rl, V), np.int32),
-                       test_points=np.zeros((V, 6, 3), np.float32), points2=np.zeros((3, s2.shape[1]), np.float32))
+                       test_points=np.zeros((V, 6, 3), np.float32), points2=np.zeros((3, s2.shape[1]), np.float32),
+                       cond_info=np.zeros((rl, 8), np.float32))
             if aux == "full":
                 arr.update(points1_spherical=np.zeros((3, s1.shape[1]), np.float32), point_index1=np.zeros(s1.shape[1], np.int32), bin_start1=np.zeros(V + 1, np.int32),
                            points2_spherical=np.zeros((3, s2.shape[1]), np.float32), voxel2=np.zeros(s2.shape[1], np.int32))

@@ -304,12 +304,12 @@ void host_points2(const float* xf, const float* s, int64_t ld, int64_t n, float*
 // round trip at its end: measured on the map maker, +6 us per iteration); xf_last: the transform record of the last iteration (for
 // `points2`), written ONCE, straight into the pinned copy; [bounds, kf_end): the keyframe tables, final once the keyframe is built, copied to
 // the host on the copy stream while the loop runs; then the rarely requested integer tables (copied at the end).
-struct AuxLayout { size_t out, xf_last, x_hist, htwh, htwdz, small_end, bounds, has_fit, mu1, sigma1, evecs1, l_diag, test_points, kf_end, n1_raw, n2_raw, n2_in, ints_end, total; };
+struct AuxLayout { size_t out, xf_last, x_hist, htwh, htwdz, cond, small_end, bounds, has_fit, mu1, sigma1, evecs1, l_diag, test_points, kf_end, n1_raw, n2_raw, n2_in, ints_end, total; };
 AuxLayout aux_layout(int V, int runlen) {
     AuxLayout L{}; size_t o = 0;
     auto take = [&o](size_t n) { const size_t at = o; o += (n + 3) & ~(size_t)3; return at; };
     const size_t rl = runlen > 0 ? runlen : 1, v = (size_t)V;
-    L.out = take(48); L.x_hist = take(rl * 6); L.htwh = take(rl * 36); L.htwdz = take(rl * 6); L.small_end = o; L.xf_last = take(48);
+    L.out = take(48); L.x_hist = take(rl * 6); L.htwh = take(rl * 36); L.htwdz = take(rl * 6); L.cond = take(rl * 8); L.small_end = o; L.xf_last = take(48);
     L.bounds = take(v * 6); L.has_fit = take(v); L.mu1 = take(v * 3); L.sigma1 = take(v * 9); L.evecs1 = take(v * 9); L.l_diag = take(v * 3);
     L.test_points = take(v * 18); L.kf_end = o; L.n1_raw = take(v); L.n2_raw = take(rl * v); L.n2_in = take(rl * v); L.ints_end = o;
     L.total = o;
@@ -340,7 +340,7 @@ icet_status ensure_pack(icet_ctx* c, int V, int runlen) {
         auto I = [d](size_t at) { return reinterpret_cast<int32_t*>(d + at); };
         float* hs = reinterpret_cast<float*>(c->h_pack);                     // pinned host memory is device-accessible under the same address
         a.bounds = F(L.bounds); a.n1_raw = I(L.n1_raw); a.has_fit = I(L.has_fit); a.mu1 = F(L.mu1); a.sigma1 = F(L.sigma1); a.evecs1 = F(L.evecs1);
-        a.l_diag = F(L.l_diag); a.x_hist = F(L.x_hist); a.htwh = F(L.htwh); a.htwdz = F(L.htwdz); a.n2_raw = I(L.n2_raw); a.n2_in = I(L.n2_in);
+        a.l_diag = F(L.l_diag); a.x_hist = F(L.x_hist); a.htwh = F(L.htwh); a.htwdz = F(L.htwdz); a.cond = F(L.cond); a.n2_raw = I(L.n2_raw); a.n2_in = I(L.n2_in);
         a.test_points = F(L.test_points); a.xf_last = hs + L.xf_last;
         c->aux_V = V; c->aux_runlen = runlen;
     }
@@ -362,6 +362,7 @@ LaunchCfg make_cfg(icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     cfg.rt2 = (p->flags & ICET_FLAG_ROUNDTRIP_SCAN2) ? 1 : 0;
     cfg.lds_slots = c->tune.lds_slots; cfg.acc_min_pts_per_thread = c->tune.acc_pts; cfg.acc_target_blocks = c->tune.acc_blocks;
     cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds; cfg.exec_pairwise = c->tune.exec_pairwise; cfg.lds_rank = (c->tune.lds_rank != 0 && c->lds_rank_ok) ? 1 : 0;
+    cfg.gn_cond_bound2 = (float)(c->tune.gn_cond_bound * c->tune.gn_cond_bound);
     if (cfg.kf_pts_per_thread > kKfMaxPtsPerThread) cfg.kf_pts_per_thread = kKfMaxPtsPerThread;      // k_bin_scatter: a tile is at most 4 waves x that many rounds x 64 positions
     if (cfg.kf_pts_per_thread < 1) cfg.kf_pts_per_thread = 1;
     cfg.stage_event = c->stage_at ? c->ev_stage : nullptr; cfg.stage_at = c->stage_at;
@@ -1071,7 +1072,7 @@ icet_status icet_solve_end(icet_ctx* c) {
     if (q.has_aux) {
         const icet_aux& a = q.aux; const size_t rl = q.rl, v = (size_t)q.V;
         auto add = [&](void* dst, size_t at, size_t n) { if (dst && n) std::memcpy(dst, c->h_pack + at, n * sizeof(uint32_t)); };
-        add(a.x_hist, L.x_hist, rl * 6); add(a.htwh, L.htwh, rl * 36); add(a.htwdz, L.htwdz, rl * 6);
+        add(a.x_hist, L.x_hist, rl * 6); add(a.htwh, L.htwh, rl * 36); add(a.htwdz, L.htwdz, rl * 6); add(a.cond_info, L.cond, rl * 8);
         add(a.n1_raw, L.n1_raw, v); add(a.n2_raw, L.n2_raw, rl * v); add(a.n2_in, L.n2_in, rl * v);
         // the per-point tables go from HBM straight into the caller's arrays (several MB; only when asked for)
         if (q.side1) {
@@ -1115,6 +1116,24 @@ icet_status icet_debug_fetch(icet_ctx* c, int32_t what, void* out, int64_t count
     return ICET_OK;
 }
 
+// Test hook: the 6x6 tail of an iteration (src/icet.cpp:410-433) on n host-side (HTWH, HTWdz), evaluated by the device function k_gn_solve runs.
+icet_status icet_debug_gn_tail(icet_ctx* c, const float* htwh, const float* htwdz, int32_t n, float* out) {
+    if (!c || !htwh || !htwdz || !out || n < 0) return ICET_ERR_BAD_ARG;
+    if (n == 0) return ICET_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    float* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), sizeof(float) * (size_t)n * (36 + 6 + 56)));
+    float* d_H = d; float* d_g = d + (size_t)n * 36; float* d_o = d_g + (size_t)n * 6;
+    hipError_t e = hipMemcpyAsync(d_H, htwh, sizeof(float) * (size_t)n * 36, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_g, htwdz, sizeof(float) * (size_t)n * 6, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_gn_tail_debug(d_H, d_g, d_o, n, (float)(c->tune.gn_cond_bound * c->tune.gn_cond_bound), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, sizeof(float) * (size_t)n * 56, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { c->err = std::string("icet_debug_gn_tail: ") + hipGetErrorString(e); return ICET_ERR_HIP; }
+    return ICET_OK;
+}
+
 icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
     if (!c || !name) return ICET_ERR_BAD_ARG;
     Tuning& t = c->tune;
@@ -1134,6 +1153,7 @@ icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
     else if (k == "lds_rank") t.lds_rank = iv < 0 ? -1 : (iv != 0);
     else if (k == "exec_pairwise") t.exec_pairwise = iv < 0 ? -1 : (iv != 0);
     else if (k == "graph") { c->graph_mode = iv < 0 ? -1 : (iv != 0); c->g_solve.have_seen = c->g_keyframe.have_seen = c->g_loop.have_seen = false; }
+    else if (k == "gn_cond_bound") { if (!(value >= 0.0 && value <= 1e6)) { c->err = "gn_cond_bound must lie in [0, 1e6]"; return ICET_ERR_BAD_ARG; } t.gn_cond_bound = value; c->g_solve.have_seen = c->g_keyframe.have_seen = c->g_loop.have_seen = false; }
     else if (k == "guard_scale") { if (!(value >= 1.0 && value <= 1024.0)) { c->err = "guard_scale must lie in [1, 1024]"; return ICET_ERR_BAD_ARG; } t.guard_scale = value; c->w.thr_T = 0; }   // tables are rebuilt by the next call
     else if (k == "lut_polar_quantile") { if (!(value >= 0.0 && value <= 1.0)) { c->err = "lut_polar_quantile must lie in [0, 1]"; return ICET_ERR_BAD_ARG; } t.lut_polar_quantile = value; c->w.thr_T = 0; }
     else { c->err = "unknown option: " + k; return ICET_ERR_BAD_ARG; }

@@ -161,22 +161,21 @@ __device__ inline void make_householder(float* x, int m, int stride, float& tau,
 // Symmetric 6x6 (row-major, lower triangle read): eigenvalues ascending, eigenvectors = columns of Q.
 // kVec = false computes the eigenvalues only: the tridiagonal recurrences never read Q, so the values are
 // bit-identical to the full solve at less than half the work.
+// Work arrays come from the caller (A[36], sm[30]: h | v | p | diag | sub), so that the literal 6x6 tail can keep them in LDS.
 template <bool kVec = true>
-__device__ inline bool eig6_sym(const float* Ain, float ev[6], float* Q) {
+__device__ inline bool eig6_sym_core(const float* Ain, float ev[6], float* Q, float* A, float* sm) {
 #pragma clang fp contract(off)
     constexpr int n = 6;
-    float A[36];
+    float* h = sm; float* v = sm + 6; float* p = sm + 12; float* diag = sm + 18; float* sub = sm + 24;
     float scale = 0.f;
     for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) scale = fmaxf(scale, fabsf(Ain[i * n + j]));
     if (scale == 0.f) scale = 1.f;
     for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) A[i * n + j] = (j <= i) ? Ain[i * n + j] / scale : 0.f;
-    float h[6];
     for (int i = 0; i < n - 1; i++) {
         int rem = n - i - 1;
         float tau, beta;
         make_householder(&A[(i + 1) * n + i], rem, n, tau, beta);
         A[(i + 1) * n + i] = 1.f;
-        float v[6], p[6];
         for (int k = 0; k < rem; k++) v[k] = A[(i + 1 + k) * n + i];
         for (int a = 0; a < rem; a++) {
             float s = 0.f;
@@ -195,15 +194,14 @@ __device__ inline bool eig6_sym(const float* Ain, float ev[6], float* Q) {
         A[(i + 1) * n + i] = beta;
         h[i] = tau;
     }
-    float diag[6], sub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < n; i++) diag[i] = A[i * n + i];
+    for (int i = 0; i < n; i++) { diag[i] = A[i * n + i]; sub[i] = 0.f; }
     for (int i = 0; i < n - 1; i++) sub[i] = A[(i + 1) * n + i];
     if (kVec) {
         for (int i = 0; i < 36; i++) Q[i] = 0.f;
         for (int i = 0; i < n; i++) Q[i * n + i] = 1.f;
         for (int k = n - 2; k >= 0; k--) {
             int rem = n - k - 1;
-            float v[6]; v[0] = 1.f;
+            v[0] = 1.f;
             for (int t = 1; t < rem; t++) v[t] = A[(k + 1 + t) * n + k];
             for (int col = 0; col < n; col++) {
                 float s = 0.f;
@@ -216,6 +214,11 @@ __device__ inline bool eig6_sym(const float* Ain, float ev[6], float* Q) {
     bool ok = tridiag_eigen<6, kVec>(diag, sub, Q);
     for (int i = 0; i < n; i++) ev[i] = diag[i] * scale;
     return ok;
+}
+template <bool kVec = true>
+__device__ inline bool eig6_sym(const float* Ain, float ev[6], float* Q) {
+    float A[36], sm[30];
+    return eig6_sym_core<kVec>(Ain, ev, Q, A, sm);
 }
 
 // Inverse of a symmetric positive-definite 6x6 (row-major) by Cholesky, fully unrolled (registers only).
@@ -340,6 +343,186 @@ __device__ inline void pinv3_sym_fast(const float a[6], float rel_tol, float w[6
         }
     }
     pinv3_sym<double>(a, rel_tol, w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The LITERAL 6x6 tail of one Gauss-Newton iteration (/root/reference/src/icet.cpp:410-430), for matrices the Cholesky route of
+// k_gn_solve cannot prove well conditioned: noise_mat = CompleteOrthogonalDecomposition(HTWH).pseudoInverse() (:410-411), pred_stds
+// (:412-417), checkCondition (:443-492: eigenvectors of HTWH, `pred_stds += U2.col(k)` and one row of L2 dropped per pruned axis),
+// dx = pinv(L2 lam U2^T) L2 U2^T HTWdz (:427-430) -- statement by statement, with Eigen 3.3's algorithms (column-pivoted Householder QR with
+// norm down-dating; rank = pivots above eps * min(rows, cols) * the largest pivot; minimum-norm completion of a rank-deficient R) in plain
+// IEEE float operations without contraction, so that on the same (HTWH, HTWdz) bits the result -- the rank decision, the number of pruned
+// axes, the SIGN of the eigenvector added to pred_stds -- does not depend on which side evaluated it (checked bit for bit against the CPU
+// checker over condition numbers 3e5 .. 3e7, tests/test_gpu_parity.py::test_gn_tail_literal_bits).  Rounds 2-4 used an eigenvalue rule
+// (|lambda_k| > 6 eps lambda_max) for the rank here; scripts/rank_rule_study.py finds it disagreeing with the pivot rule on 35 of 8400
+// matrices around cond = 1.4e6 = 1 / (6 eps), right above checkCondition's cutoff.
+// Rare by construction (a tunnel, a single wall, open ground), so it is written for fidelity, not speed: generic small matrices in scratch.
+
+// Every array of the literal tail lives in ONE workspace the caller places in LDS and ONE lane walks through it: no scratch memory in the
+// kernels that hold this rarely taken branch (as local arrays it cost k_gn_solve 3.5 KB of scratch per lane, and arrays of the hot Cholesky
+// route whose address escaped into the call would have left their registers).
+struct GnTailWs {
+    float H[36], g[6];                                            // in
+    float cov[36], ps[6], dx[6], ev[6]; int pruned, rank;         // out
+    float qr[36], C[36], Y[36]; double G[36], Ginv[36];           // cod_pinv
+    float hc[6], nUpd[6], nDir[6]; int perm[6];
+    float A[36], sm[30];                                          // eig6_sym_core
+    float U2[36], L2[36], lam[36], U2t[36], T1[36], innards[36], inv[36], T2[36], lhs[36];
+};
+
+// C (ar x bc) = A (ar x ac) * B (ac x bc), row-major, each entry a sequential float sum starting from 0 in index order (zero terms included)
+__device__ inline void mm_seq(const float* A, int ar, int ac, const float* B, int bc, float* C) {
+#pragma clang fp contract(off)
+    for (int i = 0; i < ar; i++)
+        for (int j = 0; j < bc; j++) {
+            float s = 0.f;
+            for (int k = 0; k < ac; k++) s += A[i * ac + k] * B[k * bc + j];
+            C[i * bc + j] = s;
+        }
+}
+
+// CompleteOrthogonalDecomposition<MatrixXf>(A).pseudoInverse() for A rows x cols (<= 6 x 6, row-major); out is cols x rows.  Returns the rank.
+__device__ inline int cod_pinv(const float* Ain, int rows, int cols, float* pinv, GnTailWs& w) {
+#pragma clang fp contract(off)
+    const int size = rows < cols ? rows : cols;
+    float* qr = w.qr; float* hc = w.hc; int* perm = w.perm; float* normsUpd = w.nUpd; float* normsDir = w.nDir;
+    for (int i = 0; i < rows * cols; i++) qr[i] = Ain[i];
+    for (int k = 0; k < cols; k++) {
+        float s = 0.f; for (int i = 0; i < rows; i++) s += qr[i * cols + k] * qr[i * cols + k];
+        normsDir[k] = sqrtf(s); normsUpd[k] = normsDir[k]; perm[k] = k;
+    }
+    float maxn = 0.f; for (int k = 0; k < cols; k++) maxn = fmaxf(maxn, normsUpd[k]);      // (NaN norms: fmaxf and std::max(a, b) = (a < b) ? b : a both keep the running value)
+    const float th = maxn * FLT_EPSILON; const float threshold_helper = (th * th) / float(rows);
+    const float norm_downdate_threshold = 3.4526698300124393e-04f;                          // sqrt(FLT_EPSILON), correctly rounded
+    int nonzero_pivots = size; float maxpivot = 0.f;
+    for (int k = 0; k < size; k++) {
+        int big = k; float bn = normsUpd[k];
+        for (int j = k + 1; j < cols; j++) if (normsUpd[j] > bn) { bn = normsUpd[j]; big = j; }
+        const float big_sq = bn * bn;
+        if (nonzero_pivots == size && big_sq < threshold_helper * float(rows - k)) nonzero_pivots = k;
+        if (k != big) {
+            for (int i = 0; i < rows; i++) { const float t = qr[i * cols + k]; qr[i * cols + k] = qr[i * cols + big]; qr[i * cols + big] = t; }
+            { float t = normsUpd[k]; normsUpd[k] = normsUpd[big]; normsUpd[big] = t; t = normsDir[k]; normsDir[k] = normsDir[big]; normsDir[big] = t; }
+            { const int t = perm[k]; perm[k] = perm[big]; perm[big] = t; }
+        }
+        float tau, beta;
+        make_householder(&qr[k * cols + k], rows - k, cols, tau, beta);
+        qr[k * cols + k] = beta;
+        if (fabsf(beta) > maxpivot) maxpivot = fabsf(beta);
+        hc[k] = tau;
+        for (int j = k + 1; j < cols; j++) {                      // H = I - tau v v^T on the bottom-right corner
+            float s = qr[k * cols + j];
+            for (int i = k + 1; i < rows; i++) s += qr[i * cols + k] * qr[i * cols + j];
+            s *= tau;
+            qr[k * cols + j] -= s;
+            for (int i = k + 1; i < rows; i++) qr[i * cols + j] -= s * qr[i * cols + k];
+        }
+        for (int j = k + 1; j < cols; ++j) {
+            if (normsUpd[j] != 0.f) {
+                float temp = fabsf(qr[k * cols + j]) / normsUpd[j];
+                temp = (1.f + temp) * (1.f - temp);
+                temp = temp < 0.f ? 0.f : temp;
+                const float ratio = normsUpd[j] / normsDir[j];
+                const float temp2 = temp * ratio * ratio;
+                if (temp2 <= norm_downdate_threshold) {
+                    float s = 0.f; for (int i = k + 1; i < rows; i++) s += qr[i * cols + j] * qr[i * cols + j];
+                    normsDir[j] = sqrtf(s); normsUpd[j] = normsDir[j];
+                } else {
+                    normsUpd[j] *= sqrtf(temp);
+                }
+            }
+        }
+    }
+    const float premult = fabsf(maxpivot) * (FLT_EPSILON * float(size));
+    int rank = 0;
+    for (int i = 0; i < nonzero_pivots; i++) rank += (fabsf(qr[i * cols + i]) > premult) ? 1 : 0;
+    for (int i = 0; i < cols * rows; i++) pinv[i] = 0.f;
+    if (rank == 0) return 0;
+    float* C = w.C;                                               // Q^T restricted to the first `rank` reflectors, applied to I (rows x rows)
+    for (int i = 0; i < rows * rows; i++) C[i] = 0.f;
+    for (int i = 0; i < rows; i++) C[i * rows + i] = 1.f;
+    for (int k = 0; k < rank; k++)
+        for (int j = 0; j < rows; j++) {
+            float s = C[k * rows + j];
+            for (int i = k + 1; i < rows; i++) s += qr[i * cols + k] * C[i * rows + j];
+            s *= hc[k];
+            C[k * rows + j] -= s;
+            for (int i = k + 1; i < rows; i++) C[i * rows + j] -= s * qr[i * cols + k];
+        }
+    float* Y = w.Y;                                               // permuted solution, cols x rows
+    for (int i = 0; i < cols * rows; i++) Y[i] = 0.f;
+    if (rank == cols) {
+        for (int j = 0; j < rows; j++)
+            for (int i = rank - 1; i >= 0; i--) {
+                float s = C[i * rows + j];
+                for (int t = i + 1; t < rank; t++) s -= qr[i * cols + t] * Y[t * rows + j];
+                Y[i * rows + j] = s / qr[i * cols + i];
+            }
+    } else {
+        // X = [R11 R12] (rank x cols); X^+ = X^T (X X^T)^-1 in double (what the Z-reflector stage of Eigen's COD yields); Y = X^+ C(0:rank, :)
+        double* G = w.G; double* Ginv = w.Ginv;
+        for (int i = 0; i < rank; i++) for (int j = 0; j < rank; j++) {
+            double s = 0; for (int t = 0; t < cols; t++) { const double xi = (t >= i) ? (double)qr[i * cols + t] : 0.0, xj = (t >= j) ? (double)qr[j * cols + t] : 0.0; s += xi * xj; }
+            G[i * rank + j] = s; Ginv[i * rank + j] = (i == j) ? 1.0 : 0.0;
+        }
+        for (int p = 0; p < rank; p++) {                          // Gauss-Jordan with partial pivoting (G is SPD)
+            int piv = p; for (int i = p + 1; i < rank; i++) if (fabs(G[i * rank + p]) > fabs(G[piv * rank + p])) piv = i;
+            if (piv != p) for (int j = 0; j < rank; j++) {
+                double t = G[p * rank + j]; G[p * rank + j] = G[piv * rank + j]; G[piv * rank + j] = t;
+                t = Ginv[p * rank + j]; Ginv[p * rank + j] = Ginv[piv * rank + j]; Ginv[piv * rank + j] = t;
+            }
+            const double d = G[p * rank + p];
+            for (int j = 0; j < rank; j++) { G[p * rank + j] /= d; Ginv[p * rank + j] /= d; }
+            for (int i = 0; i < rank; i++) if (i != p) {
+                const double f = G[i * rank + p];
+                for (int j = 0; j < rank; j++) { G[i * rank + j] -= f * G[p * rank + j]; Ginv[i * rank + j] -= f * Ginv[p * rank + j]; }
+            }
+        }
+        for (int t = 0; t < cols; t++) for (int j = 0; j < rows; j++) {
+            double s = 0;
+            for (int i = 0; i < rank; i++) {
+                const double xit = (t >= i) ? (double)qr[i * cols + t] : 0.0;
+                double ww = 0; for (int m = 0; m < rank; m++) ww += Ginv[i * rank + m] * (double)C[m * rows + j];
+                s += xit * ww;
+            }
+            Y[t * rows + j] = (float)s;
+        }
+    }
+    for (int k = 0; k < cols; k++) for (int j = 0; j < rows; j++) pinv[perm[k] * rows + j] = Y[k * rows + j];
+    return rank;
+}
+
+// src/icet.cpp:410-430 for the (H, g) in the workspace: cov = noise_mat, ps = pred_stds (after checkCondition's additions), dx, ev = eigenvalues
+// ascending, pruned = number of pruned axes, rank = the COD rank of HTWH.  Call from ONE lane.
+__device__ __noinline__ void gn_tail_literal(GnTailWs& w) {
+#pragma clang fp contract(off)
+    w.rank = cod_pinv(w.H, 6, 6, w.cov, w);
+    for (int k = 0; k < 6; k++) w.ps[k] = sqrtf(fabsf(w.cov[k * 6 + k]));
+    float* U2 = w.U2; float* ev = w.ev;
+    eig6_sym_core<true>(w.H, ev, U2, w.A, w.sm);
+    int k0 = 0;
+    {
+        float condition = ev[5] / ev[0];
+        int eyecount = 1;
+        while (fabsf(condition) > 1e6f && eyecount < 6) {
+            for (int k = 0; k < 6; k++) w.ps[k] += U2[k * 6 + eyecount - 1];               // src/icet.cpp:479
+            k0++;
+            condition = ev[5] / ev[eyecount];
+            eyecount++;
+        }
+    }
+    w.pruned = k0;
+    const int m = 6 - k0;
+    for (int i = 0; i < 36; i++) { w.L2[i] = 0.f; w.lam[i] = 0.f; }
+    for (int i = 0; i < m; i++) w.L2[i * 6 + k0 + i] = 1.f;
+    for (int i = 0; i < 6; i++) w.lam[i * 6 + i] = ev[i];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) w.U2t[j * 6 + i] = U2[i * 6 + j];
+    mm_seq(w.L2, m, 6, w.lam, 6, w.T1);
+    mm_seq(w.T1, m, 6, w.U2t, 6, w.innards);                                                 // L2 * lam * U2^T   (m x 6)   src/icet.cpp:427
+    cod_pinv(w.innards, m, 6, w.inv, w);                                                     // 6 x m
+    mm_seq(w.inv, 6, m, w.L2, 6, w.T2);
+    mm_seq(w.T2, 6, 6, w.U2t, 6, w.lhs);
+    mm_seq(w.lhs, 6, 6, w.g, 1, w.dx);                                                       // src/icet.cpp:430
 }
 
 }  // namespace icetdev

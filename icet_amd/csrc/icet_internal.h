@@ -81,7 +81,7 @@ static_assert(sizeof(SlotHot) == 48 && sizeof(SlotFit) == 80, "k_compact_slots c
 // Optional dense (per-voxel) dump for the reference's public side tables; device pointers or null.
 struct AuxDev {
     float* bounds; int32_t* n1_raw; int32_t* has_fit; float* mu1; float* sigma1; float* evecs1; float* l_diag;
-    float* x_hist; float* htwh; float* htwdz; int32_t* n2_raw; int32_t* n2_in; float* test_points;
+    float* x_hist; float* htwh; float* htwdz; float* cond; int32_t* n2_raw; int32_t* n2_in; float* test_points;
     float* xf_last;      // 48 floats: the transform record the LAST iteration's point pass uses (written by k_init_state / the solve of iteration runlen - 2), for `points2`
 };
 
@@ -145,6 +145,7 @@ struct Tuning {
     int exec_pairwise = -1;       // "did step v execute": one block per pair in index order with the bit table in LDS (k_exec_flags_pair) 1, chain walks (k_exec_flags) 0, by batch size -1
     double guard_scale = 1.0;     // multiplies the classification guard bands (tables are rebuilt)
     double lut_polar_quantile = 0.25;   // polar LUT cell width = this quantile of the polar bin widths
+    double gn_cond_bound = 2.5e5;   // H^T W H whose Frobenius condition bound exceeds this takes the literal 6x6 tail (COD / eigenvectors / pruning) instead of the Cholesky inverse; 0 = always literal
 };
 
 struct LaunchCfg {
@@ -170,6 +171,7 @@ struct LaunchCfg {
     int half_gap = 0;                 // ICET_FLAG_HALF_GAP_BOUNDS (non-parity extension; sets true_sort as well)
     int rt2 = 0;                      // ICET_FLAG_ROUNDTRIP_SCAN2 (parity-study option)
     int lds_rank = 0;                 // Tuning::lds_rank, resolved against the context's self-test
+    float gn_cond_bound2 = 6.25e10f;     // Tuning::gn_cond_bound squared: k_gn_solve's Cholesky route needs |A|_F |A^-1|_F <= the bound (icet_solve.hip gn_tail)
 };
 constexpr float kRejectMovingThresh = 0.3f;        // python/ICET_spherical.py:38  RM_thresh
 constexpr int kRejectMovingStartIter = 4;          // python/ICET_spherical.py:36  start_RM_iter
@@ -179,6 +181,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
 // icet_solve.hip
 hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last = nullptr, const int32_t* d_n2 = nullptr);
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st);
+hipError_t launch_gn_tail_debug(const float* d_H, const float* d_g, float* d_out, int n, float bound2, hipStream_t st);     // test hook: the 6x6 tail on its own
 // `points2` of pair 0 (include/icet.h:80): scan 2 under the transform record `xf` (AuxDev::xf_last); out = n2 x 3 column-major, ld n2 (may be pinned host memory)
 hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* xf, float* out, hipStream_t st);
 // icet_accumulate.hip

@@ -55,6 +55,42 @@ __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X
     if (xf_last) for (int k = 0; k < kXf; k++) xf_last[p * kXf + k] = xf[p * kXf + k];      // a one-iteration solve transforms scan 2 by X0 (`points2`)
 }
 
+// The 6 x 6 tail of one iteration (src/icet.cpp:410-433) for one (HTWH, HTWdz).
+// Normal case first: HTWH positive definite with a condition number that the Frobenius bound cond_2 <= |A|_F |A^-1|_F proves to be <= sqrt(bound2)
+// (default 2.5e5: a factor 4 below checkCondition's cutoff of 1e6, src/icet.cpp:453,469 -- at cond ~ 1e6 a float inverse knows its own norm to a few per
+// cent only, and with the bound AT the cutoff the device kept matrices on this route that the reference prunes; the 256 bench pairs reach 2.1e5).  Then nothing is pruned, every pivot is above the pseudo-inverse's rank threshold
+// (6 eps < 1e-6), pinv(HTWH) is the inverse and dx = HTWH^-1 HTWdz: a Cholesky factorisation gives both (route 0).  Everything else -- bound
+// inconclusive, Cholesky pivot not positive, NaN -- takes the literal restatement of the reference's statements (route 2, icet_device_math.h
+// gn_tail_literal), which decides rank, pruning and eigenvector signs exactly as the reference's algorithms do on the same bits.
+// `ws`: the literal route's workspace in LDS; `leader`: the one lane of the wave that walks it (the others wait and read the results, so that
+// the outputs are wave-uniform on either route).  Must be called by a whole wave.
+__device__ __forceinline__ void gn_tail(const float* Hm, const float* g, float bound2, float* cov, float* ps, float* dx, float* ev, int& route, int& pruned,
+                                        icetdev::GnTailWs& ws, bool leader) {
+    bool plain = icetdev::chol6_inverse(Hm, cov);
+    if (plain) {
+        float fa = 0.f, fi = 0.f;
+        for (int k = 0; k < 36; k++) { fa += Hm[k] * Hm[k]; fi += cov[k] * cov[k]; }
+        plain = fa * fi <= bound2;                                  // (false for NaN)
+    }
+    if (plain) {
+        for (int k = 0; k < 6; k++) ps[k] = sqrtf(fabsf(cov[k * 6 + k]));         // src/icet.cpp:412-417
+        for (int a = 0; a < 6; a++) { float t = 0.f; for (int b = 0; b < 6; b++) t += cov[a * 6 + b] * g[b]; dx[a] = t; }
+        for (int k = 0; k < 6; k++) ev[k] = __builtin_nanf("");     // not computed on this route
+        route = 0; pruned = 0;
+    } else {
+        if (leader) {
+            for (int k = 0; k < 36; k++) ws.H[k] = Hm[k];
+            for (int k = 0; k < 6; k++) ws.g[k] = g[k];
+            icetdev::gn_tail_literal(ws);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < 36; k++) cov[k] = ws.cov[k];
+        for (int k = 0; k < 6; k++) { ps[k] = ws.ps[k]; dx[k] = ws.dx[k]; ev[k] = ws.ev[k]; }
+        pruned = ws.pruned;
+        route = 2;
+    }
+}
+
 // fitCells2's per-voxel algebra + reduction + the 6x6 solve.  One block per pair.
 // Undecided scan-2 points that did not fit a block's LDS queue in k_gn_accumulate (see there): literal classification, each a
 // run of one, straight into the HBM accumulators.  Empty on ordinary data; the whole list when the force_exact diagnostic is on.
@@ -91,7 +127,7 @@ __device__ __noinline__ void drain_near_overflow(const NearOverflow& o, int pair
 template <int kT, int kStage>
 __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_slots, const SlotFit* __restrict__ fitS, uint32_t* __restrict__ acc,
                                                      float* __restrict__ X_all, float* __restrict__ xf_all, float* __restrict__ out, AuxDev aux,
-                                                     int V, int n, int iter, int runlen, NearOverflow over, int reject_moving, float* __restrict__ part, int nblk) {
+                                                     int V, int n, int iter, int runlen, NearOverflow over, int reject_moving, float* __restrict__ part, int nblk, float cond_bound2) {
     constexpr bool kCanon = kT == 512;
     static_assert(kStage == 0 || kCanon, "the two-stage form reduces in virtual blocks of 512 slots");
     __shared__ float J[27];
@@ -270,63 +306,10 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
         for (int a = 0; a < 6; a++) g[a] = stage[21 + a];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    // Normal case first: HTWH positive definite with condition number <= 1e6.  Then nothing is pruned
-    // (checkCondition's cutoff, src/icet.cpp:453,469), every eigenvalue is above the pseudo-inverse's rank threshold
-    // (eps * 6 < 1e-6), pinv(HTWH) is the inverse and dx = HTWH^-1 HTWdz -- a Cholesky factorisation gives both.
-    // cond_2 <= |A|_F |A^-1|_F, so that product <= 1e6 PROVES the case without an eigen-solve.  When the bound is
-    // inconclusive the eigenvalues decide, exactly as the reference does, and only a genuinely ill-conditioned or
-    // rank-deficient HTWH takes the eigenvector route with its pruning.
-    float ev[6];
-    float cov[36], ps[6], dx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    bool plain = icetdev::chol6_inverse(Hm, cov);
-    if (plain) {
-        float fa = 0.f, fi = 0.f;
-        for (int k = 0; k < 36; k++) { fa += Hm[k] * Hm[k]; fi += cov[k] * cov[k]; }
-        if (!(fa * fi <= 1e12f)) {                                  // bound inconclusive (or NaN): ask the eigenvalues
-            icetdev::eig6_sym<false>(Hm, ev, nullptr);
-            float emax = 0.f;
-            for (int k = 0; k < 6; k++) emax = fmaxf(emax, fabsf(ev[k]));
-            plain = !(fabsf(ev[5] / ev[0]) > 1e6f);
-            for (int k = 0; k < 6; k++) plain = plain && (fabsf(ev[k]) > 6.0f * FLT_EPSILON * emax);
-        }
-    }
-    if (plain) {
-        for (int k = 0; k < 6; k++) ps[k] = sqrtf(fabsf(cov[k * 6 + k]));         // src/icet.cpp:412-417
-        for (int a = 0; a < 6; a++) { float t = 0.f; for (int b = 0; b < 6; b++) t += cov[a * 6 + b] * g[b]; dx[a] = t; }
-    } else {
-        float Q[36];
-        icetdev::eig6_sym<true>(Hm, ev, Q);
-        float emax = 0.f;
-        for (int k = 0; k < 6; k++) emax = fmaxf(emax, fabsf(ev[k]));
-        const float rthr = 6.0f * FLT_EPSILON * emax;              // rank rule eps*6 relative to the largest eigenvalue
-        // noise_mat = pinv(HTWH) (src/icet.cpp:410-411)
-        float inv[6];
-        for (int k = 0; k < 6; k++) inv[k] = (fabsf(ev[k]) > rthr) ? 1.f / ev[k] : 0.f;
-        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) {
-            float t = 0.f; for (int k = 0; k < 6; k++) t += Q[a * 6 + k] * inv[k] * Q[b * 6 + k];
-            cov[a * 6 + b] = t;
-        }
-        for (int k = 0; k < 6; k++) ps[k] = sqrtf(fabsf(cov[k * 6 + k]));         // src/icet.cpp:412-417
-        // checkCondition (src/icet.cpp:443-492)
-        int k0 = 0;
-        {
-            float condition = ev[5] / ev[0];
-            int eyecount = 1;
-            while (fabsf(condition) > 1e6f && eyecount < 6) {
-                for (int k = 0; k < 6; k++) ps[k] += Q[k * 6 + eyecount - 1];       // src/icet.cpp:479
-                k0++;
-                condition = ev[5] / ev[eyecount];
-                eyecount++;
-            }
-        }
-        // dx = pinv(L2 lam U2^T) L2 U2^T HTWdz  = sum_{k >= k0} q_k (q_k . g) / lam_k     src/icet.cpp:427-430
-        for (int k = k0; k < 6; k++) {
-            if (inv[k] == 0.f) continue;
-            float pj = 0.f; for (int a = 0; a < 6; a++) pj += Q[a * 6 + k] * g[a];
-            pj *= inv[k];
-            for (int a = 0; a < 6; a++) dx[a] += Q[a * 6 + k] * pj;
-        }
-    }
+    float ev[6], cov[36], ps[6], dx[6];
+    int route, pruned;
+    __shared__ icetdev::GnTailWs tail_ws;
+    gn_tail(Hm, g, cond_bound2, cov, ps, dx, ev, route, pruned, tail_ws, lane == 0);
     // (every lane of the wave ran the scalar algebra above on the same inputs -- a wave costs what a lane costs -- so the results are
     // wave-uniform; lane 0 stages them and the lanes store them)
     float Xn[6];
@@ -346,9 +329,33 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
         if (aux.x_hist) for (int k = 0; k < 6; k++) aux.x_hist[((size_t)pair * runlen + iter) * 6 + k] = Xn[k];
         if (aux.htwh) for (int k = 0; k < 36; k++) aux.htwh[((size_t)pair * runlen + iter) * 36 + k] = Hm[k];
         if (aux.htwdz) for (int k = 0; k < 6; k++) aux.htwdz[((size_t)pair * runlen + iter) * 6 + k] = g[k];
+        if (aux.cond) { float* ci = aux.cond + ((size_t)pair * runlen + iter) * 8; for (int k = 0; k < 6; k++) ci[k] = ev[k]; ci[6] = (float)pruned; ci[7] = (float)route; }
     }
 }
+
+// Test hook (icet_debug_gn_tail): n independent (HTWH, HTWdz), one WAVE each, through the SAME gn_tail k_gn_solve runs.
+// out: 56 floats per matrix: cov[36] | pred_stds[6] | dx[6] | eigenvalues[6] | pruned | route.
+__global__ __launch_bounds__(64) void k_gn_tail_debug(const float* __restrict__ H, const float* __restrict__ gv, float* __restrict__ out, int n, float bound2) {
+    const int i = blockIdx.x;
+    float Hm[36], g[6], cov[36], ps[6], dx[6], ev[6];
+    for (int k = 0; k < 36; k++) Hm[k] = H[(size_t)i * 36 + k];
+    for (int k = 0; k < 6; k++) g[k] = gv[(size_t)i * 6 + k];
+    int route, pruned;
+    __shared__ icetdev::GnTailWs tail_ws;
+    gn_tail(Hm, g, bound2, cov, ps, dx, ev, route, pruned, tail_ws, threadIdx.x == 0);
+    if (threadIdx.x != 0) return;
+    float* o = out + (size_t)i * 56;
+    for (int k = 0; k < 36; k++) o[k] = cov[k];
+    for (int k = 0; k < 6; k++) { o[36 + k] = ps[k]; o[42 + k] = dx[k]; o[48 + k] = ev[k]; }
+    o[54] = (float)pruned; o[55] = (float)route;
+}
 }  // namespace
+
+hipError_t launch_gn_tail_debug(const float* d_H, const float* d_g, float* d_out, int n, float bound2, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    k_gn_tail_debug<<<n, 64, 0, st>>>(d_H, d_g, d_out, n, bound2);
+    return hipGetLastError();
+}
 
 #define ICET_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -403,12 +410,12 @@ hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, flo
     if (c.V > 4096 && c.n_pairs <= kTwoStageMaxPairs && w.gn_part) {
         // two stages: several blocks per pair reduce their share of the slots to 27 partial sums each, one block per pair adds them and solves
         const int nblk = kTwoStageBlocks;
-        k_gn_solve<512, 1><<<c.n_pairs * nblk, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk);
+        k_gn_solve<512, 1><<<c.n_pairs * nblk, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk, c.gn_cond_bound2);
         ICET_LAUNCH_CHECK();
-        k_gn_solve<512, 2><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk);
+        k_gn_solve<512, 2><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk, c.gn_cond_bound2);
     }
-    else if (c.V > 4096) k_gn_solve<512, 0><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1);
-    else k_gn_solve<kBlock, 0><<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1);
+    else if (c.V > 4096) k_gn_solve<512, 0><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1, c.gn_cond_bound2);
+    else k_gn_solve<kBlock, 0><<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1, c.gn_cond_bound2);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -70,8 +70,11 @@ def _raycast(scene, origin, dirs, max_range):
     # ground
     t = (scene["ground"] - oz) / torch.where(dz.abs() < eps, torch.full_like(dz, eps), dz)
     upd(t, dz < 0)
+    if scene.get("ceiling") is not None:          # tunnel scenes: a horizontal plane above the sensor
+        t = (scene["ceiling"] - oz) / torch.where(dz.abs() < eps, torch.full_like(dz, eps), dz)
+        upd(t, dz > 0)
     # walls: y = +-half_w (|x| <= half_l), x = +-half_l (|y| <= half_w), ground <= z <= wall_top
-    for yy in (-scene["half_w"], scene["half_w"]):
+    for yy in ((scene["half_w"],) if scene.get("one_wall") else (-scene["half_w"], scene["half_w"])):
         t = (yy - oy) / torch.where(dy.abs() < eps, torch.full_like(dy, eps), dy)
         x = ox + t * dx; z = oz + t * dz
         upd(t, (x.abs() <= scene["half_l"]) & (z >= scene["ground"]) & (z <= scene["wall_top"]))
@@ -167,6 +170,49 @@ def batch_motion(k):
     rs = np.random.RandomState(5000 + k)
     lim = np.array([0.6, 0.05, 0.02, 0.005, 0.005, 0.02])
     return rs.uniform(-lim, lim)
+
+
+def make_degenerate_scene(kind="tunnel", sensor_height=1.8):
+    """Scenes whose geometry leaves solution axes unobservable -- the input ICET::checkCondition (src/icet.cpp:443-492) exists for.
+    "tunnel": walls y = +-4.5 m, floor, ceiling 2.5 m above the sensor, no end walls within range (translation along x is free: with 0.5-1 mm
+    of range noise cond(H^T W H) = 2e6, one axis pruned, and the sign of the pruned eigenvector differs between the two noise levels);
+    "wall": the floor and ONE wall at y = 3 m; "ground": the floor alone (x, y and yaw are free)."""
+    g = -sensor_height
+    far = 1.0e9
+    if kind == "tunnel":
+        return dict(ground=g, half_w=4.5, half_l=far, wall_top=2.5, ceiling=2.5, boxes=[], cyls=[])
+    if kind == "wall":
+        return dict(ground=g, half_w=3.0, half_l=far, wall_top=6.0, ceiling=None, boxes=[], cyls=[], one_wall=True)
+    if kind == "ground":
+        return dict(ground=g, half_w=far, half_l=far, wall_top=g, ceiling=None, boxes=[], cyls=[])
+    raise ValueError("kind must be tunnel, wall or ground")
+
+
+# name -> (kind, sigma, motion): the degenerate pairs of tests/golden/golden_degenerate.npz and tests/test_gpu_parity.py.  What the CPU restatement
+# does on them (7 iterations, 75 x 24): tunnel_s05 / tunnel_s10: one axis pruned, pred_stds[0] = +1.0 / -1.0 (the sign of an eigenvector);
+# wall_s10: one axis, cond 7e6; wall_s30: cond 9.7e5, just below checkCondition's cutoff, nothing pruned; ground_s05 / ground_s02: two / three
+# axes; ground_s10_m: nothing pruned in the first iteration, one axis from the second on.
+_SMALL_MOTION = (0.1, 0.02, 0.0, 0.001, 0.0, 0.005)
+DEGENERATE_SCENES = {
+    "tunnel_s05": ("tunnel", 0.0005, (0, 0, 0, 0, 0, 0)), "tunnel_s10": ("tunnel", 0.001, (0, 0, 0, 0, 0, 0)), "tunnel_s10_m": ("tunnel", 0.001, _SMALL_MOTION),
+    "wall_s10": ("wall", 0.001, (0, 0, 0, 0, 0, 0)), "wall_s30": ("wall", 0.003, (0, 0, 0, 0, 0, 0)),
+    "ground_s02": ("ground", 0.0002, (0, 0, 0, 0, 0, 0)), "ground_s05": ("ground", 0.0005, (0, 0, 0, 0, 0, 0)), "ground_s10_m": ("ground", 0.001, _SMALL_MOTION),
+}
+
+
+def make_degenerate_named(name, device="cpu"):
+    kind, sigma, motion = DEGENERATE_SCENES[name]
+    return make_degenerate_pair(kind, sigma=sigma, motion=motion, device=device)
+
+
+def make_degenerate_pair(kind="tunnel", noise_seed=7001, motion=(0, 0, 0, 0, 0, 0), sigma=0.002, rings=64, steps=2048, device="cpu", order="ring", max_range=120.0):
+    """(scan1, scan2, X_true) of a degenerate scene (make_degenerate_scene), range noise N(0, sigma)."""
+    scene = make_degenerate_scene(kind)
+    X = np.asarray(motion, np.float64)
+    R = euler_R(X[3], X[4], X[5])
+    s1 = make_scan(scene, (np.zeros(3), np.eye(3)), noise_seed * 2 + 1, rings, steps, sigma, max_range, device=device, order=order)
+    s2 = make_scan(scene, (R.T @ X[:3], R.T), noise_seed * 2 + 2, rings, steps, sigma, max_range, device=device, order=order)
+    return s1, s2, X.astype(np.float32)
 
 
 def make_batch_pair(k, rings=64, steps=2048, device="cpu", order="ring"):

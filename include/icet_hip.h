@@ -110,6 +110,9 @@ typedef struct icet_aux {
                                    src/icet.cpp:387), caller's row order                                                              */
     int32_t* voxel2;            /* n2: the voxel sortSphericalCoordinates assigns to every row of points2 in the last fitScan2
                                    (src/icet.cpp:388): `pointIndices2[theta][phi]` = the rows i with voxel2[i] == T * phi + theta, ascending */
+    float*   cond_info;         /* runlen x 8: what ICET::checkCondition (src/icet.cpp:443-492) saw in every iteration: [0,6) the eigenvalues of
+                                   HTWH_i ascending (NaN when the Cholesky route proved the matrix well conditioned and never computed them),
+                                   [6] the number of pruned axes (rows dropped from L2), [7] the route: 0 Cholesky, 2 the literal restatement */
 } icet_aux;
 
 typedef struct icet_ctx icet_ctx;   /* opaque: device id, stream, workspace */
@@ -202,6 +205,12 @@ icet_status icet_last_timing(icet_ctx* ctx, float out_ms[4]);
  * from the start of the batch's concatenated scan-1 arrays (pairs for what = 4). */
 icet_status icet_debug_fetch(icet_ctx* ctx, int32_t what, void* out, int64_t count);
 
+/* Diagnostic hook for the parity tests: the 6x6 tail of one Gauss-Newton iteration (noise_mat = pinv(HTWH), pred_stds, checkCondition, dx:
+ * src/icet.cpp:410-433) evaluated on the device for n host-side matrices, through the same device function the solve kernel runs.
+ * htwh: n x 36 row-major, htwdz: n x 6; out: n x 56 = cov[36] | pred_stds[6] | dx[6] | eigenvalues[6] (NaN on the Cholesky route) |
+ * pruned axes | route (0 Cholesky inverse, 2 literal restatement; option "gn_cond_bound"). */
+icet_status icet_debug_gn_tail(icet_ctx* ctx, const float* htwh, const float* htwdz, int32_t n, float* out);
+
 /* Launch-shape and diagnostic knobs of ONE context (the library never reads the environment).  Defaults are the measured
  * optima.  Launch-shape knobs yield the same result bits; "force_exact", "guard_scale" and "lut_polar_quantile" preserve every
  * DECISION (the per-voxel counts n2_raw / n2_in) but move points between the 4-point runs and the runs of one, i.e. they regroup
@@ -214,7 +223,10 @@ icet_status icet_debug_fetch(icet_ctx* ctx, int32_t what, void* out, int64_t cou
  * "exec_bits_lds" (0: swap-loop bit table read from memory), "exec_pairwise" (which kernel computes the swap loop's executed-step bits:
  * 1 one block per pair from the recurrence, 0 chain walks over independent tiles, -1 by batch size), "batch_parts" (0 = automatic), "batch_stage" (0..4), "force_exact"
  * (every scan-2 point through the literal classification), "library_sort" (rocPRIM radix sort instead of
- * the hand-written rank sort), "guard_scale" (>= 1), "lut_polar_quantile" (0..1).  Unknown name or value
+ * the hand-written rank sort), "guard_scale" (>= 1), "lut_polar_quantile" (0..1), "gn_cond_bound" (0 .. 1e6, default 2.5e5 -- a factor 4 below checkCondition's cutoff, because a float Cholesky inverse knows its own norm to a few per cent only at such condition numbers: an H^T W H whose Frobenius bound on
+ * the condition number |A|_F |A^-1|_F exceeds it is inverted by the literal restatement of the reference's statements -- column-pivoted QR
+ * pseudo-inverse, eigenvectors, pruning -- instead of a Cholesky factorisation; 0 = always literal.  Not a launch-shape knob: between the two
+ * routes cov / dx differ by rounding times the condition number).  Unknown name or value
  * out of range: ICET_ERR_BAD_ARG. */
 icet_status icet_set_option(icet_ctx* ctx, const char* name, double value);
 

@@ -254,6 +254,44 @@ static void sortAndScramble(Sph& s, bool true_sort = false, std::vector<float>* 
     }
 }
 
+// ---------------------------------------------------------------- icet.cpp:443-492
+// checkCondition: eigen-decomposition of H^T W H (ascending), then while |lambda_5 / lambda_k| > 1e6: pred_stds += U2.col(k) (Q12),
+// drop the top row of L2.  (The reference's loop has no upper bound on eyecount -- with six axes pruned it would read eigenvalues(6);
+// bounded here.)  Returns the number of pruned axes.
+static int check_condition(const Mat& HTWH, bool libmf, float pred_stds[6], Mat& L2, Mat& lam, Mat& U2, float ev[6]) {
+    const float cutoff = 1e6f;
+    selfadjoint_eigen(HTWH, /*fixed3=*/false, ev, U2, libmf);
+    float condition = ev[5] / ev[0];
+    int keep_from = 0;
+    int eyecount = 1;
+    while (std::abs(condition) > cutoff && eyecount < 6) {
+        for (int k = 0; k < 6; k++) pred_stds[k] += U2(k, eyecount - 1);     // icet.cpp:479 (Q12)
+        keep_from++;
+        condition = ev[5] / ev[eyecount];
+        eyecount++;
+    }
+    L2 = Mat(6 - keep_from, 6);
+    for (int i = 0; i < 6 - keep_from; i++) L2(i, keep_from + i) = 1.f;
+    lam = Mat(6, 6); for (int i = 0; i < 6; i++) lam(i, i) = ev[i];
+    return keep_from;
+}
+
+// The 6x6 tail of fitScan2, icet.cpp:410-430: noise_mat = pinv(HTWH), pred_stds = sqrt|diag|, checkCondition, dx = pinv(L2 lam U2^T) L2 U2^T HTWdz.
+// A function of (HTWH, HTWdz) alone, so that the device's restatement of it can be compared bit for bit on the same inputs
+// (icet_oracle_gn_tail / icet_debug_gn_tail, tests/test_gpu_parity.py).
+static void gn_tail(const Mat& HTWH, const Mat& HTWdz, bool libmf, Mat& noise_mat, float pred_stds[6], Mat& d, float ev[6], int* pruned, int* rank) {
+    noise_mat = cod_pinv(HTWH, rank);                                         // icet.cpp:410-411
+    for (int k = 0; k < 6; k++) pred_stds[k] = std::sqrt(std::abs(noise_mat(k, k)));
+    Mat L2, lam, U2;
+    const int k0 = check_condition(HTWH, libmf, pred_stds, L2, lam, U2, ev);
+    if (pruned) *pruned = k0;
+    Mat U2t = transpose(U2);
+    Mat innards = matmul(matmul(L2, lam), U2t);                               // icet.cpp:427
+    Mat inv = cod_pinv(innards);
+    Mat lhs = matmul(matmul(inv, L2), U2t);
+    d = matmul(lhs, HTWdz);                                                   // icet.cpp:430
+}
+
 struct Solver {
     icet_oracle_params prm;
     int T, P, V, n;
@@ -482,26 +520,7 @@ struct Solver {
         }
     }
 
-    // icet.cpp:443-492
-    void checkCondition(const Mat& HTWH, Mat& L2, Mat& lam, Mat& U2) {
-        const float cutoff = 1e6f;
-        float ev[6];
-        selfadjoint_eigen(HTWH, /*fixed3=*/false, ev, U2, libmf);
-        float condition = ev[5] / ev[0];
-        int keep_from = 0;
-        int eyecount = 1;
-        while (std::abs(condition) > cutoff && eyecount < 6) {
-            for (int k = 0; k < 6; k++) pred_stds[k] += U2(k, eyecount - 1);     // icet.cpp:479 (Q12)
-            keep_from++;
-            condition = ev[5] / ev[eyecount];
-            eyecount++;
-        }
-        L2 = Mat(6 - keep_from, 6);
-        for (int i = 0; i < 6 - keep_from; i++) L2(i, keep_from + i) = 1.f;
-        lam = Mat(6, 6); for (int i = 0; i < 6; i++) lam(i, i) = ev[i];
-        if (tr && iter_no < tr->max_iters) { for (int i = 0; i < 6; i++) tr->eigvals[iter_no * 6 + i] = ev[i]; tr->pruned[iter_no] = keep_from; }
-    }
-
+    // icet.cpp:443-492: now the free function ico::check_condition (below the class it is used through gn_tail)
     // icet.cpp:372-436
     void fitScan2() {
         const int N = (int)ogx.size();
@@ -539,15 +558,9 @@ struct Solver {
                     record(T * phi + theta, c);
                 }
         }
-        noise_mat = cod_pinv(HTWH_i);                                             // icet.cpp:410-411
-        for (int k = 0; k < 6; k++) pred_stds[k] = std::sqrt(std::abs(noise_mat(k, k)));
-        Mat L2, lam, U2;
-        checkCondition(HTWH_i, L2, lam, U2);
-        Mat U2t = transpose(U2);
-        Mat innards = matmul(matmul(L2, lam), U2t);                               // icet.cpp:427
-        Mat inv = cod_pinv(innards);
-        Mat lhs = matmul(matmul(inv, L2), U2t);
-        Mat d = matmul(lhs, HTWdz_i);                                             // icet.cpp:430
+        Mat d; float ev[6]; int pruned = 0;
+        gn_tail(HTWH_i, HTWdz_i, libmf, noise_mat, pred_stds, d, ev, &pruned, nullptr);       // icet.cpp:410-430
+        if (tr && iter_no < tr->max_iters) { for (int i = 0; i < 6; i++) tr->eigvals[iter_no * 6 + i] = ev[i]; tr->pruned[iter_no] = pruned; }
         if (tr && iter_no < tr->max_iters) {
             for (int a = 0; a < 36; a++) tr->HTWH[iter_no * 36 + a] = HTWH_i.a[a];
             for (int a = 0; a < 6; a++) { tr->HTWdz[iter_no * 6 + a] = HTWdz_i.a[a]; tr->dx[iter_no * 6 + a] = d(a, 0); }
@@ -672,6 +685,16 @@ void icet_oracle_scramble(const float* r, int64_t n, int32_t* src) {
     for (int64_t i = 0; i < n; i++) {
         if (index[i] != i) { int j = index[i]; std::swap(src[i], src[j]); std::swap(index[i], index[j]); }
     }
+}
+// The 6x6 tail of one Gauss-Newton iteration on its own (icet.cpp:410-430): out = cov[36] | pred_stds[6] | dx[6] | eigenvalues[6]; returns pruned axes, *rank = COD rank of HTWH.
+int icet_oracle_gn_tail(const float* HTWH, const float* HTWdz, int libmf, float* out54, int32_t* rank) {
+    ico::Mat H(6, 6), g(6, 1), cov, d; for (int i = 0; i < 36; i++) H.a[i] = HTWH[i]; for (int i = 0; i < 6; i++) g.a[i] = HTWdz[i];
+    float ps[6], ev[6]; int pruned = 0, rk = 0;
+    ico::gn_tail(H, g, libmf != 0, cov, ps, d, ev, &pruned, &rk);
+    for (int i = 0; i < 36; i++) out54[i] = cov.a[i];
+    for (int i = 0; i < 6; i++) { out54[36 + i] = ps[i]; out54[42 + i] = d.a[i]; out54[48 + i] = ev[i]; }
+    if (rank) *rank = rk;
+    return pruned;
 }
 void icet_oracle_get_H(const float mu[3], const float angs[3], float* H18) {
     ico::Mat H = ico::get_H(mu, angs); for (int i = 0; i < 18; i++) H18[i] = H.a[i];

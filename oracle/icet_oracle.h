@@ -83,6 +83,7 @@ void icet_oracle_eig_sym(const float* A, int n, int fixed3, float* evals, float*
 int  icet_oracle_pinv(const float* A, int rows, int cols, float* out);
 void icet_oracle_c2s(const float* xyz, int64_t n, int64_t ld, float* out);
 void icet_oracle_scramble(const float* r, int64_t n, int32_t* src);
+int  icet_oracle_gn_tail(const float* HTWH, const float* HTWdz, int libmf, float* out54, int32_t* rank);   /* icet.cpp:410-430 on its own: cov[36] | pred_stds[6] | dx[6] | eigenvalues[6]; returns pruned axes */
 void icet_oracle_get_H(const float mu[3], const float angs[3], float* H18);
 void icet_oracle_R(const float angs[3], float* R9);
 

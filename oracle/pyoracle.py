@@ -59,6 +59,8 @@ def lib():
         L.icet_oracle_eig_sym.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.icet_oracle_pinv.restype = C.c_int
         L.icet_oracle_pinv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.icet_oracle_gn_tail.restype = C.c_int
+        L.icet_oracle_gn_tail.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int32)]
         L.icet_oracle_c2s.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.icet_oracle_scramble.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.icet_oracle_get_H.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -167,6 +169,14 @@ def pinv(A):
     out = np.zeros((c, r), np.float32)
     rank = lib().icet_oracle_pinv(A.ctypes.data, r, c, out.ctypes.data)
     return out, rank
+
+
+def gn_tail(HTWH, HTWdz, libmf=False):
+    """The 6x6 tail of one Gauss-Newton iteration (src/icet.cpp:410-430) on its own: dict(cov, pred_stds, dx, eigvals, pruned, rank)."""
+    H = np.ascontiguousarray(HTWH, np.float32).reshape(36); g = np.ascontiguousarray(HTWdz, np.float32).reshape(6)
+    out = np.zeros(54, np.float32); rank = C.c_int32(0)
+    pruned = lib().icet_oracle_gn_tail(H.ctypes.data, g.ctypes.data, int(libmf), out.ctypes.data, C.byref(rank))
+    return dict(cov=out[:36].reshape(6, 6).copy(), pred_stds=out[36:42].copy(), dx=out[42:48].copy(), eigvals=out[48:54].copy(), pruned=int(pruned), rank=int(rank.value))
 
 
 def c2s(scan):

@@ -47,5 +47,29 @@ def main():
         print(name, "X =", o["X"], "fits =", int(t["has_fit"].sum()), "ub =", o["n_ub_voxels"], "|X - X_libmf| =", np.abs(o["X"] - lm["X"]).max())
 
 
+def degenerate():
+    """golden_degenerate.npz: the oracle on the seeded degenerate scenes of icet_amd/lidar_sim.py (tunnel, single wall, open ground: the inputs
+    ICET::checkCondition, src/icet.cpp:443-492, exists for).  The scans are regenerated from their seeds by the tests (torch CPU generator; float64
+    checksums of both scans are stored so that a drifting generator is noticed); stored per scene: X, pred_stds, cov, per-iteration X / HTWH /
+    HTWdz / dx / eigenvalues / pruned-axis count."""
+    from icet_amd import lidar_sim as ls
+    out = {}
+    for name in ls.DEGENERATE_SCENES:
+        a, b, _ = ls.make_degenerate_named(name)
+        a = np.ascontiguousarray(a.T.numpy()); b = np.ascontiguousarray(b.T.numpy())
+        o = po.solve(a, b, trace=True, runlen=7, bins_phi=24, bins_theta=75)
+        t = o["trace"]
+        for k, v in (("X", o["X"]), ("pred_stds", o["pred_stds"]), ("cov", o["cov"]), ("X_hist", t["X"]), ("HTWH", t["HTWH"]), ("HTWdz", t["HTWdz"]), ("dx", t["dx"]),
+                     ("eigvals", t["eigvals"]), ("pruned", t["pruned"]), ("has_fit_count", np.int32(t["has_fit"].sum())),
+                     ("checksum", np.array([a.shape[0], b.shape[0], a.astype(np.float64).sum(), b.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum(), np.abs(b.astype(np.float64)).sum()]))):
+            out[name + "/" + k] = v
+        print(name, "pruned", t["pruned"], "pred_stds", o["pred_stds"], "cond", t["eigvals"][-1, 5] / t["eigvals"][-1, 0])
+    np.savez_compressed(os.path.join(HERE, "golden_degenerate.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "degenerate":
+        degenerate()
+    else:
+        main()
+        degenerate()

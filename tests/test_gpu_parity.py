@@ -1171,3 +1171,222 @@ def test_half_gap_bounds_extension_matches_its_oracle_twin(gpu_ctx, frames, samp
         assert np.array_equal(bh[:, 5] > 0, has)
         assert (bh[has, 4] >= bs[has, 4]).all() and (bh[has, 5] <= bs[has, 5]).all()
         assert (bh[has, 4] > bs[has, 4]).any() or (bh[has, 5] < bs[has, 5]).any()
+
+
+# ---- ICET::checkCondition's ill-conditioned route (src/icet.cpp:410-430, 443-492): review r4, row a15 -----------------------------------
+
+def _cond_sweep_matrices():
+    """(HTWH, HTWdz) pairs whose condition number crosses checkCondition's cutoff: the oracle's per-iteration matrices of the degenerate
+    golden scenes, rescaled along their weakest eigenvector so that cond sweeps [3e5, 3e7] (where pruning starts, and where the rank
+    threshold of the pseudo-inverse, 1 / (6 eps) = 1.4e6, sits), plus rank-deficient, zero, NaN and well-conditioned ones."""
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_degenerate.npz")))
+    names = sorted({k.split("/")[0] for k in g})
+    Hs, gs = [], []
+    conds = np.geomspace(3e5, 3e7, 120)
+    for nm in names:
+        for it in (0, 3, 6):
+            H = g[nm + "/HTWH"][it].astype(np.float64); gv = g[nm + "/HTWdz"][it]
+            Hs.append(H.astype(np.float32)); gs.append(gv)
+            w, Q = np.linalg.eigh(H)
+            for c in conds:
+                w2 = w.copy(); w2[0] = w[5] / c
+                H2 = ((Q * w2) @ Q.T).astype(np.float32)
+                Hs.append((H2 + H2.T) / 2); gs.append(gv)
+            for drop in (1, 2, 3, 5):                                   # exactly rank-deficient
+                w2 = w.copy(); w2[:drop] = 0.0
+                H2 = ((Q * w2) @ Q.T).astype(np.float32)
+                Hs.append((H2 + H2.T) / 2); gs.append(gv)
+    rng = np.random.default_rng(5)
+    for _ in range(64):                                                 # well conditioned
+        A = rng.standard_normal((6, 12)); Hs.append((A @ A.T).astype(np.float32)); gs.append(rng.standard_normal(6).astype(np.float32))
+    Hs.append(np.zeros((6, 6), np.float32)); gs.append(np.zeros(6, np.float32))                  # no voxel matched: HTWH = 0 (cond = NaN: no pruning)
+    Hs.append(np.zeros((6, 6), np.float32)); gs.append(np.ones(6, np.float32))
+    Hn = np.eye(6, dtype=np.float32); Hn[2, 2] = np.nan; Hs.append(Hn); gs.append(np.ones(6, np.float32))
+    Hs.append(np.full((6, 6), np.nan, np.float32)); gs.append(np.ones(6, np.float32))
+    Hs.append(np.diag([1, 1, 1, 1, 1, -1e-3]).astype(np.float32)); gs.append(np.ones(6, np.float32))    # indefinite
+    return np.stack(Hs), np.stack(gs)
+
+
+def _same_bits(a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def test_gn_tail_literal_bits(gpu_ctx):
+    """The device's restatement of src/icet.cpp:410-430 (pinv by column-pivoted QR, pred_stds, checkCondition's pruning with
+    `pred_stds += U2.col(k)`, dx through the pseudo-inverse of L2 lam U2^T) against the oracle's, on the SAME matrices: every output BIT FOR
+    BIT -- rank decision, pruned-axis count and eigenvector signs included -- over condition numbers 3e5 .. 3e7, rank-deficient, zero and NaN
+    input.  (The rule of rounds 2-4, |lambda_k| > 6 eps lambda_max, disagrees with the pivot rule on ~0.4 % of such matrices:
+    scripts/rank_rule_study.py.)  Then the default routing: a matrix sent down the Cholesky route is one the oracle does not prune, and its
+    inverse agrees to rounding x condition number."""
+    import icet_amd
+    from oracle import pyoracle as po
+    H, g = _cond_sweep_matrices()
+    ctx = icet_amd.Context(0)
+    ctx.set_option("gn_cond_bound", 0)                                  # everything through the literal route
+    dev = ctx.debug_gn_tail(H, g)
+    n_pruned = np.zeros(7, int); n_def = 0
+    for i in range(H.shape[0]):
+        ref = po.gn_tail(H[i], g[i])
+        assert dev["route"][i] == 2
+        assert dev["pruned"][i] == ref["pruned"], (i, dev["pruned"][i], ref["pruned"])
+        for k in ("cov", "pred_stds", "dx", "eigvals"):
+            assert _same_bits(dev[k][i], ref[k]), (i, k, dev[k][i], ref[k])
+        n_pruned[ref["pruned"]] += 1; n_def += ref["rank"] < 6
+    print("gn_tail literal route: %d matrices bit-identical to the oracle; pruned-axis histogram %s; %d rank-deficient by the pivot rule" % (H.shape[0], n_pruned.tolist(), n_def))
+    assert n_pruned[1] > 100 and n_pruned[2] > 10 and n_pruned[3] > 10 and n_def > 100      # the sweep does exercise what it claims to
+    ctx.set_option("gn_cond_bound", 2.5e5)                              # the default routing (a factor 4 below the cutoff)
+    dflt = ctx.debug_gn_tail(H, g)
+    n_chol = 0
+    for i in range(H.shape[0]):
+        ref = po.gn_tail(H[i], g[i])
+        if dflt["route"][i] == 0:
+            n_chol += 1
+            assert ref["pruned"] == 0 and ref["rank"] == 6 and dflt["pruned"][i] == 0
+            cond = ref["eigvals"][5] / ref["eigvals"][0]
+            d = np.sqrt(np.abs(np.diag(ref["cov"])))
+            assert (np.abs(dflt["cov"][i] - ref["cov"]) <= 64 * cond * 6e-8 * np.outer(d, d)).all(), (i, cond)
+        else:
+            for k in ("cov", "pred_stds", "dx", "eigvals"):
+                assert _same_bits(dflt[k][i], ref[k]), (i, k)
+    assert n_chol >= 64
+    ctx.close()
+
+
+def _degenerate_golden():
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_degenerate.npz")))
+    return {nm: {k.split("/")[1]: v for k, v in g.items() if k.startswith(nm + "/")} for nm in sorted({k.split("/")[0] for k in g})}
+
+
+def _degenerate_scans(name):
+    from icet_amd import lidar_sim as ls
+    a, b, _ = ls.make_degenerate_named(name)
+    return np.ascontiguousarray(a.T.numpy()), np.ascontiguousarray(b.T.numpy())
+
+
+def _oracle_spread(a, b, ref, trials=3):
+    """How far the ORACLE's own per-iteration tables move under a 1-ulp perturbation of scan 2 (relative 1e-7): on scenes with millimetre noise the
+    thin direction of a voxel's covariance is a few float ulps of the coordinates wide, H^T W H moves by per cents and the SIGN of the pruned
+    eigenvector -- hence of the +-1 added to pred_stds -- can flip (measured, profiles/r05_diag_degenerate.txt)."""
+    from oracle import pyoracle as po
+    t = ref["trace"]
+    rng = np.random.default_rng(123)
+    sp = dict(H=0.0, ps=0.0, Xt=0.0, Xr=0.0, pruned_same=True)
+    for _ in range(trials):
+        bp = (b.astype(np.float64) * (1.0 + rng.uniform(-1e-7, 1e-7, b.shape))).astype(np.float32)
+        o2 = po.solve(a, bp, trace=True); t2 = o2["trace"]
+        sp["H"] = max(sp["H"], float((np.abs(t2["HTWH"] - t["HTWH"]).reshape(7, -1).max(1) / np.abs(t["HTWH"]).reshape(7, -1).max(1)).max()))
+        sp["ps"] = max(sp["ps"], float(np.abs(o2["pred_stds"] - ref["pred_stds"]).max()))
+        sp["Xt"] = max(sp["Xt"], float(np.abs(o2["X"][:3] - ref["X"][:3]).max())); sp["Xr"] = max(sp["Xr"], float(np.abs(o2["X"][3:] - ref["X"][3:]).max()))
+        sp["pruned_same"] = sp["pruned_same"] and bool(np.array_equal(t2["pruned"], t["pruned"]))
+    return sp
+
+
+@pytest.mark.parametrize("name", ["tunnel_s05", "tunnel_s10", "tunnel_s10_m", "wall_s10", "wall_s30", "ground_s02", "ground_s05", "ground_s10_m"])
+def test_degenerate_scenes_take_the_pruning_route(gpu_ctx, name):
+    """Tunnel / single wall / open ground (icet_amd/lidar_sim.DEGENERATE_SCENES): HTWH has condition numbers of 1e6 .. 1e9, the reference
+    prunes one to three solution axes and ADDS THE PRUNED EIGENVECTOR to pred_stds (src/icet.cpp:479) -- pred_stds[0] = +1.0 in
+    tunnel_s05, -1.0 in tunnel_s10.  Two layers:
+    (1) EXACT: inside the real solve, every iteration's 6x6 tail is the oracle's function of the device's own (HTWH_i, HTWdz_i): the pruned-axis
+        count, the eigenvalues checkCondition saw, X_i = X_{i-1} + dx and the final pred_stds / covariance are the oracle's gn_tail of the
+        device's tables BIT FOR BIT -- sign of the pruned eigenvector included.
+    (2) against the oracle's solve of the same scans, where the two sides' HTWH differ by the usual last bits of the per-voxel moments:
+        the keyframe table bit-exact; X within the usual bounds or 1x the oracle's own 1-ulp sensitivity; where the oracle's answer is itself
+        stable under a 1-ulp perturbation of scan 2 (its pruned counts do not change / its pred_stds move by < 1e-3), the device prunes the same
+        axes in every iteration and pred_stds agree INCLUDING SIGN to 1e-3 absolute; on the others (millimetre-noise scenes at the resolution of
+        float32 coordinates: the oracle flips the sign of its own +-1.0 under that perturbation) the difference is held to the oracle's spread."""
+    from oracle import pyoracle as po
+    a, b = _degenerate_scans(name)
+    gold = _degenerate_golden()[name]
+    assert gold["checksum"][0] == a.shape[0] and gold["checksum"][1] == b.shape[0] and np.isclose(gold["checksum"][4], np.abs(a.astype(np.float64)).sum(), rtol=1e-12), "scene generator drifted"
+    ref = po.solve(a, b, trace=True)
+    t = ref["trace"]
+    assert np.array_equal(t["pruned"], gold["pruned"]) and np.allclose(ref["pred_stds"], gold["pred_stds"], rtol=1e-4, atol=1e-6)
+    r = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
+    ax = r["aux"]
+    assert np.array_equal(ax["cluster_bounds"], t["bounds"]) and np.array_equal(ax["has_fit"], t["has_fit"])
+    f = t["has_fit"] == 1
+    assert np.array_equal(ax["evecs1"][f].view(np.uint32), t["evecs1"][f].view(np.uint32))
+    ci = ax["cond_info"]
+    # (1) the tail inside the solve kernel == the oracle's tail of the device's own tables, bit for bit
+    xprev = np.zeros(6, np.float32)
+    for it in range(7):
+        tail = po.gn_tail(ax["htwh"][it], ax["htwdz"][it])
+        assert int(ci[it, 7]) == 2, "a degenerate scene must leave the Cholesky route"
+        assert int(ci[it, 6]) == tail["pruned"], (it, ci[it], tail["pruned"])
+        assert _same_bits(ci[it, :6], tail["eigvals"]), (it, ci[it, :6], tail["eigvals"])
+        assert _same_bits(ax["x_hist"][it], (xprev + tail["dx"]).astype(np.float32)), (it, ax["x_hist"][it], xprev + tail["dx"])
+        xprev = ax["x_hist"][it]
+    assert _same_bits(r["pred_stds"], tail["pred_stds"]) and _same_bits(r["cov"], tail["cov"]), (r["pred_stds"], tail["pred_stds"])
+    # (2) against the oracle's own solve
+    sp = _oracle_spread(a, b, ref)
+    dH = float((np.abs(ax["htwh"] - t["HTWH"]).reshape(7, -1).max(1) / np.abs(t["HTWH"]).reshape(7, -1).max(1)).max())
+    dps = float(np.abs(r["pred_stds"] - ref["pred_stds"]).max())
+    dt, dr = float(np.abs(r["X"][:3] - ref["X"][:3]).max()), float(np.abs(r["X"][3:] - ref["X"][3:]).max())
+    print("%s: pruned oracle %s device %s | pred_stds oracle %s device %s | dH %.2e (oracle 1-ulp spread %.2e) d pred_stds %.2e (%.2e) |dX| %.2e m %.2e rad (%.2e / %.2e) oracle pruning stable: %s"
+          % (name, t["pruned"].tolist(), ci[:, 6].astype(int).tolist(), np.round(ref["pred_stds"], 4).tolist(), np.round(r["pred_stds"], 4).tolist(), dH, sp["H"], dps, sp["ps"], dt, dr, sp["Xt"], sp["Xr"], sp["pruned_same"]))
+    assert dH <= max(2e-3, 5 * sp["H"]), (dH, sp["H"])
+    cond_o = np.abs(t["eigvals"][:, 5] / t["eigvals"][:, 0])
+    straddles = bool(((cond_o > 1e6 / 1.5) & (cond_o < 1.5e6)).any())      # a condition number within the tables' own spread of the cutoff: pruning there is a coin toss on either side
+    if straddles and not np.array_equal(ci[:, 6].astype(int), t["pruned"]):
+        # (ground_s10_m: cond 1.1e6.)  The two sides pruned the weakest axis in different iterations: what can be compared is X off that axis
+        assert np.abs(ci[:, 6].astype(int) - t["pruned"]).max() <= 1
+        w, Q = po.eig_sym(t["HTWH"][-1])
+        dX = (r["X"] - ref["X"]).astype(np.float64)
+        dX_kept = dX - Q[:, 0].astype(np.float64) * (Q[:, 0].astype(np.float64) @ dX)
+        assert np.abs(dX_kept[:3]).max() <= max(TOL_T, sp["Xt"]) and np.abs(dX_kept[3:]).max() <= max(TOL_R, sp["Xr"]), (dX, dX_kept)
+        print("   %s straddles the cutoff (oracle cond %s): pruning differs by iteration; |dX| off the weakest axis %.2e m %.2e rad" % (name, np.round(cond_o).tolist(), np.abs(dX_kept[:3]).max(), np.abs(dX_kept[3:]).max()))
+        return
+    assert dt <= max(TOL_T, sp["Xt"]) and dr <= max(TOL_R, sp["Xr"]), (dt, dr, sp)
+    if sp["pruned_same"]:
+        assert np.array_equal(ci[:, 6].astype(int), t["pruned"]), (ci[:, 6], t["pruned"])
+    else:
+        assert np.abs(ci[:, 6].astype(int) - t["pruned"]).max() <= 1
+    if sp["ps"] < 1e-3:
+        assert dps <= 1e-3, (r["pred_stds"], ref["pred_stds"])            # signs included: negative entries are the reference's behaviour
+    else:
+        assert dps <= 1.5 * sp["ps"] + 1e-3, (dps, sp["ps"])
+    assert name not in ("tunnel_s10", "tunnel_s10_m", "wall_s30") or sp["ps"] < 1e-3          # these three are the stable ones: the tight branch must be the one that ran
+
+
+def test_degenerate_pairs_inside_a_batch_leave_their_neighbours_alone(gpu_ctx):
+    """The same scenes through ONE icet_solve_batch_device call between well-conditioned pairs: a block that takes the literal route must
+    not disturb its neighbours' bits, and must give its own single-solve bits."""
+    import icet_amd
+    from icet_amd import lidar_sim as ls, api
+    dev = torch.device("cuda", 0)
+    names = ["tunnel_s05", "ground_s02", "wall_s10", "ground_s10_m"]
+    pairs = []
+    for k in range(4):
+        pairs.append(ls.make_batch_pair(k, device=dev)[:2])
+        a, b = _degenerate_scans(names[k])
+        pairs.append((torch.from_numpy(np.ascontiguousarray(a.T)).to(dev), torch.from_numpy(np.ascontiguousarray(b.T)).to(dev)))
+    pairs.append(ls.make_batch_pair(4, device=dev)[:2])
+    d1 = [(p[0].data_ptr(), p[0].shape[1], p[0].shape[1]) for p in pairs]; d2 = [(p[1].data_ptr(), p[1].shape[1], p[1].shape[1]) for p in pairs]
+    out = torch.zeros((len(pairs), 48), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx = icet_amd.Context(0)
+    ctx.solve_batch_device(d1, d2, api.Params(7, 24, 75, 25, 0.1, 0.1, 0), out.data_ptr()); ctx.sync()
+    res = out.cpu().numpy()
+    ctx.close()
+    n_literal = 0
+    for k, p in enumerate(pairs):
+        single = gpu_ctx.solve(p[0].T.cpu().numpy(), p[1].T.cpu().numpy(), 7, np.zeros(6), 24, 75, aux=True)
+        assert np.array_equal(res[k, :6], single["X"]) and np.array_equal(res[k, 6:12], single["pred_stds"]) and np.array_equal(res[k, 12:], single["cov"].reshape(36)), k
+        n_literal += int((single["aux"]["cond_info"][:, 7] == 2).any())
+        assert (single["aux"]["cond_info"][:, 7] == 2).any() == (k % 2 == 1), k
+    assert n_literal == 4
+
+
+def test_no_matching_voxel_gives_zero_update(gpu_ctx, frames):
+    """HTWH = 0 (scan 2 far away from every scan-1 voxel): cond = 0/0 = NaN, so nothing is pruned (src/icet.cpp:469 compares false), the
+    pseudo-inverse of the zero matrix is zero: X stays X0, pred_stds = 0 -- on the device as in the oracle."""
+    from oracle import pyoracle as po
+    a, _ = frames
+    b = (a + np.array([500.0, 0, 300.0], np.float32)).astype(np.float32)
+    x0 = np.array([0.1, 0, 0, 0, 0, 0.01], np.float32)
+    ref = po.solve(a, b, x0=x0, trace=True)
+    r = gpu_ctx.solve(a, b, 7, x0, 24, 75, aux=True)
+    assert (ref["trace"]["HTWH"] == 0).all() and (r["aux"]["htwh"] == 0).all()
+    assert np.array_equal(r["X"], ref["X"]) and np.array_equal(r["X"], x0) and (r["pred_stds"] == 0).all() and (ref["pred_stds"] == 0).all()
+    assert (r["aux"]["cond_info"][:, 6] == 0).all() and (r["aux"]["cond_info"][:, 7] == 2).all()

@@ -1,11 +1,14 @@
 """CPU tests (-m "not gpu"): the oracle against its committed golden vectors, against the independent NumPy
 model, and its restated Eigen decompositions against numpy.linalg.  The reference ships no tests for this
 path, so these are the pins that exist."""
+import os
 import numpy as np
 import pytest
 
 from oracle import pyoracle as po
 from oracle import icet_numpy as inp
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 # ------------------------------------------------------------------ golden vectors
@@ -344,3 +347,39 @@ def test_half_gap_bounds_extension_of_the_oracle(frames):
         assert bounds[v, 4] == np.float32(exp[0]) and bounds[v, 5] == np.float32(exp[1]), (v, bounds[v], exp)
         checked += exp[1] > 0
     assert checked > 50
+
+
+@pytest.mark.parametrize("name", ["tunnel_s05", "tunnel_s10", "wall_s30", "ground_s02", "ground_s10_m"])
+def test_oracle_reproduces_degenerate_golden(name):
+    """tests/golden/golden_degenerate.npz: tunnel / wall / ground scenes on which checkCondition (src/icet.cpp:443-492) prunes 0..3 axes and adds
+    the pruned eigenvectors -- sign included -- to pred_stds.  The scans come from their seeds; the stored checksums notice a drifting generator."""
+    from icet_amd import lidar_sim as ls
+    g = dict(np.load(os.path.join(GOLDEN, "golden_degenerate.npz")))
+    a, b, _ = ls.make_degenerate_named(name)
+    a = np.ascontiguousarray(a.T.numpy()); b = np.ascontiguousarray(b.T.numpy())
+    cs = g[name + "/checksum"]
+    assert cs[0] == a.shape[0] and cs[1] == b.shape[0]
+    assert np.isclose(cs[2], a.astype(np.float64).sum(), rtol=0, atol=1e-6 * cs[4]) and np.isclose(cs[5], np.abs(b.astype(np.float64)).sum(), rtol=1e-12)
+    o = po.solve(a, b, trace=True)
+    t = o["trace"]
+    assert np.array_equal(t["pruned"], g[name + "/pruned"])
+    assert np.allclose(o["pred_stds"], g[name + "/pred_stds"], rtol=1e-4, atol=1e-6)           # signs included
+    assert np.allclose(o["X"], g[name + "/X"], rtol=0, atol=2e-6)
+    assert np.allclose(t["eigvals"], g[name + "/eigvals"], rtol=1e-4, atol=1e-6 * np.abs(g[name + "/eigvals"]).max())
+    # the exported 6x6 tail is the function the solver runs: same dx, eigenvalues and pruned count from the traced (HTWH, HTWdz)
+    for it in range(7):
+        tail = po.gn_tail(t["HTWH"][it], t["HTWdz"][it])
+        assert tail["pruned"] == t["pruned"][it] and np.array_equal(tail["dx"], t["dx"][it]) and np.array_equal(tail["eigvals"], t["eigvals"][it])
+    last = po.gn_tail(t["HTWH"][6], t["HTWdz"][6])
+    assert np.array_equal(last["pred_stds"], o["pred_stds"]) and np.array_equal(last["cov"], o["cov"])
+
+
+def test_pruned_axis_is_removed_from_the_update():
+    """checkCondition's effect on dx (src/icet.cpp:427-430): the component of the update along a pruned eigenvector is zero."""
+    g = dict(np.load(os.path.join(GOLDEN, "golden_degenerate.npz")))
+    H, gv = g["tunnel_s10_m/HTWH"][0], g["tunnel_s10_m/HTWdz"][0]
+    tail = po.gn_tail(H, gv)
+    w, Q = po.eig_sym(H)
+    assert tail["pruned"] == 1 and abs(Q[:, 0] @ tail["dx"]) < 1e-6 * np.linalg.norm(tail["dx"]) + 1e-9
+    full = np.linalg.solve(H.astype(np.float64), gv.astype(np.float64))
+    assert abs(Q[:, 0].astype(np.float64) @ full) > 10 * abs(Q[:, 0] @ tail["dx"])               # the unpruned solve would have moved along it

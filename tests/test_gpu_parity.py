@@ -743,14 +743,18 @@ def test_many_pairs_parity_natural_signs(gpu_ctx):
     batch = out.cpu().numpy()
     bctx.close()
     dts, drs, worst, outside = np.zeros(N), np.zeros(N), np.zeros(4), []
+    d_lit, d_modes = np.zeros((N, 6)), np.zeros((N, 6))
     with ThreadPoolExecutor(min(os.cpu_count() or 1, 16)) as ex:
         for k0 in range(0, N, 32):                                  # 32 pairs at a time: the oracle runs on the host cores while the device solves
             ks = list(range(k0, min(k0 + 32, N)))
             host = [(pairs[k][0].T.cpu().numpy(), pairs[k][1].T.cpu().numpy()) for k in ks]
             futs = [ex.submit(po.solve, a, b, trace=True) for a, b in host]
+            futs_lit = [ex.submit(po.solve, a, b, mode=po.LIBMF) for a, b in host]      # the oracle with the reference's literal expression types (reported, not bounded: below)
             gpus = [gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True) for a, b in host]
-            for k, (a, b), g, fu in zip(ks, host, gpus, futs):
+            for k, (a, b), g, fu, ful in zip(ks, host, gpus, futs, futs_lit):
                 ref = fu.result()
+                lit = ful.result()
+                d_lit[k] = np.abs(batch[k, :6] - lit["X"]); d_modes[k] = np.abs(ref["X"] - lit["X"])
                 t, ax = ref["trace"], g["aux"]
                 f = t["has_fit"] == 1
                 assert np.array_equal(ax["n1_raw"], t["n1_raw"]) and np.array_equal(ax["cluster_bounds"], t["bounds"]) and np.array_equal(ax["has_fit"], t["has_fit"]), k
@@ -776,6 +780,23 @@ def test_many_pairs_parity_natural_signs(gpu_ctx):
     print("%d pairs through one icet_solve_batch_device call, natural signs: outside 2e-4 m / 2e-5 rad: %s; among the unexceptional pairs max |dX_t| %.3g m, |dX_r| %.3g rad, rel pred_stds %.3g, rel cov %.3g; median |dX_t| %.3g; within 1e-4 m / 1e-5 rad: %.1f %%"
           % (N, outside, *worst, np.median(dts), 100 * within))
     assert np.median(dts) < 5e-6 and np.median(drs) < 5e-7 and within >= 0.97, (np.median(dts), np.median(drs), within)
+    # GPU vs the oracle in its LITERAL mode (glibc float atan2 / acos / sin / cos, sequential float sums, std::hypot: the expression types of
+    # src/utils.cpp:103-108,134-136 and src/icet.cpp:160-162 -- the closest thing to the reference binary that exists here).  No bound is asserted:
+    # the two modes of the SAME oracle differ by as much from each other (eigenvector signs of thin voxels turning on last bits); the figures an
+    # integrator needs are printed, written to gpurun_out/parity_literal.txt and quoted in INTEGRATION.md.
+    def stats(d):
+        dt_, dr_ = d[:, :3].max(1), d[:, 3:].max(1)
+        big = np.nonzero((dt_ > 3e-4) | (dr_ > 1e-4))[0]
+        return "median %.3g m / %.3g rad, p99 %.3g m / %.3g rad, max %.3g m / %.3g rad, over 3e-4 m or 1e-4 rad: %d pairs %s" % (
+            np.median(dt_), np.median(dr_), np.percentile(dt_, 99), np.percentile(dr_, 99), dt_.max(), dr_.max(), big.size, big.tolist())
+    lines = ["|dX| over the %d bench pairs (one icet_solve_batch_device call):" % N, "GPU vs literal-mode oracle:          " + stats(d_lit),
+             "shared-rule oracle vs literal oracle: " + stats(d_modes), "GPU vs shared-rule oracle:           " + stats(np.abs(np.concatenate([dts[:, None]] * 3 + [drs[:, None]] * 3, 1)))]
+    print("\n".join(lines))
+    outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(outdir):
+        with open(os.path.join(outdir, "parity_literal.txt"), "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+    assert np.isfinite(d_lit).all()
 
 
 def test_two_stage_solve_gives_the_bits_of_the_one_block_solve(gpu_ctx, sample_pc):

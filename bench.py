@@ -27,6 +27,7 @@ region.  rank 0 prints ONE JSON line with the driver's contract fields plus
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -402,6 +403,46 @@ def main(argv=None):
         except Exception:
             traffic = None
 
+    # ---- the other storage order (BASELINE configs[1] names both): the SAME points stored azimuth-major (azimuth step slow, ring fast -- the
+    # firing order of a spinning lidar) when the headline is ring-major, and the other way round.  Neighbouring lanes of k_gn_accumulate then
+    # hold points of DIFFERENT voxels (rings 7.5 degrees of polar angle apart), i.e. shorter runs per lane and more LDS adds.  The reference's result
+    # depends on the storage order (its swap loop is a function of the row indices), so this is another input, not another route to the same bits.
+    az_major = None
+    if args.workload == "batch" and not args.no_latency and world == 1 and not multi and args.distinct == 0:
+        def reorder(sc):
+            az = torch.atan2(sc[1], sc[0]); az = torch.where(az < 0, az + 2 * math.pi, az)
+            step_id = torch.floor(az.double() * (steps_az / (2 * math.pi))).long()
+            if args.order == "ring":
+                key = step_id                                              # stable sort by azimuth step keeps the rings ascending inside a step
+            else:
+                key = torch.round(torch.asin((sc[2] / torch.linalg.vector_norm(sc, dim=0)).clamp(-1, 1)).double() * (rings / math.radians(45.0))).long()   # ring index up to an offset
+            idx = torch.sort(key, stable=True).indices
+            return padded(sc[:, idx].contiguous())
+        a1 = [reorder(s) for s in scans1]; a2 = [reorder(s) for s in scans2]
+        torch.cuda.synchronize()
+        e1 = [(b.data_ptr(), n, b.shape[1]) for b, n in zip(a1, n1)]; e2 = [(b.data_ptr(), n, b.shape[1]) for b, n in zip(a2, n2)]
+        out_az = torch.zeros_like(out)
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                ctx.solve_batch_device(e1, e2, p_plain, out_az.data_ptr())
+            ctx.sync()
+            t0 = time.perf_counter(); nrep_az = max(args.steps, 5)
+            for _ in range(nrep_az):
+                ctx.solve_batch_device(e1, e2, p_plain, out_az.data_ptr())
+            ctx.sync()
+            az_ms = (time.perf_counter() - t0) / nrep_az * 1e3
+            a_acc = a_kf = a_gn = 0.0; a_l = 0
+            for _ in range(3):
+                ctx.solve_batch_device(e1, e2, p_timed, out_az.data_ptr())
+                t = ctx.last_timing()
+                a_acc += t["accumulate_ms"]; a_kf += t["keyframe_ms"]; a_gn += t["gn_loop_ms"]; a_l += t["accumulate_launches"]
+        other = "azimuth" if args.order == "ring" else "ring"
+        az_launch = a_acc / max(a_l, 1)
+        az_major = {"workload": "the same %d pairs, the same points, stored %s-major" % (len(ids), other), "pairs_per_s": round(len(ids) / (az_ms * 1e-3), 1), "ms_per_step": round(az_ms, 4),
+                    "accumulate_avg_launch_ms": round(az_launch, 5), "roofline_frac": round(bytes_per_launch / (az_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if az_launch > 0 else None,
+                    "keyframe_ms_per_step": round(a_kf / 3, 4), "gn_loop_ms_per_step": round(a_gn / 3, 4), "all_finite": bool(torch.isfinite(out_az).all().item())}
+        del a1, a2
+
     one_ctx = ctx if not multi else icet_amd.Context(dev_ids[0], stream=stream.cuda_stream)
     # ---- single-pair latency (configs[1]) on rank 0's first pair -----------------------------------
     lat = None
@@ -686,6 +727,7 @@ def main(argv=None):
             "cpu_baseline": cpu,
             "latency": lat,
             "highres": hires,
+            "other_storage_order": az_major,
             "h2d_inclusive": h2d,
             "ctor": ctor,
             "sample": sample,

@@ -157,12 +157,14 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
             }
             HIPCHK(c, dev_realloc(w.fit_n_items, (size_t)w.cap_pairs));
         }
+#ifdef ICET_DIAG_LIBSORT
         const size_t need = sort_temp_bytes(w.cap_n1);
         if (need > w.sort_tmp_bytes) {
             if (w.sort_tmp) { HIPCHK(c, hipFree(w.sort_tmp)); w.sort_tmp = nullptr; }
             HIPCHK(c, hipMalloc(&w.sort_tmp, need));
             w.sort_tmp_bytes = need;
         }
+#endif
     }
     return ICET_OK;
 }
@@ -1143,7 +1145,13 @@ icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
     else if (k == "acc_pts") t.acc_pts = iv < 1 ? 1 : iv;
     else if (k == "acc_blocks") t.acc_blocks = iv < 1 ? 1 : iv;
     else if (k == "force_exact") t.force_exact = iv != 0;
-    else if (k == "library_sort") t.library_sort = iv != 0;
+    else if (k == "library_sort") {
+#ifdef ICET_DIAG_LIBSORT
+        t.library_sort = iv != 0;
+#else
+        if (iv != 0) { c->err = "library_sort: this build has ONE sort, the hand-written rank sort (the rocPRIM A/B backend is compiled in with `make EXTRA=-DICET_DIAG_LIBSORT`)"; return ICET_ERR_UNSUPPORTED; }
+#endif
+    }
     else if (k == "kf_pts") t.kf_pts = iv < 1 ? 1 : (iv > kKfMaxPtsPerThread ? kKfMaxPtsPerThread : iv);
     else if (k == "batch_parts") t.batch_parts = iv < 0 ? 0 : (iv > 8 ? 8 : iv);
     else if (k == "batch_stage") t.batch_stage = (iv < 0 || iv > 4) ? 0 : iv;

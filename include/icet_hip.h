@@ -223,7 +223,7 @@ icet_status icet_debug_gn_tail(icet_ctx* ctx, const float* htwh, const float* ht
  * "exec_bits_lds" (0: swap-loop bit table read from memory), "exec_pairwise" (which kernel computes the swap loop's executed-step bits:
  * 1 one block per pair from the recurrence, 0 chain walks over independent tiles, -1 by batch size), "batch_parts" (0 = automatic), "batch_stage" (0..4), "force_exact"
  * (every scan-2 point through the literal classification), "library_sort" (rocPRIM radix sort instead of
- * the hand-written rank sort), "guard_scale" (>= 1), "lut_polar_quantile" (0..1), "gn_cond_bound" (0 .. 1e6, default 2.5e5 -- a factor 4 below checkCondition's cutoff, because a float Cholesky inverse knows its own norm to a few per cent only at such condition numbers: an H^T W H whose Frobenius bound on
+ * the hand-written rank sort: only in a diagnostic build, `make EXTRA=-DICET_DIAG_LIBSORT`; the shipped library answers ICET_ERR_UNSUPPORTED), "guard_scale" (>= 1), "lut_polar_quantile" (0..1), "gn_cond_bound" (0 .. 1e6, default 2.5e5 -- a factor 4 below checkCondition's cutoff, because a float Cholesky inverse knows its own norm to a few per cent only at such condition numbers: an H^T W H whose Frobenius bound on
  * the condition number |A|_F |A^-1|_F exceeds it is inverted by the literal restatement of the reference's statements -- column-pivoted QR
  * pseudo-inverse, eigenvectors, pruning -- instead of a Cholesky factorisation; 0 = always literal.  Not a launch-shape knob: between the two
  * routes cov / dx differ by rounding times the condition number).  Unknown name or value

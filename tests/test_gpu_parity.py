@@ -1020,6 +1020,51 @@ def test_multi_device_sharding_with_shards_sharing_one_gpu(gpu_ctx, frames, samp
     m.close()
 
 
+def test_config3_2048_pairs_over_8_shards_on_one_card(gpu_ctx):
+    """BASELINE configs[3] at FULL size on the one card of this box: 2048 pairs (the 256 distinct bench pairs aliased x 8, every alias with its own
+    X0) round-robin over EIGHT shards -- device 0 listed eight times: eight contexts, host threads, workspaces and result buffers, i.e. everything of
+    `icet_multi_*` but the peer link -- result rows gathered by strided copies into one buffer, bit-equal to ONE context solving the 2048 pairs; the
+    RCCL gather refuses repeated device ids instead of hanging; the eight workspaces' high-water mark is asserted (what `--gpus 8` needs per card is
+    an eighth of it).  No run on more than one device has happened anywhere: this keeps the day hardware appears a formality."""
+    import icet_amd
+    from icet_amd import lidar_sim as ls, api
+    dev = torch.device("cuda", 0)
+    N, D = 2048, 256
+    pairs = [ls.make_batch_pair(k, device=dev) for k in range(D)]
+    d1 = [(pairs[k % D][0].data_ptr(), pairs[k % D][0].shape[1], pairs[k % D][0].shape[1]) for k in range(N)]
+    d2 = [(pairs[k % D][1].data_ptr(), pairs[k % D][1].shape[1], pairs[k % D][1].shape[1]) for k in range(N)]
+    x0 = torch.zeros((N, 6), dtype=torch.float32, device=dev)
+    x0[:, 0] = 0.002 * (torch.arange(N, device=dev) // D).float(); x0[:, 5] = 0.0005 * (torch.arange(N, device=dev) % 5).float()
+    prm = api.Params(7, 24, 75, 25, 0.1, 0.1, 0)
+    o_single = torch.zeros((N, 48), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx = icet_amd.Context(0)
+    ctx.solve_batch_device(d1, d2, prm, o_single.data_ptr(), x0.data_ptr()); ctx.sync(); ctx.close()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    m = icet_amd.MultiContext([0] * 8)
+    o_multi = torch.full((N, 48), float("nan"), dtype=torch.float32, device=dev)
+    m.solve_batch_device(d1, d2, prm, o_multi.data_ptr(), x0.data_ptr())
+    torch.cuda.synchronize()
+    used_gb = (free0 - torch.cuda.mem_get_info(0)[0]) / 2 ** 30
+    assert torch.equal(o_multi, o_single) and bool(torch.isfinite(o_multi).all())
+    # aliases of one pair differ through their X0 (every slot really got ITS row of x0): most land on the same registration, none is a copy of another's slot
+    r = o_multi.cpu().numpy().reshape(8, D, 48)
+    assert not np.array_equal(r[0], r[1]) and np.median(np.abs(r[1:, :, :3] - r[0:1, :, :3]).max(2)) < 1e-3
+    # asynchronous form, twice back to back into two buffers, one sync
+    o_a = torch.full((N, 48), float("nan"), dtype=torch.float32, device=dev); o_b = torch.full((N, 48), float("nan"), dtype=torch.float32, device=dev)
+    m.solve_batch_device(d1, d2, prm, o_a.data_ptr(), x0.data_ptr(), asynchronous=True)
+    m.solve_batch_device(d1, d2, prm, o_b.data_ptr(), x0.data_ptr(), asynchronous=True)
+    m.sync()
+    assert torch.equal(o_a, o_single) and torch.equal(o_b, o_single)
+    print("configs[3] on one card: 2048 pairs over 8 shards bit-equal to one context; the eight workspaces hold %.1f GB of HBM (%.2f GB per shard of 256 pairs)" % (used_gb, used_gb / 8))
+    assert used_gb < 48.0, used_gb                                    # 8 x (256 pairs x ~12 MB of tables + scratch): measured ~26 GB; a leak or a per-call reallocation would show here
+    m.set_option("gather", 1)                                        # one ncclAllGather needs distinct devices: refused, not hung
+    with pytest.raises(icet_amd.IcetError):
+        m.solve_batch_device(d1, d2, prm, o_a.data_ptr(), x0.data_ptr())
+    m.close()
+
+
 def test_coarse_grid_long_range_takes_the_wide_fixed_point_path(gpu_ctx):
     """the two-instruction float -> fixed-point conversion of k_gn_accumulate holds for |v| < 2^15 m^2 only.  A
     4 x 2 grid (90-degree voxels) over ranges of 150-220 m puts single squared distances to mu1 above 10^4 m^2 and 4-point partial
@@ -1111,14 +1156,21 @@ def test_rarely_taken_paths_give_the_same_bits(gpu_ctx, frames, sample_pc):
     fit LDS (global-scratch radix sort), buckets whose keys pile up in one cell of the counting sort (LDS radix sort), the swap-loop
     bit table read from memory instead of LDS (scans above ~0.75 M rows), the executed-step bits from the per-pair recurrence kernel (the
     kernel of throughput batches) and from the chain walks (small batches), small keyframe tiles, few / many accumulate blocks, and the
-    library (rocPRIM) sort that the hand-written rank sort replaced; the stable multi-splits with ranks from ballots instead of the values the
+    library (rocPRIM) sort that the hand-written rank sort replaced (diagnostic builds only); the stable multi-splits with ranks from ballots instead of the values the
     LDS atomics hand back (the default on a device that passed the order self-test -- which an MI355X must)."""
     a, b = frames; c, d = sample_pc
     assert gpu_ctx.debug_fetch("lds_rank_ok", 1)[0] == 1, "LDS atomics of one wave not served in lane order on this device?"
     base1 = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
     base2 = gpu_ctx.solve(c, d, 7, np.zeros(6), 48, 150)
     knobs = [("lds_slots", 32, 0), ("rs_cap", 128, 0), ("rs_max_cell", 0, 24), ("rs_max_cell", 1, 24), ("exec_bits_lds", 0, 1), ("lds_rank", 0, -1), ("exec_pairwise", 1, -1), ("exec_pairwise", 0, -1), ("kf_pts", 1, 8), ("kf_pts", 3, 8), ("acc_blocks", 7, 1536),
-             ("acc_pts", 64, 4), ("library_sort", 1, 0), ("batch_stage", 0, 4)]
+             ("acc_pts", 64, 4), ("batch_stage", 0, 4)]
+    import icet_amd
+    try:                                                     # the rocPRIM A/B backend exists only in a diagnostic build (make EXTRA=-DICET_DIAG_LIBSORT): the shipped library has one sort
+        gpu_ctx.set_option("library_sort", 1)
+        knobs.append(("library_sort", 1, 0))
+    except icet_amd.IcetError as e:
+        assert e.status == icet_amd.api.ICET_ERR_UNSUPPORTED
+    gpu_ctx.set_option("library_sort", 0)
     for key, val, default in knobs:
         gpu_ctx.set_option(key, val)
         try:

@@ -116,11 +116,13 @@ __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __re
     }
 }
 
-// pred[s[i]] = i : rank of every original row.
+#ifdef ICET_DIAG_LIBSORT
+// pred[s[i]] = i : rank of every original row (the library sort's inverse-permutation pass; the rank sort writes pred[] itself).
 __global__ __launch_bounds__(kBlock) void k_inverse_perm(const PairDesc* __restrict__ desc, const uint32_t* __restrict__ s, int32_t* __restrict__ pred,
                                                          int n_pairs, int chunks) {
     ICET_FOR_CHUNK_OF_SCAN1(i) pred[(size_t)d.off1 + s[(size_t)d.off1 + i]] = i;
 }
+#endif
 
 // The reference "sorts" rows in place with
 //     for i: if (index[i] != i) { swap(row i, row index[i]); swap(index[i], index[index[i]]); }
@@ -1315,12 +1317,16 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 4) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     if (c.use_library_sort) {
+#ifdef ICET_DIAG_LIBSORT
         if (batch) e = sort_pairs_u64(w.sort_tmp, w.sort_tmp_bytes, w.key64A, w.key64B, w.valA, w.valB, c.total_n1, 32 + pbits, st);
         else e = sort_pairs_u32(w.sort_tmp, w.sort_tmp_bytes, w.keyA, w.keyB, w.valA, w.valB, c.total_n1, 32, st);
         if (e != hipSuccess) return e;
         // valB = s : original index of the row with rank i
         k_inverse_perm<<<grid, blk, 0, st>>>(w.desc, w.valB, w.pred, np, chunks);
         ICET_LAUNCH_CHECK();
+#else
+        (void)pbits; return hipErrorNotSupported;        // (icet_set_option refuses "library_sort" in a build without the diagnostic backend)
+#endif
     } else {
         e = launch_rank_sort(w, c, st);        // valB = s, pred = s^-1  (icet_ranksort.hip)
         if (e != hipSuccess) return e;

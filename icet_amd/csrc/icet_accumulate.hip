@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : (kSmall ? 2 : kAccWavesPerSim
             h[0] = g.inner; h[1] = g.outer; h[2] = g.mu[0]; h[3] = g.mu[1]; h[4] = g.mu[2];
         }
         for (int i = threadIdx.x; i < 10 * nl; i += kAccBlock) lacc[i] = 0ull;   // only the rows in use
-        if (threadIdx.x == 0) nearq[near_cap] = 0u;
+        if (threadIdx.x < 5) nearq[near_cap + threadIdx.x] = 0u;      // the queue's fill counter, then the four counters of points that land exactly on the origin
     }
     const float* xf = xf_all + pair * kXf;
     const float tx = xf[0], ty = xf[1], tz = xf[2];
@@ -256,12 +256,11 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : (kSmall ? 2 : kAccWavesPerSim
             R2[j] = r2;
         }
         // |q|^2 outside [1e-30, 1e30] over- or underflows the stand-in coordinates while the literal formulas stay well defined
-        // (absurd inputs, but the claim is "never decides differently"): one min / max over the lane's 4 points, literal path for all 4
-        {
-            const float lo = fminf(fminf(R2[0], R2[1]), fminf(R2[2], R2[3])), hi = fmaxf(fmaxf(R2[0], R2[1]), fmaxf(R2[2], R2[3]));
-            const bool odd = !(lo >= kR2Min) | !(hi <= kR2Max);
-            nr[0] |= odd; nr[1] |= odd; nr[2] |= odd; nr[3] |= odd;
-        }
+        // (absurd inputs, but the claim is "never decides differently"): literal path.  PER POINT since round 5: one min / max over the lane's 4 points sent
+        // the three NEIGHBOURS of every exact-zero row through the literal path as well, and a real scan has 8 - 18 % of such rows, scattered: in a first
+        // iteration with X0 = 0 a third of all points overflowed the queues (339 + 86 us for that iteration of a 256-pair batch of real scans)
+#pragma unroll
+        for (int j = 0; j < 4; j++) nr[j] |= !((R2[j] >= kR2Min) & (R2[j] <= kR2Max));
         // ---- phase A2: only waves that touch an active voxel look at the hot records (radial test, d = q - mu1) ----
         // E: the point's slot, -1 for "no active voxel" and for a point that waits for the literal formulas
         const int E0 = nr[0] ? -1 : SM[0], E1 = nr[1] ? -1 : SM[1], E2 = nr[2] ? -1 : SM[2], E3 = nr[3] ? -1 : SM[3];
@@ -311,6 +310,25 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : (kSmall ? 2 : kAccWavesPerSim
         // the pair's overflow list in HBM, which k_gn_solve drains.  Integer accumulation makes the order irrelevant. ----
         if (ICET_ACC_PHASE == 2) { for (int j = 0; j < 4; j++) sink += (float)pc[j].s + pc[j].dx + pc[j].dy + pc[j].dz + (pc[j].inb ? 1.f : 0.f) + (nr[j] ? 1.f : 0.f); continue; }
         if (__ballot(nr[0] | nr[1] | nr[2] | nr[3]) != 0ull) {
+            // A point that lands EXACTLY on the origin is not parked: r = 0, theta = atan2(+-0, +-0), phi = acos(NaN) -> 1000 (src/utils.cpp:103-116), so
+            // its voxel is a function of the two sign bits and it can never pass the bounds test (phi = 1000): such points are only COUNTED, per sign
+            // pattern, and the block adds the counts to the voxels' raw counts at its end.  Why it matters: the invalid returns of a real scan are
+            // exact-zero rows (5 k - 24 k per scan of the reference's sample data), and in a first iteration with X0 = 0 every one of them lands on
+            // the origin; parked, they filled the queue, the overflow list (one global atomic each on ONE counter) and k_gn_solve's one-block drain:
+            // 600 + 284 us instead of 100 + 13 for that iteration of a 256-pair batch of real scans.
+            if (__ballot((R2[0] == 0.f) | (R2[1] == 0.f) | (R2[2] == 0.f) | (R2[3] == 0.f)) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool zq = (R2[j] == 0.f) & (QX[j] == 0.f) & (QY[j] == 0.f) & (i0 + j < end);      // x = y = +-0 exactly (not a tiny vector whose squares underflow: its theta is a real angle)
+                    const int patt = (__builtin_signbit(QY[j]) ? 2 : 0) | (__builtin_signbit(QX[j]) ? 1 : 0);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const unsigned long long m = __ballot(zq & (patt == k));
+                        if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&nearq[near_cap + 1 + k], (uint32_t)__popcll(m));
+                    }
+                    nr[j] &= !zq;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (nr[j] & (i0 + j < end)) {
@@ -426,6 +444,15 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : (kSmall ? 2 : kAccWavesPerSim
                 }
             }
         }
+        if (threadIdx.x < 4 && nearq[near_cap + 1 + threadIdx.x] != 0u) {       // the points on the origin, by sign pattern: one literal classification for all of them
+            PointClass pz;
+            classify_literal((threadIdx.x & 1) ? -0.f : 0.f, (threadIdx.x & 2) ? -0.f : 0.f, 0.f, map, thr, T, P, hs, pz, false);
+            const uint32_t cnt = nearq[near_cap + 1 + threadIdx.x];
+            if (pz.s >= 0) {                                               // (never in bounds: phi = 1000)
+                if (pz.s < nl) atomicAdd(&lacc[pz.s * 10], (unsigned long long)cnt);
+                else atomicAdd(reinterpret_cast<unsigned long long*>(gacc + (size_t)pz.s * kAccWords), (unsigned long long)cnt);
+            }
+        }
     }
     __syncthreads();
     for (int s = threadIdx.x; s < nl; s += kAccBlock) {
@@ -493,7 +520,7 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     // CUs to spare, so a block may take most of a CU's LDS and keep every active voxel of a fine grid (150 x 48: often
     // > 1000) out of the slow HBM-atomic path.
     const uint32_t near_cap = (c.n_pairs >= 32) ? kNearCap : kNearCapSmall;
-    const size_t fixed = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)((c.V + c.T + 4) / 2) * 4 + (near_cap + 1) * 4 + 32;   // + alignment of the hot records
+    const size_t fixed = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)((c.V + c.T + 4) / 2) * 4 + (near_cap + 5) * 4 + 32;   // + alignment of the hot records
     const size_t row = (kHotWords + kAccLds) * 4;
     const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : 156 * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU; a small batch: one block per CU, nearly all of its LDS
     int lds_slots = c.lds_slots > 0 ? c.lds_slots : (int)((budget > fixed ? budget - fixed : 0) / row);

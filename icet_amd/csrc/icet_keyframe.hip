@@ -67,6 +67,13 @@ __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __re
         __syncthreads();
     }
     const float cell_t = (float)Mt * 0.25f, cell_p = (float)Mp * 0.5f;
+    // the voxel of an exact-zero row: r = 0, phi = acos(NaN) -> 1000, theta = atan2(+-0, +-0) -- a function of the two sign bits.  A real scan holds
+    // (x = y = +-0 exactly -- not a tiny vector whose squares underflow: its theta is a real angle; z does not matter: z / 0 is NaN or +-inf, acos of either NaN).  A real scan holds
+    // thousands of such rows (invalid returns; 18 % of the reference's sample_pc scans): sent through voxel_literal one by one they put the
+    // double-precision atan2 / acos into nearly every wave (205 us per 256 real pairs against 123 on synthetic scans)
+    __shared__ int s_zero_voxel[4];
+    if (threadIdx.x < 4) s_zero_voxel[threadIdx.x] = voxel_literal((threadIdx.x & 1) ? -0.f : 0.f, (threadIdx.x & 2) ? -0.f : 0.f, 0.f, 0.f, T, P);
+    __syncthreads();
     int vlo = 0x7FFFFFFF, vhi = -1;                                   // voxel ids this thread has seen
     ICET_FOR_CHUNK_OF_SCAN1(i) {
         const float* x = d.s1; const float* y = d.s1 + d.ld1; const float* z = d.s1 + 2 * (size_t)d.ld1;
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __re
                               lut_t, lut_p, cell_t, cell_p, T, guard_t, guard_p, bt, prow, near);
         near = near | !ordinary;
         int v = prow + bt;
-        if (near) v = voxel_literal(px, py, pz, rr, T, P);
+        if (near) v = ((rr == 0.f) & (px == 0.f) & (py == 0.f)) ? s_zero_voxel[(__builtin_signbit(py) ? 2 : 0) | (__builtin_signbit(px) ? 1 : 0)] : voxel_literal(px, py, pz, rr, T, P);
         const float r = (rr != rr) ? 1000.0f : rr;                      // src/utils.cpp:116
         size_t o = (size_t)d.off1 + i;
         r1[o] = r;
@@ -842,20 +849,26 @@ __global__ __launch_bounds__(kBlock, kTail > 2 ? 4 : ICET_CLUSTER_WAVES) void k_
 #if !(defined(ICET_EXP_FIT) && ICET_EXP_FIT == 2)
         if ((double)outer > 0.1) {
             const unsigned long long lt = (1ull << lane) - 1ull;
-            for (int c0 = 0; c0 < cnt; c0 += 64) {
-                const int i = c0 + lane, c = c0 >> 6;
-                uint32_t rw; float r;
-                if (c < kCache) {                                     // wave-uniform: the cached chunks, selected without indexing the register arrays
-                    rw = (c == 0) ? prw[0] : (c == 1) ? prw[1] : (c == 2) ? prw[2] : prw[3];
-                    r = (c == 0) ? pr[0] : (c == 1) ? pr[1] : (c == 2) ? pr[2] : pr[3];
-                } else {
-                    rw = (i < cnt) ? sorted_row[base + i] : 0u;
-                    r = r_of(rw, i < cnt);
-                }
+            auto keep = [&](int c0, uint32_t rw, float r) {
+                const int i = c0 + lane;
                 const bool in = (i < cnt) && (r >= inner) && (r <= outer);
                 const unsigned long long m = __ballot(in);
                 if (in) { const size_t pos = base + m_cand + __popcll(m & lt); cand[pos] = rw; cand_r[pos] = r; }
                 m_cand += __popcll(m);
+            };
+#pragma unroll
+            for (int k = 0; k < kCache; k++) if (64 * k < cnt) keep(64 * k, prw[k], pr[k]);      // the cached chunks
+            // rows past the cached ones, kFilter chunks requested together: the bin that holds a real scan's exact-zero rows (5 k - 24 k rows, in ONE wave)
+            // was two dependent memory round trips per 64 rows here -- 190 us per 256 real pairs for this kernel against 100 on synthetic scans
+            constexpr int kFilter = kTail > 4 ? 8 : 4;
+            for (int c0 = 64 * kCache; c0 < cnt; c0 += 64 * kFilter) {
+                uint32_t tw[kFilter]; float tr[kFilter];
+#pragma unroll
+                for (int k = 0; k < kFilter; k++) tw[k] = (c0 + 64 * k + lane < cnt) ? sorted_row[base + c0 + 64 * k + lane] : 0u;
+#pragma unroll
+                for (int k = 0; k < kFilter; k++) tr[k] = r_of(tw[k], c0 + 64 * k + lane < cnt);
+#pragma unroll
+                for (int k = 0; k < kFilter; k++) if (c0 + 64 * k < cnt) keep(c0 + 64 * k, tw[k], tr[k]);
             }
             // announce the batches: one list and one counter per pair (a single counter for the whole launch serialises ~50 k
             // returning atomics on one word: measured 0.4 ms)

@@ -28,6 +28,7 @@
 #include "icet_internal.h"
 #include "icet_device_common.h"
 #include "icet_block_sort.h"
+#include <algorithm>
 
 namespace icet {
 namespace {
@@ -86,7 +87,10 @@ __global__ __launch_bounds__(kSplitLoadThreads) void k_rs_splitters(PairDesc* __
 #pragma unroll
     for (int r = 0; r < 4; r++) {                               // element e = 4 * tid + r: each thread loads its own four samples
         const int j = 4 * tid + r;
-        x[r] = (j < ns) ? __float_as_uint(radius_of(d.s1[(size_t)j * stride], d.s1[d.ld1 + (size_t)j * stride], d.s1[2 * (size_t)d.ld1 + (size_t)j * stride])) : 0xFFFFFFFFu;
+        // sample j comes from a pseudo-random place inside the j-th stride, not from its start: a lidar scan is periodic in its row index (64 rings x 1024 or 2048
+        // azimuth steps), and every 32nd / 64th row of a column-major scan is ONE ring -- the reference's sample scans then got buckets of 2 - 7 k rows against a mean of 900
+        const size_t row = (size_t)min(n - 1, j * stride + (int)((((uint32_t)j * 2654435761u) >> 12) % (uint32_t)stride));
+        x[r] = (j < ns) ? __float_as_uint(radius_of(d.s1[row], d.s1[d.ld1 + row], d.s1[2 * (size_t)d.ld1 + row])) : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int k = 2; k <= kSamples; k <<= 1) {                   // bitonic sort, ascending
@@ -212,9 +216,16 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter(const PairDesc* __restric
 // 16 scattered ones -- the scattered form is bound by the number of store requests, not by instructions (ranks from LDS atomics alone: 116 -> 112 us
 // per 256 pairs; staged: 101; with all loads issued before the first atomic: 83).
 static_assert(kMaxBuckets <= kBlock && kMaxBuckets % 64 == 0 && kMaxBuckets <= 256, "k_rs_scatter_staged: one thread per bucket scans them, ids travel in 8 bits");
+// Bucket 0 of a pair whose first splitter is 0 holds exactly the rows with r == 0 -- the invalid returns of a real scan, 5 k - 24 k rows -- and a stable
+// multi-split leaves them in row order, which IS their final order (ties by row index): their s[] / pred[] entries are written here, where every row
+// knows its place, and k_rs_bucket_sort skips the bucket (it used to load the 24 k equal keys through one block's global-scratch path).
+__device__ __forceinline__ bool zero_bucket_done(const uint32_t* __restrict__ splitters, int pair, const int32_t* __restrict__ n_buckets) {
+    return n_buckets[pair] >= 2 && splitters[(size_t)pair * kMaxBuckets + 1] == 0u;
+}
 __global__ __launch_bounds__(kBlock) void k_rs_scatter_staged(const PairDesc* __restrict__ desc, const float* __restrict__ r1, const uint8_t* __restrict__ bkt,
                                                               const uint32_t* __restrict__ tile_base, const int32_t* __restrict__ bucket_start,
-                                                              uint2* __restrict__ bkv, int n_pairs, int chunks) {
+                                                              uint2* __restrict__ bkv, int n_pairs, int chunks,
+                                                              const uint32_t* __restrict__ splitters, const int32_t* __restrict__ n_buckets, uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out) {
     __shared__ uint32_t lb[4 * kMaxBuckets];                         // per wave and bucket: rows counted, then the wave's first slot in the stage
     __shared__ int32_t gdelta[kMaxBuckets];                          // bucket: (global position - stage position) of its rows of this tile
     __shared__ uint32_t wtot[kMaxBuckets / 64];
@@ -275,10 +286,16 @@ __global__ __launch_bounds__(kBlock) void k_rs_scatter_staged(const PairDesc* __
         }
     __syncthreads();
     const int nt = hi_ - lo_;
+    const bool zero_done = zero_bucket_done(splitters, pair, n_buckets);
 #pragma unroll
     for (int k = 0; k < kScatterRounds; k++) {
         const int j = k * kBlock + (int)threadIdx.x;
-        if (j < nt) bkv[(int64_t)o + gdelta[stage_b[j]] + j] = stage[j];
+        if (j < nt) {
+            const int b = stage_b[j];
+            const int dest = gdelta[b] + j;
+            bkv[(int64_t)o + dest] = stage[j];
+            if (zero_done && b == 0) { s_out[o + dest] = stage[j].y; pred_out[o + stage[j].y] = dest; }      // (bucket 0 starts at rank 0)
+        }
     }
 }
 
@@ -482,7 +499,7 @@ template <int kRsPerBlock>
 __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* __restrict__ desc, const int32_t* __restrict__ bucket_start,
                                                                const int32_t* __restrict__ n_buckets, uint2* __restrict__ bkv, uint2* __restrict__ alt,
                                                                uint32_t* __restrict__ s_out, int32_t* __restrict__ pred_out, int kCap, int logC, int max_cell, int n_pairs,
-                                                               const uint32_t* __restrict__ splitters) {
+                                                               const uint32_t* __restrict__ splitters, int zero_in_scatter) {
     extern __shared__ uint32_t smem[];
     // all buckets of a pair on one XCD (decode_block): their scattered 4-byte writes of pred[] then complete whole cache lines in
     // ONE L2 instead of leaving partial lines in eight
@@ -504,6 +521,7 @@ __global__ __launch_bounds__(kSortBlock) void k_rs_bucket_sort(const PairDesc* _
         const int bkt = part + q * kStride;
         const bool ok = bkt < nb;
         los[q] = ok ? bs[bkt] : 0; ns[q] = ok ? bs[bkt + 1] - los[q] : 0;
+        if (zero_in_scatter && bkt == 0 && zero_bucket_done(splitters, pair, n_buckets)) ns[q] = 0;      // the bucket of exact zeros was finished by the multi-split
         // bucket = number of splitters strictly below the key: an inner bucket holds splitter[bkt] < key <= splitter[bkt + 1]
         const bool inner = ok && bkt >= 1 && bkt + 1 < nb;
         const uint32_t a = inner ? splitters[(size_t)pair * kMaxBuckets + bkt] : 0xFFFFFFFFu, b2 = inner ? splitters[(size_t)pair * kMaxBuckets + bkt + 1] : 0u;
@@ -583,18 +601,19 @@ hipError_t launch_rank_sort(const Workspace& w, const LaunchCfg& c, hipStream_t 
     // (its per-pair scan block also reduces the tiles' voxel ranges, written by k_scan1_spherical, to the pair's)
     hipError_t e = launch_class_scan(w.counts, w.tile_base, w.bucket_start, kMaxBuckets, chunks, np, st, nullptr, nullptr, 0, nullptr, nullptr, w.tile_vr, w.vrange);
     if (e != hipSuccess) return e;
-    if (c.lds_rank) k_rs_scatter_staged<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks);
+    if (c.lds_rank) k_rs_scatter_staged<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks, w.splitters, w.n_buckets, w.valB, w.pred);
     else k_rs_scatter<<<grid, blk, 0, st>>>(w.desc, w.r1, w.bkt, w.tile_base, w.bucket_start, reinterpret_cast<uint2*>(w.key64A), np, chunks);
     ICET_LAUNCH_CHECK();
     const int cap = rank_sort_cap(c.max_n1, c.rs_cap, c.n_pairs);
+    const int zero_in_scatter = c.lds_rank ? 1 : 0;                       // (the ballot form of the multi-split does not write the zero bucket's ranks)
     // two buckets per block (the second one's pairs in flight during the first one's sort) once the launch fills the chip several times over;
     // a small batch -- one pair is at most 256 blocks on 256 CUs -- keeps a block per bucket
     if (groups * kMaxBuckets >= 16 * 256 && kRsPerBlockBatch != 1)
         k_rs_bucket_sort<kRsPerBlockBatch><<<dim3(groups * (kMaxBuckets / kRsPerBlockBatch)), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, reinterpret_cast<uint2*>(w.key64A),
-                                                                                             reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np, w.splitters);
+                                                                                             reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np, w.splitters, zero_in_scatter);
     else
         k_rs_bucket_sort<1><<<dim3(groups * kMaxBuckets), kSortBlock, rank_sort_lds_bytes(cap), st>>>(w.desc, w.bucket_start, w.n_buckets, reinterpret_cast<uint2*>(w.key64A),
-                                                                                             reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np, w.splitters);
+                                                                                             reinterpret_cast<uint2*>(w.key64B), w.valB, w.pred, cap, rank_sort_log_cells(cap), c.rs_max_cell, np, w.splitters, zero_in_scatter);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -234,3 +234,11 @@ def make_sequence(n_frames, scene_seed=2000, noise_seed=2001, motion=DEFAULT_MOT
         t = t + Rw @ t_step
         Rw = Rw @ R_step
     return scans
+
+
+def real_batch_rotation(k):
+    """Rotation of pair k of the REAL-data batch (bench.py `sample_batch`, tests): the reference's two sample pairs alternate (even k: frame_804/805, odd k:
+    sample_pc_1/2) and BOTH scans of pair k are turned by one small rotation (roll / pitch +-0.01, yaw +-0.05 rad, seed 7000 + k), so that every pair's rows
+    fall into other voxels and sort differently while the registration stays the pair's and the invalid returns stay exact-zero rows.  float32 3 x 3."""
+    ang = np.random.RandomState(7000 + k).uniform(-1, 1, 3) * np.array([0.01, 0.01, 0.05])
+    return euler_R(*ang).astype(np.float32)

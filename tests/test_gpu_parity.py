@@ -1065,6 +1065,45 @@ def test_config3_2048_pairs_over_8_shards_on_one_card(gpu_ctx):
     m.close()
 
 
+def test_real_scan_batch_keyframe_bits_and_solution(gpu_ctx, frames, sample_pc):
+    """The REAL-data throughput batch of bench.py (`sample_batch`; review r4, item 4): 64 pairs built from the reference's two sample pairs, pair k turned by
+    its own small rotation, thousands of exact-zero rows per scan kept, through ONE icet_solve_batch_device call.  Every pair must give its single-solve bits;
+    on a sample of them the keyframe table is the oracle's bit for bit (zero rows: the voxel of r = 0 from the two sign bits, the rank sort's bucket of equal
+    keys finished by its multi-split, the zero-row voxel's cluster) and X / pred_stds / cov within the usual bounds."""
+    import icet_amd
+    from icet_amd import lidar_sim as ls, api
+    from oracle import pyoracle as po
+    dev = torch.device("cuda", 0)
+    base = [tuple(torch.from_numpy(np.ascontiguousarray(x.T)).to(dev) for x in frames), tuple(torch.from_numpy(np.ascontiguousarray(x.T)).to(dev) for x in sample_pc)]
+    N = 64
+    pairs = []
+    for k in range(N):
+        R = torch.as_tensor(ls.real_batch_rotation(k), device=dev)
+        pairs.append(((R @ base[k % 2][0]).contiguous(), (R @ base[k % 2][1]).contiguous()))
+    d1 = [(p[0].data_ptr(), p[0].shape[1], p[0].shape[1]) for p in pairs]; d2 = [(p[1].data_ptr(), p[1].shape[1], p[1].shape[1]) for p in pairs]
+    out = torch.zeros((N, 48), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx = icet_amd.Context(0)
+    ctx.solve_batch_device(d1, d2, api.Params(7, 24, 75, 25, 0.1, 0.1, 0), out.data_ptr()); ctx.sync()
+    batch = out.cpu().numpy()
+    ctx.close()
+    assert np.isfinite(batch).all()
+    for k in (0, 1, 2, 3, 30, 63):
+        a = np.ascontiguousarray(pairs[k][0].T.cpu().numpy()); b = np.ascontiguousarray(pairs[k][1].T.cpu().numpy())
+        assert int((np.abs(a).max(1) == 0).sum()) > 4000                 # the invalid returns are still exact-zero rows after the rotation
+        g = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True)
+        assert np.array_equal(batch[k, :6], g["X"]) and np.array_equal(batch[k, 6:12], g["pred_stds"]) and np.array_equal(batch[k, 12:], g["cov"].reshape(36)), k
+        ref = po.solve(a, b, trace=True)
+        t, ax = ref["trace"], g["aux"]
+        f = t["has_fit"] == 1
+        assert np.array_equal(ax["n1_raw"], t["n1_raw"]) and np.array_equal(ax["cluster_bounds"], t["bounds"]) and np.array_equal(ax["has_fit"], t["has_fit"]), k
+        for name_g, name_o in (("mu1", "mu1"), ("sigma1", "sigma1"), ("evecs1", "evecs1"), ("l_diag", "Ldiag")):
+            assert np.array_equal(ax[name_g][f].view(np.uint32), t[name_o][f].view(np.uint32)), (k, name_g)
+        act = f & (t["n1_raw"] > 25) & (t["bounds"][:, 5] > 1)
+        assert np.array_equal(ax["n2_raw"][0][act], t["n2_raw"][0][act]), k
+        _check_solution(g, ref)
+
+
 def test_coarse_grid_long_range_takes_the_wide_fixed_point_path(gpu_ctx):
     """the two-instruction float -> fixed-point conversion of k_gn_accumulate holds for |v| < 2^15 m^2 only.  A
     4 x 2 grid (90-degree voxels) over ranges of 150-220 m puts single squared distances to mu1 above 10^4 m^2 and 4-point partial

@@ -27,7 +27,7 @@ FLAG_HALF_GAP_BOUNDS = 8  # non-parity extension (half-gap cluster buffers of th
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_begin", "icet_solve_keyframe_tables", "icet_solve_end", "icet_solve_batch",
                     "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_debug_gn_tail", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_keyframe_device_n", "icet_register_device_n", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
                     "icet_multi_solve_batch", "icet_multi_solve_batch_device", "icet_multi_solve_batch_device_after", "icet_multi_solve_batch_device_async", "icet_multi_sync", "icet_multi_set_option",
-                    "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_map",
+                    "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_push_many_device", "icet_node_map",
                     "icet_node_prev_scan", "icet_node_aligned", "icet_node_snail_trail", "icet_node_last_timing", "icet_stream", "icet_device",
                     "icet_load_scan", "icet_free_scan", "icet_save_scan_npy")
 _NON_STATUS = ("icet_version", "icet_last_error", "icet_stream", "icet_device", "icet_free_scan", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context")
@@ -120,6 +120,7 @@ def load_library():
     L.icet_node_destroy.argtypes = [C.c_void_p]
     L.icet_node_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(NodeResult)]
     L.icet_node_push_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(NodeResult)]
+    L.icet_node_push_many_device.argtypes = [C.c_void_p, C.POINTER(DevScan), C.c_int32, C.POINTER(NodeResult)]
     L.icet_node_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.icet_node_last_timing.argtypes = [C.c_void_p, C.c_void_p]
     L.icet_node_prev_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
@@ -505,6 +506,16 @@ class Node:
         if st != ICET_OK:
             raise IcetError(st, "icet_node_push_device")
         return _result_dict(r)
+
+    def push_many_device(self, frames):
+        """A burst of frames already in HBM, [(device_ptr, n, ld), ...]: icet_node_push_many_device -- chained on the device, one copy of all results at the end."""
+        k = len(frames)
+        A = (DevScan * max(k, 1))(*[DevScan(int(p), int(n), int(ld)) for (p, n, ld) in frames])
+        R = (NodeResult * max(k, 1))()
+        st = load_library().icet_node_push_many_device(self._h, A, k, R)
+        if st != ICET_OK:
+            raise IcetError(st, "icet_node_push_many_device")
+        return [_result_dict(R[i]) for i in range(k)]
 
     def map(self):
         """``EigenQueue::getQueue()``: rows x 3, oldest first."""

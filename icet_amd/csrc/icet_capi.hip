@@ -803,12 +803,22 @@ icet_status icet_keyframe_device_n(icet_ctx* c, const icet_params* p, int32_t n_
     c->kf_pairs = 0;
     icet_status s = ensure_workspace(c, p, n_pairs, tot1, 0);
     if (s != ICET_OK) return s;
-    if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
-    if (c->graph_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_graph)); c->graph_in_flight = false; }
-    for (int k = 0; k < n_pairs; k++) {
-        PairDesc& d = c->h_desc[k];
-        d.s1 = scan1[k].ptr; d.n1 = (int32_t)scan1[k].n; d.ld1 = (int32_t)scan1[k].ld;
-        d.s2 = nullptr; d.n2 = 0; d.ld2 = 0; d.off1 = 0; d.off2 = 0;
+    // A sequential caller hands the SAME buffers to this half frame after frame (include/icet_nodes.h): the pinned descriptor staging then already holds
+    // this call's scan-1 halves and is left alone -- rewriting it means waiting, on the HOST, for whatever replay or copy of this context still reads it,
+    // and a burst of frames (icet_node_push_many_device) would have the host wait for the device twice per frame instead of running ahead
+    bool same_desc = true;
+    for (int k = 0; k < n_pairs && same_desc; k++) {
+        const PairDesc& d = c->h_desc[k];
+        same_desc = d.s1 == scan1[k].ptr && d.n1 == (int32_t)scan1[k].n && d.ld1 == (int32_t)scan1[k].ld;
+    }
+    if (!same_desc) {
+        if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
+        if (c->graph_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_graph)); c->graph_in_flight = false; }
+        for (int k = 0; k < n_pairs; k++) {
+            PairDesc& d = c->h_desc[k];
+            d.s1 = scan1[k].ptr; d.n1 = (int32_t)scan1[k].n; d.ld1 = (int32_t)scan1[k].ld;
+            d.s2 = nullptr; d.n2 = 0; d.ld2 = 0; d.off1 = 0; d.off2 = 0;
+        }
     }
     if (graph_eligible(c, p, n_pairs)) {
         s = ensure_thresholds(c, p->bins_theta, p->bins_phi);
@@ -839,9 +849,16 @@ icet_status icet_register_device_n(icet_ctx* c, const icet_params* p, int32_t n_
     if (p->runlen == 0) return write_runlen0(c, n_pairs, d_x0, d_out);
     icet_status s = ensure_workspace(c, p, n_pairs, 0, tot2);              // only the scan-2 overflow list can grow here: the keyframe tables stay
     if (s != ICET_OK) return s;
-    if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
-    if (c->graph_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_graph)); c->graph_in_flight = false; }
-    for (int k = 0; k < n_pairs; k++) { PairDesc& d = c->h_desc[k]; d.s2 = scan2[k].ptr; d.n2 = (int32_t)scan2[k].n; d.ld2 = (int32_t)scan2[k].ld; }
+    bool same_desc = true;                                                 // (see icet_keyframe_device_n)
+    for (int k = 0; k < n_pairs && same_desc; k++) {
+        const PairDesc& d = c->h_desc[k];
+        same_desc = d.s2 == scan2[k].ptr && d.n2 == (int32_t)scan2[k].n && d.ld2 == (int32_t)scan2[k].ld;
+    }
+    if (!same_desc) {
+        if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
+        if (c->graph_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_graph)); c->graph_in_flight = false; }
+        for (int k = 0; k < n_pairs; k++) { PairDesc& d = c->h_desc[k]; d.s2 = scan2[k].ptr; d.n2 = (int32_t)scan2[k].n; d.ld2 = (int32_t)scan2[k].ld; }
+    }
     if (graph_eligible(c, p, n_pairs))
         return run_or_replay(c, c->g_loop, graph_key_of(c, p, n_pairs, d_x0, d_out, d_rows, (const void*)2), [&]() { return enqueue_loop(c, p, n_pairs, d_x0, d_out, nullptr, true, nullptr, nullptr, d_rows); });
     return enqueue_loop(c, p, n_pairs, d_x0, d_out, nullptr, true, nullptr, nullptr, d_rows);

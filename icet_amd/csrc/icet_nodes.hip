@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kFB) void k_range_count(const float* __restrict__ x
 }
 
 // pass 2: exclusive scan of the block counts (one block; at most a few thousand entries), total -> n_kept
-__global__ __launch_bounds__(kFB) void k_range_scan(const int32_t* __restrict__ counts, int32_t* __restrict__ bases, int n_blocks, int32_t* __restrict__ n_kept) {
+__global__ __launch_bounds__(kFB) void k_range_scan(const int32_t* __restrict__ counts, int32_t* __restrict__ bases, int n_blocks, int32_t* __restrict__ n_kept, int32_t* __restrict__ n_kept_copy = nullptr) {
     __shared__ int part[kFB];
     const int per = (n_blocks + kFB - 1) / kFB;
     const int lo = threadIdx.x * per, hi = min(n_blocks, lo + per);
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kFB) void k_range_scan(const int32_t* __restrict__ 
     for (int i = lo; i < hi; i++) s += counts[i];
     part[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int t = 0; t < kFB; t++) { const int v = part[t]; part[t] = run; run += v; } *n_kept = run; }
+    if (threadIdx.x == 0) { int run = 0; for (int t = 0; t < kFB; t++) { const int v = part[t]; part[t] = run; run += v; } *n_kept = run; if (n_kept_copy) *n_kept_copy = run; }
     __syncthreads();
     int run = part[threadIdx.x];
     for (int i = lo; i < hi; i++) { bases[i] = run; run += counts[i]; }
@@ -104,6 +104,14 @@ __global__ __launch_bounds__(kFB) void k_range_scatter(const float* __restrict__
         if (keep[k]) { const int o = run + before + below[k]; ox[o] = vx[k]; oy[o] = vy[k]; oz[o] = vz[k]; }
         run += total;
     }
+}
+
+// A burst's frame (icet_node_push_many_device): its 48 result floats into the burst's table, and the next frame's X0 <- X (odometry.cpp:82) or zeros
+// (simpleMapMaker.cpp:124) -- one tiny kernel behind the loop instead of two device-to-device copies (a hipMemcpyAsync of a few bytes costs a stream ~20 us).
+__global__ void k_burst_collect(const float* __restrict__ out, float* __restrict__ out_all, float* __restrict__ x0, int seed) {
+    const int i = threadIdx.x;
+    if (i < 48) out_all[i] = out[i];
+    if (i < 6) x0[i] = seed ? out[i] : 0.f;
 }
 
 // EigenQueue::add_new_scan (src/simpleMapMaker.cpp:34-41): rows [pos, pos + m) (mod cap) take the down-sampled scan
@@ -233,6 +241,9 @@ struct icet_node {
     std::vector<float> snail;                                                               // scanMatcher.cpp:27-28,79-84: rows x 3 row-major, host
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [5]: start of the loop on the owner's stream (pipelined)
     bool timing_valid = false, timed_map = false;
+    // icet_node_push_many_device: per-frame results and kept-row counts of a burst, in HBM until its end, and the events that order the three streams
+    float* d_out_all = nullptr; float* h_out_all = nullptr; int32_t* d_nk_all = nullptr; int32_t* h_nk_all = nullptr; int cap_many = 0;
+    hipEvent_t ev_loop = nullptr, ev_kf = nullptr;
 };
 
 namespace {
@@ -442,6 +453,125 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
     return ICET_OK;
 }
 
+// Post-processing of one solved frame on the host: seed, guard, pose chain (odometry.cpp:82-98, simpleMapMaker.cpp:124-137) -- what push_frame does
+// after its synchronisation, for a frame whose 48 result floats are in `out`.
+void finish_frame_host(icet_node* nd, const float* out, int64_t nk, icet_node_result* res) {
+    std::memset(res, 0, sizeof(*res));
+    float X[6];
+    std::memcpy(X, out, sizeof(X)); std::memcpy(res->pred_stds, out + 6, sizeof(float) * 6);
+    for (int k = 0; k < 6; k++) nd->X0[k] = nd->p.seed_x0 ? X[k] : 0.f;
+    const float tt = nd->p.trans_thresh, rt = nd->p.rot_thresh;
+    if ((tt > 0.f && (std::fabs(X[0]) > tt || std::fabs(X[1]) > tt || std::fabs(X[2]) > tt)) ||
+        (rt > 0.f && (std::fabs(X[3]) > rt || std::fabs(X[4]) > rt || std::fabs(X[5]) > rt))) {
+        for (int k = 0; k < 6; k++) X[k] = 0.f;
+        res->diverged = 1;
+    }
+    float R[9]; euler_R_host(X[3], X[4], X[5], R);
+    const float Hi[16] = {R[0], R[1], R[2], X[0], R[3], R[4], R[5], X[1], R[6], R[7], R[8], X[2], 0, 0, 0, 1};
+    float P[16];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { float acc = 0.f; for (int k = 0; k < 4; k++) acc += nd->pose[r * 4 + k] * Hi[k * 4 + c]; P[r * 4 + c] = acc; }
+    std::memcpy(nd->pose, P, sizeof(P));
+    res->solved = 1; res->n_kept = nk;
+    std::memcpy(res->X, X, sizeof(X)); std::memcpy(res->pose, P, sizeof(P)); quat_of(P, res->quat);
+    res->map_rows = 0;
+}
+
+// A burst of frames without a host round trip between them (the pipelined odometry configuration: range filter, no map, no extra clouds).  What
+// push_frame does per frame -- filter on the node's stream, the loop against the keyframe parked one frame ago on one context, the keyframe of the new
+// scan on the other -- is enqueued for every frame back to back; the seed X0 <- X of the previous frame (odometry.cpp:82) travels device to device,
+// the three streams are ordered by events, every pointer the solve's halves see is the same from frame to frame (so that both replay their captured
+// graphs), and the frames' 48 result floats and kept-row counts are collected in HBM and copied out ONCE.  Seed, guard and pose chain are functions
+// of the X sequence and are evaluated on the host afterwards, frame by frame, exactly as push_frame does.  Same bits as frame-by-frame pushes.
+icet_status push_many_fast(icet_node* nd, const icet_dev_scan* fr, int K, icet_node_result* res) {
+    hipStream_t st = nd->stream;
+    nd->timing_valid = false;
+    int64_t nmax = 0;
+    for (int k = 0; k < K; k++) nmax = std::max<int64_t>(nmax, fr[k].n);
+    for (int w = 0; w < 2; w++) if (w != nd->prev) { icet_status s = ensure_scan(nd, w, nmax); if (s != ICET_OK) return s; }
+    if (nd->cap_scan[nd->prev] < nmax) {
+        // the buffer that holds the previous scan must grow too (it becomes `cur` in the burst's second frame): keep its rows
+        NCHK(nd, hipDeviceSynchronize());
+        const int64_t cap = (nmax + nmax / 8 + 63) / 64 * 64, oldl = nd->ld_scan[nd->prev], rows = nd->n_scan[nd->prev];
+        float* nb = nullptr;
+        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nb), sizeof(float) * 3 * (size_t)cap));
+        if (rows) NCHK(nd, hipMemcpy2D(nb, cap * sizeof(float), nd->d_scan[nd->prev], oldl * sizeof(float), rows * sizeof(float), 3, hipMemcpyDeviceToDevice));
+        NCHK(nd, hipFree(nd->d_scan[nd->prev]));
+        nd->d_scan[nd->prev] = nb; nd->cap_scan[nd->prev] = cap; nd->ld_scan[nd->prev] = cap;
+        // the parked keyframe was built from the old buffer's rows (its tables live in the context): still valid; the loop never reads scan 1 again
+    }
+    const int n_blocks_max = (int)((nmax + kFB * kFRows - 1) / (kFB * kFRows));
+    if (n_blocks_max > nd->cap_blocks) {
+        NCHK(nd, hipStreamSynchronize(st));
+        if (nd->d_counts) NCHK(nd, hipFree(nd->d_counts));
+        if (nd->d_bases) NCHK(nd, hipFree(nd->d_bases));
+        nd->d_counts = nd->d_bases = nullptr;
+        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_counts), sizeof(int32_t) * n_blocks_max));
+        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_bases), sizeof(int32_t) * n_blocks_max));
+        nd->cap_blocks = n_blocks_max;
+    }
+    if (K > nd->cap_many) {
+        NCHK(nd, hipDeviceSynchronize());
+        if (nd->d_out_all) NCHK(nd, hipFree(nd->d_out_all));
+        if (nd->d_nk_all) NCHK(nd, hipFree(nd->d_nk_all));
+        if (nd->h_out_all) NCHK(nd, hipHostFree(nd->h_out_all));
+        if (nd->h_nk_all) NCHK(nd, hipHostFree(nd->h_nk_all));
+        nd->d_out_all = nullptr; nd->d_nk_all = nullptr; nd->h_out_all = nullptr; nd->h_nk_all = nullptr; nd->cap_many = 0;
+        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_out_all), sizeof(float) * 48 * (size_t)K));
+        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_nk_all), sizeof(int32_t) * (size_t)K));
+        NCHK(nd, hipHostMalloc(reinterpret_cast<void**>(&nd->h_out_all), sizeof(float) * 48 * (size_t)K));
+        NCHK(nd, hipHostMalloc(reinterpret_cast<void**>(&nd->h_nk_all), sizeof(int32_t) * (size_t)K));
+        nd->cap_many = K;
+    }
+    if (!nd->ev_loop) { NCHK(nd, hipEventCreateWithFlags(&nd->ev_loop, hipEventDisableTiming)); NCHK(nd, hipEventCreateWithFlags(&nd->ev_kf, hipEventDisableTiming)); }
+    icet_params sp = nd->p.solve; sp.flags = ICET_FLAG_NONE;
+    std::memcpy(nd->h_x0, nd->X0, sizeof(nd->X0));
+    int prev = nd->prev, owner = nd->owner;
+    for (int k = 0; k < K; k++) {
+        const int cur = prev ^ 1;
+        const int64_t n = fr[k].n, ld = fr[k].ld, lcur = nd->cap_scan[cur];
+        icet_ctx* own = nd->kf[owner]; icet_ctx* oth = nd->kf[owner ^ 1];
+        hipStream_t so = reinterpret_cast<hipStream_t>(icet_stream(own)), sk = reinterpret_cast<hipStream_t>(icet_stream(oth));
+        int32_t* d_cnt = nd->d_nkept + cur;
+        // the buffer and the counter this frame's filter writes were last read by frame k - 2 (its loop and its keyframe build); the previous frame's loop ran on
+        // the stream of that keyframe build and after that loop's result: behind ev_loop both are done.  (NOT behind ev_kf: the previous frame's keyframe build
+        // runs beside its loop and may run on beside this filter -- it reads the OTHER buffer.)
+        if (k > 0) NCHK(nd, hipStreamWaitEvent(st, nd->ev_loop, 0));
+        const float *x = fr[k].ptr, *y = x + ld, *z = x + 2 * ld;
+        float* o = nd->d_scan[cur];
+        const int n_blocks = (int)((n + kFB * kFRows - 1) / (kFB * kFRows));
+        if (n > 0) {
+            k_range_count<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_counts);
+            k_range_scan<<<1, kFB, 0, st>>>(nd->d_counts, nd->d_bases, n_blocks, d_cnt, nd->d_nk_all + k);
+            k_range_scatter<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_bases, o, o + lcur, o + 2 * lcur);
+            NCHK(nd, hipGetLastError());
+        }
+        NCHK(nd, hipEventRecord(nd->ev[1], st));
+        NCHK(nd, hipStreamWaitEvent(so, nd->ev[1], 0));
+        NCHK(nd, hipStreamWaitEvent(sk, nd->ev[1], 0));
+        // X0: the node's seed for the burst's first frame, then the previous frame's X (or zeros), device to device
+        if (k == 0) NCHK(nd, hipMemcpyAsync(nd->d_x0, nd->h_x0, sizeof(float) * 6, hipMemcpyHostToDevice, so));
+        else NCHK(nd, hipStreamWaitEvent(so, nd->ev_loop, 0));                       // the previous frame's result and the X0 made from it (on the other context's stream)
+        icet_dev_scan b{nd->d_scan[cur], lcur, lcur};                               // rows: the buffer's capacity as upper bound, the count is read on the device
+        icet_status s = icet_register_device_n(own, &sp, 1, &b, d_cnt, nd->d_x0, nd->d_out);
+        if (s != ICET_OK) { nd->err = icet_last_error(own); return s; }
+        k_burst_collect<<<1, 64, 0, so>>>(nd->d_out, nd->d_out_all + 48 * (size_t)k, nd->d_x0, nd->p.seed_x0 ? 1 : 0);
+        NCHK(nd, hipGetLastError());
+        NCHK(nd, hipEventRecord(nd->ev_loop, so));
+        s = icet_keyframe_device_n(oth, &sp, 1, &b, d_cnt);
+        if (s != ICET_OK) { nd->err = icet_last_error(oth); return s; }
+        NCHK(nd, hipEventRecord(nd->ev_kf, sk));
+        prev = cur; owner ^= 1;
+    }
+    for (icet_ctx* c : nd->kf) NCHK(nd, hipStreamSynchronize(reinterpret_cast<hipStream_t>(icet_stream(c))));
+    NCHK(nd, hipMemcpyAsync(nd->h_out_all, nd->d_out_all, sizeof(float) * 48 * (size_t)K, hipMemcpyDeviceToHost, st));
+    NCHK(nd, hipMemcpyAsync(nd->h_nk_all, nd->d_nk_all, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
+    NCHK(nd, hipStreamSynchronize(st));
+    for (int k = 0; k < K; k++) finish_frame_host(nd, nd->h_out_all + 48 * (size_t)k, nd->h_nk_all[k], &res[k]);
+    nd->prev = prev; nd->owner = owner;
+    nd->n_scan[prev] = nd->h_nk_all[K - 1]; nd->ld_scan[prev] = nd->cap_scan[prev];
+    return ICET_OK;
+}
+
 // No exception may cross the C ABI (std::async can throw std::system_error, the shuffle's vector bad_alloc -- rethrown by get()), and
 // a frame that fails half way must not leave the node's idea of "previous scan" and the parked keyframe disagreeing: on ANY failure
 // the device is drained and the node drops back to "no previous scan" -- the next cloud is stored like the first one
@@ -505,6 +635,12 @@ icet_status icet_node_destroy(icet_node* nd) {
     void* hp[] = {nd->h_nkept, nd->h_out, nd->h_x0, nd->h_idx};
     for (void* q : hp) if (q) (void)hipHostFree(q);
     for (hipEvent_t e : nd->ev) if (e) (void)hipEventDestroy(e);
+    if (nd->ev_loop) (void)hipEventDestroy(nd->ev_loop);
+    if (nd->ev_kf) (void)hipEventDestroy(nd->ev_kf);
+    if (nd->d_out_all) (void)hipFree(nd->d_out_all);
+    if (nd->d_nk_all) (void)hipFree(nd->d_nk_all);
+    if (nd->h_out_all) (void)hipHostFree(nd->h_out_all);
+    if (nd->h_nk_all) (void)hipHostFree(nd->h_nk_all);
     for (icet_ctx* k : nd->kf) if (k) (void)icet_destroy(k);
     delete nd;
     return ICET_OK;
@@ -514,6 +650,32 @@ icet_status icet_node_push_device(icet_node* nd, const float* d_scan, int64_t n,
     if (!nd || !res || n < 0 || ld < n || (n > 0 && !d_scan) || n >= ((int64_t)1 << 30)) return ICET_ERR_BAD_ARG;
     if (hipSetDevice(nd->device) != hipSuccess) return ICET_ERR_NO_DEVICE;
     return push_device(nd, d_scan, n, ld, res);
+}
+
+icet_status icet_node_push_many_device(icet_node* nd, const icet_dev_scan* frames, int32_t n_frames, icet_node_result* results) {
+    if (!nd || n_frames < 0 || (n_frames > 0 && (!frames || !results))) return ICET_ERR_BAD_ARG;
+    for (int k = 0; k < n_frames; k++)
+        if (frames[k].n < 0 || frames[k].ld < frames[k].n || (frames[k].n > 0 && !frames[k].ptr) || frames[k].n >= ((int64_t)1 << 30)) return ICET_ERR_BAD_ARG;
+    if (hipSetDevice(nd->device) != hipSuccess) return ICET_ERR_NO_DEVICE;
+    int k0 = 0;
+    // what cannot go through the burst path -- the very first cloud (stored, not solved), an empty cloud, and every configuration whose frame needs the host
+    // in the middle (map queue, aligned cloud, snail trail, no range filter, no pipeline) -- goes frame by frame
+    const bool fast_cfg = nd->pipelined && nd->p.map_capacity == 0 && !(nd->p.flags & (ICET_NODE_NO_RANGE_FILTER | ICET_NODE_ALIGNED_CLOUD | ICET_NODE_SNAIL_TRAIL));
+    bool all_nonempty = true;
+    for (int k = 0; k < n_frames; k++) all_nonempty = all_nonempty && frames[k].n > 0;
+    if (!fast_cfg || !all_nonempty) {
+        for (int k = 0; k < n_frames; k++) { icet_status s = push_device(nd, frames[k].ptr, frames[k].n, frames[k].ld, &results[k]); if (s != ICET_OK) return s; }
+        return ICET_OK;
+    }
+    if (!nd->initialized && n_frames > 0) { icet_status s = push_device(nd, frames[0].ptr, frames[0].n, frames[0].ld, &results[0]); if (s != ICET_OK) return s; k0 = 1; }
+    if (k0 >= n_frames) return ICET_OK;
+    icet_status s;
+    try {
+        s = push_many_fast(nd, frames + k0, n_frames - k0, results + k0);
+    } catch (const std::bad_alloc&) { nd->err = "out of host memory"; s = ICET_ERR_NOMEM;
+    } catch (...) { nd->err = "host error"; s = ICET_ERR_NOMEM; }
+    if (s != ICET_OK) { (void)hipDeviceSynchronize(); nd->initialized = false; nd->timing_valid = false; }
+    return s;
 }
 
 icet_status icet_node_push(icet_node* nd, const float* scan, int64_t n, int64_t ld, icet_node_result* res) {

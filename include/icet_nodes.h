@@ -69,6 +69,14 @@ icet_status icet_node_destroy(icet_node* node);
 icet_status icet_node_push(icet_node* node, const float* scan, int64_t n, int64_t ld, icet_node_result* res);
 icet_status icet_node_push_device(icet_node* node, const float* d_scan, int64_t n, int64_t ld, icet_node_result* res);
 
+/* A BURST of frames, device pointers, results for all of them at the end: what a caller gets that replays a log, batches frames between
+ * publications, or simply does not want the host between two frames.  For the pipelined odometry configuration (range filter on, no map queue, no
+ * aligned cloud / snail trail) the frames are chained on the device -- X0 <- X of the previous frame (odometry.cpp:82) travels device to device, the
+ * per-frame results wait in HBM, ONE copy and one synchronisation at the end -- and seed, guard and pose chain are evaluated on the host afterwards,
+ * frame by frame, with the bits of frame-by-frame pushes.  Any other configuration is pushed frame by frame by the call.  Every frame's buffer must
+ * stay valid until the call returns.  results[k] belongs to frames[k] (a first-ever frame: solved = 0). */
+icet_status icet_node_push_many_device(icet_node* node, const icet_dev_scan* frames, int32_t n_frames, icet_node_result* results);
+
 /* `EigenQueue::getQueue()` (simpleMapMaker.cpp:43-50): copies the valid rows, oldest first, to the host as rows x 3
  * column-major with leading dimension `ld` (>= rows).  `out` may be NULL to query `rows` only. */
 icet_status icet_node_map(icet_node* node, float* out, int64_t ld, int64_t* rows);

@@ -155,6 +155,41 @@ def test_gpu_odometry_node_matches_oracle(gpu_ctx, seq64):
 
 
 @pytest.mark.gpu
+def test_gpu_odometry_burst_equals_frame_by_frame(gpu_ctx, seq64):
+    """icet_node_push_many_device: the frames of a burst chained on the device (X0 <- X device to device, one copy of all results at the end) must give the
+    bits of frame-by-frame pushes -- X, pred_stds, pose, quaternion, kept rows, the stored previous scan -- for the burst started cold (first cloud inside the
+    burst), for a burst after single pushes, for two bursts in a row and for a single push after a burst; configurations that need the host inside a frame
+    (the map maker) go frame by frame through the same entry."""
+    from icet_amd import api
+    dev = torch.device("cuda", 0)
+    seq = seq64 + _sequence(7, rings=64, steps=2048)[4:]              # seven frames of the same drive
+    bufs = [torch.from_numpy(np.ascontiguousarray(s.T)).to(dev) for s in seq]
+    fr = [(b.data_ptr(), b.shape[1], b.shape[1]) for b in bufs]
+    ref_node = api.Node(gpu_ctx, **api.ODOMETRY_NODE)
+    ref = [ref_node.push_device(*f) for f in fr]
+    ref_prev = ref_node.prev_scan()
+    ref_node.close()
+    def same(a, b):
+        return all(np.array_equal(a[k], b[k]) for k in ("X", "pred_stds", "pose", "quat")) and a["solved"] == b["solved"] and a["n_kept"] == b["n_kept"] and a["diverged"] == b["diverged"]
+    for split in ((len(fr),), (1, len(fr) - 1), (2, 1, len(fr) - 3), (1, 2, len(fr) - 3)):
+        nd = api.Node(gpu_ctx, **api.ODOMETRY_NODE)
+        got, k = [], 0
+        for j, m in enumerate(split):
+            if m == 1 and j % 2 == 1:
+                got.append(nd.push_device(*fr[k]))                      # a single push between bursts
+            else:
+                got += nd.push_many_device(fr[k:k + m])
+            k += m
+        assert len(got) == len(ref) and all(same(a, b) for a, b in zip(got, ref)), split
+        assert np.array_equal(nd.prev_scan(), ref_prev)
+        nd.close()
+    mm, mref = api.Node(gpu_ctx, **api.MAP_MAKER_NODE), api.Node(gpu_ctx, **api.MAP_MAKER_NODE)
+    a = mm.push_many_device(fr[:3]); b = [mref.push_device(*f) for f in fr[:3]]
+    assert all(same(x, y) for x, y in zip(a, b)) and np.array_equal(mm.map(), mref.map())
+    mm.close(); mref.close()
+
+
+@pytest.mark.gpu
 def test_gpu_map_maker_node_matches_oracle(gpu_ctx, seq64):
     from oracle import pyoracle as po
     from icet_amd import api

@@ -243,6 +243,15 @@ icet_status ensure_thresholds(icet_ctx* c, int T, int P) {
     build_thresholds(P, M_PI, h.data() + T + 1);
     HIPCHK(c, dev_realloc(w.thr, h.size()));
     HIPCHK(c, hipMemcpy(w.thr, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    // the voxel of an exact-zero row, by the sign bits of (y, x): r = 0, phi = acos(NaN) -> 1000, theta = atan2(+-0, +-0) (src/utils.cpp:103-116) binned as
+    // sortSphericalCoordinates bins them (src/icet.cpp:545-546) -- the formulas of theta_cr / phi_cr / voxel_of (icet_device_common.h) in host arithmetic
+    for (int k = 0; k < 4; k++) {
+        float th = (float)std::atan2((k & 2) ? -0.0 : 0.0, (k & 1) ? -0.0 : 0.0);
+        if (th < 0.0f) th = (float)((double)th + 2.0 * M_PI);
+        const float ph = 1000.0f;
+        const int bt = static_cast<int>(((double)th / (2.0 * M_PI)) * (double)T) % T, bp = static_cast<int>(((double)ph / M_PI) * (double)P) % P;
+        w.zero_voxel[k] = T * bp + bt;
+    }
     w.thr_T = T; w.thr_P = P;
     return ICET_OK;
 }

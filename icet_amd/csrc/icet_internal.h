@@ -123,6 +123,7 @@ struct Workspace {
     float* thr = nullptr; int thr_T = 0, thr_P = 0;   // bin-edge tables: T+1 azimuth thresholds, then P+1 polar thresholds
     void* lut = nullptr; int lut_Mt = 0, lut_Mp = 0;  // classification LUTs of k_gn_accumulate: Mt azimuth cells, then Mp polar cells (8 B each)
     float guard_t = 0.f, guard_p = 0.f;               // guard bands (diamond-angle / cosine units) around voxel edges
+    int zero_voxel[4] = {0, 0, 0, 0};                 // voxel of an exact-zero row by the sign bits of (y, x) (ensure_thresholds)
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
 };
 

@@ -44,11 +44,13 @@ __device__ __noinline__ int voxel_literal(float px, float py, float pz, float r_
     return voxel_of(theta_cr(py, px), phi_cr(pz, r_raw), T, P);
 }
 
+__device__ __forceinline__ int zero_voxel_of(int patt, const int4& zv) { return patt == 0 ? zv.x : (patt == 1 ? zv.y : (patt == 2 ? zv.z : zv.w)); }
+
 __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __restrict__ desc, float* __restrict__ r1,
                                                             unsigned long long* __restrict__ key64, uint32_t* __restrict__ key32,
                                                             uint32_t* __restrict__ val, uint16_t* __restrict__ bin16, int T, int P, int n_pairs, int chunks,
                                                             const uint32_t* __restrict__ splitters, uint8_t* __restrict__ bkt, uint32_t* __restrict__ counts,
-                                                            const LutCell* __restrict__ lut, int Mt, int Mp, float guard_t, float guard_p, int32_t* __restrict__ tile_vr) {
+                                                            const LutCell* __restrict__ lut, int Mt, int Mp, float guard_t, float guard_p, int32_t* __restrict__ tile_vr, int4 zv) {
     // First step of the rank sort fused in (icet_ranksort.hip): the pair's splitters are already known (k_rs_splitters
     // samples the radii straight from the Cartesian rows), so each row's bucket and this tile's bucket histogram cost no
     // extra pass over r1[].  splitters == nullptr: library-sort diagnostic path, nothing of this is needed.
@@ -67,13 +69,10 @@ __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __re
         __syncthreads();
     }
     const float cell_t = (float)Mt * 0.25f, cell_p = (float)Mp * 0.5f;
-    // the voxel of an exact-zero row: r = 0, phi = acos(NaN) -> 1000, theta = atan2(+-0, +-0) -- a function of the two sign bits.  A real scan holds
+    // the voxel of an exact-zero row: r = 0, phi = acos(NaN) -> 1000, theta = atan2(+-0, +-0) -- a function of the two sign bits, tabulated by the host (zv)
     // (x = y = +-0 exactly -- not a tiny vector whose squares underflow: its theta is a real angle; z does not matter: z / 0 is NaN or +-inf, acos of either NaN).  A real scan holds
     // thousands of such rows (invalid returns; 18 % of the reference's sample_pc scans): sent through voxel_literal one by one they put the
     // double-precision atan2 / acos into nearly every wave (205 us per 256 real pairs against 123 on synthetic scans)
-    __shared__ int s_zero_voxel[4];
-    if (threadIdx.x < 4) s_zero_voxel[threadIdx.x] = voxel_literal((threadIdx.x & 1) ? -0.f : 0.f, (threadIdx.x & 2) ? -0.f : 0.f, 0.f, 0.f, T, P);
-    __syncthreads();
     int vlo = 0x7FFFFFFF, vhi = -1;                                   // voxel ids this thread has seen
     ICET_FOR_CHUNK_OF_SCAN1(i) {
         const float* x = d.s1; const float* y = d.s1 + d.ld1; const float* z = d.s1 + 2 * (size_t)d.ld1;
@@ -88,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void k_scan1_spherical(const PairDesc* __re
                               lut_t, lut_p, cell_t, cell_p, T, guard_t, guard_p, bt, prow, near);
         near = near | !ordinary;
         int v = prow + bt;
-        if (near) v = ((rr == 0.f) & (px == 0.f) & (py == 0.f)) ? s_zero_voxel[(__builtin_signbit(py) ? 2 : 0) | (__builtin_signbit(px) ? 1 : 0)] : voxel_literal(px, py, pz, rr, T, P);
+        if (near) v = ((rr == 0.f) & (px == 0.f) & (py == 0.f)) ? zero_voxel_of((__builtin_signbit(py) ? 2 : 0) | (__builtin_signbit(px) ? 1 : 0), zv) : voxel_literal(px, py, pz, rr, T, P);
         const float r = (rr != rr) ? 1000.0f : rr;                      // src/utils.cpp:116
         size_t o = (size_t)d.off1 + i;
         r1[o] = r;
@@ -1326,7 +1325,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
     }
     k_scan1_spherical<<<grid, blk, scan1_lds_bytes(w), st>>>(w.desc, w.r1, (batch && c.use_library_sort) ? w.key64A : nullptr, c.use_library_sort ? w.keyA : nullptr, w.valA, w.bin16,
                                                               c.T, c.P, np, chunks, c.use_library_sort ? nullptr : w.splitters, w.bkt, w.counts,
-                                                              reinterpret_cast<const LutCell*>(w.lut), w.lut_Mt, w.lut_Mp, w.guard_t, w.guard_p, w.tile_vr);
+                                                              reinterpret_cast<const LutCell*>(w.lut), w.lut_Mt, w.lut_Mp, w.guard_t, w.guard_p, w.tile_vr, make_int4(w.zero_voxel[0], w.zero_voxel[1], w.zero_voxel[2], w.zero_voxel[3]));
     ICET_LAUNCH_CHECK();
     if (c.stage_event && c.stage_at == 4) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
     if (c.use_library_sort) {

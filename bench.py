@@ -93,6 +93,37 @@ def plan_launch(args, env):
     return "run", "rank of a %s-rank launch" % world
 
 
+
+def measure_traffic_live(timeout_s=240):
+    """HBM bytes per k_gn_accumulate launch, measured NOW on this box: two child runs of this script under `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE and
+    WRITE_SIZE in separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled: on gfx950 it reports half the bytes of a 16-B/lane
+    coalesced streaming read), each over the default workload's whole-batch launches.  Returns (bytes, note) or (None, why)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    vals = {}
+    env = dict(os.environ); env["TMPDIR"] = "/tmp"; env["ICET_BENCH_CHILD"] = "1"
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="icet_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3", os.path.abspath(__file__),
+               "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-latency", "--no-h2d", "--min-timed-s", "0"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+        except Exception as e:
+            return None, "rocprofv3 %s pass: %s" % (counter, type(e).__name__)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, "rocprofv3 %s pass failed (rc %d)" % (counter, r.returncode)
+        v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0], newline="")) if "k_gn_accumulate" in row["Kernel_Name"] and row["Counter_Name"] == counter]
+        shutil.rmtree(d, ignore_errors=True)
+        if not v:
+            return None, "no k_gn_accumulate rows in the %s pass" % counter
+        v = [x for x in v if x >= 0.6 * max(v)]              # the whole-batch launches (the timed steps); parts of other steps are smaller
+        vals[counter] = sum(v) / len(v)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per launch"
+
+
 def run_nodes(args):
     """--workload odometry | mapmaker: the per-frame body of the reference's two nodes (include/icet_nodes.h).
     A step is ONE lidar frame pushed from HBM: range filter -> ICET(prev, cur) -> pose chain (-> 600k-row map update).
@@ -440,12 +471,18 @@ def main(argv=None):
     bytes_per_launch = 12.0 * float(sum(n2_timed))
     achieved = bytes_per_launch / (acc_launch_ms * 1e-3) / 1e9 if acc_launch_ms > 0 else 0.0
     bytes_path = sum(12.0 * a + 12.0 * b * iters + 192.0 for a, b in zip(n1, n2)) * (1 if multi else world)      # whole job
-    traffic = None
+    traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and args.workload == "batch" and n_local == 256 and args.distinct == 0:
-        # PMC numbers are collected by profiles/collect.sh on exactly this workload (256 distinct pairs per GPU)
+    default_workload = args.workload == "batch" and n_local == 256 and args.distinct == 0 and not args.set and not args.flags and args.order == "ring"
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)      # no profiler inside a profiled run
+    if default_workload and rank == 0 and n_gpus == 1 and not args.no_latency and not os.environ.get("ICET_BENCH_CHILD") and not under_profiler:
+        # measured live (review r4, weak 9: the number used to come from a file a builder-side profile run had left behind)
+        traffic, traffic_note = measure_traffic_live()
+    if traffic is None and os.path.exists(tpath) and args.workload == "batch" and n_local == 256 and args.distinct == 0:
+        # fallback: the PMC numbers profiles/collect.sh collected on exactly this workload (256 distinct pairs per GPU)
         try:
             traffic = json.load(open(tpath)).get("k_gn_accumulate_bytes_per_launch")
+            traffic_note = "from profiles/traffic_latest.json (a builder-side rocprofv3 --pmc run of this workload)" + ((": live measurement unavailable: " + traffic_note) if traffic_note else "")
         except Exception:
             traffic = None
 
@@ -807,7 +844,7 @@ def main(argv=None):
                        "collective": collective_note or ("rccl" if (world > 1 and backend == "nccl") else (backend if world > 1 else None)),
                        "gen_s": round(t_gen, 1)},
             "roofline": {"kernel": "k_gn_accumulate", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(acc_launch_ms, 5), "launches_timed": launches,
                          "whole_path_GBs": round(bytes_path / (ms_per_step * 1e-3) / 1e9, 1),
                          "keyframe_ms_per_step": round(kf_ms / reps, 4), "gn_loop_ms_per_step": round(gn_ms / reps, 4)},

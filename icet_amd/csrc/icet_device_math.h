@@ -353,12 +353,12 @@ __device__ inline void pinv3_sym_fast(const float a[6], float rel_tol, float w[6
 // norm down-dating; rank = pivots above eps * min(rows, cols) * the largest pivot; minimum-norm completion of a rank-deficient R) in plain
 // IEEE float operations without contraction, so that on the same (HTWH, HTWdz) bits the result -- the rank decision, the number of pruned
 // axes, the SIGN of the eigenvector added to pred_stds -- does not depend on which side evaluated it (checked bit for bit against the CPU
-// checker over condition numbers 3e5 .. 3e7, tests/test_gpu_parity.py::test_gn_tail_literal_bits).  Rounds 2-4 used an eigenvalue rule
+// checker over condition numbers 5e4 .. 3e7, tests/test_gpu_parity.py::test_gn_tail_literal_bits).  Rounds 2-4 used an eigenvalue rule
 // (|lambda_k| > 6 eps lambda_max) for the rank here; scripts/rank_rule_study.py finds it disagreeing with the pivot rule on 35 of 8400
 // matrices around cond = 1.4e6 = 1 / (6 eps), right above checkCondition's cutoff.
 // Rare by construction (a tunnel, a single wall, open ground), so it is written for fidelity, not speed: generic small matrices in scratch.
 
-// Every array of the literal tail lives in ONE workspace the caller places in LDS and ONE lane walks through it: no scratch memory in the
+// Every array of the literal tail lives in ONE workspace the caller places in LDS and one WAVE walks through it: no scratch memory in the
 // kernels that hold this rarely taken branch (as local arrays it cost k_gn_solve 3.5 KB of scratch per lane, and arrays of the hot Cholesky
 // route whose address escaped into the call would have left their registers).
 struct GnTailWs {
@@ -370,27 +370,38 @@ struct GnTailWs {
     float U2[36], L2[36], lam[36], U2t[36], T1[36], innards[36], inv[36], T2[36], lhs[36];
 };
 
-// C (ar x bc) = A (ar x ac) * B (ac x bc), row-major, each entry a sequential float sum starting from 0 in index order (zero terms included)
-__device__ inline void mm_seq(const float* A, int ar, int ac, const float* B, int bc, float* C) {
+// The wave walks the workspace TOGETHER (round 5b; one lane alone took 157 us per evaluation, half of it in the six small matrix products): whatever is
+// independent per column or per element -- a product's 36 entries, a Householder reflector applied to the columns right of the pivot, the back
+// substitution of each right-hand side -- goes to one lane per column / element, each with ITS sequential order of float operations unchanged, so the bits
+// are the single lane's; scalar decisions (pivot search, the reflector's norm, rank) are evaluated by every lane on the same LDS words.  Between phases a
+// wave-level fence: LDS operations of one wave complete in program order, the fence keeps the compiler from moving or caching them.
+#define ICET_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// C (ar x bc) = A (ar x ac) * B (ac x bc), row-major, each entry a sequential float sum starting from 0 in index order (zero terms included); one lane per entry
+__device__ inline void mm_seq(const float* A, int ar, int ac, const float* B, int bc, float* C, int lane) {
 #pragma clang fp contract(off)
-    for (int i = 0; i < ar; i++)
-        for (int j = 0; j < bc; j++) {
-            float s = 0.f;
-            for (int k = 0; k < ac; k++) s += A[i * ac + k] * B[k * bc + j];
-            C[i * bc + j] = s;
-        }
+    if (lane < ar * bc) {
+        const int i = lane / bc, j = lane - i * bc;
+        float s = 0.f;
+        for (int k = 0; k < ac; k++) s += A[i * ac + k] * B[k * bc + j];
+        C[i * bc + j] = s;
+    }
+    ICET_WSYNC();
 }
 
-// CompleteOrthogonalDecomposition<MatrixXf>(A).pseudoInverse() for A rows x cols (<= 6 x 6, row-major); out is cols x rows.  Returns the rank.
-__device__ inline int cod_pinv(const float* Ain, int rows, int cols, float* pinv, GnTailWs& w) {
+// CompleteOrthogonalDecomposition<MatrixXf>(A).pseudoInverse() for A rows x cols (<= 6 x 6, row-major); out is cols x rows.  Returns the rank (wave-uniform).
+__device__ inline int cod_pinv(const float* Ain, int rows, int cols, float* pinv, GnTailWs& w, int lane) {
 #pragma clang fp contract(off)
     const int size = rows < cols ? rows : cols;
     float* qr = w.qr; float* hc = w.hc; int* perm = w.perm; float* normsUpd = w.nUpd; float* normsDir = w.nDir;
-    for (int i = 0; i < rows * cols; i++) qr[i] = Ain[i];
-    for (int k = 0; k < cols; k++) {
+    if (lane < rows * cols) qr[lane] = Ain[lane];
+    ICET_WSYNC();
+    if (lane < cols) {
+        const int k = lane;
         float s = 0.f; for (int i = 0; i < rows; i++) s += qr[i * cols + k] * qr[i * cols + k];
         normsDir[k] = sqrtf(s); normsUpd[k] = normsDir[k]; perm[k] = k;
     }
+    ICET_WSYNC();
     float maxn = 0.f; for (int k = 0; k < cols; k++) maxn = fmaxf(maxn, normsUpd[k]);      // (NaN norms: fmaxf and std::max(a, b) = (a < b) ? b : a both keep the running value)
     const float th = maxn * FLT_EPSILON; const float threshold_helper = (th * th) / float(rows);
     const float norm_downdate_threshold = 3.4526698300124393e-04f;                          // sqrt(FLT_EPSILON), correctly rounded
@@ -400,129 +411,170 @@ __device__ inline int cod_pinv(const float* Ain, int rows, int cols, float* pinv
         for (int j = k + 1; j < cols; j++) if (normsUpd[j] > bn) { bn = normsUpd[j]; big = j; }
         const float big_sq = bn * bn;
         if (nonzero_pivots == size && big_sq < threshold_helper * float(rows - k)) nonzero_pivots = k;
-        if (k != big) {
-            for (int i = 0; i < rows; i++) { const float t = qr[i * cols + k]; qr[i * cols + k] = qr[i * cols + big]; qr[i * cols + big] = t; }
-            { float t = normsUpd[k]; normsUpd[k] = normsUpd[big]; normsUpd[big] = t; t = normsDir[k]; normsDir[k] = normsDir[big]; normsDir[big] = t; }
-            { const int t = perm[k]; perm[k] = perm[big]; perm[big] = t; }
+        if (k != big) {                                           // (wave-uniform)
+            float t0 = 0.f, t1 = 0.f;
+            if (lane < rows) { t0 = qr[lane * cols + k]; t1 = qr[lane * cols + big]; }
+            const float u0 = normsUpd[k], u1 = normsUpd[big], d0 = normsDir[k], d1 = normsDir[big]; const int p0 = perm[k], p1 = perm[big];
+            ICET_WSYNC();
+            if (lane < rows) { qr[lane * cols + k] = t1; qr[lane * cols + big] = t0; }
+            if (lane == 0) { normsUpd[k] = u1; normsUpd[big] = u0; normsDir[k] = d1; normsDir[big] = d0; perm[k] = p1; perm[big] = p0; }
+            ICET_WSYNC();
         }
+        // make_householder on column k, rows k .. rows - 1: the scalars by every lane, the essential part one lane per entry
+        const int m = rows - k;
+        float tailSq = 0.f;
+        for (int i = 1; i < m; i++) { const float x = qr[(k + i) * cols + k]; tailSq += x * x; }
+        const float c0 = qr[k * cols + k];
         float tau, beta;
-        make_householder(&qr[k * cols + k], rows - k, cols, tau, beta);
-        qr[k * cols + k] = beta;
+        const bool flat = tailSq <= FLT_MIN;
+        if (flat) { tau = 0.f; beta = c0; }
+        else { beta = sqrtf(c0 * c0 + tailSq); if (c0 >= 0.f) beta = -beta; tau = (beta - c0) / beta; }
+        ICET_WSYNC();
+        if (lane >= 1 && lane < m) { const int at = (k + lane) * cols + k; qr[at] = flat ? 0.f : qr[at] / (c0 - beta); }
+        if (lane == 0) { qr[k * cols + k] = beta; hc[k] = tau; }
         if (fabsf(beta) > maxpivot) maxpivot = fabsf(beta);
-        hc[k] = tau;
-        for (int j = k + 1; j < cols; j++) {                      // H = I - tau v v^T on the bottom-right corner
-            float s = qr[k * cols + j];
-            for (int i = k + 1; i < rows; i++) s += qr[i * cols + k] * qr[i * cols + j];
-            s *= tau;
-            qr[k * cols + j] -= s;
-            for (int i = k + 1; i < rows; i++) qr[i * cols + j] -= s * qr[i * cols + k];
-        }
-        for (int j = k + 1; j < cols; ++j) {
-            if (normsUpd[j] != 0.f) {
+        ICET_WSYNC();
+        if (lane > k && lane < cols) {                            // H = I - tau v v^T on the bottom-right corner, a lane per column
+            const int j = lane;
+            float sdot = qr[k * cols + j];
+            for (int i = k + 1; i < rows; i++) sdot += qr[i * cols + k] * qr[i * cols + j];
+            sdot *= tau;
+            qr[k * cols + j] -= sdot;
+            for (int i = k + 1; i < rows; i++) qr[i * cols + j] -= sdot * qr[i * cols + k];
+            if (normsUpd[j] != 0.f) {                             // norm down-dating of the same column
                 float temp = fabsf(qr[k * cols + j]) / normsUpd[j];
                 temp = (1.f + temp) * (1.f - temp);
                 temp = temp < 0.f ? 0.f : temp;
                 const float ratio = normsUpd[j] / normsDir[j];
                 const float temp2 = temp * ratio * ratio;
                 if (temp2 <= norm_downdate_threshold) {
-                    float s = 0.f; for (int i = k + 1; i < rows; i++) s += qr[i * cols + j] * qr[i * cols + j];
-                    normsDir[j] = sqrtf(s); normsUpd[j] = normsDir[j];
+                    float s2 = 0.f; for (int i = k + 1; i < rows; i++) s2 += qr[i * cols + j] * qr[i * cols + j];
+                    normsDir[j] = sqrtf(s2); normsUpd[j] = normsDir[j];
                 } else {
                     normsUpd[j] *= sqrtf(temp);
                 }
             }
         }
+        ICET_WSYNC();
     }
     const float premult = fabsf(maxpivot) * (FLT_EPSILON * float(size));
     int rank = 0;
     for (int i = 0; i < nonzero_pivots; i++) rank += (fabsf(qr[i * cols + i]) > premult) ? 1 : 0;
-    for (int i = 0; i < cols * rows; i++) pinv[i] = 0.f;
+    if (lane < cols * rows) pinv[lane] = 0.f;
+    ICET_WSYNC();
     if (rank == 0) return 0;
     float* C = w.C;                                               // Q^T restricted to the first `rank` reflectors, applied to I (rows x rows)
-    for (int i = 0; i < rows * rows; i++) C[i] = 0.f;
-    for (int i = 0; i < rows; i++) C[i * rows + i] = 1.f;
-    for (int k = 0; k < rank; k++)
-        for (int j = 0; j < rows; j++) {
-            float s = C[k * rows + j];
-            for (int i = k + 1; i < rows; i++) s += qr[i * cols + k] * C[i * rows + j];
-            s *= hc[k];
-            C[k * rows + j] -= s;
-            for (int i = k + 1; i < rows; i++) C[i * rows + j] -= s * qr[i * cols + k];
+    if (lane < rows * rows) C[lane] = (lane / rows == lane % rows) ? 1.f : 0.f;
+    ICET_WSYNC();
+    for (int k = 0; k < rank; k++) {
+        if (lane < rows) {
+            const int j = lane;
+            float sd = C[k * rows + j];
+            for (int i = k + 1; i < rows; i++) sd += qr[i * cols + k] * C[i * rows + j];
+            sd *= hc[k];
+            C[k * rows + j] -= sd;
+            for (int i = k + 1; i < rows; i++) C[i * rows + j] -= sd * qr[i * cols + k];
         }
+        ICET_WSYNC();
+    }
     float* Y = w.Y;                                               // permuted solution, cols x rows
-    for (int i = 0; i < cols * rows; i++) Y[i] = 0.f;
+    if (lane < cols * rows) Y[lane] = 0.f;
+    ICET_WSYNC();
     if (rank == cols) {
-        for (int j = 0; j < rows; j++)
+        if (lane < rows) {
+            const int j = lane;
             for (int i = rank - 1; i >= 0; i--) {
-                float s = C[i * rows + j];
-                for (int t = i + 1; t < rank; t++) s -= qr[i * cols + t] * Y[t * rows + j];
-                Y[i * rows + j] = s / qr[i * cols + i];
+                float sd = C[i * rows + j];
+                for (int t = i + 1; t < rank; t++) sd -= qr[i * cols + t] * Y[t * rows + j];
+                Y[i * rows + j] = sd / qr[i * cols + i];
             }
+        }
+        ICET_WSYNC();
     } else {
         // X = [R11 R12] (rank x cols); X^+ = X^T (X X^T)^-1 in double (what the Z-reflector stage of Eigen's COD yields); Y = X^+ C(0:rank, :)
         double* G = w.G; double* Ginv = w.Ginv;
-        for (int i = 0; i < rank; i++) for (int j = 0; j < rank; j++) {
-            double s = 0; for (int t = 0; t < cols; t++) { const double xi = (t >= i) ? (double)qr[i * cols + t] : 0.0, xj = (t >= j) ? (double)qr[j * cols + t] : 0.0; s += xi * xj; }
-            G[i * rank + j] = s; Ginv[i * rank + j] = (i == j) ? 1.0 : 0.0;
+        if (lane < rank * rank) {
+            const int i = lane / rank, j = lane - i * rank;
+            double sd = 0; for (int t = 0; t < cols; t++) { const double xi = (t >= i) ? (double)qr[i * cols + t] : 0.0, xj = (t >= j) ? (double)qr[j * cols + t] : 0.0; sd += xi * xj; }
+            G[i * rank + j] = sd; Ginv[i * rank + j] = (i == j) ? 1.0 : 0.0;
         }
-        for (int p = 0; p < rank; p++) {                          // Gauss-Jordan with partial pivoting (G is SPD)
+        ICET_WSYNC();
+        for (int p = 0; p < rank; p++) {                          // Gauss-Jordan with partial pivoting (G is SPD); row operations: a lane per entry
             int piv = p; for (int i = p + 1; i < rank; i++) if (fabs(G[i * rank + p]) > fabs(G[piv * rank + p])) piv = i;
-            if (piv != p) for (int j = 0; j < rank; j++) {
-                double t = G[p * rank + j]; G[p * rank + j] = G[piv * rank + j]; G[piv * rank + j] = t;
-                t = Ginv[p * rank + j]; Ginv[p * rank + j] = Ginv[piv * rank + j]; Ginv[piv * rank + j] = t;
+            if (piv != p) {
+                double g0 = 0, g1 = 0, h0 = 0, h1 = 0;
+                if (lane < rank) { g0 = G[p * rank + lane]; g1 = G[piv * rank + lane]; h0 = Ginv[p * rank + lane]; h1 = Ginv[piv * rank + lane]; }
+                ICET_WSYNC();
+                if (lane < rank) { G[p * rank + lane] = g1; G[piv * rank + lane] = g0; Ginv[p * rank + lane] = h1; Ginv[piv * rank + lane] = h0; }
+                ICET_WSYNC();
             }
             const double d = G[p * rank + p];
-            for (int j = 0; j < rank; j++) { G[p * rank + j] /= d; Ginv[p * rank + j] /= d; }
-            for (int i = 0; i < rank; i++) if (i != p) {
-                const double f = G[i * rank + p];
-                for (int j = 0; j < rank; j++) { G[i * rank + j] -= f * G[p * rank + j]; Ginv[i * rank + j] -= f * Ginv[p * rank + j]; }
-            }
+            ICET_WSYNC();
+            if (lane < rank) { G[p * rank + lane] /= d; Ginv[p * rank + lane] /= d; }
+            ICET_WSYNC();
+            double f = 0, gp = 0, hp = 0; bool mine = false; int ii = 0, jj = 0;
+            if (lane < rank * rank) { ii = lane / rank; jj = lane - ii * rank; mine = ii != p; if (mine) { f = G[ii * rank + p]; gp = G[p * rank + jj]; hp = Ginv[p * rank + jj]; } }
+            ICET_WSYNC();
+            if (mine) { G[ii * rank + jj] -= f * gp; Ginv[ii * rank + jj] -= f * hp; }
+            ICET_WSYNC();
         }
-        for (int t = 0; t < cols; t++) for (int j = 0; j < rows; j++) {
-            double s = 0;
+        if (lane < cols * rows) {
+            const int t = lane / rows, j = lane - t * rows;
+            double sd = 0;
             for (int i = 0; i < rank; i++) {
                 const double xit = (t >= i) ? (double)qr[i * cols + t] : 0.0;
-                double ww = 0; for (int m = 0; m < rank; m++) ww += Ginv[i * rank + m] * (double)C[m * rows + j];
-                s += xit * ww;
+                double ww = 0; for (int mm = 0; mm < rank; mm++) ww += Ginv[i * rank + mm] * (double)C[mm * rows + j];
+                sd += xit * ww;
             }
-            Y[t * rows + j] = (float)s;
+            Y[t * rows + j] = (float)sd;
         }
+        ICET_WSYNC();
     }
-    for (int k = 0; k < cols; k++) for (int j = 0; j < rows; j++) pinv[perm[k] * rows + j] = Y[k * rows + j];
+    if (lane < cols * rows) { const int k = lane / rows, j = lane - k * rows; pinv[perm[k] * rows + j] = Y[k * rows + j]; }
+    ICET_WSYNC();
     return rank;
 }
 
 // src/icet.cpp:410-430 for the (H, g) in the workspace: cov = noise_mat, ps = pred_stds (after checkCondition's additions), dx, ev = eigenvalues
-// ascending, pruned = number of pruned axes, rank = the COD rank of HTWH.  Call from ONE lane.
+// ascending, pruned = number of pruned axes, rank = the COD rank of HTWH.  Call from a WHOLE wave (wave-uniform control flow).
 __device__ __noinline__ void gn_tail_literal(GnTailWs& w) {
 #pragma clang fp contract(off)
-    w.rank = cod_pinv(w.H, 6, 6, w.cov, w);
-    for (int k = 0; k < 6; k++) w.ps[k] = sqrtf(fabsf(w.cov[k * 6 + k]));
+    const int lane = (int)(threadIdx.x & 63u);
+    const int rank = cod_pinv(w.H, 6, 6, w.cov, w, lane);
     float* U2 = w.U2; float* ev = w.ev;
-    eig6_sym_core<true>(w.H, ev, U2, w.A, w.sm);
-    int k0 = 0;
-    {
-        float condition = ev[5] / ev[0];
-        int eyecount = 1;
-        while (fabsf(condition) > 1e6f && eyecount < 6) {
-            for (int k = 0; k < 6; k++) w.ps[k] += U2[k * 6 + eyecount - 1];               // src/icet.cpp:479
-            k0++;
-            condition = ev[5] / ev[eyecount];
-            eyecount++;
+    if (lane == 0) {
+        w.rank = rank;
+        for (int k = 0; k < 6; k++) w.ps[k] = sqrtf(fabsf(w.cov[k * 6 + k]));
+        eig6_sym_core<true>(w.H, ev, U2, w.A, w.sm);
+        int k0 = 0;
+        {
+            float condition = ev[5] / ev[0];
+            int eyecount = 1;
+            while (fabsf(condition) > 1e6f && eyecount < 6) {
+                for (int k = 0; k < 6; k++) w.ps[k] += U2[k * 6 + eyecount - 1];           // src/icet.cpp:479
+                k0++;
+                condition = ev[5] / ev[eyecount];
+                eyecount++;
+            }
         }
+        w.pruned = k0;
     }
-    w.pruned = k0;
-    const int m = 6 - k0;
-    for (int i = 0; i < 36; i++) { w.L2[i] = 0.f; w.lam[i] = 0.f; }
-    for (int i = 0; i < m; i++) w.L2[i * 6 + k0 + i] = 1.f;
-    for (int i = 0; i < 6; i++) w.lam[i * 6 + i] = ev[i];
-    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) w.U2t[j * 6 + i] = U2[i * 6 + j];
-    mm_seq(w.L2, m, 6, w.lam, 6, w.T1);
-    mm_seq(w.T1, m, 6, w.U2t, 6, w.innards);                                                 // L2 * lam * U2^T   (m x 6)   src/icet.cpp:427
-    cod_pinv(w.innards, m, 6, w.inv, w);                                                     // 6 x m
-    mm_seq(w.inv, 6, m, w.L2, 6, w.T2);
-    mm_seq(w.T2, 6, 6, w.U2t, 6, w.lhs);
-    mm_seq(w.lhs, 6, 6, w.g, 1, w.dx);                                                       // src/icet.cpp:430
+    ICET_WSYNC();
+    const int k0 = w.pruned, m = 6 - k0;
+    if (lane < 36) {
+        const int i = lane / 6, j = lane - 6 * i;
+        w.L2[lane] = (i < m && j == k0 + i) ? 1.f : 0.f;
+        w.lam[lane] = (i == j) ? ev[i] : 0.f;
+        w.U2t[j * 6 + i] = U2[i * 6 + j];
+    }
+    ICET_WSYNC();
+    mm_seq(w.L2, m, 6, w.lam, 6, w.T1, lane);
+    mm_seq(w.T1, m, 6, w.U2t, 6, w.innards, lane);                                           // L2 * lam * U2^T   (m x 6)   src/icet.cpp:427
+    cod_pinv(w.innards, m, 6, w.inv, w, lane);                                               // 6 x m
+    mm_seq(w.inv, 6, m, w.L2, 6, w.T2, lane);
+    mm_seq(w.T2, 6, 6, w.U2t, 6, w.lhs, lane);
+    mm_seq(w.lhs, 6, 6, w.g, 1, w.dx, lane);                                                 // src/icet.cpp:430
 }
+#undef ICET_WSYNC
 
 }  // namespace icetdev

@@ -62,8 +62,8 @@ __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X
 // (6 eps < 1e-6), pinv(HTWH) is the inverse and dx = HTWH^-1 HTWdz: a Cholesky factorisation gives both (route 0).  Everything else -- bound
 // inconclusive, Cholesky pivot not positive, NaN -- takes the literal restatement of the reference's statements (route 2, icet_device_math.h
 // gn_tail_literal), which decides rank, pruning and eigenvector signs exactly as the reference's algorithms do on the same bits.
-// `ws`: the literal route's workspace in LDS; `leader`: the one lane of the wave that walks it (the others wait and read the results, so that
-// the outputs are wave-uniform on either route).  Must be called by a whole wave.
+// `ws`: the literal route's workspace in LDS; `leader`: the one lane of the wave that fills in the matrix (the whole wave then walks the workspace and
+// reads the results, so that the outputs are wave-uniform on either route).  Must be called by a whole wave, every lane with the same matrix.
 __device__ __forceinline__ void gn_tail(const float* Hm, const float* g, float bound2, float* cov, float* ps, float* dx, float* ev, int& route, int& pruned,
                                         icetdev::GnTailWs& ws, bool leader) {
     bool plain = icetdev::chol6_inverse(Hm, cov);
@@ -81,8 +81,9 @@ __device__ __forceinline__ void gn_tail(const float* Hm, const float* g, float b
         if (leader) {
             for (int k = 0; k < 36; k++) ws.H[k] = Hm[k];
             for (int k = 0; k < 6; k++) ws.g[k] = g[k];
-            icetdev::gn_tail_literal(ws);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        icetdev::gn_tail_literal(ws);                                // the whole wave walks the workspace (`plain` is wave-uniform: every lane holds the same matrix)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         for (int k = 0; k < 36; k++) cov[k] = ws.cov[k];
         for (int k = 0; k < 6; k++) { ps[k] = ws.ps[k]; dx[k] = ws.dx[k]; ev[k] = ws.ev[k]; }

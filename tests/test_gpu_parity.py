@@ -1294,12 +1294,12 @@ def test_half_gap_bounds_extension_matches_its_oracle_twin(gpu_ctx, frames, samp
 
 def _cond_sweep_matrices():
     """(HTWH, HTWdz) pairs whose condition number crosses checkCondition's cutoff: the oracle's per-iteration matrices of the degenerate
-    golden scenes, rescaled along their weakest eigenvector so that cond sweeps [3e5, 3e7] (where pruning starts, and where the rank
+    golden scenes, rescaled along their weakest eigenvector so that cond sweeps [5e4, 3e7] (where pruning starts, and where the rank
     threshold of the pseudo-inverse, 1 / (6 eps) = 1.4e6, sits), plus rank-deficient, zero, NaN and well-conditioned ones."""
     g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_degenerate.npz")))
     names = sorted({k.split("/")[0] for k in g})
     Hs, gs = [], []
-    conds = np.geomspace(3e5, 3e7, 120)
+    conds = np.geomspace(5e4, 3e7, 140)                                 # crosses the Cholesky route's bound (2.5e5), checkCondition's cutoff (1e6) and the rank threshold (1.4e6)
     for nm in names:
         for it in (0, 3, 6):
             H = g[nm + "/HTWH"][it].astype(np.float64); gv = g[nm + "/HTWdz"][it]

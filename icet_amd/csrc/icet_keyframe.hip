@@ -850,7 +850,10 @@ __global__ __launch_bounds__(kBlock, kTail > 2 ? 4 : ICET_CLUSTER_WAVES) void k_
             const unsigned long long lt = (1ull << lane) - 1ull;
             auto keep = [&](int c0, uint32_t rw, float r) {
                 const int i = c0 + lane;
-                const bool in = (i < cnt) && (r >= inner) && (r <= outer);
+                // (a row with r == 0 -- the invalid returns of a real scan, thousands of them in ONE bin whose "cluster" is [-buff, buff] -- has phi = 1000 and can
+                // never pass the polar bounds (src/icet.cpp:632-633): not a candidate.  As candidates they became ~370 work items of k_fit_roundtrip per real scan,
+                // every row of which came back as "did not survive")
+                const bool in = (i < cnt) && !(rw & kSortedZeroBit) && (r >= inner) && (r <= outer);
                 const unsigned long long m = __ballot(in);
                 if (in) { const size_t pos = base + m_cand + __popcll(m & lt); cand[pos] = rw; cand_r[pos] = r; }
                 m_cand += __popcll(m);

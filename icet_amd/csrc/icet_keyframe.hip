@@ -1347,7 +1347,7 @@ hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev*
         if (e != hipSuccess) return e;
     }
     if (c.stage_event && c.stage_at == 1) { e = hipEventRecord(c.stage_event, st); if (e != hipSuccess) return e; }
-    e = hipMemsetAsync(w.flags, 0, sizeof(int32_t) * c.n_pairs, st); if (e != hipSuccess) return e;
+    if (c.use_library_sort) { e = hipMemsetAsync(w.flags, 0, sizeof(int32_t) * c.n_pairs, st); if (e != hipSuccess) return e; }      // (otherwise k_rs_splitters cleared the flags)
     if (c.true_sort) {
         // non-parity extension: the rows stay in sorted order (what the reference's comment says the loop is meant to do)
         e = hipMemcpyAsync(w.src, w.valB, sizeof(int32_t) * (size_t)c.total_n1, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return e;

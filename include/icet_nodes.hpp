@@ -59,6 +59,17 @@ public:
         if (status != ICET_OK) { error = "icet_node_push failed"; return false; }
         return last.solved != 0;
     }
+    // A burst of frames that already live in HBM (icet_node_push_many_device): chained on the device, one copy of all results at the end; results[k] belongs to
+    // frames[k] (`last` = the burst's last frame).  Returns the number of frames that were solved (a first-ever frame is only stored).
+    int pointCloudBurst(const icet_dev_scan* frames, int n_frames, std::vector<icet_node_result>& results) {
+        results.assign(n_frames > 0 ? (size_t)n_frames : 0, icet_node_result{});
+        if (!node_ || n_frames <= 0) return 0;
+        status = icet_node_push_many_device(node_, frames, n_frames, results.data());
+        if (status != ICET_OK) { error = "icet_node_push_many_device failed"; return 0; }
+        last = results.back();
+        int solved = 0; for (const icet_node_result& r : results) solved += r.solved != 0;
+        return solved;
+    }
     // EigenQueue::getQueue(): rows x 3 column-major
     std::vector<float> mapPC(int64_t* rows) {
         int64_t r = 0; std::vector<float> out;

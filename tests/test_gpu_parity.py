@@ -335,6 +335,30 @@ def test_edge_cases(gpu_ctx, frames):
     zz = np.zeros((5000, 3), np.float32)
     r = gpu_ctx.solve(zz, zz, 3, np.zeros(6), 24, 75)
     assert (r["X"] == 0).all()
+    # zero rows with every sign pattern (theta = atan2(+-0, +-0) puts them into four different voxels; their voxel comes from a host table, their scan-2
+    # twins are counted per sign pattern, the rank sort's zero bucket is finished by its multi-split), next to tiny vectors whose squares underflow to
+    # r = 0 but whose theta is a real angle, with X0 = 0, X0 with a NEGATIVE zero translation and an ordinary X0: per-voxel counts and the keyframe as the oracle's
+    rng = np.random.default_rng(7)
+    def salted(src):
+        o = src.copy()
+        idx = rng.choice(o.shape[0], 6000, replace=False)
+        signs = rng.choice([0.0, -0.0], size=(6000, 3)).astype(np.float32)
+        o[idx] = signs
+        tiny = rng.choice(np.setdiff1d(np.arange(o.shape[0]), idx), 200, replace=False)
+        o[tiny] = (rng.normal(size=(200, 3)) * 1e-25).astype(np.float32)
+        return o
+    sa, sb = salted(a), salted(b)
+    for x0v in (np.zeros(6, np.float32), np.array([-0.0, 0.0, -0.0, 0, 0, 0], np.float32), np.array([0.05, -0.02, 0.01, 0.001, -0.002, 0.003], np.float32)):
+        r = gpu_ctx.solve(sa, sb, 3, x0v, 24, 75, aux=True)
+        ref = po.solve(sa, sb, x0=x0v, runlen=3, trace=True)
+        t, ax = ref["trace"], r["aux"]
+        f = t["has_fit"] == 1
+        assert np.array_equal(ax["n1_raw"], t["n1_raw"]) and np.array_equal(ax["cluster_bounds"], t["bounds"]) and np.array_equal(ax["has_fit"], t["has_fit"])
+        assert np.array_equal(ax["sigma1"][f].view(np.uint32), t["sigma1"][f].view(np.uint32))
+        act = f & (t["n1_raw"] > 25) & (t["bounds"][:, 5] > 1)
+        assert np.array_equal(ax["n2_raw"][0][act], t["n2_raw"][0][act]), x0v
+        assert (ax["n2_in"][0][act] != np.maximum(t["n2_in"][0][act], 0)).sum() <= 3
+        _check_solution(r, ref, tol_t=2 * TOL_T, tol_r=2 * TOL_R, rtol_std=RTOL_STD_LOOSE, rtol_cov=RTOL_COV_LOOSE)
 
 
 def test_scan2_order_invariance_full_size(gpu_ctx):

@@ -386,6 +386,9 @@ __global__ __launch_bounds__(kBlock, ICET_SCR_WAVES) void k_scramble_src(const P
                 any |= act[k];
             }
             if (rounds > max_walk) { over = any != 0u; any = 0u; }   // (uniform) chains still running: the serial replay takes the pair
+#ifdef ICET_TIMING_SCR_CAP
+            if (rounds >= ICET_TIMING_SCR_CAP) any = 0u;            // timing build only (wrong src, valid rows)
+#endif
         }
         if (over) atomicOr(&flags[pair], 1);
         uint16_t fb[kWalk];                                      // packed word of the row that lands here (its voxel id is what the histogram needs)

@@ -23,8 +23,12 @@ constexpr int kMaxVirtualBlocks = (kMaxVoxels + 511) / 512;     // 20
 static_assert(kTwoStageMaxPairs * kMaxVirtualBlocks * 27 <= kGnPartWords, "Workspace::gn_part");
 __device__ __forceinline__ void write_xf(float* xf, const float X[6]) {
     const float phi = X[3], theta = X[4], psi = X[5];
-    float sph, cph, sth, cth, sps, cps;
-    sincosf(phi, &sph, &cph); sincosf(theta, &sth, &cth); sincosf(psi, &sps, &cps);
+    // the shared arithmetic rule: the correctly rounded float of the exact value -- evaluated in double, rounded once -- like
+    // every other transcendental of the path.  With ocml's float sincosf (1 ulp) the matrix differed from the CPU restatement's in a last bit now and then, and the
+    // FIRST iteration of a solve with X0 != 0 then put a point or two per 100 k into the neighbouring voxel (tests/param_sweep.py found it).  One lane per pair
+    // and iteration: six double evaluations.
+    const float sph = (float)sin((double)phi), cph = (float)cos((double)phi), sth = (float)sin((double)theta), cth = (float)cos((double)theta);
+    const float sps = (float)sin((double)psi), cps = (float)cos((double)psi);
     xf[0] = X[0]; xf[1] = X[1]; xf[2] = X[2];
     xf[3] = cth * cps;  xf[4] = sps * cph + sph * sth * cps;  xf[5] = sph * sps - sth * cph * cps;
     xf[6] = -sps * cth; xf[7] = cph * cps - sph * sth * sps;  xf[8] = sph * cps + sth * sps * cph;

@@ -45,6 +45,8 @@
 //       - the per-voxel sums (mean, centred products) are exact: accumulated in double from float addends, rounded to
 //         float once, then divided in float -- the value every summation order approximates;
 //       - hypot in the QR step is Eigen 3.3's own formula p * sqrt(1 + (q/p)^2) (numext::hypot), not libm's.
+//       (round 5: the sines / cosines of the rotation matrix and of get_H's Jacobians follow the rule as well -- they were glibc's float functions in
+//       every mode until then, the device used ocml's, and the two matrices differed in a last bit now and then.)
 //     mode | ICET_ORACLE_LIBMF switches all three back to the literal expression types of the reference source (glibc float
 //     functions, sequential float sums, std::hypot): tests use it to show that the choice moves X by less than the
 //     algorithm's own 1-ulp sensitivity.
@@ -116,29 +118,38 @@ static inline void mean_cov(const std::vector<float>& cx, const std::vector<floa
     }
     for (int a = 0; a < 9; a++) cov.a[a] = (float)c[a] / static_cast<float>(rows - 1);
 }
-static Mat eulerR(float phi, float theta, float psi) {
-    using std::cos; using std::sin;
+// Shared rule: the six sines / cosines are the correctly rounded floats (sin_cr / cos_cr), like every other transcendental of the path -- the device's
+// write_xf evaluates them the same way, so both sides transform scan 2 with the SAME matrix bits whenever they hold the same X; libmf: glibc's float functions.
+struct Trig6 { float sph, cph, sth, cth, sps, cps; };
+static inline Trig6 trig6(float phi, float theta, float psi, bool libmf) {
+    Trig6 t;
+    if (libmf) { t.sph = std::sin(phi); t.cph = std::cos(phi); t.sth = std::sin(theta); t.cth = std::cos(theta); t.sps = std::sin(psi); t.cps = std::cos(psi); }
+    else { t.sph = sin_cr(phi); t.cph = cos_cr(phi); t.sth = sin_cr(theta); t.cth = cos_cr(theta); t.sps = sin_cr(psi); t.cps = cos_cr(psi); }
+    return t;
+}
+static Mat eulerR(float phi_, float theta_, float psi_, bool libmf = false) {
+    const Trig6 t = trig6(phi_, theta_, psi_, libmf);
     Mat m(3, 3);
-    m(0,0) = cos(theta)*cos(psi); m(0,1) = sin(psi)*cos(phi)+sin(phi)*sin(theta)*cos(psi); m(0,2) = sin(phi)*sin(psi)-sin(theta)*cos(phi)*cos(psi);
-    m(1,0) = -sin(psi)*cos(theta); m(1,1) = cos(phi)*cos(psi)-sin(phi)*sin(theta)*sin(psi); m(1,2) = sin(phi)*cos(psi)+sin(theta)*sin(psi)*cos(phi);
-    m(2,0) = sin(theta); m(2,1) = -sin(phi)*cos(theta); m(2,2) = cos(phi)*cos(theta);
+    m(0,0) = t.cth*t.cps; m(0,1) = t.sps*t.cph+t.sph*t.sth*t.cps; m(0,2) = t.sph*t.sps-t.sth*t.cph*t.cps;
+    m(1,0) = -t.sps*t.cth; m(1,1) = t.cph*t.cps-t.sph*t.sth*t.sps; m(1,2) = t.sph*t.cps+t.sth*t.sps*t.cph;
+    m(2,0) = t.sth; m(2,1) = -t.sph*t.cth; m(2,2) = t.cph*t.cth;
     return m;
 }
 
 // ---------------------------------------------------------------- icet.cpp:494-532
-static Mat get_H(const float mu[3], const float angs[3]) {
-    using std::cos; using std::sin;
-    float phi = angs[0], theta = angs[1], psi = angs[2];
+static Mat get_H(const float mu[3], const float angs[3], bool libmf = false) {
+    const Trig6 t = trig6(angs[0], angs[1], angs[2], libmf);
+    const float sph = t.sph, cph = t.cph, sth = t.sth, cth = t.cth, sps = t.sps, cps = t.cps;
     Mat H(3, 6);
     H(0,0) = -1.f; H(1,1) = -1.f; H(2,2) = -1.f;
-    float Jx[9] = {0.f, (-sin(psi)*sin(phi) + cos(phi)*sin(theta)*cos(psi)), (cos(phi)*sin(psi) + sin(theta)*sin(phi)*cos(psi)),
-                   0.f, (-sin(phi)*cos(psi) - cos(phi)*sin(theta)*sin(psi)), (cos(phi)*cos(psi) - sin(theta)*sin(psi)*sin(phi)),
-                   0.f, (-cos(phi)*cos(theta)), (-sin(phi)*cos(theta))};
-    float Jy[9] = {(-sin(theta)*cos(psi)), (cos(theta)*sin(phi)*cos(psi)), (-cos(theta)*cos(phi)*cos(psi)),
-                   (sin(psi)*sin(theta)), (-cos(theta)*sin(phi)*sin(psi)), (cos(theta)*sin(psi)*cos(phi)),
-                   (cos(theta)), (sin(phi)*sin(theta)), (-sin(theta)*cos(phi))};
-    float Jz[9] = {(-cos(theta)*sin(psi)), (cos(psi)*cos(phi) - sin(phi)*sin(theta)*sin(psi)), (cos(psi)*sin(phi) + sin(theta)*cos(phi)*sin(psi)),
-                   (-cos(psi)*cos(theta)), (-sin(psi)*cos(phi) - sin(phi)*sin(theta)*cos(psi)), (-sin(phi)*sin(psi) + sin(theta)*cos(psi)*cos(phi)),
+    float Jx[9] = {0.f, (-sps*sph + cph*sth*cps), (cph*sps + sth*sph*cps),
+                   0.f, (-sph*cps - cph*sth*sps), (cph*cps - sth*sps*sph),
+                   0.f, (-cph*cth), (-sph*cth)};
+    float Jy[9] = {(-sth*cps), (cth*sph*cps), (-cth*cph*cps),
+                   (sps*sth), (-cth*sph*sps), (cth*sps*cph),
+                   (cth), (sph*sth), (-sth*cph)};
+    float Jz[9] = {(-cth*sps), (cps*cph - sph*sth*sps), (cps*sph + sth*cph*sps),
+                   (-cps*cth), (-sps*cph - sph*sth*cps), (-sph*sps + sth*cps*cph),
                    0.f, 0.f, 0.f};
     for (int i = 0; i < 3; i++) {
         H(i, 3) = Jx[3*i] * mu[0] + Jx[3*i+1] * mu[1] + Jx[3*i+2] * mu[2];
@@ -475,7 +486,7 @@ struct Solver {
                 Mat Rp = matmul(matmul(matmul(LUt, Rn), transpose(f.V)), transpose(Lm));   // icet.cpp:317
                 Mat W = cod_pinv(Rp);                                                        // icet.cpp:320-321
                 float angs[3] = {X[3], X[4], X[5]};
-                Mat H_j = get_H(mean, angs);
+                Mat H_j = get_H(mean, angs, libmf);
                 Mat H_z = matmul(LUt, H_j);                                                  // icet.cpp:329
                 Mat HzT = transpose(H_z);
                 Mat HzTW = matmul(HzT, W);
@@ -524,7 +535,7 @@ struct Solver {
     // icet.cpp:372-436
     void fitScan2() {
         const int N = (int)ogx.size();
-        Mat rot = eulerR(X[3], X[4], X[5]);
+        Mat rot = eulerR(X[3], X[4], X[5], libmf);
         p2x.resize(N); p2y.resize(N); p2z.resize(N);
         for (int i = 0; i < N; i++) {
             float a = ogx[i] + X[0], b = ogy[i] + X[1], c = ogz[i] + X[2];        // rowwise() + trans

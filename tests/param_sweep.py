@@ -67,3 +67,58 @@ def run_case(ctx, a, b, T, P, kw, runlen, x0):
     return bits, d, r, ref, int(f.sum())
 
 
+
+
+# ---- random batches: every pair must carry the bits of its own single solve ------------------------------------------------------------------
+def draw_scan_pair(rng, pools):
+    a0, b0 = pools[rng.integers(len(pools))]
+    kind = rng.random()
+    if kind < 0.05: return np.zeros((0, 3), np.float32), b0[:2000]
+    if kind < 0.10: return a0[:3000], np.zeros((0, 3), np.float32)
+    if kind < 0.15: return a0[:int(rng.integers(1, 40))], b0[:int(rng.integers(1, 40))]
+    m = int(rng.choice([2500, 9000, 30000, a0.shape[0]]))
+    if m >= a0.shape[0]: return a0, b0
+    if rng.random() < 0.5:
+        s = int(rng.integers(0, a0.shape[0] - m)); return a0[s:s + m], b0[s:s + m + int(rng.integers(0, 300))]
+    k = a0.shape[0] // m
+    return a0[::k], b0[int(rng.integers(0, k))::k]
+
+
+
+def run_batch(ctx, single, rng, pools):
+    """One random batch -- ragged pairs (empty, tiny, strided, whole scans), a size on either side of the library's small-batch / throughput switch (32 pairs),
+    random parameters -- through icet_solve_batch (host pointers) and icet_solve_batch_device (descriptors whose leading dimension exceeds the row count, NaN in
+    the padding).  Returns (description, [(pair, n1, n2, host path equal, device path equal) for every pair that differs from its single solve])."""
+    import torch
+    from icet_amd import api
+    k = int(rng.choice([1, 2, 7, 31, 32, 33, 48]))
+    T = int(rng.choice([12, 40, 75, 128])); P = int(rng.choice([3, 11, 24, 48]))
+    kw = dict(n=int(rng.choice([3, 25, 60])), thresh=float(rng.choice([0.05, 0.1, 0.5])), buff=float(rng.choice([0.0, 0.1, 1.0])))
+    runlen = int(rng.integers(1, 9))
+    pairs = [draw_scan_pair(rng, pools) for _ in range(k)]
+    s1 = [np.ascontiguousarray(p[0]) for p in pairs]; s2 = [np.ascontiguousarray(p[1]) for p in pairs]
+    x0 = (rng.normal(size=(k, 6)) * np.array([0.1, 0.1, 0.03, 0.003, 0.003, 0.01])).astype(np.float32)
+    x0[rng.random(k) < 0.4] = 0
+    host = ctx.solve_batch(s1, s2, runlen, x0, P, T, **kw)
+    # the same batch resident in HBM, every scan in a buffer with a leading dimension larger than its row count (3 x ld floats, rows 0 .. n-1 used)
+    bufs, d1, d2 = [], [], []
+    for lst, dl in ((s1, d1), (s2, d2)):
+        for s in lst:
+            n = s.shape[0]; ld = (n + int(rng.integers(0, 70)) + 3) & ~3
+            t = torch.full((3, max(ld, 4)), float("nan"), device="cuda")
+            if n: t[:, :n] = torch.from_numpy(np.ascontiguousarray(s.T)).cuda()
+            bufs.append(t); dl.append((t.data_ptr(), n, t.shape[1]))
+    out = torch.zeros(k, 48, device="cuda"); dx0 = torch.from_numpy(x0).cuda()
+    prm = api.Params(runlen, P, T, kw["n"], kw["thresh"], kw["buff"], 0)
+    ctx.solve_batch_device(d1, d2, prm, out.data_ptr(), dx0.data_ptr()); torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    diffs = []
+    for j in range(k):
+        r = single.solve(s1[j], s2[j], runlen, x0[j], P, T, **kw)
+        okh = np.array_equal(host["X"][j].view(np.uint32), r["X"].view(np.uint32)) and np.array_equal(host["pred_stds"][j].view(np.uint32), r["pred_stds"].view(np.uint32)) \
+            and np.array_equal(host["cov"][j].view(np.uint32), r["cov"].reshape(6, 6).view(np.uint32))
+        okd = np.array_equal(o[j, :6].view(np.uint32), r["X"].view(np.uint32)) and np.array_equal(o[j, 6:12].view(np.uint32), r["pred_stds"].view(np.uint32)) \
+            and np.array_equal(o[j, 12:48].view(np.uint32), r["cov"].reshape(36).view(np.uint32))
+        if not (okh and okd): diffs.append((j, s1[j].shape[0], s2[j].shape[0], okh, okd))
+    desc = "pairs=%2d T=%3d P=%2d n=%2d thresh=%.2f buff=%.1f runlen=%d rows1=%d..%d" % (k, T, P, kw["n"], kw["thresh"], kw["buff"], runlen, min(s.shape[0] for s in s1), max(s.shape[0] for s in s1))
+    return desc, diffs

@@ -1574,3 +1574,19 @@ def test_random_parameter_space(gpu_ctx, seed, with_flags):
             for w in beyond:
                 fh.write("%d %.3g %.3g %.3g %.3g\n" % w)
     assert len(beyond) <= 14 and len(ill) <= 12, (beyond, ill)            # the draws are deliberately extreme
+
+
+def test_random_batches_carry_their_single_solve_bits(gpu_ctx):
+    """12 seeded random batches (tests/param_sweep.run_batch; 134 more were run by hand, scripts/fuzz_batch.py -> profiles/r05_fuzz_batch.txt): 1 .. 48 ragged pairs --
+    empty scans, scans of a few rows, strided and whole real / synthetic scans -- random grid, minimum points, thresh, buff, runlen and X0, once through icet_solve_batch
+    and once through icet_solve_batch_device with padded leading dimensions.  Every pair of every batch: the BITS of its own single solve in another context (integer
+    accumulation: no dependence on batch size, chunking, launch shape or neighbours)."""
+    from icet_amd import api
+    from tests.param_sweep import run_batch, pools
+    rng = np.random.default_rng(1)
+    pl = pools()
+    single = api.Context()
+    for _ in range(12):
+        desc, diffs = run_batch(gpu_ctx, single, rng, pl)
+        assert not diffs, (desc, diffs[:6])
+    single.close()

@@ -122,3 +122,38 @@ def run_batch(ctx, single, rng, pools):
         if not (okh and okd): diffs.append((j, s1[j].shape[0], s2[j].shape[0], okh, okd))
     desc = "pairs=%2d T=%3d P=%2d n=%2d thresh=%.2f buff=%.1f runlen=%d rows1=%d..%d" % (k, T, P, kw["n"], kw["thresh"], kw["buff"], runlen, min(s.shape[0] for s in s1), max(s.shape[0] for s in s1))
     return desc, diffs
+
+
+# ---- adversarial scans: ties, lattice points on voxel edges, non-finite rows, extreme magnitudes --------------------------------------------------
+def spoil(rng, scan):
+    """A copy of `scan` with one or more of: ranges quantised to 1 cm (thousands of equal sort keys: the reference's order among them is by row), points snapped
+    to a 0.25 m lattice (azimuths of exactly pi / 4, pi / 2 ...: ON voxel edges of the usual grids; z = 0: phi = pi / 2 exactly), duplicated rows, NaN / +-inf
+    entries, rows scaled by 1e-20 / 1e+18 (squares under- / overflow), exact zeros of either sign."""
+    o = scan.astype(np.float32).copy()
+    n = o.shape[0]
+    what = []
+    if rng.random() < 0.5:
+        r = np.linalg.norm(o.astype(np.float64), axis=1); ok = r > 0
+        q = np.round(r[ok] * 100) / 100
+        o[ok] = (o[ok].astype(np.float64) * (q / r[ok])[:, None]).astype(np.float32); what.append("quantised")
+    if rng.random() < 0.5:
+        idx = rng.choice(n, n // 3, replace=False); o[idx] = np.round(o[idx] * 4) / 4; what.append("lattice")
+    if rng.random() < 0.4:
+        idx = rng.choice(n, n // 10, replace=False); o[idx] = o[rng.choice(n, n // 10)]; what.append("duplicates")
+    if rng.random() < 0.4:
+        idx = rng.choice(n, 30, replace=False)
+        o[idx, rng.integers(0, 3, 30)] = rng.choice(np.array([np.nan, np.inf, -np.inf], np.float32), 30); what.append("nonfinite")
+    if rng.random() < 0.4:
+        idx = rng.choice(n, 40, replace=False); o[idx[:20]] *= np.float32(1e-20); o[idx[20:]] *= np.float32(1e18); what.append("magnitudes")
+    if rng.random() < 0.4:
+        idx = rng.choice(n, n // 20, replace=False); o[idx] = rng.choice(np.array([0.0, -0.0], np.float32), (n // 20, 3)); what.append("zeros")
+    return o, "+".join(what) or "plain"
+
+
+def draw_adversarial(rng, pools):
+    a, b, T, P, kw, runlen, x0 = draw_case(rng, pools)
+    if a.shape[0] > 45000: a, b = a[::3], b[::3]
+    T = int(rng.choice([8, 16, 24, 64, 75, 128])); P = int(rng.choice([2, 4, 8, 24, 32]))      # multiples of 8 put the lattice azimuths ON edges; P even puts z = 0 on one
+    a, wa = spoil(rng, a); b, wb = spoil(rng, b)
+    x0 = np.zeros(6, np.float32)                      # the identity transform: the first iteration's counts must be the oracle's exactly
+    return a, b, T, P, kw, min(runlen, 4), x0, wa + " | " + wb

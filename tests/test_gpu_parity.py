@@ -1590,3 +1590,27 @@ def test_random_batches_carry_their_single_solve_bits(gpu_ctx):
         desc, diffs = run_batch(gpu_ctx, single, rng, pl)
         assert not diffs, (desc, diffs[:6])
     single.close()
+
+
+def test_adversarial_scans(gpu_ctx):
+    """30 seeded adversarial pairs (tests/param_sweep.spoil: thousands of equal sort keys, lattice points EXACTLY on voxel edges, duplicated rows, NaN / +-inf entries,
+    rows scaled by 1e-20 / 1e+18, signed zeros; 180 more by hand, scripts/fuzz_adversarial.py -> profiles/r05_fuzz_adversarial.txt).  The keyframe table is the oracle's
+    bits in every one.  The first iteration's per-voxel counts of scan 2 are the oracle's in every one when the device round-trips scan 2 through spherical coordinates
+    as the reference does (ICET_FLAG_ROUNDTRIP_SCAN2); on the default path -- which skips that round trip, DESIGN.md section 7 -- a fifth of these pairs differ in a few
+    counts: a lattice point that sits ON an edge moves off it in the round trip, and a vector whose squares are denormal comes back 1e-5 away from where it was."""
+    from icet_amd import api
+    from tests.param_sweep import draw_adversarial, run_case, pools
+    pl = pools()
+    n_default_diff = 0
+    for flag in (api.FLAG_ROUNDTRIP_SCAN2, 0):
+        rng = np.random.default_rng(1)
+        for c in range(30):
+            a, b, T, P, kw, runlen, x0, what = draw_adversarial(rng, pl)
+            if flag: kw["_twin"] = (flag, None)
+            bits, d, r, ref, fits = run_case(gpu_ctx, a, b, T, P, kw, runlen, x0)
+            counts_equal = bits.pop("n2_raw0")
+            assert all(bits.values()), (c, what, T, P, kw, {k: v for k, v in bits.items() if not v})
+            assert np.isfinite(r["X"]).all() == np.isfinite(ref["X"]).all()
+            if flag: assert counts_equal, (c, what, T, P, kw)
+            else: n_default_diff += 0 if counts_equal else 1
+    assert n_default_diff <= 12

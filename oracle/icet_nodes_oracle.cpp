@@ -124,7 +124,8 @@ int icet_oracle_node_push(void* h, const float* scan, int64_t n, int64_t ld, ice
     auto pack = [](const Scan& s) { std::vector<float> m; m.reserve(3 * s.x.size()); m.insert(m.end(), s.x.begin(), s.x.end()); m.insert(m.end(), s.y.begin(), s.y.end()); m.insert(m.end(), s.z.begin(), s.z.end()); return m; };
     const std::vector<float> m1 = pack(nd->prev), m2 = pack(cur);
     float X[6], stds[6], cov[36];
-    const int rc = icet_oracle_solve(&nd->p.solve, m1.data(), nd->prev.n(), nd->prev.n(), m2.data(), cur.n(), cur.n(), nd->X0, X, stds, cov, nullptr);
+    static const float none[3] = {0.f, 0.f, 0.f};                // an empty scan (every row inside min_range, an empty cloud): the solve wants a pointer, reads nothing
+    const int rc = icet_oracle_solve(&nd->p.solve, m1.empty() ? none : m1.data(), nd->prev.n(), nd->prev.n(), m2.empty() ? none : m2.data(), cur.n(), cur.n(), nd->X0, X, stds, cov, nullptr);
     if (rc != 0) return rc;
     // seed for the next frame: odometry.cpp:82 / simpleMapMaker.cpp:124
     for (int k = 0; k < 6; k++) nd->X0[k] = nd->p.seed_x0 ? X[k] : 0.f;

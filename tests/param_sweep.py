@@ -157,3 +157,61 @@ def draw_adversarial(rng, pools):
     a, wa = spoil(rng, a); b, wb = spoil(rng, b)
     x0 = np.zeros(6, np.float32)                      # the identity transform: the first iteration's counts must be the oracle's exactly
     return a, b, T, P, kw, min(runlen, 4), x0, wa + " | " + wb
+
+
+# ---- the sequential callers: random node settings, hostile frames ----------------------------------------------------------------------------------
+def draw_node_case(rng):
+    """(node keyword arguments, list of frames): a short synthetic drive with some frames replaced by hostile ones -- empty, entirely inside min_range, a few rows,
+    NaN / zero rows mixed in, the same frame twice."""
+    from icet_amd import api, lidar_sim as ls
+    base = dict([api.ODOMETRY_NODE, api.MAP_MAKER_NODE, api.SCAN_REGISTRATION_NODE][int(rng.integers(3))])
+    base.update(runlen=int(rng.integers(1, 8)), min_range=float(rng.choice([0.0, 0.2, 2.0, 6.0])), n=int(rng.choice([10, 25, 50])))
+    if base.get("map_capacity", 0):
+        base.update(map_capacity=int(rng.choice([3000, 20000, 600000])), map_downsample=int(rng.choice([0, 500, 4000])))
+        base["map_downsample"] = min(base["map_downsample"], base["map_capacity"])      # (icet_node_create refuses a per-frame sample larger than the queue)
+    if rng.random() < 0.4: base.update(trans_thresh=float(rng.choice([1e-6, 0.05, 1.0])), rot_thresh=float(rng.choice([0.0, 1e-6, 0.5])))
+    nf = int(rng.integers(3, 8))
+    motion = (float(rng.normal(0.2, 0.1)), float(rng.normal(0, 0.03)), 0.005, 0.001, -0.001, float(rng.normal(0, 0.01)))
+    frames = [s.T.contiguous().numpy() for s in ls.make_sequence(nf, motion=motion, rings=int(rng.choice([16, 32])), steps=int(rng.choice([512, 1024])))]
+    for k in range(nf):
+        u = rng.random()
+        f = frames[k]
+        if u < 0.08: frames[k] = np.zeros((0, 3), np.float32)
+        elif u < 0.16: frames[k] = (f / np.maximum(np.linalg.norm(f, axis=1, keepdims=True), 1e-9) * 0.1).astype(np.float32)      # everything inside min_range (unless 0)
+        elif u < 0.24: frames[k] = f[:int(rng.integers(1, 30))].copy()
+        elif u < 0.36:
+            g = f.copy(); idx = rng.choice(len(g), len(g) // 8, replace=False); g[idx] = 0.0
+            g[rng.choice(len(g), 5, replace=False), int(rng.integers(3))] = np.nan; frames[k] = g
+        elif u < 0.42 and k: frames[k] = frames[k - 1].copy()
+    return base, frames
+
+
+def run_node_case(ctx, kw, frames):
+    """GPU node against the oracle's node, frame by frame; then the same frames as ONE device burst against the frame-by-frame results (bits).  Returns a list of
+    complaints (empty = fine)."""
+    import torch
+    from icet_amd import api
+    from oracle import pyoracle as po
+    bad = []
+    g, o = api.Node(ctx, **kw), po.Node(**kw)
+    got = []
+    for k, s in enumerate(frames):
+        rg, ro = g.push(s), o.push(s)
+        got.append(rg)
+        for key in ("solved", "diverged", "n_kept", "map_rows"):
+            if rg[key] != ro[key]: bad.append("frame %d: %s device %s oracle %s" % (k, key, rg[key], ro[key]))
+        if not np.isfinite(rg["X"]).all() == np.isfinite(ro["X"]).all(): bad.append("frame %d: finiteness of X differs" % k)
+    if kw.get("map_capacity", 0) and not bad:
+        mg, mo = g.map(), o.map()
+        if mg.shape != mo.shape: bad.append("map shape device %s oracle %s" % (mg.shape, mo.shape))
+    g.close(); o.close()
+    dev = torch.device("cuda", 0)
+    bufs = [torch.from_numpy(np.ascontiguousarray(s.T) if len(s) else np.zeros((3, 4), np.float32)).to(dev) for s in frames]
+    fr = [(b.data_ptr(), len(s), b.shape[1]) for b, s in zip(bufs, frames)]
+    nb = api.Node(ctx, **kw)
+    burst = nb.push_many_device(fr)
+    for k, (a, b) in enumerate(zip(burst, got)):
+        same = all(np.array_equal(a[key], b[key], equal_nan=True) for key in ("X", "pred_stds", "pose", "quat")) and all(a[key] == b[key] for key in ("solved", "diverged", "n_kept", "map_rows"))
+        if not same: bad.append("burst frame %d differs from the frame-by-frame push" % k)
+    nb.close()
+    return bad

@@ -514,14 +514,22 @@ hipError_t launch_rt2_prepare(const Workspace& w, const LaunchCfg& c, hipStream_
     return hipSuccess;
 }
 
+// LDS of one k_gn_accumulate block apart from its slot rows: both look-up tables, the voxel -> slot map, the queue of parked points; and the bytes of a slot row.
+// The SMALLEST launch keeps 32 rows (launch_gn_accumulate): ensure_thresholds sizes the look-up tables so that it fits the device.
+size_t acc_fixed_lds_bytes(int T, int P, int Mt, int Mp, bool small_batch) {
+    const uint32_t near_cap = small_batch ? kNearCapSmall : kNearCap;
+    return (size_t)(Mt + Mp + 2) * sizeof(LutCell) + (size_t)(((size_t)T * P + T + 4) / 2) * 4 + (near_cap + 5) * 4 + 32;   // + alignment of the hot records
+}
+size_t acc_row_lds_bytes() { return (kHotWords + kAccLds) * 4; }
+
 hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
     // LDS rows for active voxels: a throughput batch keeps 320 rows (measured optimum on 64-channel scans: fewer rows
     // spill busy voxels to HBM atomics, more rows cost occupancy); a small batch has
     // CUs to spare, so a block may take most of a CU's LDS and keep every active voxel of a fine grid (150 x 48: often
     // > 1000) out of the slow HBM-atomic path.
     const uint32_t near_cap = (c.n_pairs >= 32) ? kNearCap : kNearCapSmall;
-    const size_t fixed = (size_t)(w.lut_Mt + w.lut_Mp + 2) * sizeof(LutCell) + (size_t)((c.V + c.T + 4) / 2) * 4 + (near_cap + 5) * 4 + 32;   // + alignment of the hot records
-    const size_t row = (kHotWords + kAccLds) * 4;
+    const size_t fixed = acc_fixed_lds_bytes(c.T, c.P, w.lut_Mt, w.lut_Mp, near_cap == kNearCapSmall);
+    const size_t row = acc_row_lds_bytes();
     const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : 156 * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU; a small batch: one block per CU, nearly all of its LDS
     int lds_slots = c.lds_slots > 0 ? c.lds_slots : (int)((budget > fixed ? budget - fixed : 0) / row);
     lds_slots = lds_slots < 32 ? 32 : lds_slots;

@@ -96,8 +96,8 @@ bool params_ok(const icet_params* p) {
 icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs, int64_t total_n1, int64_t total_n2) {
     Workspace& w = c->w;
     const int V = p->bins_phi * p->bins_theta;
-    if ((int64_t)p->bins_phi * p->bins_theta > kMaxVoxels) { c->err = "bins_phi*bins_theta exceeds the voxel limit (10000: the multi-split keeps 16 B per voxel in one block's LDS)"; return ICET_ERR_UNSUPPORTED; }
-    if ((size_t)V * 16 + 4096 > (size_t)c->max_lds) { c->err = "grid too fine for this device's LDS (16 B per voxel per block)"; return ICET_ERR_UNSUPPORTED; }
+    if ((int64_t)p->bins_phi * p->bins_theta > kMaxVoxels) { c->err = "bins_phi*bins_theta exceeds the voxel limit (10000: the multi-split keeps 12 B per voxel, the Gauss-Newton pass a 2-byte map entry and its look-up tables, in one block's LDS)"; return ICET_ERR_UNSUPPORTED; }
+    if ((size_t)V * 12 + 8 + 4096 > (size_t)c->max_lds) { c->err = "grid too fine for this device's LDS (k_bin_scatter keeps 12 B per voxel in one block)"; return ICET_ERR_UNSUPPORTED; }
     if (total_n1 >= (int64_t)1 << 31) { c->err = "total scan-1 points per call must be < 2^31"; return ICET_ERR_UNSUPPORTED; }
     const bool grow_pairs = n_pairs > w.cap_pairs || V > w.cap_V;
     if (grow_pairs) {
@@ -190,13 +190,13 @@ void build_thresholds(int nb, double period, float* out) {
 // edge" yields the bin and "far from the named edge" implies far from every edge.  Cells that fail this (near the poles) get
 // edge = NaN, which fails the kernel's guard test, so their points take the literal path.
 struct HostCell { float edge; int32_t idx; };
-int build_lut(const std::vector<double>& edges, double lo, double range, double quantile, double guard, std::vector<HostCell>& out) {
+int build_lut(const std::vector<double>& edges, double lo, double range, double quantile, double guard, std::vector<HostCell>& out, int max_cells = 1 << 16) {
     std::vector<double> widths;
     for (size_t k = 1; k < edges.size(); k++) widths.push_back(edges[k] - edges[k - 1]);
     std::sort(widths.begin(), widths.end());
     const double w_ref = widths.empty() ? range : widths[(size_t)(quantile * (double)(widths.size() - 1))];
     int M = 64;
-    while (range / M > 0.45 * w_ref && M < (1 << 16)) M *= 2;
+    while (range / M > 0.45 * w_ref && 2 * M <= max_cells) M *= 2;     // (a cell that still holds two edges is marked ambiguous below: its points take the literal path)
     out.resize(M);
     const double cw = range / M, slack = 0.02 * cw + guard;      // the kernel's float cell index may be off by a rounding at a cell boundary
     for (int c = 0; c < M; c++) {
@@ -229,7 +229,18 @@ icet_status ensure_thresholds(icet_ctx* c, int T, int P) {
         w.guard_t = 5e-6f * (float)c->tune.guard_scale; w.guard_p = 2.5e-6f * (float)c->tune.guard_scale;       // scale: experiments / tests only
         std::vector<HostCell> lt, lp;
         const double qp = c->tune.lut_polar_quantile;
-        const int Mt = build_lut(et, 0.0, 4.0, 0.0, w.guard_t, lt), Mp = build_lut(ep, -1.0, 2.0, qp, w.guard_p, lp);
+        // Both tables live in the LDS of k_scan1_spherical and k_gn_accumulate blocks next to the voxel map.  A grid that is extremely fine in ONE direction
+        // (thousands of azimuth bins on one ring) would want more cells than fit: the tables are then capped -- coarser cells hold two edges, are marked
+        // ambiguous and send their points through the literal formulas: slower, same result -- and only a grid whose MINIMUM does not fit is refused.
+        int cap_t = 1 << 16, cap_p = 1 << 16, Mt = 0, Mp = 0;
+        for (;;) {
+            Mt = build_lut(et, 0.0, 4.0, 0.0, w.guard_t, lt, cap_t); Mp = build_lut(ep, -1.0, 2.0, qp, w.guard_p, lp, cap_p);
+            const size_t need_acc = acc_fixed_lds_bytes(T, P, Mt, Mp, true) + 32 * acc_row_lds_bytes();
+            const size_t need_scan1 = (size_t)(Mt + Mp + 2) * sizeof(HostCell) + 4096;      // + the kernel's static tables (init_keyframe_kernels)
+            if (std::max(need_acc, need_scan1) <= (size_t)c->max_lds) break;
+            if (Mt <= 64 && Mp <= 64) { c->err = "grid too fine for this device's LDS (voxel map + look-up tables of one block)"; return ICET_ERR_UNSUPPORTED; }
+            if (Mt >= Mp) cap_t = Mt / 2; else cap_p = Mp / 2;
+        }
         // one spare cell per table: pa == 4 / w == 1 index cell M (it names the last edge, so the point goes to the literal path)
         for (HostCell& c : lp) c.idx *= T;                                 // polar cells carry the map row offset T * edge index
         std::vector<HostCell> all(lt); all.push_back(HostCell{4.0f, T}); all.insert(all.end(), lp.begin(), lp.end()); all.push_back(HostCell{1.0f, P * T});

@@ -187,6 +187,8 @@ hipError_t launch_gn_tail_debug(const float* d_H, const float* d_g, float* d_out
 hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* xf, float* out, hipStream_t st);
 // icet_accumulate.hip
 hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st);
+size_t acc_fixed_lds_bytes(int T, int P, int Mt, int Mp, bool small_batch);   // LDS of a k_gn_accumulate block without its slot rows
+size_t acc_row_lds_bytes();
 // ICET_FLAG_ROUNDTRIP_SCAN2: points2_OG = sphericalToCartesian(cartesianToSpherical(scan 2)) (src/icet.cpp:263-275, without the permutation): w.desc -> w.desc_rt
 hipError_t launch_rt2_prepare(const Workspace& w, const LaunchCfg& c, hipStream_t st);
 hipError_t launch_patch_counts(const Workspace& w, const LaunchCfg& c, const int32_t* d_n1, const int32_t* d_n2, hipStream_t st);   // icet_solve.hip

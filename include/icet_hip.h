@@ -27,7 +27,7 @@ typedef enum icet_status {
     ICET_ERR_NO_DEVICE = 2,   /* no HIP device / device id out of range                          */
     ICET_ERR_HIP = 3,         /* a HIP runtime call or kernel launch failed (see icet_last_error) */
     ICET_ERR_NOMEM = 4,       /* device or host allocation failed                                 */
-    ICET_ERR_UNSUPPORTED = 5  /* e.g. bins_phi*bins_theta above the voxel limit (10000: 16 B of one block's LDS per voxel) */
+    ICET_ERR_UNSUPPORTED = 5  /* e.g. bins_phi*bins_theta above the voxel limit (10000: the voxel tables of one pair live in one block's LDS) */
 } icet_status;
 
 /* Mirrors the reference constructor's scalar arguments (include/icet.h:38-40, defaults n=25,

@@ -1614,3 +1614,23 @@ def test_adversarial_scans(gpu_ctx):
             if flag: assert counts_equal, (c, what, T, P, kw)
             else: n_default_diff += 0 if counts_equal else 1
     assert n_default_diff <= 12
+
+
+def test_extreme_grids_up_to_the_voxel_limit(gpu_ctx, frames):
+    """One voxel, one ring, one column, and the 10 000-voxel limit in every shape -- 200 x 50, 100 x 100, 10 000 x 1, 1 x 10 000, 5000 x 2, 2 x 5000 (scripts/fuzz_grids.py ->
+    profiles/r05_fuzz_grids.txt).  A grid that is extremely fine in one direction wants larger look-up tables than a block's LDS holds: until round 5 such a grid failed at the
+    first launch with hipErrorInvalidValue; the tables are now capped (coarser cells hold two edges and send their points through the literal formulas).  Keyframe table and
+    first-iteration counts: the oracle's bits; one voxel more than the limit, or a non-positive dimension: refused before anything runs."""
+    from icet_amd import api
+    from tests.param_sweep import run_case
+    a, b = frames
+    for (T, P) in ((1, 1), (1, 24), (75, 1), (2, 2), (200, 50), (100, 100), (10000, 1), (1, 10000), (5000, 2), (2, 5000), (2500, 4), (8, 1250)):
+        bits, d, r, ref, fits = run_case(gpu_ctx, a, b, T, P, dict(n=25, thresh=0.1, buff=0.1), 3, np.zeros(6, np.float32))
+        assert all(bits.values()), (T, P, {k: v for k, v in bits.items() if not v})
+        assert np.isfinite(r["X"]).all()
+    for (T, P, st) in ((10001, 1, "ICET_ERR_UNSUPPORTED"), (101, 100, "ICET_ERR_UNSUPPORTED"), (1, 10001, "ICET_ERR_UNSUPPORTED"), (0, 5, "ICET_ERR_BAD_ARG"), (5, 0, "ICET_ERR_BAD_ARG"), (-1, 3, "ICET_ERR_BAD_ARG")):
+        with pytest.raises(api.IcetError) as ei:
+            gpu_ctx.solve(a, b, 3, np.zeros(6), P, T)
+        assert st in str(ei.value), (T, P, str(ei.value))
+    r = gpu_ctx.solve(a, b, 3, np.zeros(6), 24, 75)                     # the context is usable after a refusal
+    assert np.isfinite(r["X"]).all()

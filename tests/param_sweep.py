@@ -215,3 +215,22 @@ def run_node_case(ctx, kw, frames):
         if not same: bad.append("burst frame %d differs from the frame-by-frame push" % k)
     nb.close()
     return bad
+
+
+# ---- sort-key stress: ties by the ten thousand ----------------------------------------------------------------------------------------------------
+def tie_cases():
+    """[(name, scan1, scan2)]: scans made of a few distinct rows repeated many times, unit directions scaled to one range (two distinct float ranges in 60 000 rows),
+    a scan whose first half is ONE row."""
+    rng = np.random.default_rng(5)
+    a0, b0 = pools()[0]
+    cases = []
+    for distinct, n in ((1, 50000), (5, 200000), (40, 120000), (1000, 300000)):
+        pts = a0[rng.choice(len(a0), distinct, replace=False)]
+        pts = pts[np.linalg.norm(pts, axis=1) > 0] if distinct > 1 else a0[np.linalg.norm(a0, axis=1) > 1][:1]
+        cases.append(("%d distinct rows x %d" % (len(pts), n), pts[rng.integers(0, len(pts), n)].copy(), pts[rng.integers(0, len(pts), n)].copy()))
+    shell = a0[np.linalg.norm(a0, axis=1) > 1][:60000].astype(np.float64)
+    shell = (shell / np.linalg.norm(shell, axis=1, keepdims=True) * 8.0).astype(np.float32)          # ranges within an ulp or two of 8: thousands of exact ties
+    cases.append(("unit directions x 8.0", shell, shell[::-1].copy()))
+    half = a0.copy(); half[: len(half) // 2] = half[0]                                                  # half the scan is ONE row
+    cases.append(("half the scan one row", half, b0))
+    return cases

@@ -1634,3 +1634,17 @@ def test_extreme_grids_up_to_the_voxel_limit(gpu_ctx, frames):
         assert st in str(ei.value), (T, P, str(ei.value))
     r = gpu_ctx.solve(a, b, 3, np.zeros(6), 24, 75)                     # the context is usable after a refusal
     assert np.isfinite(r["X"]).all()
+
+
+def test_massive_sort_ties(gpu_ctx):
+    """The rank sort under ties by the ten thousand (tests/param_sweep.tie_cases; scripts/fuzz_ties.py -> profiles/r05_fuzz_ties.txt): 1, 5, 38 and 930 distinct rows
+    repeated up to 300 000 times, 60 000 unit directions scaled to ONE range, a scan whose first half is one row.  The reference's order among equal ranges is the
+    row order (stable sort, oracle header); the swap loop, the clusters and the Gaussians built on it must be the oracle's bits.  (Crowded counting-sort cells take
+    the general path of the bucket sort: such a scan costs up to 30 ms instead of 0.3 -- correct, not fast.)"""
+    from tests.param_sweep import run_case, tie_cases
+    for name, a, b in tie_cases():
+        bits, d, r, ref, fits = run_case(gpu_ctx, np.ascontiguousarray(a), np.ascontiguousarray(b), 75, 24, dict(n=25, thresh=0.1, buff=0.1), 3, np.zeros(6, np.float32))
+        assert all(bits.values()), (name, {k: v for k, v in bits.items() if not v})
+        n = a.shape[0]
+        from oracle import pyoracle as po
+        assert np.array_equal(gpu_ctx.debug_fetch("src", n), po.scramble(po.c2s(np.ascontiguousarray(a))[:, 0])), name

@@ -533,6 +533,8 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : 156 * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU; a small batch: one block per CU, nearly all of its LDS
     int lds_slots = c.lds_slots > 0 ? c.lds_slots : (int)((budget > fixed ? budget - fixed : 0) / row);
     lds_slots = lds_slots < 32 ? 32 : lds_slots;
+    const int fit = (int)((160 * 1024 - fixed) / row);               // what a block can hold at all (option "lds_slots" is a wish, not a launch failure); >= 32: ensure_thresholds
+    if (lds_slots > fit) lds_slots = fit;
     if (lds_slots > c.V) lds_slots = c.V;
     int chunks = chunks_for(c.n_pairs, c.max_n2, kAccBlock * c.acc_min_pts_per_thread, c.acc_target_blocks);
     chunks = std::max(chunks, (int)(((long long)c.max_n2 + (1 << 20) - 1) >> 20));          // a block's counts live in 21-bit fields: at most 2^20 (+ rounding) points per block

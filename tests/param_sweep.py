@@ -234,3 +234,57 @@ def tie_cases():
     half = a0.copy(); half[: len(half) // 2] = half[0]                                                  # half the scan is ONE row
     cases.append(("half the scan one row", half, b0))
     return cases
+
+
+# ---- launch-shape and path-selection knobs -----------------------------------------------------------------------------------------------------------
+# (force_exact, guard_scale and lut_polar_quantile are not here: they change WHICH points wait for the literal formulas -- the decisions stay, tests/test_gpu_parity.py
+# ::test_fast_classification_equals_literal_evaluation -- but a parked point enters the sums as a run of one, so the float partial sums are grouped differently)
+KNOBS = dict(lds_slots=[0, 32, 64, 200, 500, 1800, 100000], acc_pts=[1, 2, 8, 64], acc_blocks=[1, 100, 1536, 4000, 20000], kf_pts=[1, 2, 8],
+             batch_parts=[0, 1, 2, 3, 8], rs_cap=[0, 64, 500, 3000], rs_max_cell=[0, 1, 4, 100], exec_bits_lds=[0, 1], lds_rank=[-1, 0, 1], exec_pairwise=[-1, 0, 1],
+             graph=[-1, 0, 1])
+
+
+
+def run_knob_draws(draws, seed, log=None):
+    """Random settings of the knobs above, each in a fresh context: a single solve (twice: the second call may be a graph replay) and a ragged 40-pair device batch
+    (twice) must give the bits of the default settings.  Returns the knob settings that did not."""
+    import torch
+    from icet_amd import api
+    failed = []
+    rng = np.random.default_rng(seed)
+    pl = pools()
+    ref_ctx = api.Context()
+    dev = torch.device("cuda", 0)
+    # one ragged 40-pair batch resident in HBM
+    pairs = []
+    for k in range(40):
+        a0, b0 = pl[k % len(pl)]
+        m = [a0.shape[0], 30000, 9000][k % 3]
+        pairs.append((np.ascontiguousarray(a0[:m]), np.ascontiguousarray(b0[:m])))
+    bufs = [(torch.from_numpy(np.ascontiguousarray(a.T)).to(dev), torch.from_numpy(np.ascontiguousarray(b.T)).to(dev)) for a, b in pairs]
+    d1 = [(t.data_ptr(), t.shape[1], t.shape[1]) for t, _ in bufs]; d2 = [(t.data_ptr(), t.shape[1], t.shape[1]) for _, t in bufs]
+    prm = api.Params(5, 24, 75, 25, 0.1, 0.1, 0)
+    x0 = torch.zeros(40, 6, device=dev); x0[::3, 0] = 0.05
+    def batch(ctx):
+        out = torch.zeros(40, 48, device=dev)
+        ctx.solve_batch_device(d1, d2, prm, out.data_ptr(), x0.data_ptr()); torch.cuda.synchronize()
+        return out.cpu().numpy()
+    sa, sb = pl[1]
+    ref_single = ref_ctx.solve(sa, sb, 5, np.array([0.02, 0, 0, 0, 0, 0.001], np.float32), 24, 75)
+    ref_batch = batch(ref_ctx)
+    bad = 0
+    for dno in range(draws):
+        ctx = api.Context()
+        kn = {k: (rng.choice(v) if rng.random() < 0.5 else None) for k, v in KNOBS.items()}
+        kn = {k: (float(v) if isinstance(v, (float, np.floating)) else int(v)) for k, v in kn.items() if v is not None}
+        for k, v in kn.items(): ctx.set_option(k, v)
+        r = ctx.solve(sa, sb, 5, np.array([0.02, 0, 0, 0, 0, 0.001], np.float32), 24, 75)
+        r2 = ctx.solve(sa, sb, 5, np.array([0.02, 0, 0, 0, 0, 0.001], np.float32), 24, 75)       # (a second call: the graph replay path when "graph" allows it)
+        ob = batch(ctx); ob2 = batch(ctx)
+        ok_s = all(np.array_equal(r[k].view(np.uint32), ref_single[k].view(np.uint32)) and np.array_equal(r2[k].view(np.uint32), ref_single[k].view(np.uint32)) for k in ("X", "pred_stds", "cov"))
+        ok_b = np.array_equal(ob.view(np.uint32), ref_batch.view(np.uint32)) and np.array_equal(ob2.view(np.uint32), ref_batch.view(np.uint32))
+        bad += 0 if (ok_s and ok_b) else 1
+        if log: log("draw %3d single=%s batch=%s  %s" % (dno, "ok" if ok_s else "DIFF", "ok" if ok_b else "DIFF", kn))
+        if not (ok_s and ok_b): failed.append(kn)
+        ctx.close()
+    return failed

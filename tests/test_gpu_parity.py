@@ -1648,3 +1648,12 @@ def test_massive_sort_ties(gpu_ctx):
         n = a.shape[0]
         from oracle import pyoracle as po
         assert np.array_equal(gpu_ctx.debug_fetch("src", n), po.scramble(po.c2s(np.ascontiguousarray(a))[:, 0])), name
+
+
+def test_random_launch_knobs_do_not_show_in_the_bits():
+    """25 random settings of the launch-shape / path-selection options (tests/param_sweep.KNOBS: LDS slot rows incl. more than fit, points and blocks of the point pass,
+    keyframe tile size, batch parts, rank-sort capacity and cell limit, bit table in LDS or memory, LDS-rank or ballot multi-split, pairwise or tiled swap-loop flags,
+    graph replay on / off; 60 more by hand, profiles/r05_fuzz_knobs.txt): single solve and 40-pair device batch, first call and repeat, carry the default settings' bits."""
+    from tests.param_sweep import run_knob_draws
+    failed = run_knob_draws(25, 1)
+    assert not failed, failed[:3]

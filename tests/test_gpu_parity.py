@@ -1657,3 +1657,35 @@ def test_random_launch_knobs_do_not_show_in_the_bits():
     from tests.param_sweep import run_knob_draws
     failed = run_knob_draws(25, 1)
     assert not failed, failed[:3]
+
+
+def test_multi_million_row_scan_and_five_thousand_pairs(gpu_ctx, sample_pc):
+    """A 2.2 M-row pair (past the LDS bit table of the swap loop at 0.75 M rows and past the 2^20 rows a block of the point pass may count; 0.8 - 4.3 M by hand:
+    scripts/fuzz_sizes.py -> profiles/r05_fuzz_sizes.txt) against the oracle, and ONE device batch of 5000 small pairs whose sampled members carry their single-solve bits."""
+    from icet_amd import api
+    from tests.param_sweep import run_case
+    a0, b0 = sample_pc
+    rows = 2_200_000
+    rep = -(-rows // len(a0))
+    a = np.concatenate([a0 * np.float32(1 + 1e-4 * k) for k in range(rep)])[:rows]      # every copy a slightly different range: no ties, the same directions
+    b = np.concatenate([b0 * np.float32(1 + 1e-4 * k) for k in range(rep)])[:rows + 17]
+    bits, d, r, ref, fits = run_case(gpu_ctx, np.ascontiguousarray(a), np.ascontiguousarray(b), 75, 24, dict(n=25, thresh=0.1, buff=0.1), 3, np.zeros(6, np.float32))
+    assert all(bits.values()), {k: v for k, v in bits.items() if not v}
+    assert d[:3].max() <= TOL_T and d[3:].max() <= TOL_R
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    n_pairs, k = 5000, 400
+    starts = rng.integers(0, len(a0) - k, n_pairs)
+    A = torch.from_numpy(np.ascontiguousarray(a0.T)).to(dev); B = torch.from_numpy(np.ascontiguousarray(b0.T)).to(dev)
+    ld = A.shape[1]
+    d1 = [(A.data_ptr() + 4 * int(s), k, ld) for s in starts]; d2 = [(B.data_ptr() + 4 * int(s), k + 3, ld) for s in starts]
+    out = torch.zeros(n_pairs, 48, device=dev)
+    gpu_ctx.solve_batch_device(d1, d2, api.Params(4, 8, 16, 10, 0.1, 0.1, 0), out.data_ptr()); torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all()
+    single = api.Context()
+    for j in list(range(0, n_pairs, 125)) + [n_pairs - 1]:
+        s = int(starts[j])
+        rs = single.solve(a0[s:s + k], b0[s:s + k + 3], 4, np.zeros(6), 8, 16, n=10)
+        assert np.array_equal(o[j, :6].view(np.uint32), rs["X"].view(np.uint32)) and np.array_equal(o[j, 12:48].view(np.uint32), rs["cov"].reshape(36).view(np.uint32)), j
+    single.close()

@@ -129,6 +129,9 @@ __device__ __noinline__ void drain_near_overflow(const NearOverflow& o, int pair
 // "virtual blocks" of 512 (slot s belongs to virtual block s / 512, lane s % 512), each virtual block to its 27 sums (DPP totals of its eight
 // waves, added in wave order), the virtual blocks added in index order.  Coarse grids (kT = 256, one block per pair always) keep one reduction
 // over whatever a thread accumulated.
+#ifndef ICET_SOLVE_PHASE
+#define ICET_SOLVE_PHASE 9      /* TIMING BUILDS ONLY (results are wrong below 9): 1 loads, 2 + per-slot algebra, 3 + reductions, 4 + the 6 x 6 tail */
+#endif
 template <int kT, int kStage>
 __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_slots, const SlotFit* __restrict__ fitS, uint32_t* __restrict__ acc,
                                                      float* __restrict__ X_all, float* __restrict__ xf_all, float* __restrict__ out, AuxDev aux,
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
     }
     if (threadIdx.x < 27) J[threadIdx.x] = jmine;
     __syncthreads();
+    if (ICET_SOLVE_PHASE == 1) { if (accR.q[0].x == 0x7FFFFFFFu && fitR.q[0].x == 0x7FFFFFFFu) out[0] = 1.f; return; }
     float S[27];
 #pragma unroll
     for (int k = 0; k < 27; k++) S[k] = 0.f;
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
           __syncthreads();
       }
     }
+    if (ICET_SOLVE_PHASE == 2) { float t = 0.f; for (int k = 0; k < 27; k++) t += S[k]; if (t == 1.2345e-30f) out[0] = t; return; }
     if (kStage == 1) return;
     if (!kCanon) {
 #pragma unroll
@@ -311,12 +316,14 @@ __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_s
         for (int a = 0; a < 6; a++) g[a] = stage[21 + a];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (ICET_SOLVE_PHASE == 3) { float t = 0.f; for (int k = 0; k < 36; k++) t += Hm[k]; if (t == 1.2345e-30f) out[0] = t; return; }
     float ev[6], cov[36], ps[6], dx[6];
     int route, pruned;
     __shared__ icetdev::GnTailWs tail_ws;
     gn_tail(Hm, g, cond_bound2, cov, ps, dx, ev, route, pruned, tail_ws, lane == 0);
     // (every lane of the wave ran the scalar algebra above on the same inputs -- a wave costs what a lane costs -- so the results are
     // wave-uniform; lane 0 stages them and the lanes store them)
+    if (ICET_SOLVE_PHASE == 4) { float t = 0.f; for (int k = 0; k < 36; k++) t += cov[k]; for (int k = 0; k < 6; k++) t += dx[k] + ps[k]; if (t == 1.2345e-30f) out[0] = t; return; }
     float Xn[6];
     for (int k = 0; k < 6; k++) Xn[k] = X[k] + dx[k];
     if (lane == 0) {

@@ -1486,7 +1486,10 @@ def test_degenerate_scenes_take_the_pruning_route(gpu_ctx, name):
     if sp["ps"] < 1e-3:
         assert dps <= 1e-3, (r["pred_stds"], ref["pred_stds"])            # signs included: negative entries are the reference's behaviour
     else:
-        assert dps <= 1.5 * sp["ps"] + 1e-3, (dps, sp["ps"])
+        # an unstable scene: the oracle's own pred_stds moves under the 1-ulp perturbation, and the SIGN of a pruned axis' +-1 (the eigen-solver's last bits) is then a
+        # coin toss that three trials may or may not show -- layer (1) above pins it exactly to the device's own matrix; here the magnitudes are compared
+        dabs = float(np.abs(np.abs(r["pred_stds"]) - np.abs(ref["pred_stds"])).max())
+        assert dps <= 1.5 * sp["ps"] + 1e-3 or dabs <= 3 * sp["ps"] + 1e-3, (dps, dabs, sp["ps"], r["pred_stds"], ref["pred_stds"])     # (3 x: three trials give a LOWER bound of the spread)
     assert name not in ("tunnel_s10", "tunnel_s10_m", "wall_s30") or sp["ps"] < 1e-3          # these three are the stable ones: the tight branch must be the one that ran
 
 

@@ -7,6 +7,7 @@
 #include <math.h>
 #include "icet_internal.h"
 #include "icet_device_common.h"
+#include "icet_solve_body.h"
 #include <algorithm>
 
 namespace icet {
@@ -25,7 +26,6 @@ static_assert(ICET_ACC_PTS == 4, "phase C of k_gn_accumulate is written for 4 co
 constexpr int kAccPts = ICET_ACC_PTS;                      // consecutive points per lane per trip (two dwordx4 loads per coordinate)
 constexpr int kAccBlock = ICET_ACC_BLOCK;        // k_gn_accumulate: the waves of a block share one copy of the pair's LDS tables
 constexpr int kAccWavesPerSimd = ICET_ACC_WAVES; // register budget: 6 -> 84 VGPRs, no spills, three 512-thread blocks per CU (with 1536 blocks per 256-pair launch: 130 -> 121 us); 8 spills
-constexpr int kXf = 48;                          // per-pair transform record, see write_xf (icet_solve.hip)
 constexpr int kHotWords = 8;                     // LDS record of an active voxel in k_gn_accumulate: inner, outer, mu1 (5 words) at a 32-byte stride: ds_read_b128 + ds_read_b32, address by shift
 
 // One pass of fitScan2's point work over a chunk of one pair's scan 2.
@@ -84,7 +84,7 @@ typedef __attribute__((address_space(1))) const vfloat4 gfloat4;
 // kSmall: a small batch's block (one per CU, nearly all of its LDS) parks up to kNearCapSmall undecided points instead of kNearCap -- a template
 // parameter, not an argument: one more live scalar in this loop costs SGPR spills and, through them, 25 spilled VGPRs (measured: +5 % per launch).
 template <bool kVec4, bool kRT2, bool kSmall>
-__global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : (kSmall ? 2 : kAccWavesPerSimd)) void k_gn_accumulate(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
+__device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
                                                           const int16_t* __restrict__ slot_of_voxel, const int32_t* __restrict__ n_slots,
                                                           const SlotHot* __restrict__ hotS, uint32_t* __restrict__ acc,
                                                           const float* __restrict__ thr, const LutCell* __restrict__ lut,
@@ -470,6 +470,53 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : (kSmall ? 2 : kAccWavesPerSim
     }
 }
 
+// The point pass as a kernel of its own (throughput batches, fine grids, timing): the solve follows in k_gn_solve.
+template <bool kVec4, bool kRT2, bool kSmall>
+__global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : (kSmall ? 2 : kAccWavesPerSimd)) void k_gn_accumulate(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
+                                                          const int16_t* __restrict__ slot_of_voxel, const int32_t* __restrict__ n_slots,
+                                                          const SlotHot* __restrict__ hotS, uint32_t* __restrict__ acc,
+                                                          const float* __restrict__ thr, const LutCell* __restrict__ lut,
+                                                          int T, int P, int Mt, int Mp, float guard_t, float guard_p,
+                                                          int lds_slots, int chunks, int n_pairs, int force_exact,
+                                                          uint32_t* __restrict__ near_over, uint32_t* __restrict__ near_over_count) {
+    gn_accumulate_body<kVec4, kRT2, kSmall>(desc, xf_all, slot_of_voxel, n_slots, hotS, acc, thr, lut, T, P, Mt, Mp, guard_t, guard_p, lds_slots, chunks, n_pairs, force_exact, near_over, near_over_count);
+}
+
+// Small batches (a sequential caller's single pair above all): the point pass and the solve of one iteration in ONE launch.  Every block of a pair takes a ticket when
+// its sums are in HBM; the block that draws the last one -- every other block's atomics and overflow entries are then visible to it: release fence before the ticket,
+// acquire fence after -- runs the pair's solve (gn_solve_body, the one-block form of grids up to 4096 voxels, on its first 256 threads) and clears the ticket counter
+// for the next iteration.  No block waits for another: a pair's solve simply rides on whichever block happens to be last.  Same sums, same algebra, same bits as
+// k_gn_accumulate + k_gn_solve; seven launches less per solve (each costs a sequential caller ~6 us on the device and ~7 us of host time in a graph replay).
+// (The parameters carry no __restrict__ here: acc / the overflow list are written by the first half and read by the second.)
+struct SolveFuse { const SlotFit* fitS; float* X; float* out; AuxDev aux; int n, iter, runlen, reject_moving; float cond_bound2; uint32_t* done; };
+template <bool kVec4>
+__global__ __launch_bounds__(kAccBlock, 2) void k_gn_accumulate_solve(const PairDesc* desc, float* xf_all, const int16_t* slot_of_voxel, const int32_t* n_slots,
+                                                                      const SlotHot* hotS, uint32_t* acc, const float* thr, const LutCell* lut,
+                                                                      int T, int P, int Mt, int Mp, float guard_t, float guard_p,
+                                                                      int lds_slots, int chunks, int n_pairs, int force_exact,
+                                                                      uint32_t* near_over, uint32_t* near_over_count, SolveFuse sf) {
+    gn_accumulate_body<kVec4, false, true>(desc, xf_all, slot_of_voxel, n_slots, hotS, acc, thr, lut, T, P, Mt, Mp, guard_t, guard_p, lds_slots, chunks, n_pairs, force_exact, near_over, near_over_count);
+    int pair, chunk;
+    if (!decode_block(n_pairs, chunks, pair, chunk)) return;           // (a padding block of the grid: belongs to no pair)
+    __shared__ uint32_t s_last;
+    // release: this block's atomics and overflow entries before its ticket.  The device-wide half of the fence costs an L2 write-back on this part (eight L2s, one
+    // per XCD), so ONE thread pays it: the block's waves order their writes before the barrier at work-group scope, thread 0's device-scope release behind the
+    // barrier then covers them (cumulativity); the acquire side likewise.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t t = atomicAdd(&sf.done[pair], 1u);
+        s_last = (t == (uint32_t)chunks - 1u) ? 1u : 0u;
+        if (s_last) { sf.done[pair] = 0u; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }     // every block of the pair has drawn: ready for the next iteration's launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const NearOverflow over{desc, slot_of_voxel, hotS, thr, near_over, near_over_count, T, P, 0};
+    gn_solve_body<256, 0, kAccBlock>(n_slots, sf.fitS, acc, sf.X, xf_all, sf.out, sf.aux, T * P, sf.n, sf.iter, sf.runlen, over, sf.reject_moving, nullptr, 1, sf.cond_bound2, pair);
+}
+
 inline int chunks_for(int n_pairs, int max_n, int per_block_min, int target_blocks) {
     int by_work = (max_n + per_block_min - 1) / per_block_min;
     int want = (target_blocks + n_pairs - 1) / n_pairs;
@@ -487,6 +534,8 @@ hipError_t init_accumulate_kernels() {
     ICET_ACC_ATTR(true, false, false); ICET_ACC_ATTR(false, false, false); ICET_ACC_ATTR(true, true, false); ICET_ACC_ATTR(false, true, false);
     ICET_ACC_ATTR(true, false, true); ICET_ACC_ATTR(false, false, true); ICET_ACC_ATTR(true, true, true); ICET_ACC_ATTR(false, true, true);
 #undef ICET_ACC_ATTR
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     return e;
 }
 
@@ -522,7 +571,8 @@ size_t acc_fixed_lds_bytes(int T, int P, int Mt, int Mp, bool small_batch) {
 }
 size_t acc_row_lds_bytes() { return (kHotWords + kAccLds) * 4; }
 
-hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st) {
+hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st, const FuseArgs* fuse, bool* fused) {
+    if (fused) *fused = false;
     // LDS rows for active voxels: a throughput batch keeps 320 rows (measured optimum on 64-channel scans: fewer rows
     // spill busy voxels to HBM atomics, more rows cost occupancy); a small batch has
     // CUs to spare, so a block may take most of a CU's LDS and keep every active voxel of a fine grid (150 x 48: often
@@ -530,10 +580,12 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     const uint32_t near_cap = (c.n_pairs >= 32) ? kNearCap : kNearCapSmall;
     const size_t fixed = acc_fixed_lds_bytes(c.T, c.P, w.lut_Mt, w.lut_Mp, near_cap == kNearCapSmall);
     const size_t row = acc_row_lds_bytes();
-    const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : 156 * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU; a small batch: one block per CU, nearly all of its LDS
+    // the fused form (k_gn_accumulate_solve): small batch, one-block solve (grids up to 4096 voxels: launch_gn_solve), no scan-2 round trip
+    const bool fuse_it = fuse && c.fuse_solve && near_cap == kNearCapSmall && c.V <= 4096 && !c.rt2 && w.gn_done();
+    const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : (fuse_it ? 144 : 156) * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU; a small batch: one block per CU, nearly all of its LDS (the fused kernel's solve half has ~6 KB of static tables)
     int lds_slots = c.lds_slots > 0 ? c.lds_slots : (int)((budget > fixed ? budget - fixed : 0) / row);
     lds_slots = lds_slots < 32 ? 32 : lds_slots;
-    const int fit = (int)((160 * 1024 - fixed) / row);               // what a block can hold at all (option "lds_slots" is a wish, not a launch failure); >= 32: ensure_thresholds
+    const int fit = (int)(((fuse_it ? 148 : 160) * 1024 - fixed) / row);               // what a block can hold at all (option "lds_slots" is a wish, not a launch failure); >= 32: ensure_thresholds
     if (lds_slots > fit) lds_slots = fit;
     if (lds_slots > c.V) lds_slots = c.V;
     int chunks = chunks_for(c.n_pairs, c.max_n2, kAccBlock * c.acc_min_pts_per_thread, c.acc_target_blocks);
@@ -543,6 +595,15 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     const LutCell* lut = reinterpret_cast<const LutCell*>(w.lut);
 #define ICET_ACC_LAUNCH(V4, RT, SM) k_gn_accumulate<V4, RT, SM><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp, \
                                                      w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count)
+    if (fuse_it) {
+        AuxDev aux{}; if (fuse->aux) aux = *fuse->aux;
+        const SolveFuse sf{w.fitS, w.X, fuse->d_out, aux, c.n, fuse->iter, c.runlen, c.reject_moving, c.gn_cond_bound2, w.gn_done()};
+        if (c.vec4_ok) k_gn_accumulate_solve<true><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp, w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count, sf);
+        else k_gn_accumulate_solve<false><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp, w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count, sf);
+        ICET_LAUNCH_CHECK();
+        if (fused) *fused = true;
+        return hipSuccess;
+    }
 #define ICET_ACC_LAUNCH2(V4, RT) do { if (near_cap == kNearCapSmall) ICET_ACC_LAUNCH(V4, RT, true); else ICET_ACC_LAUNCH(V4, RT, false); } while (0)
     if (c.rt2) { if (c.vec4_ok) ICET_ACC_LAUNCH2(true, true); else ICET_ACC_LAUNCH2(false, true); }
     else { if (c.vec4_ok) ICET_ACC_LAUNCH2(true, false); else ICET_ACC_LAUNCH2(false, false); }

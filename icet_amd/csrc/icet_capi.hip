@@ -114,7 +114,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, dev_realloc(w.hotD, pv)); HIPCHK(c, dev_realloc(w.fitD, pv)); HIPCHK(c, dev_realloc(w.activeD, pv)); HIPCHK(c, dev_realloc(w.midD, pv));
         HIPCHK(c, dev_realloc(w.hotS, pv)); HIPCHK(c, dev_realloc(w.fitS, pv));
         HIPCHK(c, dev_realloc(w.slot_of_voxel, (size_t)np * ((VV + 1) & ~1)));
-        HIPCHK(c, dev_realloc(w.n_slots, np)); HIPCHK(c, dev_realloc(w.near_over_count, np));
+        HIPCHK(c, dev_realloc(w.n_slots, np)); HIPCHK(c, dev_realloc(w.near_over_count, 2 * (size_t)np));
         HIPCHK(c, dev_realloc(w.acc, pv * kAccWords));
         HIPCHK(c, hipMemset(w.acc, 0, pv * kAccWords * sizeof(uint32_t)));
         HIPCHK(c, dev_realloc(w.xf, (size_t)np * 48));
@@ -383,7 +383,7 @@ LaunchCfg make_cfg(icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     cfg.reject_moving = (p->flags & ICET_FLAG_REJECT_MOVING) ? 1 : 0;
     cfg.rt2 = (p->flags & ICET_FLAG_ROUNDTRIP_SCAN2) ? 1 : 0;
     cfg.lds_slots = c->tune.lds_slots; cfg.acc_min_pts_per_thread = c->tune.acc_pts; cfg.acc_target_blocks = c->tune.acc_blocks;
-    cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds; cfg.exec_pairwise = c->tune.exec_pairwise; cfg.lds_rank = (c->tune.lds_rank != 0 && c->lds_rank_ok) ? 1 : 0;
+    cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds; cfg.exec_pairwise = c->tune.exec_pairwise; cfg.fuse_solve = c->tune.fuse_solve != 0 ? 1 : 0; cfg.lds_rank = (c->tune.lds_rank != 0 && c->lds_rank_ok) ? 1 : 0;
     cfg.gn_cond_bound2 = (float)(c->tune.gn_cond_bound * c->tune.gn_cond_bound);
     if (cfg.kf_pts_per_thread > kKfMaxPtsPerThread) cfg.kf_pts_per_thread = kKfMaxPtsPerThread;      // k_bin_scatter: a tile is at most 4 waves x that many rounds x 64 positions
     if (cfg.kf_pts_per_thread < 1) cfg.kf_pts_per_thread = 1;
@@ -498,9 +498,12 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
     const bool per_iter = (p->flags & ICET_FLAG_TIMING) != 0;
     for (int it = 0; it < p->runlen; it++) {
         if (per_iter) HIPCHK(c, hipEventRecord(c->ev_acc[2 * it], c->stream));
-        HIPCHK(c, launch_gn_accumulate(wl, lcfg, c->stream));
+        // (per-iteration timing wants the two halves apart; otherwise a small batch runs the solve inside the point pass' launch)
+        const FuseArgs fa{it, d_out, aux};
+        bool fused = false;
+        HIPCHK(c, launch_gn_accumulate(wl, lcfg, c->stream, per_iter ? nullptr : &fa, &fused));
         if (per_iter) HIPCHK(c, hipEventRecord(c->ev_acc[2 * it + 1], c->stream));
-        HIPCHK(c, launch_gn_solve(wl, lcfg, it, d_out, aux, c->stream));
+        if (!fused) HIPCHK(c, launch_gn_solve(wl, lcfg, it, d_out, aux, c->stream));
         if (want_pts2 && it == p->runlen - 2) { const icet_status ps = enqueue_points2(); if (ps != ICET_OK) return ps; }
     }
     if (!c->capturing) { HIPCHK(c, hipEventRecord(c->ev_c, c->stream)); c->timing_valid = true; c->last_iters = per_iter ? p->runlen : 0; }
@@ -1197,6 +1200,7 @@ icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
     else if (k == "exec_bits_lds") t.exec_bits_lds = iv != 0;
     else if (k == "lds_rank") t.lds_rank = iv < 0 ? -1 : (iv != 0);
     else if (k == "exec_pairwise") t.exec_pairwise = iv < 0 ? -1 : (iv != 0);
+    else if (k == "fuse_solve") { t.fuse_solve = iv < 0 ? -1 : (iv != 0); c->g_solve.have_seen = c->g_keyframe.have_seen = c->g_loop.have_seen = false; }
     else if (k == "graph") { c->graph_mode = iv < 0 ? -1 : (iv != 0); c->g_solve.have_seen = c->g_keyframe.have_seen = c->g_loop.have_seen = false; }
     else if (k == "gn_cond_bound") { if (!(value >= 0.0 && value <= 1e6)) { c->err = "gn_cond_bound must lie in [0, 1e6]"; return ICET_ERR_BAD_ARG; } t.gn_cond_bound = value; c->g_solve.have_seen = c->g_keyframe.have_seen = c->g_loop.have_seen = false; }
     else if (k == "guard_scale") { if (!(value >= 1.0 && value <= 1024.0)) { c->err = "guard_scale must lie in [1, 1024]"; return ICET_ERR_BAD_ARG; } t.guard_scale = value; c->w.thr_T = 0; }   // tables are rebuilt by the next call

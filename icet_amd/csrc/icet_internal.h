@@ -113,7 +113,8 @@ struct Workspace {
     // Scan-2 points that the fast classification cannot decide and that did not fit the block's LDS queue (k_gn_accumulate):
     // point indices, one segment of n2 entries per pair, and the fill count per pair.  Drained -- and the count reset -- by
     // k_gn_solve.  Empty on ordinary data (~0.02 % of the points are undecided and a block's queue holds 512 of them).
-    uint32_t* near_over = nullptr; int64_t cap_n2 = 0; uint32_t* near_over_count = nullptr;
+    uint32_t* near_over = nullptr; int64_t cap_n2 = 0; uint32_t* near_over_count = nullptr;   // (2 x cap_pairs words: the second half are the point pass' per-pair block tickets, gn_done())
+    uint32_t* gn_done() const { return near_over_count ? near_over_count + cap_pairs : nullptr; }
     float* xf = nullptr;                      // pairs x 48: t[3], R[9] row-major, angles[3], pad, J[27] (see write_xf)
     float* gn_part = nullptr;                 // two-stage solve of fine grids: kGnPartWords floats of partial sums (icet_solve.hip)
     float* X = nullptr;                       // pairs x 6
@@ -130,6 +131,9 @@ struct Workspace {
 // Launch-shape and diagnostic knobs.  Defaults are the measured optima; every value gives the same bits
 // (tests/test_gpu_parity.py::test_rarely_taken_paths_give_the_same_bits).  Set per context through icet_set_option -- the
 // library never reads the environment.
+#ifndef ICET_FUSE_DEFAULT
+#define ICET_FUSE_DEFAULT 0       /* measured: no gain on MI355X (LABNOTES round 5); 1 / -1: small batches run the solve inside the point pass' launch */
+#endif
 struct Tuning {
     int lds_slots = 0;            // active-voxel rows kept in LDS by k_gn_accumulate (0 = sized from the LDS budget)
     int acc_pts = 4;              // k_gn_accumulate: minimum points per thread per block
@@ -143,6 +147,7 @@ struct Tuning {
     int rs_max_cell = 24;         // per-bucket counting sort: a cell above this many rows sends the bucket to the radix sort (0: always)
     int exec_bits_lds = 1;        // k_scramble_src keeps the pair's swap-loop bit table in LDS (0: reads it from memory, the path of scans above ~0.75 M rows)
     int lds_rank = -1;            // the stable multi-splits take a row's rank from the value its LDS atomic hands back (1 / -1: if this device passed lds_rank_selftest; 0: ballots per id bit)
+    int fuse_solve = ICET_FUSE_DEFAULT;   // small batches: the pair's last point-pass block runs the solve in the same launch (1 / -1), or one k_gn_solve launch per iteration (0)
     int exec_pairwise = -1;       // "did step v execute": one block per pair in index order with the bit table in LDS (k_exec_flags_pair) 1, chain walks (k_exec_flags) 0, by batch size -1
     double guard_scale = 1.0;     // multiplies the classification guard bands (tables are rebuilt)
     double lut_polar_quantile = 0.25;   // polar LUT cell width = this quantile of the polar bin widths
@@ -168,6 +173,7 @@ struct LaunchCfg {
     int force_exact = 0;              // diagnostic: route every point through the literal evaluation
     int rs_cap = 0;                   // Tuning::rs_cap
     int rs_max_cell = 24, exec_bits_lds = 1, exec_pairwise = -1;   // Tuning::rs_max_cell, ::exec_bits_lds, ::exec_pairwise
+    int fuse_solve = 0;               // Tuning::fuse_solve (-1 resolved to 1)
     int reject_moving = 0;            // ICET_FLAG_REJECT_MOVING (non-parity extension)
     int half_gap = 0;                 // ICET_FLAG_HALF_GAP_BOUNDS (non-parity extension; sets true_sort as well)
     int rt2 = 0;                      // ICET_FLAG_ROUNDTRIP_SCAN2 (parity-study option)
@@ -180,13 +186,16 @@ constexpr int kRejectMovingStartIter = 4;          // python/ICET_spherical.py:3
 // icet_keyframe.hip
 hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* aux, hipStream_t st, const int32_t* d_n1 = nullptr);   // d_n1: scan-1 row counts known to the device only (the descriptors hold upper bounds)
 // icet_solve.hip
-hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last = nullptr, const int32_t* d_n2 = nullptr);
+hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last = nullptr, const int32_t* d_n2 = nullptr);   // (also clears the block tickets)
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st);
 hipError_t launch_gn_tail_debug(const float* d_H, const float* d_g, float* d_out, int n, float bound2, hipStream_t st);     // test hook: the 6x6 tail on its own
 // `points2` of pair 0 (include/icet.h:80): scan 2 under the transform record `xf` (AuxDev::xf_last); out = n2 x 3 column-major, ld n2 (may be pinned host memory)
 hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* xf, float* out, hipStream_t st);
 // icet_accumulate.hip
-hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st);
+// fuse: when given and the launch qualifies (a small batch on a grid of <= 4096 voxels, no scan-2 round trip, option "fuse_solve" not 0), the block of each pair that
+// finishes LAST runs that pair's solve of iteration fuse->iter inside the same launch (*fused = true: the caller skips launch_gn_solve)
+struct FuseArgs { int iter; float* d_out; const AuxDev* aux; };
+hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st, const FuseArgs* fuse = nullptr, bool* fused = nullptr);
 size_t acc_fixed_lds_bytes(int T, int P, int Mt, int Mp, bool small_batch);   // LDS of a k_gn_accumulate block without its slot rows
 size_t acc_row_lds_bytes();
 // ICET_FLAG_ROUNDTRIP_SCAN2: points2_OG = sphericalToCartesian(cartesianToSpherical(scan 2)) (src/icet.cpp:263-275, without the permutation): w.desc -> w.desc_rt

@@ -17,9 +17,10 @@ namespace {
 // (desc / n2: the scan-2 row counts that only the device knows -- k_patch_counts' job, folded in when this is the loop's first kernel: one launch
 // less in front of a sequential caller's first iteration)
 __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X, float* __restrict__ xf, int n_pairs, float* __restrict__ xf_last,
-                             PairDesc* __restrict__ desc, const int32_t* __restrict__ n2) {
+                             PairDesc* __restrict__ desc, const int32_t* __restrict__ n2, uint32_t* __restrict__ done) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
+    if (done) done[p] = 0u;                                      // the point pass' block tickets (k_gn_accumulate_solve)
     if (n2) desc[p].n2 = max(0, min(n2[p], desc[p].n2));
     float x[6];
     for (int k = 0; k < 6; k++) { x[k] = x0 ? x0[p * 6 + k] : 0.f; X[p * 6 + k] = x[k]; }
@@ -78,7 +79,7 @@ hipError_t launch_patch_counts(const Workspace& w, const LaunchCfg& c, const int
 }
 
 hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last, const int32_t* d_n2) {
-    k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs, xf_last, w.desc, d_n2);
+    k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs, xf_last, w.desc, d_n2, w.gn_done());
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

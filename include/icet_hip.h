@@ -221,7 +221,9 @@ icet_status icet_debug_gn_tail(icet_ctx* ctx, const float* htwh, const float* ht
  * "lds_rank" (the keyframe's stable multi-splits take a row's rank among equal classes from the value its LDS atomic hands back: -1 / 1 if
  * the device passed the order self-test run at icet_create, 0 = one ballot per class-id bit; same bits either way),
  * "exec_bits_lds" (0: swap-loop bit table read from memory), "exec_pairwise" (which kernel computes the swap loop's executed-step bits:
- * 1 one block per pair from the recurrence, 0 chain walks over independent tiles, -1 by batch size), "batch_parts" (0 = automatic), "batch_stage" (0..4), "force_exact"
+ * 1 one block per pair from the recurrence, 0 chain walks over independent tiles, -1 by batch size), "fuse_solve" (batches below 32 pairs on grids up to 4096 voxels:
+ * 1 the block of a pair that finishes its share of an iteration's point pass last runs the pair's solve in the same launch -- 7 launches less per solve, same
+ * bits; default 0: measured no faster on MI355X, where a device-scope fence is an L2 write-back), "batch_parts" (0 = automatic), "batch_stage" (0..4), "force_exact"
  * (every scan-2 point through the literal classification), "library_sort" (rocPRIM radix sort instead of
  * the hand-written rank sort: only in a diagnostic build, `make EXTRA=-DICET_DIAG_LIBSORT`; the shipped library answers ICET_ERR_UNSUPPORTED), "guard_scale" (>= 1), "lut_polar_quantile" (0..1), "gn_cond_bound" (0 .. 1e6, default 2.5e5 -- a factor 4 below checkCondition's cutoff, because a float Cholesky inverse knows its own norm to a few per cent only at such condition numbers: an H^T W H whose Frobenius bound on
  * the condition number |A|_F |A^-1|_F exceeds it is inverted by the literal restatement of the reference's statements -- column-pivoted QR

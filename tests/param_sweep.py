@@ -241,7 +241,7 @@ def tie_cases():
 # ::test_fast_classification_equals_literal_evaluation -- but a parked point enters the sums as a run of one, so the float partial sums are grouped differently)
 KNOBS = dict(lds_slots=[0, 32, 64, 200, 500, 1800, 100000], acc_pts=[1, 2, 8, 64], acc_blocks=[1, 100, 1536, 4000, 20000], kf_pts=[1, 2, 8],
              batch_parts=[0, 1, 2, 3, 8], rs_cap=[0, 64, 500, 3000], rs_max_cell=[0, 1, 4, 100], exec_bits_lds=[0, 1], lds_rank=[-1, 0, 1], exec_pairwise=[-1, 0, 1],
-             graph=[-1, 0, 1])
+             graph=[-1, 0, 1], fuse_solve=[-1, 0, 1])
 
 
 

@@ -27,10 +27,10 @@ FLAG_HALF_GAP_BOUNDS = 8  # non-parity extension (half-gap cluster buffers of th
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_begin", "icet_solve_keyframe_tables", "icet_solve_end", "icet_solve_batch",
                     "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_debug_gn_tail", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_keyframe_device_n", "icet_register_device_n", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
                     "icet_multi_solve_batch", "icet_multi_solve_batch_device", "icet_multi_solve_batch_device_after", "icet_multi_solve_batch_device_async", "icet_multi_sync", "icet_multi_set_option",
-                    "icet_node_create", "icet_node_destroy", "icet_node_push", "icet_node_push_device", "icet_node_push_many_device", "icet_node_map",
+                    "icet_node_create", "icet_node_destroy", "icet_node_last_error", "icet_node_push", "icet_node_push_device", "icet_node_push_many_device", "icet_node_map",
                     "icet_node_prev_scan", "icet_node_aligned", "icet_node_snail_trail", "icet_node_last_timing", "icet_stream", "icet_device",
                     "icet_load_scan", "icet_free_scan", "icet_save_scan_npy")
-_NON_STATUS = ("icet_version", "icet_last_error", "icet_stream", "icet_device", "icet_free_scan", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context")
+_NON_STATUS = ("icet_version", "icet_last_error", "icet_node_last_error", "icet_stream", "icet_device", "icet_free_scan", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context")
 
 
 class IcetError(RuntimeError):
@@ -118,6 +118,7 @@ def load_library():
     L.icet_multi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.icet_node_create.argtypes = [C.c_void_p, C.POINTER(NodeParams), C.POINTER(C.c_void_p)]
     L.icet_node_destroy.argtypes = [C.c_void_p]
+    L.icet_node_last_error.argtypes = [C.c_void_p]; L.icet_node_last_error.restype = C.c_char_p
     L.icet_node_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(NodeResult)]
     L.icet_node_push_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(NodeResult)]
     L.icet_node_push_many_device.argtypes = [C.c_void_p, C.POINTER(DevScan), C.c_int32, C.POINTER(NodeResult)]
@@ -496,7 +497,7 @@ class Node:
         r = NodeResult()
         st = load_library().icet_node_push(self._h, a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[1], C.byref(r))
         if st != ICET_OK:
-            raise IcetError(st, "icet_node_push")
+            raise IcetError(st, "icet_node_push: " + (load_library().icet_node_last_error(self._h) or b"").decode())
         return _result_dict(r)
 
     def push_device(self, d_ptr, n, ld):
@@ -504,7 +505,7 @@ class Node:
         r = NodeResult()
         st = load_library().icet_node_push_device(self._h, C.c_void_p(int(d_ptr)), int(n), int(ld), C.byref(r))
         if st != ICET_OK:
-            raise IcetError(st, "icet_node_push_device")
+            raise IcetError(st, "icet_node_push_device: " + (load_library().icet_node_last_error(self._h) or b"").decode())
         return _result_dict(r)
 
     def push_many_device(self, frames):
@@ -514,7 +515,7 @@ class Node:
         R = (NodeResult * max(k, 1))()
         st = load_library().icet_node_push_many_device(self._h, A, k, R)
         if st != ICET_OK:
-            raise IcetError(st, "icet_node_push_many_device")
+            raise IcetError(st, "icet_node_push_many_device: " + (load_library().icet_node_last_error(self._h) or b"").decode())
         return [_result_dict(R[i]) for i in range(k)]
 
     def map(self):
@@ -523,12 +524,12 @@ class Node:
         L = load_library()
         st = L.icet_node_map(self._h, None, 0, C.byref(rows))
         if st != ICET_OK:
-            raise IcetError(st, "icet_node_map")
+            raise IcetError(st, "icet_node_map: " + (load_library().icet_node_last_error(self._h) or b"").decode())
         out = np.zeros((3, max(rows.value, 1)), np.float32)
         if rows.value:
             st = L.icet_node_map(self._h, out.ctypes.data_as(C.c_void_p), rows.value, C.byref(rows))
             if st != ICET_OK:
-                raise IcetError(st, "icet_node_map")
+                raise IcetError(st, "icet_node_map: " + (load_library().icet_node_last_error(self._h) or b"").decode())
         return np.ascontiguousarray(out[:, :rows.value].T)
 
     def prev_scan(self):
@@ -537,12 +538,12 @@ class Node:
         L = load_library()
         st = L.icet_node_prev_scan(self._h, None, 0, C.byref(rows))
         if st != ICET_OK:
-            raise IcetError(st, "icet_node_prev_scan")
+            raise IcetError(st, "icet_node_prev_scan: " + (load_library().icet_node_last_error(self._h) or b"").decode())
         out = np.zeros((3, max(rows.value, 1)), np.float32)
         if rows.value:
             st = L.icet_node_prev_scan(self._h, out.ctypes.data_as(C.c_void_p), rows.value, C.byref(rows))
             if st != ICET_OK:
-                raise IcetError(st, "icet_node_prev_scan")
+                raise IcetError(st, "icet_node_prev_scan: " + (load_library().icet_node_last_error(self._h) or b"").decode())
         return np.ascontiguousarray(out[:, :rows.value].T)
 
     def _rows(self, fn, what):
@@ -569,7 +570,7 @@ class Node:
         t = (C.c_float * 3)()
         st = load_library().icet_node_last_timing(self._h, t)
         if st != ICET_OK:
-            raise IcetError(st, "icet_node_last_timing")
+            raise IcetError(st, "icet_node_last_timing: " + (load_library().icet_node_last_error(self._h) or b"").decode())
         return dict(filter_ms=t[0], solve_ms=t[1], map_ms=t[2])
 
 

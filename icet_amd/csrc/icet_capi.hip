@@ -744,7 +744,8 @@ static icet_ctx::GraphKey graph_key_of(icet_ctx* c, const icet_params* p, int32_
     return key;
 }
 static bool graph_eligible(const icet_ctx* c, const icet_params* p, int32_t n_pairs) {
-    return c->graph_mode && n_pairs <= 8 && !(p->flags & (ICET_FLAG_TIMING | ICET_FLAG_ROUNDTRIP_SCAN2)) && !c->stage_at;
+    static const bool env_off = getenv("ICET_NO_GRAPH") != nullptr;      // (experiments: every context of the process without graph replay)
+    return !env_off && c->graph_mode && n_pairs <= 8 && !(p->flags & (ICET_FLAG_TIMING | ICET_FLAG_ROUNDTRIP_SCAN2)) && !c->stage_at;
 }
 // Runs `enq` (which enqueues on c->stream) eagerly, or captured into `slot` and replayed.  The pinned descriptor staging must already hold this call's
 // descriptors; the caller has waited for a replay in flight before it wrote them.
@@ -1209,6 +1210,9 @@ icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
     return ICET_OK;
 }
 
+} // extern "C" (reopened below)
+void icet_ctx_set_stream(icet_ctx* c, hipStream_t s) { if (c) c->stream = s; }
+extern "C" {
 void* icet_stream(icet_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
 int icet_device(const icet_ctx* c) { return c ? c->device : -1; }
 

@@ -235,3 +235,7 @@ hipError_t sort_pairs_u32(void* tmp, size_t tmp_bytes, const uint32_t* key_in, u
                           const uint32_t* val_in, uint32_t* val_out, int64_t total_n, int end_bit, hipStream_t st);
 
 }  // namespace icet
+
+// nodes: point a context at another stream for the calls that follow (the caller restores it; a captured graph replays into whatever stream is set)
+struct icet_ctx;
+void icet_ctx_set_stream(icet_ctx* c, hipStream_t s);

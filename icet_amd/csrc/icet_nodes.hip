@@ -23,6 +23,13 @@
 #include <numeric>
 #include <random>
 #include <future>
+#include <thread>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -212,6 +219,8 @@ void quat_of(const float* P /* 4x4 row-major */, float q[4]) {
 
 }  // namespace
 
+void icet_ctx_set_stream(icet_ctx* c, hipStream_t s);      // icet_capi.hip (internal)
+
 struct icet_node {
     // Keyframe pipelining: scan 2 of frame k is scan 1 of frame k + 1, so the keyframe of a scan is built the
     // moment the scan arrives, on the OTHER of two contexts / streams, while the Gauss-Newton loop of the current pair iterates; the
@@ -244,6 +253,8 @@ struct icet_node {
     // icet_node_push_many_device: per-frame results and kept-row counts of a burst, in HBM until its end, and the events that order the three streams
     float* d_out_all = nullptr; float* h_out_all = nullptr; int32_t* d_nk_all = nullptr; int32_t* h_nk_all = nullptr; int cap_many = 0;
     hipEvent_t ev_loop = nullptr, ev_kf = nullptr;
+    hipEvent_t ev_kfdone[2] = {nullptr, nullptr}; bool kf_built[2] = {false, false};          // per context: its last keyframe build has been enqueued / the event behind it
+    hipEvent_t ev_loop2[2] = {nullptr, nullptr}, ev_kf2[2] = {nullptr, nullptr};      // per frame parity: end of the loop / of the keyframe build (a burst's filter waits for the frame two back)
 };
 
 namespace {
@@ -281,6 +292,7 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
             nd->owner = 0;
             icet_status ks = icet_keyframe_device(nd->kf[0], &sp, 1, &a);
             if (ks != ICET_OK) { nd->err = icet_last_error(nd->kf[0]); return ks; }
+            NCHK(nd, hipEventRecord(nd->ev_kfdone[0], reinterpret_cast<hipStream_t>(icet_stream(nd->kf[0])))); nd->kf_built[0] = true; nd->kf_built[1] = false;
         }
         nd->initialized = true;
         res->solved = 0; res->n_kept = n;
@@ -355,19 +367,30 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         // the loop against the keyframe parked one frame ago (the host has synchronised the filter's stream above), then -- behind
         // it in host order, beside it on the device -- the keyframe of THIS scan on the other context, for the next frame
         icet_ctx* own = nd->kf[nd->owner]; icet_ctx* oth = nd->kf[nd->owner ^ 1];
-        so = reinterpret_cast<hipStream_t>(icet_stream(own));
-        if (fast) {                                               // nobody waited for the filter: both solve streams do
+        hipStream_t s_own = reinterpret_cast<hipStream_t>(icet_stream(own)), s_oth = reinterpret_cast<hipStream_t>(icet_stream(oth));
+        // The loop runs on the FILTER's stream: a dependency between two streams costs ~60 us on this part before the waiting queue starts (measured on the device
+        // timeline: filter end -> first loop kernel), and filter -> loop -> result is the frame's critical path.  The context keeps its own stream for its keyframe
+        // builds; the build this loop needs (previous frame, that stream) finished long ago as a rule -- an event says so.
+        static const bool loop_on_filter_stream = getenv("ICET_NODE_LOOP_OWN_STREAM") == nullptr;
+        so = loop_on_filter_stream ? st : s_own;
+        if (loop_on_filter_stream) {
+            if (nd->kf_built[nd->owner]) NCHK(nd, hipStreamWaitEvent(st, nd->ev_kfdone[nd->owner], 0));
+            if (fast) NCHK(nd, hipStreamWaitEvent(s_oth, nd->ev[1], 0));
+            icet_ctx_set_stream(own, st);
+        } else if (fast) {                                        // nobody waited for the filter: both solve streams do
             NCHK(nd, hipStreamWaitEvent(so, nd->ev[1], 0));
-            NCHK(nd, hipStreamWaitEvent(reinterpret_cast<hipStream_t>(icet_stream(oth)), nd->ev[1], 0));
+            NCHK(nd, hipStreamWaitEvent(s_oth, nd->ev[1], 0));
         }
         NCHK(nd, hipEventRecord(nd->ev[5], so));
         // X0 is read from pinned host memory by the kernel itself (no H2D command); the results stay in HBM during the loop and come back in one copy
         s = icet_register_device_n(own, &sp, 1, &b, fast ? d_cnt : nullptr, nd->h_x0, nd->d_out);
+        icet_ctx_set_stream(own, s_own);
         if (s != ICET_OK) { nd->err = icet_last_error(own); return s; }
         NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, so));
         NCHK(nd, hipEventRecord(nd->ev[2], so));
         s = icet_keyframe_device_n(oth, &sp, 1, &b, fast ? d_cnt : nullptr);
         if (s != ICET_OK) { nd->err = icet_last_error(oth); return s; }
+        NCHK(nd, hipEventRecord(nd->ev_kfdone[nd->owner ^ 1], s_oth)); nd->kf_built[nd->owner ^ 1] = true;
         flip_owner = true;                                        // committed together with nd->prev once the frame has succeeded
     } else {
         s = icet_solve_batch_device(nd->ctx, &sp, 1, &a, &b, nd->h_x0, nd->d_out);
@@ -523,19 +546,70 @@ icet_status push_many_fast(icet_node* nd, const icet_dev_scan* fr, int K, icet_n
         nd->cap_many = K;
     }
     if (!nd->ev_loop) { NCHK(nd, hipEventCreateWithFlags(&nd->ev_loop, hipEventDisableTiming)); NCHK(nd, hipEventCreateWithFlags(&nd->ev_kf, hipEventDisableTiming)); }
+    for (int i = 0; i < 2; i++) if (!nd->ev_loop2[i]) { NCHK(nd, hipEventCreateWithFlags(&nd->ev_loop2[i], hipEventDisableTiming)); NCHK(nd, hipEventCreateWithFlags(&nd->ev_kf2[i], hipEventDisableTiming)); }
     icet_params sp = nd->p.solve; sp.flags = ICET_FLAG_NONE;
     std::memcpy(nd->h_x0, nd->X0, sizeof(nd->X0));
     int prev = nd->prev, owner = nd->owner;
+    // A burst is bound by the host: per frame three filter launches, the loop's graph (~80 us of host time) and the keyframe's graph (~140 us), all on one thread.
+    // The keyframe builds go to a helper thread: they run on the OTHER context / stream of each frame and depend on nothing the main thread does after it has made
+    // that stream wait for the frame's filter.  What the two threads must agree on: frame k + 1's loop is enqueued on the context frame k's keyframe build was
+    // enqueued on -- behind it, so the main thread waits (on the host) until the helper has finished enqueueing frame k's build.
+    struct KfJob { icet_ctx* ctx; icet_dev_scan b; const int32_t* d_cnt; hipStream_t sk; hipEvent_t done_ev; };
+    struct KfShared { std::mutex m; std::condition_variable cv; std::deque<KfJob> q; int done = 0; bool stop = false; icet_status status = ICET_OK; std::string err; double t_job = 0; } sh;
+    const bool helper_on = !(nd->p.flags & ICET_NODE_SERIAL_ENQUEUE) && K > 1;
+    std::thread helper;
+    if (helper_on) helper = std::thread([&sh, nd, sp]() {
+        (void)hipSetDevice(nd->device);
+        for (;;) {
+            KfJob j;
+            { std::unique_lock<std::mutex> lk(sh.m); sh.cv.wait(lk, [&] { return sh.stop || !sh.q.empty(); }); if (sh.q.empty()) return; j = sh.q.front(); sh.q.pop_front(); }
+            icet_status s = ICET_OK; std::string e;
+            if (sh.status == ICET_OK) {                               // (after a failure the remaining jobs are only counted)
+                const double tj = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                s = icet_keyframe_device_n(j.ctx, &sp, 1, &j.b, j.d_cnt);
+                sh.t_job += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - tj;
+                if (s != ICET_OK) e = icet_last_error(j.ctx);
+                else if (hipEventRecord(j.done_ev, j.sk) != hipSuccess) { s = ICET_ERR_HIP; e = "hipEventRecord(ev_kf)"; }
+            }
+            { std::lock_guard<std::mutex> lk(sh.m); if (s != ICET_OK && sh.status == ICET_OK) { sh.status = s; sh.err = e; } sh.done++; }
+            sh.cv.notify_all();
+        }
+    });
+    auto helper_finish = [&]() { if (helper.joinable()) { { std::lock_guard<std::mutex> lk(sh.m); sh.stop = true; } sh.cv.notify_all(); helper.join(); } };
+    struct Joiner { decltype(helper_finish)& f; ~Joiner() { f(); } } joiner{helper_finish};      // every return path below joins the helper
+    // (In the frame-by-frame path the loop runs on the filter's stream -- +10 % frames/s.  Here it does not pay: a burst is a chain loop k-1 -> build k -> loop k+1 across
+    // two streams whichever way the loops are placed; measured 3.68 k frames/s with the loops on the filter's stream against 3.81 k on their contexts' streams.)
+    static const bool loops_on_st = getenv("ICET_NODE_BURST_LOOPS_ON_FILTER_STREAM") != nullptr;
+    if (loops_on_st) for (icet_ctx* c : nd->kf) NCHK(nd, hipStreamSynchronize(reinterpret_cast<hipStream_t>(icet_stream(c))));     // the build the first loop needs was enqueued by an earlier call: done (once per burst)
+    int posted = 0;
+    const bool trace = getenv("ICET_NODE_TRACE") != nullptr; double t_filter = 0, t_wait = 0, t_reg = 0, t_kf_inline = 0;
+    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     for (int k = 0; k < K; k++) {
+        const double t0 = now();
+        double tw = 0;
+        if (helper_on) {
+            // The previous frame's build may still be being enqueued -- possibly CAPTURED into a graph -- by the helper, on the stream this frame's loop will use and
+            // on which two frames' old events were recorded.  Nothing of this frame may touch that stream before the helper is done with it: not a stream wait on
+            // it, and not a wait on an event that was recorded on it either (HIP refuses that with "dependency created on uncaptured work in another stream" while
+            // the recording stream is capturing, whenever the event was recorded -- found as a failure of one run in three of the burst test).
+            std::unique_lock<std::mutex> lk(sh.m);
+            sh.cv.wait(lk, [&] { return sh.done >= posted; });
+            if (sh.status != ICET_OK) { nd->err = sh.err; return sh.status; }
+            tw = now() - t0; t_wait += tw;
+        }
         const int cur = prev ^ 1;
         const int64_t n = fr[k].n, ld = fr[k].ld, lcur = nd->cap_scan[cur];
         icet_ctx* own = nd->kf[owner]; icet_ctx* oth = nd->kf[owner ^ 1];
-        hipStream_t so = reinterpret_cast<hipStream_t>(icet_stream(own)), sk = reinterpret_cast<hipStream_t>(icet_stream(oth));
+        // the loop runs on the filter's stream, as in the frame-by-frame path (no stream-to-stream dependency between filter and loop, and none for the X0 chain);
+        // the keyframe builds keep their contexts' own streams
+        hipStream_t s_own = reinterpret_cast<hipStream_t>(icet_stream(own)), sk = reinterpret_cast<hipStream_t>(icet_stream(oth));
+        hipStream_t so = loops_on_st ? st : s_own;
         int32_t* d_cnt = nd->d_nkept + cur;
-        // the buffer and the counter this frame's filter writes were last read by frame k - 2 (its loop and its keyframe build); the previous frame's loop ran on
-        // the stream of that keyframe build and after that loop's result: behind ev_loop both are done.  (NOT behind ev_kf: the previous frame's keyframe build
-        // runs beside its loop and may run on beside this filter -- it reads the OTHER buffer.)
-        if (k > 0) NCHK(nd, hipStreamWaitEvent(st, nd->ev_loop, 0));
+        // the buffer and the counter this frame's filter writes were last read by frame k - 2: by its loop (as scan 2) and by its keyframe build (as scan 1).  The
+        // filter waits for exactly those two (events per frame parity) -- not for the previous frame's loop, which only ends a whole loop later: measured, that
+        // wait held the next filter, and behind it the next keyframe build, back by ~55 us per frame.  (The frames before the burst ended with a host wait.)
+        if (k > 1) { if (!loops_on_st) NCHK(nd, hipStreamWaitEvent(st, nd->ev_loop2[k & 1], 0)); NCHK(nd, hipStreamWaitEvent(st, nd->ev_kf2[k & 1], 0)); }      // (the loops share the filter's stream: stream order)
         const float *x = fr[k].ptr, *y = x + ld, *z = x + 2 * ld;
         float* o = nd->d_scan[cur];
         const int n_blocks = (int)((n + kFB * kFRows - 1) / (kFB * kFRows));
@@ -546,26 +620,46 @@ icet_status push_many_fast(icet_node* nd, const icet_dev_scan* fr, int K, icet_n
             NCHK(nd, hipGetLastError());
         }
         NCHK(nd, hipEventRecord(nd->ev[1], st));
-        NCHK(nd, hipStreamWaitEvent(so, nd->ev[1], 0));
-        NCHK(nd, hipStreamWaitEvent(sk, nd->ev[1], 0));
+        const double t1 = now(); t_filter += t1 - t0 - tw;
+        const double t2 = t1;
+        if (!loops_on_st) NCHK(nd, hipStreamWaitEvent(so, nd->ev[1], 0));
+        NCHK(nd, hipStreamWaitEvent(sk, nd->ev[1], 0));                              // (behind the filter in st's order lies the previous loop, which read the tables this build overwrites)
         // X0: the node's seed for the burst's first frame, then the previous frame's X (or zeros), device to device
         if (k == 0) NCHK(nd, hipMemcpyAsync(nd->d_x0, nd->h_x0, sizeof(float) * 6, hipMemcpyHostToDevice, so));
-        else NCHK(nd, hipStreamWaitEvent(so, nd->ev_loop, 0));                       // the previous frame's result and the X0 made from it (on the other context's stream)
+        else if (!loops_on_st) NCHK(nd, hipStreamWaitEvent(so, nd->ev_loop2[(k - 1) & 1], 0));         // the previous frame's result and the X0 made from it (on the other context's stream)
+        if (loops_on_st && k > 0) NCHK(nd, hipStreamWaitEvent(st, nd->ev_kf2[(k - 1) & 1], 0));       // this loop reads the tables the previous frame's build wrote (on that context's stream)
         icet_dev_scan b{nd->d_scan[cur], lcur, lcur};                               // rows: the buffer's capacity as upper bound, the count is read on the device
+        if (helper_on) {
+            // this frame's build may start now (its stream waits for the filter); the loop goes on `own`, the context of the PREVIOUS frame's build: behind it (above)
+            { std::lock_guard<std::mutex> lk(sh.m); sh.q.push_back(KfJob{oth, b, d_cnt, sk, nd->ev_kf2[k & 1]}); } sh.cv.notify_all(); posted++;
+        }
+        if (loops_on_st) icet_ctx_set_stream(own, st);
         icet_status s = icet_register_device_n(own, &sp, 1, &b, d_cnt, nd->d_x0, nd->d_out);
+        icet_ctx_set_stream(own, s_own);
         if (s != ICET_OK) { nd->err = icet_last_error(own); return s; }
         k_burst_collect<<<1, 64, 0, so>>>(nd->d_out, nd->d_out_all + 48 * (size_t)k, nd->d_x0, nd->p.seed_x0 ? 1 : 0);
         NCHK(nd, hipGetLastError());
-        NCHK(nd, hipEventRecord(nd->ev_loop, so));
-        s = icet_keyframe_device_n(oth, &sp, 1, &b, d_cnt);
-        if (s != ICET_OK) { nd->err = icet_last_error(oth); return s; }
-        NCHK(nd, hipEventRecord(nd->ev_kf, sk));
+        NCHK(nd, hipEventRecord(nd->ev_loop2[k & 1], so));
+        const double t3 = now(); t_reg += t3 - t2;
+        if (!helper_on) {
+            s = icet_keyframe_device_n(oth, &sp, 1, &b, d_cnt);
+            if (s != ICET_OK) { nd->err = icet_last_error(oth); return s; }
+            NCHK(nd, hipEventRecord(nd->ev_kf2[k & 1], sk));
+        }
+        t_kf_inline += now() - t3;
         prev = cur; owner ^= 1;
+    }
+    const double t_enq = now() - t_begin;
+    if (helper_on) {
+        { std::unique_lock<std::mutex> lk(sh.m); sh.cv.wait(lk, [&] { return sh.done >= posted; }); }
+        helper_finish();
+        if (sh.status != ICET_OK) { nd->err = sh.err; return sh.status; }
     }
     for (icet_ctx* c : nd->kf) NCHK(nd, hipStreamSynchronize(reinterpret_cast<hipStream_t>(icet_stream(c))));
     NCHK(nd, hipMemcpyAsync(nd->h_out_all, nd->d_out_all, sizeof(float) * 48 * (size_t)K, hipMemcpyDeviceToHost, st));
     NCHK(nd, hipMemcpyAsync(nd->h_nk_all, nd->d_nk_all, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
     NCHK(nd, hipStreamSynchronize(st));
+    if (trace) fprintf(stderr, "burst K=%d helper=%d: enqueue %.0f us total (per frame: filter+events %.1f, wait for helper %.1f, loop graph %.1f, keyframe inline %.1f; helper job %.1f), until results %.0f us\n", K, (int)helper_on, t_enq, t_filter / K, t_wait / K, t_reg / K, t_kf_inline / K, sh.t_job / K, now() - t_begin);
     for (int k = 0; k < K; k++) finish_frame_host(nd, nd->h_out_all + 48 * (size_t)k, nd->h_nk_all[k], &res[k]);
     nd->prev = prev; nd->owner = owner;
     nd->n_scan[prev] = nd->h_nk_all[K - 1]; nd->ld_scan[prev] = nd->cap_scan[prev];
@@ -610,6 +704,7 @@ icet_status icet_node_create(icet_ctx* ctx, const icet_node_params* p, icet_node
         hipHostMalloc(reinterpret_cast<void**>(&nd->h_out), sizeof(float) * 48) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_x0), sizeof(float) * 6) != hipSuccess)
         return fail(ICET_ERR_NOMEM);
     for (hipEvent_t& e : nd->ev) if (hipEventCreate(&e) != hipSuccess) return fail(ICET_ERR_HIP);
+    for (hipEvent_t& e : nd->ev_kfdone) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(ICET_ERR_HIP);
     if (!(p->flags & ICET_NODE_NO_PIPELINE)) {
         for (icet_ctx*& k : nd->kf) { icet_status cs = icet_create(&k, nd->device, nullptr); if (cs != ICET_OK) return fail(cs); }
         nd->pipelined = true;
@@ -637,6 +732,9 @@ icet_status icet_node_destroy(icet_node* nd) {
     for (hipEvent_t e : nd->ev) if (e) (void)hipEventDestroy(e);
     if (nd->ev_loop) (void)hipEventDestroy(nd->ev_loop);
     if (nd->ev_kf) (void)hipEventDestroy(nd->ev_kf);
+    for (hipEvent_t e : nd->ev_loop2) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : nd->ev_kfdone) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : nd->ev_kf2) if (e) (void)hipEventDestroy(e);
     if (nd->d_out_all) (void)hipFree(nd->d_out_all);
     if (nd->d_nk_all) (void)hipFree(nd->d_nk_all);
     if (nd->h_out_all) (void)hipHostFree(nd->h_out_all);
@@ -645,6 +743,8 @@ icet_status icet_node_destroy(icet_node* nd) {
     delete nd;
     return ICET_OK;
 }
+
+const char* icet_node_last_error(const icet_node* nd) { return nd ? nd->err.c_str() : ""; }
 
 icet_status icet_node_push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t ld, icet_node_result* res) {
     if (!nd || !res || n < 0 || ld < n || (n > 0 && !d_scan) || n >= ((int64_t)1 << 30)) return ICET_ERR_BAD_ARG;

@@ -43,8 +43,10 @@ typedef struct icet_node_params {
 enum { ICET_NODE_NO_RANGE_FILTER = 1,   /* every row of every scan is kept (min_range ignored)                              */
        ICET_NODE_ALIGNED_CLOUD   = 2,   /* keep scan2_in_scan1_frame of the last frame on the device (icet_node_aligned)    */
        ICET_NODE_SNAIL_TRAIL     = 4,   /* maintain the snail trail (icet_node_snail_trail)                                 */
-       ICET_NODE_NO_PIPELINE     = 8 }; /* build every frame's keyframe inside its own solve, as the reference does, instead of one frame
+       ICET_NODE_NO_PIPELINE     = 8,   /* build every frame's keyframe inside its own solve, as the reference does, instead of one frame
                                            ahead on a second stream (same result bits either way; for A/B timing and the tests)          */
+       ICET_NODE_SERIAL_ENQUEUE  = 16 }; /* icet_node_push_many_device: enqueue the keyframe builds on the calling thread instead of a helper
+                                           thread (same result bits; for A/B timing)                                                     */
 
 typedef struct icet_node_result {
     int32_t solved;           /* 0 for the first scan: it is only stored (odometry.cpp:46-52)                              */
@@ -62,6 +64,8 @@ typedef struct icet_node icet_node;   /* opaque: previous scan in HBM, X0, pose,
 /* The node borrows `ctx` (its device, stream and workspace); destroy the node before the context. */
 icet_status icet_node_create(icet_ctx* ctx, const icet_node_params* p, icet_node** out);
 icet_status icet_node_destroy(icet_node* node);
+/* What went wrong in the last call on this node that did not return ICET_OK (the failing HIP call or the solve's own message); "" if nothing did. */
+const char* icet_node_last_error(const icet_node* node);
 
 /* One lidar frame.  `scan` is a HOST pointer in icet_node_push and a DEVICE pointer in icet_node_push_device (the
  * buffer may be reused as soon as the call returns: the node keeps its own filtered copy).  Both return after the frame's

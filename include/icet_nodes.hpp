@@ -56,7 +56,7 @@ public:
     bool pointCloudCallback(const float* scan, int64_t n, int64_t ld) {
         if (!node_) return false;
         status = icet_node_push(node_, scan, n, ld, &last);
-        if (status != ICET_OK) { error = "icet_node_push failed"; return false; }
+        if (status != ICET_OK) { error = std::string("icet_node_push failed: ") + icet_node_last_error(node_); return false; }
         return last.solved != 0;
     }
     // A burst of frames that already live in HBM (icet_node_push_many_device): chained on the device, one copy of all results at the end; results[k] belongs to
@@ -65,7 +65,7 @@ public:
         results.assign(n_frames > 0 ? (size_t)n_frames : 0, icet_node_result{});
         if (!node_ || n_frames <= 0) return 0;
         status = icet_node_push_many_device(node_, frames, n_frames, results.data());
-        if (status != ICET_OK) { error = "icet_node_push_many_device failed"; return 0; }
+        if (status != ICET_OK) { error = std::string("icet_node_push_many_device failed: ") + icet_node_last_error(node_); return 0; }
         last = results.back();
         int solved = 0; for (const icet_node_result& r : results) solved += r.solved != 0;
         return solved;

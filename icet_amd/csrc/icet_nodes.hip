@@ -221,6 +221,16 @@ void quat_of(const float* P /* 4x4 row-major */, float q[4]) {
 
 void icet_ctx_set_stream(icet_ctx* c, hipStream_t s);      // icet_capi.hip (internal)
 
+// The helper thread of a pipelined node: it ENQUEUES the keyframe builds (icet_keyframe_device_n on the context the build goes into, then the event that says it is
+// done) while the calling thread enqueues the frame's loop.  A build is ~20 launches or one graph launch of 20 nodes -- 35 to 140 us of host time that used to sit between
+// the loop's launch and the build's start, so that the build of frame k ran into frame k + 1, whose loop needs it.  One job at a time in order; the calling thread waits
+// for "idle" before it touches anything the helper may be using (kf_wait_idle).
+struct KfJob { icet_ctx* ctx; icet_params sp; icet_dev_scan b; const int32_t* d_cnt; hipStream_t sk; hipEvent_t done_ev; };
+struct KfWorker {
+    std::thread th; std::mutex m; std::condition_variable cv; std::deque<KfJob> q;
+    long posted = 0, done = 0; bool stop = false; icet_status status = ICET_OK; std::string err; int device = 0;
+};
+
 struct icet_node {
     // Keyframe pipelining: scan 2 of frame k is scan 1 of frame k + 1, so the keyframe of a scan is built the
     // moment the scan arrives, on the OTHER of two contexts / streams, while the Gauss-Newton loop of the current pair iterates; the
@@ -253,6 +263,7 @@ struct icet_node {
     // icet_node_push_many_device: per-frame results and kept-row counts of a burst, in HBM until its end, and the events that order the three streams
     float* d_out_all = nullptr; float* h_out_all = nullptr; int32_t* d_nk_all = nullptr; int32_t* h_nk_all = nullptr; int cap_many = 0;
     hipEvent_t ev_loop = nullptr, ev_kf = nullptr;
+    KfWorker* kw = nullptr;                                       // started with the first build that goes through it
     hipEvent_t ev_kfdone[2] = {nullptr, nullptr}; bool kf_built[2] = {false, false};          // per context: its last keyframe build has been enqueued / the event behind it
     hipEvent_t ev_loop2[2] = {nullptr, nullptr}, ev_kf2[2] = {nullptr, nullptr};      // per frame parity: end of the loop / of the keyframe build (a burst's filter waits for the frame two back)
 };
@@ -262,6 +273,48 @@ namespace {
 #define NCHK(nd, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     (nd)->err = std::string(#call) + ": " + hipGetErrorString(e_); \
     return e_ == hipErrorOutOfMemory ? ICET_ERR_NOMEM : ICET_ERR_HIP; } } while (0)
+
+bool kf_worker_start(icet_node* nd) {
+    if (nd->kw) return true;
+    try {
+        KfWorker* w = new KfWorker(); w->device = nd->device;
+        w->th = std::thread([w]() {
+            (void)hipSetDevice(w->device);
+            for (;;) {
+                KfJob j;
+                { std::unique_lock<std::mutex> lk(w->m); w->cv.wait(lk, [&] { return w->stop || !w->q.empty(); }); if (w->q.empty()) return; j = w->q.front(); w->q.pop_front(); }
+                icet_status s = ICET_OK; std::string e;
+                bool skip; { std::lock_guard<std::mutex> lk(w->m); skip = w->status != ICET_OK; }      // after a failure the jobs behind it are only counted
+                if (!skip) {
+                    s = icet_keyframe_device_n(j.ctx, &j.sp, 1, &j.b, j.d_cnt);
+                    if (s != ICET_OK) e = icet_last_error(j.ctx);
+                    else if (hipEventRecord(j.done_ev, j.sk) != hipSuccess) { s = ICET_ERR_HIP; e = "hipEventRecord(keyframe build done)"; }
+                }
+                { std::lock_guard<std::mutex> lk(w->m); if (s != ICET_OK && w->status == ICET_OK) { w->status = s; w->err = e; } w->done++; }
+                w->cv.notify_all();
+            }
+        });
+        nd->kw = w;
+        return true;
+    } catch (...) { return false; }                               // no thread to be had: the caller enqueues the builds itself
+}
+void kf_post(icet_node* nd, const KfJob& j) { { std::lock_guard<std::mutex> lk(nd->kw->m); nd->kw->q.push_back(j); nd->kw->posted++; } nd->kw->cv.notify_all(); }
+// Blocks until the helper has nothing left to enqueue; a failure of one of its jobs is reported (once) here, to whoever waits next.
+icet_status kf_wait_idle(icet_node* nd) {
+    if (!nd->kw) return ICET_OK;
+    std::unique_lock<std::mutex> lk(nd->kw->m);
+    nd->kw->cv.wait(lk, [&] { return nd->kw->done >= nd->kw->posted; });
+    const icet_status s = nd->kw->status;
+    if (s != ICET_OK) { nd->err = nd->kw->err; nd->kw->status = ICET_OK; nd->kw->err.clear(); }
+    return s;
+}
+void kf_worker_stop(icet_node* nd) {
+    if (!nd->kw) return;
+    { std::lock_guard<std::mutex> lk(nd->kw->m); nd->kw->stop = true; }
+    nd->kw->cv.notify_all();
+    if (nd->kw->th.joinable()) nd->kw->th.join();
+    delete nd->kw; nd->kw = nullptr;
+}
 
 icet_status ensure_scan(icet_node* nd, int which, int64_t n) {
     if (n <= nd->cap_scan[which]) return ICET_OK;
@@ -276,6 +329,7 @@ icet_status ensure_scan(icet_node* nd, int which, int64_t n) {
 // One frame with the raw scan already in HBM (column-major, ld).
 icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld, icet_node_result* res) {
     std::memset(res, 0, sizeof(*res));
+    { const icet_status hs = kf_wait_idle(nd); if (hs != ICET_OK) return hs; }      // the previous frame's keyframe build has been enqueued (or says why not)
     hipStream_t st = nd->stream;
     const int cur = nd->prev ^ 1;
     nd->timing_valid = false;
@@ -382,15 +436,20 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
             NCHK(nd, hipStreamWaitEvent(s_oth, nd->ev[1], 0));
         }
         NCHK(nd, hipEventRecord(nd->ev[5], so));
+        // (Handing this build to the helper thread as well -- so that it starts beside the loop and not one graph launch behind it -- was measured: 4.83-4.93 k frames/s
+        // with, 4.82-4.92 k without.  The build is not what the next frame waits for; it stays on this thread, where a failure is reported by the call that caused it.)
+        const bool via_helper = false;
         // X0 is read from pinned host memory by the kernel itself (no H2D command); the results stay in HBM during the loop and come back in one copy
         s = icet_register_device_n(own, &sp, 1, &b, fast ? d_cnt : nullptr, nd->h_x0, nd->d_out);
         icet_ctx_set_stream(own, s_own);
         if (s != ICET_OK) { nd->err = icet_last_error(own); return s; }
         NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, so));
         NCHK(nd, hipEventRecord(nd->ev[2], so));
-        s = icet_keyframe_device_n(oth, &sp, 1, &b, fast ? d_cnt : nullptr);
-        if (s != ICET_OK) { nd->err = icet_last_error(oth); return s; }
-        NCHK(nd, hipEventRecord(nd->ev_kfdone[nd->owner ^ 1], s_oth)); nd->kf_built[nd->owner ^ 1] = true;
+        if (!via_helper) {
+            s = icet_keyframe_device_n(oth, &sp, 1, &b, fast ? d_cnt : nullptr);
+            if (s != ICET_OK) { nd->err = icet_last_error(oth); return s; }
+            NCHK(nd, hipEventRecord(nd->ev_kfdone[nd->owner ^ 1], s_oth)); nd->kf_built[nd->owner ^ 1] = true;
+        }
         flip_owner = true;                                        // committed together with nd->prev once the frame has succeeded
     } else {
         s = icet_solve_batch_device(nd->ctx, &sp, 1, &a, &b, nd->h_x0, nd->d_out);
@@ -554,34 +613,11 @@ icet_status push_many_fast(icet_node* nd, const icet_dev_scan* fr, int K, icet_n
     // The keyframe builds go to a helper thread: they run on the OTHER context / stream of each frame and depend on nothing the main thread does after it has made
     // that stream wait for the frame's filter.  What the two threads must agree on: frame k + 1's loop is enqueued on the context frame k's keyframe build was
     // enqueued on -- behind it, so the main thread waits (on the host) until the helper has finished enqueueing frame k's build.
-    struct KfJob { icet_ctx* ctx; icet_dev_scan b; const int32_t* d_cnt; hipStream_t sk; hipEvent_t done_ev; };
-    struct KfShared { std::mutex m; std::condition_variable cv; std::deque<KfJob> q; int done = 0; bool stop = false; icet_status status = ICET_OK; std::string err; double t_job = 0; } sh;
-    const bool helper_on = !(nd->p.flags & ICET_NODE_SERIAL_ENQUEUE) && K > 1;
-    std::thread helper;
-    if (helper_on) helper = std::thread([&sh, nd, sp]() {
-        (void)hipSetDevice(nd->device);
-        for (;;) {
-            KfJob j;
-            { std::unique_lock<std::mutex> lk(sh.m); sh.cv.wait(lk, [&] { return sh.stop || !sh.q.empty(); }); if (sh.q.empty()) return; j = sh.q.front(); sh.q.pop_front(); }
-            icet_status s = ICET_OK; std::string e;
-            if (sh.status == ICET_OK) {                               // (after a failure the remaining jobs are only counted)
-                const double tj = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-                s = icet_keyframe_device_n(j.ctx, &sp, 1, &j.b, j.d_cnt);
-                sh.t_job += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - tj;
-                if (s != ICET_OK) e = icet_last_error(j.ctx);
-                else if (hipEventRecord(j.done_ev, j.sk) != hipSuccess) { s = ICET_ERR_HIP; e = "hipEventRecord(ev_kf)"; }
-            }
-            { std::lock_guard<std::mutex> lk(sh.m); if (s != ICET_OK && sh.status == ICET_OK) { sh.status = s; sh.err = e; } sh.done++; }
-            sh.cv.notify_all();
-        }
-    });
-    auto helper_finish = [&]() { if (helper.joinable()) { { std::lock_guard<std::mutex> lk(sh.m); sh.stop = true; } sh.cv.notify_all(); helper.join(); } };
-    struct Joiner { decltype(helper_finish)& f; ~Joiner() { f(); } } joiner{helper_finish};      // every return path below joins the helper
+    const bool helper_on = !(nd->p.flags & ICET_NODE_SERIAL_ENQUEUE) && K > 1 && kf_worker_start(nd);
     // (In the frame-by-frame path the loop runs on the filter's stream -- +10 % frames/s.  Here it does not pay: a burst is a chain loop k-1 -> build k -> loop k+1 across
     // two streams whichever way the loops are placed; measured 3.68 k frames/s with the loops on the filter's stream against 3.81 k on their contexts' streams.)
     static const bool loops_on_st = getenv("ICET_NODE_BURST_LOOPS_ON_FILTER_STREAM") != nullptr;
     if (loops_on_st) for (icet_ctx* c : nd->kf) NCHK(nd, hipStreamSynchronize(reinterpret_cast<hipStream_t>(icet_stream(c))));     // the build the first loop needs was enqueued by an earlier call: done (once per burst)
-    int posted = 0;
     const bool trace = getenv("ICET_NODE_TRACE") != nullptr; double t_filter = 0, t_wait = 0, t_reg = 0, t_kf_inline = 0;
     auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
@@ -593,9 +629,7 @@ icet_status push_many_fast(icet_node* nd, const icet_dev_scan* fr, int K, icet_n
             // on which two frames' old events were recorded.  Nothing of this frame may touch that stream before the helper is done with it: not a stream wait on
             // it, and not a wait on an event that was recorded on it either (HIP refuses that with "dependency created on uncaptured work in another stream" while
             // the recording stream is capturing, whenever the event was recorded -- found as a failure of one run in three of the burst test).
-            std::unique_lock<std::mutex> lk(sh.m);
-            sh.cv.wait(lk, [&] { return sh.done >= posted; });
-            if (sh.status != ICET_OK) { nd->err = sh.err; return sh.status; }
+            const icet_status hs = kf_wait_idle(nd); if (hs != ICET_OK) return hs;
             tw = now() - t0; t_wait += tw;
         }
         const int cur = prev ^ 1;
@@ -631,7 +665,7 @@ icet_status push_many_fast(icet_node* nd, const icet_dev_scan* fr, int K, icet_n
         icet_dev_scan b{nd->d_scan[cur], lcur, lcur};                               // rows: the buffer's capacity as upper bound, the count is read on the device
         if (helper_on) {
             // this frame's build may start now (its stream waits for the filter); the loop goes on `own`, the context of the PREVIOUS frame's build: behind it (above)
-            { std::lock_guard<std::mutex> lk(sh.m); sh.q.push_back(KfJob{oth, b, d_cnt, sk, nd->ev_kf2[k & 1]}); } sh.cv.notify_all(); posted++;
+            kf_post(nd, KfJob{oth, sp, b, d_cnt, sk, nd->ev_kf2[k & 1]});
         }
         if (loops_on_st) icet_ctx_set_stream(own, st);
         icet_status s = icet_register_device_n(own, &sp, 1, &b, d_cnt, nd->d_x0, nd->d_out);
@@ -650,16 +684,12 @@ icet_status push_many_fast(icet_node* nd, const icet_dev_scan* fr, int K, icet_n
         prev = cur; owner ^= 1;
     }
     const double t_enq = now() - t_begin;
-    if (helper_on) {
-        { std::unique_lock<std::mutex> lk(sh.m); sh.cv.wait(lk, [&] { return sh.done >= posted; }); }
-        helper_finish();
-        if (sh.status != ICET_OK) { nd->err = sh.err; return sh.status; }
-    }
+    if (helper_on) { const icet_status hs = kf_wait_idle(nd); if (hs != ICET_OK) return hs; }
     for (icet_ctx* c : nd->kf) NCHK(nd, hipStreamSynchronize(reinterpret_cast<hipStream_t>(icet_stream(c))));
     NCHK(nd, hipMemcpyAsync(nd->h_out_all, nd->d_out_all, sizeof(float) * 48 * (size_t)K, hipMemcpyDeviceToHost, st));
     NCHK(nd, hipMemcpyAsync(nd->h_nk_all, nd->d_nk_all, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
     NCHK(nd, hipStreamSynchronize(st));
-    if (trace) fprintf(stderr, "burst K=%d helper=%d: enqueue %.0f us total (per frame: filter+events %.1f, wait for helper %.1f, loop graph %.1f, keyframe inline %.1f; helper job %.1f), until results %.0f us\n", K, (int)helper_on, t_enq, t_filter / K, t_wait / K, t_reg / K, t_kf_inline / K, sh.t_job / K, now() - t_begin);
+    if (trace) fprintf(stderr, "burst K=%d helper=%d: enqueue %.0f us total (per frame: filter+events %.1f, wait for helper %.1f, loop graph %.1f, keyframe inline %.1f; helper job %.1f), until results %.0f us\n", K, (int)helper_on, t_enq, t_filter / K, t_wait / K, t_reg / K, t_kf_inline / K, 0.0, now() - t_begin);
     for (int k = 0; k < K; k++) finish_frame_host(nd, nd->h_out_all + 48 * (size_t)k, nd->h_nk_all[k], &res[k]);
     nd->prev = prev; nd->owner = owner;
     nd->n_scan[prev] = nd->h_nk_all[K - 1]; nd->ld_scan[prev] = nd->cap_scan[prev];
@@ -679,6 +709,7 @@ icet_status push_device(icet_node* nd, const float* d_scan, int64_t n, int64_t l
     } catch (const std::exception& e) { nd->err = std::string("host error: ") + e.what(); s = ICET_ERR_NOMEM;
     } catch (...) { nd->err = "host error"; s = ICET_ERR_NOMEM; }
     if (s != ICET_OK && was_initialized) {
+        (void)kf_wait_idle(nd);
         (void)hipDeviceSynchronize();
         nd->initialized = false; nd->timing_valid = false;
     }
@@ -723,6 +754,7 @@ icet_status icet_node_create(icet_ctx* ctx, const icet_node_params* p, icet_node
 
 icet_status icet_node_destroy(icet_node* nd) {
     if (!nd) return ICET_ERR_BAD_ARG;
+    kf_worker_stop(nd);                      // (drains what it still has to enqueue, then joins)
     (void)hipSetDevice(nd->device);
     (void)hipDeviceSynchronize();            // not the borrowed stream: the context may already be gone
     void* dp[] = {nd->d_scan[0], nd->d_scan[1], nd->d_stage, nd->d_counts, nd->d_bases, nd->d_nkept, nd->d_x0, nd->d_out, nd->d_map, nd->d_idx, nd->d_aligned};
@@ -757,6 +789,7 @@ icet_status icet_node_push_many_device(icet_node* nd, const icet_dev_scan* frame
     for (int k = 0; k < n_frames; k++)
         if (frames[k].n < 0 || frames[k].ld < frames[k].n || (frames[k].n > 0 && !frames[k].ptr) || frames[k].n >= ((int64_t)1 << 30)) return ICET_ERR_BAD_ARG;
     if (hipSetDevice(nd->device) != hipSuccess) return ICET_ERR_NO_DEVICE;
+    { const icet_status hs = kf_wait_idle(nd); if (hs != ICET_OK) { (void)hipDeviceSynchronize(); nd->initialized = false; return hs; } }
     int k0 = 0;
     // what cannot go through the burst path -- the very first cloud (stored, not solved), an empty cloud, and every configuration whose frame needs the host
     // in the middle (map queue, aligned cloud, snail trail, no range filter, no pipeline) -- goes frame by frame
@@ -774,7 +807,7 @@ icet_status icet_node_push_many_device(icet_node* nd, const icet_dev_scan* frame
         s = push_many_fast(nd, frames + k0, n_frames - k0, results + k0);
     } catch (const std::bad_alloc&) { nd->err = "out of host memory"; s = ICET_ERR_NOMEM;
     } catch (...) { nd->err = "host error"; s = ICET_ERR_NOMEM; }
-    if (s != ICET_OK) { (void)hipDeviceSynchronize(); nd->initialized = false; nd->timing_valid = false; }
+    if (s != ICET_OK) { (void)kf_wait_idle(nd); (void)hipDeviceSynchronize(); nd->initialized = false; nd->timing_valid = false; }
     return s;
 }
 
@@ -794,6 +827,7 @@ icet_status icet_node_push(icet_node* nd, const float* scan, int64_t n, int64_t 
 
 icet_status icet_node_map(icet_node* nd, float* out, int64_t ld, int64_t* rows_out) {
     if (!nd || !rows_out) return ICET_ERR_BAD_ARG;
+    (void)kf_wait_idle(nd);
     const int64_t rows = nd->map_filled ? nd->p.map_capacity : nd->map_pos;
     *rows_out = rows;
     if (!out || rows == 0) return ICET_OK;
@@ -814,6 +848,7 @@ icet_status icet_node_map(icet_node* nd, float* out, int64_t ld, int64_t* rows_o
 
 icet_status icet_node_prev_scan(icet_node* nd, float* out, int64_t ld, int64_t* rows_out) {
     if (!nd || !rows_out) return ICET_ERR_BAD_ARG;
+    (void)kf_wait_idle(nd);
     const int64_t rows = nd->initialized ? nd->n_scan[nd->prev] : 0;
     *rows_out = rows;
     if (!out || rows == 0) return ICET_OK;
@@ -826,6 +861,7 @@ icet_status icet_node_prev_scan(icet_node* nd, float* out, int64_t ld, int64_t* 
 
 icet_status icet_node_aligned(icet_node* nd, float* out, int64_t ld, int64_t* rows_out) {
     if (!nd || !rows_out) return ICET_ERR_BAD_ARG;
+    (void)kf_wait_idle(nd);
     const int64_t rows = nd->n_aligned;
     *rows_out = rows;
     if (!out || rows == 0) return ICET_OK;

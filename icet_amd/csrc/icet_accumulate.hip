@@ -581,7 +581,8 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     const size_t fixed = acc_fixed_lds_bytes(c.T, c.P, w.lut_Mt, w.lut_Mp, near_cap == kNearCapSmall);
     const size_t row = acc_row_lds_bytes();
     // the fused form (k_gn_accumulate_solve): small batch, one-block solve (grids up to 4096 voxels: launch_gn_solve), no scan-2 round trip
-    const bool fuse_it = fuse && c.fuse_solve && near_cap == kNearCapSmall && c.V <= 4096 && !c.rt2 && w.gn_done();
+    // (... and a grid whose tables leave the fused kernel -- 12 KB less dynamic LDS: its solve half has static tables -- fewer than the 32 slot rows every launch keeps)
+    const bool fuse_it = fuse && c.fuse_solve && near_cap == kNearCapSmall && c.V <= 4096 && !c.rt2 && w.gn_done() && fixed + 32 * row <= (size_t)148 * 1024;
     const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : (fuse_it ? 144 : 156) * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU; a small batch: one block per CU, nearly all of its LDS (the fused kernel's solve half has ~6 KB of static tables)
     int lds_slots = c.lds_slots > 0 ? c.lds_slots : (int)((budget > fixed ? budget - fixed : 0) / row);
     lds_slots = lds_slots < 32 ? 32 : lds_slots;

@@ -38,6 +38,8 @@ def child(out_path, n):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) < 2:
+        sys.exit("usage: cmp_libs.py path/to/other/libicet_hip.so [pairs]   (bitwise comparison of this build's results with another build's)")
     if sys.argv[1] == "--child":
         child(sys.argv[2], int(sys.argv[3]))
         sys.exit(0)

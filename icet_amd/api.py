@@ -25,7 +25,7 @@ FLAG_HALF_GAP_BOUNDS = 8  # non-parity extension (half-gap cluster buffers of th
 
 # every symbol include/icet_hip.h, include/icet_nodes.h and include/icet_io.h declare
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_begin", "icet_solve_keyframe_tables", "icet_solve_end", "icet_solve_batch",
-                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_debug_fetch", "icet_debug_gn_tail", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_keyframe_device_n", "icet_register_device_n", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
+                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_last_timing_iters", "icet_keep_stats", "icet_debug_fetch", "icet_debug_gn_tail", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_keyframe_device_n", "icet_register_device_n", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
                     "icet_multi_solve_batch", "icet_multi_solve_batch_device", "icet_multi_solve_batch_device_after", "icet_multi_solve_batch_device_async", "icet_multi_sync", "icet_multi_set_option",
                     "icet_node_create", "icet_node_destroy", "icet_node_last_error", "icet_node_push", "icet_node_push_device", "icet_node_push_many_device", "icet_node_map",
                     "icet_node_prev_scan", "icet_node_aligned", "icet_node_snail_trail", "icet_node_last_timing", "icet_stream", "icet_device",
@@ -97,6 +97,8 @@ def load_library():
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.icet_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.POINTER(DevScan), C.c_void_p, C.c_void_p]
     L.icet_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+    L.icet_last_timing_iters.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.icet_keep_stats.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.icet_debug_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     L.icet_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.icet_debug_gn_tail.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
@@ -227,6 +229,18 @@ class Context:
         t = np.zeros(4, np.float32)
         self._check(load_library().icet_last_timing(self._h, t.ctypes.data))
         return dict(keyframe_ms=float(t[0]), gn_loop_ms=float(t[1]), accumulate_ms=float(t[2]), accumulate_launches=int(t[3]))
+
+    def last_timing_iters(self, cap=64):
+        """Per-iteration HIP-event times (ms) of the point-pass launches of the last ICET_FLAG_TIMING call (icet_last_timing_iters)."""
+        t = np.zeros(cap, np.float32); n = C.c_int32(0)
+        self._check(load_library().icet_last_timing_iters(self._h, t.ctypes.data, cap, C.byref(n)))
+        return t[:n.value].copy()
+
+    def keep_stats(self, n_pairs):
+        """The keep list of the point pass after the last throughput batch (icet_keep_stats): (n_pairs, 4) int32 = mode, groups kept, list passes, lists built."""
+        out = np.zeros((n_pairs, 4), np.int32)
+        self._check(load_library().icet_keep_stats(self._h, n_pairs, out.ctypes.data))
+        return out
 
     def debug_gn_tail(self, htwh, htwdz):
         """icet_debug_gn_tail (test hook): the 6x6 tail of an iteration on the device for n (HTWH, HTWdz).  Returns dict of arrays with leading dimension n:

@@ -9,6 +9,7 @@
 #include "icet_device_common.h"
 #include "icet_solve_body.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace icet {
 namespace {
@@ -83,25 +84,91 @@ typedef __attribute__((address_space(1))) const vfloat4 gfloat4;
 // (src/icet.cpp:303) -- a double-precision atan2 + acos inside the loop, in a kernel of its own so that the default kernel keeps its registers.
 // kSmall: a small batch's block (one per CU, nearly all of its LDS) parks up to kNearCapSmall undecided points instead of kNearCap -- a template
 // parameter, not an argument: one more live scalar in this loop costs SGPR spills and, through them, 25 spilled VGPRs (measured: +5 % per launch).
-template <bool kVec4, bool kRT2, bool kSmall>
+// What the kernel with the keep list (kKeep) takes on top: the masks it writes in a full pass, the list it walks otherwise, the per-pair state, the bin edges in
+// the stand-in coordinates, and the margin constants of keep_margin below.
+struct KeepDev { unsigned long long* mask; const uint32_t* list; const float* edges; const int32_t* modes; float c1, c2, capT, capP, invT; };
+// Which pair the blocks of slot `s` take, and what they do with it (KeepArgs::modes_next).  Within each group of 256 slots: the pairs that walk their whole scan
+// first, then the list pairs from the longest list to the shortest (eight classes of list length between the group's extremes, index order inside a class).  Blocks
+// start in slot order and a launch is about two rounds of blocks, so what starts LAST should be SHORT: with the list pairs in index order the launch ended 15-20 us
+// after its average block slot had run dry (list lengths differ by 2x between pairs).  Every wave works the order out for itself from the group's mode words --
+// one coalesced read of 4 words per lane, then ballots on registers -- no LDS, no atomics; which block takes which pair never shows in the bits.
+__device__ __forceinline__ int keep_pair_of_slot(const int32_t* __restrict__ modes, int n_pairs, int s, int& mode_word) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int gb = s & ~255, ng = min(256, n_pairs - gb), sl = s - gb;
+    int m[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) m[c] = (c * 64 + lane < ng) ? modes[gb + c * 64 + lane] : -1;      // 0 whole scan, n_keep + 1 list, -1 no such pair
+    int hi = 0, lo = 0x7FFFFFFF;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { hi = max(hi, m[c]); lo = min(lo, m[c] > 0 ? m[c] : 0x7FFFFFFF); }
+    hi = wave_reduce_max_i(hi); lo = wave_reduce_min_i(lo);
+    const float scale = 7.999f / (float)max(hi - lo + 1, 1);
+    int cls[4], cnt[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) cnt[k] = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        cls[c] = m[c] < 0 ? 9 : (m[c] == 0 ? 0 : 1 + (int)((float)(hi - m[c]) * scale));            // 1 = the longest lists ... 8 = the shortest
+#pragma unroll
+        for (int k = 0; k < 9; k++) cnt[k] += __popcll(__ballot(cls[c] == k));
+    }
+    int k_of = 0, r = sl;                                             // the slot's class and its rank inside it
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const bool past = (k_of == k) & (r >= cnt[k]); r -= past ? cnt[k] : 0; k_of += past ? 1 : 0; }
+    int found = -1, word = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const unsigned long long bm = __ballot(cls[c] == k_of);
+        const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+        const unsigned long long hit = __ballot(cls[c] == k_of && rk == r);
+        if (found < 0 && hit != 0ull) { const int l = __builtin_ctzll(hit); found = gb + c * 64 + l; word = __builtin_amdgcn_readlane(m[c], l); }
+        r -= __popcll(bm);
+    }
+    mode_word = word;
+    return found;
+}
+constexpr int kKeepOwn = 63;            // list pass: entries a wave-trip owns (lanes 1..63); lane 0 repeats the last entry of the previous trip (the "ghost")
+
+template <bool kVec4, bool kRT2, bool kSmall, bool kKeep>
 __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
                                                           const int16_t* __restrict__ slot_of_voxel, const int32_t* __restrict__ n_slots,
                                                           const SlotHot* __restrict__ hotS, uint32_t* __restrict__ acc,
                                                           const float* __restrict__ thr, const LutCell* __restrict__ lut,
                                                           int T, int P, int Mt, int Mp, float guard_t, float guard_p,
                                                           int lds_slots, int chunks, int n_pairs, int force_exact,
-                                                          uint32_t* __restrict__ near_over, uint32_t* __restrict__ near_over_count) {
+                                                          uint32_t* __restrict__ near_over, uint32_t* __restrict__ near_over_count, const KeepDev& kd) {
     constexpr uint32_t near_cap = kSmall ? kNearCapSmall : kNearCap;
+    constexpr int kW = kAccBlock / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int V = T * P;
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;
+    [[maybe_unused]] int mode_word = 0;
+    if constexpr (kKeep) { pair = keep_pair_of_slot(kd.modes, n_pairs, pair, mode_word); if (pair < 0) return; }      // whole-scan pairs first
     const PairDesc d = desc[pair];
     int cs = (d.n2 + chunks - 1) / chunks;
     cs = (cs + kAccPts * 64 - 1) / (kAccPts * 64) * (kAccPts * 64);   // whole WAVE-trips (256 points): chunks of equal size whatever the block's trip; a block's last trip may leave waves idle
     const int begin = chunk * cs;
-    if (begin >= d.n2) return;
-    const int end = min(d.n2, begin + cs);
+    // keep list (KeepState, icet_internal.h): a pair in list mode is walked in wave-trips of kKeepOwn list entries, trips [tau_begin, tau_end) for this block
+    int list_mode = 0, nk = 0, tau_begin = 0, tau_end = 0;
+    if constexpr (kKeep) { list_mode = mode_word > 0; nk = mode_word - 1; }
+    if (kKeep && list_mode) {
+        const int n_trips = nk / kKeepOwn + 1;                            // (the last trip may own nothing: it then only finishes the previous trip's last entry)
+        int tpb = (n_trips + chunks - 1) / chunks; tpb = (tpb + kW - 1) / kW * kW;
+        tau_begin = chunk * tpb; tau_end = min(n_trips, tau_begin + tpb);
+        if (tau_begin >= n_trips) return;
+    } else if (begin >= d.n2) return;
+    const int end = (kKeep && list_mode) ? d.n2 : min(d.n2, begin + cs);
+    const int lane = (int)(threadIdx.x & 63u);
+    // list pass: lane l of trip tau holds list entry 63 tau - 1 + l.  The list is read UNCONDITIONALLY at a clamped index and the "no such entry" case is selected a
+    // trip later, when the value is used: a load under a condition is followed by its select, i.e. by a wait for the load itself and for every point load requested
+    // before it.  The first two trips' entries are requested HERE, in front of the block's table set-up, so that the first point loads can go out right behind it.
+    const uint32_t* L = kd.list + ((size_t)d.off2 >> 2) + pair;
+    const int e_max = max(nk - 1, 0);
+    auto entry_raw = [&](int tau) -> int { return (int)L[min(max(kKeepOwn * tau - 1 + lane, 0), e_max)]; };
+    auto entry_ok = [&](int tau) -> bool { return (tau < tau_end) & ((unsigned)(kKeepOwn * tau - 1 + lane) < (unsigned)nk); };
+    [[maybe_unused]] int gc_first = -1, gn_first = -1;
+    if (kKeep && list_mode) { gc_first = entry_raw(tau_begin + (int)(threadIdx.x >> 6)); gn_first = entry_raw(tau_begin + (int)(threadIdx.x >> 6) + kW); }
 
     LutCell* lut_t = reinterpret_cast<LutCell*>(smem);                    // Mt + 1 cells (the spare one catches pa == 4)
     LutCell* lut_p = lut_t + (Mt + 1);                                    // Mp + 1 cells (w == 1)
@@ -114,6 +181,11 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
     int16_t* map = reinterpret_cast<int16_t*>(hot + lds_slots * kHotWords);
     const int map_words = (V + 1) / 2;
     uint32_t* nearq = reinterpret_cast<uint32_t*>(map) + (V + T + 4) / 2;   // near_cap point indices, then the fill counter
+    // keep masks (full pass of a kKeep kernel): bin edges in pa / w units (T + 2 and P + 2 floats) and, per voxel, which of {itself, its lower-azimuth
+    // neighbour, its higher-azimuth neighbour} is active (bits 0..2), padded by T zeros in front and 2 T behind so that the rows above / below index inside
+    [[maybe_unused]] float* k_edge_t = reinterpret_cast<float*>(nearq + near_cap + 5);
+    [[maybe_unused]] float* k_edge_p = k_edge_t + (T + 2);
+    [[maybe_unused]] uint8_t* k_nb = reinterpret_cast<uint8_t*>(k_edge_p + (P + 2)) + T;
     const int ns = n_slots[pair];
     const int nl = min(ns, lds_slots);
     const SlotHot* hs = hotS + (size_t)pair * V;
@@ -154,6 +226,23 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
     const float R00 = xf[3], R01 = xf[4], R02 = xf[5], R10 = xf[6], R11 = xf[7], R12 = xf[8], R20 = xf[9], R21 = xf[10], R22 = xf[11];
     const float cell_t = (float)Mt * 0.25f, cell_p = (float)Mp * 0.5f;
     __syncthreads();
+    if constexpr (kKeep) {
+        if (!list_mode) {                                                   // block-uniform
+            for (int i = threadIdx.x; i < T + P + 4; i += kAccBlock) {
+                const int k = i < T + 2 ? i : i - (T + 2);
+                k_edge_t[i] = (i < T + 2) ? kd.edges[min(k, T)] : kd.edges[T + 1 + min(k, P)];      // (k_edge_p follows k_edge_t)
+            }
+            for (int v = (int)threadIdx.x - T; v < V + 2 * T + 1; v += kAccBlock) {
+                uint32_t code = 0u;
+                if (v >= 0 && v < V) {
+                    const int bt = v % T, r0 = v - bt;
+                    code = (map[v] >= 0 ? 1u : 0u) | (map[r0 + (bt == 0 ? T - 1 : bt - 1)] >= 0 ? 2u : 0u) | (map[r0 + (bt == T - 1 ? 0 : bt + 1)] >= 0 ? 4u : 0u);
+                }
+                k_nb[v] = (uint8_t)code;
+            }
+            __syncthreads();
+        }
+    }
 
     gfloat* px = (gfloat*)d.s2; gfloat* py = px + d.ld2; gfloat* pz = px + 2 * (size_t)d.ld2;   // scans live in HBM: global_load, not flat
     uint32_t* gacc = acc + (size_t)pair * V * kAccWords;
@@ -182,8 +271,12 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
 #endif
     [[maybe_unused]] float sink = 0.f;
     float XN[4], YN[4], ZN[4];
-    load4(begin + kAccPts * (int)threadIdx.x, XN, YN, ZN);
-    for (int t0 = begin + kAccPts * threadIdx.x; t0 < begin + cs; t0 += kAccPts * kAccBlock) {   // whole waves iterate together
+    // One wave-trip: the lane's group of 4 consecutive points starting at i0 (its raw coordinates are in XN / YN / ZN), the next group's loads issued
+    // behind the transform.  kMode 0: the plain pass; 1: a full pass that also writes the keep mask of its 256 points; 2: a pass over the keep
+    // list -- `grp` is the lane's group index in the scan (-1: none), lane 0 the ghost of the previous trip's last entry.
+    auto trip = [&](auto mode_c, const int i0, const bool have_next, const int i0_next, [[maybe_unused]] const int grp) {
+      constexpr int kMode = decltype(mode_c)::value;
+      [[maybe_unused]] const bool ghost = kMode == 2 && lane == 0;
       auto flush = [&](int slot, uint32_t cr, uint32_t ci, float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {
           if (ICET_ACC_PHASE == 4) { sink += (float)(slot + (int)cr + (int)ci) + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + a8; return; }
           if (slot >= 0) {
@@ -206,10 +299,7 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
               }
           }
       };
-      // The lane's kAccPts CONSECUTIVE points are taken 4 at a time.
-#pragma unroll
-      for (int g = 0; g < kAccPts / 4; g++) {
-        const int i0 = t0 + 4 * g;
+      {
         PointClass pc[4];
         float QX[4], QY[4], QZ[4], RR[4];
         // == transform_point (icet_device_common.h), on the scalars already in registers: the deferred literal path must see the same bits.
@@ -229,12 +319,12 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
 #pragma unroll
             for (int h = 0; h < 2; h++) { QX[2 * h] = q[3 * h].x; QX[2 * h + 1] = q[3 * h].y; QY[2 * h] = q[3 * h + 1].x; QY[2 * h + 1] = q[3 * h + 1].y; QZ[2 * h] = q[3 * h + 2].x; QZ[2 * h + 1] = q[3 * h + 2].y; }
         }
-        if (g + 1 < kAccPts / 4) load4(i0 + 4, XN, YN, ZN);
-        else if (t0 + kAccPts * kAccBlock < begin + cs) load4(t0 + kAccPts * kAccBlock, XN, YN, ZN);
-        if (ICET_ACC_PHASE == 0) { sink += (QX[0] + QX[1] + QX[2] + QX[3]) + (QY[0] + QY[1] + QY[2] + QY[3]) + (QZ[0] + QZ[1] + QZ[2] + QZ[3]); continue; }
+        if (have_next) load4(i0_next, XN, YN, ZN);
+        if (ICET_ACC_PHASE == 0) { sink += (QX[0] + QX[1] + QX[2] + QX[3]) + (QY[0] + QY[1] + QY[2] + QY[3]) + (QZ[0] + QZ[1] + QZ[2] + QZ[3]); return; }
         int SM[4];
         bool nr[4];
         float R2[4];
+        [[maybe_unused]] bool keep_any = false;
         // ---- phase A: angular classification of the 4 points.  Straight-line code (bitwise | and &, no clamps: the
         // LUTs carry one spare cell and the map T+1 spare entries, so even a NaN or pa == 4 indexes inside LDS) so
         // that the four look-up chains overlap. ----
@@ -254,6 +344,31 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
             SM[j] = map[row + bt];
             nr[j] = (force_exact != 0) | !(fabsf(pa - et.edge) >= guard_t) | !(fabsf(w - ep.edge) >= guard_p);
             R2[j] = r2;
+            if constexpr (kMode == 1) {
+                // keep_margin.  Can this point reach the angular bin of an ACTIVE voxel while X stays within the budgets of the list (|t - t_ref| <= bt,
+                // |R - R_ref|_F <= br)?  With q = R^T (p + t): |q' - q| <= br |q| + bt =: dmax, so its polar angle moves by at most asin(dmax / |q|) and its azimuth by at
+                // most asin(dmax / rho), rho the horizontal range; for ratios <= 0.5, asin(x) <= 1.05 x: Mp = c1 + c2 / |q|, Mt = (c1 |q| + c2) / rho with
+                // c1 = 1.05 br + 1e-4 (the slack covers every rounding in sight), c2 = 1.05 bt.  The stand-ins move LESS than the angles (|d pa / d theta| <= 1,
+                // |d w / d phi| <= 1), so "farther than M from an edge in pa / w" implies "farther than M in angle".  The point is kept if its own bin, or a
+                // neighbour it is within M of (3 x 3, azimuth wrapping), is active -- or if nothing can be said: M beyond a bin width or 0.5 rad (close to the
+                // sensor or to the pole axis), a guard-band / out-of-range point, an ambiguous cell.
+                const float irho = __builtin_amdgcn_rsqf(fmaf(qx, qx, qy * qy));
+                const float Mpol = fmaf(kd.c2, rs, kd.c1), Maz = fmaf(kd.c1, RR[j], kd.c2) * irho;
+                const float lo_t = k_edge_t[bt], hi_t = k_edge_t[bt + 1];
+                const int bpi = static_cast<int>(fmaf((float)row, kd.invT, 0.5f));
+                const float lo_p = k_edge_p[bpi], hi_p = k_edge_p[bpi + 1];
+                const bool nlt = !((pa - lo_t) >= Maz), nht = !((hi_t - pa) >= Maz), nlp = !((w - lo_p) >= Mpol), nhp = !((hi_p - w) >= Mpol);
+                const bool unsure = !(Maz <= kd.capT) | !(Mpol <= kd.capP) | (bt >= T) | (row >= V) | nr[j] | !((r2 >= kR2Min) & (r2 <= kR2Max));
+                const int v = row + bt;
+                const uint32_t c0 = k_nb[v], cm = k_nb[v - T], cp = k_nb[v + T];
+                const uint32_t msk = 1u | (nlt ? 2u : 0u) | (nht ? 4u : 0u);
+                const uint32_t hit = (c0 & msk) | (nlp ? (cm & msk) : 0u) | (nhp ? (cp & msk) : 0u);
+                keep_any |= (i0 + j < end) & (unsure | (hit != 0u));
+            }
+        }
+        if constexpr (kMode == 1) {
+            const unsigned long long km = __ballot(keep_any);
+            if (lane == 0 && i0 < end) kd.mask[((size_t)d.off2 >> 8) + pair + (i0 >> 8)] = km;      // lane 0's group starts an aligned block of 256 points
         }
         // |q|^2 outside [1e-30, 1e30] over- or underflows the stand-in coordinates while the literal formulas stay well defined
         // (absurd inputs, but the claim is "never decides differently"): literal path.  PER POINT since round 5: one min / max over the lane's 4 points sent
@@ -264,7 +379,7 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
         // ---- phase A2: only waves that touch an active voxel look at the hot records (radial test, d = q - mu1) ----
         // E: the point's slot, -1 for "no active voxel" and for a point that waits for the literal formulas
         const int E0 = nr[0] ? -1 : SM[0], E1 = nr[1] ? -1 : SM[1], E2 = nr[2] ? -1 : SM[2], E3 = nr[3] ? -1 : SM[3];
-        if (ICET_ACC_PHASE == 1) { sink += (float)(E0 + E1 + E2 + E3) + RR[0] + RR[1] + RR[2] + RR[3] + QX[0] + QY[1] + QZ[2]; continue; }
+        if (ICET_ACC_PHASE == 1) { sink += (float)(E0 + E1 + E2 + E3) + RR[0] + RR[1] + RR[2] + RR[3] + QX[0] + QY[1] + QZ[2]; return; }
         if (__ballot((E0 & E1 & E2 & E3) >= 0) != 0ull) {                  // some lane holds a point with E >= 0 (the sign bits do not all agree on "negative")
             // A slot beyond the LDS table (more active voxels than lds_slots; the launch sizes the table so that this is rare) keeps
             // its record in HBM.  Its points stay in the lane's runs like any other -- how the sums are grouped must not depend on a
@@ -308,7 +423,7 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
         // traffic (measured: 119 -> 238 us per launch).  The point's INDEX is parked in the block's LDS queue and classified
         // after the loop, as a run of one; past kNearCap entries (adversarial input, or the force_exact diagnostic) it goes to
         // the pair's overflow list in HBM, which k_gn_solve drains.  Integer accumulation makes the order irrelevant. ----
-        if (ICET_ACC_PHASE == 2) { for (int j = 0; j < 4; j++) sink += (float)pc[j].s + pc[j].dx + pc[j].dy + pc[j].dz + (pc[j].inb ? 1.f : 0.f) + (nr[j] ? 1.f : 0.f); continue; }
+        if (ICET_ACC_PHASE == 2) { for (int j = 0; j < 4; j++) sink += (float)pc[j].s + pc[j].dx + pc[j].dy + pc[j].dz + (pc[j].inb ? 1.f : 0.f) + (nr[j] ? 1.f : 0.f); return; }
         if (__ballot(nr[0] | nr[1] | nr[2] | nr[3]) != 0ull) {
             // A point that lands EXACTLY on the origin is not parked: r = 0, theta = atan2(+-0, +-0), phi = acos(NaN) -> 1000 (src/utils.cpp:103-116), so
             // its voxel is a function of the two sign bits and it can never pass the bounds test (phi = 1000): such points are only COUNTED, per sign
@@ -320,10 +435,11 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const bool zq = (R2[j] == 0.f) & (QX[j] == 0.f) & (QY[j] == 0.f) & (i0 + j < end);      // x = y = +-0 exactly (not a tiny vector whose squares underflow: its theta is a real angle)
+                    const bool zc = zq & !ghost;                                                         // (the ghost's points are counted and parked by the lane that owns them)
                     const int patt = (__builtin_signbit(QY[j]) ? 2 : 0) | (__builtin_signbit(QX[j]) ? 1 : 0);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const unsigned long long m = __ballot(zq & (patt == k));
+                        const unsigned long long m = __ballot(zc & (patt == k));
                         if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&nearq[near_cap + 1 + k], (uint32_t)__popcll(m));
                     }
                     nr[j] &= !zq;
@@ -331,16 +447,16 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (nr[j] & (i0 + j < end)) {
+                if (nr[j] & (i0 + j < end) & !ghost) {
                     const uint32_t e = atomicAdd(&nearq[near_cap], 1u);
                     if (e < near_cap) nearq[e] = (uint32_t)(i0 + j);
                     else near_over[(size_t)d.off2 + atomicAdd(&near_over_count[pair], 1u)] = (uint32_t)(i0 + j);
                 }
             }
         }
-        if (ICET_ACC_PHASE == 3) { for (int j = 0; j < 4; j++) sink += (float)pc[j].s + pc[j].dx + pc[j].dy + pc[j].dz + (pc[j].inb ? 1.f : 0.f); continue; }
+        if (ICET_ACC_PHASE == 3) { for (int j = 0; j < 4; j++) sink += (float)pc[j].s + pc[j].dx + pc[j].dy + pc[j].dz + (pc[j].inb ? 1.f : 0.f); return; }
         const int s0 = pc[0].s, s1 = pc[1].s, s2 = pc[2].s, s3 = pc[3].s;
-        if (__ballot((s0 >= 0) | (s1 >= 0) | (s2 >= 0) | (s3 >= 0)) == 0ull) continue;   // wave-uniform: nothing here lands in an active voxel
+        if (__ballot((s0 >= 0) | (s1 >= 0) | (s2 >= 0) | (s3 >= 0)) == 0ull) return;   // wave-uniform: nothing here lands in an active voxel
         // ---- phase C: run-length accumulation over the lane's 4 consecutive points.  Lidar storage order keeps neighbours in one
         // voxel (on the bench scans 92 % of the lanes see a single run, the rest two), so the sums are formed per RUN -- a maximal
         // group of consecutive points of one slot, summed in point order -- and a lane converts to fixed point and touches LDS once
@@ -367,7 +483,9 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
             // extended backwards over the suffix run of the previous group of the same aligned 256-point block (a wave's trip).
             const uint32_t zr = 1u + (z2 ? 1u : 0u) + (z1 ? 1u : 0u);
             const uint32_t zi = (i3 ? 1u : 0u) + ((z2 & i2) ? 1u : 0u) + ((z1 & i1) ? 1u : 0u);
-            const bool fw = z3 & (s3 >= 0) & (wave_shl1(s0, -2) == s3);
+            // (list pass: only where the next lane's group IS the next group of the same aligned 256-point block of the scan -- where the full pass hands on)
+            bool fw = z3 & (s3 >= 0) & (wave_shl1(s0, -2) == s3);
+            if constexpr (kMode == 2) fw &= (wave_shl1(grp, -7) == grp + 1) & (((grp + 1) & 63) != 0);
             const bool h1 = fw & z1 & i1, h2 = fw & z2 & i2, h3 = fw & i3;
             const float g1x = wave_shr1_zero(h1 ? pc[1].dx : 0.f), g1y = wave_shr1_zero(h1 ? pc[1].dy : 0.f), g1z = wave_shr1_zero(h1 ? pc[1].dz : 0.f);
             const float g2x = wave_shr1_zero(h2 ? pc[2].dx : 0.f), g2y = wave_shr1_zero(h2 ? pc[2].dy : 0.f), g2z = wave_shr1_zero(h2 ? pc[2].dz : 0.f);
@@ -394,14 +512,15 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
             const float A0 = Axy.x, A1 = Axy.y, A3 = Asq.x, A6 = Asq.y, A5 = Acz.x, A7 = Acz.y;
             const uint32_t ar = 1u + (a1 ? 1u : 0u) + (a2 ? 1u : 0u) + (a3 ? 1u : 0u) + (gc & 0xFFu);
             const uint32_t ai = (i0 ? 1u : 0u) + ((a1 & i1) ? 1u : 0u) + ((a2 & i2) ? 1u : 0u) + ((a3 & i3) ? 1u : 0u) + (gc >> 8);
-            flush(s0, ar, ai, A0, A1, A2, A3, A4, A5, A6, A7, A8);
+            flush(ghost ? -1 : s0, ar, ai, A0, A1, A2, A3, A4, A5, A6, A7, A8);                 // (the ghost is here for its suffix run alone)
             if (__ballot(z3 & (s3 >= 0) & !fw) != 0ull) {                   // a suffix run that could not be handed on
                 f2 Zxy, Zsq, Zcz; float Z2, Z4, Z8;
                 { const bool m = z1 & i1; const float x = m ? pc[1].dx : 0.f, y = m ? pc[1].dy : 0.f, z = m ? pc[1].dz : 0.f;
                   Zxy = f2{x, y}; Z2 = z; Zsq = Zxy * Zxy; Zcz = f2{z, z} * Zxy; Z4 = x * y; Z8 = z * z; }
                 { const bool m = z2 & i2; ICET_ACC_ADD(Z, m ? pc[2].dx : 0.f, m ? pc[2].dy : 0.f, m ? pc[2].dz : 0.f) }
                 { const bool m = i3;      ICET_ACC_ADD(Z, m ? pc[3].dx : 0.f, m ? pc[3].dy : 0.f, m ? pc[3].dz : 0.f) }
-                flush((z3 & !fw) ? s3 : -1, zr, zi, Zxy.x, Zxy.y, Z2, Zsq.x, Z4, Zcz.x, Zsq.y, Zcz.y, Z8);
+                // list pass: lane 63 cannot see its successor -- its suffix run is handed on or flushed by the next trip's ghost
+                flush((z3 & !fw & !(kMode == 2 && lane == 63)) ? s3 : -1, zr, zi, Zxy.x, Zxy.y, Z2, Zsq.x, Z4, Zcz.x, Zsq.y, Zcz.y, Z8);
             }
 #undef ICET_ACC_ADD
             const bool m1 = !a1 & !z1, m2 = !a2 & !z2;                      // points of a run strictly between A and Z
@@ -409,15 +528,34 @@ __device__ __forceinline__ void gn_accumulate_body(const PairDesc* __restrict__ 
                 const bool joint = m1 & m2 & e2;                            // points 1 and 2 form one run
                 const float bx = i1 ? pc[1].dx : 0.f, by = i1 ? pc[1].dy : 0.f, bz = i1 ? pc[1].dz : 0.f;
                 const float cx = i2 ? pc[2].dx : 0.f, cy = i2 ? pc[2].dy : 0.f, cz = i2 ? pc[2].dz : 0.f;
-                if (m1 & !joint) flush(s1, 1u, i1 ? 1u : 0u, bx, by, bz, bx * bx, bx * by, bx * bz, by * by, by * bz, bz * bz);
+                if (m1 & !joint) flush(ghost ? -1 : s1, 1u, i1 ? 1u : 0u, bx, by, bz, bx * bx, bx * by, bx * bz, by * by, by * bz, bz * bz);
                 if (m2) {
                     const float jx = joint ? bx : 0.f, jy = joint ? by : 0.f, jz = joint ? bz : 0.f;
-                    flush(s2, joint ? 2u : 1u, (i2 ? 1u : 0u) + ((joint & i1) ? 1u : 0u), jx + cx, jy + cy, jz + cz,
+                    flush(ghost ? -1 : s2, joint ? 2u : 1u, (i2 ? 1u : 0u) + ((joint & i1) ? 1u : 0u), jx + cx, jy + cy, jz + cz,
                           fmaf(cx, cx, jx * jx), fmaf(cx, cy, jx * jy), fmaf(cx, cz, jx * jz), fmaf(cy, cy, jy * jy), fmaf(cy, cz, jy * jz), fmaf(cz, cz, jz * jz));
                 }
             }
         }
-      }   // sub-groups of 4
+      }
+    };
+    if (kKeep && list_mode) {
+        // Lane l of trip tau holds list entry 63 tau - 1 + l.  Lane 0 is the GHOST: it repeats the last entry of the previous trip (whose lane 63 cannot see its
+        // successor) to finish that group's suffix run -- handed to lane 1 where the full pass hands it to the next lane, flushed otherwise -- and contributes
+        // nothing else.  The entries of trip tau + 2 kW are requested while trip tau is classified: the point loads of the next trip need theirs in a register.
+        int tau = tau_begin + (int)(threadIdx.x >> 6);
+        int gc = gc_first, gn_raw = gn_first;
+        gc = entry_ok(tau) ? gc : -1;
+        load4(gc >= 0 ? 4 * gc : end, XN, YN, ZN);
+        for (; tau < tau_end; tau += kW) {                                          // wave-uniform
+            const int gnn_raw = entry_raw(tau + 2 * kW);                            // in flight while this trip is classified
+            const int gn = entry_ok(tau + kW) ? gn_raw : -1;                        // (requested a trip ago)
+            trip(std::integral_constant<int, 2>{}, gc >= 0 ? 4 * gc : end, tau + kW < tau_end, gn >= 0 ? 4 * gn : end, gc);
+            gc = gn; gn_raw = gnn_raw;
+        }
+    } else {
+        load4(begin + kAccPts * (int)threadIdx.x, XN, YN, ZN);
+        for (int t0 = begin + kAccPts * threadIdx.x; t0 < begin + cs; t0 += kAccPts * kAccBlock)    // whole waves iterate together
+            trip(std::integral_constant<int, kKeep ? 1 : 0>{}, t0, t0 + kAccPts * kAccBlock < begin + cs, t0 + kAccPts * kAccBlock, -1);
     }
     if (ICET_ACC_PHASE != 9 && sink == 1.2345e-30f) near_over_count[pair] = 1u;      // keeps the timing builds' work alive
     __syncthreads();
@@ -479,7 +617,20 @@ __global__ __launch_bounds__(kAccBlock, kRT2 ? 1 : (kSmall ? 2 : kAccWavesPerSim
                                                           int T, int P, int Mt, int Mp, float guard_t, float guard_p,
                                                           int lds_slots, int chunks, int n_pairs, int force_exact,
                                                           uint32_t* __restrict__ near_over, uint32_t* __restrict__ near_over_count) {
-    gn_accumulate_body<kVec4, kRT2, kSmall>(desc, xf_all, slot_of_voxel, n_slots, hotS, acc, thr, lut, T, P, Mt, Mp, guard_t, guard_p, lds_slots, chunks, n_pairs, force_exact, near_over, near_over_count);
+    gn_accumulate_body<kVec4, kRT2, kSmall, false>(desc, xf_all, slot_of_voxel, n_slots, hotS, acc, thr, lut, T, P, Mt, Mp, guard_t, guard_p, lds_slots, chunks, n_pairs, force_exact, near_over, near_over_count, KeepDev{});
+}
+
+// The point pass with the keep list (throughput batches; KeepState in icet_internal.h): every block reads its pair's mode -- the list, or the whole scan plus
+// the keep masks of its points.  Same sums, same bits as k_gn_accumulate.
+template <bool kVec4>
+__global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void k_gn_accumulate_keep(const PairDesc* __restrict__ desc, const float* __restrict__ xf_all,
+                                                          const int16_t* __restrict__ slot_of_voxel, const int32_t* __restrict__ n_slots,
+                                                          const SlotHot* __restrict__ hotS, uint32_t* __restrict__ acc,
+                                                          const float* __restrict__ thr, const LutCell* __restrict__ lut,
+                                                          int T, int P, int Mt, int Mp, float guard_t, float guard_p,
+                                                          int lds_slots, int chunks, int n_pairs, int force_exact,
+                                                          uint32_t* __restrict__ near_over, uint32_t* __restrict__ near_over_count, KeepDev kd) {
+    gn_accumulate_body<kVec4, false, false, true>(desc, xf_all, slot_of_voxel, n_slots, hotS, acc, thr, lut, T, P, Mt, Mp, guard_t, guard_p, lds_slots, chunks, n_pairs, force_exact, near_over, near_over_count, kd);
 }
 
 // Small batches (a sequential caller's single pair above all): the point pass and the solve of one iteration in ONE launch.  Every block of a pair takes a ticket when
@@ -495,7 +646,7 @@ __global__ __launch_bounds__(kAccBlock, 2) void k_gn_accumulate_solve(const Pair
                                                                       int T, int P, int Mt, int Mp, float guard_t, float guard_p,
                                                                       int lds_slots, int chunks, int n_pairs, int force_exact,
                                                                       uint32_t* near_over, uint32_t* near_over_count, SolveFuse sf) {
-    gn_accumulate_body<kVec4, false, true>(desc, xf_all, slot_of_voxel, n_slots, hotS, acc, thr, lut, T, P, Mt, Mp, guard_t, guard_p, lds_slots, chunks, n_pairs, force_exact, near_over, near_over_count);
+    gn_accumulate_body<kVec4, false, true, false>(desc, xf_all, slot_of_voxel, n_slots, hotS, acc, thr, lut, T, P, Mt, Mp, guard_t, guard_p, lds_slots, chunks, n_pairs, force_exact, near_over, near_over_count, KeepDev{});
     int pair, chunk;
     if (!decode_block(n_pairs, chunks, pair, chunk)) return;           // (a padding block of the grid: belongs to no pair)
     __shared__ uint32_t s_last;
@@ -514,7 +665,7 @@ __global__ __launch_bounds__(kAccBlock, 2) void k_gn_accumulate_solve(const Pair
     if (!s_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const NearOverflow over{desc, slot_of_voxel, hotS, thr, near_over, near_over_count, T, P, 0};
-    gn_solve_body<256, 0, kAccBlock>(n_slots, sf.fitS, acc, sf.X, xf_all, sf.out, sf.aux, T * P, sf.n, sf.iter, sf.runlen, over, sf.reject_moving, nullptr, 1, sf.cond_bound2, pair);
+    gn_solve_body<256, 0, kAccBlock>(n_slots, sf.fitS, acc, sf.X, xf_all, sf.out, sf.aux, T * P, sf.n, sf.iter, sf.runlen, over, sf.reject_moving, nullptr, 1, sf.cond_bound2, KeepArgs{}, pair);
 }
 
 inline int chunks_for(int n_pairs, int max_n, int per_block_min, int target_blocks) {
@@ -534,6 +685,8 @@ hipError_t init_accumulate_kernels() {
     ICET_ACC_ATTR(true, false, false); ICET_ACC_ATTR(false, false, false); ICET_ACC_ATTR(true, true, false); ICET_ACC_ATTR(false, true, false);
     ICET_ACC_ATTR(true, false, true); ICET_ACC_ATTR(false, false, true); ICET_ACC_ATTR(true, true, true); ICET_ACC_ATTR(false, true, true);
 #undef ICET_ACC_ATTR
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate_keep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate_keep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gn_accumulate_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     return e;
@@ -565,20 +718,22 @@ hipError_t launch_rt2_prepare(const Workspace& w, const LaunchCfg& c, hipStream_
 
 // LDS of one k_gn_accumulate block apart from its slot rows: both look-up tables, the voxel -> slot map, the queue of parked points; and the bytes of a slot row.
 // The SMALLEST launch keeps 32 rows (launch_gn_accumulate): ensure_thresholds sizes the look-up tables so that it fits the device.
-size_t acc_fixed_lds_bytes(int T, int P, int Mt, int Mp, bool small_batch) {
+size_t acc_fixed_lds_bytes(int T, int P, int Mt, int Mp, bool small_batch, bool keep) {
     const uint32_t near_cap = small_batch ? kNearCapSmall : kNearCap;
-    return (size_t)(Mt + Mp + 2) * sizeof(LutCell) + (size_t)(((size_t)T * P + T + 4) / 2) * 4 + (near_cap + 5) * 4 + 32;   // + alignment of the hot records
+    const size_t keep_bytes = keep ? (size_t)(T + P + 4) * 4 + (((size_t)T * P + 3 * (size_t)T + 1 + 3) & ~(size_t)3) : 0;      // bin edges + the voxels' neighbourhood codes (k_edge_t, k_nb)
+    return (size_t)(Mt + Mp + 2) * sizeof(LutCell) + (size_t)(((size_t)T * P + T + 4) / 2) * 4 + (near_cap + 5) * 4 + 32 + keep_bytes;   // + alignment of the hot records
 }
 size_t acc_row_lds_bytes() { return (kHotWords + kAccLds) * 4; }
 
-hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st, const FuseArgs* fuse, bool* fused) {
+hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st, const FuseArgs* fuse, bool* fused, int keep_pass) {
     if (fused) *fused = false;
+    if (keep_pass && (c.n_pairs < 32 || c.rt2 || !w.keep_state || !w.keep_mask || !w.keep_list || !w.edges || !w.keep_modes)) return hipErrorInvalidValue;      // (enqueue_loop asks for it on throughput batches only)
     // LDS rows for active voxels: a throughput batch keeps 320 rows (measured optimum on 64-channel scans: fewer rows
     // spill busy voxels to HBM atomics, more rows cost occupancy); a small batch has
     // CUs to spare, so a block may take most of a CU's LDS and keep every active voxel of a fine grid (150 x 48: often
     // > 1000) out of the slow HBM-atomic path.
     const uint32_t near_cap = (c.n_pairs >= 32) ? kNearCap : kNearCapSmall;
-    const size_t fixed = acc_fixed_lds_bytes(c.T, c.P, w.lut_Mt, w.lut_Mp, near_cap == kNearCapSmall);
+    const size_t fixed = acc_fixed_lds_bytes(c.T, c.P, w.lut_Mt, w.lut_Mp, near_cap == kNearCapSmall, keep_pass != 0);
     const size_t row = acc_row_lds_bytes();
     // the fused form (k_gn_accumulate_solve): small batch, one-block solve (grids up to 4096 voxels: launch_gn_solve), no scan-2 round trip
     // (... and a grid whose tables leave the fused kernel -- 12 KB less dynamic LDS: its solve half has static tables -- fewer than the 32 slot rows every launch keeps)
@@ -603,6 +758,15 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
         else k_gn_accumulate_solve<false><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp, w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count, sf);
         ICET_LAUNCH_CHECK();
         if (fused) *fused = true;
+        return hipSuccess;
+    }
+    if (keep_pass) {
+        const double two_pi = 6.283185307179586476925286766559;
+        const KeepDev kd{w.keep_mask, w.keep_list, w.edges, w.keep_modes + (size_t)(keep_pass >> 1) * c.n_pairs, 1.05f * c.keep_br + 1e-4f, 1.05f * c.keep_bt,
+                         (float)std::min(two_pi / c.T, 0.5), (float)std::min(0.5 * two_pi / c.P, 0.5), 1.0f / (float)c.T};
+        if (c.vec4_ok) k_gn_accumulate_keep<true><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp, w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count, kd);
+        else k_gn_accumulate_keep<false><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp, w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count, kd);
+        ICET_LAUNCH_CHECK();
         return hipSuccess;
     }
 #define ICET_ACC_LAUNCH2(V4, RT) do { if (near_cap == kNearCapSmall) ICET_ACC_LAUNCH(V4, RT, true); else ICET_ACC_LAUNCH(V4, RT, false); } while (0)

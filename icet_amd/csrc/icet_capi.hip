@@ -248,6 +248,10 @@ icet_status ensure_thresholds(icet_ctx* c, int T, int P) {
         HIPCHK(c, hipMalloc(&w.lut, all.size() * sizeof(HostCell)));
         HIPCHK(c, hipMemcpy(w.lut, all.data(), all.size() * sizeof(HostCell), hipMemcpyHostToDevice));
         w.lut_Mt = Mt; w.lut_Mp = Mp;
+        // the same edges as floats, for the keep masks of the point pass (margins of 1e-2 rad: the float rounding of an edge is far inside their slack)
+        std::vector<float> ef; for (double e : et) ef.push_back((float)e); for (double e : ep) ef.push_back((float)e);
+        HIPCHK(c, dev_realloc(w.edges, ef.size()));
+        HIPCHK(c, hipMemcpy(w.edges, ef.data(), ef.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     std::vector<float> h((size_t)T + P + 2);
     build_thresholds(T, 2 * M_PI, h.data());
@@ -385,6 +389,11 @@ LaunchCfg make_cfg(icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     cfg.lds_slots = c->tune.lds_slots; cfg.acc_min_pts_per_thread = c->tune.acc_pts; cfg.acc_target_blocks = c->tune.acc_blocks;
     cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds; cfg.exec_pairwise = c->tune.exec_pairwise; cfg.fuse_solve = c->tune.fuse_solve != 0 ? 1 : 0; cfg.lds_rank = (c->tune.lds_rank != 0 && c->lds_rank_ok) ? 1 : 0;
     cfg.gn_cond_bound2 = (float)(c->tune.gn_cond_bound * c->tune.gn_cond_bound);
+    // the keep list of the point pass (KeepState, icet_internal.h): throughput batches only -- a small batch's point pass is a few microseconds of launch floor --,
+    // never with the scan-2 round trip (a kernel of its own) nor when fewer than two passes could walk a list; same bits either way
+    cfg.keep_from = c->tune.keep_from < 0 ? 0 : c->tune.keep_from; cfg.keep_bt = (float)c->tune.keep_budget_t; cfg.keep_br = (float)c->tune.keep_budget_r; cfg.keep_check_scale = (float)c->tune.keep_check_scale;
+    cfg.keep = (c->tune.keep != 0 && n_pairs >= 32 && !cfg.rt2 && p->runlen >= cfg.keep_from + 3 && c->w.lut_Mt > 0 &&
+                acc_fixed_lds_bytes(cfg.T, cfg.P, c->w.lut_Mt, c->w.lut_Mp, false, true) + 64 * acc_row_lds_bytes() <= (size_t)c->max_lds) ? 1 : 0;
     if (cfg.kf_pts_per_thread > kKfMaxPtsPerThread) cfg.kf_pts_per_thread = kKfMaxPtsPerThread;      // k_bin_scatter: a tile is at most 4 waves x that many rounds x 64 positions
     if (cfg.kf_pts_per_thread < 1) cfg.kf_pts_per_thread = 1;
     cfg.stage_event = c->stage_at ? c->ev_stage : nullptr; cfg.stage_at = c->stage_at;
@@ -478,6 +487,18 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
         wl = w; wl.desc = w.desc_rt;
     }
     LaunchCfg lcfg = cfg; if (cfg.rt2) lcfg.vec4_ok = 1;     // the copy is 64-float aligned whatever the caller's layout was
+    if (cfg.keep) {                                          // masks, list and per-pair state of the keep list (grown here: only throughput batches use them)
+        int64_t tot2 = 0; for (int k = 0; k < n_pairs; k++) tot2 += c->h_desc[k].n2;
+        const size_t need_mask = (size_t)(tot2 >> 8) + (size_t)n_pairs + 2, need_list = (size_t)(tot2 >> 2) + (size_t)n_pairs + 4;
+        if (need_mask > w.cap_keep_mask || need_list > w.cap_keep_list || n_pairs > w.cap_keep_pairs) {
+            if (c->capturing) { c->err = "keep list: workspace growth during capture"; return ICET_ERR_HIP; }
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (need_mask > w.cap_keep_mask) { HIPCHK(c, dev_realloc(w.keep_mask, need_mask)); w.cap_keep_mask = need_mask; }
+            if (need_list > w.cap_keep_list) { HIPCHK(c, dev_realloc(w.keep_list, need_list)); w.cap_keep_list = need_list; }
+            if (n_pairs > w.cap_keep_pairs) { HIPCHK(c, dev_realloc(w.keep_state, (size_t)n_pairs)); HIPCHK(c, dev_realloc(w.keep_modes, 2 * (size_t)n_pairs)); w.cap_keep_pairs = n_pairs; }
+            wl.keep_modes = w.keep_modes; wl.keep_mask = w.keep_mask; wl.keep_list = w.keep_list; wl.keep_state = w.keep_state; wl.cap_keep_mask = w.cap_keep_mask; wl.cap_keep_list = w.cap_keep_list; wl.cap_keep_pairs = w.cap_keep_pairs;
+        }
+    }
     HIPCHK(c, launch_init_state(w, cfg, d_x0, c->stream, want_pts2 ? aux->xf_last : nullptr, cfg.rt2 ? nullptr : d_counts2));
     // `points2` (include/icet.h:80): scan 2 as the LAST fitScan2 transforms it (src/icet.cpp:375-378).  That transform is known as soon as the
     // solve of iteration runlen - 2 has run: k_gn_solve / k_init_state snapshot its record in aux->xf_last (pinned host memory) and ev_prev
@@ -501,9 +522,12 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
         // (per-iteration timing wants the two halves apart; otherwise a small batch runs the solve inside the point pass' launch)
         const FuseArgs fa{it, d_out, aux};
         bool fused = false;
-        HIPCHK(c, launch_gn_accumulate(wl, lcfg, c->stream, per_iter ? nullptr : &fa, &fused));
+        // keep list: from iteration keep_from on the point pass is the kernel that walks a pair's list or, for a pair without a valid one, its whole scan + keep masks;
+        // the solve behind it builds / checks the lists (not behind the last pass: nothing follows)
+        const int keep_pass = (lcfg.keep && it >= lcfg.keep_from) ? 1 : 0;
+        HIPCHK(c, launch_gn_accumulate(wl, lcfg, c->stream, per_iter ? nullptr : &fa, &fused, keep_pass ? 1 + 2 * (it & 1) : 0));
         if (per_iter) HIPCHK(c, hipEventRecord(c->ev_acc[2 * it + 1], c->stream));
-        if (!fused) HIPCHK(c, launch_gn_solve(wl, lcfg, it, d_out, aux, c->stream));
+        if (!fused) HIPCHK(c, launch_gn_solve(wl, lcfg, it, d_out, aux, c->stream, keep_pass ? (it + 1 < p->runlen ? 1 : 2) : 0));
         if (want_pts2 && it == p->runlen - 2) { const icet_status ps = enqueue_points2(); if (ps != ICET_OK) return ps; }
     }
     if (!c->capturing) { HIPCHK(c, hipEventRecord(c->ev_c, c->stream)); c->timing_valid = true; c->last_iters = per_iter ? p->runlen : 0; }
@@ -584,7 +608,7 @@ icet_status icet_destroy(icet_ctx* c) {
     Workspace& w = c->w;
     void* ps[] = {w.key64A, w.key64B, w.bin16, w.execbits, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.cart1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src,
                   w.desc_rt, w.rt2, w.gn_part, w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.near_over, w.near_over_count, w.acc, w.xf, w.X, w.flags, w.vrange, w.tile_vr,
-                  w.sort_tmp, w.fit_items, w.fit_n_items, w.live_bins, w.n_live, w.thr, w.lut, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
+                  w.sort_tmp, w.fit_items, w.fit_n_items, w.live_bins, w.n_live, w.thr, w.lut, w.keep_mask, w.keep_list, w.keep_state, w.keep_modes, w.edges, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);
     free_aux(c);
     if (c->st_copy) (void)hipStreamSynchronize(c->st_copy);
@@ -1202,6 +1226,11 @@ icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
     else if (k == "lds_rank") t.lds_rank = iv < 0 ? -1 : (iv != 0);
     else if (k == "exec_pairwise") t.exec_pairwise = iv < 0 ? -1 : (iv != 0);
     else if (k == "fuse_solve") { t.fuse_solve = iv < 0 ? -1 : (iv != 0); c->g_solve.have_seen = c->g_keyframe.have_seen = c->g_loop.have_seen = false; }
+    else if (k == "keep") t.keep = iv != 0;
+    else if (k == "keep_from") t.keep_from = iv < 0 ? 0 : iv;
+    else if (k == "keep_budget_t") { if (!(value > 0.0 && value <= 100.0)) { c->err = "keep_budget_t must lie in (0, 100]"; return ICET_ERR_BAD_ARG; } t.keep_budget_t = value; }
+    else if (k == "keep_budget_r") { if (!(value > 0.0 && value <= 1.0)) { c->err = "keep_budget_r must lie in (0, 1]"; return ICET_ERR_BAD_ARG; } t.keep_budget_r = value; }
+    else if (k == "keep_check_scale") t.keep_check_scale = value > 0 ? value : 1.0;      // timing experiments (Tuning)
     else if (k == "graph") { c->graph_mode = iv < 0 ? -1 : (iv != 0); c->g_solve.have_seen = c->g_keyframe.have_seen = c->g_loop.have_seen = false; }
     else if (k == "gn_cond_bound") { if (!(value >= 0.0 && value <= 1e6)) { c->err = "gn_cond_bound must lie in [0, 1e6]"; return ICET_ERR_BAD_ARG; } t.gn_cond_bound = value; c->g_solve.have_seen = c->g_keyframe.have_seen = c->g_loop.have_seen = false; }
     else if (k == "guard_scale") { if (!(value >= 1.0 && value <= 1024.0)) { c->err = "guard_scale must lie in [1, 1024]"; return ICET_ERR_BAD_ARG; } t.guard_scale = value; c->w.thr_T = 0; }   // tables are rebuilt by the next call
@@ -1225,6 +1254,27 @@ icet_status icet_last_timing(icet_ctx* c, float out_ms[4]) {
     HIPCHK(c, hipEventElapsedTime(&b, c->ev_b, c->ev_c));
     for (int it = 0; it < c->last_iters; it++) { float t = 0; HIPCHK(c, hipEventElapsedTime(&t, c->ev_acc[2 * it], c->ev_acc[2 * it + 1])); acc += t; }
     out_ms[0] = a; out_ms[1] = b; out_ms[2] = c->last_iters ? acc : -1.f; out_ms[3] = (float)c->last_iters;
+    return ICET_OK;
+}
+
+icet_status icet_last_timing_iters(icet_ctx* c, float* acc_ms, int32_t cap, int32_t* n_out) {
+    if (!c || !acc_ms || !n_out || cap < 0) return ICET_ERR_BAD_ARG;
+    if (!c->timing_valid) { c->err = "no timed call yet"; return ICET_ERR_BAD_ARG; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int n = c->last_iters < cap ? c->last_iters : cap;
+    for (int it = 0; it < n; it++) HIPCHK(c, hipEventElapsedTime(&acc_ms[it], c->ev_acc[2 * it], c->ev_acc[2 * it + 1]));
+    *n_out = n;
+    return ICET_OK;
+}
+
+icet_status icet_keep_stats(icet_ctx* c, int32_t n_pairs, int32_t* out) {
+    if (!c || !out || n_pairs < 0) return ICET_ERR_BAD_ARG;
+    if (!c->w.keep_state || n_pairs > c->w.cap_keep_pairs) { c->err = "no keep-list state for that many pairs (the last call did not use the keep list)"; return ICET_ERR_BAD_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<KeepState> h((size_t)n_pairs);
+    HIPCHK(c, hipMemcpy(h.data(), c->w.keep_state, sizeof(KeepState) * (size_t)n_pairs, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n_pairs; k++) { out[4 * k] = h[k].mode; out[4 * k + 1] = h[k].n_keep; out[4 * k + 2] = h[k].list_passes; out[4 * k + 3] = h[k].builds; }
     return ICET_OK;
 }
 

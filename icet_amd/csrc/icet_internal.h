@@ -78,6 +78,29 @@ static_assert(sizeof(FitMid) == 64, "k_fit_scan1 stages this record as 16 words"
 
 static_assert(sizeof(SlotHot) == 48 && sizeof(SlotFit) == 80, "k_compact_slots copies these records as 12 + 20 words");
 
+// The KEEP LIST of the point pass (round 6).  H^T W H only ever sees scan-2 points that fall into the angular bin of an ACTIVE voxel
+// (raw count, src/icet.cpp:290,315) or inside its bounds (sums, :299-306); on lidar data 40-60 % of scan 2 lies in bins without a scan-1
+// Gaussian and pays the full classification in every iteration for nothing.  A full pass at X_ref therefore also writes, per aligned group
+// of 4 points, whether ANY of them lies within an angular margin of an active bin (one 64-bit ballot per 256 points: keep_mask); the solve
+// behind it expands the masks into the ordered list of kept groups (keep_list), and the following passes walk the list instead of the scan
+// for as long as X stays within the budgets the margin was computed for (|t - t_ref| <= budget_t, |R - R_ref|_F <= budget_r: then no dropped
+// point can have reached an active bin, see keep_margin in icet_accumulate.hip); a pair that leaves them falls back to the full scan for
+// one pass, which rebuilds masks and list.  The list pass forms EXACTLY the float partial sums of the full pass (a kept group is an aligned
+// group of the original stream; a suffix run is handed to the next lane only where the full pass would hand it on), so the result bits do not
+// change: the keep list is a launch-shape option (tests/test_gpu_parity.py::test_keep_list_is_bit_neutral).
+struct KeepState {
+    int32_t mode;                    // 0: the next point pass walks the whole scan (and writes keep masks); 1: it walks keep_list
+    int32_t n_keep;                  // groups in the list
+    int32_t list_passes, builds;     // statistics of the current solve: passes that walked the list / lists built
+    float ref[12];                   // t[3] | R[9] of the pass the masks were written in
+};
+static_assert(sizeof(KeepState) == 64, "one cache line quarter per pair");
+// modes_next: what the point pass of the NEXT iteration does with each pair, one word per pair: 0 = the whole scan, n_keep + 1 = the list.  Its blocks take the
+// pairs in the order "whole-scan pairs ascending, then list pairs descending" (keep_pair_of_slot, icet_accumulate.hip): a whole-scan block runs ~2x as long as a
+// list block and a launch is only two rounds of blocks -- started in the second round, ONE such block set the end of the launch (measured: 105-115 us per launch
+// whatever the lists' length, against 97 for the plain pass).
+struct KeepArgs { const PairDesc* desc; const unsigned long long* mask; uint32_t* list; KeepState* state; float bt2, br2; int on; int32_t* modes_next; int n_pairs; };
+
 // Optional dense (per-voxel) dump for the reference's public side tables; device pointers or null.
 struct AuxDev {
     float* bounds; int32_t* n1_raw; int32_t* has_fit; float* mu1; float* sigma1; float* evecs1; float* l_diag;
@@ -125,6 +148,11 @@ struct Workspace {
     void* lut = nullptr; int lut_Mt = 0, lut_Mp = 0;  // classification LUTs of k_gn_accumulate: Mt azimuth cells, then Mp polar cells (8 B each)
     float guard_t = 0.f, guard_p = 0.f;               // guard bands (diamond-angle / cosine units) around voxel edges
     int zero_voxel[4] = {0, 0, 0, 0};                 // voxel of an exact-zero row by the sign bits of (y, x) (ensure_thresholds)
+    // keep list of the point pass (KeepState above): one mask word per 256 scan-2 points (pair's first word: off2 / 256 + pair), one list entry per group of
+    // 4 points (off2 / 4 + pair), the per-pair state; edges: T + 1 azimuth bin edges in diamond-angle units, then P + 1 polar edges in w = -cos(phi) units
+    unsigned long long* keep_mask = nullptr; size_t cap_keep_mask = 0; uint32_t* keep_list = nullptr; size_t cap_keep_list = 0; KeepState* keep_state = nullptr; int32_t cap_keep_pairs = 0;
+    int32_t* keep_modes = nullptr;            // 2 x cap_keep_pairs: per pair what the point pass of an even / odd iteration does with it (KeepArgs::modes_next)
+    float* edges = nullptr;
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
 };
 
@@ -151,6 +179,11 @@ struct Tuning {
     int exec_pairwise = -1;       // "did step v execute": one block per pair in index order with the bit table in LDS (k_exec_flags_pair) 1, chain walks (k_exec_flags) 0, by batch size -1
     double guard_scale = 1.0;     // multiplies the classification guard bands (tables are rebuilt)
     double lut_polar_quantile = 0.25;   // polar LUT cell width = this quantile of the polar bin widths
+    int keep = 0;                 // keep list of the point pass (KeepState): 1 throughput batches (>= 32 pairs), 0 never (default: measured a net loss on MI355X)
+    int keep_from = 1;            // first iteration whose full pass writes keep masks (0 pays when X0 is already close: a seeded sequential caller)
+    double keep_budget_t = 0.08;  // metres / radians (Frobenius) X may move from the pass the masks were written in before the pair falls back to the full scan
+    double keep_budget_r = 0.008;
+    double keep_check_scale = 1.0; // TIMING EXPERIMENTS ONLY: the budget CHECK (not the margins) times this; above 1 the results are wrong (a pair keeps its list beyond what the margins cover)
     double gn_cond_bound = 2.5e5;   // H^T W H whose Frobenius condition bound exceeds this takes the literal 6x6 tail (COD / eigenvectors / pruning) instead of the Cholesky inverse; 0 = always literal
 };
 
@@ -178,6 +211,8 @@ struct LaunchCfg {
     int half_gap = 0;                 // ICET_FLAG_HALF_GAP_BOUNDS (non-parity extension; sets true_sort as well)
     int rt2 = 0;                      // ICET_FLAG_ROUNDTRIP_SCAN2 (parity-study option)
     int lds_rank = 0;                 // Tuning::lds_rank, resolved against the context's self-test
+    int keep = 0, keep_from = 1;      // Tuning::keep resolved for this launch (batch size, flags), Tuning::keep_from
+    float keep_bt = 0.f, keep_br = 0.f, keep_check_scale = 1.f;   // Tuning::keep_budget_t / _r / keep_check_scale
     float gn_cond_bound2 = 6.25e10f;     // Tuning::gn_cond_bound squared: k_gn_solve's Cholesky route needs |A|_F |A^-1|_F <= the bound (icet_solve.hip gn_tail)
 };
 constexpr float kRejectMovingThresh = 0.3f;        // python/ICET_spherical.py:38  RM_thresh
@@ -186,8 +221,9 @@ constexpr int kRejectMovingStartIter = 4;          // python/ICET_spherical.py:3
 // icet_keyframe.hip
 hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* aux, hipStream_t st, const int32_t* d_n1 = nullptr);   // d_n1: scan-1 row counts known to the device only (the descriptors hold upper bounds)
 // icet_solve.hip
-hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last = nullptr, const int32_t* d_n2 = nullptr);   // (also clears the block tickets)
-hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st);
+hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last = nullptr, const int32_t* d_n2 = nullptr);   // (also clears the block tickets and the keep-list state)
+// keep_pass: the point pass in front of this solve was launched with keep_pass (below): build the list of every pair that walked its whole scan, check every pair's budgets
+hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st, int keep_pass = 0);
 hipError_t launch_gn_tail_debug(const float* d_H, const float* d_g, float* d_out, int n, float bound2, hipStream_t st);     // test hook: the 6x6 tail on its own
 // `points2` of pair 0 (include/icet.h:80): scan 2 under the transform record `xf` (AuxDev::xf_last); out = n2 x 3 column-major, ld n2 (may be pinned host memory)
 hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* xf, float* out, hipStream_t st);
@@ -195,8 +231,9 @@ hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* x
 // fuse: when given and the launch qualifies (a small batch on a grid of <= 4096 voxels, no scan-2 round trip, option "fuse_solve" not 0), the block of each pair that
 // finishes LAST runs that pair's solve of iteration fuse->iter inside the same launch (*fused = true: the caller skips launch_gn_solve)
 struct FuseArgs { int iter; float* d_out; const AuxDev* aux; };
-hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st, const FuseArgs* fuse = nullptr, bool* fused = nullptr);
-size_t acc_fixed_lds_bytes(int T, int P, int Mt, int Mp, bool small_batch);   // LDS of a k_gn_accumulate block without its slot rows
+// keep_pass: the kernel with the keep list (a pair in list mode walks its list, any other pair its whole scan and writes keep masks), 1 + 2 x (iteration & 1); 0: the plain kernel
+hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStream_t st, const FuseArgs* fuse = nullptr, bool* fused = nullptr, int keep_pass = 0);
+size_t acc_fixed_lds_bytes(int T, int P, int Mt, int Mp, bool small_batch, bool keep = false);   // LDS of a k_gn_accumulate block without its slot rows
 size_t acc_row_lds_bytes();
 // ICET_FLAG_ROUNDTRIP_SCAN2: points2_OG = sphericalToCartesian(cartesianToSpherical(scan 2)) (src/icet.cpp:263-275, without the permutation): w.desc -> w.desc_rt
 hipError_t launch_rt2_prepare(const Workspace& w, const LaunchCfg& c, hipStream_t st);

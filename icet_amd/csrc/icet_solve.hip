@@ -17,10 +17,14 @@ namespace {
 // (desc / n2: the scan-2 row counts that only the device knows -- k_patch_counts' job, folded in when this is the loop's first kernel: one launch
 // less in front of a sequential caller's first iteration)
 __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X, float* __restrict__ xf, int n_pairs, float* __restrict__ xf_last,
-                             PairDesc* __restrict__ desc, const int32_t* __restrict__ n2, uint32_t* __restrict__ done) {
+                             PairDesc* __restrict__ desc, const int32_t* __restrict__ n2, uint32_t* __restrict__ done, KeepState* __restrict__ keep, int32_t* __restrict__ keep_modes) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     if (done) done[p] = 0u;                                      // the point pass' block tickets (k_gn_accumulate_solve)
+    if (keep) {                                                  // every solve starts on the whole scan, the pairs in index order
+        keep[p].mode = 0; keep[p].n_keep = 0; keep[p].list_passes = 0; keep[p].builds = 0;
+        keep_modes[p] = 0; keep_modes[n_pairs + p] = 0;
+    }
     if (n2) desc[p].n2 = max(0, min(n2[p], desc[p].n2));
     float x[6];
     for (int k = 0; k < 6; k++) { x[k] = x0 ? x0[p * 6 + k] : 0.f; X[p * 6 + k] = x[k]; }
@@ -32,8 +36,8 @@ __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X
 template <int kT, int kStage>
 __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_slots, const SlotFit* __restrict__ fitS, uint32_t* __restrict__ acc,
                                                      float* __restrict__ X_all, float* __restrict__ xf_all, float* __restrict__ out, AuxDev aux,
-                                                     int V, int n, int iter, int runlen, NearOverflow over, int reject_moving, float* __restrict__ part, int nblk, float cond_bound2) {
-    gn_solve_body<kT, kStage>(n_slots, fitS, acc, X_all, xf_all, out, aux, V, n, iter, runlen, over, reject_moving, part, nblk, cond_bound2);
+                                                     int V, int n, int iter, int runlen, NearOverflow over, int reject_moving, float* __restrict__ part, int nblk, float cond_bound2, KeepArgs keep) {
+    gn_solve_body<kT, kStage>(n_slots, fitS, acc, X_all, xf_all, out, aux, V, n, iter, runlen, over, reject_moving, part, nblk, cond_bound2, keep);
 }
 
 
@@ -79,7 +83,7 @@ hipError_t launch_patch_counts(const Workspace& w, const LaunchCfg& c, const int
 }
 
 hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last, const int32_t* d_n2) {
-    k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs, xf_last, w.desc, d_n2, w.gn_done());
+    k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs, xf_last, w.desc, d_n2, w.gn_done(), c.keep ? w.keep_state : nullptr, w.keep_modes);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -108,18 +112,20 @@ hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* x
     return hipSuccess;
 }
 
-hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* auxp, hipStream_t st) {
+hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* auxp, hipStream_t st, int keep_pass) {
     AuxDev aux{}; if (auxp) aux = *auxp;
+    const KeepArgs keep{w.desc, w.keep_mask, w.keep_list, w.keep_state, c.keep_bt * c.keep_bt * c.keep_check_scale * c.keep_check_scale, c.keep_br * c.keep_br * c.keep_check_scale * c.keep_check_scale, w.keep_state ? keep_pass : 0,      // 1: build / check; 2: behind the last pass (statistics only)
+                        w.keep_modes ? w.keep_modes + (size_t)((iter + 1) & 1) * c.n_pairs : nullptr, c.n_pairs};
     NearOverflow over{w.desc, w.slot_of_voxel, w.hotS, w.thr, w.near_over, w.near_over_count, c.T, c.P, c.rt2};
     if (c.V > 4096 && c.n_pairs <= kTwoStageMaxPairs && w.gn_part) {
         // two stages: several blocks per pair reduce their share of the slots to 27 partial sums each, one block per pair adds them and solves
         const int nblk = kTwoStageBlocks;
-        k_gn_solve<512, 1><<<c.n_pairs * nblk, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk, c.gn_cond_bound2);
+        k_gn_solve<512, 1><<<c.n_pairs * nblk, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk, c.gn_cond_bound2, keep);
         ICET_LAUNCH_CHECK();
-        k_gn_solve<512, 2><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk, c.gn_cond_bound2);
+        k_gn_solve<512, 2><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk, c.gn_cond_bound2, keep);
     }
-    else if (c.V > 4096) k_gn_solve<512, 0><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1, c.gn_cond_bound2);
-    else k_gn_solve<kBlock, 0><<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1, c.gn_cond_bound2);
+    else if (c.V > 4096) k_gn_solve<512, 0><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1, c.gn_cond_bound2, keep);
+    else k_gn_solve<kBlock, 0><<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1, c.gn_cond_bound2, keep);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

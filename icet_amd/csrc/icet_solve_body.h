@@ -104,6 +104,70 @@ __device__ __noinline__ void drain_near_overflow(const NearOverflow& o, int pair
     }
 }
 
+// The keep list of the point pass (KeepState, icet_internal.h), maintained by the block that runs a pair's 6 x 6 part.  keep_list_build: a pair whose point pass walked
+// the whole scan has left one 64-bit keep mask per 256 points; its set bits, in order, are the list (entry = group index in the scan).  In rounds of 256 mask
+// words: one thread per word, the block's exclusive prefix of the popcounts places a word's entries, the thread writes them bit by bit into an LDS stage (16-bit,
+// relative to the round), and the block copies the stage out in coalesced stores.  (Two earlier forms, measured on the 256-pair batch: one WAVE per word with lane l
+// writing bit l at its rank -- ~120 words one after the other per wave, +12 us per solve; one thread per word storing straight to memory -- 4.6 M four-byte
+// store transactions per launch, +15..25 us.)  The transform the masks were written under (the record BEFORE this solve's update) becomes the list's reference.
+// Returns with s_ref = that reference (or the older one of a pair that walked its list) for keep_budget_check, behind a barrier.
+constexpr int kKeepRound = 256;
+template <int kThreads>
+__device__ __forceinline__ int keep_list_build(const KeepArgs& k, int pair, const float* xf, float* s_ref, int* s_wtot) {
+    static_assert(kThreads >= kKeepRound && kThreads % 64 == 0, "one thread per mask word of a round");
+    __shared__ uint16_t s_ent[kKeepRound * 64];
+    KeepState* st = k.state + pair;
+    const int mode = st->mode;                                          // block-uniform
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int kW = kKeepRound / 64;
+    if (mode != 0 || k.on == 2) {                                       // (on == 2: behind the last pass -- statistics only)
+        if (threadIdx.x < 12) s_ref[threadIdx.x] = st->ref[threadIdx.x];
+        if (threadIdx.x == 0 && mode != 0) st->list_passes += 1;
+        const int nk = st->n_keep;
+        __syncthreads();
+        return nk;
+    }
+    const PairDesc d = k.desc[pair];
+    const int nw = (d.n2 + 255) >> 8;
+    const unsigned long long* M = k.mask + ((size_t)d.off2 >> 8) + pair;
+    uint32_t* L = k.list + ((size_t)d.off2 >> 2) + pair;
+    if (threadIdx.x < 12) { const float v = xf[threadIdx.x]; s_ref[threadIdx.x] = v; st->ref[threadIdx.x] = v; }
+    int carry = 0;                                                      // entries of the words of earlier rounds
+    for (int w0 = 0; w0 < nw; w0 += kKeepRound) {                       // block-uniform
+        const int w = w0 + (int)threadIdx.x;
+        unsigned long long m = ((int)threadIdx.x < kKeepRound && w < nw) ? M[w] : 0ull;
+        const int c = __popcll(m);
+        const int incl = wave_incl_sum(c);
+        if (lane == 63 && wv < kW) s_wtot[wv] = incl;
+        __syncthreads();
+        int base = incl - c, total = 0;
+#pragma unroll
+        for (int q = 0; q < kW; q++) { const int t = s_wtot[q]; base += q < wv ? t : 0; total += t; }
+        const uint32_t g0 = threadIdx.x * 64u;
+        while (m != 0ull) {
+            s_ent[base++] = (uint16_t)(g0 + (uint32_t)__builtin_ctzll(m));
+            m &= m - 1ull;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < total; j += kThreads) L[carry + j] = (uint32_t)w0 * 64u + s_ent[j];
+        carry += total;
+        __syncthreads();                                                // (the stage and s_wtot are written again in the next round)
+    }
+    if (threadIdx.x == 0) { st->n_keep = carry; st->builds += 1; }
+    return carry;
+}
+// The pair's next transform record against the list's reference: inside the budgets the next point pass may walk the list (no dropped point can have reached an
+// active bin: keep_margin, icet_accumulate.hip), outside it walks the whole scan and the list is rebuilt behind it.  Called by the first wave.
+__device__ __forceinline__ void keep_budget_check(const KeepArgs& k, int pair, const float* xf_new, const float* s_ref, int lane, int n_keep) {
+    const float dv = (lane < 12) ? xf_new[lane] - s_ref[lane] : 0.f;
+    const float dt2 = wave_total(lane < 3 ? dv * dv : 0.f), dr2 = wave_total(lane >= 3 ? dv * dv : 0.f);
+    if (lane == 0) {
+        const int mode = (dt2 <= k.bt2 && dr2 <= k.br2) ? 1 : 0;                        // (NaN: the whole scan)
+        k.state[pair].mode = mode;
+        k.modes_next[pair] = mode ? n_keep + 1 : 0;
+    }
+}
+
 // kT threads per block: 256 for ordinary grids (a 64-channel scan on 75 x 24 has ~220 active voxels: one round), 512 -- the most that 248 VGPRs allow --
 // for fine grids (150 x 48: > 1000 active voxels, three rounds of the per-voxel algebra instead of five)
 // kStage 0: everything in ONE block per pair (coarse grids, batches).  The two-stage form of fine grids and small batches (a 150 x 48 grid has
@@ -123,7 +187,8 @@ __device__ __noinline__ void drain_near_overflow(const NearOverflow& o, int pair
 template <int kT, int kStage, int kBlockT = kT>
 __device__ __forceinline__ void gn_solve_body(const int32_t* n_slots, const SlotFit* fitS, uint32_t* acc,
                                               float* X_all, float* xf_all, float* out, const AuxDev& aux,
-                                              int V, int n, int iter, int runlen, const NearOverflow& over, int reject_moving, float* part, int nblk, float cond_bound2, int pair_of_block = -1) {
+                                              int V, int n, int iter, int runlen, const NearOverflow& over, int reject_moving, float* part, int nblk, float cond_bound2,
+                                              const KeepArgs& keep = KeepArgs{}, int pair_of_block = -1) {
     // No contraction of a * b + c in this function: the bits of the per-voxel algebra must not depend on which instantiation the compiler is looking at (its choice of
     // what to fuse follows the surrounding code: after this body moved into a header the two-stage and the one-block form of one pair disagreed in last bits), and the
     // CPU restatement evaluates these expressions unfused as well.
@@ -164,6 +229,10 @@ __device__ __forceinline__ void gn_solve_body(const int32_t* n_slots, const Slot
     }
     if (threadIdx.x < 27) J[threadIdx.x] = jmine;
     __syncthreads();
+    __shared__ float s_keep_ref[12];
+    __shared__ int s_keep_wtot[kT / 64];
+    [[maybe_unused]] int keep_n = 0;
+    if constexpr (kStage != 1 && kBlockT == kT) { if (keep.on) keep_n = keep_list_build<kT>(keep, pair, xf_all + pair * kXf, s_keep_ref, s_keep_wtot); }      // (block-uniform; ends with a barrier)
     if (ICET_SOLVE_PHASE == 1) { if (accR.q[0].x == 0x7FFFFFFFu && fitR.q[0].x == 0x7FFFFFFFu) out[0] = 1.f; return; }
     float S[27];
 #pragma unroll
@@ -327,6 +396,7 @@ __device__ __forceinline__ void gn_solve_body(const int32_t* n_slots, const Slot
         for (int k = 0; k < 36; k++) r[12 + k] = cov[k];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if constexpr (kStage != 1 && kBlockT == kT) { if (keep.on == 1) keep_budget_check(keep, pair, stage, s_keep_ref, lane, keep_n); }
     if (lane < kXf) xf_all[pair * kXf + lane] = stage[lane];
     if (aux.xf_last && iter == runlen - 2 && lane < kXf) aux.xf_last[pair * kXf + lane] = stage[lane];      // what the last point pass will use (`points2`)
     if (lane < 48) out[(size_t)pair * 48 + lane] = stage[kXf + lane];

@@ -192,6 +192,11 @@ icet_status icet_reserve(icet_ctx* ctx, const icet_params* p, int32_t n_pairs, i
  * bin/accumulate kernel only (sum over iterations; -1 unless ICET_FLAG_TIMING was set), [3] number of
  * accumulate launches timed. */
 icet_status icet_last_timing(icet_ctx* ctx, float out_ms[4]);
+/* The same call's point-pass launches one by one (ICET_FLAG_TIMING): acc_ms[it] = HIP-event time of iteration it's launch, *n_out = how many were written (<= cap). */
+icet_status icet_last_timing_iters(icet_ctx* ctx, float* acc_ms, int32_t cap, int32_t* n_out);
+/* The keep list of the point pass after the most recent throughput batch (option "keep"): out[4 k ..] = { mode at the end, groups of 4 points in pair k's last list,
+ * passes that walked a list, lists built }.  ICET_ERR_BAD_ARG when the last call did not use the keep list (small batch, option off). */
+icet_status icet_keep_stats(icet_ctx* ctx, int32_t n_pairs, int32_t* out);
 
 /* Diagnostic hook for the parity tests: copy an internal per-point array of the scan-1 (keyframe) build
  * of the most recent call to the host.  `what`: 0 = float32 r of scan 1 in input order
@@ -216,6 +221,11 @@ icet_status icet_debug_gn_tail(icet_ctx* ctx, const float* htwh, const float* ht
  * DECISION (the per-voxel counts n2_raw / n2_in) but move points between the 4-point runs and the runs of one, i.e. they regroup
  * float partial sums: X agrees to rounding, not bitwise.  Names: "lds_slots", "acc_pts",
  * "acc_blocks", "kf_pts", "rs_cap", "rs_max_cell" (0: per-bucket radix sort instead of the counting sort),
+ * "keep" (the KEEP LIST of the point pass, batches of >= 32 pairs: H^T W H only sees scan-2 points in the angular bin of a voxel that has a scan-1 Gaussian -- src/icet.cpp:290-302 --
+ * so a full pass also marks, per aligned group of 4 points, whether any of them is within an angular margin of such a bin, and later passes walk the list of marked
+ * groups instead of the scan for as long as X stays within "keep_budget_t" (m, default 0.08) / "keep_budget_r" (Frobenius norm of the rotation difference, default 0.008)
+ * of the X the marks were made at; a pair that leaves the budgets walks its whole scan once more and gets a new list.  The list pass forms the float partial sums of the
+ * full pass exactly: SAME BITS with the option on, off, or with any budgets.  -1 / 1 on (default), 0 off; "keep_from" (default 1): first iteration whose pass makes marks),
  * "graph" (device-resident batches of <= 8 pairs: when a call's launch geometry and pointers equal the previous call's, the whole
  * solve is captured into a hipGraph and replayed from then on -- one hipGraphLaunch instead of ~33 launches on the host; 0 = never, default -1 = on),
  * "lds_rank" (the keyframe's stable multi-splits take a row's rank among equal classes from the value its LDS atomic hands back: -1 / 1 if

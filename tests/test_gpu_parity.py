@@ -1692,3 +1692,70 @@ def test_multi_million_row_scan_and_five_thousand_pairs(gpu_ctx, sample_pc):
         rs = single.solve(a0[s:s + k], b0[s:s + k + 3], 4, np.zeros(6), 8, 16, n=10)
         assert np.array_equal(o[j, :6].view(np.uint32), rs["X"].view(np.uint32)) and np.array_equal(o[j, 12:48].view(np.uint32), rs["cov"].reshape(36).view(np.uint32)), j
     single.close()
+
+
+def _keep_batch(dev, frames, sample_pc, n_syn=40, n_real=8):
+    from icet_amd import lidar_sim as ls
+    pairs = [ls.make_batch_pair(k, device=dev)[:2] for k in list(range(n_syn - 2)) + [39, 232]]       # 39 / 232: the pairs whose X keeps moving by decimetres (fall back, rebuild)
+    base = [tuple(torch.from_numpy(np.ascontiguousarray(x.T)).to(dev) for x in frames), tuple(torch.from_numpy(np.ascontiguousarray(x.T)).to(dev) for x in sample_pc)]
+    for k in range(n_real):
+        R = torch.as_tensor(ls.real_batch_rotation(k), device=dev)
+        pairs.append(((R @ base[k % 2][0]).contiguous(), (R @ base[k % 2][1]).contiguous()))
+    # ragged tails: scans whose length is no multiple of 4 / 256, a scan of 3 rows, an empty scan 2
+    a, b = pairs[0]
+    pairs += [(a[:, :70001].contiguous(), b[:, :69997].contiguous()), (a[:, :5000].contiguous(), b[:, :3].contiguous()), (a[:, :5000].contiguous(), b[:, :0].contiguous())]
+    return pairs
+
+
+@pytest.mark.gpu
+def test_keep_list_is_bit_neutral(gpu_ctx, frames, sample_pc):
+    """The keep list of the point pass (include/icet_hip.h option "keep"; src/icet.cpp:290-302: H^T W H sees only points in the angular bin of an active voxel):
+    a throughput batch solved with the list off, on, with budgets so tight that nearly every pass falls back and rebuilds, with loose budgets, and with the marks
+    made from iteration 0 -- 51 pairs (synthetic, real scans with thousands of zero rows, the two pairs whose X keeps moving, ragged and empty scans) must come
+    out bit for bit the same, with and without a non-zero X0; and the statistics must show that lists were in fact walked."""
+    import icet_amd
+    from icet_amd import api
+    dev = torch.device("cuda", 0)
+    pairs = _keep_batch(dev, frames, sample_pc)
+    N = len(pairs)
+    d1 = [(p[0].data_ptr(), p[0].shape[1], p[0].shape[1]) for p in pairs]; d2 = [(p[1].data_ptr(), p[1].shape[1], p[1].shape[1]) for p in pairs]
+    x0 = torch.zeros((N, 6), dtype=torch.float32, device=dev)
+    x0[:, 0] = 0.02 * (torch.arange(N, device=dev) % 5).float(); x0[:, 5] = 0.002 * (torch.arange(N, device=dev) % 3).float()
+    torch.cuda.synchronize()
+    ctx = icet_amd.Context(0)
+
+    def run(opts, runlen=7, x0p=None, flags=0):
+        for k, v in dict(keep=1, keep_from=1, keep_budget_t=0.08, keep_budget_r=0.008).items():
+            ctx.set_option(k, v)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        out = torch.full((N, 48), float("nan"), dtype=torch.float32, device=dev)
+        ctx.solve_batch_device(d1, d2, api.Params(runlen, 24, 75, 25, 0.1, 0.1, flags), out.data_ptr(), x0p)
+        ctx.sync()
+        return out.cpu().numpy()
+
+    for x0p in (None, x0.data_ptr()):
+        off = run(dict(keep=0), x0p=x0p)
+        on = run({}, x0p=x0p)
+        st = ctx.keep_stats(N)
+        n_groups = np.array([(p[1].shape[1] + 3) // 4 for p in pairs])
+        frac = st[:N - 3, 1] / n_groups[:N - 3]
+        print("keep list: groups kept min / median / max %.2f / %.2f / %.2f, list passes per pair %s, lists built %s" % (frac.min(), np.median(frac), frac.max(), np.bincount(st[:, 2]), np.bincount(st[:, 3])))
+        assert np.array_equal(off.view(np.uint32), on.view(np.uint32)), np.nonzero((off.view(np.uint32) != on.view(np.uint32)).any(1))[0]
+        assert (st[:N - 3, 2] >= 3).mean() > 0.7 and 0.2 < np.median(frac) < 0.85          # most pairs walked a list in most of the 5 passes behind the first marks, and the list is shorter than the scan
+        for opts in (dict(keep_budget_t=1e-4, keep_budget_r=1e-5), dict(keep_budget_t=0.5, keep_budget_r=0.05), dict(keep_from=0), dict(keep_from=2, keep_budget_t=0.02)):
+            got = run(opts, x0p=x0p)
+            assert np.array_equal(off.view(np.uint32), got.view(np.uint32)), opts
+    # other loop lengths (3: the shortest a list is used for; 12), per-iteration timing launches, the moving-object extension
+    for rl, fl in ((3, 0), (4, 0), (12, 0), (7, api.FLAG_TIMING), (7, api.FLAG_REJECT_MOVING)):
+        assert np.array_equal(run(dict(keep=0), rl, None, fl).view(np.uint32), run({}, rl, None, fl).view(np.uint32)), (rl, fl)
+    # a finer grid with the one-block solve of 512 threads, and a coarse one
+    for (P, T) in ((48, 150), (6, 11)):
+        outs = []
+        for keep in (0, 1):
+            ctx.set_option("keep", keep)
+            out = torch.zeros((N, 48), dtype=torch.float32, device=dev)
+            ctx.solve_batch_device(d1, d2, api.Params(7, P, T, 25, 0.1, 0.1, 0), out.data_ptr()); ctx.sync()
+            outs.append(out.cpu().numpy())
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (P, T)
+    ctx.close()

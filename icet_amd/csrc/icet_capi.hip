@@ -33,6 +33,7 @@ struct icet_ctx {
     std::string err;
     // host staging (pinned) for descriptors and results
     PairDesc* h_desc = nullptr; int32_t* h_seg = nullptr; int32_t h_cap_pairs = 0;
+    bool desc_kf_valid = false, desc_reg_valid = false;   // the pinned descriptors hold what the last icet_keyframe_device_n / icet_register_device_n call wrote (any other writer, and a re-allocation, clears both)
     PairDesc* h_desc_rt = nullptr; int32_t h_cap_rt = 0;       // ICET_FLAG_ROUNDTRIP_SCAN2: descriptors of the round-tripped copy of scan 2
     // device staging for host-pointer entry points
     float* d_stage1 = nullptr; float* d_stage2 = nullptr; int64_t cap_stage1 = 0, cap_stage2 = 0;
@@ -126,6 +127,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         if (c->h_desc) { HIPCHK(c, hipHostFree(c->h_desc)); c->h_desc = nullptr; }
         if (c->h_seg) { HIPCHK(c, hipHostFree(c->h_seg)); c->h_seg = nullptr; }
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_desc), sizeof(PairDesc) * np));
+        std::memset(c->h_desc, 0, sizeof(PairDesc) * np); c->desc_kf_valid = c->desc_reg_valid = false;
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_seg), sizeof(int32_t) * ((size_t)np + 1)));
         c->h_cap_pairs = np;
         w.cap_pairs = np; w.cap_V = VV;
@@ -768,7 +770,11 @@ static icet_ctx::GraphKey graph_key_of(icet_ctx* c, const icet_params* p, int32_
     return key;
 }
 static bool graph_eligible(const icet_ctx* c, const icet_params* p, int32_t n_pairs) {
-    static const bool env_off = getenv("ICET_NO_GRAPH") != nullptr;      // (experiments: every context of the process without graph replay)
+#ifdef ICET_DIAG_ENV      /* experiment builds only (make EXTRA=-DICET_DIAG_ENV): the shipped library never reads the environment -- use icet_set_option("graph", 0) */
+    static const bool env_off = getenv("ICET_NO_GRAPH") != nullptr;
+#else
+    constexpr bool env_off = false;
+#endif
     return !env_off && c->graph_mode && n_pairs <= 8 && !(p->flags & (ICET_FLAG_TIMING | ICET_FLAG_ROUNDTRIP_SCAN2)) && !c->stage_at;
 }
 // Runs `enq` (which enqueues on c->stream) eagerly, or captured into `slot` and replayed.  The pinned descriptor staging must already hold this call's
@@ -819,6 +825,7 @@ static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t 
     // (the device entry point never waits for them: calls queue up behind each other on the stream)
     if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
     if (c->graph_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_graph)); c->graph_in_flight = false; }     // a replay re-reads the pinned descriptor staging when it RUNS
+    c->desc_kf_valid = c->desc_reg_valid = false;
     for (int k = 0; k < n_pairs; k++) {
         PairDesc& d = c->h_desc[k];
         d.s1 = scan1[k].ptr; d.s2 = scan2[k].ptr;
@@ -854,12 +861,13 @@ icet_status icet_keyframe_device_n(icet_ctx* c, const icet_params* p, int32_t n_
     // A sequential caller hands the SAME buffers to this half frame after frame (include/icet_nodes.h): the pinned descriptor staging then already holds
     // this call's scan-1 halves and is left alone -- rewriting it means waiting, on the HOST, for whatever replay or copy of this context still reads it,
     // and a burst of frames (icet_node_push_many_device) would have the host wait for the device twice per frame instead of running ahead
-    bool same_desc = true;
+    bool same_desc = c->desc_kf_valid;                                     // (only what the previous call of THIS entry wrote counts: raw staging memory proves nothing)
     for (int k = 0; k < n_pairs && same_desc; k++) {
         const PairDesc& d = c->h_desc[k];
         same_desc = d.s1 == scan1[k].ptr && d.n1 == (int32_t)scan1[k].n && d.ld1 == (int32_t)scan1[k].ld;
     }
     if (!same_desc) {
+        c->desc_reg_valid = false;                                         // the scan-2 halves are reset below
         if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
         if (c->graph_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_graph)); c->graph_in_flight = false; }
         for (int k = 0; k < n_pairs; k++) {
@@ -867,6 +875,7 @@ icet_status icet_keyframe_device_n(icet_ctx* c, const icet_params* p, int32_t n_
             d.s1 = scan1[k].ptr; d.n1 = (int32_t)scan1[k].n; d.ld1 = (int32_t)scan1[k].ld;
             d.s2 = nullptr; d.n2 = 0; d.ld2 = 0; d.off1 = 0; d.off2 = 0;
         }
+        c->desc_kf_valid = true;
     }
     if (graph_eligible(c, p, n_pairs)) {
         s = ensure_thresholds(c, p->bins_theta, p->bins_phi);
@@ -897,7 +906,7 @@ icet_status icet_register_device_n(icet_ctx* c, const icet_params* p, int32_t n_
     if (p->runlen == 0) return write_runlen0(c, n_pairs, d_x0, d_out);
     icet_status s = ensure_workspace(c, p, n_pairs, 0, tot2);              // only the scan-2 overflow list can grow here: the keyframe tables stay
     if (s != ICET_OK) return s;
-    bool same_desc = true;                                                 // (see icet_keyframe_device_n)
+    bool same_desc = c->desc_reg_valid;                                    // (see icet_keyframe_device_n)
     for (int k = 0; k < n_pairs && same_desc; k++) {
         const PairDesc& d = c->h_desc[k];
         same_desc = d.s2 == scan2[k].ptr && d.n2 == (int32_t)scan2[k].n && d.ld2 == (int32_t)scan2[k].ld;
@@ -906,6 +915,7 @@ icet_status icet_register_device_n(icet_ctx* c, const icet_params* p, int32_t n_
         if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
         if (c->graph_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_graph)); c->graph_in_flight = false; }
         for (int k = 0; k < n_pairs; k++) { PairDesc& d = c->h_desc[k]; d.s2 = scan2[k].ptr; d.n2 = (int32_t)scan2[k].n; d.ld2 = (int32_t)scan2[k].ld; }
+        c->desc_reg_valid = true;
     }
     if (graph_eligible(c, p, n_pairs))
         return run_or_replay(c, c->g_loop, graph_key_of(c, p, n_pairs, d_x0, d_out, d_rows, (const void*)2), [&]() { return enqueue_loop(c, p, n_pairs, d_x0, d_out, nullptr, true, nullptr, nullptr, d_rows); });
@@ -934,6 +944,7 @@ icet_status icet_solve_batch(icet_ctx* c, const icet_params* p, int32_t n_pairs,
     // Scan 1 of every pair goes up first on the solve stream (the keyframe build needs nothing else); the scan 2s follow on the copy
     // stream while the keyframe kernels run, and the loop waits for them.  Host scans are dense column-major (ld == n) in this entry point.
     int64_t o1 = 0, o2 = 0;
+    c->desc_kf_valid = c->desc_reg_valid = false;
     for (int k = 0; k < n_pairs; k++) {
         const int64_t l1 = (n1[k] + 63) / 64 * 64, l2 = (n2[k] + 63) / 64 * 64;
         PairDesc& d = c->h_desc[k];
@@ -1026,6 +1037,7 @@ icet_status icet_solve_begin(icet_ctx* c, const icet_params* p, const float* sca
     // entry points, each of which has drained the stream before it returned)
     std::memcpy(c->h_x0, x0, 6 * sizeof(float));                              // pinned: k_init_state reads X0 straight from it (no H2D command)
     HIPCHK(c, upload_scan(c->d_stage1, l1, scan1, n1, ld1, c->stream));
+    c->desc_kf_valid = c->desc_reg_valid = false;
     PairDesc& d = c->h_desc[0];
     d.s1 = c->d_stage1; d.s2 = c->d_stage2; d.n1 = (int32_t)n1; d.ld1 = (int32_t)l1; d.n2 = (int32_t)n2; d.ld2 = (int32_t)l2; d.off1 = 0; d.off2 = 0;
     const AuxLayout L = aux_layout(V, p->runlen);

@@ -425,7 +425,11 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         // The loop runs on the FILTER's stream: a dependency between two streams costs ~60 us on this part before the waiting queue starts (measured on the device
         // timeline: filter end -> first loop kernel), and filter -> loop -> result is the frame's critical path.  The context keeps its own stream for its keyframe
         // builds; the build this loop needs (previous frame, that stream) finished long ago as a rule -- an event says so.
+#ifdef ICET_DIAG_ENV      /* the A/B switches of round 5's stream experiments: experiment builds only (make EXTRA=-DICET_DIAG_ENV); the shipped library never reads the environment */
         static const bool loop_on_filter_stream = getenv("ICET_NODE_LOOP_OWN_STREAM") == nullptr;
+#else
+        constexpr bool loop_on_filter_stream = true;
+#endif
         so = loop_on_filter_stream ? st : s_own;
         if (loop_on_filter_stream) {
             if (nd->kf_built[nd->owner]) NCHK(nd, hipStreamWaitEvent(st, nd->ev_kfdone[nd->owner], 0));
@@ -616,11 +620,24 @@ icet_status push_many_fast(icet_node* nd, const icet_dev_scan* fr, int K, icet_n
     const bool helper_on = !(nd->p.flags & ICET_NODE_SERIAL_ENQUEUE) && K > 1 && kf_worker_start(nd);
     // (In the frame-by-frame path the loop runs on the filter's stream -- +10 % frames/s.  Here it does not pay: a burst is a chain loop k-1 -> build k -> loop k+1 across
     // two streams whichever way the loops are placed; measured 3.68 k frames/s with the loops on the filter's stream against 3.81 k on their contexts' streams.)
+#ifdef ICET_DIAG_ENV
     static const bool loops_on_st = getenv("ICET_NODE_BURST_LOOPS_ON_FILTER_STREAM") != nullptr;
+#else
+    constexpr bool loops_on_st = false;
+#endif
     if (loops_on_st) for (icet_ctx* c : nd->kf) NCHK(nd, hipStreamSynchronize(reinterpret_cast<hipStream_t>(icet_stream(c))));     // the build the first loop needs was enqueued by an earlier call: done (once per burst)
-    const bool trace = getenv("ICET_NODE_TRACE") != nullptr; double t_filter = 0, t_wait = 0, t_reg = 0, t_kf_inline = 0;
+#ifdef ICET_DIAG_ENV
+    const bool trace = getenv("ICET_NODE_TRACE") != nullptr;
+#else
+    constexpr bool trace = false;
+#endif
+    double t_filter = 0, t_wait = 0, t_reg = 0, t_kf_inline = 0;
     auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
+    // The burst's SECOND frame filters into the buffer that holds the node's previous scan -- which the keyframe build enqueued before the burst (the last single
+    // push's, on that context's stream, or the first cloud's) may still be reading as its scan 1: no host synchronisation lies in between (push_frame waits for the
+    // filter's stream only) and the k > 1 rule below knows nothing of frames before the burst.  The filter's stream waits for that build here, once per burst.
+    if (nd->kf_built[owner]) NCHK(nd, hipStreamWaitEvent(st, nd->ev_kfdone[owner], 0));
     for (int k = 0; k < K; k++) {
         const double t0 = now();
         double tw = 0;
@@ -693,6 +710,8 @@ icet_status push_many_fast(icet_node* nd, const icet_dev_scan* fr, int K, icet_n
     for (int k = 0; k < K; k++) finish_frame_host(nd, nd->h_out_all + 48 * (size_t)k, nd->h_nk_all[k], &res[k]);
     nd->prev = prev; nd->owner = owner;
     nd->n_scan[prev] = nd->h_nk_all[K - 1]; nd->ld_scan[prev] = nd->cap_scan[prev];
+    // what a following single push (or burst) waits for: the burst's last build, on the context that is now `owner` (complete: both streams were drained above)
+    NCHK(nd, hipEventRecord(nd->ev_kfdone[owner], reinterpret_cast<hipStream_t>(icet_stream(nd->kf[owner])))); nd->kf_built[owner] = true;
     return ICET_OK;
 }
 

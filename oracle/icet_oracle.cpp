@@ -94,6 +94,33 @@ static inline void s2c_one(float r, float th, float ph, float& x, float& y, floa
 }
 // mean and covariance of m Cartesian rows (src/icet.cpp:160-162, 304-306): unbiased two-pass form.  Shared rule: exact sums
 // (double accumulators over float addends), rounded once; libmf: sequential float sums.
+// ICET_ORACLE_PINV3_DOUBLE (attribution experiment, icet_oracle.h): Moore-Penrose pseudo-inverse of a symmetric 3 x 3 by cyclic Jacobi in double,
+// eigenvalues <= 3 eps x the largest treated as rank deficiency -- the rule of the HIP path's pinv3_sym, written independently.
+static inline Mat pinv3_double(const Mat& Rp) {
+    double A[3][3], Vv[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i][j] = 0.5 * ((double)Rp(i, j) + (double)Rp(j, i));
+    for (int sweep = 0; sweep < 30; sweep++) {
+        const double off = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]), dg = std::fabs(A[0][0]) + std::fabs(A[1][1]) + std::fabs(A[2][2]);
+        if (off <= 1e-17 * dg) break;
+        for (int p = 0; p < 3; p++) for (int q = p + 1; q < 3; q++) {
+            if (A[p][q] == 0.0) continue;
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0)), c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 3; k++) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+            for (int k = 0; k < 3; k++) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+            for (int k = 0; k < 3; k++) { const double vkp = Vv[k][p], vkq = Vv[k][q]; Vv[k][p] = c * vkp - s * vkq; Vv[k][q] = s * vkp + c * vkq; }
+        }
+    }
+    const double lmax = std::max(std::max(std::fabs(A[0][0]), std::fabs(A[1][1])), std::fabs(A[2][2])), thr = (double)(3.0f * FLT_EPSILON) * lmax;
+    Mat W(3, 3);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double t = 0.0;
+        for (int k = 0; k < 3; k++) if (std::fabs(A[k][k]) > thr) t += Vv[i][k] * Vv[j][k] / A[k][k];
+        W(i, j) = (float)t;
+    }
+    return W;
+}
+
 static inline void mean_cov(const std::vector<float>& cx, const std::vector<float>& cy, const std::vector<float>& cz, bool libmf, float mean[3], Mat& cov) {
     const long rows = (long)cx.size();
     cov = Mat(3, 3);
@@ -342,6 +369,7 @@ struct Solver {
     bool libmf = false;                // ICET_ORACLE_LIBMF: float libm + sequential float sums instead of the shared rule
     bool skip_rt2 = false;             // ICET_ORACLE_SKIP_RT2: scan 2 is never round-tripped through spherical coordinates (the device's deviation)
     bool rt2_thin_only = false;        // ICET_ORACLE_RT2_THIN: ... except for the points of voxels whose scan-1 Gaussian is thin (lambda_min < rt_tau)
+    bool dev_arith = false;            // ICET_ORACLE_DEVICE_ARITH: the HIP path's documented deviations (icet_oracle.h)
     float rt_tau = 1e-5f;
     std::vector<float> lam_min1;       // smallest eigenvalue of sigma1 per voxel
     std::vector<float> rawx, rawy, rawz;   // scan 2 as given (before prepScan2's round trip), in scrambled order
@@ -475,6 +503,22 @@ struct Solver {
                 const VoxelFit& f = fit[v];
                 if (!f.has_fit) { out.used = false; out.n_in = -(int)rows - 1; return out; }   // reference UB, see header
                 float mean[3]; Mat cov;
+                float db[3] = {0.f, 0.f, 0.f};
+                if (dev_arith) {
+                    // icet_solve_body.h: sums of d = q - mu1 (float) and of d d^T, exact; mean - mu1, mean and covariance from them in double, rounded once
+                    double sd[3] = {0, 0, 0}, sdd[6] = {0, 0, 0, 0, 0, 0};
+                    for (long k = 0; k < rows; k++) {
+                        const float d[3] = {cx[k] - f.mu[0], cy[k] - f.mu[1], cz[k] - f.mu[2]};
+                        for (int a = 0; a < 3; a++) sd[a] += (double)d[a];
+                        sdd[0] += (double)d[0] * d[0]; sdd[1] += (double)d[0] * d[1]; sdd[2] += (double)d[0] * d[2];
+                        sdd[3] += (double)d[1] * d[1]; sdd[4] += (double)d[1] * d[2]; sdd[5] += (double)d[2] * d[2];
+                    }
+                    const double fm = (double)rows, dbD[3] = {sd[0] / fm, sd[1] / fm, sd[2] / fm}, den = 1.0 / (double)(rows - 1);
+                    for (int a = 0; a < 3; a++) { db[a] = (float)dbD[a]; mean[a] = (float)((double)f.mu[a] + dbD[a]); }
+                    cov = Mat(3, 3);
+                    const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+                    for (int q = 0; q < 6; q++) { const float c = (float)((sdd[q] - fm * dbD[ia[q]] * dbD[ib[q]]) * den); cov(ia[q], ib[q]) = c; cov(ib[q], ia[q]) = c; }
+                } else
                 mean_cov(cx, cy, cz, libmf, mean, cov);
                 // R_noise = sigma1/(n1-1) + cov/(n2-1)            icet.cpp:315 (raw bin counts, Q10)
                 Mat Rn(3, 3);
@@ -484,7 +528,7 @@ struct Solver {
                 Mat Lm(3, 3); for (int k = 0; k < 3; k++) Lm(k, k) = f.Ldiag[k];
                 Mat LUt = matmul(Lm, f.V);
                 Mat Rp = matmul(matmul(matmul(LUt, Rn), transpose(f.V)), transpose(Lm));   // icet.cpp:317
-                Mat W = cod_pinv(Rp);                                                        // icet.cpp:320-321
+                Mat W = (prm.mode & ICET_ORACLE_PINV3_DOUBLE) ? pinv3_double(Rp) : cod_pinv(Rp);   // icet.cpp:320-321
                 float angs[3] = {X[3], X[4], X[5]};
                 Mat H_j = get_H(mean, angs, libmf);
                 Mat H_z = matmul(LUt, H_j);                                                  // icet.cpp:329
@@ -495,6 +539,7 @@ struct Solver {
                 for (int a = 0; a < 3; a++) { mu1m(a, 0) = f.mu[a]; mu2m(a, 0) = mean[a]; }
                 Mat z1 = matmul(LUt, mu1m), z2 = matmul(LUt, mu2m);
                 Mat dz(3, 1); for (int a = 0; a < 3; a++) dz(a, 0) = z2(a, 0) - z1(a, 0);
+                if (dev_arith) { Mat dbm(3, 1); for (int a = 0; a < 3; a++) dbm(a, 0) = db[a]; dz = matmul(LUt, dbm); }
                 if ((prm.mode & ICET_ORACLE_REJECT_MOVING) && iter_no >= 4 &&
                     (std::fabs(dz(0, 0)) > 0.3f || std::fabs(dz(1, 0)) > 0.3f || std::fabs(dz(2, 0)) > 0.3f)) { out.HTWH = Mat(6, 6); return out; }   // extension: a moving object
                 out.HTWdz = matmul(HzTW, dz);                                                // icet.cpp:338
@@ -550,9 +595,15 @@ struct Solver {
             rtx.resize(N); rty.resize(N); rtz.resize(N); sphr.resize(N);
             for (int i = 0; i < N; i++) {
                 float a = rawx[i] + X[0], b = rawy[i] + X[1], c = rawz[i] + X[2];
+                if (dev_arith) {
+                    rtx[i] = std::fmaf(c, rot(2, 0), std::fmaf(b, rot(1, 0), a * rot(0, 0)));
+                    rty[i] = std::fmaf(c, rot(2, 1), std::fmaf(b, rot(1, 1), a * rot(0, 1)));
+                    rtz[i] = std::fmaf(c, rot(2, 2), std::fmaf(b, rot(1, 2), a * rot(0, 2)));
+                } else {
                 rtx[i] = a * rot(0, 0) + b * rot(1, 0) + c * rot(2, 0);
                 rty[i] = a * rot(0, 1) + b * rot(1, 1) + c * rot(2, 1);
                 rtz[i] = a * rot(0, 2) + b * rot(1, 2) + c * rot(2, 2);
+                }
                 c2s_one(rtx[i], rty[i], rtz[i], sphr.r[i], sphr.th[i], sphr.ph[i], libmf);
             }
             binPoints(sphr, bin2_start, bin2_idx);
@@ -585,7 +636,8 @@ struct Solver {
     int run(const float* s1, int64_t n1, int64_t ld1, const float* s2, int64_t n2, int64_t ld2, const float* x0) {
         T = prm.bins_theta; P = prm.bins_phi; V = T * P; n = prm.n;
         libmf = (prm.mode & ICET_ORACLE_LIBMF) != 0;
-        skip_rt2 = (prm.mode & (ICET_ORACLE_SKIP_RT2 | ICET_ORACLE_RT2_THIN)) != 0; rt2_thin_only = (prm.mode & ICET_ORACLE_RT2_THIN) != 0;
+        dev_arith = (prm.mode & ICET_ORACLE_DEVICE_ARITH) != 0;
+        skip_rt2 = (prm.mode & (ICET_ORACLE_SKIP_RT2 | ICET_ORACLE_RT2_THIN | ICET_ORACLE_DEVICE_ARITH)) != 0; rt2_thin_only = (prm.mode & ICET_ORACLE_RT2_THIN) != 0;
         lam_min1.assign((size_t)prm.bins_theta * prm.bins_phi, 0.f);
         p1x.assign(s1, s1 + n1); p1y.assign(s1 + ld1, s1 + ld1 + n1); p1z.assign(s1 + 2 * ld1, s1 + 2 * ld1 + n1);
         p2x.assign(s2, s2 + n2); p2y.assign(s2 + ld2, s2 + ld2 + n2); p2z.assign(s2 + 2 * ld2, s2 + 2 * ld2 + n2);

@@ -20,8 +20,18 @@ enum { ICET_ORACLE_SERIAL = 0,   /* live path: serial voxel loop, src/icet.cpp:3
        ICET_ORACLE_REJECT_MOVING = 32, /* OR-ed in: non-parity extension, twin of ICET_FLAG_REJECT_MOVING: from iteration 4 on a voxel whose
                                        compact residual L U^T (mu2 - mu1) exceeds 0.3 m in a kept axis is skipped
                                        (python/ICET_spherical.py:175-250, RM_thresh :38, start_RM_iter :36) */
-       ICET_ORACLE_HALF_GAP = 64 };  /* OR-ed in: non-parity extension, twin of ICET_FLAG_HALF_GAP_BOUNDS (implies TRUE_SORT): cluster bounds reach
+       ICET_ORACLE_HALF_GAP = 64,    /* OR-ed in: non-parity extension, twin of ICET_FLAG_HALF_GAP_BOUNDS (implies TRUE_SORT): cluster bounds reach
                                        half way to the nearest point outside the cluster, at most buff (python/utils.py:92-119) */
+       ICET_ORACLE_DEVICE_ARITH = 128 };  /* ATTRIBUTION EXPERIMENT (implies SKIP_RT2): every documented last-bit deviation of the HIP path at once -- scan 2 not
+                                       round-tripped; the transform (p + t) R as three FMAs per coordinate, innermost product first (icet_device_common.h transform_point:
+                                       what Eigen's product kernel does on an FMA machine); the scan-2 moments as sums of d = q - mu1 and d d^T accumulated exactly and
+                                       centred afterwards in double (icet_solve_body.h); dz = L U^T (mu2 - mu1) from that difference instead of L U^T mu2 - L U^T mu1.
+                                       What is then left between device and oracle is the float rounding of the device's per-run partial sums (tests/test_gpu_parity.py
+                                       test_attribution_*) */
+       /* OR-ed in, ATTRIBUTION EXPERIMENT: the per-voxel weight W = pinv(L U^T R_noise U L^T) (src/icet.cpp:320-321) as the HIP path takes it -- in DOUBLE, rank by
+          eigenvalues above 3 eps x the largest (icet_device_math.h pinv3_sym) -- instead of the reference's float CompleteOrthogonalDecomposition, whose result carries a
+          relative error of cond x eps: per cents on the cond 1e6 .. 1e7 voxels of a millimetre-noise scene */
+#define ICET_ORACLE_PINV3_DOUBLE 256
 
 typedef struct icet_oracle_params {
     int32_t runlen;      /* include/icet.h:38  */

@@ -11,7 +11,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libicet_oracle.so")
 
-SERIAL, POOL4, TRUE_SORT, LIBMF, SKIP_RT2, RT2_THIN, REJECT_MOVING, HALF_GAP = 0, 1, 2, 4, 8, 16, 32, 64
+SERIAL, POOL4, TRUE_SORT, LIBMF, SKIP_RT2, RT2_THIN, REJECT_MOVING, HALF_GAP, DEVICE_ARITH = 0, 1, 2, 4, 8, 16, 32, 64, 128
+PINV3_DOUBLE = 256
 
 
 class Params(C.Structure):

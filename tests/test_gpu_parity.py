@@ -58,21 +58,42 @@ def _write_margins():
                 f.write("%s %.3g %.3g %.3g %.3g\n" % m)
 
 
-def oracle_sensitivity(a, b, trials=3, scan1_too=False, **kw):
+def oracle_sensitivity(a, b, trials=32, scan1_too=False, x0=None, **kw):
     """How far the ORACLE's own answer moves when scan 2 (and, with scan1_too, scan 1) is perturbed by ~1 float32 ulp
     (relative 1e-7): the Gauss-Newton loop re-bins every iteration, so a point flipping across a voxel edge can move X by
     far more than rounding would; a 1-ulp change in scan 1 also reaches the per-voxel covariances whose smallest eigenvalues
     set weights of 1e7 (measured on the bench batch: typically 2e-4 .. 1e-3 m).  Used to calibrate the tolerance on
-    ill-conditioned pairs."""
+    ill-conditioned pairs.  32 trials (round 6; review r5: three trials give a LOWER bound of a heavy-tailed spread), solved on the host's
+    cores in parallel; returns the per-component maximum, `oracle_sensitivity.last` also holds the 90 % quantile.  Users bound by 1.5 x the maximum."""
     from oracle import pyoracle as po
-    base = po.solve(a, b, **kw)["X"]
+    base = po.solve(a, b, x0=x0, **kw)["X"]
     rng = np.random.default_rng(123)
-    dev = np.zeros(6)
+    A, B = [], []
     for _ in range(trials):
-        ap = (a.astype(np.float64) * (1.0 + rng.uniform(-1e-7, 1e-7, a.shape))).astype(np.float32) if scan1_too else a
-        bp = (b.astype(np.float64) * (1.0 + rng.uniform(-1e-7, 1e-7, b.shape))).astype(np.float32)
-        dev = np.maximum(dev, np.abs(po.solve(ap, bp, **kw)["X"] - base))
-    return dev
+        A.append((a.astype(np.float64) * (1.0 + rng.uniform(-1e-7, 1e-7, a.shape))).astype(np.float32) if scan1_too else a)
+        B.append((b.astype(np.float64) * (1.0 + rng.uniform(-1e-7, 1e-7, b.shape))).astype(np.float32))
+    X0 = None if x0 is None else np.tile(np.asarray(x0, np.float32).reshape(1, 6), (trials, 1))
+    res = po.solve_batch(A, B, x0=X0, n_threads=max(1, min(16, os.cpu_count() or 1)), **kw)
+    dev = np.abs(res["X"].astype(np.float64) - base)
+    oracle_sensitivity.last = dict(max=dev.max(0), p90=np.quantile(dev, 0.9, axis=0), trials=trials)
+    return dev.max(0)
+
+
+HATCH = 1.5          # a bound "within the oracle's own 1-ulp spread" means: within HATCH x the maximum over 32 trials
+
+
+def _replay_each_iteration(gpu_ctx, a, b, ref, P=24, T=75, x0=None, flags=0, **kw):
+    """The non-chaotic comparison (review r5, weak 1): every Gauss-Newton iteration REPLAYED on the device from the ORACLE's X_{i-1} -- one step from the same
+    state, no accumulated divergence.  Returns per iteration (raw-count differences on the active voxels, max |dHTWH| / max |HTWH|)."""
+    t = ref["trace"]
+    act = (t["has_fit"] == 1) & (t["n1_raw"] > kw.get("n", 25)) & (t["bounds"][:, 5] > 1)
+    out = []
+    for it in range(t["X"].shape[0]):
+        x_in = (np.zeros(6, np.float32) if x0 is None else np.asarray(x0, np.float32)) if it == 0 else t["X"][it - 1]
+        rp = gpu_ctx.solve(a, b, 1, x_in, P, T, aux=True, flags=flags, **kw)
+        flips = int((rp["aux"]["n2_raw"][0][act] != t["n2_raw"][it][act]).sum())
+        out.append((flips, float(np.abs(rp["aux"]["htwh"][0] - t["HTWH"][it]).max() / max(float(np.abs(t["HTWH"][it]).max()), 1e-30))))
+    return out
 
 
 def _check_solution(res, ref, tol_t=TOL_T, tol_r=TOL_R, rtol_std=RTOL_STD, rtol_cov=RTOL_COV):
@@ -193,7 +214,7 @@ def test_highres_config5_exactly_as_bench_times_it(gpu_ctx):
     Asserted: the keyframe table and the sort + swap loop bit for bit; every iteration REPLAYED from the oracle's own state (one
     Gauss-Newton step from the same X: no accumulated divergence) within the parity bound with at most a handful of voxels counting
     differently; the free-running result within the parity bound AND within 2 x the oracle's own sensitivity to a 1-ulp perturbation
-    of scan 2 computed here (floored at 2e-5 m); pred_stds / cov within 2 x the batch p99."""
+    of scan 2 computed here (32 trials, x 1.5; floored at 2e-5 m); pred_stds / cov within 2 x the batch p99."""
     from icet_amd import lidar_sim as ls
     from oracle import pyoracle as po
     P, T, RL = 48, 150, 10
@@ -225,15 +246,11 @@ def test_highres_config5_exactly_as_bench_times_it(gpu_ctx):
         print("iter %d: free-running |dX| %.2e m %.2e rad, %d voxel counts differ; replayed from the oracle's X: %.2e m %.2e rad, %d raw counts differ"
               % (it, free[:3].max(), free[3:].max(), nd, d[:3].max(), d[3:].max(), flips))
     print("first iteration with a differing decision: %s" % first)
-    rng = np.random.default_rng(123)
-    sens = np.zeros(6)
-    for _ in range(4):
-        bp = (b.astype(np.float64) * (1.0 + rng.uniform(-1e-7, 1e-7, b.shape))).astype(np.float32)
-        sens = np.maximum(sens, np.abs(po.solve(a, bp, runlen=RL, bins_phi=P, bins_theta=T)["X"] - ref["X"]))
+    sens = oracle_sensitivity(a, b, runlen=RL, bins_phi=P, bins_theta=T)
     dX = np.abs(g["X"] - ref["X"])
     print("configs[4] as benchmarked: |dX_t| %.3g m, |dX_r| %.3g rad; oracle 1-ulp sensitivity %.3g m / %.3g rad" % (dX[:3].max(), dX[3:].max(), sens[:3].max(), sens[3:].max()))
     _check_solution(g, ref, rtol_std=RTOL_STD_P99, rtol_cov=RTOL_COV_P99)
-    assert dX[:3].max() <= max(2 * sens[:3].max(), 2e-5) and dX[3:].max() <= max(2 * sens[3:].max(), 2e-6), (dX, sens)
+    assert dX[:3].max() <= max(HATCH * sens[:3].max(), 2e-5) and dX[3:].max() <= max(HATCH * sens[3:].max(), 2e-6), (dX, sens)
 
 
 def test_million_row_scans(gpu_ctx):
@@ -285,8 +302,8 @@ def test_batch_equals_singles_and_oracle(gpu_ctx, frames, sample_pc):
         ref = po.solve(s1[k], s2[k], x0=x0[k])
         # the truncated scans (k = 2, 3) are partial views with few voxels and a poorly constrained z / roll: held to the larger of the
         # parity bound and 5 x the oracle's own answer-to-answer spread under a 1-ulp perturbation of both scans
-        sens = oracle_sensitivity(s1[k], s2[k], trials=4, scan1_too=True, x0=x0[k]) if k in (2, 3) else np.zeros(6)
-        _check_solution(dict(X=out["X"][k], pred_stds=out["pred_stds"][k], cov=out["cov"][k]), ref, max(TOL_T, 5 * sens[:3].max()), max(TOL_R, 5 * sens[3:].max()))
+        sens = oracle_sensitivity(s1[k], s2[k], scan1_too=True, x0=x0[k]) if k in (2, 3) else np.zeros(6)
+        _check_solution(dict(X=out["X"][k], pred_stds=out["pred_stds"][k], cov=out["cov"][k]), ref, max(TOL_T, HATCH * sens[:3].max()), max(TOL_R, HATCH * sens[3:].max()))
 
 
 def test_identical_scans_within_oracle_sensitivity(gpu_ctx, frames):
@@ -301,12 +318,12 @@ def test_identical_scans_within_oracle_sensitivity(gpu_ctx, frames):
     r1 = gpu_ctx.solve(a, a, 1, np.zeros(6), 24, 75)
     s1 = oracle_sensitivity(a, a, runlen=1)
     d1 = np.abs(r1["X"] - po.solve(a, a, runlen=1)["X"])
-    assert d1[:3].max() <= max(5 * s1[:3].max(), 5e-6) and d1[3:].max() <= max(5 * s1[3:].max(), 5e-6), (r1["X"], s1)
+    assert d1[:3].max() <= max(HATCH * s1[:3].max(), 5e-6) and d1[3:].max() <= max(HATCH * s1[3:].max(), 5e-6), (r1["X"], s1)
     r = gpu_ctx.solve(a, a, 7, np.zeros(6), 24, 75)
     ref = po.solve(a, a)
     sens = oracle_sensitivity(a, a)
     d = np.abs(r["X"] - ref["X"])
-    assert d[:3].max() <= max(5 * sens[:3].max(), TOL_T) and d[3:].max() <= max(5 * sens[3:].max(), TOL_R), (r["X"], ref["X"], sens)
+    assert d[:3].max() <= max(HATCH * sens[:3].max(), TOL_T) and d[3:].max() <= max(HATCH * sens[3:].max(), TOL_R), (r["X"], ref["X"], sens)
 
 
 def test_edge_cases(gpu_ctx, frames):
@@ -1127,10 +1144,19 @@ def test_real_scan_batch_keyframe_bits_and_solution(gpu_ctx, frames, sample_pc):
         assert np.array_equal(ax["n2_raw"][0][act], t["n2_raw"][0][act]), k
         # a real scan turned by an arbitrary small rotation is a less forgiving input than the fixtures as given (rings no longer aligned with the grid, ~100 active
         # voxels): held to the larger of the parity bounds and 1x the oracle's own answer-to-answer spread under a 1-ulp perturbation of both scans
-        sens = oracle_sensitivity(a, b, trials=3, scan1_too=True)
+        sens = oracle_sensitivity(a, b, scan1_too=True)
         dt, dr = float(np.abs(g["X"][:3] - ref["X"][:3]).max()), float(np.abs(g["X"][3:] - ref["X"][3:]).max())
-        print("real batch pair %d: |dX| %.3g m %.3g rad (oracle 1-ulp spread %.3g m %.3g rad)" % (k, dt, dr, sens[:3].max(), sens[3:].max()))
-        _check_solution(g, ref, tol_t=max(TOL_T, float(sens[:3].max())), tol_r=max(TOL_R, float(sens[3:].max())), rtol_std=RTOL_STD_LOOSE, rtol_cov=RTOL_COV_LOOSE)
+        # (round 6) the two non-chaotic checks behind the spread bound: every iteration replayed from the oracle's state -- same decisions, H^T W H to 2e-3 -- and the
+        # ATTRIBUTION: against the oracle run with the device's documented deviations (scan 2 not round-tripped, FMA transform, moments about mu1:
+        # ICET_ORACLE_DEVICE_ARITH) the millimetres are gone (measured: pair 0 2.3e-3 m -> 5e-8 m)
+        rep = _replay_each_iteration(gpu_ctx, a, b, ref)
+        attr = po.solve(a, b, mode=po.DEVICE_ARITH)
+        da = float(np.abs(g["X"][:3] - attr["X"][:3]).max()), float(np.abs(g["X"][3:] - attr["X"][3:]).max())
+        print("real batch pair %d: |dX| %.3g m %.3g rad (oracle 1-ulp spread, 32 trials: max %.3g m %.3g rad, p90 %.3g m); replayed per iteration: count flips %s, dH %s; against the oracle in device arithmetic: %.3g m %.3g rad"
+              % (k, dt, dr, sens[:3].max(), sens[3:].max(), oracle_sensitivity.last["p90"][:3].max(), [f for f, _ in rep], ["%.1e" % h for _, h in rep], da[0], da[1]))
+        assert max(f for f, _ in rep) <= 2 and max(h for _, h in rep) <= 2e-3, rep
+        assert da[0] <= TOL_T / 10 and da[1] <= TOL_R / 10, da
+        _check_solution(g, ref, tol_t=max(TOL_T, HATCH * float(sens[:3].max())), tol_r=max(TOL_R, HATCH * float(sens[3:].max())), rtol_std=RTOL_STD_LOOSE, rtol_cov=RTOL_COV_LOOSE)
 
 
 def test_coarse_grid_long_range_takes_the_wide_fixed_point_path(gpu_ctx):
@@ -1162,7 +1188,7 @@ def test_coarse_grid_long_range_takes_the_wide_fixed_point_path(gpu_ctx):
     assert (np.abs(ax["htwh"][0] - h0) / np.outer(sc, sc)).max() < 2e-3
     assert np.abs(ax["x_hist"][0] - t["X"][0]).max() < 40 * 5e-6 + 1e-5
     sens = oracle_sensitivity(a, b, **kw)
-    assert np.abs(g["X"][:3] - ref["X"][:3]).max() <= max(40 * TOL_T, 5 * sens[:3].max()) and np.abs(g["X"][3:] - ref["X"][3:]).max() <= max(TOL_R, 5 * sens[3:].max()), (g["X"], ref["X"], sens)
+    assert np.abs(g["X"][:3] - ref["X"][:3]).max() <= max(40 * TOL_T, HATCH * sens[:3].max()) and np.abs(g["X"][3:] - ref["X"][3:]).max() <= max(TOL_R, HATCH * sens[3:].max()), (g["X"], ref["X"], sens)
 
 
 def test_scan2_round_trip_option(gpu_ctx, frames):
@@ -1405,22 +1431,22 @@ def _degenerate_scans(name):
     return np.ascontiguousarray(a.T.numpy()), np.ascontiguousarray(b.T.numpy())
 
 
-def _oracle_spread(a, b, ref, trials=3):
+def _oracle_spread(a, b, ref, trials=32):
     """How far the ORACLE's own per-iteration tables move under a 1-ulp perturbation of scan 2 (relative 1e-7): on scenes with millimetre noise the
     thin direction of a voxel's covariance is a few float ulps of the coordinates wide, H^T W H moves by per cents and the SIGN of the pruned
-    eigenvector -- hence of the +-1 added to pred_stds -- can flip (measured, profiles/r05_diag_degenerate.txt)."""
+    eigenvector -- hence of the +-1 added to pred_stds -- can flip (measured, profiles/r05_diag_degenerate.txt).  32 trials on the host's cores
+    (round 6; three were a lower bound of a heavy-tailed spread): maxima, and the 90 % quantile of the H^T W H spread."""
     from oracle import pyoracle as po
+    from concurrent.futures import ThreadPoolExecutor
     t = ref["trace"]
     rng = np.random.default_rng(123)
-    sp = dict(H=0.0, ps=0.0, Xt=0.0, Xr=0.0, pruned_same=True)
-    for _ in range(trials):
-        bp = (b.astype(np.float64) * (1.0 + rng.uniform(-1e-7, 1e-7, b.shape))).astype(np.float32)
-        o2 = po.solve(a, bp, trace=True); t2 = o2["trace"]
-        sp["H"] = max(sp["H"], float((np.abs(t2["HTWH"] - t["HTWH"]).reshape(7, -1).max(1) / np.abs(t["HTWH"]).reshape(7, -1).max(1)).max()))
-        sp["ps"] = max(sp["ps"], float(np.abs(o2["pred_stds"] - ref["pred_stds"]).max()))
-        sp["Xt"] = max(sp["Xt"], float(np.abs(o2["X"][:3] - ref["X"][:3]).max())); sp["Xr"] = max(sp["Xr"], float(np.abs(o2["X"][3:] - ref["X"][3:]).max()))
-        sp["pruned_same"] = sp["pruned_same"] and bool(np.array_equal(t2["pruned"], t["pruned"]))
-    return sp
+    perturbed = [(b.astype(np.float64) * (1.0 + rng.uniform(-1e-7, 1e-7, b.shape))).astype(np.float32) for _ in range(trials)]
+    with ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1))) as ex:          # (the C call releases the GIL)
+        sols = list(ex.map(lambda bp: po.solve(a, bp, trace=True), perturbed))
+    Hs = [float((np.abs(o2["trace"]["HTWH"] - t["HTWH"]).reshape(7, -1).max(1) / np.abs(t["HTWH"]).reshape(7, -1).max(1)).max()) for o2 in sols]
+    return dict(H=max(Hs), H_p90=float(np.quantile(Hs, 0.9)), ps=max(float(np.abs(o2["pred_stds"] - ref["pred_stds"]).max()) for o2 in sols),
+                Xt=max(float(np.abs(o2["X"][:3] - ref["X"][:3]).max()) for o2 in sols), Xr=max(float(np.abs(o2["X"][3:] - ref["X"][3:]).max()) for o2 in sols),
+                pruned_same=all(bool(np.array_equal(o2["trace"]["pruned"], t["pruned"])) for o2 in sols), trials=trials)
 
 
 @pytest.mark.parametrize("name", ["tunnel_s05", "tunnel_s10", "tunnel_s10_m", "wall_s10", "wall_s30", "ground_s02", "ground_s05", "ground_s10_m"])
@@ -1466,7 +1492,20 @@ def test_degenerate_scenes_take_the_pruning_route(gpu_ctx, name):
     dt, dr = float(np.abs(r["X"][:3] - ref["X"][:3]).max()), float(np.abs(r["X"][3:] - ref["X"][3:]).max())
     print("%s: pruned oracle %s device %s | pred_stds oracle %s device %s | dH %.2e (oracle 1-ulp spread %.2e) d pred_stds %.2e (%.2e) |dX| %.2e m %.2e rad (%.2e / %.2e) oracle pruning stable: %s"
           % (name, t["pruned"].tolist(), ci[:, 6].astype(int).tolist(), np.round(ref["pred_stds"], 4).tolist(), np.round(r["pred_stds"], 4).tolist(), dH, sp["H"], dps, sp["ps"], dt, dr, sp["Xt"], sp["Xr"], sp["pruned_same"]))
-    assert dH <= max(2e-3, 5 * sp["H"]), (dH, sp["H"])
+    # (round 6) H^T W H against the unmodified oracle: within 1.5 x the oracle's own 32-trial spread -- or ATTRIBUTED: against the oracle run with the device's
+    # documented arithmetic (ICET_ORACLE_DEVICE_ARITH: no scan-2 round trip, FMA transform, moments about mu1) and the per-voxel weight W = pinv(R_noise) taken in
+    # double as icet_device_math.h pinv3_sym takes it (ICET_ORACLE_PINV3_DOUBLE) most of the difference is gone.  What that says: the reference's float
+    # CompleteOrthogonalDecomposition of a cond 1e6 .. 1e7 voxel carries a relative error of cond x eps -- per cents -- that moves with the last bits of its input;
+    # the device does not reproduce that noise, it inverts in double (wall_s10: 0.14 -> 0.024; ground_s10_m: 0.17 -> 0.07 and pred_stds agree again; ground_s02: 0.034 -> 0.004).
+    attr = po.solve(a, b, trace=True, mode=po.DEVICE_ARITH | po.PINV3_DOUBLE)
+    ta = attr["trace"]
+    dH_attr = float((np.abs(ax["htwh"] - ta["HTWH"]).reshape(7, -1).max(1) / np.abs(ta["HTWH"]).reshape(7, -1).max(1)).max())
+    rep_attr = _replay_each_iteration(gpu_ctx, a, b, attr)
+    print("   %s: dH vs the oracle in device arithmetic + double W: %.2e (unmodified: %.2e; oracle 32-trial spread max %.2e p90 %.2e); replayed from its state: count flips %s dH %s; d pred_stds %.2e"
+          % (name, dH_attr, dH, sp["H"], sp["H_p90"], [f for f, _ in rep_attr], ["%.1e" % h for _, h in rep_attr], float(np.abs(r["pred_stds"] - attr["pred_stds"]).max())))
+    assert max(f for f, _ in rep_attr) == 0, rep_attr                      # one step from the same state: the same decisions
+    assert dH <= max(2e-3, HATCH * sp["H"]) or (dH_attr <= max(2e-3, 0.6 * dH) and dH_attr <= 0.1), (dH, sp["H"], dH_attr)
+    assert float(np.median([h for _, h in rep_attr])) <= 0.05, rep_attr
     cond_o = np.abs(t["eigvals"][:, 5] / t["eigvals"][:, 0])
     straddles = bool(((cond_o > 1e6 / 1.5) & (cond_o < 1.5e6)).any())      # a condition number within the tables' own spread of the cutoff: pruning there is a coin toss on either side
     if straddles and not np.array_equal(ci[:, 6].astype(int), t["pruned"]):
@@ -1489,7 +1528,7 @@ def test_degenerate_scenes_take_the_pruning_route(gpu_ctx, name):
         # an unstable scene: the oracle's own pred_stds moves under the 1-ulp perturbation, and the SIGN of a pruned axis' +-1 (the eigen-solver's last bits) is then a
         # coin toss that three trials may or may not show -- layer (1) above pins it exactly to the device's own matrix; here the magnitudes are compared
         dabs = float(np.abs(np.abs(r["pred_stds"]) - np.abs(ref["pred_stds"])).max())
-        assert dps <= 1.5 * sp["ps"] + 1e-3 or dabs <= 3 * sp["ps"] + 1e-3, (dps, dabs, sp["ps"], r["pred_stds"], ref["pred_stds"])     # (3 x: three trials give a LOWER bound of the spread)
+        assert dps <= HATCH * sp["ps"] + 1e-3 or dabs <= HATCH * sp["ps"] + 1e-3, (dps, dabs, sp["ps"], r["pred_stds"], ref["pred_stds"])
     assert name not in ("tunnel_s10", "tunnel_s10_m", "wall_s30") or sp["ps"] < 1e-3          # these three are the stable ones: the tight branch must be the one that ran
 
 
@@ -1542,14 +1581,15 @@ def test_random_parameter_space(gpu_ctx, seed, with_flags):
     zero and non-zero X0, stretches / strides of the sample scans with their zero rows, 3 k .. 131 k rows; 600 draws over five seeds were run by hand,
     scripts/fuzz_params.py -> profiles/r05_fuzz_params.txt).  In EVERY draw the whole keyframe table is the oracle's bits (NaN covariances of one-point clusters in
     the same places) and so are the first iteration's per-voxel counts (X0 = 0; see param_sweep.run_case for X0 != 0).  The solution: within the parity bound, or within
-    5 x the oracle's own spread under a 1-ulp perturbation of the scans; a draw whose spread exceeds 10 x the parity bound is an ill-posed problem (a handful of voxels,
+    1.5 x the oracle's own spread under a 1-ulp perturbation of the scans; a draw whose spread exceeds 10 x the parity bound is an ill-posed problem (a handful of voxels,
     an axis at the condition cutoff, pruning that comes and goes: the oracle's own answer moves by centimetres, scripts/fuzz_diag.py -> profiles/r05_fuzz_diag.txt) and
-    only its first update is compared.  with_flags: each draw also picks one of the opt-in extensions (ICET_FLAG_TRUE_SORT, _HALF_GAP_BOUNDS, _REJECT_MOVING) or none,
+    only its first update is compared.  (Round 6: the spread is the maximum over 2 x 16 trials and the factor is 1.5, and every draw admitted through it is also REPLAYED
+    iteration by iteration from the oracle's state.)  with_flags: each draw also picks one of the opt-in extensions (ICET_FLAG_TRUE_SORT, _HALF_GAP_BOUNDS, _REJECT_MOVING) or none,
     and is held to that extension's CPU twin."""
     from tests.param_sweep import draw_case, run_case, pools
     rng = np.random.default_rng(seed)
     pl = pools()
-    beyond, ill = [], []
+    beyond, ill, replays = [], [], []
     for c in range(40):
         a, b, T, P, kw, runlen, x0 = draw_case(rng, pl, with_flags=with_flags)
         bits, d, r, ref, fits = run_case(gpu_ctx, a, b, T, P, kw, runlen, x0)
@@ -1559,23 +1599,32 @@ def test_random_parameter_space(gpu_ctx, seed, with_flags):
         assert np.isfinite(r["X"]).all()
         if d[:3].max() > TOL_T or d[3:].max() > TOL_R:
             okw = dict(x0=x0, runlen=runlen, bins_phi=P, bins_theta=T, **okw)
-            sens = np.maximum(oracle_sensitivity(a, b, trials=3, scan1_too=True, **okw), oracle_sensitivity(a, b, trials=3, **okw))
+            sens = np.maximum(oracle_sensitivity(a, b, trials=16, scan1_too=True, **okw), oracle_sensitivity(a, b, trials=16, **okw))
             beyond.append((c, d[:3].max(), d[3:].max(), sens[:3].max(), sens[3:].max()))
             if sens[:3].max() > 10 * TOL_T or sens[3:].max() > 10 * TOL_R:
                 ill.append(c)
                 d0 = np.abs(r["aux"]["x_hist"][0] - ref["trace"]["X"][0])
                 if d0.max() > 1e-3:                                       # (seven used voxels with weights of 1e9: even ONE update moves by a centimetre inside the oracle)
                     o1 = dict(okw, runlen=1)
-                    s0 = np.maximum(oracle_sensitivity(a, b, trials=3, scan1_too=True, **o1), oracle_sensitivity(a, b, trials=3, **o1))
-                    assert d0.max() <= 5 * s0.max(), (c, T, P, kw, d0, s0)
+                    s0 = np.maximum(oracle_sensitivity(a, b, trials=16, scan1_too=True, **o1), oracle_sensitivity(a, b, trials=16, **o1))
+                    assert d0.max() <= HATCH * s0.max(), (c, T, P, kw, d0, s0)
             else:
-                assert d[:3].max() <= max(TOL_T, 5 * sens[:3].max()) and d[3:].max() <= max(TOL_R, 5 * sens[3:].max()), (c, T, P, kw, runlen, d, sens)
+                assert d[:3].max() <= max(TOL_T, HATCH * sens[:3].max()) and d[3:].max() <= max(TOL_R, HATCH * sens[3:].max()), (c, T, P, kw, runlen, d, sens)
+            # (round 6) whoever is admitted through the spread also passes the non-chaotic check: every iteration replayed from the oracle's state takes the
+            # oracle's decisions (with X != 0 the FMA transform may put a point or two per 100 k across an edge) and builds its H^T W H
+            rkw = {k: v for k, v in kw.items() if k != "_twin"}
+            rep = _replay_each_iteration(gpu_ctx, a, b, ref, P=P, T=T, x0=x0, flags=kw.get("_twin", (0, None))[0], **rkw)
+            replays.append((c, max(f for f, _ in rep), max(h for _, h in rep)))
+            assert max(f for f, _ in rep) <= 4, (c, rep)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "parity_param_sweep_%d.txt" % seed), "w") as fh:
             fh.write("# test_random_parameter_space (seed %d, flags %s): 40 draws, keyframe bits equal in all; beyond the parity bound: %d, of them ill-posed: %d\n# case |dX_t| |dX_r| oracle spread t / r\n" % (seed, with_flags, len(beyond), len(ill)))
             for w in beyond:
                 fh.write("%d %.3g %.3g %.3g %.3g\n" % w)
+            fh.write("# replayed from the oracle's state (draws beyond the bound): case, max raw-count differences per iteration, max rel dHTWH\n")
+            for w in replays:
+                fh.write("%d %d %.3g\n" % w)
     assert len(beyond) <= 14 and len(ill) <= 12, (beyond, ill)            # the draws are deliberately extreme
 
 

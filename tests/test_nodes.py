@@ -162,7 +162,7 @@ def test_gpu_odometry_burst_equals_frame_by_frame(gpu_ctx, seq64):
     (the map maker) go frame by frame through the same entry."""
     from icet_amd import api
     dev = torch.device("cuda", 0)
-    seq = seq64 + _sequence(7, rings=64, steps=2048)[4:]              # seven frames of the same drive
+    seq = seq64 + _sequence(12, rings=64, steps=2048)[4:]             # twelve frames of the same drive
     bufs = [torch.from_numpy(np.ascontiguousarray(s.T)).to(dev) for s in seq]
     fr = [(b.data_ptr(), b.shape[1], b.shape[1]) for b in bufs]
     ref_node = api.Node(gpu_ctx, **api.ODOMETRY_NODE)
@@ -171,11 +171,13 @@ def test_gpu_odometry_burst_equals_frame_by_frame(gpu_ctx, seq64):
     ref_node.close()
     def same(a, b):
         return all(np.array_equal(a[k], b[k]) for k in ("X", "pred_stds", "pose", "quat")) and a["solved"] == b["solved"] and a["n_kept"] == b["n_kept"] and a["diverged"] == b["diverged"]
-    for split in ((len(fr),), (1, len(fr) - 1), (2, 1, len(fr) - 3), (1, 2, len(fr) - 3)):
+    # (1, 3, 1, 3, ...) and equal-size bursts right behind a single push: the steady-state path of a burst (its buffers already sized: no device-wide
+    # synchronisation at its start), where the second frame's filter overwrites the scan the last push's keyframe build may still be reading
+    for split in ((len(fr),), (1, len(fr) - 1), (2, 1, len(fr) - 3), (1, 2, len(fr) - 3), (1, 3, 1, 3, 1, len(fr) - 9), (2, 2, 1, 2, 1, 2, len(fr) - 10), (1, 3, 3, 3, len(fr) - 10)):
         nd = api.Node(gpu_ctx, **api.ODOMETRY_NODE)
         got, k = [], 0
         for j, m in enumerate(split):
-            if m == 1 and j % 2 == 1:
+            if m == 1 and (j % 2 == 1 or len(split) > 4):
                 got.append(nd.push_device(*fr[k]))                      # a single push between bursts
             else:
                 got += nd.push_many_device(fr[k:k + m])

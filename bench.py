@@ -61,6 +61,8 @@ def parse(argv=None):
     ap.add_argument("--multi-gather", choices=["peer", "rccl"], default="peer", help="--multi: peer copies (default) or the library's RCCL all-gather")
     ap.add_argument("--min-timed-s", type=float, default=0.5, help="the K timed steps are repeated until the timed region is at least this long")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive sub-record")
+    ap.add_argument("--traffic", choices=["live", "file", "none"], default="live",
+                    help="roofline.traffic: measured by two child runs under rocprofv3 --pmc (each capped at 60 s; falls back to the file), read from profiles/traffic_latest.json, or left null")
     ap.add_argument("--flags", type=int, default=0, help="icet_params.flags for the solves (e.g. 16 = ICET_FLAG_ROUNDTRIP_SCAN2: what the reference's scan-2 round trips cost); echoed in config")
     ap.add_argument("--dry-run-launch", action="store_true", help="print what `--gpus N` would start (JSON) and exit: no GPU, no child")
     return ap.parse_args(argv)
@@ -94,7 +96,15 @@ def plan_launch(args, env):
 
 
 
-def measure_traffic_live(timeout_s=240):
+def _is_elf(path):
+    try:
+        with open(path, "rb") as f:
+            return f.read(4) == b"\x7fELF"
+    except OSError:
+        return False
+
+
+def measure_traffic_live(timeout_s=60):
     """HBM bytes per k_gn_accumulate launch, measured NOW on this box: two child runs of this script under `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE and
     WRITE_SIZE in separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled: on gfx950 it reports half the bytes of a 16-B/lane
     coalesced streaming read), each over the default workload's whole-batch launches.  Returns (bytes, note) or (None, why)."""
@@ -102,11 +112,17 @@ def measure_traffic_live(timeout_s=240):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
+    # The program behind `--` must be the interpreter ITSELF: the profiler's preloaded library has initialised the GPU by then, and a shim or wrapper script
+    # (pyenv, a `#!/usr/bin/env` launcher) would be an exec after that -- not allowed on this pool
+    py = os.path.realpath(sys.executable)
+    if not _is_elf(py):
+        return None, "the interpreter (%s) is not an ELF binary: no live measurement" % py
     vals = {}
     env = dict(os.environ); env["TMPDIR"] = "/tmp"; env["ICET_BENCH_CHILD"] = "1"
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="icet_pmc_", dir="/tmp")
-        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3", os.path.abspath(__file__),
+        # counters for k_gn_accumulate only: with every dispatch of the pair generator profiled a pass took 70 s (round 5: 142 s of the default run's 155 s)
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--kernel-include-regex", "k_gn_accumulate", "--output-format", "csv", "-d", d, "--", py, os.path.abspath(__file__),
                "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-latency", "--no-h2d", "--min-timed-s", "0"]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
@@ -336,7 +352,11 @@ def main(argv=None):
         return (R @ a).contiguous(), (R @ b).contiguous()
     real_cache = {}
 
+    walls = {}; _w = [time.perf_counter(), "startup"]
+    def mark(name):                                                # wall seconds of every phase of this script (what the driver's clock is spent on)
+        t = time.perf_counter(); walls[_w[1]] = round(walls.get(_w[1], 0.0) + t - _w[0], 2); _w[0] = t; _w[1] = name
     # ---- synthetic inputs, generated in HBM ------------------------------------------------------
+    mark("generate")
     t_gen = time.time()
     scans1, scans2 = [], []
     distinct = args.distinct if args.distinct > 0 else len(ids)
@@ -376,6 +396,7 @@ def main(argv=None):
     d1 = [(b.data_ptr(), n, b.shape[1]) for b, n in zip(bufs1, n1)]
     d2 = [(b.data_ptr(), n, b.shape[1]) for b, n in zip(bufs2, n2)]
 
+    mark("warmup_and_timed_region")
     p_plain = api.Params(iters, P, T, 25, 0.1, 0.1, args.flags)
     p_timed = api.Params(iters, P, T, 25, 0.1, 0.1, args.flags | api.FLAG_TIMING)
     out = torch.zeros((len(ids), 48), dtype=torch.float32, device=dev)
@@ -457,6 +478,7 @@ def main(argv=None):
         fence()
         gather_ms = (time.perf_counter() - tg) / 20 * 1e3
 
+    mark("roofline_events")
     # ---- per-kernel timing with HIP events on the solve stream (extra steps, not part of `value`) ----
     acc_ms, kf_ms, gn_ms, launches = 0.0, 0.0, 0.0, 0
     reps = max(3, min(args.steps, 10))
@@ -475,10 +497,12 @@ def main(argv=None):
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     default_workload = args.workload == "batch" and n_local == 256 and args.distinct == 0 and not args.set and not args.flags and args.order == "ring"
     under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)      # no profiler inside a profiled run
-    if default_workload and rank == 0 and n_gpus == 1 and not args.no_latency and not os.environ.get("ICET_BENCH_CHILD") and not under_profiler:
+    if args.traffic == "live" and default_workload and rank == 0 and n_gpus == 1 and not args.no_latency and not os.environ.get("ICET_BENCH_CHILD") and not under_profiler:
         # measured live (review r4, weak 9: the number used to come from a file a builder-side profile run had left behind)
+        mark("traffic_live")
         traffic, traffic_note = measure_traffic_live()
-    if traffic is None and os.path.exists(tpath) and args.workload == "batch" and n_local == 256 and args.distinct == 0:
+        mark("roofline_events")
+    if traffic is None and args.traffic != "none" and os.path.exists(tpath) and args.workload == "batch" and n_local == 256 and args.distinct == 0:
         # fallback: the PMC numbers profiles/collect.sh collected on exactly this workload (256 distinct pairs per GPU)
         try:
             traffic = json.load(open(tpath)).get("k_gn_accumulate_bytes_per_launch")
@@ -486,6 +510,7 @@ def main(argv=None):
         except Exception:
             traffic = None
 
+    mark("other_storage_order")
     # ---- the other storage order (BASELINE configs[1] names both): the SAME points stored azimuth-major (azimuth step slow, ring fast -- the
     # firing order of a spinning lidar) when the headline is ring-major, and the other way round.  Neighbouring lanes of k_gn_accumulate then
     # hold points of DIFFERENT voxels (rings 7.5 degrees of polar angle apart), i.e. shorter runs per lane and more LDS adds.  The reference's result
@@ -526,6 +551,7 @@ def main(argv=None):
                     "keyframe_ms_per_step": round(a_kf / 3, 4), "gn_loop_ms_per_step": round(a_gn / 3, 4), "all_finite": bool(torch.isfinite(out_az).all().item())}
         del a1, a2
 
+    mark("sample_batch")
     # ---- throughput on REAL lidar data (review r4, item 4): 256 pairs made from the reference's two sample pairs (real_pair above), ONE
     # icet_solve_batch_device call per step.  Real scans differ from the synthetic ones where it hurts: thousands of exact-zero rows that share one key and
     # one voxel, a near field that puts tens of thousands of rows into a few bins, half the rows in a third of the voxels.
@@ -564,6 +590,7 @@ def main(argv=None):
         del r1, r2, rp
 
     one_ctx = ctx if not multi else icet_amd.Context(dev_ids[0], stream=stream.cuda_stream)
+    mark("latency")
     # ---- single-pair latency (configs[1]) on rank 0's first pair -----------------------------------
     lat = None
     if args.workload == "batch" and not args.no_latency:
@@ -589,6 +616,7 @@ def main(argv=None):
                "keyframe_ms": round(lt["keyframe_ms"], 4), "gn_loop_ms": round(lt["gn_loop_ms"], 4), "accumulate_avg_launch_ms": round(l_acc, 5),
                "whole_path_GBs": round((12.0 * n1[0] + 12.0 * n2[0] * iters + 192.0) / (lat_ms * 1e-3) / 1e9, 1)}
 
+    mark("highres")
     # ---- configs[4] (high-resolution sweep) as a sub-record of the default line: one 128-channel pair, 150 x 48 voxels, 10 iterations ----
     hires = None
     if args.workload == "batch" and not args.no_latency and rank == 0:
@@ -620,6 +648,7 @@ def main(argv=None):
                  "whole_path_GBs": round(h_bytes / (h_ms * 1e-3) / 1e9, 1)}
         del hb1, hb2, h1, h2
 
+    mark("h2d_inclusive")
     # ---- PCIe-inclusive ("reported both with and without H2D"): 64 pairs through icet_solve_batch, host pointers in,
     # host results out -- from pageable numpy arrays and from pinned torch tensors.  Never `value`. ----
     h2d = None
@@ -658,6 +687,7 @@ def main(argv=None):
                        "scan 2s are uploaded on a copy stream beside the keyframe build"}
         hctx.close()
 
+    mark("ctor")
     # ---- the constructor path (what src/odometry.cpp:73-79 pays per frame): ONE 64-ch pair from PAGEABLE host memory through icet_solve with the
     # side tables include/icet.h asks for, and the same through the compiled adapter (tests/cpp/adapter_demo.cpp against the Eigen-API mock) ----
     ctor = None
@@ -723,6 +753,7 @@ def main(argv=None):
             ctor["adapter_class_ICET_ms"] = None; ctor["adapter_note"] = "adapter_demo not run: %s" % type(e).__name__
         cctx.close()
 
+    mark("cpu_baseline")
     # ---- CPU baseline: the oracle ("port") on this box's host cores, bounded sample, rank 0 at N=1 -----
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
@@ -781,6 +812,7 @@ def main(argv=None):
                "pairs_over_1e-4_m_or_1e-5_rad_natural_signs": int(over1.size), "pairs_over_3e-4_m_or_1e-4_rad_natural_signs": int(over3.size),
                "pair_ids_over_3e-4_m_or_1e-4_rad": [int(k) for k in over3], "vs_literal_mode": vs_literal}
 
+    mark("sample")
     # ---- configs[0] with a number, and the first non-synthetic figures: the reference's own sample pairs (src/sample_data/frame_804/805.npy,
     # python/point_clouds/sample_pc_1/2.npy, committed as float32 fixtures) through the GPU path and through the oracle on the host (literal mode:
     # serial loop = the live path of src/icet.cpp:391-404, and the 4-worker ThreadPool structure of :346-370), as src/icet_cpp_demo.cpp:25-45 runs them ----
@@ -821,6 +853,7 @@ def main(argv=None):
                                      "bits_equal_resident_and_host_path": bool(np.array_equal(so[0, :6].cpu().numpy(), r["X"]))}
         sctx.close()
 
+    mark("end")
     if rank == 0:
         line = {
             "metric": "scan-pairs/sec + ms/pair, 64-ch 75x24 voxels 7 iters; HBM GB/s vs peak" if args.workload in ("batch", "sample") else "scan-pairs/sec, 128-ch 150x48 voxels 10 iters",
@@ -847,6 +880,7 @@ def main(argv=None):
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(acc_launch_ms, 5), "launches_timed": launches,
                          "whole_path_GBs": round(bytes_path / (ms_per_step * 1e-3) / 1e9, 1),
+                         "whole_path_frac": round(bytes_path / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4),      # B_pair x pairs / t / peak (frac above is the dominant kernel alone)
                          "keyframe_ms_per_step": round(kf_ms / reps, 4), "gn_loop_ms_per_step": round(gn_ms / reps, 4)},
             "cpu_baseline": cpu,
             "latency": lat,
@@ -857,11 +891,20 @@ def main(argv=None):
             "ctor": ctor,
             "sample": sample,
             "published_reference_ms_per_pair": PUBLISHED_MS_PER_PAIR,
+            "wall_s_by_phase": walls,
         }
         print(json.dumps(line), flush=True)
+    # `--gpus N` measures N ranks gathering over RCCL or says loudly that it did not: a line whose gather fell back to gloo is printed (for the record) and the run FAILS
+    # (review r5, next 7).  Only the explicit rehearsal switch ICET_BENCH_BACKEND=gloo (N ranks on one card) is exempt.
+    rccl_missing = world > 1 and not multi and backend != "nccl" and os.environ.get("ICET_BENCH_BACKEND", "nccl") == "nccl"
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rccl_missing:
+        sys.stderr.write("bench.py: --gpus %d asked for one rank per GPU over RCCL, but the gather ran on gloo (%s): exit code 3\n" % (args.gpus, collective_note))
+        if multi: one_ctx.close(); mctx.close()
+        else: ctx.close()
+        return 3
     if multi:
         one_ctx.close(); mctx.close()
     else:

@@ -21,11 +21,12 @@ FLAG_TIMING = 1
 FLAG_TRUE_SORT = 2      # non-parity extension, see include/icet_hip.h
 FLAG_REJECT_MOVING = 4  # non-parity extension (moving-object rejection of the Python variant), see include/icet_hip.h
 FLAG_ROUNDTRIP_SCAN2 = 16  # parity-study option: the reference's two spherical round trips of scan 2 (see include/icet_hip.h)
+FLAG_DOUBLE_W = 32         # accuracy option: per-voxel W in double instead of the reference's float COD (see include/icet_hip.h)
 FLAG_HALF_GAP_BOUNDS = 8  # non-parity extension (half-gap cluster buffers of the Python variant; implies TRUE_SORT), see include/icet_hip.h
 
 # every symbol include/icet_hip.h, include/icet_nodes.h and include/icet_io.h declare
 EXPORTED_SYMBOLS = ("icet_create", "icet_destroy", "icet_last_error", "icet_version", "icet_solve", "icet_solve_begin", "icet_solve_keyframe_tables", "icet_solve_end", "icet_solve_batch",
-                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_last_timing_iters", "icet_keep_stats", "icet_debug_fetch", "icet_debug_gn_tail", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_keyframe_device_n", "icet_register_device_n", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
+                    "icet_solve_batch_device", "icet_sync", "icet_reserve", "icet_last_timing", "icet_last_timing_iters", "icet_keep_stats", "icet_debug_fetch", "icet_debug_gn_tail", "icet_debug_pinv3", "icet_set_option", "icet_keyframe_device", "icet_register_device", "icet_keyframe_device_n", "icet_register_device_n", "icet_multi_create", "icet_multi_destroy", "icet_multi_last_error", "icet_multi_devices", "icet_multi_context",
                     "icet_multi_solve_batch", "icet_multi_solve_batch_device", "icet_multi_solve_batch_device_after", "icet_multi_solve_batch_device_async", "icet_multi_sync", "icet_multi_set_option",
                     "icet_node_create", "icet_node_destroy", "icet_node_last_error", "icet_node_push", "icet_node_push_device", "icet_node_push_many_device", "icet_node_map",
                     "icet_node_prev_scan", "icet_node_aligned", "icet_node_snail_trail", "icet_node_last_timing", "icet_stream", "icet_device",
@@ -102,6 +103,7 @@ def load_library():
     L.icet_debug_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
     L.icet_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.icet_debug_gn_tail.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.icet_debug_pinv3.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.icet_keyframe_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan)]
     L.icet_register_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.c_void_p, C.c_void_p]
     L.icet_keyframe_device_n.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int32, C.POINTER(DevScan), C.c_void_p]
@@ -241,6 +243,13 @@ class Context:
         out = np.zeros((n_pairs, 4), np.int32)
         self._check(load_library().icet_keep_stats(self._h, n_pairs, out.ctypes.data))
         return out
+
+    def debug_pinv3(self, mats):
+        """icet_debug_pinv3 (test hook): the 3 x 3 float COD pseudo-inverse of ICET_FLAG_REFERENCE_W on the device for n matrices (n, 3, 3) -> (n, 3, 3)."""
+        A = np.ascontiguousarray(mats, np.float32).reshape(-1, 9)
+        out = np.zeros_like(A)
+        self._check(load_library().icet_debug_pinv3(self._h, A.ctypes.data, A.shape[0], out.ctypes.data))
+        return out.reshape(-1, 3, 3)
 
     def debug_gn_tail(self, htwh, htwdz):
         """icet_debug_gn_tail (test hook): the 6x6 tail of an iteration on the device for n (HTWH, HTWdz).  Returns dict of arrays with leading dimension n:

@@ -665,7 +665,7 @@ __global__ __launch_bounds__(kAccBlock, 2) void k_gn_accumulate_solve(const Pair
     if (!s_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const NearOverflow over{desc, slot_of_voxel, hotS, thr, near_over, near_over_count, T, P, 0};
-    gn_solve_body<256, 0, kAccBlock>(n_slots, sf.fitS, acc, sf.X, xf_all, sf.out, sf.aux, T * P, sf.n, sf.iter, sf.runlen, over, sf.reject_moving, nullptr, 1, sf.cond_bound2, KeepArgs{}, pair);
+    gn_solve_body<256, 0, kAccBlock, true>(n_slots, sf.fitS, acc, sf.X, xf_all, sf.out, sf.aux, T * P, sf.n, sf.iter, sf.runlen, over, sf.reject_moving, nullptr, 1, sf.cond_bound2, KeepArgs{}, pair);      // (the default W; ICET_FLAG_DOUBLE_W is not fused)
 }
 
 inline int chunks_for(int n_pairs, int max_n, int per_block_min, int target_blocks) {
@@ -737,7 +737,7 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
     const size_t row = acc_row_lds_bytes();
     // the fused form (k_gn_accumulate_solve): small batch, one-block solve (grids up to 4096 voxels: launch_gn_solve), no scan-2 round trip
     // (... and a grid whose tables leave the fused kernel -- 12 KB less dynamic LDS: its solve half has static tables -- fewer than the 32 slot rows every launch keeps)
-    const bool fuse_it = fuse && c.fuse_solve && near_cap == kNearCapSmall && c.V <= 4096 && !c.rt2 && w.gn_done() && fixed + 32 * row <= (size_t)148 * 1024;
+    const bool fuse_it = fuse && c.fuse_solve && near_cap == kNearCapSmall && c.V <= 4096 && !c.rt2 && c.ref_w && w.gn_done() && fixed + 32 * row <= (size_t)148 * 1024;
     const size_t budget = (c.n_pairs >= 32) ? fixed + 320 * row : (fuse_it ? 144 : 156) * 1024;   // 320 rows: ~46 KB/block for 75 x 24, three blocks per CU; a small batch: one block per CU, nearly all of its LDS (the fused kernel's solve half has ~6 KB of static tables)
     int lds_slots = c.lds_slots > 0 ? c.lds_slots : (int)((budget > fixed ? budget - fixed : 0) / row);
     lds_slots = lds_slots < 32 ? 32 : lds_slots;

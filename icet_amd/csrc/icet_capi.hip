@@ -388,6 +388,7 @@ LaunchCfg make_cfg(icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     cfg.true_sort = (p->flags & (ICET_FLAG_TRUE_SORT | ICET_FLAG_HALF_GAP_BOUNDS)) ? 1 : 0;
     cfg.reject_moving = (p->flags & ICET_FLAG_REJECT_MOVING) ? 1 : 0;
     cfg.rt2 = (p->flags & ICET_FLAG_ROUNDTRIP_SCAN2) ? 1 : 0;
+    cfg.ref_w = (p->flags & ICET_FLAG_DOUBLE_W) ? 0 : 1;
     cfg.lds_slots = c->tune.lds_slots; cfg.acc_min_pts_per_thread = c->tune.acc_pts; cfg.acc_target_blocks = c->tune.acc_blocks;
     cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds; cfg.exec_pairwise = c->tune.exec_pairwise; cfg.fuse_solve = c->tune.fuse_solve != 0 ? 1 : 0; cfg.lds_rank = (c->tune.lds_rank != 0 && c->lds_rank_ok) ? 1 : 0;
     cfg.gn_cond_bound2 = (float)(c->tune.gn_cond_bound * c->tune.gn_cond_bound);
@@ -762,7 +763,7 @@ static icet_ctx::GraphKey graph_key_of(icet_ctx* c, const icet_params* p, int32_
     auto bits = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return (int64_t)i; };
     const int64_t vals[] = {k.T, k.P, k.V, k.n, k.runlen, bits(k.thresh), bits(k.buff), k.n_pairs, k.max_n1, k.max_n2, k.total_n1, k.lds_slots, k.acc_min_pts_per_thread,
                             k.acc_target_blocks, k.kf_chunks, k.kf_pts_per_thread, k.use_library_sort, k.vec4_ok, k.true_sort, k.force_exact, k.rs_cap, k.rs_max_cell,
-                            k.exec_bits_lds, k.exec_pairwise, k.lds_rank, k.reject_moving, k.half_gap, k.rt2, p->flags, (int64_t)(intptr_t)a0, (int64_t)(intptr_t)a1, (int64_t)(intptr_t)a2, (int64_t)(intptr_t)a3,
+                            k.exec_bits_lds, k.exec_pairwise, k.lds_rank, k.reject_moving, k.half_gap, k.rt2 + 2 * k.ref_w, p->flags, (int64_t)(intptr_t)a0, (int64_t)(intptr_t)a1, (int64_t)(intptr_t)a2, (int64_t)(intptr_t)a3,
                             (int64_t)(intptr_t)c->w.desc, (int64_t)(intptr_t)c->w.thr, (int64_t)(intptr_t)c->w.lut, (int64_t)(intptr_t)c->w.r1, (int64_t)(intptr_t)c->w.counts,
                             (int64_t)(intptr_t)c->w.near_over, (int64_t)(intptr_t)c->w.acc, (int64_t)(intptr_t)c->w.fit_items, (int64_t)(intptr_t)c->w.sort_tmp, (int64_t)(intptr_t)c->w.tile_vr};
     static_assert(sizeof(vals) == sizeof(key.v), "GraphKey size");
@@ -1210,6 +1211,22 @@ icet_status icet_debug_gn_tail(icet_ctx* c, const float* htwh, const float* htwd
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) { c->err = std::string("icet_debug_gn_tail: ") + hipGetErrorString(e); return ICET_ERR_HIP; }
+    return ICET_OK;
+}
+
+// Test hook: the per-voxel weight's pseudo-inverse under ICET_FLAG_REFERENCE_W (src/icet.cpp:320-321) on n host-side 3 x 3 matrices, through the device function the solve runs.
+icet_status icet_debug_pinv3(icet_ctx* c, const float* a, int32_t n, float* out) {
+    if (!c || !a || !out || n < 0) return ICET_ERR_BAD_ARG;
+    if (n == 0) return ICET_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    float* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), sizeof(float) * (size_t)n * 18));
+    hipError_t e = hipMemcpyAsync(d, a, sizeof(float) * (size_t)n * 9, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_pinv3_debug(d, d + (size_t)n * 9, n, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + (size_t)n * 9, sizeof(float) * (size_t)n * 9, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { c->err = std::string("icet_debug_pinv3: ") + hipGetErrorString(e); return ICET_ERR_HIP; }
     return ICET_OK;
 }
 

@@ -345,6 +345,154 @@ __device__ inline void pinv3_sym_fast(const float a[6], float rel_tol, float w[6
     pinv3_sym<double>(a, rel_tol, w);
 }
 
+// CompleteOrthogonalDecomposition<MatrixXf>(A).pseudoInverse() of ONE 3 x 3 per lane (row-major in, row-major out): the reference's arithmetic for the per-voxel
+// weight W = pinv(L U^T R_noise U L^T) (src/icet.cpp:320-321).  Eigen 3.3's algorithm as the CPU restatement states it (column-pivoted Householder QR with norm
+// down-dating, rank = pivots above 3 eps x the largest among the non-zero pivots, minimum-norm completion of a rank-deficient R in double), plain IEEE float, no
+// contraction, every operation in the restatement's order -- bit-identical to it on the same matrix (tests/test_gpu_parity.py::test_pinv3_reference_bits).
+// Written on REGISTERS: every index is a compile-time constant (a column exchange is a pair of selects per entry, a loop up to the run-time rank is unrolled
+// under guards), because k_gn_solve has no scratch memory to spare -- a first version with local arrays cost each solve launch 35 us.
+struct Col3 { float x, y, z; };
+__device__ __forceinline__ void swap_if(bool c, float& a, float& b) { const float t = a; a = c ? b : a; b = c ? t : b; }
+__device__ __forceinline__ void swap_if(bool c, int& a, int& b) { const int t = a; a = c ? b : a; b = c ? t : b; }
+__device__ __forceinline__ void swap_if(bool c, Col3& a, Col3& b) { swap_if(c, a.x, b.x); swap_if(c, a.y, b.y); swap_if(c, a.z, b.z); }
+__device__ inline void cod_pinv3_lane(const float Ain[9], float pinv[9]) {
+#pragma clang fp contract(off)
+    // columns of the working matrix (row i of column k = qr(i, k))
+    Col3 c0{Ain[0], Ain[3], Ain[6]}, c1{Ain[1], Ain[4], Ain[7]}, c2{Ain[2], Ain[5], Ain[8]};
+    auto norm3 = [](const Col3& c) { float s = 0.f; s += c.x * c.x; s += c.y * c.y; s += c.z * c.z; return sqrtf(s); };
+    float nd0 = norm3(c0), nd1 = norm3(c1), nd2 = norm3(c2), nu0 = nd0, nu1 = nd1, nu2 = nd2;
+    int p0 = 0, p1 = 1, p2 = 2;
+    float maxn = 0.f; maxn = fmaxf(maxn, nu0); maxn = fmaxf(maxn, nu1); maxn = fmaxf(maxn, nu2);
+    const float th = maxn * FLT_EPSILON; const float threshold_helper = (th * th) / 3.f;
+    const float ndt = 3.4526698300124393e-04f;                                               // sqrt(FLT_EPSILON), correctly rounded
+    int nonzero_pivots = 3; float maxpivot = 0.f;
+    auto downdate = [&](float rkj, float& nu, float& nd, float tail_sq_below) {             // norm down-dating of one column behind step k
+        if (nu != 0.f) {
+            float temp = fabsf(rkj) / nu;
+            temp = (1.f + temp) * (1.f - temp);
+            temp = temp < 0.f ? 0.f : temp;
+            const float ratio = nu / nd;
+            const float temp2 = temp * ratio * ratio;
+            if (temp2 <= ndt) { nd = sqrtf(tail_sq_below); nu = nd; } else nu *= sqrtf(temp);
+        }
+    };
+    // ---- k = 0 ----
+    {
+        int big = 0; float bn = nu0;
+        if (nu1 > bn) { bn = nu1; big = 1; }
+        if (nu2 > bn) { bn = nu2; big = 2; }
+        if (bn * bn < threshold_helper * 3.f) nonzero_pivots = 0;
+        swap_if(big == 1, c0, c1); swap_if(big == 1, nu0, nu1); swap_if(big == 1, nd0, nd1); swap_if(big == 1, p0, p1);
+        swap_if(big == 2, c0, c2); swap_if(big == 2, nu0, nu2); swap_if(big == 2, nd0, nd2); swap_if(big == 2, p0, p2);
+    }
+    float tau0, tau1, tau2;
+    {
+        float tailSq = 0.f; tailSq += c0.y * c0.y; tailSq += c0.z * c0.z;
+        const float h = c0.x; float beta;
+        if (tailSq <= FLT_MIN) { tau0 = 0.f; beta = h; c0.y = 0.f; c0.z = 0.f; }
+        else { beta = sqrtf(h * h + tailSq); if (h >= 0.f) beta = -beta; c0.y = c0.y / (h - beta); c0.z = c0.z / (h - beta); tau0 = (beta - h) / beta; }
+        c0.x = beta;
+        if (fabsf(beta) > maxpivot) maxpivot = fabsf(beta);
+        auto apply = [&](Col3& c) { float sd = c.x; sd += c0.y * c.y; sd += c0.z * c.z; sd *= tau0; c.x -= sd; c.y -= sd * c0.y; c.z -= sd * c0.z; };
+        apply(c1); apply(c2);
+        { float t = 0.f; t += c1.y * c1.y; t += c1.z * c1.z; downdate(c1.x, nu1, nd1, t); }
+        { float t = 0.f; t += c2.y * c2.y; t += c2.z * c2.z; downdate(c2.x, nu2, nd2, t); }
+    }
+    // ---- k = 1 ----
+    {
+        int big = 1; float bn = nu1;
+        if (nu2 > bn) { bn = nu2; big = 2; }
+        if (nonzero_pivots == 3 && bn * bn < threshold_helper * 2.f) nonzero_pivots = 1;
+        swap_if(big == 2, c1, c2); swap_if(big == 2, nu1, nu2); swap_if(big == 2, nd1, nd2); swap_if(big == 2, p1, p2);
+        float tailSq = 0.f; tailSq += c1.z * c1.z;
+        const float h = c1.y; float beta;
+        if (tailSq <= FLT_MIN) { tau1 = 0.f; beta = h; c1.z = 0.f; }
+        else { beta = sqrtf(h * h + tailSq); if (h >= 0.f) beta = -beta; c1.z = c1.z / (h - beta); tau1 = (beta - h) / beta; }
+        c1.y = beta;
+        if (fabsf(beta) > maxpivot) maxpivot = fabsf(beta);
+        { float sd = c2.y; sd += c1.z * c2.z; sd *= tau1; c2.y -= sd; c2.z -= sd * c1.z; }
+        { float t = 0.f; t += c2.z * c2.z; downdate(c2.y, nu2, nd2, t); }
+    }
+    // ---- k = 2 ----
+    {
+        if (nonzero_pivots == 3 && nu2 * nu2 < threshold_helper * 1.f) nonzero_pivots = 2;
+        const float h = c2.z;                                        // (no tail: tailSq = 0 <= FLT_MIN)
+        tau2 = 0.f;
+        if (fabsf(h) > maxpivot) maxpivot = fabsf(h);
+    }
+    const float premult = fabsf(maxpivot) * (FLT_EPSILON * 3.f);
+    int rank = 0;
+    rank += (0 < nonzero_pivots && fabsf(c0.x) > premult) ? 1 : 0;
+    rank += (1 < nonzero_pivots && fabsf(c1.y) > premult) ? 1 : 0;
+    rank += (2 < nonzero_pivots && fabsf(c2.z) > premult) ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) pinv[k] = 0.f;
+    if (rank == 0) return;
+    // R (upper triangle) and the reflectors' essential parts
+    const float r00 = c0.x, r01 = c1.x, r02 = c2.x, r11 = c1.y, r12 = c2.y, r22 = c2.z;
+    const float v10 = c0.y, v20 = c0.z, v21 = c1.z;
+    // C = Q^T restricted to the first `rank` reflectors, applied to I: rows C0, C1, C2 (each a row vector over j)
+    float C0[3] = {1.f, 0.f, 0.f}, C1[3] = {0.f, 1.f, 0.f}, C2[3] = {0.f, 0.f, 1.f};
+#pragma unroll
+    for (int j = 0; j < 3; j++) { float sd = C0[j]; sd += v10 * C1[j]; sd += v20 * C2[j]; sd *= tau0; C0[j] -= sd; C1[j] -= sd * v10; C2[j] -= sd * v20; }
+    if (rank > 1) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) { float sd = C1[j]; sd += v21 * C2[j]; sd *= tau1; C1[j] -= sd; C2[j] -= sd * v21; }
+    }
+    if (rank > 2) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) { float sd = C2[j]; sd *= tau2; C2[j] -= sd; }
+    }
+    float Y0[3], Y1[3], Y2[3];
+    if (rank == 3) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            Y2[j] = C2[j] / r22;
+            { float sv = C1[j]; sv -= r12 * Y2[j]; Y1[j] = sv / r11; }
+            { float sv = C0[j]; sv -= r01 * Y1[j]; sv -= r02 * Y2[j]; Y0[j] = sv / r00; }
+        }
+    } else {
+        // X = [R11 R12] (rank x 3); X^+ = X^T (X X^T)^-1; Y = X^+ C(0:rank, :), in double
+        const double x00 = r00, x01 = r01, x02 = r02, x11 = r11, x12 = r12;
+        double gi00, gi01 = 0.0, gi10 = 0.0, gi11 = 0.0;
+        if (rank == 1) {
+            double g = 0; g += x00 * x00; g += x01 * x01; g += x02 * x02;
+            gi00 = 1.0 / g;
+        } else {
+            double g00 = 0, g01 = 0, g10 = 0, g11 = 0;
+            g00 += x00 * x00; g00 += x01 * x01; g00 += x02 * x02;
+            g01 += x00 * 0.0; g01 += x01 * x11; g01 += x02 * x12;
+            g10 += 0.0 * x00; g10 += x11 * x01; g10 += x12 * x02;
+            g11 += 0.0 * 0.0; g11 += x11 * x11; g11 += x12 * x12;
+            double a00 = g00, a01 = g01, a10 = g10, a11 = g11, b00 = 1.0, b01 = 0.0, b10 = 0.0, b11 = 1.0;
+            // Gauss-Jordan with partial pivoting, as the restatement does it
+            if (fabs(a10) > fabs(a00)) { double t; t = a00; a00 = a10; a10 = t; t = a01; a01 = a11; a11 = t; t = b00; b00 = b10; b10 = t; t = b01; b01 = b11; b11 = t; }
+            { const double dd = a00; a00 /= dd; a01 /= dd; b00 /= dd; b01 /= dd; }
+            { const double f = a10; a10 -= f * a00; a11 -= f * a01; b10 -= f * b00; b11 -= f * b01; }
+            { const double dd = a11; a10 /= dd; a11 /= dd; b10 /= dd; b11 /= dd; }
+            { const double f = a01; a00 -= f * a10; a01 -= f * a11; b00 -= f * b10; b01 -= f * b11; }
+            gi00 = b00; gi01 = b01; gi10 = b10; gi11 = b11;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            // w_i = sum_m Ginv(i, m) C(m, j);  Y(t, j) = sum_i X(i, t) w_i
+            double w0 = 0, w1 = 0;
+            w0 += gi00 * (double)C0[j]; if (rank > 1) w0 += gi01 * (double)C1[j];
+            if (rank > 1) { w1 += gi10 * (double)C0[j]; w1 += gi11 * (double)C1[j]; }
+            double y0 = 0, y1 = 0, y2 = 0;
+            y0 += x00 * w0; if (rank > 1) y0 += 0.0 * w1;
+            y1 += x01 * w0; if (rank > 1) y1 += x11 * w1;
+            y2 += x02 * w0; if (rank > 1) y2 += x12 * w1;
+            Y0[j] = (float)y0; Y1[j] = (float)y1; Y2[j] = (float)y2;
+        }
+    }
+    // pinv(perm[k], j) = Y(k, j)
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) pinv[r * 3 + j] = (p0 == r) ? Y0[j] : ((p1 == r) ? Y1[j] : Y2[j]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The LITERAL 6x6 tail of one Gauss-Newton iteration (/root/reference/src/icet.cpp:410-430), for matrices the Cholesky route of
 // k_gn_solve cannot prove well conditioned: noise_mat = CompleteOrthogonalDecomposition(HTWH).pseudoInverse() (:410-411), pred_stds

@@ -210,6 +210,7 @@ struct LaunchCfg {
     int reject_moving = 0;            // ICET_FLAG_REJECT_MOVING (non-parity extension)
     int half_gap = 0;                 // ICET_FLAG_HALF_GAP_BOUNDS (non-parity extension; sets true_sort as well)
     int rt2 = 0;                      // ICET_FLAG_ROUNDTRIP_SCAN2 (parity-study option)
+    int ref_w = 1;                    // per-voxel W by the reference's float COD (default); 0: ICET_FLAG_DOUBLE_W, in double with an eigenvalue rank rule
     int lds_rank = 0;                 // Tuning::lds_rank, resolved against the context's self-test
     int keep = 0, keep_from = 1;      // Tuning::keep resolved for this launch (batch size, flags), Tuning::keep_from
     float keep_bt = 0.f, keep_br = 0.f, keep_check_scale = 1.f;   // Tuning::keep_budget_t / _r / keep_check_scale
@@ -225,6 +226,7 @@ hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float
 // keep_pass: the point pass in front of this solve was launched with keep_pass (below): build the list of every pair that walked its whole scan, check every pair's budgets
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st, int keep_pass = 0);
 hipError_t launch_gn_tail_debug(const float* d_H, const float* d_g, float* d_out, int n, float bound2, hipStream_t st);     // test hook: the 6x6 tail on its own
+hipError_t launch_pinv3_debug(const float* d_A, float* d_out, int n, hipStream_t st);                                        // test hook: the 3x3 float COD pseudo-inverse of ICET_FLAG_REFERENCE_W
 // `points2` of pair 0 (include/icet.h:80): scan 2 under the transform record `xf` (AuxDev::xf_last); out = n2 x 3 column-major, ld n2 (may be pinned host memory)
 hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* xf, float* out, hipStream_t st);
 // icet_accumulate.hip

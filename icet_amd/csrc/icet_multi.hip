@@ -27,44 +27,11 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include "icet_multi_sched.h"
 
 namespace {
 
-// One persistent host thread per device entry with a FIFO of jobs: post() appends, wait() blocks until the queue has drained.
-struct Worker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<std::function<void()>> jobs;
-    bool quit = false, busy = false;
-    void loop() {
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            cv.wait(lk, [&] { return !jobs.empty() || quit; });
-            if (jobs.empty() && quit) return;
-            std::function<void()> j = std::move(jobs.front());
-            jobs.pop_front(); busy = true;
-            lk.unlock();
-            j();                                   // jobs catch their own exceptions (nothing may escape a thread)
-            lk.lock();
-            busy = false;
-            cv.notify_all();
-        }
-    }
-    void post(std::function<void()> j) {
-        std::lock_guard<std::mutex> lk(mu);
-        jobs.push_back(std::move(j));
-        cv.notify_all();
-    }
-    void wait() {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return jobs.empty() && !busy; });
-    }
-    void stop() {
-        { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); }
-        if (th.joinable()) th.join();
-    }
-};
+using icet_sched::Worker;      // one persistent host thread per device entry with a FIFO of jobs, and the two-phase protocol of a call: icet_multi_sched.h
 
 // The handful of RCCL entry points the gather needs, resolved from librccl.so.1 on first use.
 struct Rccl {
@@ -94,7 +61,7 @@ struct icet_multi {
     std::vector<icet_ctx*> ctx;
     std::vector<float*> d_part;          // per device: results of its pairs (device-resident entry), cap x 48, then cap x 6 of X0
     std::vector<int32_t> cap_part;
-    std::vector<Worker*> workers;
+    icet_sched::Sched sched;             // the device threads and the record of their failures (icet_multi_sched.h)
     hipEvent_t ev_producer = nullptr;    // recorded on the caller's stream (device_ids[0]); every device's stream waits for it
     int gather_mode = 0;                 // 0 peer copies, 1 RCCL all-gather
     Rccl rccl;
@@ -103,9 +70,7 @@ struct icet_multi {
     std::vector<int32_t> cap_full;
     // asynchronous calls: the first failure of every device since the last icet_multi_sync, and one event per device recorded behind
     // the last gather it enqueued
-    std::vector<icet_status> st; std::vector<std::string> herr; std::vector<hipEvent_t> ev_done;
-    std::mutex st_mu;
-    bool pending = false;
+    std::vector<hipEvent_t> ev_done;
     std::string err;
 };
 
@@ -117,9 +82,7 @@ void set_err(icet_multi* m, int d, icet_ctx* c, const char* what) {
 
 // run fn(d) on every device's worker and wait for all of them
 template <typename F> void run_all(icet_multi* m, F fn) {
-    const int D = (int)m->dev.size();
-    for (int d = 0; d < D; d++) m->workers[d]->post([fn, d]() { fn(d); });
-    for (int d = 0; d < D; d++) m->workers[d]->wait();
+    m->sched.run_all(fn);
 }
 
 bool ids_distinct(const icet_multi* m) {
@@ -161,14 +124,9 @@ icet_status icet_multi_create(icet_multi** out, const int32_t* device_ids, int32
         m->dev.assign(device_ids, device_ids + n_devices);
         m->ctx.assign(n_devices, nullptr); m->d_part.assign(n_devices, nullptr); m->cap_part.assign(n_devices, 0);
         m->d_full.assign(n_devices, nullptr); m->cap_full.assign(n_devices, 0);
-        m->st.assign(n_devices, ICET_OK); m->herr.assign(n_devices, std::string()); m->ev_done.assign(n_devices, nullptr);
-        m->workers.reserve(n_devices);
-        for (int i = 0; i < n_devices; i++) {
-            Worker* w = new Worker();
-            m->workers.push_back(w);                               // reserved above: cannot throw
-            w->th = std::thread([w]() { w->loop(); });             // std::system_error -> caught below; icet_multi_destroy joins the ones that started
-        }
+        m->ev_done.assign(n_devices, nullptr);
     } catch (...) { icet_multi_destroy(m); return ICET_ERR_NOMEM; }
+    if (!m->sched.start(n_devices)) { icet_multi_destroy(m); return ICET_ERR_NOMEM; }      // (std::system_error / bad_alloc: the threads that started have been joined)
     for (int i = 0; i < n_devices; i++) {
         icet_status s = icet_create(&m->ctx[i], device_ids[i], nullptr);
         if (s != ICET_OK) { icet_multi_destroy(m); return s; }
@@ -193,7 +151,7 @@ icet_status icet_multi_create(icet_multi** out, const int32_t* device_ids, int32
 
 icet_status icet_multi_destroy(icet_multi* m) {
     if (!m) return ICET_ERR_BAD_ARG;
-    for (Worker* w : m->workers) { w->stop(); delete w; }
+    m->sched.stop();
     for (size_t i = 0; i < m->comms.size(); i++) if (m->comms[i]) (void)m->rccl.CommDestroy(m->comms[i]);
     for (size_t i = 0; i < m->ctx.size(); i++) {
         (void)hipSetDevice(m->dev[i]);
@@ -261,8 +219,7 @@ icet_status icet_multi_solve_batch(icet_multi* m, const icet_params* p, int32_t 
                 }
             } catch (...) { stp[d] = ICET_ERR_NOMEM; }
         });
-    } catch (...) {                                     // posting a job allocates (std::function): wait for the ones already posted
-        for (int d = 0; d < D; d++) m->workers[d]->wait();
+    } catch (...) {                                     // posting a job allocates (std::function): run_all has waited for the ones already posted
         m->err = "cannot hand the work to the device threads"; return ICET_ERR_NOMEM;
     }
     for (int d = 0; d < D; d++) if (st[d] != ICET_OK) { set_err(m, d, m->ctx[d], "icet_solve_batch"); return st[d]; }
@@ -307,59 +264,59 @@ static icet_status multi_enqueue(icet_multi* m, const icet_params* p, int32_t n_
         if ((mode == 1 ? mrows : np) > m->cap_part[d] || (mode == 1 && D * mrows > m->cap_full[d])) grow = true;
     }
     if (grow) {
-        std::vector<icet_status> st1;
-        try { st1.assign(D, ICET_OK); } catch (...) { m->err = "out of host memory"; return ICET_ERR_NOMEM; }
-        icet_status* s1 = st1.data();
-        try {
-            run_all(m, [=](int d) {
-                const int np = (n_pairs - d + D - 1) / D;
-                const int need = mode == 1 ? mrows : np;
-                if (hipSetDevice(m->dev[d]) != hipSuccess) { s1[d] = ICET_ERR_NO_DEVICE; return; }
-                hipStream_t s = reinterpret_cast<hipStream_t>(icet_stream(m->ctx[d]));
-                if (hipStreamSynchronize(s) != hipSuccess) { s1[d] = ICET_ERR_HIP; return; }
-                if (need > m->cap_part[d]) {
-                    if (m->d_part[d]) { (void)hipFree(m->d_part[d]); m->d_part[d] = nullptr; m->cap_part[d] = 0; }
-                    // results (48 floats) and the share's X0 (6 floats) per pair
-                    if (hipMalloc(reinterpret_cast<void**>(&m->d_part[d]), sizeof(float) * 54 * (size_t)need) != hipSuccess) { s1[d] = ICET_ERR_NOMEM; return; }
-                    (void)hipMemsetAsync(m->d_part[d], 0, sizeof(float) * 54 * (size_t)need, s);
-                    m->cap_part[d] = need;
-                }
-                if (mode == 1 && D * mrows > m->cap_full[d]) {
-                    if (m->d_full[d]) { (void)hipFree(m->d_full[d]); m->d_full[d] = nullptr; m->cap_full[d] = 0; }
-                    if (hipMalloc(reinterpret_cast<void**>(&m->d_full[d]), sizeof(float) * 48 * (size_t)D * mrows) != hipSuccess) { s1[d] = ICET_ERR_NOMEM; return; }
-                    m->cap_full[d] = D * mrows;
-                }
-            });
-        } catch (...) {
-            for (int d = 0; d < D; d++) m->workers[d]->wait();
-            m->err = "cannot hand the work to the device threads"; return ICET_ERR_NOMEM;
-        }
-        for (int d = 0; d < D; d++) if (st1[d] != ICET_OK) { m->err = "device " + std::to_string(m->dev[d]) + ": cannot grow the result buffers"; return st1[d]; }
+        int fail_status = 0;
+        const int bad = m->sched.prepare_all([=](int d) -> int {
+            const int np = (n_pairs - d + D - 1) / D;
+            const int need = mode == 1 ? mrows : np;
+            if (hipSetDevice(m->dev[d]) != hipSuccess) return (int)ICET_ERR_NO_DEVICE;
+            hipStream_t s = reinterpret_cast<hipStream_t>(icet_stream(m->ctx[d]));
+            if (hipStreamSynchronize(s) != hipSuccess) return (int)ICET_ERR_HIP;
+            if (need > m->cap_part[d]) {
+                if (m->d_part[d]) { (void)hipFree(m->d_part[d]); m->d_part[d] = nullptr; m->cap_part[d] = 0; }
+                // results (48 floats) and the share's X0 (6 floats) per pair
+                if (hipMalloc(reinterpret_cast<void**>(&m->d_part[d]), sizeof(float) * 54 * (size_t)need) != hipSuccess) return (int)ICET_ERR_NOMEM;
+                (void)hipMemsetAsync(m->d_part[d], 0, sizeof(float) * 54 * (size_t)need, s);
+                m->cap_part[d] = need;
+            }
+            if (mode == 1 && D * mrows > m->cap_full[d]) {
+                if (m->d_full[d]) { (void)hipFree(m->d_full[d]); m->d_full[d] = nullptr; m->cap_full[d] = 0; }
+                if (hipMalloc(reinterpret_cast<void**>(&m->d_full[d]), sizeof(float) * 48 * (size_t)D * mrows) != hipSuccess) return (int)ICET_ERR_NOMEM;
+                m->cap_full[d] = D * mrows;
+            }
+            return 0;
+        }, &fail_status);
+        if (bad == -2) { m->err = "cannot hand the work to the device threads"; return ICET_ERR_NOMEM; }
+        if (bad >= 0) { m->err = "device " + std::to_string(m->dev[bad]) + ": cannot grow the result buffers"; return (icet_status)fail_status; }
     }
     // ---- phase 2: solve + gather, asynchronously.  The shares are cut here (the caller's descriptor arrays need not outlive the call) ----
     const icet_params prm = *p;
     try {
-        std::vector<std::vector<icet_dev_scan>> as(D), bs(D);
-        for (int k = 0; k < n_pairs; k++) { as[k % D].push_back(scan1[k]); bs[k % D].push_back(scan2[k]); }
-        m->pending = true;
-        for (int d = 0; d < D; d++) {
-            m->workers[d]->post([m, d, D, mode, mrows, n_pairs, prm, d_x0, d_out, wait_producer, a = std::move(as[d]), b = std::move(bs[d])]() {
-                icet_status st = ICET_OK; std::string why;
+        auto as = std::make_shared<std::vector<std::vector<icet_dev_scan>>>(D), bs = std::make_shared<std::vector<std::vector<icet_dev_scan>>>(D);
+        for (int k = 0; k < n_pairs; k++) { (*as)[k % D].push_back(scan1[k]); (*bs)[k % D].push_back(scan2[k]); }
+        const bool posted = m->sched.post_all(
+            // the rank's share: its rows of X0 (rows d, d + D, ... of the buffer on device 0: a strided peer copy; same device when d == 0), then the solve
+            [m, D, prm, d_x0, wait_producer, as, bs](int d, std::string& why) -> int {
+                const std::vector<icet_dev_scan>& a = (*as)[d]; const std::vector<icet_dev_scan>& b = (*bs)[d];
                 const int np = (int)a.size();
                 hipError_t e = hipSetDevice(m->dev[d]);
                 hipStream_t s = reinterpret_cast<hipStream_t>(icet_stream(m->ctx[d]));
                 float* part = m->d_part[d]; float* px0 = part + 48 * (size_t)m->cap_part[d];
                 if (e == hipSuccess && wait_producer) e = hipStreamWaitEvent(s, m->ev_producer, 0);
-                // this device's rows of X0: rows d, d + D, ... of the buffer on device 0 (a strided peer copy; same device when d == 0)
                 if (e == hipSuccess && d_x0 && np) e = hipMemcpy2DAsync(px0, 6 * sizeof(float), d_x0 + 6 * (size_t)d, 6 * sizeof(float) * D, 6 * sizeof(float), np, hipMemcpyDefault, s);
-                if (e != hipSuccess) { why = hipGetErrorString(e); st = ICET_ERR_HIP; }
-                if (st == ICET_OK && np) { st = icet_solve_batch_device(m->ctx[d], &prm, np, a.data(), b.data(), d_x0 ? px0 : nullptr, part); if (st != ICET_OK) why = icet_last_error(m->ctx[d]); }
-                // (a failure above does NOT skip the collective: the other ranks have queued theirs and would wait for this one for ever)
-                e = hipSuccess;
+                if (e != hipSuccess) { why = hipGetErrorString(e); return (int)ICET_ERR_HIP; }
+                if (np) { const icet_status st = icet_solve_batch_device(m->ctx[d], &prm, np, a.data(), b.data(), d_x0 ? px0 : nullptr, part); if (st != ICET_OK) { why = icet_last_error(m->ctx[d]); return (int)st; } }
+                return 0;
+            },
+            // the gather: entered whatever the solve returned when it is a collective (RCCL); the peer copy of a failed share is skipped
+            [m, D, mode, mrows, n_pairs, d_out, as](int d, int solve_status, std::string& why) -> int {
+                const int np = (int)(*as)[d].size();
+                hipStream_t s = reinterpret_cast<hipStream_t>(icet_stream(m->ctx[d]));
+                float* part = m->d_part[d];
+                hipError_t e = hipSuccess;
                 if (mode == 1) {
                     ncclResult_t r = m->rccl.AllGather(part, m->d_full[d], (size_t)mrows * 48, ncclFloat, m->comms[d], s);
-                    if (r != ncclSuccess) { if (st == ICET_OK) { st = ICET_ERR_HIP; why = std::string("ncclAllGather: ") + m->rccl.GetErrorString(r); } }
-                    else if (d == 0) {
+                    if (r != ncclSuccess) { why = std::string("ncclAllGather: ") + m->rccl.GetErrorString(r); return (int)ICET_ERR_HIP; }
+                    if (d == 0) {
                         // undo the round-robin interleave on the gathering device: block r of the receive buffer holds pairs r, r + D, ...
                         for (int r2 = 0; r2 < D && e == hipSuccess; r2++) {
                             const int rows = (n_pairs - r2 + D - 1) / D;
@@ -367,15 +324,19 @@ static icet_status multi_enqueue(icet_multi* m, const icet_params* p, int32_t n_
                                                                48 * sizeof(float), rows, hipMemcpyDeviceToDevice, s);
                         }
                     }
-                } else if (np && st == ICET_OK) {
+                } else if (np && solve_status == 0) {
                     e = hipMemcpy2DAsync(d_out + 48 * (size_t)d, 48 * sizeof(float) * D, part, 48 * sizeof(float), 48 * sizeof(float), np, hipMemcpyDefault, s);
                 }
-                if (e == hipSuccess) e = hipEventRecord(m->ev_done[d], s);
-                if (e != hipSuccess && st == ICET_OK) { st = ICET_ERR_HIP; why = hipGetErrorString(e); }
-                if (st != ICET_OK) { std::lock_guard<std::mutex> lk(m->st_mu); if (m->st[d] == ICET_OK) { m->st[d] = st; try { m->herr[d] = why; } catch (...) {} } }
+                if (e != hipSuccess) { why = hipGetErrorString(e); return (int)ICET_ERR_HIP; }
+                return 0;
+            },
+            [m](int d, std::string& why) -> int {
+                const hipError_t e = hipEventRecord(m->ev_done[d], reinterpret_cast<hipStream_t>(icet_stream(m->ctx[d])));
+                if (e != hipSuccess) { why = hipGetErrorString(e); return (int)ICET_ERR_HIP; }
+                return 0;
             });
-        }
-    } catch (...) {                                     // cutting the shares or posting a job allocates: the jobs already posted still run and are collected by the sync
+        if (!posted) { m->err = "cannot hand the work to the device threads"; return ICET_ERR_NOMEM; }      // (the jobs already posted still run and are collected by the sync)
+    } catch (...) {                                     // cutting the shares allocates
         m->err = "cannot hand the work to the device threads"; return ICET_ERR_NOMEM;
     }
     return ICET_OK;
@@ -383,19 +344,16 @@ static icet_status multi_enqueue(icet_multi* m, const icet_params* p, int32_t n_
 
 icet_status icet_multi_sync(icet_multi* m) {
     if (!m) return ICET_ERR_BAD_ARG;
-    const int D = (int)m->dev.size();
-    for (int d = 0; d < D; d++) m->workers[d]->wait();              // every job has enqueued its work and recorded its event
-    icet_status first = ICET_OK;
-    for (int d = 0; d < D; d++) {
-        hipError_t e = m->pending ? hipSetDevice(m->dev[d]) : hipSuccess;
-        if (e == hipSuccess && m->pending) e = hipStreamSynchronize(reinterpret_cast<hipStream_t>(icet_stream(m->ctx[d])));
-        std::lock_guard<std::mutex> lk(m->st_mu);
-        if (e != hipSuccess && m->st[d] == ICET_OK) { m->st[d] = ICET_ERR_HIP; m->herr[d] = hipGetErrorString(e); }
-        if (m->st[d] != ICET_OK && first == ICET_OK) { first = m->st[d]; m->err = "device " + std::to_string(m->dev[d]) + ": " + m->herr[d]; }
-        m->st[d] = ICET_OK; m->herr[d].clear();
-    }
-    m->pending = false;
-    return first;
+    int status = 0; std::string why;
+    const int bad = m->sched.sync([m](int d, std::string& msg) -> int {      // every job has enqueued its work and recorded its event: drain the device
+        hipError_t e = hipSetDevice(m->dev[d]);
+        if (e == hipSuccess) e = hipStreamSynchronize(reinterpret_cast<hipStream_t>(icet_stream(m->ctx[d])));
+        if (e != hipSuccess) { msg = hipGetErrorString(e); return (int)ICET_ERR_HIP; }
+        return 0;
+    }, &status, &why);
+    if (bad < 0) return ICET_OK;
+    m->err = "device " + std::to_string(m->dev[bad]) + ": " + why;
+    return (icet_status)status;
 }
 
 icet_status icet_multi_solve_batch_device_async(icet_multi* m, const icet_params* p, int32_t n_pairs, const icet_dev_scan* scan1, const icet_dev_scan* scan2,

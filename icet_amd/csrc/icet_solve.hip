@@ -33,11 +33,11 @@ __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X
 }
 
 // One launch per iteration behind the point pass: gn_solve_body (icet_solve_body.h) with the block it was written for.
-template <int kT, int kStage>
+template <int kT, int kStage, bool kRefW = false>
 __global__ __launch_bounds__(kT) void k_gn_solve(const int32_t* __restrict__ n_slots, const SlotFit* __restrict__ fitS, uint32_t* __restrict__ acc,
                                                      float* __restrict__ X_all, float* __restrict__ xf_all, float* __restrict__ out, AuxDev aux,
                                                      int V, int n, int iter, int runlen, NearOverflow over, int reject_moving, float* __restrict__ part, int nblk, float cond_bound2, KeepArgs keep) {
-    gn_solve_body<kT, kStage>(n_slots, fitS, acc, X_all, xf_all, out, aux, V, n, iter, runlen, over, reject_moving, part, nblk, cond_bound2, keep);
+    gn_solve_body<kT, kStage, kT, kRefW>(n_slots, fitS, acc, X_all, xf_all, out, aux, V, n, iter, runlen, over, reject_moving, part, nblk, cond_bound2, keep);
 }
 
 
@@ -57,7 +57,22 @@ __global__ __launch_bounds__(64) void k_gn_tail_debug(const float* __restrict__ 
     for (int k = 0; k < 6; k++) { o[36 + k] = ps[k]; o[42 + k] = dx[k]; o[48 + k] = ev[k]; }
     o[54] = (float)pruned; o[55] = (float)route;
 }
+// Test hook (icet_debug_pinv3): n independent 3 x 3 matrices through the per-voxel pseudo-inverse of ICET_FLAG_REFERENCE_W, one lane each.
+__global__ __launch_bounds__(64) void k_pinv3_debug(const float* __restrict__ A, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    float a[9], w[9];
+    for (int k = 0; k < 9; k++) a[k] = A[(size_t)i * 9 + k];
+    icetdev::cod_pinv3_lane(a, w);
+    for (int k = 0; k < 9; k++) out[(size_t)i * 9 + k] = w[k];
+}
 }  // namespace
+
+hipError_t launch_pinv3_debug(const float* d_A, float* d_out, int n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    k_pinv3_debug<<<(n + 63) / 64, 64, 0, st>>>(d_A, d_out, n);
+    return hipGetLastError();
+}
 
 hipError_t launch_gn_tail_debug(const float* d_H, const float* d_g, float* d_out, int n, float bound2, hipStream_t st) {
     if (n <= 0) return hipSuccess;
@@ -117,15 +132,19 @@ hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, flo
     const KeepArgs keep{w.desc, w.keep_mask, w.keep_list, w.keep_state, c.keep_bt * c.keep_bt * c.keep_check_scale * c.keep_check_scale, c.keep_br * c.keep_br * c.keep_check_scale * c.keep_check_scale, w.keep_state ? keep_pass : 0,      // 1: build / check; 2: behind the last pass (statistics only)
                         w.keep_modes ? w.keep_modes + (size_t)((iter + 1) & 1) * c.n_pairs : nullptr, c.n_pairs};
     NearOverflow over{w.desc, w.slot_of_voxel, w.hotS, w.thr, w.near_over, w.near_over_count, c.T, c.P, c.rt2};
-    if (c.V > 4096 && c.n_pairs <= kTwoStageMaxPairs && w.gn_part) {
-        // two stages: several blocks per pair reduce their share of the slots to 27 partial sums each, one block per pair adds them and solves
-        const int nblk = kTwoStageBlocks;
-        k_gn_solve<512, 1><<<c.n_pairs * nblk, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk, c.gn_cond_bound2, keep);
-        ICET_LAUNCH_CHECK();
-        k_gn_solve<512, 2><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk, c.gn_cond_bound2, keep);
-    }
-    else if (c.V > 4096) k_gn_solve<512, 0><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1, c.gn_cond_bound2, keep);
-    else k_gn_solve<kBlock, 0><<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1, c.gn_cond_bound2, keep);
+#define ICET_SOLVE_LAUNCHES(RW) do {                                                                                                                                   \
+    if (c.V > 4096 && c.n_pairs <= kTwoStageMaxPairs && w.gn_part) {                                                                                                      \
+        /* two stages: several blocks per pair reduce their share of the slots to 27 partial sums each, one block per pair adds them and solves */                        \
+        const int nblk = kTwoStageBlocks;                                                                                                                                 \
+        k_gn_solve<512, 1, RW><<<c.n_pairs * nblk, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk, c.gn_cond_bound2, keep); \
+        ICET_LAUNCH_CHECK();                                                                                                                                              \
+        k_gn_solve<512, 2, RW><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, w.gn_part, nblk, c.gn_cond_bound2, keep); \
+    }                                                                                                                                                                     \
+    else if (c.V > 4096) k_gn_solve<512, 0, RW><<<c.n_pairs, 512, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1, c.gn_cond_bound2, keep); \
+    else k_gn_solve<kBlock, 0, RW><<<c.n_pairs, kBlock, 0, st>>>(w.n_slots, w.fitS, w.acc, w.X, w.xf, d_out, aux, c.V, c.n, iter, c.runlen, over, c.reject_moving, nullptr, 1, c.gn_cond_bound2, keep); \
+} while (0)
+    if (c.ref_w) ICET_SOLVE_LAUNCHES(true); else ICET_SOLVE_LAUNCHES(false);
+#undef ICET_SOLVE_LAUNCHES
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

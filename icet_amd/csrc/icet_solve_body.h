@@ -184,7 +184,9 @@ __device__ __forceinline__ void keep_budget_check(const KeepArgs& k, int pair, c
 #endif
 // kBlockT: threads of the calling block (> kT when the caller is the point-pass kernel: its threads beyond kT own no slot and no row of the reduction table, but
 // reach every barrier).  The pointers carry no __restrict__: in the fused kernel acc / the overflow list were written through other names a few lines earlier.
-template <int kT, int kStage, int kBlockT = kT>
+// kRefW (ICET_FLAG_REFERENCE_W): the per-voxel weight W as the reference computes it -- the float CompleteOrthogonalDecomposition of the full (not
+// symmetrised) 3 x 3 L U^T R_noise U L^T -- instead of the double-precision pseudo-inverse of the default path.
+template <int kT, int kStage, int kBlockT = kT, bool kRefW = false>
 __device__ __forceinline__ void gn_solve_body(const int32_t* n_slots, const SlotFit* fitS, uint32_t* acc,
                                               float* X_all, float* xf_all, float* out, const AuxDev& aux,
                                               int V, int n, int iter, int runlen, const NearOverflow& over, int reject_moving, float* part, int nblk, float cond_bound2,
@@ -304,6 +306,17 @@ __device__ __forceinline__ void gn_solve_body(const int32_t* n_slots, const Slot
         Rp[4] = MR[3] * M[6] + MR[4] * M[7] + MR[5] * M[8];
         Rp[5] = MR[6] * M[6] + MR[7] * M[7] + MR[8] * M[8];
         float W[6];
+        float W9[9];
+        if constexpr (kRefW) {
+            // the matrix the reference hands to Eigen: ((L U^T R_n) U) L^T, all nine entries (the two triangles differ by roundings), then its float COD
+            float Rp9[9];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) Rp9[3 * i + j] = MR[3 * i] * M[3 * j] + MR[3 * i + 1] * M[3 * j + 1] + MR[3 * i + 2] * M[3 * j + 2];
+            icetdev::cod_pinv3_lane(Rp9, W9);
+            W[0] = W9[0]; W[1] = W9[1]; W[2] = W9[2]; W[3] = W9[4]; W[4] = W9[5]; W[5] = W9[8];
+        } else
         icetdev::pinv3_sym_fast(Rp, 3.0f * FLT_EPSILON, W);                 // src/icet.cpp:320-321
         // H_z = M * [-I | Jx mu | Jy mu | Jz mu]                                  src/icet.cpp:324-329
         float Hj[9];      // columns 3..5 of H_j, row-major 3x3
@@ -323,9 +336,15 @@ __device__ __forceinline__ void gn_solve_body(const int32_t* n_slots, const Slot
         float WH[18];     // W * Hz
 #pragma unroll
         for (int j = 0; j < 6; j++) {
+            if constexpr (kRefW) {                                  // (W is not exactly symmetric there)
+                WH[j]      = W9[0] * Hz[j] + W9[1] * Hz[6 + j] + W9[2] * Hz[12 + j];
+                WH[6 + j]  = W9[3] * Hz[j] + W9[4] * Hz[6 + j] + W9[5] * Hz[12 + j];
+                WH[12 + j] = W9[6] * Hz[j] + W9[7] * Hz[6 + j] + W9[8] * Hz[12 + j];
+            } else {
             WH[j]      = W[0] * Hz[j] + W[1] * Hz[6 + j] + W[2] * Hz[12 + j];
             WH[6 + j]  = W[1] * Hz[j] + W[3] * Hz[6 + j] + W[4] * Hz[12 + j];
             WH[12 + j] = W[2] * Hz[j] + W[4] * Hz[6 + j] + W[5] * Hz[12 + j];
+            }
         }
         int q = 0;
 #pragma unroll

@@ -61,13 +61,21 @@ enum { ICET_FLAG_NONE = 0,
                                   that exists is more than `thresh` away, so this only tightens bounds whose neighbour lies within 2 buff).
                                   Needs the voxel's rows in ascending range, so it implies ICET_FLAG_TRUE_SORT.  Oracle twin:
                                   ICET_ORACLE_HALF_GAP. */
-       ICET_FLAG_ROUNDTRIP_SCAN2 = 16 /* PARITY-STUDY OPTION (not an extension: it makes the loop MORE literal).  The reference passes scan 2 through
+       ICET_FLAG_ROUNDTRIP_SCAN2 = 16, /* PARITY-STUDY OPTION (not an extension: it makes the loop MORE literal).  The reference passes scan 2 through
                                   cartesianToSpherical -> sphericalToCartesian twice: once as a whole (points2_OG, src/icet.cpp:275) and, every
                                   iteration, the in-bounds points of every voxel (:303).  Each trip moves a point by 1-2 ulp; the default path
                                   skips both (one of several last-bit triggers behind the pairs that differ from the CPU restatement by
                                   > 5e-5 m; restoring them closes some of those pairs, not all).  With this flag both trips are made, under the shared arithmetic rule (correctly rounded angles and
                                   sines / cosines): a pre-pass over scan 2, and a double-precision atan2 + acos per in-bounds point per
-                                  iteration -- about twice the loop time.  Decisions (which voxel, inside the bounds) are unchanged. */ };
+                                  iteration -- about twice the loop time.  Decisions (which voxel, inside the bounds) are unchanged. */
+       ICET_FLAG_DOUBLE_W = 32 /* ACCURACY OPTION (the default of rounds 2-5).  The per-voxel weight W = pinv(L U^T R_noise U L^T) (src/icet.cpp:317-321) is, in the reference,
+                                  Eigen's float CompleteOrthogonalDecomposition of a float matrix: its result carries a relative error of cond x eps and its rank decision is
+                                  the pivot rule.  Since round 6 the device does exactly that by default (Eigen 3.3's algorithm statement by statement on the full, unsymmetrised
+                                  3 x 3, bit-identical to the CPU restatement's function on the same matrix: tests test_pinv3_reference_bits).  With this flag W is taken in
+                                  DOUBLE with an eigenvalue rank rule instead -- the better-conditioned answer.  On lidar scenes the two agree to rounding; on voxels whose
+                                  covariance is thin to the point of cond 1e6 .. 1e7 (millimetre-noise scenes, clusters of three points) they do not: H^T W H differs by 10 %
+                                  and more, a condition number at checkCondition's cutoff lands on the other side (other pruned axes, pred_stds of 1e-4 instead of -0.9995),
+                                  while the reference's own answer moves by per cents with the last bit of its input. */ };
 
 /* A scan that already lives in device memory (HBM) on the context's device. */
 typedef struct icet_dev_scan {
@@ -215,6 +223,9 @@ icet_status icet_debug_fetch(icet_ctx* ctx, int32_t what, void* out, int64_t cou
  * htwh: n x 36 row-major, htwdz: n x 6; out: n x 56 = cov[36] | pred_stds[6] | dx[6] | eigenvalues[6] (NaN on the Cholesky route) |
  * pruned axes | route (0 Cholesky inverse, 2 literal restatement; option "gn_cond_bound"). */
 icet_status icet_debug_gn_tail(icet_ctx* ctx, const float* htwh, const float* htwdz, int32_t n, float* out);
+/* Diagnostic hook for the parity tests: the per-voxel weight W = pinv(.) of ICET_FLAG_REFERENCE_W (Eigen's float CompleteOrthogonalDecomposition, src/icet.cpp:320-321) for n
+ * host-side 3 x 3 matrices (row-major, n x 9 in, n x 9 out), through the device function the solve kernel runs. */
+icet_status icet_debug_pinv3(icet_ctx* ctx, const float* a, int32_t n, float* out);
 
 /* Launch-shape and diagnostic knobs of ONE context (the library never reads the environment).  Defaults are the measured
  * optima.  Launch-shape knobs yield the same result bits; "force_exact", "guard_scale" and "lut_polar_quantile" preserve every

@@ -1223,7 +1223,8 @@ def test_scan2_round_trip_option(gpu_ctx, frames):
     d0 = np.abs(g0["X"][:3] - ref["X"][:3]).max(); d1 = np.abs(g1["X"][:3] - ref["X"][:3]).max()
     print("pair 18: |dX_t| %.3g m without, %.3g m with the round trips" % (d0, d1))
     assert np.array_equal(g0["aux"]["cluster_bounds"], g1["aux"]["cluster_bounds"]) and np.array_equal(g0["aux"]["n2_in"][0], g1["aux"]["n2_in"][0])
-    assert d1 <= 1e-5 and d0 >= 5 * d1
+    assert d1 <= 1e-5 and d0 <= 1e-5      # (until round 5 d0 was 9.6e-5 m on this pair and the trips closed it to 2.5e-6: with W taken as the reference takes it -- float COD -- the
+                                           # pair agrees to 1.2e-6 m WITHOUT the trips: what looked like the round trips' doing was mostly the double-precision W)
     # a real scan with thousands of exact zero rows (the sentinel branch of the round trip: r = 0, phi = NaN -> 1000), and the batched pre-pass
     fa, fb = frames
     r = ctx.solve(fa, fb, 7, np.zeros(6), 24, 75, flags=api.FLAG_ROUNDTRIP_SCAN2)
@@ -1463,6 +1464,7 @@ def test_degenerate_scenes_take_the_pruning_route(gpu_ctx, name):
         axes in every iteration and pred_stds agree INCLUDING SIGN to 1e-3 absolute; on the others (millimetre-noise scenes at the resolution of
         float32 coordinates: the oracle flips the sign of its own +-1.0 under that perturbation) the difference is held to the oracle's spread."""
     from oracle import pyoracle as po
+    from icet_amd import api
     a, b = _degenerate_scans(name)
     gold = _degenerate_golden()[name]
     assert gold["checksum"][0] == a.shape[0] and gold["checksum"][1] == b.shape[0] and np.isclose(gold["checksum"][4], np.abs(a.astype(np.float64)).sum(), rtol=1e-12), "scene generator drifted"
@@ -1492,20 +1494,22 @@ def test_degenerate_scenes_take_the_pruning_route(gpu_ctx, name):
     dt, dr = float(np.abs(r["X"][:3] - ref["X"][:3]).max()), float(np.abs(r["X"][3:] - ref["X"][3:]).max())
     print("%s: pruned oracle %s device %s | pred_stds oracle %s device %s | dH %.2e (oracle 1-ulp spread %.2e) d pred_stds %.2e (%.2e) |dX| %.2e m %.2e rad (%.2e / %.2e) oracle pruning stable: %s"
           % (name, t["pruned"].tolist(), ci[:, 6].astype(int).tolist(), np.round(ref["pred_stds"], 4).tolist(), np.round(r["pred_stds"], 4).tolist(), dH, sp["H"], dps, sp["ps"], dt, dr, sp["Xt"], sp["Xr"], sp["pruned_same"]))
-    # (round 6) H^T W H against the unmodified oracle: within 1.5 x the oracle's own 32-trial spread -- or ATTRIBUTED: against the oracle run with the device's
-    # documented arithmetic (ICET_ORACLE_DEVICE_ARITH: no scan-2 round trip, FMA transform, moments about mu1) and the per-voxel weight W = pinv(R_noise) taken in
-    # double as icet_device_math.h pinv3_sym takes it (ICET_ORACLE_PINV3_DOUBLE) most of the difference is gone.  What that says: the reference's float
-    # CompleteOrthogonalDecomposition of a cond 1e6 .. 1e7 voxel carries a relative error of cond x eps -- per cents -- that moves with the last bits of its input;
-    # the device does not reproduce that noise, it inverts in double (wall_s10: 0.14 -> 0.024; ground_s10_m: 0.17 -> 0.07 and pred_stds agree again; ground_s02: 0.034 -> 0.004).
-    attr = po.solve(a, b, trace=True, mode=po.DEVICE_ARITH | po.PINV3_DOUBLE)
-    ta = attr["trace"]
-    dH_attr = float((np.abs(ax["htwh"] - ta["HTWH"]).reshape(7, -1).max(1) / np.abs(ta["HTWH"]).reshape(7, -1).max(1)).max())
-    rep_attr = _replay_each_iteration(gpu_ctx, a, b, attr)
-    print("   %s: dH vs the oracle in device arithmetic + double W: %.2e (unmodified: %.2e; oracle 32-trial spread max %.2e p90 %.2e); replayed from its state: count flips %s dH %s; d pred_stds %.2e"
-          % (name, dH_attr, dH, sp["H"], sp["H_p90"], [f for f, _ in rep_attr], ["%.1e" % h for _, h in rep_attr], float(np.abs(r["pred_stds"] - attr["pred_stds"]).max())))
-    assert max(f for f, _ in rep_attr) == 0, rep_attr                      # one step from the same state: the same decisions
-    assert dH <= max(2e-3, HATCH * sp["H"]) or (dH_attr <= max(2e-3, 0.6 * dH) and dH_attr <= 0.1), (dH, sp["H"], dH_attr)
-    assert float(np.median([h for _, h in rep_attr])) <= 0.05, rep_attr
+    # (round 6) H^T W H against the UNMODIFIED oracle: within 1.5 x the oracle's own 32-trial spread, and every iteration replayed from the oracle's state takes the
+    # oracle's decisions.  Until round 5 this stood at 0.14 (wall_s10) / 0.17 (ground_s10_m) against spreads of 0.09 / 0.07; the ATTRIBUTION (scripts/diag_attribution.py,
+    # profiles/r06_attribution.txt): the per-voxel weight W = pinv(R_noise) was taken in double, while the reference's float CompleteOrthogonalDecomposition of a cond
+    # 1e6 .. 1e7 voxel carries a relative error of cond x eps and decides its rank by pivots.  The device now runs the reference's float COD (bit-identical to the
+    # restatement's function: test_pinv3_reference_bits); the double path is ICET_FLAG_DOUBLE_W, shown below against the oracle run the same way.
+    rep_o = _replay_each_iteration(gpu_ctx, a, b, ref)
+    r2 = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True, flags=api.FLAG_DOUBLE_W)
+    dH2 = float((np.abs(r2["aux"]["htwh"] - t["HTWH"]).reshape(7, -1).max(1) / np.abs(t["HTWH"]).reshape(7, -1).max(1)).max())
+    ta = po.solve(a, b, trace=True, mode=po.DEVICE_ARITH | po.PINV3_DOUBLE)["trace"]
+    dH2_attr = float((np.abs(r2["aux"]["htwh"] - ta["HTWH"]).reshape(7, -1).max(1) / np.abs(ta["HTWH"]).reshape(7, -1).max(1)).max())
+    print("   %s: dH %.2e (oracle 32-trial spread max %.2e p90 %.2e); replayed from the oracle's state: count flips %s dH %s | with ICET_FLAG_DOUBLE_W: dH %.2e, against the oracle in device arithmetic + double W %.2e, pruned %s"
+          % (name, dH, sp["H"], sp["H_p90"], [f for f, _ in rep_o], ["%.1e" % h for _, h in rep_o], dH2, dH2_attr, r2["aux"]["cond_info"][:, 6].astype(int).tolist()))
+    assert max(f for f, _ in rep_o) == 0, rep_o                            # one step from the same state: the same decisions
+    assert dH <= max(2e-3, HATCH * sp["H"]), (dH, sp["H"])
+    assert float(np.median([h for _, h in rep_o])) <= max(2e-3, sp["H"]), (rep_o, sp["H"])
+    assert dH2_attr <= 0.1, (dH2, dH2_attr)
     cond_o = np.abs(t["eigvals"][:, 5] / t["eigvals"][:, 0])
     straddles = bool(((cond_o > 1e6 / 1.5) & (cond_o < 1.5e6)).any())      # a condition number within the tables' own spread of the cutoff: pruning there is a coin toss on either side
     if straddles and not np.array_equal(ci[:, 6].astype(int), t["pruned"]):
@@ -1575,9 +1579,9 @@ def test_no_matching_voxel_gives_zero_update(gpu_ctx, frames):
     assert (r["aux"]["cond_info"][:, 6] == 0).all() and (r["aux"]["cond_info"][:, 7] == 2).all()
 
 
-@pytest.mark.parametrize("seed,with_flags", [(1, False), (11, True)])
+@pytest.mark.parametrize("seed,with_flags", [(1, False), (2, False), (3, False), (4, False), (5, False), (6, False), (11, True), (12, True), (13, True), (14, True), (15, True), (16, True)])
 def test_random_parameter_space(gpu_ctx, seed, with_flags):
-    """40 seeded draws from the parameter space (tests/param_sweep.py: grids from 7 x 3 to 199 x 48, minimum points 3 .. 120, thresh 0.02 .. 1, buff 0 .. 2, runlen 1 .. 9,
+    """(Twelve seeds in the suite since round 6: 480 draws.)  40 seeded draws from the parameter space (tests/param_sweep.py: grids from 7 x 3 to 199 x 48, minimum points 3 .. 120, thresh 0.02 .. 1, buff 0 .. 2, runlen 1 .. 9,
     zero and non-zero X0, stretches / strides of the sample scans with their zero rows, 3 k .. 131 k rows; 600 draws over five seeds were run by hand,
     scripts/fuzz_params.py -> profiles/r05_fuzz_params.txt).  In EVERY draw the whole keyframe table is the oracle's bits (NaN covariances of one-point clusters in
     the same places) and so are the first iteration's per-voxel counts (X0 = 0; see param_sweep.run_case for X0 != 0).  The solution: within the parity bound, or within
@@ -1589,14 +1593,21 @@ def test_random_parameter_space(gpu_ctx, seed, with_flags):
     from tests.param_sweep import draw_case, run_case, pools
     rng = np.random.default_rng(seed)
     pl = pools()
-    beyond, ill, replays = [], [], []
+    beyond, ill, replays, nan_both = [], [], [], []
     for c in range(40):
         a, b, T, P, kw, runlen, x0 = draw_case(rng, pl, with_flags=with_flags)
         bits, d, r, ref, fits = run_case(gpu_ctx, a, b, T, P, kw, runlen, x0)
         assert all(bits.values()), (c, T, P, kw, runlen, {k: v for k, v in bits.items() if not v})
         okw = {k: v for k, v in kw.items() if k != "_twin"}
         if kw.get("_twin", (0, None))[1] is not None: okw["mode"] = kw["_twin"][1]
-        assert np.isfinite(r["X"]).all()
+        # (n = 3: a cluster of a few collinear points has a 0 / 0 in its fit, and the reference's loop carries the NaN into X -- src/icet.cpp has no guard; the
+        # restatement does the same and the device must agree on WHERE that happens: found by seed 4, draws 10 and 30)
+        assert bool(np.isfinite(r["X"]).all()) == bool(np.isfinite(ref["X"]).all()), (c, T, P, kw, runlen, r["X"], ref["X"])
+        if not np.isfinite(ref["X"]).all():
+            first_bad = int(np.argmax(~np.isfinite(ref["trace"]["X"]).all(1)))
+            assert int(np.argmax(~np.isfinite(r["aux"]["x_hist"]).all(1))) == first_bad, (c, "NaN enters in another iteration")
+            nan_both.append(c)
+            continue
         if d[:3].max() > TOL_T or d[3:].max() > TOL_R:
             okw = dict(x0=x0, runlen=runlen, bins_phi=P, bins_theta=T, **okw)
             sens = np.maximum(oracle_sensitivity(a, b, trials=16, scan1_too=True, **okw), oracle_sensitivity(a, b, trials=16, **okw))
@@ -1625,17 +1636,18 @@ def test_random_parameter_space(gpu_ctx, seed, with_flags):
             fh.write("# replayed from the oracle's state (draws beyond the bound): case, max raw-count differences per iteration, max rel dHTWH\n")
             for w in replays:
                 fh.write("%d %d %.3g\n" % w)
-    assert len(beyond) <= 14 and len(ill) <= 12, (beyond, ill)            # the draws are deliberately extreme
+    assert len(beyond) <= 14 and len(ill) <= 12 and len(nan_both) <= 4, (beyond, ill, nan_both)            # the draws are deliberately extreme
 
 
-def test_random_batches_carry_their_single_solve_bits(gpu_ctx):
-    """12 seeded random batches (tests/param_sweep.run_batch; 134 more were run by hand, scripts/fuzz_batch.py -> profiles/r05_fuzz_batch.txt): 1 .. 48 ragged pairs --
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_batches_carry_their_single_solve_bits(gpu_ctx, seed):
+    """(Three seeds in the suite since round 6.)  12 seeded random batches (tests/param_sweep.run_batch; 134 more were run by hand, scripts/fuzz_batch.py -> profiles/r05_fuzz_batch.txt): 1 .. 48 ragged pairs --
     empty scans, scans of a few rows, strided and whole real / synthetic scans -- random grid, minimum points, thresh, buff, runlen and X0, once through icet_solve_batch
     and once through icet_solve_batch_device with padded leading dimensions.  Every pair of every batch: the BITS of its own single solve in another context (integer
     accumulation: no dependence on batch size, chunking, launch shape or neighbours)."""
     from icet_amd import api
     from tests.param_sweep import run_batch, pools
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(seed)
     pl = pools()
     single = api.Context()
     for _ in range(12):
@@ -1644,8 +1656,9 @@ def test_random_batches_carry_their_single_solve_bits(gpu_ctx):
     single.close()
 
 
-def test_adversarial_scans(gpu_ctx):
-    """30 seeded adversarial pairs (tests/param_sweep.spoil: thousands of equal sort keys, lattice points EXACTLY on voxel edges, duplicated rows, NaN / +-inf entries,
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_adversarial_scans(gpu_ctx, seed):
+    """(Four seeds in the suite since round 6: 120 pairs, each on both paths.)  30 seeded adversarial pairs (tests/param_sweep.spoil: thousands of equal sort keys, lattice points EXACTLY on voxel edges, duplicated rows, NaN / +-inf entries,
     rows scaled by 1e-20 / 1e+18, signed zeros; 180 more by hand, scripts/fuzz_adversarial.py -> profiles/r05_fuzz_adversarial.txt).  The keyframe table is the oracle's
     bits in every one.  The first iteration's per-voxel counts of scan 2 are the oracle's in every one when the device round-trips scan 2 through spherical coordinates
     as the reference does (ICET_FLAG_ROUNDTRIP_SCAN2); on the default path -- which skips that round trip, DESIGN.md section 7 -- a fifth of these pairs differ in a few
@@ -1655,7 +1668,7 @@ def test_adversarial_scans(gpu_ctx):
     pl = pools()
     n_default_diff = 0
     for flag in (api.FLAG_ROUNDTRIP_SCAN2, 0):
-        rng = np.random.default_rng(1)
+        rng = np.random.default_rng(seed)
         for c in range(30):
             a, b, T, P, kw, runlen, x0, what = draw_adversarial(rng, pl)
             if flag: kw["_twin"] = (flag, None)
@@ -1808,3 +1821,137 @@ def test_keep_list_is_bit_neutral(gpu_ctx, frames, sample_pc):
             outs.append(out.cpu().numpy())
         assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (P, T)
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_multi_shard_fuzz_on_one_card(gpu_ctx, seed):
+    """icet_multi_* with 1-6 shards on ONE card (an id may repeat: one context and one host thread per entry), ten random ragged batches per seed through the host-pointer
+    entry and the device-resident entries, synchronous and asynchronous (scripts/fuzz_multi.py, 76 batches by hand in round 5): every pair carries the bits of its single solve."""
+    from icet_amd import api
+    from tests.param_sweep import pools as make_pools, draw_scan_pair
+    rng = np.random.default_rng(seed)
+    pools = make_pools()
+    dev = torch.device("cuda", 0)
+    for bno in range(10):
+        shards = int(rng.integers(1, 7)); k = int(rng.choice([1, 3, 8, 17, 40]))
+        T = int(rng.choice([40, 75, 128])); P = int(rng.choice([11, 24, 48])); runlen = int(rng.integers(1, 8))
+        kw = dict(n=int(rng.choice([10, 25])), thresh=0.1, buff=float(rng.choice([0.0, 0.1])))
+        pairs = [draw_scan_pair(rng, pools) for _ in range(k)]
+        s1 = [np.ascontiguousarray(p[0]) for p in pairs]; s2 = [np.ascontiguousarray(p[1]) for p in pairs]
+        x0 = (rng.normal(size=(k, 6)) * np.array([0.1, 0.1, 0.03, 0.003, 0.003, 0.01])).astype(np.float32); x0[rng.random(k) < 0.4] = 0
+        m = api.MultiContext([0] * shards)
+        host = m.solve_batch(s1, s2, runlen, x0, P, T, **kw)
+        bufs1 = [torch.from_numpy(np.ascontiguousarray(s.T) if len(s) else np.zeros((3, 4), np.float32)).to(dev) for s in s1]
+        bufs2 = [torch.from_numpy(np.ascontiguousarray(s.T) if len(s) else np.zeros((3, 4), np.float32)).to(dev) for s in s2]
+        d1 = [(b.data_ptr(), len(s), b.shape[1]) for b, s in zip(bufs1, s1)]; d2 = [(b.data_ptr(), len(s), b.shape[1]) for b, s in zip(bufs2, s2)]
+        prm = api.Params(runlen, P, T, kw["n"], kw["thresh"], kw["buff"], 0)
+        out = torch.zeros(k, 48, device=dev); dx0 = torch.from_numpy(x0).to(dev); torch.cuda.synchronize()
+        m.solve_batch_device(d1, d2, prm, out.data_ptr(), dx0.data_ptr()); o_sync = out.cpu().numpy()
+        out.zero_(); torch.cuda.synchronize()
+        m.solve_batch_device(d1, d2, prm, out.data_ptr(), dx0.data_ptr(), asynchronous=True); m.sync(); o_async = out.cpu().numpy()
+        m.close()
+        for j in range(k):
+            r = gpu_ctx.solve(s1[j], s2[j], runlen, x0[j], P, T, **kw)
+            ref = np.concatenate([r["X"], r["pred_stds"], r["cov"].reshape(36)]).view(np.uint32)
+            h = np.concatenate([host["X"][j], host["pred_stds"][j], host["cov"][j].reshape(36)]).view(np.uint32)
+            assert np.array_equal(h, ref) and np.array_equal(o_sync[j].view(np.uint32), ref) and np.array_equal(o_async[j].view(np.uint32), ref), (seed, bno, shards, k, j)
+
+
+def test_four_host_threads_with_their_own_contexts(gpu_ctx):
+    """Four host threads, each with its own context, solving different random draws of the parameter space at the same time, three times over (scripts/fuzz_threads.py):
+    every result carries the bits of the same solve done alone -- nothing static in the library, as in the reference (include/icet.h:43 hints at concurrent objects)."""
+    import threading
+    from icet_amd import api
+    from tests.param_sweep import draw_case, pools as make_pools
+    rng = np.random.default_rng(1); pools = make_pools()
+    ctxs = [api.Context() for _ in range(4)]
+    for rnd in range(3):
+        jobs = [[draw_case(rng, pools) for _ in range(5)] for _ in range(4)]
+        refs = [[gpu_ctx.solve(a, b, rl, x0, P, T, **kw) for (a, b, T, P, kw, rl, x0) in js] for js in jobs]
+        out = [[None] * 5 for _ in range(4)]; errs = []
+        def work(t):
+            try:
+                for _ in range(3):
+                    for i, (a, b, T, P, kw, rl, x0) in enumerate(jobs[t]):
+                        out[t][i] = ctxs[t].solve(a, b, rl, x0, P, T, **kw)
+            except Exception as e:
+                errs.append(repr(e))
+        th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        [t.start() for t in th]; [t.join() for t in th]
+        assert not errs, errs
+        for t in range(4):
+            for i in range(5):
+                assert all(np.array_equal(out[t][i][k].view(np.uint32), refs[t][i][k].view(np.uint32)) for k in ("X", "pred_stds", "cov")), (rnd, t, i)
+    for c in ctxs:
+        c.close()
+
+
+def _pinv3_matrices():
+    rng = np.random.default_rng(7)
+    mats = []
+    def rot():
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3))); return q
+    for cond in np.logspace(0, 10, 41):
+        for _ in range(24):
+            Q = rot(); lam = np.array([1.0, cond ** -rng.uniform(0.3, 1.0), 1.0 / cond]) * 10.0 ** rng.uniform(-8, 2)
+            A = (Q * lam) @ Q.T
+            A32 = A.astype(np.float32)
+            mats.append(A32)                                                               # symmetric to the last bit
+            mats.append((A32 * (1 + rng.uniform(-6e-8, 6e-8, (3, 3)))).astype(np.float32))   # the two triangles differ by roundings, as the reference's float products leave them
+            for mask in ((1, 1, 0), (0, 1, 1), (1, 0, 0)):                                   # axes masked out by L: exact zero rows / columns
+                m = np.array(mask, np.float32); mats.append(A32 * np.outer(m, m))
+    for _ in range(200):                                                                     # exactly rank-deficient
+        u, v = rng.normal(size=3), rng.normal(size=3)
+        mats.append(np.outer(u, u).astype(np.float32)); mats.append((np.outer(u, u) + np.outer(v, v)).astype(np.float32))
+    mats += [np.zeros((3, 3), np.float32), np.eye(3, dtype=np.float32), np.full((3, 3), np.nan, np.float32), np.diag([1e-38, 1e-40, 1e-42]).astype(np.float32),
+             np.diag([1e30, 1.0, 1e-30]).astype(np.float32), np.array([[1, 0, 0], [0, np.nan, 0], [0, 0, 1]], np.float32)]
+    return np.stack(mats)
+
+
+def test_pinv3_reference_bits(gpu_ctx):
+    """The per-voxel weight of ICET_FLAG_REFERENCE_W: W = CompleteOrthogonalDecomposition<MatrixXf>(R).pseudoInverse() (src/icet.cpp:320-321) evaluated on the device for
+    5300 3 x 3 matrices -- condition numbers 1 .. 1e10 (symmetric and with the two triangles a rounding apart), one or two axes masked out by L, exactly rank-deficient, zero,
+    NaN, denormal and huge scales -- through the device function the solve kernel runs (icet_debug_pinv3): BIT-IDENTICAL to the oracle's restatement of Eigen's algorithm
+    (oracle/smalllinalg.h cod_pinv), rank decisions included."""
+    from oracle import pyoracle as po
+    mats = _pinv3_matrices()
+    dev = gpu_ctx.debug_pinv3(mats)
+    ranks = []
+    for k in range(mats.shape[0]):
+        ref, rk = po.pinv(mats[k]); ranks.append(rk)
+        nr, nd = np.isnan(ref), np.isnan(dev[k])
+        assert np.array_equal(nr, nd) and np.array_equal(ref.view(np.uint32)[~nr], dev[k].view(np.uint32)[~nd]), (k, mats[k], ref, dev[k])
+    print("pinv3: %d matrices bit-identical to the oracle; rank histogram %s" % (mats.shape[0], np.bincount(ranks, minlength=4).tolist()))
+    assert min(np.bincount(ranks, minlength=4)[1:]) > 100
+
+
+@pytest.mark.parametrize("name", ["wall_s10", "ground_s10_m", "ground_s05"])
+def test_double_w_option_on_degenerate_scenes(gpu_ctx, name):
+    """The per-voxel weight W (src/icet.cpp:320-321): by default as the reference takes it -- Eigen's float COD -- and with ICET_FLAG_DOUBLE_W (include/icet_hip.h) in double, the
+    default of rounds 2-5.  On the scenes where the two stand apart the DEFAULT follows the unmodified oracle: H^T W H within 1.5 x the oracle's own 32-trial spread in
+    every iteration, the pruned axes equal, pred_stds equal to 1e-3 where the oracle's are stable (ground_s10_m: the double path prunes nothing and reports pred_stds of
+    1e-4 where the reference reports -0.9995).  On an ordinary pair the two paths agree to float tolerance."""
+    from oracle import pyoracle as po
+    from icet_amd import api
+    a, b = _degenerate_scans(name)
+    ref = po.solve(a, b, trace=True); t = ref["trace"]
+    sp = _oracle_spread(a, b, ref)
+    out = {}
+    for flag in (0, api.FLAG_DOUBLE_W):
+        r = gpu_ctx.solve(a, b, 7, np.zeros(6), 24, 75, aux=True, flags=flag)
+        dH = float((np.abs(r["aux"]["htwh"] - t["HTWH"]).reshape(7, -1).max(1) / np.abs(t["HTWH"]).reshape(7, -1).max(1)).max())
+        out[flag] = (dH, r["aux"]["cond_info"][:, 6].astype(int).tolist(), float(np.abs(r["pred_stds"] - ref["pred_stds"]).max()))
+    print("%s: dH default (float COD) %.2e, ICET_FLAG_DOUBLE_W %.2e (oracle spread max %.2e p90 %.2e); pruned default %s double %s oracle %s; d pred_stds %.2e / %.2e (oracle spread %.2e)"
+          % (name, out[0][0], out[32][0], sp["H"], sp["H_p90"], out[0][1], out[32][1], t["pruned"].tolist(), out[0][2], out[32][2], sp["ps"]))
+    assert out[0][0] <= max(2e-3, HATCH * sp["H"]), (out, sp)
+    assert out[0][1] == t["pruned"].tolist() or not sp["pruned_same"], (out, t["pruned"])
+    if sp["ps"] < 1e-3:
+        assert out[0][2] <= 1e-3, out
+
+
+def test_double_w_option_on_an_ordinary_pair(gpu_ctx, frames):
+    from icet_amd import api
+    r0 = gpu_ctx.solve(frames[0], frames[1], 7, np.zeros(6), 24, 75)
+    r1 = gpu_ctx.solve(frames[0], frames[1], 7, np.zeros(6), 24, 75, flags=api.FLAG_DOUBLE_W)
+    _check_solution(r1, r0)
+    assert not np.array_equal(r0["X"], r1["X"])                            # (the flag does change the arithmetic)

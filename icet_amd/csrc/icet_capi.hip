@@ -122,6 +122,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         HIPCHK(c, dev_realloc(w.X, (size_t)np * 6));
         HIPCHK(c, dev_realloc(w.gn_part, (size_t)kGnPartWords));
         HIPCHK(c, dev_realloc(w.flags, np));
+        HIPCHK(c, dev_realloc(w.zero_rows, (size_t)np * 4));
         HIPCHK(c, dev_realloc(w.vrange, (size_t)np * 2));
         HIPCHK(c, dev_realloc(w.splitters, (size_t)np * kRankSortMaxBuckets)); HIPCHK(c, dev_realloc(w.n_buckets, np)); HIPCHK(c, dev_realloc(w.bucket_start, (size_t)np * (kRankSortMaxBuckets + 1)));
         if (c->h_desc) { HIPCHK(c, hipHostFree(c->h_desc)); c->h_desc = nullptr; }
@@ -610,7 +611,7 @@ icet_status icet_destroy(icet_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     Workspace& w = c->w;
     void* ps[] = {w.key64A, w.key64B, w.bin16, w.execbits, w.binpos, w.bkt, w.splitters, w.n_buckets, w.bucket_start, w.counts, w.tile_base, w.desc, w.seg_off, w.r1, w.cart1, w.keyA, w.keyB, w.valA, w.valB, w.pred, w.src,
-                  w.desc_rt, w.rt2, w.gn_part, w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.near_over, w.near_over_count, w.acc, w.xf, w.X, w.flags, w.vrange, w.tile_vr,
+                  w.desc_rt, w.rt2, w.gn_part, w.bin_count, w.bin_start, w.hotD, w.fitD, w.activeD, w.midD, w.hotS, w.fitS, w.slot_of_voxel, w.n_slots, w.near_over, w.near_over_count, w.acc, w.xf, w.X, w.flags, w.zero_rows, w.vrange, w.tile_vr,
                   w.sort_tmp, w.fit_items, w.fit_n_items, w.live_bins, w.n_live, w.thr, w.lut, w.keep_mask, w.keep_list, w.keep_state, w.keep_modes, w.edges, c->d_stage1, c->d_stage2, c->d_out, c->d_x0};
     for (void* p : ps) if (p) (void)hipFree(p);
     free_aux(c);

@@ -142,6 +142,7 @@ struct Workspace {
     float* gn_part = nullptr;                 // two-stage solve of fine grids: kGnPartWords floats of partial sums (icet_solve.hip)
     float* X = nullptr;                       // pairs x 6
     int32_t* flags = nullptr;                 // pairs: bit0 = scramble walk overflow
+    int32_t* zero_rows = nullptr;             // pairs x 4: exact-zero rows of scan 1 by the sign pattern of (y, x) -- the invalid returns of a real scan, thousands in ONE voxel (k_scan1_spherical counts, k_fit_cluster skips a bin that holds nothing else)
     int32_t* vrange = nullptr;                // pairs x 2: smallest / largest voxel id any scan-1 row of the pair has: the voxel multi-split's tables are touched inside it only
     int32_t* tile_vr = nullptr; size_t cap_tile_vr = 0;   // pairs x tiles x 2: the same per tile (k_scan1_spherical), reduced per pair by the rank sort's k_bin_scan
     float* thr = nullptr; int thr_T = 0, thr_P = 0;   // bin-edge tables: T+1 azimuth thresholds, then P+1 polar thresholds

@@ -75,9 +75,10 @@ constexpr int kSplitLoadThreads = 512;
 // (n1_dev: scan-1 row counts that only the device knows -- the descriptor holds an upper bound; this is the keyframe's first kernel, so it also
 // does k_patch_counts' job for its pair: one launch less in front of a sequential caller's keyframe)
 __global__ __launch_bounds__(kSplitLoadThreads) void k_rs_splitters(PairDesc* __restrict__ desc,
-                                                     uint32_t* __restrict__ splitters, int32_t* __restrict__ n_buckets, const int32_t* __restrict__ n1_dev, int32_t* __restrict__ flags) {
+                                                     uint32_t* __restrict__ splitters, int32_t* __restrict__ n_buckets, const int32_t* __restrict__ n1_dev, int32_t* __restrict__ flags, int32_t* __restrict__ zero_rows) {
     __shared__ uint32_t sm[kSamples];
     const int pair = blockIdx.x, tid = threadIdx.x;
+    if (tid < 4) zero_rows[4 * pair + tid] = 0;                 // the pair's exact-zero row counts (k_scan1_spherical adds, k_fit_cluster reads): cleared by the keyframe's first kernel
     if (tid == 0) flags[pair] = 0;                              // the pair's "bounded walk overflowed" flag (k_exec_flags / k_scramble_src set it): cleared here, the keyframe's first kernel, instead of by a memset node
     const PairDesc d = desc[pair];
     const int n = n1_dev ? max(0, min(n1_dev[pair], d.n1)) : d.n1;
@@ -589,7 +590,7 @@ hipError_t init_rank_sort_kernels() {
 }
 
 hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st, const int32_t* d_n1) {
-    k_rs_splitters<<<c.n_pairs, kSplitLoadThreads, 0, st>>>(w.desc, w.splitters, w.n_buckets, d_n1, w.flags);
+    k_rs_splitters<<<c.n_pairs, kSplitLoadThreads, 0, st>>>(w.desc, w.splitters, w.n_buckets, d_n1, w.flags, w.zero_rows);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -342,7 +342,7 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         nd->n_scan[nd->prev] = n; nd->ld_scan[nd->prev] = l;
         if (nd->pipelined) {
             icet_dev_scan a{nd->d_scan[nd->prev], n, l};
-            icet_params sp = nd->p.solve; sp.flags = ICET_FLAG_NONE;
+            icet_params sp = nd->p.solve; sp.flags = (nd->p.flags & ICET_NODE_DOUBLE_W) ? ICET_FLAG_DOUBLE_W : ICET_FLAG_NONE;
             nd->owner = 0;
             icet_status ks = icet_keyframe_device(nd->kf[0], &sp, 1, &a);
             if (ks != ICET_OK) { nd->err = icet_last_error(nd->kf[0]); return ks; }
@@ -415,7 +415,7 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
     }
     std::memcpy(nd->h_x0, nd->X0, sizeof(nd->X0));
     icet_dev_scan a{nd->d_scan[nd->prev], nd->n_scan[nd->prev], nd->ld_scan[nd->prev]}, b{nd->d_scan[cur], nk, lcur};
-    icet_params sp = nd->p.solve; sp.flags = ICET_FLAG_NONE;
+    icet_params sp = nd->p.solve; sp.flags = (nd->p.flags & ICET_NODE_DOUBLE_W) ? ICET_FLAG_DOUBLE_W : ICET_FLAG_NONE;
     hipStream_t so = st;                                          // the stream the result arrives on
     if (nd->pipelined) {
         // the loop against the keyframe parked one frame ago (the host has synchronised the filter's stream above), then -- behind
@@ -610,7 +610,7 @@ icet_status push_many_fast(icet_node* nd, const icet_dev_scan* fr, int K, icet_n
     }
     if (!nd->ev_loop) { NCHK(nd, hipEventCreateWithFlags(&nd->ev_loop, hipEventDisableTiming)); NCHK(nd, hipEventCreateWithFlags(&nd->ev_kf, hipEventDisableTiming)); }
     for (int i = 0; i < 2; i++) if (!nd->ev_loop2[i]) { NCHK(nd, hipEventCreateWithFlags(&nd->ev_loop2[i], hipEventDisableTiming)); NCHK(nd, hipEventCreateWithFlags(&nd->ev_kf2[i], hipEventDisableTiming)); }
-    icet_params sp = nd->p.solve; sp.flags = ICET_FLAG_NONE;
+    icet_params sp = nd->p.solve; sp.flags = (nd->p.flags & ICET_NODE_DOUBLE_W) ? ICET_FLAG_DOUBLE_W : ICET_FLAG_NONE;
     std::memcpy(nd->h_x0, nd->X0, sizeof(nd->X0));
     int prev = nd->prev, owner = nd->owner;
     // A burst is bound by the host: per frame three filter launches, the loop's graph (~80 us of host time) and the keyframe's graph (~140 us), all on one thread.

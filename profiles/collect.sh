@@ -5,6 +5,7 @@
 #   traffic_latest.json                          HBM bytes per k_gn_accumulate launch (FETCH_SIZE doubled as
 #                                                MI355X_MICROARCH.md section HBM prescribes for wide coalesced
 #                                                reads on gfx950, plus WRITE_SIZE), read by bench.py
+# (round 6: the counter passes collect for this library's kernels only -- --kernel-include-regex -- so that the pair generator's thousands of dispatches run unprofiled: a pass takes 20 s instead of 70)
 # Outputs go to gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/.
 set -e
 TAG=${1:-run}
@@ -19,11 +20,11 @@ grep -E "^\"Name\"|icet::" /tmp/p_stats/*/*kernel_stats.csv > $OUT/${TAG}_kernel
 python3 $R/profiles/summarize.py $OUT/${TAG}_kernel_stats.csv 7 > $OUT/${TAG}_kernels.txt
 python3 $R/profiles/trace_summary.py $(ls /tmp/p_stats/*/*kernel_trace.csv | head -1) >> $OUT/${TAG}_kernels.txt
 grep "^{\"metric\"" $OUT/stats.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- $CMD > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d /tmp/p_write -- $CMD > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/p_sq1 -- $CMD > $OUT/sq1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/p_sq2 -- $CMD > $OUT/sq2.log 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d /tmp/p_tcc -- $CMD > $OUT/tcc.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "icet" --output-format csv -d /tmp/p_fetch -- $CMD > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --kernel-include-regex "icet" --output-format csv -d /tmp/p_write -- $CMD > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-include-regex "icet" --output-format csv -d /tmp/p_sq1 -- $CMD > $OUT/sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-include-regex "icet" --output-format csv -d /tmp/p_sq2 -- $CMD > $OUT/sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --kernel-include-regex "icet" --output-format csv -d /tmp/p_tcc -- $CMD > $OUT/tcc.log 2>&1
 for d in p_fetch p_write p_sq1 p_sq2 p_tcc; do
   f=$(ls /tmp/$d/*/*counter_collection.csv | head -1)
   grep -E "Kernel_Name|icet::|onesweep" $f | grep -v "at::native" > /tmp/$d.csv

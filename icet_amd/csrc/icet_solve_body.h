@@ -92,15 +92,53 @@ __device__ __noinline__ void drain_near_overflow(const NearOverflow& o, int pair
     const float* px = d.s2; const float* py = px + d.ld2; const float* pz = px + 2 * (size_t)d.ld2;
     const int16_t* map = o.slot_of_voxel + (size_t)pair * ((V + 1) & ~1);
     const SlotHot* hs = o.hotS + (size_t)pair * V;
-    for (uint32_t e = threadIdx.x; e < nov; e += blockDim.x) {
-        const int i = (int)o.list[(size_t)d.off2 + e];
-        float qx, qy, qz;
-        transform_point(px[i], py[i], pz[i], xf, qx, qy, qz);
+    // The exact-zero rows of a real scan (5 k - 24 k per scan) all land on ONE point once t != 0 -- the transformed origin -- and when an update is mostly vertical that
+    // point lies next to the pole axis, where the polar look-up cells are ambiguous: every one of them is parked, thousands overflow the blocks' queues and arrive here
+    // (27 us of literal classifications by this one block: k_gn_solve 40 us instead of 13 in iterations 1-2 of a 256-pair batch of real scans).  Points whose transformed
+    // coordinates are bit for bit the transformed origin's are COUNTED; the point is classified once and its contribution added count times -- integer accumulation:
+    // exactly what that many runs of one add.
+    float o0, o1, o2;
+    transform_point(0.f, 0.f, 0.f, xf, o0, o1, o2);
+    __shared__ uint32_t s_org;
+    if (threadIdx.x == 0) s_org = 0u;
+    __syncthreads();
+    constexpr int kU = 4;                                                 // entries per thread per round, their loads in flight together: a round is two dependent memory round trips (index -> row)
+    for (uint32_t e0 = 0; e0 < nov; e0 += kU * blockDim.x) {              // block-uniform trip count: the ballots below need whole waves
+        int idx[kU]; bool have[kU]; float x[kU], y[kU], z[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) { const uint32_t e = e0 + u * blockDim.x + threadIdx.x; have[u] = e < nov; idx[u] = have[u] ? (int)o.list[(size_t)d.off2 + e] : 0; }
+#pragma unroll
+        for (int u = 0; u < kU; u++) { x[u] = have[u] ? px[idx[u]] : 0.f; y[u] = have[u] ? py[idx[u]] : 0.f; z[u] = have[u] ? pz[idx[u]] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            float qx, qy, qz;
+            transform_point(x[u], y[u], z[u], xf, qx, qy, qz);
+            const bool org = have[u] & (__float_as_uint(qx) == __float_as_uint(o0)) & (__float_as_uint(qy) == __float_as_uint(o1)) & (__float_as_uint(qz) == __float_as_uint(o2));
+            const unsigned long long m = __ballot(org);
+            if (m != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&s_org, (uint32_t)__popcll(m));
+            if (have[u] && !org) {
+                PointClass pc;
+                classify_literal(qx, qy, qz, map, o.thr, o.T, o.P, hs, pc, o.rt2 != 0);
+                if (pc.s >= 0)
+                    acc_add_hbm(acc_pair + (size_t)pc.s * kAccWords, 1u, pc.inb ? 1u : 0u, pc.dx, pc.dy, pc.dz, pc.dx * pc.dx, pc.dx * pc.dy, pc.dx * pc.dz,
+                                pc.dy * pc.dy, pc.dy * pc.dz, pc.dz * pc.dz);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_org != 0u) {
+        const unsigned long long cnt = s_org;
         PointClass pc;
-        classify_literal(qx, qy, qz, map, o.thr, o.T, o.P, hs, pc, o.rt2 != 0);
-        if (pc.s >= 0)
-            acc_add_hbm(acc_pair + (size_t)pc.s * kAccWords, 1u, pc.inb ? 1u : 0u, pc.dx, pc.dy, pc.dz, pc.dx * pc.dx, pc.dx * pc.dy, pc.dx * pc.dz,
-                        pc.dy * pc.dy, pc.dy * pc.dz, pc.dz * pc.dz);
+        classify_literal(o0, o1, o2, map, o.thr, o.T, o.P, hs, pc, o.rt2 != 0);
+        if (pc.s >= 0) {
+            unsigned long long* G = reinterpret_cast<unsigned long long*>(acc_pair + (size_t)pc.s * kAccWords);
+            atomicAdd(&G[0], cnt | ((pc.inb ? cnt : 0ull) << 32));
+            if (pc.inb) {
+                atomicAdd(&G[1], cnt * to_fix(pc.dx)); atomicAdd(&G[2], cnt * to_fix(pc.dy)); atomicAdd(&G[3], cnt * to_fix(pc.dz));
+                atomicAdd(&G[4], cnt * to_fix(pc.dx * pc.dx)); atomicAdd(&G[5], cnt * to_fix(pc.dx * pc.dy)); atomicAdd(&G[6], cnt * to_fix(pc.dx * pc.dz));
+                atomicAdd(&G[7], cnt * to_fix(pc.dy * pc.dy)); atomicAdd(&G[8], cnt * to_fix(pc.dy * pc.dz)); atomicAdd(&G[9], cnt * to_fix(pc.dz * pc.dz));
+            }
+        }
     }
 }
 

@@ -15,7 +15,8 @@ if os.environ.get("REAL"):
     pairs = []
     for k in range(NP):
         R = torch.as_tensor(ls.real_batch_rotation(k), device=dev)
-        pairs.append(((R @ base[k % 2][0]).contiguous(), (R @ base[k % 2][1]).contiguous()))
+        kind = int(os.environ["REALKIND"]) if os.environ.get("REALKIND") else k % 2
+        pairs.append(((R @ base[kind][0]).contiguous(), (R @ base[kind][1]).contiguous()))
 SC = float(os.environ.get("SCALE2", "1"))
 if SC != 1: pairs = [(a, b[:, :int(b.shape[1] * SC) // 256 * 256].contiguous()) for a, b in pairs]
 ONLY = os.environ.get("ONLY")

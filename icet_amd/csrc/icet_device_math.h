@@ -141,84 +141,182 @@ __device__ inline bool eig3_sym(float a00, float a10, float a11, float a20, floa
     return ok;
 }
 
-// Householder vector of x[0..m) (stride in floats): essential part overwrites x[1..m), returns tau/beta.
-__device__ inline void make_householder(float* x, int m, int stride, float& tau, float& beta) {
-#pragma clang fp contract(off)
-    float tailSq = 0.f;
-    for (int i = 1; i < m; i++) tailSq += x[i * stride] * x[i * stride];
-    float c0 = x[0];
-    if (tailSq <= FLT_MIN) {
-        tau = 0.f; beta = c0;
-        for (int i = 1; i < m; i++) x[i * stride] = 0.f;
-    } else {
-        beta = sqrtf(c0 * c0 + tailSq);
-        if (c0 >= 0.f) beta = -beta;
-        for (int i = 1; i < m; i++) x[i * stride] = x[i * stride] / (c0 - beta);
-        tau = (beta - c0) / beta;
-    }
-}
-
-// Symmetric 6x6 (row-major, lower triangle read): eigenvalues ascending, eigenvectors = columns of Q.
-// kVec = false computes the eigenvalues only: the tridiagonal recurrences never read Q, so the values are
-// bit-identical to the full solve at less than half the work.
-// Work arrays come from the caller (A[36], sm[30]: h | v | p | diag | sub), so that the literal 6x6 tail can keep them in LDS.
-template <bool kVec = true>
-__device__ inline bool eig6_sym_core(const float* Ain, float ev[6], float* Q, float* A, float* sm) {
+// SelfAdjointEigenSolver<MatrixXf> on a symmetric 6x6 (row-major, lower triangle read; src/icet.cpp:455-458): eigenvalues ascending, eigenvectors = columns of Q --
+// Householder tridiagonalisation, implicit symmetric QR with Wilkinson shift, selection sort -- on REGISTERS, by a whole wave (round 6; rounds 4-5 ran it on one
+// lane through LDS arrays with run-time indices: 39 us of the literal route's 67; here 16).
+// Every lane evaluates the scalar recurrences -- scaling, the five Householder steps of the tridiagonalisation, the implicit-QR sweeps on (diag, sub), deflation,
+// the final selection sort -- on the same values in the same order of float operations as the one-lane form (all loops unrolled, run-time positions turned into
+// predicates and selects, so that nothing is indexed dynamically and nothing leaves the register file), and the one part whose work is per column / per row is
+// spread over lanes: lane c < 6 accumulates column c of Q = H0 H1 ... H4, a 6 x 6 transpose through v_readlane hands lane r < 6 ROW r, and every Givens rotation of a sweep
+// touches two registers per lane.  Out: ev[6] on every lane, Qrow[j] = Q[lane][j] on lanes 0..5 (other lanes: undefined).  Bit-identical to the CPU checker's
+// one-thread form (tests/test_gpu_parity.py::test_gn_tail_literal_bits).  What it costs is the serial chain: ~60 rotations of ~100 dependent instructions.
+__device__ __forceinline__ void swap_if(bool c, float& a, float& b) { const float t = a; a = c ? b : a; b = c ? t : b; }
+__device__ __forceinline__ void swap_if(bool c, int& a, int& b) { const int t = a; a = c ? b : a; b = c ? t : b; }
+__device__ __forceinline__ float sel6(const float a[6], int i) { float r = a[0]; r = i == 1 ? a[1] : r; r = i == 2 ? a[2] : r; r = i == 3 ? a[3] : r; r = i == 4 ? a[4] : r; r = i == 5 ? a[5] : r; return r; }
+__device__ inline bool eig6_sym_wave(const float* Ain, float ev[6], float Qrow[6], int lane) {
 #pragma clang fp contract(off)
     constexpr int n = 6;
-    float* h = sm; float* v = sm + 6; float* p = sm + 12; float* diag = sm + 18; float* sub = sm + 24;
+    float A[36];
     float scale = 0.f;
-    for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) scale = fmaxf(scale, fabsf(Ain[i * n + j]));
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) scale = fmaxf(scale, fabsf(Ain[i * n + j]));
+    }
     if (scale == 0.f) scale = 1.f;
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) A[i * n + j] = (j <= i) ? Ain[i * n + j] / scale : 0.f;
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int j = 0; j < n; j++) A[i * n + j] = (j <= i) ? Ain[i * n + j] / scale : 0.f;
+    }
+    float h[5];
+#pragma unroll
     for (int i = 0; i < n - 1; i++) {
-        int rem = n - i - 1;
+        const int rem = n - i - 1;
+        // the Householder vector of column i below the diagonal: essential part in place, tau / beta
         float tau, beta;
-        make_householder(&A[(i + 1) * n + i], rem, n, tau, beta);
+        {
+            float tailSq = 0.f;
+#pragma unroll
+            for (int t = 1; t < rem; t++) tailSq += A[(i + 1 + t) * n + i] * A[(i + 1 + t) * n + i];
+            const float c0 = A[(i + 1) * n + i];
+            const bool flat = tailSq <= FLT_MIN;
+            float b2 = sqrtf(c0 * c0 + tailSq);
+            if (c0 >= 0.f) b2 = -b2;
+            beta = flat ? c0 : b2;
+            tau = flat ? 0.f : (b2 - c0) / b2;
+#pragma unroll
+            for (int t = 1; t < rem; t++) A[(i + 1 + t) * n + i] = flat ? 0.f : A[(i + 1 + t) * n + i] / (c0 - b2);
+        }
         A[(i + 1) * n + i] = 1.f;
+        float v[5], p[5];
+#pragma unroll
         for (int k = 0; k < rem; k++) v[k] = A[(i + 1 + k) * n + i];
+#pragma unroll
         for (int a = 0; a < rem; a++) {
             float s = 0.f;
+#pragma unroll
             for (int b = 0; b < rem; b++) {
-                int ra = i + 1 + a, rb = i + 1 + b;
-                float m = (ra >= rb) ? A[ra * n + rb] : A[rb * n + ra];
+                const int ra = i + 1 + a, rb = i + 1 + b;
+                const float m = (ra >= rb) ? A[ra * n + rb] : A[rb * n + ra];
                 s += m * (tau * v[b]);
             }
             p[a] = s;
         }
-        float dot = 0.f; for (int k = 0; k < rem; k++) dot += p[k] * v[k];
-        float alpha = tau * -0.5f * dot;
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < rem; k++) dot += p[k] * v[k];
+        const float alpha = tau * -0.5f * dot;
+#pragma unroll
         for (int k = 0; k < rem; k++) p[k] += alpha * v[k];
-        for (int a = 0; a < rem; a++) for (int b = 0; b <= a; b++)
-            A[(i + 1 + a) * n + i + 1 + b] -= v[a] * p[b] + p[a] * v[b];
+#pragma unroll
+        for (int a = 0; a < rem; a++) {
+#pragma unroll
+            for (int b = 0; b <= a; b++) A[(i + 1 + a) * n + i + 1 + b] -= v[a] * p[b] + p[a] * v[b];
+        }
         A[(i + 1) * n + i] = beta;
         h[i] = tau;
     }
+    float diag[6], sub[6];
+#pragma unroll
     for (int i = 0; i < n; i++) { diag[i] = A[i * n + i]; sub[i] = 0.f; }
+#pragma unroll
     for (int i = 0; i < n - 1; i++) sub[i] = A[(i + 1) * n + i];
-    if (kVec) {
-        for (int i = 0; i < 36; i++) Q[i] = 0.f;
-        for (int i = 0; i < n; i++) Q[i * n + i] = 1.f;
-        for (int k = n - 2; k >= 0; k--) {
-            int rem = n - k - 1;
-            v[0] = 1.f;
-            for (int t = 1; t < rem; t++) v[t] = A[(k + 1 + t) * n + k];
-            for (int col = 0; col < n; col++) {
-                float s = 0.f;
-                for (int t = 0; t < rem; t++) s += v[t] * Q[(k + 1 + t) * n + col];
-                s *= h[k];
-                for (int t = 0; t < rem; t++) Q[(k + 1 + t) * n + col] -= s * v[t];
+    // Q = H0 ... H4 applied to I, column `lane` (lanes >= 6 run along on column 5's unit vector: never read)
+    float Qc[6];
+    const int col = lane < 6 ? lane : 5;
+#pragma unroll
+    for (int r = 0; r < n; r++) Qc[r] = (r == col) ? 1.f : 0.f;
+#pragma unroll
+    for (int k = n - 2; k >= 0; k--) {
+        const int rem = n - k - 1;
+        float v[5];
+        v[0] = 1.f;
+#pragma unroll
+        for (int t = 1; t < rem; t++) v[t] = A[(k + 1 + t) * n + k];
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < rem; t++) s += v[t] * Qc[k + 1 + t];
+        s *= h[k];
+#pragma unroll
+        for (int t = 0; t < rem; t++) Qc[k + 1 + t] -= s * v[t];
+    }
+#pragma unroll
+    for (int j = 0; j < n; j++) {
+#pragma unroll
+        for (int r = 0; r < n; r++) {
+            const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Qc[r]), j));   // Q[r][j]
+            if (r == 0) Qrow[j] = t; else Qrow[j] = (lane == r) ? t : Qrow[j];
+        }
+    }
+    // tridiag_eigen<6, true>
+    int end = n - 1, start = 0, iter = 0;
+    const float precision = 2.f * FLT_EPSILON;
+    while (end > 0) {
+#pragma unroll
+        for (int i = 0; i < n - 1; i++) {
+            const bool small = fabsf(sub[i]) <= (fabsf(diag[i]) + fabsf(diag[i + 1])) * precision || fabsf(sub[i]) <= FLT_MIN;
+            sub[i] = (i >= start && i < end && small) ? 0.f : sub[i];
+        }
+#pragma unroll
+        for (int c = n - 1; c >= 1; c--) end = (end == c && sub[c - 1] == 0.f) ? c - 1 : end;
+        if (end <= 0) break;
+        iter++;
+        if (iter > 30 * n) break;
+        start = end - 1;
+#pragma unroll
+        for (int c = n - 2; c >= 1; c--) start = (start == c && sub[c - 1] != 0.f) ? c - 1 : start;
+        // tridiag_qr_step<6, true>(diag, sub, start, end, Q)
+        const float d_e1 = sel6(diag, end - 1), d_e = sel6(diag, end);
+        const float td = (d_e1 - d_e) * 0.5f;
+        const float e = sel6(sub, end - 1);
+        float mu = d_e;
+        if (td == 0.f) {
+            mu -= fabsf(e);
+        } else if (e != 0.f) {
+            const float e2 = e * e;
+            const float hy = eigen_hypot(td, e);
+            if (e2 == 0.f) mu -= e / ((td + (td > 0.f ? hy : -hy)) / e);
+            else           mu -= e2 / (td + (td > 0.f ? hy : -hy));
+        }
+        float x = sel6(diag, start) - mu;
+        float z = sel6(sub, start);
+#pragma unroll
+        for (int k = 0; k < n - 1; k++) {
+            if (k >= start && k < end && z != 0.f) {                 // (the same on every lane)
+                float c, s; make_givens(x, z, c, s);
+                const float sdk  = s * diag[k] + c * sub[k];
+                const float dkp1 = s * sub[k] + c * diag[k + 1];
+                diag[k]     = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+                diag[k + 1] = s * sdk + c * dkp1;
+                sub[k]      = c * sdk - s * dkp1;
+                if (k > 0) sub[k > 0 ? k - 1 : 0] = (k > start) ? c * sub[k > 0 ? k - 1 : 0] - s * z : sub[k > 0 ? k - 1 : 0];
+                x = sub[k];
+                if (k < n - 2) {
+                    const bool more = k < end - 1;
+                    z = more ? -s * sub[k + 1] : z;
+                    sub[k + 1] = more ? c * sub[k + 1] : sub[k + 1];
+                }
+                const float xi = Qrow[k], yi = Qrow[k + 1];
+                Qrow[k]     = c * xi - s * yi;
+                Qrow[k + 1] = s * xi + c * yi;
             }
         }
     }
-    bool ok = tridiag_eigen<6, kVec>(diag, sub, Q);
+    const bool ok = iter <= 30 * n;
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < n - 1; i++) {
+            int k = i; float mn = diag[i];
+#pragma unroll
+            for (int j = i + 1; j < n; j++) { const bool lt = diag[j] < mn; mn = lt ? diag[j] : mn; k = lt ? j : k; }
+#pragma unroll
+            for (int j = i + 1; j < n; j++) { swap_if(k == j, diag[i], diag[j]); swap_if(k == j, Qrow[i], Qrow[j]); }
+        }
+    }
+#pragma unroll
     for (int i = 0; i < n; i++) ev[i] = diag[i] * scale;
     return ok;
-}
-template <bool kVec = true>
-__device__ inline bool eig6_sym(const float* Ain, float ev[6], float* Q) {
-    float A[36], sm[30];
-    return eig6_sym_core<kVec>(Ain, ev, Q, A, sm);
 }
 
 // Inverse of a symmetric positive-definite 6x6 (row-major) by Cholesky, fully unrolled (registers only).
@@ -352,8 +450,6 @@ __device__ inline void pinv3_sym_fast(const float a[6], float rel_tol, float w[6
 // Written on REGISTERS: every index is a compile-time constant (a column exchange is a pair of selects per entry, a loop up to the run-time rank is unrolled
 // under guards), because k_gn_solve has no scratch memory to spare -- a first version with local arrays cost each solve launch 35 us.
 struct Col3 { float x, y, z; };
-__device__ __forceinline__ void swap_if(bool c, float& a, float& b) { const float t = a; a = c ? b : a; b = c ? t : b; }
-__device__ __forceinline__ void swap_if(bool c, int& a, int& b) { const int t = a; a = c ? b : a; b = c ? t : b; }
 __device__ __forceinline__ void swap_if(bool c, Col3& a, Col3& b) { swap_if(c, a.x, b.x); swap_if(c, a.y, b.y); swap_if(c, a.z, b.z); }
 __device__ inline void cod_pinv3_lane(const float Ain[9], float pinv[9]) {
 #pragma clang fp contract(off)
@@ -504,26 +600,31 @@ __device__ inline void cod_pinv3_lane(const float Ain[9], float pinv[9]) {
 // checker over condition numbers 5e4 .. 3e7, tests/test_gpu_parity.py::test_gn_tail_literal_bits).  Rounds 2-4 used an eigenvalue rule
 // (|lambda_k| > 6 eps lambda_max) for the rank here; scripts/rank_rule_study.py finds it disagreeing with the pivot rule on 35 of 8400
 // matrices around cond = 1.4e6 = 1 / (6 eps), right above checkCondition's cutoff.
-// Rare by construction (a tunnel, a single wall, open ground), so it is written for fidelity, not speed: generic small matrices in scratch.
+// Rare by construction (a tunnel, a single wall, open ground).  Rounds 4-5 wrote it for fidelity with generic small matrices in an LDS workspace (67 us per
+// evaluation); round 6 moved the two decompositions into registers (eig6_sym_wave, cod_pinv_c6_wave: 32 us, the same bits).
 
-// Every array of the literal tail lives in ONE workspace the caller places in LDS and one WAVE walks through it: no scratch memory in the
-// kernels that hold this rarely taken branch (as local arrays it cost k_gn_solve 3.5 KB of scratch per lane, and arrays of the hot Cholesky
-// route whose address escaped into the call would have left their registers).
+// What the phases of the literal tail hand to each other lives in ONE workspace the caller places in LDS: input, results, and the operands of the small products
+// (no scratch memory in the kernels that hold this rarely taken branch).
 struct GnTailWs {
     float H[36], g[6];                                            // in
     float cov[36], ps[6], dx[6], ev[6]; int pruned, rank;         // out
-    float qr[36], C[36], Y[36]; double G[36], Ginv[36];           // cod_pinv
-    float hc[6], nUpd[6], nDir[6]; int perm[6];
-    float A[36], sm[30];                                          // eig6_sym_core
     float U2[36], L2[36], lam[36], U2t[36], T1[36], innards[36], inv[36], T2[36], lhs[36];
+#ifdef ICET_TAIL_TIMING
+    unsigned long long ts[8];                                     // diagnostic build: wall_clock64 at the phase boundaries of gn_tail_literal
+#endif
 };
 
-// The wave walks the workspace TOGETHER (round 5b; one lane alone took 157 us per evaluation, half of it in the six small matrix products): whatever is
+// The wave works TOGETHER (round 5b; one lane alone took 157 us per evaluation, half of it in the six small matrix products): whatever is
 // independent per column or per element -- a product's 36 entries, a Householder reflector applied to the columns right of the pivot, the back
 // substitution of each right-hand side -- goes to one lane per column / element, each with ITS sequential order of float operations unchanged, so the bits
-// are the single lane's; scalar decisions (pivot search, the reflector's norm, rank) are evaluated by every lane on the same LDS words.  Between phases a
-// wave-level fence: LDS operations of one wave complete in program order, the fence keeps the compiler from moving or caching them.
+// are the single lane's; scalar decisions (pivot search, the reflector's norm, rank) are evaluated by every lane on the same values.  Between phases that
+// meet in LDS a wave-level fence: LDS operations of one wave complete in program order, the fence keeps the compiler from moving or caching them.
 #define ICET_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#ifdef ICET_TAIL_TIMING
+#define ICET_TS(k) do { if ((threadIdx.x & 63u) == 0) w.ts[k] = wall_clock64(); } while (0)
+#else
+#define ICET_TS(k) do { } while (0)
+#endif
 
 // C (ar x bc) = A (ar x ac) * B (ac x bc), row-major, each entry a sequential float sum starting from 0 in index order (zero terms included); one lane per entry
 __device__ inline void mm_seq(const float* A, int ar, int ac, const float* B, int bc, float* C, int lane) {
@@ -537,149 +638,195 @@ __device__ inline void mm_seq(const float* A, int ar, int ac, const float* B, in
     ICET_WSYNC();
 }
 
-// CompleteOrthogonalDecomposition<MatrixXf>(A).pseudoInverse() for A rows x cols (<= 6 x 6, row-major); out is cols x rows.  Returns the rank (wave-uniform).
-__device__ inline int cod_pinv(const float* Ain, int rows, int cols, float* pinv, GnTailWs& w, int lane) {
+// CompleteOrthogonalDecomposition<MatrixXf>(A).pseudoInverse() for a rows x 6 matrix A (rows <= 6, row-major in LDS: the two calls of the literal route; out is 6 x rows)
+// on REGISTERS (round 6; rounds 4-5: the same statements over LDS words, a fence between phases, 12.5 us per call; here 6.5): lane j < 6 owns COLUMN j of the working matrix qr (and of C = Q^T I and of the solution Y), its two column norms and its
+// entry of the permutation; what the one-matrix algorithm reads from another column (the pivot column's reflector, R's entries in the back substitution) travels by
+// v_readlane; scalar decisions (pivot search, the reflector's norm, the rank) are evaluated by every lane on the same broadcast values.  The rank-deficient branch keeps its
+// one-lane-per-entry Gauss-Jordan in double on a fixed 6 x 6 lane grid (rows and pivot row exchanged by ds_bpermute).  All loops unrolled, run-time sizes as predicates: no
+// local array is indexed dynamically, nothing goes through LDS but the input and the result.  Returns the rank (wave-uniform); bit-identical to the CPU checker's cod_pinv.
+__device__ __forceinline__ float rl(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
+__device__ __forceinline__ double rld(double x, int l) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ inline int cod_pinv_c6_wave(const float* Ain, int rows_in, float* pinv, int lane) {
 #pragma clang fp contract(off)
-    const int size = rows < cols ? rows : cols;
-    float* qr = w.qr; float* hc = w.hc; int* perm = w.perm; float* normsUpd = w.nUpd; float* normsDir = w.nDir;
-    if (lane < rows * cols) qr[lane] = Ain[lane];
-    ICET_WSYNC();
-    if (lane < cols) {
-        const int k = lane;
-        float s = 0.f; for (int i = 0; i < rows; i++) s += qr[i * cols + k] * qr[i * cols + k];
-        normsDir[k] = sqrtf(s); normsUpd[k] = normsDir[k]; perm[k] = k;
+    constexpr int cols = 6;
+    const int rows = __builtin_amdgcn_readfirstlane(rows_in);
+    const int size = rows;                                        // rows <= cols
+    const int cj = lane < cols ? lane : cols - 1;                 // (lanes >= 6 run along on column 5: never read, never written out)
+    float q[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) q[i] = (i < rows) ? Ain[(i < rows ? i : 0) * cols + cj] : 0.f;
+    float nDir, nUpd; int perm = cj;
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) s = (i < rows) ? s + q[i] * q[i] : s;
+        nDir = sqrtf(s); nUpd = nDir;
     }
-    ICET_WSYNC();
-    float maxn = 0.f; for (int k = 0; k < cols; k++) maxn = fmaxf(maxn, normsUpd[k]);      // (NaN norms: fmaxf and std::max(a, b) = (a < b) ? b : a both keep the running value)
+    float maxn = 0.f;
+#pragma unroll
+    for (int k = 0; k < cols; k++) maxn = fmaxf(maxn, rl(nUpd, k));
     const float th = maxn * FLT_EPSILON; const float threshold_helper = (th * th) / float(rows);
-    const float norm_downdate_threshold = 3.4526698300124393e-04f;                          // sqrt(FLT_EPSILON), correctly rounded
+    const float norm_downdate_threshold = 3.4526698300124393e-04f;
     int nonzero_pivots = size; float maxpivot = 0.f;
-    for (int k = 0; k < size; k++) {
-        int big = k; float bn = normsUpd[k];
-        for (int j = k + 1; j < cols; j++) if (normsUpd[j] > bn) { bn = normsUpd[j]; big = j; }
-        const float big_sq = bn * bn;
-        if (nonzero_pivots == size && big_sq < threshold_helper * float(rows - k)) nonzero_pivots = k;
-        if (k != big) {                                           // (wave-uniform)
-            float t0 = 0.f, t1 = 0.f;
-            if (lane < rows) { t0 = qr[lane * cols + k]; t1 = qr[lane * cols + big]; }
-            const float u0 = normsUpd[k], u1 = normsUpd[big], d0 = normsDir[k], d1 = normsDir[big]; const int p0 = perm[k], p1 = perm[big];
-            ICET_WSYNC();
-            if (lane < rows) { qr[lane * cols + k] = t1; qr[lane * cols + big] = t0; }
-            if (lane == 0) { normsUpd[k] = u1; normsUpd[big] = u0; normsDir[k] = d1; normsDir[big] = d0; perm[k] = p1; perm[big] = p0; }
-            ICET_WSYNC();
-        }
-        // make_householder on column k, rows k .. rows - 1: the scalars by every lane, the essential part one lane per entry
-        const int m = rows - k;
-        float tailSq = 0.f;
-        for (int i = 1; i < m; i++) { const float x = qr[(k + i) * cols + k]; tailSq += x * x; }
-        const float c0 = qr[k * cols + k];
-        float tau, beta;
-        const bool flat = tailSq <= FLT_MIN;
-        if (flat) { tau = 0.f; beta = c0; }
-        else { beta = sqrtf(c0 * c0 + tailSq); if (c0 >= 0.f) beta = -beta; tau = (beta - c0) / beta; }
-        ICET_WSYNC();
-        if (lane >= 1 && lane < m) { const int at = (k + lane) * cols + k; qr[at] = flat ? 0.f : qr[at] / (c0 - beta); }
-        if (lane == 0) { qr[k * cols + k] = beta; hc[k] = tau; }
-        if (fabsf(beta) > maxpivot) maxpivot = fabsf(beta);
-        ICET_WSYNC();
-        if (lane > k && lane < cols) {                            // H = I - tau v v^T on the bottom-right corner, a lane per column
-            const int j = lane;
-            float sdot = qr[k * cols + j];
-            for (int i = k + 1; i < rows; i++) sdot += qr[i * cols + k] * qr[i * cols + j];
-            sdot *= tau;
-            qr[k * cols + j] -= sdot;
-            for (int i = k + 1; i < rows; i++) qr[i * cols + j] -= sdot * qr[i * cols + k];
-            if (normsUpd[j] != 0.f) {                             // norm down-dating of the same column
-                float temp = fabsf(qr[k * cols + j]) / normsUpd[j];
-                temp = (1.f + temp) * (1.f - temp);
-                temp = temp < 0.f ? 0.f : temp;
-                const float ratio = normsUpd[j] / normsDir[j];
-                const float temp2 = temp * ratio * ratio;
-                if (temp2 <= norm_downdate_threshold) {
-                    float s2 = 0.f; for (int i = k + 1; i < rows; i++) s2 += qr[i * cols + j] * qr[i * cols + j];
-                    normsDir[j] = sqrtf(s2); normsUpd[j] = normsDir[j];
-                } else {
-                    normsUpd[j] *= sqrtf(temp);
+    float hc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (k < size) {
+            int big = k; float bn = rl(nUpd, k);
+#pragma unroll
+            for (int j = k + 1; j < cols; j++) { const float nj = rl(nUpd, j); const bool gt = nj > bn; bn = gt ? nj : bn; big = gt ? j : big; }
+            big = __builtin_amdgcn_readfirstlane(big);
+            const float big_sq = bn * bn;
+            if (nonzero_pivots == size && big_sq < threshold_helper * float(rows - k)) nonzero_pivots = k;
+            if (k != big) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) { const float a = rl(q[i], k), b = rl(q[i], big); q[i] = (lane == k) ? b : (lane == big) ? a : q[i]; }
+                { const float a = rl(nUpd, k), b = rl(nUpd, big); nUpd = (lane == k) ? b : (lane == big) ? a : nUpd; }
+                { const float a = rl(nDir, k), b = rl(nDir, big); nDir = (lane == k) ? b : (lane == big) ? a : nDir; }
+                { const int a = __builtin_amdgcn_readlane(perm, k), b = __builtin_amdgcn_readlane(perm, big); perm = (lane == k) ? b : (lane == big) ? a : perm; }
+            }
+            // make_householder on column k, rows k .. rows - 1
+            float x[6];
+#pragma unroll
+            for (int i = k; i < 6; i++) x[i] = rl(q[i], k);
+            float tailSq = 0.f;
+#pragma unroll
+            for (int i = k + 1; i < 6; i++) tailSq = (i < rows) ? tailSq + x[i] * x[i] : tailSq;
+            const float c0 = x[k];
+            float tau, beta;
+            const bool flat = tailSq <= FLT_MIN;
+            if (flat) { tau = 0.f; beta = c0; }
+            else { beta = sqrtf(c0 * c0 + tailSq); if (c0 >= 0.f) beta = -beta; tau = (beta - c0) / beta; }
+            float e[6];
+#pragma unroll
+            for (int i = k + 1; i < 6; i++) e[i] = (i < rows) ? (flat ? 0.f : x[i] / (c0 - beta)) : 0.f;
+            if (lane == k) {
+                q[k] = beta;
+#pragma unroll
+                for (int i = k + 1; i < 6; i++) q[i] = (i < rows) ? e[i] : q[i];
+            }
+            hc[k] = tau;
+            if (fabsf(beta) > maxpivot) maxpivot = fabsf(beta);
+            if (lane > k && lane < cols) {                        // H = I - tau v v^T on the columns right of the pivot, a lane per column
+                float sdot = q[k];
+#pragma unroll
+                for (int i = k + 1; i < 6; i++) sdot = (i < rows) ? sdot + e[i] * q[i] : sdot;
+                sdot *= tau;
+                q[k] -= sdot;
+#pragma unroll
+                for (int i = k + 1; i < 6; i++) q[i] = (i < rows) ? q[i] - sdot * e[i] : q[i];
+                if (nUpd != 0.f) {                                // norm down-dating of the same column
+                    float temp = fabsf(q[k]) / nUpd;
+                    temp = (1.f + temp) * (1.f - temp);
+                    temp = temp < 0.f ? 0.f : temp;
+                    const float ratio = nUpd / nDir;
+                    const float temp2 = temp * ratio * ratio;
+                    if (temp2 <= norm_downdate_threshold) {
+                        float s2 = 0.f;
+#pragma unroll
+                        for (int i = k + 1; i < 6; i++) s2 = (i < rows) ? s2 + q[i] * q[i] : s2;
+                        nDir = sqrtf(s2); nUpd = nDir;
+                    } else {
+                        nUpd *= sqrtf(temp);
+                    }
                 }
             }
         }
-        ICET_WSYNC();
     }
     const float premult = fabsf(maxpivot) * (FLT_EPSILON * float(size));
     int rank = 0;
-    for (int i = 0; i < nonzero_pivots; i++) rank += (fabsf(qr[i * cols + i]) > premult) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) rank += (i < nonzero_pivots && fabsf(rl(q[i], i)) > premult) ? 1 : 0;
+    rank = __builtin_amdgcn_readfirstlane(rank);
     if (lane < cols * rows) pinv[lane] = 0.f;
-    ICET_WSYNC();
     if (rank == 0) return 0;
-    float* C = w.C;                                               // Q^T restricted to the first `rank` reflectors, applied to I (rows x rows)
-    if (lane < rows * rows) C[lane] = (lane / rows == lane % rows) ? 1.f : 0.f;
-    ICET_WSYNC();
-    for (int k = 0; k < rank; k++) {
-        if (lane < rows) {
-            const int j = lane;
-            float sd = C[k * rows + j];
-            for (int i = k + 1; i < rows; i++) sd += qr[i * cols + k] * C[i * rows + j];
+    float Cc[6];                                                  // Q^T restricted to the first `rank` reflectors, applied to I (rows x rows): column `lane`
+#pragma unroll
+    for (int i = 0; i < 6; i++) Cc[i] = (i == cj) ? 1.f : 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (k < rank) {
+            float v[6];
+#pragma unroll
+            for (int i = k + 1; i < 6; i++) v[i] = rl(q[i], k);
+            float sd = Cc[k];
+#pragma unroll
+            for (int i = k + 1; i < 6; i++) sd = (i < rows) ? sd + v[i] * Cc[i] : sd;
             sd *= hc[k];
-            C[k * rows + j] -= sd;
-            for (int i = k + 1; i < rows; i++) C[i * rows + j] -= sd * qr[i * cols + k];
+            Cc[k] -= sd;
+#pragma unroll
+            for (int i = k + 1; i < 6; i++) Cc[i] = (i < rows) ? Cc[i] - sd * v[i] : Cc[i];
         }
-        ICET_WSYNC();
     }
-    float* Y = w.Y;                                               // permuted solution, cols x rows
-    if (lane < cols * rows) Y[lane] = 0.f;
-    ICET_WSYNC();
+    float R[6][6];                                                // R[i][t], t >= i: the upper triangle of qr, on every lane
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+        for (int t = i; t < 6; t++) R[i][t] = rl(q[i], t);
+    }
+    float Yc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                 // permuted solution (cols x rows), column `lane`
     if (rank == cols) {
-        if (lane < rows) {
-            const int j = lane;
-            for (int i = rank - 1; i >= 0; i--) {
-                float sd = C[i * rows + j];
-                for (int t = i + 1; t < rank; t++) sd -= qr[i * cols + t] * Y[t * rows + j];
-                Y[i * rows + j] = sd / qr[i * cols + i];
-            }
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {
+            float sd = Cc[i];
+#pragma unroll
+            for (int t = i + 1; t < 6; t++) sd -= R[i][t] * Yc[t];
+            Yc[i] = sd / R[i][i];
         }
-        ICET_WSYNC();
     } else {
-        // X = [R11 R12] (rank x cols); X^+ = X^T (X X^T)^-1 in double (what the Z-reflector stage of Eigen's COD yields); Y = X^+ C(0:rank, :)
-        double* G = w.G; double* Ginv = w.Ginv;
-        if (lane < rank * rank) {
-            const int i = lane / rank, j = lane - i * rank;
-            double sd = 0; for (int t = 0; t < cols; t++) { const double xi = (t >= i) ? (double)qr[i * cols + t] : 0.0, xj = (t >= j) ? (double)qr[j * cols + t] : 0.0; sd += xi * xj; }
-            G[i * rank + j] = sd; Ginv[i * rank + j] = (i == j) ? 1.0 : 0.0;
-        }
-        ICET_WSYNC();
-        for (int p = 0; p < rank; p++) {                          // Gauss-Jordan with partial pivoting (G is SPD); row operations: a lane per entry
-            int piv = p; for (int i = p + 1; i < rank; i++) if (fabs(G[i * rank + p]) > fabs(G[piv * rank + p])) piv = i;
-            if (piv != p) {
-                double g0 = 0, g1 = 0, h0 = 0, h1 = 0;
-                if (lane < rank) { g0 = G[p * rank + lane]; g1 = G[piv * rank + lane]; h0 = Ginv[p * rank + lane]; h1 = Ginv[piv * rank + lane]; }
-                ICET_WSYNC();
-                if (lane < rank) { G[p * rank + lane] = g1; G[piv * rank + lane] = g0; Ginv[p * rank + lane] = h1; Ginv[piv * rank + lane] = h0; }
-                ICET_WSYNC();
-            }
-            const double d = G[p * rank + p];
-            ICET_WSYNC();
-            if (lane < rank) { G[p * rank + lane] /= d; Ginv[p * rank + lane] /= d; }
-            ICET_WSYNC();
-            double f = 0, gp = 0, hp = 0; bool mine = false; int ii = 0, jj = 0;
-            if (lane < rank * rank) { ii = lane / rank; jj = lane - ii * rank; mine = ii != p; if (mine) { f = G[ii * rank + p]; gp = G[p * rank + jj]; hp = Ginv[p * rank + jj]; } }
-            ICET_WSYNC();
-            if (mine) { G[ii * rank + jj] -= f * gp; Ginv[ii * rank + jj] -= f * hp; }
-            ICET_WSYNC();
-        }
-        if (lane < cols * rows) {
-            const int t = lane / rows, j = lane - t * rows;
+        // X = [R11 R12] (rank x cols); X^+ = X^T (X X^T)^-1 in double; Y = X^+ C(0:rank, :).  G, Ginv: entry (ii, jj) on lane ii * 6 + jj.
+        const int ii = lane / 6, jj = lane - 6 * ii;
+        const bool cell = lane < 36 && ii < rank && jj < rank;
+        double G = 0.0, Ginv = 0.0;
+        {
             double sd = 0;
-            for (int i = 0; i < rank; i++) {
-                const double xit = (t >= i) ? (double)qr[i * cols + t] : 0.0;
-                double ww = 0; for (int mm = 0; mm < rank; mm++) ww += Ginv[i * rank + mm] * (double)C[mm * rows + j];
-                sd += xit * ww;
+#pragma unroll
+            for (int t = 0; t < cols; t++) {
+                float xi = 0.f, xj = 0.f;
+#pragma unroll
+                for (int i = 0; i <= t; i++) { xi = (ii == i) ? R[i][t] : xi; xj = (jj == i) ? R[i][t] : xj; }
+                sd += (double)xi * (double)xj;
             }
-            Y[t * rows + j] = (float)sd;
+            G = sd; Ginv = (ii == jj) ? 1.0 : 0.0;
         }
-        ICET_WSYNC();
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            if (p < rank) {
+                int piv = p; double best = fabs(rld(G, p * 6 + p));
+#pragma unroll
+                for (int i = p + 1; i < 6; i++) { const double gi = fabs(rld(G, i * 6 + p)); const bool gt = i < rank && gi > best; best = gt ? gi : best; piv = gt ? i : piv; }
+                piv = __builtin_amdgcn_readfirstlane(piv);
+                if (piv != p) {
+                    const int src = (ii == p) ? piv * 6 + jj : (ii == piv) ? p * 6 + jj : lane;
+                    G = __shfl(G, src & 63); Ginv = __shfl(Ginv, src & 63);
+                }
+                const double d = rld(G, p * 7);
+                if (cell && ii == p) { G /= d; Ginv /= d; }
+                const int rowp = (lane < 36) ? p * 6 + jj : lane, colp = (lane < 36) ? ii * 6 + p : lane;
+                const double f = __shfl(G, colp), gp = __shfl(G, rowp), hp = __shfl(Ginv, rowp);
+                if (cell && ii != p) { G -= f * gp; Ginv -= f * hp; }
+            }
+        }
+        double sdt[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            if (i < rank) {
+                double ww = 0;
+#pragma unroll
+                for (int mm = 0; mm < 6; mm++) { const double gim = rld(Ginv, i * 6 + mm); ww = (mm < rank) ? ww + gim * (double)Cc[mm] : ww; }
+#pragma unroll
+                for (int t = 0; t < 6; t++) { const double xit = (t >= i) ? (double)R[i][t < i ? i : t] : 0.0; sdt[t] += xit * ww; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 6; t++) Yc[t] = (float)sdt[t];
     }
-    if (lane < cols * rows) { const int k = lane / rows, j = lane - k * rows; pinv[perm[k] * rows + j] = Y[k * rows + j]; }
-    ICET_WSYNC();
+#pragma unroll
+    for (int k = 0; k < cols; k++) { const int pk = __builtin_amdgcn_readlane(perm, k); if (lane < rows) pinv[pk * rows + lane] = Yc[k]; }
     return rank;
 }
 
@@ -688,41 +835,60 @@ __device__ inline int cod_pinv(const float* Ain, int rows, int cols, float* pinv
 __device__ __noinline__ void gn_tail_literal(GnTailWs& w) {
 #pragma clang fp contract(off)
     const int lane = (int)(threadIdx.x & 63u);
-    const int rank = cod_pinv(w.H, 6, 6, w.cov, w, lane);
-    float* U2 = w.U2; float* ev = w.ev;
-    if (lane == 0) {
-        w.rank = rank;
-        for (int k = 0; k < 6; k++) w.ps[k] = sqrtf(fabsf(w.cov[k * 6 + k]));
-        eig6_sym_core<true>(w.H, ev, U2, w.A, w.sm);
-        int k0 = 0;
-        {
-            float condition = ev[5] / ev[0];
-            int eyecount = 1;
-            while (fabsf(condition) > 1e6f && eyecount < 6) {
-                for (int k = 0; k < 6; k++) w.ps[k] += U2[k * 6 + eyecount - 1];           // src/icet.cpp:479
-                k0++;
-                condition = ev[5] / ev[eyecount];
-                eyecount++;
-            }
+    ICET_TS(0);
+    const int rank = cod_pinv_c6_wave(w.H, 6, w.cov, lane);
+    ICET_WSYNC();
+    ICET_TS(1);
+    float* U2 = w.U2;
+    float ev[6], Qrow[6];
+    {
+        float Hr[36];
+#pragma unroll
+        for (int k = 0; k < 36; k++) Hr[k] = w.H[k];
+        eig6_sym_wave(Hr, ev, Qrow, lane);                            // every lane: the eigenvalues; lane r < 6: row r of the eigenvectors
+    }
+    ICET_TS(2);
+    int k0 = 0;
+    {
+        // checkCondition (src/icet.cpp:443-492), one lane per entry of pred_stds: the pruning loop runs on the eigenvalues every lane holds
+        float ps = (lane < 6) ? sqrtf(fabsf(w.cov[(lane < 6 ? lane : 0) * 7])) : 0.f;
+        float condition = ev[5] / ev[0];
+        int eyecount = 1;
+        while (fabsf(condition) > 1e6f && eyecount < 6) {
+            ps += sel6(Qrow, eyecount - 1);                           // src/icet.cpp:479
+            k0++;
+            condition = ev[5] / sel6(ev, eyecount);
+            eyecount++;
         }
-        w.pruned = k0;
+        if (lane < 6) {
+            w.ps[lane] = ps; w.ev[lane] = sel6(ev, lane);
+#pragma unroll
+            for (int j = 0; j < 6; j++) U2[lane * 6 + j] = Qrow[j];
+        }
+        if (lane == 0) { w.rank = rank; w.pruned = k0; }
     }
     ICET_WSYNC();
-    const int k0 = w.pruned, m = 6 - k0;
+    const int m = 6 - k0;
     if (lane < 36) {
         const int i = lane / 6, j = lane - 6 * i;
         w.L2[lane] = (i < m && j == k0 + i) ? 1.f : 0.f;
-        w.lam[lane] = (i == j) ? ev[i] : 0.f;
+        w.lam[lane] = (i == j) ? w.ev[i] : 0.f;
         w.U2t[j * 6 + i] = U2[i * 6 + j];
     }
     ICET_WSYNC();
+    ICET_TS(3);
     mm_seq(w.L2, m, 6, w.lam, 6, w.T1, lane);
     mm_seq(w.T1, m, 6, w.U2t, 6, w.innards, lane);                                           // L2 * lam * U2^T   (m x 6)   src/icet.cpp:427
-    cod_pinv(w.innards, m, 6, w.inv, w, lane);                                               // 6 x m
+    ICET_TS(4);
+    cod_pinv_c6_wave(w.innards, m, w.inv, lane);                                             // 6 x m
+    ICET_WSYNC();
+    ICET_TS(5);
     mm_seq(w.inv, 6, m, w.L2, 6, w.T2, lane);
     mm_seq(w.T2, 6, 6, w.U2t, 6, w.lhs, lane);
     mm_seq(w.lhs, 6, 6, w.g, 1, w.dx, lane);                                                 // src/icet.cpp:430
+    ICET_TS(6);
 }
+#undef ICET_TS
 #undef ICET_WSYNC
 
 }  // namespace icetdev

@@ -50,8 +50,15 @@ __global__ __launch_bounds__(64) void k_gn_tail_debug(const float* __restrict__ 
     for (int k = 0; k < 6; k++) g[k] = gv[(size_t)i * 6 + k];
     int route, pruned;
     __shared__ icetdev::GnTailWs tail_ws;
+#ifdef ICET_TAIL_TIMING
+    const unsigned long long t_in = wall_clock64();
+#endif
     gn_tail(Hm, g, bound2, cov, ps, dx, ev, route, pruned, tail_ws, threadIdx.x == 0);
     if (threadIdx.x != 0) return;
+#ifdef ICET_TAIL_TIMING
+    if (i == 0) { const unsigned long long t_out = wall_clock64(); const unsigned long long* ts = tail_ws.ts;
+        printf("tail (10 ns ticks): whole %llu | entry %llu pinv(H) %llu eig %llu prune %llu setup %llu products %llu pinv(innards) %llu products %llu exit %llu\n", t_out - t_in, ts[0] - t_in, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], 0ull, ts[5] - ts[4], ts[6] - ts[5], t_out - ts[6]); }
+#endif
     float* o = out + (size_t)i * 56;
     for (int k = 0; k < 36; k++) o[k] = cov[k];
     for (int k = 0; k < 6; k++) { o[36 + k] = ps[k]; o[42 + k] = dx[k]; o[48 + k] = ev[k]; }

@@ -46,7 +46,7 @@ def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; the sequential workloads: 8 -- each of a node's two contexts sees a launch key, captures its graph and replays it from its third frame on)")
     ap.add_argument("--pairs-per-gpu", type=int, default=256)
     ap.add_argument("--workload", choices=["batch", "highres", "odometry", "mapmaker", "sample"], default="batch",
                     help="sample: the batch built from the reference's two REAL scan pairs (tests/golden/scans_*.npz), each pair k rotated by its own small rigid motion, zero rows kept")
@@ -65,7 +65,9 @@ def parse(argv=None):
                     help="roofline.traffic: measured by two child runs under rocprofv3 --pmc (each capped at 60 s; falls back to the file), read from profiles/traffic_latest.json, or left null")
     ap.add_argument("--flags", type=int, default=0, help="icet_params.flags for the solves (e.g. 16 = ICET_FLAG_ROUNDTRIP_SCAN2: what the reference's scan-2 round trips cost); echoed in config")
     ap.add_argument("--dry-run-launch", action="store_true", help="print what `--gpus N` would start (JSON) and exit: no GPU, no child")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.warmup is None: a.warmup = 8 if a.workload in ("odometry", "mapmaker") else 3
+    return a
 
 
 def launcher_command(args, argv, port=None):
@@ -176,8 +178,9 @@ def run_nodes(args):
     for k in range(args.warmup + 1, n_frames):
         r = push(k)
         per_frame_X.append(r["X"].copy())
-        t = node.last_timing()
-        for key in tim: tim[key] += t[key]
+        if kw["map_capacity"]:                       # (the one-launch odometry frame records no timing events: phases from a second node below)
+            t = node.last_timing()
+            for key in tim: tim[key] += t[key]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -185,6 +188,18 @@ def run_nodes(args):
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
     for key in tim: tim[key] /= max(args.steps, 1)
+    if not kw["map_capacity"] and world == 1:
+        # the pipelined odometry frame is one graph launch (filter + loop together): the phases are timed on a second node that keeps them apart (ICET_NODE_TIME_PHASES)
+        node_t = api.Node(ctx, **dict(kw, flags=kw.get("flags", 0) | api.NODE_TIME_PHASES))
+        for k in range(args.warmup + 1):
+            node_t.push_device(bufs[k].data_ptr(), frames[k].shape[1], bufs[k].shape[1])
+        tim = {"filter_ms": 0.0, "solve_ms": 0.0, "map_ms": 0.0}
+        m_t = min(args.steps, 16)
+        for k in range(args.warmup + 1, args.warmup + 1 + m_t):
+            node_t.push_device(bufs[k].data_ptr(), frames[k].shape[1], bufs[k].shape[1])
+            t = node_t.last_timing()
+            for key in tim: tim[key] += t[key] / m_t
+        node_t.close()
     # ---- the same frames as ONE burst (icet_node_push_many_device): chained on the device, X0 <- X device to device, one copy of all results at the end
     # (review r4, item 6: the per-frame entry pays a D2H + a host round trip in the middle of every frame and is bound by the HOST of the box) ----
     burst = None
@@ -217,7 +232,7 @@ def run_nodes(args):
         note = "12 B read + 12 B written per ring row x %d rows; HIP events around the kernel" % cap
     else:
         kern, bytes_per_launch, ms = "k_range_count+k_range_scan+k_range_scatter", 36.0 * n_mean, tim["filter_ms"]
-        note = "x|y|z read by the count and the scatter pass + kept rows written (~36 B/row); filter_ms also holds the 4-byte row-count download"
+        note = "x|y|z read by the count and the scatter pass + kept rows written (~36 B/row); filter_ms / solve_ms from a second node with ICET_NODE_TIME_PHASES (the timed frames run filter + loop as one graph launch)"
     achieved = bytes_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

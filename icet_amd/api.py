@@ -471,6 +471,7 @@ ODOMETRY_NODE = dict(runlen=7, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buf
 MAP_MAKER_NODE = dict(runlen=12, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1, min_range=0.2, seed_x0=0,
                       trans_thresh=0.3, rot_thresh=0.3, map_capacity=600000, map_downsample=2000)      # src/simpleMapMaker.cpp:62,98,113-124,147,241-242
 NODE_NO_RANGE_FILTER, NODE_ALIGNED_CLOUD, NODE_SNAIL_TRAIL = 1, 2, 4
+NODE_NO_PIPELINE, NODE_SERIAL_ENQUEUE, NODE_DOUBLE_W, NODE_TIME_PHASES = 8, 16, 32, 64      # include/icet_nodes.h
 SCAN_REGISTRATION_NODE = dict(runlen=7, bins_phi=24, bins_theta=75, n=25, thresh=0.1, buff=0.1, min_range=0.0, seed_x0=0,
                               trans_thresh=0.0, rot_thresh=0.0, map_capacity=0, map_downsample=0, flags=7)  # src/scanMatcher.cpp:44,55-64,76,79-84
 

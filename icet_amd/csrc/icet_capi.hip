@@ -68,11 +68,16 @@ struct icet_ctx {
     hipEvent_t ev_desc = nullptr; bool desc_in_flight = false;   // completion of the last copy out of the pinned descriptor staging
     // Small device batches whose launch geometry repeats call after call are replayed from a captured hipGraph (option "graph"): the ~33
     // launches of a single-pair solve then cost one hipGraphLaunch on the host, and the command processor runs them back to back.
-    struct GraphKey { int64_t v[43]; };                        // every LaunchCfg field + the pointers the launches take (graph_key_of)
+    struct GraphKey { int64_t v[44]; };                        // every LaunchCfg field + the pointers the launches take + the prologue's key (graph_key_of)
     struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; GraphKey key{}, seen{}; bool have_seen = false, have_graph = false; };
     bool capturing = false; int graph_mode = -1;               // -1: replay batches of <= 8 pairs whose launch key repeats; 0 never; 1 same as -1
     GraphSlot g_solve, g_keyframe, g_loop;                     // the whole solve (icet_solve_batch_device) and its two halves (icet_keyframe_device_n / icet_register_device_n)
     hipEvent_t ev_graph = nullptr; bool graph_in_flight = false;
+    // A caller inside this library (the sequential nodes, icet_nodes.hip) can put work of its own at the head of the NEXT icet_register_device_n call's launch
+    // sequence -- enqueued on the context's stream right before the loop's first kernel, captured into the same graph: the range filter and the loop of a frame
+    // are then ONE hipGraphLaunch (round 6: the loop's graph used to start 30-40 us after the filter's last kernel).  `prologue_key` names what the hook's
+    // launches depend on (buffers, grid): it is part of the graph key.  Cleared by the caller after the call (icet_ctx_set_prologue).
+    hipError_t (*prologue)(void*, hipStream_t) = nullptr; void* prologue_user = nullptr; int64_t prologue_key = 0;
 };
 
 namespace {
@@ -421,10 +426,16 @@ LaunchCfg make_cfg(icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     return cfg;
 }
 
-icet_status upload_desc(icet_ctx* c, int32_t n_pairs) {
+icet_status upload_desc(icet_ctx* c, int32_t n_pairs, bool by_next_kernel = false) {
     Workspace& w = c->w;
-    HIPCHK(c, hipMemcpyAsync(w.desc, c->h_desc, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(w.seg_off, c->h_seg, sizeof(int32_t) * (n_pairs + 1), hipMemcpyHostToDevice, c->stream));
+    if (by_next_kernel) {
+        // (the caller's next launch, k_init_state, copies the pinned words itself)
+    } else if (n_pairs <= kUploadDescMaxPairs) {
+        HIPCHK(c, launch_upload_desc(w, c->h_desc, c->h_seg, n_pairs, c->stream));       // small batch: a kernel reads the pinned words (no copy command, no memcpy node)
+    } else {
+        HIPCHK(c, hipMemcpyAsync(w.desc, c->h_desc, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(w.seg_off, c->h_seg, sizeof(int32_t) * (n_pairs + 1), hipMemcpyHostToDevice, c->stream));
+    }
     if (!c->ev_desc) HIPCHK(c, hipEventCreateWithFlags(&c->ev_desc, hipEventDisableTiming));
     if (!c->capturing) { HIPCHK(c, hipEventRecord(c->ev_desc, c->stream)); c->desc_in_flight = true; }     // (a captured event cannot be waited for on the host: the replay path orders the staging itself)
     return ICET_OK;
@@ -448,9 +459,13 @@ icet_status enqueue_keyframe(icet_ctx* c, const icet_params* p, int32_t n_pairs,
             w.cap_tile_vr = need_vr;
         }
     }
-    { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }
+    // a small batch: k_rs_splitters, the keyframe's first kernel, takes the descriptors from the pinned staging itself
+    const bool first_uploads = n_pairs <= kUploadDescMaxPairs && !cfg.use_library_sort;
+    { icet_status us = upload_desc(c, n_pairs, first_uploads); if (us != ICET_OK) return us; }
     if (!c->capturing) HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
-    HIPCHK(c, launch_keyframe(w, cfg, aux, c->stream, d_counts1));      // (d_counts1: the descriptors hold upper bounds, the device knows the row counts: patched by the first kernel)
+    LaunchCfg kcfg = cfg; if (first_uploads) { kcfg.h_desc_up = c->h_desc; kcfg.h_seg_up = c->h_seg; }
+    HIPCHK(c, launch_keyframe(w, kcfg, aux, c->stream, d_counts1));      // (d_counts1: the descriptors hold upper bounds, the device knows the row counts: patched by the first kernel)
+    if (first_uploads && !c->capturing) { HIPCHK(c, hipEventRecord(c->ev_desc, c->stream)); c->desc_in_flight = true; }      // (the staging has been read once these kernels have run)
     return ICET_OK;
 }
 
@@ -458,7 +473,9 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
     const bool want_pts2 = aux && aux->xf_last && p->runlen > 0;      // pts2_out: the device computes `points2` (else only the transform snapshot + its event: the host does)
     Workspace& w = c->w;
     const LaunchCfg cfg = make_cfg(c, p, n_pairs);
-    if (reupload) { icet_status us = upload_desc(c, n_pairs); if (us != ICET_OK) return us; }      // the scan-2 halves arrived after the keyframe call
+    // the scan-2 halves arrived after the keyframe call.  A small batch without the scan-2 round trip: k_init_state, the first kernel below that reads a descriptor, uploads them
+    const bool init_uploads = reupload && n_pairs <= kUploadDescMaxPairs && !cfg.rt2 && !cfg.keep;
+    if (reupload) { icet_status us = upload_desc(c, n_pairs, init_uploads); if (us != ICET_OK) return us; }
     if (d_counts2 && cfg.rt2) HIPCHK(c, launch_patch_counts(w, cfg, nullptr, d_counts2, c->stream));      // (otherwise k_init_state, the loop's first kernel, patches them)
     while ((int)c->ev_acc.size() < 2 * p->runlen) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_acc.push_back(e); }
     Workspace wl = w;                                    // what the loop kernels see: with ICET_FLAG_ROUNDTRIP_SCAN2 their scan 2 is the round-tripped copy
@@ -503,7 +520,8 @@ icet_status enqueue_loop(icet_ctx* c, const icet_params* p, int32_t n_pairs, con
             wl.keep_modes = w.keep_modes; wl.keep_mask = w.keep_mask; wl.keep_list = w.keep_list; wl.keep_state = w.keep_state; wl.cap_keep_mask = w.cap_keep_mask; wl.cap_keep_list = w.cap_keep_list; wl.cap_keep_pairs = w.cap_keep_pairs;
         }
     }
-    HIPCHK(c, launch_init_state(w, cfg, d_x0, c->stream, want_pts2 ? aux->xf_last : nullptr, cfg.rt2 ? nullptr : d_counts2));
+    HIPCHK(c, launch_init_state(w, cfg, d_x0, c->stream, want_pts2 ? aux->xf_last : nullptr, cfg.rt2 ? nullptr : d_counts2, init_uploads ? c->h_desc : nullptr, init_uploads ? c->h_seg : nullptr));
+    if (init_uploads && !c->capturing) { HIPCHK(c, hipEventRecord(c->ev_desc, c->stream)); c->desc_in_flight = true; }      // (the staging is read by THIS kernel: the event of upload_desc, moved behind it)
     // `points2` (include/icet.h:80): scan 2 as the LAST fitScan2 transforms it (src/icet.cpp:375-378).  That transform is known as soon as the
     // solve of iteration runlen - 2 has run: k_gn_solve / k_init_state snapshot its record in aux->xf_last (pinned host memory) and ev_prev
     // marks the moment.  icet_solve_end then transforms scan 2 ON THE HOST while the last iteration still runs on the device (measured: a
@@ -766,7 +784,8 @@ static icet_ctx::GraphKey graph_key_of(icet_ctx* c, const icet_params* p, int32_
                             k.acc_target_blocks, k.kf_chunks, k.kf_pts_per_thread, k.use_library_sort, k.vec4_ok, k.true_sort, k.force_exact, k.rs_cap, k.rs_max_cell,
                             k.exec_bits_lds, k.exec_pairwise, k.lds_rank, k.reject_moving, k.half_gap, k.rt2 + 2 * k.ref_w, p->flags, (int64_t)(intptr_t)a0, (int64_t)(intptr_t)a1, (int64_t)(intptr_t)a2, (int64_t)(intptr_t)a3,
                             (int64_t)(intptr_t)c->w.desc, (int64_t)(intptr_t)c->w.thr, (int64_t)(intptr_t)c->w.lut, (int64_t)(intptr_t)c->w.r1, (int64_t)(intptr_t)c->w.counts,
-                            (int64_t)(intptr_t)c->w.near_over, (int64_t)(intptr_t)c->w.acc, (int64_t)(intptr_t)c->w.fit_items, (int64_t)(intptr_t)c->w.sort_tmp, (int64_t)(intptr_t)c->w.tile_vr};
+                            (int64_t)(intptr_t)c->w.near_over, (int64_t)(intptr_t)c->w.acc, (int64_t)(intptr_t)c->w.fit_items, (int64_t)(intptr_t)c->w.sort_tmp, (int64_t)(intptr_t)c->w.tile_vr,
+                            c->prologue ? c->prologue_key : 0};
     static_assert(sizeof(vals) == sizeof(key.v), "GraphKey size");
     std::memcpy(key.v, vals, sizeof(vals));
     return key;
@@ -919,9 +938,12 @@ icet_status icet_register_device_n(icet_ctx* c, const icet_params* p, int32_t n_
         for (int k = 0; k < n_pairs; k++) { PairDesc& d = c->h_desc[k]; d.s2 = scan2[k].ptr; d.n2 = (int32_t)scan2[k].n; d.ld2 = (int32_t)scan2[k].ld; }
         c->desc_reg_valid = true;
     }
-    if (graph_eligible(c, p, n_pairs))
-        return run_or_replay(c, c->g_loop, graph_key_of(c, p, n_pairs, d_x0, d_out, d_rows, (const void*)2), [&]() { return enqueue_loop(c, p, n_pairs, d_x0, d_out, nullptr, true, nullptr, nullptr, d_rows); });
-    return enqueue_loop(c, p, n_pairs, d_x0, d_out, nullptr, true, nullptr, nullptr, d_rows);
+    auto enq = [&]() -> icet_status {
+        if (c->prologue) HIPCHK(c, c->prologue(c->prologue_user, c->stream));
+        return enqueue_loop(c, p, n_pairs, d_x0, d_out, nullptr, true, nullptr, nullptr, d_rows);
+    };
+    if (graph_eligible(c, p, n_pairs)) return run_or_replay(c, c->g_loop, graph_key_of(c, p, n_pairs, d_x0, d_out, d_rows, (const void*)2), enq);
+    return enq();
 }
 
 icet_status icet_solve_batch(icet_ctx* c, const icet_params* p, int32_t n_pairs,
@@ -1271,6 +1293,7 @@ icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
 
 } // extern "C" (reopened below)
 void icet_ctx_set_stream(icet_ctx* c, hipStream_t s) { if (c) c->stream = s; }
+void icet_ctx_set_prologue(icet_ctx* c, hipError_t (*fn)(void*, hipStream_t), void* user, int64_t key) { if (c) { c->prologue = fn; c->prologue_user = user; c->prologue_key = key; } }
 extern "C" {
 void* icet_stream(icet_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
 int icet_device(const icet_ctx* c) { return c ? c->device : -1; }

@@ -216,6 +216,7 @@ struct LaunchCfg {
     int keep = 0, keep_from = 1;      // Tuning::keep resolved for this launch (batch size, flags), Tuning::keep_from
     float keep_bt = 0.f, keep_br = 0.f, keep_check_scale = 1.f;   // Tuning::keep_budget_t / _r / keep_check_scale
     float gn_cond_bound2 = 6.25e10f;     // Tuning::gn_cond_bound squared: k_gn_solve's Cholesky route needs |A|_F |A^-1|_F <= the bound (icet_solve.hip gn_tail)
+    const PairDesc* h_desc_up = nullptr; const int32_t* h_seg_up = nullptr;      // set: the keyframe's first kernel (k_rs_splitters) copies the descriptors / segment offsets from this pinned staging itself (small batches: launch_upload_desc's job)
 };
 constexpr float kRejectMovingThresh = 0.3f;        // python/ICET_spherical.py:38  RM_thresh
 constexpr int kRejectMovingStartIter = 4;          // python/ICET_spherical.py:36  start_RM_iter
@@ -223,7 +224,7 @@ constexpr int kRejectMovingStartIter = 4;          // python/ICET_spherical.py:3
 // icet_keyframe.hip
 hipError_t launch_keyframe(const Workspace& w, const LaunchCfg& c, const AuxDev* aux, hipStream_t st, const int32_t* d_n1 = nullptr);   // d_n1: scan-1 row counts known to the device only (the descriptors hold upper bounds)
 // icet_solve.hip
-hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last = nullptr, const int32_t* d_n2 = nullptr);   // (also clears the block tickets and the keep-list state)
+hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last = nullptr, const int32_t* d_n2 = nullptr, const PairDesc* h_desc = nullptr, const int32_t* h_seg = nullptr);   // (also clears the block tickets and the keep-list state)
 // keep_pass: the point pass in front of this solve was launched with keep_pass (below): build the list of every pair that walked its whole scan, check every pair's budgets
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* aux, hipStream_t st, int keep_pass = 0);
 hipError_t launch_gn_tail_debug(const float* d_H, const float* d_g, float* d_out, int n, float bound2, hipStream_t st);     // test hook: the 6x6 tail on its own
@@ -241,6 +242,10 @@ size_t acc_row_lds_bytes();
 // ICET_FLAG_ROUNDTRIP_SCAN2: points2_OG = sphericalToCartesian(cartesianToSpherical(scan 2)) (src/icet.cpp:263-275, without the permutation): w.desc -> w.desc_rt
 hipError_t launch_rt2_prepare(const Workspace& w, const LaunchCfg& c, hipStream_t st);
 hipError_t launch_patch_counts(const Workspace& w, const LaunchCfg& c, const int32_t* d_n1, const int32_t* d_n2, hipStream_t st);   // icet_solve.hip
+// Descriptors and segment offsets of a SMALL batch from the pinned staging into the workspace by a kernel (round 6): a copy command of a few dozen bytes costs a stream
+// -- and a replayed graph, as a memcpy node -- 10 to 60 us on this part before the next kernel starts; a kernel that reads the pinned words itself costs a launch.
+constexpr int kUploadDescMaxPairs = 64;
+hipError_t launch_upload_desc(const Workspace& w, const PairDesc* h_desc, const int32_t* h_seg, int n_pairs, hipStream_t st);   // icet_solve.hip
 // icet_sidetables.hip: the per-point members of the reference object, on request (pair 0 of a single-pair solve)
 hipError_t launch_side_scan1(const Workspace& w, const LaunchCfg& c, float* sph, int32_t* index, hipStream_t st);
 hipError_t launch_side_scan2(const Workspace& w, const LaunchCfg& c, const float* xf, float* pts, float* sph, int32_t* voxel, hipStream_t st);

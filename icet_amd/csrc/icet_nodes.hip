@@ -38,6 +38,10 @@ namespace {
 constexpr int kFB = 256;            // threads per block of the filter kernels
 constexpr int kFRows = 8;           // rows per thread: a block owns 2048 consecutive rows
 
+// Where a frame's raw scan is, for filter launches that are part of a captured graph (round 6): the record lives in pinned host memory, the host fills it in before
+// every replay and the kernels read it (the same arrangement as the loop's X0) -- the launches themselves (grid from the buffers' CAPACITY) never change.
+struct FrameDesc { const float* x; int32_t n, ld; };
+
 __device__ __forceinline__ bool keep_row(float x, float y, float z, float min_range) {
     float d;
     {
@@ -51,8 +55,9 @@ __device__ __forceinline__ bool keep_row(float x, float y, float z, float min_ra
 
 // pass 1: kept rows per block
 __global__ __launch_bounds__(kFB) void k_range_count(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
-                                                    float min_range, int32_t* __restrict__ counts) {
+                                                    float min_range, int32_t* __restrict__ counts, const FrameDesc* __restrict__ fd = nullptr) {
     __shared__ int wsum[kFB / 64];
+    if (fd) { const FrameDesc d = *fd; x = d.x; y = d.x + d.ld; z = d.x + 2 * (size_t)d.ld; n = d.n; }
     const int base = blockIdx.x * kFB * kFRows;
     int c = 0;
 #pragma unroll
@@ -85,8 +90,9 @@ __global__ __launch_bounds__(kFB) void k_range_scan(const int32_t* __restrict__ 
 // row is: kept rows in earlier k-slices + kept rows of lower threads in its own slice.
 __global__ __launch_bounds__(kFB) void k_range_scatter(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
                                                       float min_range, const int32_t* __restrict__ bases,
-                                                      float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz) {
+                                                      float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, const FrameDesc* __restrict__ fd = nullptr) {
     __shared__ int wcnt[kFRows][kFB / 64];
+    if (fd) { const FrameDesc d = *fd; x = d.x; y = d.x + d.ld; z = d.x + 2 * (size_t)d.ld; n = d.n; }
     const int base = blockIdx.x * kFB * kFRows;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float vx[kFRows], vy[kFRows], vz[kFRows];
@@ -220,12 +226,16 @@ void quat_of(const float* P /* 4x4 row-major */, float q[4]) {
 }  // namespace
 
 void icet_ctx_set_stream(icet_ctx* c, hipStream_t s);      // icet_capi.hip (internal)
+void icet_ctx_set_prologue(icet_ctx* c, hipError_t (*fn)(void*, hipStream_t), void* user, int64_t key);      // icet_capi.hip (internal)
 
 // The helper thread of a pipelined node: it ENQUEUES the keyframe builds (icet_keyframe_device_n on the context the build goes into, then the event that says it is
 // done) while the calling thread enqueues the frame's loop.  A build is ~20 launches or one graph launch of 20 nodes -- 35 to 140 us of host time that used to sit between
 // the loop's launch and the build's start, so that the build of frame k ran into frame k + 1, whose loop needs it.  One job at a time in order; the calling thread waits
 // for "idle" before it touches anything the helper may be using (kf_wait_idle).
-struct KfJob { icet_ctx* ctx; icet_params sp; icet_dev_scan b; const int32_t* d_cnt; hipStream_t sk; hipEvent_t done_ev; };
+struct FilterLaunch { const FrameDesc* fd; float min_range; int32_t* counts; int32_t* bases; int n_blocks; int32_t* d_cnt; int32_t* h_cnt; float* o; int64_t ld_o; };      // one range filter's three launches
+namespace { hipError_t filter_prologue(void* user, hipStream_t st); }
+// (f2_ev set: the build is preceded by the keyframe side's own range filter of the raw frame -- the one-launch frame of push_frame -- and f2_ev says when that has read the frame)
+struct KfJob { icet_ctx* ctx; icet_params sp; icet_dev_scan b; const int32_t* d_cnt; hipStream_t sk; hipEvent_t done_ev; FilterLaunch f2{}; hipEvent_t f2_ev = nullptr; };
 struct KfWorker {
     std::thread th; std::mutex m; std::condition_variable cv; std::deque<KfJob> q;
     long posted = 0, done = 0; bool stop = false; icet_status status = ICET_OK; std::string err; int device = 0;
@@ -266,6 +276,16 @@ struct icet_node {
     KfWorker* kw = nullptr;                                       // started with the first build that goes through it
     hipEvent_t ev_kfdone[2] = {nullptr, nullptr}; bool kf_built[2] = {false, false};          // per context: its last keyframe build has been enqueued / the event behind it
     hipEvent_t ev_loop2[2] = {nullptr, nullptr}, ev_kf2[2] = {nullptr, nullptr};      // per frame parity: end of the loop / of the keyframe build (a burst's filter waits for the frame two back)
+    // The one-launch frame (round 6, push_frame): the loop's context captures the range filter in front of its loop (FilterLaunch = what its hook enqueues), and the
+    // keyframe build of the same scan runs on the other context's stream behind a filter of ITS OWN into a second buffer -- no dependency between the two streams inside a frame.
+    FrameDesc* h_frame = nullptr;                                 // pinned, [2]: by scan buffer
+    FilterLaunch fl[2];
+    float* d_scan_kf[2] = {nullptr, nullptr}; int64_t cap_scan_kf[2] = {0, 0};
+    int32_t* d_counts_kf = nullptr; int32_t* d_bases_kf = nullptr; int cap_blocks_kf = 0; int32_t* d_nkept_kf = nullptr;
+    hipEvent_t ev_f2 = nullptr;                                   // the keyframe side's filter has read the caller's frame
+#ifdef ICET_DIAG_ENV
+    double tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long tr_n = 0, tr_seen = 0;       // ICET_NODE_TRACE: host microseconds of push_frame by section, summed (printed by icet_node_destroy)
+#endif
 };
 
 namespace {
@@ -285,7 +305,10 @@ bool kf_worker_start(icet_node* nd) {
                 { std::unique_lock<std::mutex> lk(w->m); w->cv.wait(lk, [&] { return w->stop || !w->q.empty(); }); if (w->q.empty()) return; j = w->q.front(); w->q.pop_front(); }
                 icet_status s = ICET_OK; std::string e;
                 bool skip; { std::lock_guard<std::mutex> lk(w->m); skip = w->status != ICET_OK; }      // after a failure the jobs behind it are only counted
-                if (!skip) {
+                if (!skip && j.f2_ev) {
+                    if (filter_prologue(&j.f2, j.sk) != hipSuccess || hipEventRecord(j.f2_ev, j.sk) != hipSuccess) { s = ICET_ERR_HIP; e = "range filter in front of the keyframe build"; }
+                }
+                if (!skip && s == ICET_OK) {
                     s = icet_keyframe_device_n(j.ctx, &j.sp, 1, &j.b, j.d_cnt);
                     if (s != ICET_OK) e = icet_last_error(j.ctx);
                     else if (hipEventRecord(j.done_ev, j.sk) != hipSuccess) { s = ICET_ERR_HIP; e = "hipEventRecord(keyframe build done)"; }
@@ -326,8 +349,56 @@ icet_status ensure_scan(icet_node* nd, int which, int64_t n) {
     return ICET_OK;
 }
 
+// ---- the one-launch frame (round 6) ----
+hipError_t filter_prologue(void* user, hipStream_t st) {          // the hook icet_register_device_n runs in front of its loop (icet_ctx_set_prologue)
+    const FilterLaunch& f = *static_cast<const FilterLaunch*>(user);
+    k_range_count<<<f.n_blocks, kFB, 0, st>>>(nullptr, nullptr, nullptr, 0, f.min_range, f.counts, f.fd);
+    k_range_scan<<<1, kFB, 0, st>>>(f.counts, f.bases, f.n_blocks, f.d_cnt, f.h_cnt);
+    k_range_scatter<<<f.n_blocks, kFB, 0, st>>>(nullptr, nullptr, nullptr, 0, f.min_range, f.bases, f.o, f.o + f.ld_o, f.o + 2 * f.ld_o, f.fd);
+    return hipGetLastError();
+}
+int64_t filter_key(const FilterLaunch& f) {            // everything the hook's launches depend on (FNV-1a): part of the loop's graph key
+    const uint64_t v[] = {(uint64_t)(uintptr_t)f.fd, (uint64_t)__builtin_bit_cast(uint32_t, f.min_range), (uint64_t)(uintptr_t)f.counts, (uint64_t)(uintptr_t)f.bases, (uint64_t)f.n_blocks,
+                          (uint64_t)(uintptr_t)f.d_cnt, (uint64_t)(uintptr_t)f.h_cnt, (uint64_t)(uintptr_t)f.o, (uint64_t)f.ld_o};
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t x : v) for (int b = 0; b < 8; b++) { h ^= (x >> (8 * b)) & 0xffu; h *= 1099511628211ull; }
+    return (int64_t)(h | 1ull);
+}
+// the keyframe side's own filtered copy of scan `which`, its block counters and its row counters
+icet_status ensure_kf_side(icet_node* nd, int which, int64_t n) {
+    if (!nd->h_frame) { NCHK(nd, hipHostMalloc(reinterpret_cast<void**>(&nd->h_frame), 2 * sizeof(FrameDesc))); std::memset(nd->h_frame, 0, 2 * sizeof(FrameDesc)); }
+    if (!nd->d_nkept_kf) NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_nkept_kf), 2 * sizeof(int32_t)));
+    if (!nd->ev_f2) NCHK(nd, hipEventCreateWithFlags(&nd->ev_f2, hipEventDisableTiming));
+    if (n > nd->cap_scan_kf[which]) {
+        NCHK(nd, hipDeviceSynchronize());
+        if (nd->d_scan_kf[which]) { NCHK(nd, hipFree(nd->d_scan_kf[which])); nd->d_scan_kf[which] = nullptr; }
+        const int64_t cap = (n + n / 8 + 63) / 64 * 64;
+        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_scan_kf[which]), sizeof(float) * 3 * (size_t)cap));
+        nd->cap_scan_kf[which] = cap;
+    }
+    const int nbl = (int)((nd->cap_scan_kf[which] + kFB * kFRows - 1) / (kFB * kFRows));
+    if (nbl > nd->cap_blocks_kf) {
+        NCHK(nd, hipDeviceSynchronize());
+        if (nd->d_counts_kf) NCHK(nd, hipFree(nd->d_counts_kf));
+        if (nd->d_bases_kf) NCHK(nd, hipFree(nd->d_bases_kf));
+        nd->d_counts_kf = nd->d_bases_kf = nullptr;
+        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_counts_kf), sizeof(int32_t) * nbl));
+        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_bases_kf), sizeof(int32_t) * nbl));
+        nd->cap_blocks_kf = nbl;
+    }
+    return ICET_OK;
+}
+
 // One frame with the raw scan already in HBM (column-major, ld).
 icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld, icet_node_result* res) {
+#ifdef ICET_DIAG_ENV
+    static const bool trace_on = getenv("ICET_NODE_TRACE") != nullptr;
+    auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tq[6] = {0, 0, 0, 0, 0, 0}; tq[0] = now_us();
+#define ICET_TR(k) do { if (trace_on) tq[k] = now_us(); } while (0)
+#else
+#define ICET_TR(k) do { } while (0)
+#endif
     std::memset(res, 0, sizeof(*res));
     { const icet_status hs = kf_wait_idle(nd); if (hs != ICET_OK) return hs; }      // the previous frame's keyframe build has been enqueued (or says why not)
     hipStream_t st = nd->stream;
@@ -357,9 +428,24 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
     // ---- range filter: stable compaction into the "current" buffer (odometry.cpp:57-70) ----
     icet_status s = ensure_scan(nd, cur, n); if (s != ICET_OK) return s;
     const int64_t lcur = nd->cap_scan[cur];
-    const int n_blocks = (int)((n + kFB * kFRows - 1) / (kFB * kFRows));
+    // Whoever needs the kept-row count on the HOST before the solve can be enqueued (the map maker's shuffle runs over exactly that many
+    // indices; the aligned cloud and the unpipelined solve are sized by it) waits for the filter here.  The pipelined odometry frame does
+    // not: the solve's two halves take the unfiltered row count as an upper bound for their launch geometry and read the actual count on
+    // the device (icet_register_device_n / icet_keyframe_device_n), so the whole frame is enqueued without a host round trip in the middle.
+    const bool fast = nd->pipelined && nd->p.map_capacity == 0 && n > 0 &&
+                      !(nd->p.flags & (ICET_NODE_NO_RANGE_FILTER | ICET_NODE_ALIGNED_CLOUD | ICET_NODE_SNAIL_TRAIL));
+#ifdef ICET_DIAG_ENV      /* the A/B switches of round 5's stream experiments: experiment builds only (make EXTRA=-DICET_DIAG_ENV); the shipped library never reads the environment */
+    static const bool loop_on_filter_stream = getenv("ICET_NODE_LOOP_OWN_STREAM") == nullptr;
+#else
+    constexpr bool loop_on_filter_stream = true;
+#endif
+    // ... and since round 6 such a frame is ONE launch on the critical path: the loop's context captures the filter in front of its loop (one graph: the loop's first kernel
+    // used to start 30-40 us after the filter's last one), and the keyframe build of this scan, on the other stream, filters the raw frame once more for itself instead of
+    // waiting for this stream's filter (a dependency between two streams costs more than 20 us of duplicated filter).  ICET_NODE_TIME_PHASES keeps the phases apart.
+    const bool fused = fast && loop_on_filter_stream && nd->p.solve.runlen > 0 && !(nd->p.flags & ICET_NODE_TIME_PHASES);
+    const int n_blocks = fused ? (int)((lcur + kFB * kFRows - 1) / (kFB * kFRows)) : (int)((n + kFB * kFRows - 1) / (kFB * kFRows));      // fused: by CAPACITY (the launch does not change with n)
     if (n_blocks > nd->cap_blocks) {
-        NCHK(nd, hipStreamSynchronize(st));
+        NCHK(nd, hipDeviceSynchronize());
         if (nd->d_counts) NCHK(nd, hipFree(nd->d_counts));
         if (nd->d_bases) NCHK(nd, hipFree(nd->d_bases));
         nd->d_counts = nd->d_bases = nullptr;
@@ -367,26 +453,25 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_bases), sizeof(int32_t) * n_blocks));
         nd->cap_blocks = n_blocks;
     }
-    // Whoever needs the kept-row count on the HOST before the solve can be enqueued (the map maker's shuffle runs over exactly that many
-    // indices; the aligned cloud and the unpipelined solve are sized by it) waits for the filter here.  The pipelined odometry frame does
-    // not: the solve's two halves take the unfiltered row count as an upper bound for their launch geometry and read the actual count on
-    // the device (icet_register_device_n / icet_keyframe_device_n), so the whole frame is enqueued without a host round trip in the middle.
-    const bool fast = nd->pipelined && nd->p.map_capacity == 0 && n > 0 &&
-                      !(nd->p.flags & (ICET_NODE_NO_RANGE_FILTER | ICET_NODE_ALIGNED_CLOUD | ICET_NODE_SNAIL_TRAIL));
+    if (fused) { s = ensure_kf_side(nd, cur, n); if (s != ICET_OK) return s; }
     int32_t* d_cnt = nd->d_nkept + cur;
-    NCHK(nd, hipEventRecord(nd->ev[0], st));
+    if (!fused) NCHK(nd, hipEventRecord(nd->ev[0], st));         // (the one-launch frame records no timing events: each costs the host 5-10 us IN FRONT of the launch)
     if (nd->p.flags & ICET_NODE_NO_RANGE_FILTER) {               // scanMatcher.cpp:44: the cloud goes to the constructor as it is
         if (n) NCHK(nd, hipMemcpy2DAsync(nd->d_scan[cur], lcur * sizeof(float), d_scan, ld * sizeof(float), n * sizeof(float), 3, hipMemcpyDeviceToDevice, st));
         *nd->h_nkept = (int32_t)n;
+    } else if (fused) {
+        nd->h_frame[cur] = FrameDesc{d_scan, (int32_t)n, (int32_t)ld};                          // what both filters of this frame read
+        nd->fl[cur] = FilterLaunch{nd->h_frame + cur, nd->p.min_range, nd->d_counts, nd->d_bases, n_blocks, d_cnt, nd->h_nkept, nd->d_scan[cur], lcur};
     } else if (n > 0) {
         const float *x = d_scan, *y = d_scan + ld, *z = d_scan + 2 * ld;
         float* o = nd->d_scan[cur];
         k_range_count<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_counts);
-        k_range_scan<<<1, kFB, 0, st>>>(nd->d_counts, nd->d_bases, n_blocks, d_cnt);
+        // the kept-row count goes to the host by the kernel's own store into pinned memory: a hipMemcpyAsync of four bytes costs the stream ~20 us on this part (round 5's
+        // burst timeline), and the frame's other small copy -- the 48 result floats -- went the same way in round 6 (below)
+        k_range_scan<<<1, kFB, 0, st>>>(nd->d_counts, nd->d_bases, n_blocks, d_cnt, nd->h_nkept);
         k_range_scatter<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_bases, o, o + lcur, o + 2 * lcur);
         NCHK(nd, hipGetLastError());
-        if (fast) NCHK(nd, hipEventRecord(nd->ev[1], st));        // what the solve streams wait for: the filtered scan, not the copy of its count to the host
-        NCHK(nd, hipMemcpyAsync(nd->h_nkept, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (fast) NCHK(nd, hipEventRecord(nd->ev[1], st));        // what the solve streams wait for: the filtered scan
     } else {
         *nd->h_nkept = 0;
     }
@@ -425,48 +510,76 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         // The loop runs on the FILTER's stream: a dependency between two streams costs ~60 us on this part before the waiting queue starts (measured on the device
         // timeline: filter end -> first loop kernel), and filter -> loop -> result is the frame's critical path.  The context keeps its own stream for its keyframe
         // builds; the build this loop needs (previous frame, that stream) finished long ago as a rule -- an event says so.
-#ifdef ICET_DIAG_ENV      /* the A/B switches of round 5's stream experiments: experiment builds only (make EXTRA=-DICET_DIAG_ENV); the shipped library never reads the environment */
-        static const bool loop_on_filter_stream = getenv("ICET_NODE_LOOP_OWN_STREAM") == nullptr;
-#else
-        constexpr bool loop_on_filter_stream = true;
-#endif
         so = loop_on_filter_stream ? st : s_own;
         if (loop_on_filter_stream) {
-            if (nd->kf_built[nd->owner]) NCHK(nd, hipStreamWaitEvent(st, nd->ev_kfdone[nd->owner], 0));
-            if (fast) NCHK(nd, hipStreamWaitEvent(s_oth, nd->ev[1], 0));
+            // (the build is done, as a rule, by the time the next frame arrives: asking costs the host a microsecond, a wait command in the stream five to ten)
+            if (nd->kf_built[nd->owner] && hipEventQuery(nd->ev_kfdone[nd->owner]) != hipSuccess) { (void)hipGetLastError(); NCHK(nd, hipStreamWaitEvent(st, nd->ev_kfdone[nd->owner], 0)); }
+            if (fast && !fused) NCHK(nd, hipStreamWaitEvent(s_oth, nd->ev[1], 0));
             icet_ctx_set_stream(own, st);
         } else if (fast) {                                        // nobody waited for the filter: both solve streams do
             NCHK(nd, hipStreamWaitEvent(so, nd->ev[1], 0));
             NCHK(nd, hipStreamWaitEvent(s_oth, nd->ev[1], 0));
         }
-        NCHK(nd, hipEventRecord(nd->ev[5], so));
-        // (Handing this build to the helper thread as well -- so that it starts beside the loop and not one graph launch behind it -- was measured: 4.83-4.93 k frames/s
-        // with, 4.82-4.92 k without.  The build is not what the next frame waits for; it stays on this thread, where a failure is reported by the call that caused it.)
-        const bool via_helper = false;
-        // X0 is read from pinned host memory by the kernel itself (no H2D command); the results stay in HBM during the loop and come back in one copy
-        s = icet_register_device_n(own, &sp, 1, &b, fast ? d_cnt : nullptr, nd->h_x0, nd->d_out);
+        if (!fused) NCHK(nd, hipEventRecord(nd->ev[5], so));
+        // The keyframe side of a one-launch frame is enqueued by the node's HELPER thread (the one bursts use), posted BEFORE this thread launches the loop's graph: its
+        // ~45 us of enqueueing (three filter launches, an event, a graph of 18 kernels) then run beside the loop's launch and not behind it -- the build, not the loop,
+        // is what the next frame waits for, and it used to start 60 us into the frame.  (Round 5, frame in phases: measured, no gain, 4.83-4.93 k frames/s with, 4.82-4.92 k
+        // without.)  A failure of the build is reported by the next call that waits for the helper.
+        const bool via_helper = fused && !(nd->p.flags & ICET_NODE_SERIAL_ENQUEUE) && kf_worker_start(nd);
+        const int64_t lkf = fused ? nd->cap_scan_kf[cur] : 0;
+        const FilterLaunch f2{nd->h_frame ? nd->h_frame + cur : nullptr, nd->p.min_range, nd->d_counts_kf, nd->d_bases_kf, (int)((lkf + kFB * kFRows - 1) / (kFB * kFRows)),
+                              nd->d_nkept_kf ? nd->d_nkept_kf + cur : nullptr, nullptr, fused ? nd->d_scan_kf[cur] : nullptr, lkf};      // the other stream's own filtered copy of this scan
+        if (via_helper) {
+            KfJob j{oth, sp, icet_dev_scan{nd->d_scan_kf[cur], lkf, lkf}, nd->d_nkept_kf + cur, s_oth, nd->ev_kfdone[nd->owner ^ 1]};
+            j.f2 = f2; j.f2_ev = nd->ev_f2;
+            kf_post(nd, j); nd->kf_built[nd->owner ^ 1] = true;
+        }
+        // X0 is read from pinned host memory by the kernel itself (no H2D command), and k_gn_solve stores the 48 result floats of every iteration straight into pinned
+        // host memory (the same pointer is valid on the device): no copy command in the frame.  (runlen 0 is a memset + copy of X0 on the device side: it keeps the
+        // device buffer and its copy.)
+        float* out_dev = sp.runlen > 0 ? nd->h_out : nd->d_out;
+        ICET_TR(1);
+        if (fused) icet_ctx_set_prologue(own, filter_prologue, &nd->fl[cur], filter_key(nd->fl[cur]));        // filter + loop: one graph, one launch
+        s = icet_register_device_n(own, &sp, 1, &b, fast ? d_cnt : nullptr, nd->h_x0, out_dev);
+        if (fused) icet_ctx_set_prologue(own, nullptr, nullptr, 0);
+        ICET_TR(2);
         icet_ctx_set_stream(own, s_own);
-        if (s != ICET_OK) { nd->err = icet_last_error(own); return s; }
-        NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, so));
-        NCHK(nd, hipEventRecord(nd->ev[2], so));
+        if (s != ICET_OK) { nd->err = icet_last_error(own); if (via_helper) (void)kf_wait_idle(nd); return s; }
+        if (out_dev != nd->h_out) NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, so));
+        if (!fused) NCHK(nd, hipEventRecord(nd->ev[2], so));
         if (!via_helper) {
-            s = icet_keyframe_device_n(oth, &sp, 1, &b, fast ? d_cnt : nullptr);
+            if (fused) {
+                // (the same kept rows in the same order: the same keyframe bits), then the build from it
+                NCHK(nd, filter_prologue(const_cast<FilterLaunch*>(&f2), s_oth));
+                NCHK(nd, hipEventRecord(nd->ev_f2, s_oth));       // the caller's frame has been read (waited for before this push returns)
+                icet_dev_scan bk{nd->d_scan_kf[cur], lkf, lkf};
+                s = icet_keyframe_device_n(oth, &sp, 1, &bk, nd->d_nkept_kf + cur);
+            } else {
+                s = icet_keyframe_device_n(oth, &sp, 1, &b, fast ? d_cnt : nullptr);
+            }
             if (s != ICET_OK) { nd->err = icet_last_error(oth); return s; }
             NCHK(nd, hipEventRecord(nd->ev_kfdone[nd->owner ^ 1], s_oth)); nd->kf_built[nd->owner ^ 1] = true;
         }
         flip_owner = true;                                        // committed together with nd->prev once the frame has succeeded
     } else {
-        s = icet_solve_batch_device(nd->ctx, &sp, 1, &a, &b, nd->h_x0, nd->d_out);
+        float* out_dev = sp.runlen > 0 ? nd->h_out : nd->d_out;
+        s = icet_solve_batch_device(nd->ctx, &sp, 1, &a, &b, nd->h_x0, out_dev);
         if (s != ICET_OK) { nd->err = icet_last_error(nd->ctx); return s; }
-        NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, st));
+        if (out_dev != nd->h_out) NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, st));
         NCHK(nd, hipEventRecord(nd->ev[2], st));
     }
     if (shuffle.valid()) {
         m_map = shuffle.get();
         if (m_map) NCHK(nd, hipMemcpyAsync(nd->d_idx, nd->h_idx, sizeof(int32_t) * m_map, hipMemcpyHostToDevice, st));
     }
+    ICET_TR(3);
     if (so != st) NCHK(nd, hipStreamSynchronize(so));
     NCHK(nd, hipStreamSynchronize(st));
+    ICET_TR(4);
+    if (fused) {                                                  // the caller's frame may be released when this returns: the other stream's filter has read it (long done: it started beside this stream's)
+        const icet_status hs = kf_wait_idle(nd); if (hs != ICET_OK) return hs;      // (the helper has recorded the event)
+        NCHK(nd, hipEventSynchronize(nd->ev_f2));
+    }
     if (fast) { nk = *nd->h_nkept; nd->n_scan[cur] = nk; }        // the filter's count has arrived with everything else
     float X[6];
     std::memcpy(X, nd->h_out, sizeof(X)); std::memcpy(res->pred_stds, nd->h_out + 6, sizeof(float) * 6);
@@ -535,9 +648,13 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
     res->solved = 1; res->n_kept = nk;
     std::memcpy(res->X, X, sizeof(X)); std::memcpy(res->pose, P, sizeof(P)); quat_of(P, res->quat);
     res->map_rows = nd->map_filled ? nd->p.map_capacity : nd->map_pos;
-    nd->timing_valid = true;
+    nd->timing_valid = !fused;
+#ifdef ICET_DIAG_ENV
+    if (trace_on && tq[1] > 0) { tq[5] = now_us(); if (++nd->tr_seen > 6) { for (int k = 0; k < 5; k++) nd->tr[k] += tq[k + 1] - tq[k]; nd->tr_n++; } }      // (steady state: the first frames capture their graphs)
+#endif
     return ICET_OK;
 }
+#undef ICET_TR
 
 // Post-processing of one solved frame on the host: seed, guard, pose chain (odometry.cpp:82-98, simpleMapMaker.cpp:124-137) -- what push_frame does
 // after its synchronisation, for a frame whose 48 result floats are in `out`.
@@ -773,16 +890,22 @@ icet_status icet_node_create(icet_ctx* ctx, const icet_node_params* p, icet_node
 
 icet_status icet_node_destroy(icet_node* nd) {
     if (!nd) return ICET_ERR_BAD_ARG;
+#ifdef ICET_DIAG_ENV
+    if (nd->tr_n) std::fprintf(stderr, "push_frame host us over %ld frames: to-register %.1f | register (loop graph launch) %.1f | keyframe side enqueue %.1f | synchronize %.1f | tail %.1f\n", nd->tr_n,
+                               nd->tr[0] / nd->tr_n, nd->tr[1] / nd->tr_n, nd->tr[2] / nd->tr_n, nd->tr[3] / nd->tr_n, nd->tr[4] / nd->tr_n);
+#endif
     kf_worker_stop(nd);                      // (drains what it still has to enqueue, then joins)
     (void)hipSetDevice(nd->device);
     (void)hipDeviceSynchronize();            // not the borrowed stream: the context may already be gone
-    void* dp[] = {nd->d_scan[0], nd->d_scan[1], nd->d_stage, nd->d_counts, nd->d_bases, nd->d_nkept, nd->d_x0, nd->d_out, nd->d_map, nd->d_idx, nd->d_aligned};
+    void* dp[] = {nd->d_scan[0], nd->d_scan[1], nd->d_stage, nd->d_counts, nd->d_bases, nd->d_nkept, nd->d_x0, nd->d_out, nd->d_map, nd->d_idx, nd->d_aligned,
+                  nd->d_scan_kf[0], nd->d_scan_kf[1], nd->d_counts_kf, nd->d_bases_kf, nd->d_nkept_kf};
     for (void* q : dp) if (q) (void)hipFree(q);
-    void* hp[] = {nd->h_nkept, nd->h_out, nd->h_x0, nd->h_idx};
+    void* hp[] = {nd->h_nkept, nd->h_out, nd->h_x0, nd->h_idx, nd->h_frame};
     for (void* q : hp) if (q) (void)hipHostFree(q);
     for (hipEvent_t e : nd->ev) if (e) (void)hipEventDestroy(e);
     if (nd->ev_loop) (void)hipEventDestroy(nd->ev_loop);
     if (nd->ev_kf) (void)hipEventDestroy(nd->ev_kf);
+    if (nd->ev_f2) (void)hipEventDestroy(nd->ev_f2);
     for (hipEvent_t e : nd->ev_loop2) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : nd->ev_kfdone) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : nd->ev_kf2) if (e) (void)hipEventDestroy(e);

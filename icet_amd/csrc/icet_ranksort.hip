@@ -75,14 +75,17 @@ constexpr int kSplitLoadThreads = 512;
 // (n1_dev: scan-1 row counts that only the device knows -- the descriptor holds an upper bound; this is the keyframe's first kernel, so it also
 // does k_patch_counts' job for its pair: one launch less in front of a sequential caller's keyframe)
 __global__ __launch_bounds__(kSplitLoadThreads) void k_rs_splitters(PairDesc* __restrict__ desc,
-                                                     uint32_t* __restrict__ splitters, int32_t* __restrict__ n_buckets, const int32_t* __restrict__ n1_dev, int32_t* __restrict__ flags, int32_t* __restrict__ zero_rows) {
+                                                     uint32_t* __restrict__ splitters, int32_t* __restrict__ n_buckets, const int32_t* __restrict__ n1_dev, int32_t* __restrict__ flags, int32_t* __restrict__ zero_rows, const PairDesc* __restrict__ h_desc, const int32_t* __restrict__ h_seg, int32_t* __restrict__ seg, int n_pairs) {
     __shared__ uint32_t sm[kSamples];
     const int pair = blockIdx.x, tid = threadIdx.x;
     if (tid < 4) zero_rows[4 * pair + tid] = 0;                 // the pair's exact-zero row counts (k_scan1_spherical adds, k_fit_cluster reads): cleared by the keyframe's first kernel
     if (tid == 0) flags[pair] = 0;                              // the pair's "bounded walk overflowed" flag (k_exec_flags / k_scramble_src set it): cleared here, the keyframe's first kernel, instead of by a memset node
-    const PairDesc d = desc[pair];
+    // (h_desc: the descriptors still sit in the pinned staging -- a small batch, whose first kernel this is: every thread reads its pair's record from there and one
+    // of them puts it, and the pair's segment offset, where the later kernels look; a copy command in front of this kernel costs the stream 10 - 60 us)
+    const PairDesc d = h_desc ? h_desc[pair] : desc[pair];
     const int n = n1_dev ? max(0, min(n1_dev[pair], d.n1)) : d.n1;
-    if (n1_dev && tid == 0) desc[pair].n1 = n;                  // (every thread of this block took both values itself; later kernels read the descriptor)
+    if (h_desc && tid == 0) { PairDesc dn = d; dn.n1 = n; desc[pair] = dn; seg[pair] = h_seg[pair]; if (pair == 0) seg[n_pairs] = h_seg[n_pairs]; }
+    else if (n1_dev && tid == 0) desc[pair].n1 = n;             // (every thread of this block took both values itself; later kernels read the descriptor)
     const int stride = max(1, (n + kSamples - 1) / kSamples);
     const int ns = n > 0 ? (n + stride - 1) / stride : 0;
     uint32_t x[4];
@@ -590,7 +593,7 @@ hipError_t init_rank_sort_kernels() {
 }
 
 hipError_t launch_rank_sort_splitters(const Workspace& w, const LaunchCfg& c, hipStream_t st, const int32_t* d_n1) {
-    k_rs_splitters<<<c.n_pairs, kSplitLoadThreads, 0, st>>>(w.desc, w.splitters, w.n_buckets, d_n1, w.flags, w.zero_rows);
+    k_rs_splitters<<<c.n_pairs, kSplitLoadThreads, 0, st>>>(w.desc, w.splitters, w.n_buckets, d_n1, w.flags, w.zero_rows, c.h_desc_up, c.h_seg_up, w.seg_off, c.n_pairs);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

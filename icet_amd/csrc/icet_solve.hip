@@ -17,9 +17,12 @@ namespace {
 // (desc / n2: the scan-2 row counts that only the device knows -- k_patch_counts' job, folded in when this is the loop's first kernel: one launch
 // less in front of a sequential caller's first iteration)
 __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X, float* __restrict__ xf, int n_pairs, float* __restrict__ xf_last,
-                             PairDesc* __restrict__ desc, const int32_t* __restrict__ n2, uint32_t* __restrict__ done, KeepState* __restrict__ keep, int32_t* __restrict__ keep_modes) {
+                             PairDesc* __restrict__ desc, const int32_t* __restrict__ n2, uint32_t* __restrict__ done, KeepState* __restrict__ keep, int32_t* __restrict__ keep_modes,
+                             const PairDesc* __restrict__ h_desc, const int32_t* __restrict__ h_seg, int32_t* __restrict__ seg) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
+    // (h_desc: k_upload_desc's job as well, when this is the first kernel that reads the descriptors -- the register half of a sequential caller: one launch less)
+    if (h_desc) { desc[p] = h_desc[p]; seg[p] = h_seg[p]; if (p == 0) seg[n_pairs] = h_seg[n_pairs]; }
     if (done) done[p] = 0u;                                      // the point pass' block tickets (k_gn_accumulate_solve)
     if (keep) {                                                  // every solve starts on the whole scan, the pairs in index order
         keep[p].mode = 0; keep[p].n_keep = 0; keep[p].list_passes = 0; keep[p].builds = 0;
@@ -104,8 +107,19 @@ hipError_t launch_patch_counts(const Workspace& w, const LaunchCfg& c, const int
     return hipSuccess;
 }
 
-hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last, const int32_t* d_n2) {
-    k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs, xf_last, w.desc, d_n2, w.gn_done(), c.keep ? w.keep_state : nullptr, w.keep_modes);
+__global__ __launch_bounds__(256) void k_upload_desc(const uint32_t* __restrict__ h_desc, uint32_t* __restrict__ desc, int n_desc_words, const int32_t* __restrict__ h_seg, int32_t* __restrict__ seg, int n_seg) {
+    for (int i = threadIdx.x; i < n_desc_words; i += 256) desc[i] = h_desc[i];
+    for (int i = threadIdx.x; i < n_seg; i += 256) seg[i] = h_seg[i];
+}
+hipError_t launch_upload_desc(const Workspace& w, const PairDesc* h_desc, const int32_t* h_seg, int n_pairs, hipStream_t st) {
+    static_assert(sizeof(PairDesc) % 4 == 0, "copied as 32-bit words");
+    k_upload_desc<<<1, 256, 0, st>>>(reinterpret_cast<const uint32_t*>(h_desc), reinterpret_cast<uint32_t*>(w.desc), n_pairs * (int)(sizeof(PairDesc) / 4), h_seg, w.seg_off, n_pairs + 1);
+    ICET_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last, const int32_t* d_n2, const PairDesc* h_desc, const int32_t* h_seg) {
+    k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs, xf_last, w.desc, d_n2, w.gn_done(), c.keep ? w.keep_state : nullptr, w.keep_modes, h_desc, h_seg, w.seg_off);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -47,9 +47,13 @@ enum { ICET_NODE_NO_RANGE_FILTER = 1,   /* every row of every scan is kept (min_
                                            ahead on a second stream (same result bits either way; for A/B timing and the tests)          */
        ICET_NODE_SERIAL_ENQUEUE  = 16, /* icet_node_push_many_device: enqueue the keyframe builds on the calling thread instead of a helper
                                            thread (same result bits; for A/B timing)                                                     */
-       ICET_NODE_DOUBLE_W        = 32 }; /* the solves run with ICET_FLAG_DOUBLE_W (include/icet_hip.h): the per-voxel weight in double instead of the reference's float
+       ICET_NODE_DOUBLE_W        = 32,   /* the solves run with ICET_FLAG_DOUBLE_W (include/icet_hip.h): the per-voxel weight in double instead of the reference's float
                                             CompleteOrthogonalDecomposition -- 2.4 us less per Gauss-Newton iteration (a 64-channel frame: 0.224 -> 0.205 ms), not the reference's
                                             arithmetic on thin voxels */
+       ICET_NODE_TIME_PHASES     = 64 }; /* keep a frame's range filter and its loop apart, with timing events in between, for icet_node_last_timing (the arrangement
+                                            of rounds 4-5).  Without it a pipelined odometry frame is ONE graph launch -- filter and loop together, no events: each costs
+                                            the host 5-10 us in front of the launch -- and the keyframe build filters the raw frame a second time for itself on its own
+                                            stream (same result bits either way) */
 
 typedef struct icet_node_result {
     int32_t solved;           /* 0 for the first scan: it is only stored (odometry.cpp:46-52)                              */
@@ -98,7 +102,8 @@ icet_status icet_node_aligned(icet_node* node, float* out, int64_t ld, int64_t* 
 icet_status icet_node_snail_trail(icet_node* node, float* out, int64_t ld, int64_t* rows);
 
 /* Device-side time of the pieces of the most recent push, measured with HIP events on the context's stream:
- * [0] range filter ms, [1] ICET solve ms, [2] map-queue kernel ms (0 if no map). */
+ * [0] range filter ms, [1] ICET solve ms, [2] map-queue kernel ms (0 if no map).  ICET_ERR_BAD_ARG when the push recorded none: the first cloud, a burst, and the
+ * one-launch odometry frame (range filter on, no map, no aligned cloud / snail trail, pipelined) unless the node has ICET_NODE_TIME_PHASES. */
 icet_status icet_node_last_timing(icet_node* node, float out_ms[3]);
 
 #ifdef __cplusplus

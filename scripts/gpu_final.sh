@@ -4,8 +4,8 @@ set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 1000 python -m pytest tests -q -m gpu -s --durations=10 > gpurun_out/gpu_suite.log 2>&1; echo "pytest rc=$?" >> gpurun_out/gpu_suite.log; tail -4 gpurun_out/gpu_suite.log
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/r06_bench_default.json 2> gpurun_out/r06_bench_default.err || echo "bench failed"
-timeout -k 10 300 python bench.py --workload odometry --steps 40 --warmup 3 > gpurun_out/r06_bench_odometry.json 2> gpurun_out/r06_bench_odometry.err || echo "odometry bench failed"
-timeout -k 10 300 python bench.py --workload mapmaker --steps 40 --warmup 3 > gpurun_out/r06_bench_mapmaker.json 2> gpurun_out/r06_bench_mapmaker.err || echo "mapmaker bench failed"
+timeout -k 10 300 python bench.py --workload odometry --steps 40 > gpurun_out/r06_bench_odometry.json 2> gpurun_out/r06_bench_odometry.err || echo "odometry bench failed"
+timeout -k 10 300 python bench.py --workload mapmaker --steps 40 > gpurun_out/r06_bench_mapmaker.json 2> gpurun_out/r06_bench_mapmaker.err || echo "mapmaker bench failed"
 bash scripts/kseq.sh --workload sample > gpurun_out/r06_kseq_sample.txt 2>&1
 bash scripts/kseq.sh > gpurun_out/r06_kseq_default.txt 2>&1
 python - <<'PY'

@@ -141,9 +141,7 @@ def test_gpu_odometry_node_matches_oracle(gpu_ctx, seq64):
             assert np.allclose(rg["pred_stds"], ro["pred_stds"], rtol=2e-2, atol=1e-7)
             assert np.abs(rg["pose"] - ro["pose"]).max() <= 1e-3
             assert min(np.abs(rg["quat"] - ro["quat"]).max(), np.abs(rg["quat"] + ro["quat"]).max()) <= 1e-3
-            t = g.last_timing()
-            assert t["filter_ms"] > 0 and t["solve_ms"] > 0
-    g.close(); o.close()
+    g.close(); o.close()                                               # (phase timings: test_gpu_one_launch_frame_equals_phased_frame)
     # the keyframe of every scan is built one frame ahead on a second stream; with ICET_NODE_NO_PIPELINE (flags = 8) it
     # is built inside the frame's own solve, as the reference does: the results must be the same BITS
     kw = dict(api.ODOMETRY_NODE); kw["flags"] = kw.get("flags", 0) | 8
@@ -189,6 +187,40 @@ def test_gpu_odometry_burst_equals_frame_by_frame(gpu_ctx, seq64):
     a = mm.push_many_device(fr[:3]); b = [mref.push_device(*f) for f in fr[:3]]
     assert all(same(x, y) for x, y in zip(a, b)) and np.array_equal(mm.map(), mref.map())
     mm.close(); mref.close()
+
+
+@pytest.mark.gpu
+def test_gpu_one_launch_frame_equals_phased_frame(gpu_ctx, seq64):
+    """Round 6: a pipelined odometry frame is ONE graph launch (range filter captured in front of the loop, the keyframe build behind a filter of its own on the other
+    stream).  ICET_NODE_TIME_PHASES keeps the older arrangement (filter, then loop, events in between).  Same bits for everything a caller can read -- over frames whose
+    row counts differ (the captured launches are sized by the buffers' capacity), a frame that grows the buffers, a burst in between and the map-less settings of the
+    random-settings test."""
+    from icet_amd import api
+    dev = torch.device("cuda", 0)
+    seq = seq64 + _sequence(10, rings=64, steps=2048)[4:]
+    seq = [s if k % 3 else s[: len(s) - 517 * k] for k, s in enumerate(seq)]                # ragged row counts
+    seq.insert(6, np.concatenate([seq[5], seq[4][:40000]]))                                 # one frame larger than every buffer so far
+    bufs = [torch.from_numpy(np.ascontiguousarray(s.T)).to(dev) for s in seq]
+    fr = [(b.data_ptr(), b.shape[1], b.shape[1]) for b in bufs]
+    def same(a, b):
+        return all(np.array_equal(a[k], b[k]) for k in ("X", "pred_stds", "pose", "quat")) and a["solved"] == b["solved"] and a["n_kept"] == b["n_kept"] and a["diverged"] == b["diverged"]
+    for extra in (dict(), dict(seed_x0=0), dict(min_range=6.0, runlen=3)):
+        kw = dict(api.ODOMETRY_NODE); kw.update(extra)
+        one, ph = api.Node(gpu_ctx, **kw), api.Node(gpu_ctx, **dict(kw, flags=api.NODE_TIME_PHASES))
+        for k, f in enumerate(fr):
+            if k == 8:                                                                      # a burst of two in the middle of the sequence
+                ra = one.push_many_device(fr[8:10]); rb = ph.push_many_device(fr[8:10])
+                assert all(same(x, y) for x, y in zip(ra, rb))
+                continue
+            if k == 9: continue
+            ra, rb = one.push_device(*f), ph.push_device(*f)
+            assert same(ra, rb), (extra, k)
+            assert np.array_equal(one.prev_scan(), ph.prev_scan())
+        t2 = ph.last_timing()
+        assert t2["filter_ms"] > 0.003 and t2["solve_ms"] > 0
+        with pytest.raises(Exception):                                                      # the one-launch frame records no timing events
+            one.last_timing()
+        one.close(); ph.close()
 
 
 @pytest.mark.gpu

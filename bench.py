@@ -200,30 +200,21 @@ def run_nodes(args):
             t = node_t.last_timing()
             for key in tim: tim[key] += t[key] / m_t
         node_t.close()
-    # ---- the same frames as ONE burst (icet_node_push_many_device): chained on the device, X0 <- X device to device, one copy of all results at the end
-    # (review r4, item 6: the per-frame entry pays a D2H + a host round trip in the middle of every frame and is bound by the HOST of the box) ----
+    # ---- the same frames through ONE call (icet_node_push_many_device): the library pushes them one after the other -- what is left out is this script's per-frame
+    # Python / ctypes work (round 6: the device-chained burst of rounds 4-5 was slower than one-launch frames and was removed) ----
     burst = None
     if args.workload == "odometry" and world == 1:
         node_b = api.Node(ctx, **kw)
         for k in range(args.warmup + 1):
             node_b.push_device(bufs[k].data_ptr(), frames[k].shape[1], bufs[k].shape[1])
         fr = [(bufs[k].data_ptr(), frames[k].shape[1], bufs[k].shape[1]) for k in range(args.warmup + 1, n_frames)]
-        node_b.push_many_device(fr[:2])                                  # warm the burst path's graphs (the two contexts see device-side X0 pointers here)
-        node_c = api.Node(ctx, **kw)
-        for k in range(args.warmup + 1):
-            node_c.push_device(bufs[k].data_ptr(), frames[k].shape[1], bufs[k].shape[1])
-        node_c.push_many_device(fr[:2]); node_c.close()
-        node_b.close()
-        node_b = api.Node(ctx, **kw)
-        for k in range(args.warmup + 1):
-            node_b.push_device(bufs[k].data_ptr(), frames[k].shape[1], bufs[k].shape[1])
         torch.cuda.synchronize()
         tb = time.perf_counter()
         rb = node_b.push_many_device(fr)
         tb = time.perf_counter() - tb
         same = all(np.array_equal(rb[i]["X"], per_frame_X[i]) for i in range(len(fr)))
         burst = {"frames": len(fr), "frames_per_s": round(len(fr) / tb, 1), "ms_per_frame": round(tb / len(fr) * 1e3, 4), "bits_equal_frame_by_frame": bool(same),
-                 "note": "icet_node_push_many_device: the burst's frames chained on the device, one D2H of all results; device time per frame = filter + loop"}
+                 "note": "icet_node_push_many_device: the same frames through one library call (frame by frame inside the library, no per-frame Python / FFI work)"}
         node_b.close()
     n_mean = int(np.mean([f.shape[1] for f in frames]))
     cap = kw["map_capacity"]

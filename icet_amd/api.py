@@ -533,7 +533,7 @@ class Node:
         return _result_dict(r)
 
     def push_many_device(self, frames):
-        """A burst of frames already in HBM, [(device_ptr, n, ld), ...]: icet_node_push_many_device -- chained on the device, one copy of all results at the end."""
+        """A burst of frames already in HBM, [(device_ptr, n, ld), ...]: icet_node_push_many_device -- pushed one after the other inside the library (one FFI call for all of them)."""
         k = len(frames)
         A = (DevScan * max(k, 1))(*[DevScan(int(p), int(n), int(ld)) for (p, n, ld) in frames])
         R = (NodeResult * max(k, 1))()

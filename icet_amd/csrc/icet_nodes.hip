@@ -119,14 +119,6 @@ __global__ __launch_bounds__(kFB) void k_range_scatter(const float* __restrict__
     }
 }
 
-// A burst's frame (icet_node_push_many_device): its 48 result floats into the burst's table, and the next frame's X0 <- X (odometry.cpp:82) or zeros
-// (simpleMapMaker.cpp:124) -- one tiny kernel behind the loop instead of two device-to-device copies (a hipMemcpyAsync of a few bytes costs a stream ~20 us).
-__global__ void k_burst_collect(const float* __restrict__ out, float* __restrict__ out_all, float* __restrict__ x0, int seed) {
-    const int i = threadIdx.x;
-    if (i < 48) out_all[i] = out[i];
-    if (i < 6) x0[i] = seed ? out[i] : 0.f;
-}
-
 // EigenQueue::add_new_scan (src/simpleMapMaker.cpp:34-41): rows [pos, pos + m) (mod cap) take the down-sampled scan
 // rows, then EVERY ring row becomes (row - trans) * Rinv.  One pass over the ring.
 __global__ __launch_bounds__(256) void k_map_add_scan(float* __restrict__ qx, float* __restrict__ qy, float* __restrict__ qz, int cap, int pos, int m,
@@ -270,12 +262,8 @@ struct icet_node {
     std::vector<float> snail;                                                               // scanMatcher.cpp:27-28,79-84: rows x 3 row-major, host
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [5]: start of the loop on the owner's stream (pipelined)
     bool timing_valid = false, timed_map = false;
-    // icet_node_push_many_device: per-frame results and kept-row counts of a burst, in HBM until its end, and the events that order the three streams
-    float* d_out_all = nullptr; float* h_out_all = nullptr; int32_t* d_nk_all = nullptr; int32_t* h_nk_all = nullptr; int cap_many = 0;
-    hipEvent_t ev_loop = nullptr, ev_kf = nullptr;
     KfWorker* kw = nullptr;                                       // started with the first build that goes through it
     hipEvent_t ev_kfdone[2] = {nullptr, nullptr}; bool kf_built[2] = {false, false};          // per context: its last keyframe build has been enqueued / the event behind it
-    hipEvent_t ev_loop2[2] = {nullptr, nullptr}, ev_kf2[2] = {nullptr, nullptr};      // per frame parity: end of the loop / of the keyframe build (a burst's filter waits for the frame two back)
     // The one-launch frame (round 6, push_frame): the loop's context captures the range filter in front of its loop (FilterLaunch = what its hook enqueues), and the
     // keyframe build of the same scan runs on the other context's stream behind a filter of ITS OWN into a second buffer -- no dependency between the two streams inside a frame.
     FrameDesc* h_frame = nullptr;                                 // pinned, [2]: by scan buffer
@@ -521,7 +509,7 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
             NCHK(nd, hipStreamWaitEvent(s_oth, nd->ev[1], 0));
         }
         if (!fused) NCHK(nd, hipEventRecord(nd->ev[5], so));
-        // The keyframe side of a one-launch frame is enqueued by the node's HELPER thread (the one bursts use), posted BEFORE this thread launches the loop's graph: its
+        // The keyframe side of a one-launch frame is enqueued by the node's HELPER thread, posted BEFORE this thread launches the loop's graph: its
         // ~45 us of enqueueing (three filter launches, an event, a graph of 18 kernels) then run beside the loop's launch and not behind it -- the build, not the loop,
         // is what the next frame waits for, and it used to start 60 us into the frame.  (Round 5, frame in phases: measured, no gain, 4.83-4.93 k frames/s with, 4.82-4.92 k
         // without.)  A failure of the build is reported by the next call that waits for the helper.
@@ -656,181 +644,6 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
 }
 #undef ICET_TR
 
-// Post-processing of one solved frame on the host: seed, guard, pose chain (odometry.cpp:82-98, simpleMapMaker.cpp:124-137) -- what push_frame does
-// after its synchronisation, for a frame whose 48 result floats are in `out`.
-void finish_frame_host(icet_node* nd, const float* out, int64_t nk, icet_node_result* res) {
-    std::memset(res, 0, sizeof(*res));
-    float X[6];
-    std::memcpy(X, out, sizeof(X)); std::memcpy(res->pred_stds, out + 6, sizeof(float) * 6);
-    for (int k = 0; k < 6; k++) nd->X0[k] = nd->p.seed_x0 ? X[k] : 0.f;
-    const float tt = nd->p.trans_thresh, rt = nd->p.rot_thresh;
-    if ((tt > 0.f && (std::fabs(X[0]) > tt || std::fabs(X[1]) > tt || std::fabs(X[2]) > tt)) ||
-        (rt > 0.f && (std::fabs(X[3]) > rt || std::fabs(X[4]) > rt || std::fabs(X[5]) > rt))) {
-        for (int k = 0; k < 6; k++) X[k] = 0.f;
-        res->diverged = 1;
-    }
-    float R[9]; euler_R_host(X[3], X[4], X[5], R);
-    const float Hi[16] = {R[0], R[1], R[2], X[0], R[3], R[4], R[5], X[1], R[6], R[7], R[8], X[2], 0, 0, 0, 1};
-    float P[16];
-    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { float acc = 0.f; for (int k = 0; k < 4; k++) acc += nd->pose[r * 4 + k] * Hi[k * 4 + c]; P[r * 4 + c] = acc; }
-    std::memcpy(nd->pose, P, sizeof(P));
-    res->solved = 1; res->n_kept = nk;
-    std::memcpy(res->X, X, sizeof(X)); std::memcpy(res->pose, P, sizeof(P)); quat_of(P, res->quat);
-    res->map_rows = 0;
-}
-
-// A burst of frames without a host round trip between them (the pipelined odometry configuration: range filter, no map, no extra clouds).  What
-// push_frame does per frame -- filter on the node's stream, the loop against the keyframe parked one frame ago on one context, the keyframe of the new
-// scan on the other -- is enqueued for every frame back to back; the seed X0 <- X of the previous frame (odometry.cpp:82) travels device to device,
-// the three streams are ordered by events, every pointer the solve's halves see is the same from frame to frame (so that both replay their captured
-// graphs), and the frames' 48 result floats and kept-row counts are collected in HBM and copied out ONCE.  Seed, guard and pose chain are functions
-// of the X sequence and are evaluated on the host afterwards, frame by frame, exactly as push_frame does.  Same bits as frame-by-frame pushes.
-icet_status push_many_fast(icet_node* nd, const icet_dev_scan* fr, int K, icet_node_result* res) {
-    hipStream_t st = nd->stream;
-    nd->timing_valid = false;
-    int64_t nmax = 0;
-    for (int k = 0; k < K; k++) nmax = std::max<int64_t>(nmax, fr[k].n);
-    for (int w = 0; w < 2; w++) if (w != nd->prev) { icet_status s = ensure_scan(nd, w, nmax); if (s != ICET_OK) return s; }
-    if (nd->cap_scan[nd->prev] < nmax) {
-        // the buffer that holds the previous scan must grow too (it becomes `cur` in the burst's second frame): keep its rows
-        NCHK(nd, hipDeviceSynchronize());
-        const int64_t cap = (nmax + nmax / 8 + 63) / 64 * 64, oldl = nd->ld_scan[nd->prev], rows = nd->n_scan[nd->prev];
-        float* nb = nullptr;
-        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nb), sizeof(float) * 3 * (size_t)cap));
-        if (rows) NCHK(nd, hipMemcpy2D(nb, cap * sizeof(float), nd->d_scan[nd->prev], oldl * sizeof(float), rows * sizeof(float), 3, hipMemcpyDeviceToDevice));
-        NCHK(nd, hipFree(nd->d_scan[nd->prev]));
-        nd->d_scan[nd->prev] = nb; nd->cap_scan[nd->prev] = cap; nd->ld_scan[nd->prev] = cap;
-        // the parked keyframe was built from the old buffer's rows (its tables live in the context): still valid; the loop never reads scan 1 again
-    }
-    const int n_blocks_max = (int)((nmax + kFB * kFRows - 1) / (kFB * kFRows));
-    if (n_blocks_max > nd->cap_blocks) {
-        NCHK(nd, hipStreamSynchronize(st));
-        if (nd->d_counts) NCHK(nd, hipFree(nd->d_counts));
-        if (nd->d_bases) NCHK(nd, hipFree(nd->d_bases));
-        nd->d_counts = nd->d_bases = nullptr;
-        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_counts), sizeof(int32_t) * n_blocks_max));
-        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_bases), sizeof(int32_t) * n_blocks_max));
-        nd->cap_blocks = n_blocks_max;
-    }
-    if (K > nd->cap_many) {
-        NCHK(nd, hipDeviceSynchronize());
-        if (nd->d_out_all) NCHK(nd, hipFree(nd->d_out_all));
-        if (nd->d_nk_all) NCHK(nd, hipFree(nd->d_nk_all));
-        if (nd->h_out_all) NCHK(nd, hipHostFree(nd->h_out_all));
-        if (nd->h_nk_all) NCHK(nd, hipHostFree(nd->h_nk_all));
-        nd->d_out_all = nullptr; nd->d_nk_all = nullptr; nd->h_out_all = nullptr; nd->h_nk_all = nullptr; nd->cap_many = 0;
-        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_out_all), sizeof(float) * 48 * (size_t)K));
-        NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_nk_all), sizeof(int32_t) * (size_t)K));
-        NCHK(nd, hipHostMalloc(reinterpret_cast<void**>(&nd->h_out_all), sizeof(float) * 48 * (size_t)K));
-        NCHK(nd, hipHostMalloc(reinterpret_cast<void**>(&nd->h_nk_all), sizeof(int32_t) * (size_t)K));
-        nd->cap_many = K;
-    }
-    if (!nd->ev_loop) { NCHK(nd, hipEventCreateWithFlags(&nd->ev_loop, hipEventDisableTiming)); NCHK(nd, hipEventCreateWithFlags(&nd->ev_kf, hipEventDisableTiming)); }
-    for (int i = 0; i < 2; i++) if (!nd->ev_loop2[i]) { NCHK(nd, hipEventCreateWithFlags(&nd->ev_loop2[i], hipEventDisableTiming)); NCHK(nd, hipEventCreateWithFlags(&nd->ev_kf2[i], hipEventDisableTiming)); }
-    icet_params sp = nd->p.solve; sp.flags = (nd->p.flags & ICET_NODE_DOUBLE_W) ? ICET_FLAG_DOUBLE_W : ICET_FLAG_NONE;
-    std::memcpy(nd->h_x0, nd->X0, sizeof(nd->X0));
-    int prev = nd->prev, owner = nd->owner;
-    // A burst is bound by the host: per frame three filter launches, the loop's graph (~80 us of host time) and the keyframe's graph (~140 us), all on one thread.
-    // The keyframe builds go to a helper thread: they run on the OTHER context / stream of each frame and depend on nothing the main thread does after it has made
-    // that stream wait for the frame's filter.  What the two threads must agree on: frame k + 1's loop is enqueued on the context frame k's keyframe build was
-    // enqueued on -- behind it, so the main thread waits (on the host) until the helper has finished enqueueing frame k's build.
-    const bool helper_on = !(nd->p.flags & ICET_NODE_SERIAL_ENQUEUE) && K > 1 && kf_worker_start(nd);
-    // (In the frame-by-frame path the loop runs on the filter's stream -- +10 % frames/s.  Here it does not pay: a burst is a chain loop k-1 -> build k -> loop k+1 across
-    // two streams whichever way the loops are placed; measured 3.68 k frames/s with the loops on the filter's stream against 3.81 k on their contexts' streams.)
-#ifdef ICET_DIAG_ENV
-    static const bool loops_on_st = getenv("ICET_NODE_BURST_LOOPS_ON_FILTER_STREAM") != nullptr;
-#else
-    constexpr bool loops_on_st = false;
-#endif
-    if (loops_on_st) for (icet_ctx* c : nd->kf) NCHK(nd, hipStreamSynchronize(reinterpret_cast<hipStream_t>(icet_stream(c))));     // the build the first loop needs was enqueued by an earlier call: done (once per burst)
-#ifdef ICET_DIAG_ENV
-    const bool trace = getenv("ICET_NODE_TRACE") != nullptr;
-#else
-    constexpr bool trace = false;
-#endif
-    double t_filter = 0, t_wait = 0, t_reg = 0, t_kf_inline = 0;
-    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_begin = now();
-    // The burst's SECOND frame filters into the buffer that holds the node's previous scan -- which the keyframe build enqueued before the burst (the last single
-    // push's, on that context's stream, or the first cloud's) may still be reading as its scan 1: no host synchronisation lies in between (push_frame waits for the
-    // filter's stream only) and the k > 1 rule below knows nothing of frames before the burst.  The filter's stream waits for that build here, once per burst.
-    if (nd->kf_built[owner]) NCHK(nd, hipStreamWaitEvent(st, nd->ev_kfdone[owner], 0));
-    for (int k = 0; k < K; k++) {
-        const double t0 = now();
-        double tw = 0;
-        if (helper_on) {
-            // The previous frame's build may still be being enqueued -- possibly CAPTURED into a graph -- by the helper, on the stream this frame's loop will use and
-            // on which two frames' old events were recorded.  Nothing of this frame may touch that stream before the helper is done with it: not a stream wait on
-            // it, and not a wait on an event that was recorded on it either (HIP refuses that with "dependency created on uncaptured work in another stream" while
-            // the recording stream is capturing, whenever the event was recorded -- found as a failure of one run in three of the burst test).
-            const icet_status hs = kf_wait_idle(nd); if (hs != ICET_OK) return hs;
-            tw = now() - t0; t_wait += tw;
-        }
-        const int cur = prev ^ 1;
-        const int64_t n = fr[k].n, ld = fr[k].ld, lcur = nd->cap_scan[cur];
-        icet_ctx* own = nd->kf[owner]; icet_ctx* oth = nd->kf[owner ^ 1];
-        // the loop runs on the filter's stream, as in the frame-by-frame path (no stream-to-stream dependency between filter and loop, and none for the X0 chain);
-        // the keyframe builds keep their contexts' own streams
-        hipStream_t s_own = reinterpret_cast<hipStream_t>(icet_stream(own)), sk = reinterpret_cast<hipStream_t>(icet_stream(oth));
-        hipStream_t so = loops_on_st ? st : s_own;
-        int32_t* d_cnt = nd->d_nkept + cur;
-        // the buffer and the counter this frame's filter writes were last read by frame k - 2: by its loop (as scan 2) and by its keyframe build (as scan 1).  The
-        // filter waits for exactly those two (events per frame parity) -- not for the previous frame's loop, which only ends a whole loop later: measured, that
-        // wait held the next filter, and behind it the next keyframe build, back by ~55 us per frame.  (The frames before the burst ended with a host wait.)
-        if (k > 1) { if (!loops_on_st) NCHK(nd, hipStreamWaitEvent(st, nd->ev_loop2[k & 1], 0)); NCHK(nd, hipStreamWaitEvent(st, nd->ev_kf2[k & 1], 0)); }      // (the loops share the filter's stream: stream order)
-        const float *x = fr[k].ptr, *y = x + ld, *z = x + 2 * ld;
-        float* o = nd->d_scan[cur];
-        const int n_blocks = (int)((n + kFB * kFRows - 1) / (kFB * kFRows));
-        if (n > 0) {
-            k_range_count<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_counts);
-            k_range_scan<<<1, kFB, 0, st>>>(nd->d_counts, nd->d_bases, n_blocks, d_cnt, nd->d_nk_all + k);
-            k_range_scatter<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_bases, o, o + lcur, o + 2 * lcur);
-            NCHK(nd, hipGetLastError());
-        }
-        NCHK(nd, hipEventRecord(nd->ev[1], st));
-        const double t1 = now(); t_filter += t1 - t0 - tw;
-        const double t2 = t1;
-        if (!loops_on_st) NCHK(nd, hipStreamWaitEvent(so, nd->ev[1], 0));
-        NCHK(nd, hipStreamWaitEvent(sk, nd->ev[1], 0));                              // (behind the filter in st's order lies the previous loop, which read the tables this build overwrites)
-        // X0: the node's seed for the burst's first frame, then the previous frame's X (or zeros), device to device
-        if (k == 0) NCHK(nd, hipMemcpyAsync(nd->d_x0, nd->h_x0, sizeof(float) * 6, hipMemcpyHostToDevice, so));
-        else if (!loops_on_st) NCHK(nd, hipStreamWaitEvent(so, nd->ev_loop2[(k - 1) & 1], 0));         // the previous frame's result and the X0 made from it (on the other context's stream)
-        if (loops_on_st && k > 0) NCHK(nd, hipStreamWaitEvent(st, nd->ev_kf2[(k - 1) & 1], 0));       // this loop reads the tables the previous frame's build wrote (on that context's stream)
-        icet_dev_scan b{nd->d_scan[cur], lcur, lcur};                               // rows: the buffer's capacity as upper bound, the count is read on the device
-        if (helper_on) {
-            // this frame's build may start now (its stream waits for the filter); the loop goes on `own`, the context of the PREVIOUS frame's build: behind it (above)
-            kf_post(nd, KfJob{oth, sp, b, d_cnt, sk, nd->ev_kf2[k & 1]});
-        }
-        if (loops_on_st) icet_ctx_set_stream(own, st);
-        icet_status s = icet_register_device_n(own, &sp, 1, &b, d_cnt, nd->d_x0, nd->d_out);
-        icet_ctx_set_stream(own, s_own);
-        if (s != ICET_OK) { nd->err = icet_last_error(own); return s; }
-        k_burst_collect<<<1, 64, 0, so>>>(nd->d_out, nd->d_out_all + 48 * (size_t)k, nd->d_x0, nd->p.seed_x0 ? 1 : 0);
-        NCHK(nd, hipGetLastError());
-        NCHK(nd, hipEventRecord(nd->ev_loop2[k & 1], so));
-        const double t3 = now(); t_reg += t3 - t2;
-        if (!helper_on) {
-            s = icet_keyframe_device_n(oth, &sp, 1, &b, d_cnt);
-            if (s != ICET_OK) { nd->err = icet_last_error(oth); return s; }
-            NCHK(nd, hipEventRecord(nd->ev_kf2[k & 1], sk));
-        }
-        t_kf_inline += now() - t3;
-        prev = cur; owner ^= 1;
-    }
-    const double t_enq = now() - t_begin;
-    if (helper_on) { const icet_status hs = kf_wait_idle(nd); if (hs != ICET_OK) return hs; }
-    for (icet_ctx* c : nd->kf) NCHK(nd, hipStreamSynchronize(reinterpret_cast<hipStream_t>(icet_stream(c))));
-    NCHK(nd, hipMemcpyAsync(nd->h_out_all, nd->d_out_all, sizeof(float) * 48 * (size_t)K, hipMemcpyDeviceToHost, st));
-    NCHK(nd, hipMemcpyAsync(nd->h_nk_all, nd->d_nk_all, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
-    NCHK(nd, hipStreamSynchronize(st));
-    if (trace) fprintf(stderr, "burst K=%d helper=%d: enqueue %.0f us total (per frame: filter+events %.1f, wait for helper %.1f, loop graph %.1f, keyframe inline %.1f; helper job %.1f), until results %.0f us\n", K, (int)helper_on, t_enq, t_filter / K, t_wait / K, t_reg / K, t_kf_inline / K, 0.0, now() - t_begin);
-    for (int k = 0; k < K; k++) finish_frame_host(nd, nd->h_out_all + 48 * (size_t)k, nd->h_nk_all[k], &res[k]);
-    nd->prev = prev; nd->owner = owner;
-    nd->n_scan[prev] = nd->h_nk_all[K - 1]; nd->ld_scan[prev] = nd->cap_scan[prev];
-    // what a following single push (or burst) waits for: the burst's last build, on the context that is now `owner` (complete: both streams were drained above)
-    NCHK(nd, hipEventRecord(nd->ev_kfdone[owner], reinterpret_cast<hipStream_t>(icet_stream(nd->kf[owner])))); nd->kf_built[owner] = true;
-    return ICET_OK;
-}
 
 // No exception may cross the C ABI (std::async can throw std::system_error, the shuffle's vector bad_alloc -- rethrown by get()), and
 // a frame that fails half way must not leave the node's idea of "previous scan" and the parked keyframe disagreeing: on ANY failure
@@ -903,16 +716,8 @@ icet_status icet_node_destroy(icet_node* nd) {
     void* hp[] = {nd->h_nkept, nd->h_out, nd->h_x0, nd->h_idx, nd->h_frame};
     for (void* q : hp) if (q) (void)hipHostFree(q);
     for (hipEvent_t e : nd->ev) if (e) (void)hipEventDestroy(e);
-    if (nd->ev_loop) (void)hipEventDestroy(nd->ev_loop);
-    if (nd->ev_kf) (void)hipEventDestroy(nd->ev_kf);
     if (nd->ev_f2) (void)hipEventDestroy(nd->ev_f2);
-    for (hipEvent_t e : nd->ev_loop2) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : nd->ev_kfdone) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : nd->ev_kf2) if (e) (void)hipEventDestroy(e);
-    if (nd->d_out_all) (void)hipFree(nd->d_out_all);
-    if (nd->d_nk_all) (void)hipFree(nd->d_nk_all);
-    if (nd->h_out_all) (void)hipHostFree(nd->h_out_all);
-    if (nd->h_nk_all) (void)hipHostFree(nd->h_nk_all);
     for (icet_ctx* k : nd->kf) if (k) (void)icet_destroy(k);
     delete nd;
     return ICET_OK;
@@ -932,25 +737,12 @@ icet_status icet_node_push_many_device(icet_node* nd, const icet_dev_scan* frame
         if (frames[k].n < 0 || frames[k].ld < frames[k].n || (frames[k].n > 0 && !frames[k].ptr) || frames[k].n >= ((int64_t)1 << 30)) return ICET_ERR_BAD_ARG;
     if (hipSetDevice(nd->device) != hipSuccess) return ICET_ERR_NO_DEVICE;
     { const icet_status hs = kf_wait_idle(nd); if (hs != ICET_OK) { (void)hipDeviceSynchronize(); nd->initialized = false; return hs; } }
-    int k0 = 0;
-    // what cannot go through the burst path -- the very first cloud (stored, not solved), an empty cloud, and every configuration whose frame needs the host
-    // in the middle (map queue, aligned cloud, snail trail, no range filter, no pipeline) -- goes frame by frame
-    const bool fast_cfg = nd->pipelined && nd->p.map_capacity == 0 && !(nd->p.flags & (ICET_NODE_NO_RANGE_FILTER | ICET_NODE_ALIGNED_CLOUD | ICET_NODE_SNAIL_TRAIL));
-    bool all_nonempty = true;
-    for (int k = 0; k < n_frames; k++) all_nonempty = all_nonempty && frames[k].n > 0;
-    if (!fast_cfg || !all_nonempty) {
-        for (int k = 0; k < n_frames; k++) { icet_status s = push_device(nd, frames[k].ptr, frames[k].n, frames[k].ld, &results[k]); if (s != ICET_OK) return s; }
-        return ICET_OK;
-    }
-    if (!nd->initialized && n_frames > 0) { icet_status s = push_device(nd, frames[0].ptr, frames[0].n, frames[0].ld, &results[0]); if (s != ICET_OK) return s; k0 = 1; }
-    if (k0 >= n_frames) return ICET_OK;
-    icet_status s;
-    try {
-        s = push_many_fast(nd, frames + k0, n_frames - k0, results + k0);
-    } catch (const std::bad_alloc&) { nd->err = "out of host memory"; s = ICET_ERR_NOMEM;
-    } catch (...) { nd->err = "host error"; s = ICET_ERR_NOMEM; }
-    if (s != ICET_OK) { (void)kf_wait_idle(nd); (void)hipDeviceSynchronize(); nd->initialized = false; nd->timing_valid = false; }
-    return s;
+    // Rounds 4-5 chained a burst's frames on the device (X0 <- X device to device, results parked in HBM, one copy at the end).  That needs two hand-overs between
+    // streams per frame -- the build of frame k waits for the loop of frame k - 1 to let go of the context's tables, the loop of frame k + 1 for that build -- at 30 to
+    // 60 us each on this part, and ran at 4.0 - 4.7 k frames/s; since a frame is one graph launch (push_frame, round 6) the host in the loop costs ~25 us and frame by
+    // frame runs at 5.0 - 5.2 k.  The burst entry is therefore a loop over frames (no Python / FFI call per frame for the caller: that is what it still saves).
+    for (int k = 0; k < n_frames; k++) { const icet_status s = push_device(nd, frames[k].ptr, frames[k].n, frames[k].ld, &results[k]); if (s != ICET_OK) return s; }
+    return ICET_OK;
 }
 
 icet_status icet_node_push(icet_node* nd, const float* scan, int64_t n, int64_t ld, icet_node_result* res) {

@@ -45,8 +45,8 @@ enum { ICET_NODE_NO_RANGE_FILTER = 1,   /* every row of every scan is kept (min_
        ICET_NODE_SNAIL_TRAIL     = 4,   /* maintain the snail trail (icet_node_snail_trail)                                 */
        ICET_NODE_NO_PIPELINE     = 8,   /* build every frame's keyframe inside its own solve, as the reference does, instead of one frame
                                            ahead on a second stream (same result bits either way; for A/B timing and the tests)          */
-       ICET_NODE_SERIAL_ENQUEUE  = 16, /* icet_node_push_many_device: enqueue the keyframe builds on the calling thread instead of a helper
-                                           thread (same result bits; for A/B timing)                                                     */
+       ICET_NODE_SERIAL_ENQUEUE  = 16, /* a one-launch frame (see ICET_NODE_TIME_PHASES): enqueue the keyframe side on the calling thread, behind the loop's
+                                           launch, instead of on the node's helper thread beside it (same result bits; for A/B timing)   */
        ICET_NODE_DOUBLE_W        = 32,   /* the solves run with ICET_FLAG_DOUBLE_W (include/icet_hip.h): the per-voxel weight in double instead of the reference's float
                                             CompleteOrthogonalDecomposition -- 2.4 us less per Gauss-Newton iteration (a 64-channel frame: 0.224 -> 0.205 ms), not the reference's
                                             arithmetic on thin voxels */
@@ -80,12 +80,11 @@ const char* icet_node_last_error(const icet_node* node);
 icet_status icet_node_push(icet_node* node, const float* scan, int64_t n, int64_t ld, icet_node_result* res);
 icet_status icet_node_push_device(icet_node* node, const float* d_scan, int64_t n, int64_t ld, icet_node_result* res);
 
-/* A BURST of frames, device pointers, results for all of them at the end: what a caller gets that replays a log, batches frames between
- * publications, or simply does not want the host between two frames.  For the pipelined odometry configuration (range filter on, no map queue, no
- * aligned cloud / snail trail) the frames are chained on the device -- X0 <- X of the previous frame (odometry.cpp:82) travels device to device, the
- * per-frame results wait in HBM, ONE copy and one synchronisation at the end -- and seed, guard and pose chain are evaluated on the host afterwards,
- * frame by frame, with the bits of frame-by-frame pushes.  Any other configuration is pushed frame by frame by the call.  Every frame's buffer must
- * stay valid until the call returns.  results[k] belongs to frames[k] (a first-ever frame: solved = 0). */
+/* A BURST of frames, device pointers, results for all of them at the end: what a caller gets that replays a log or batches frames between publications.  The
+ * frames are pushed one after the other by the call itself, with the bits of frame-by-frame pushes (what the caller saves is its own per-frame call).  Rounds 4-5
+ * chained a burst's frames on the device (X0 <- X device to device, one copy of all results at the end); with two contexts that costs two hand-overs between streams
+ * per frame, and since a frame is one graph launch (round 6) frame-by-frame is the faster arrangement on this part: 5.0-5.2 k frames/s against 4.0-4.7 k.  Every
+ * frame's buffer must stay valid until the call returns.  results[k] belongs to frames[k] (a first-ever frame: solved = 0). */
 icet_status icet_node_push_many_device(icet_node* node, const icet_dev_scan* frames, int32_t n_frames, icet_node_result* results);
 
 /* `EigenQueue::getQueue()` (simpleMapMaker.cpp:43-50): copies the valid rows, oldest first, to the host as rows x 3
@@ -102,7 +101,7 @@ icet_status icet_node_aligned(icet_node* node, float* out, int64_t ld, int64_t* 
 icet_status icet_node_snail_trail(icet_node* node, float* out, int64_t ld, int64_t* rows);
 
 /* Device-side time of the pieces of the most recent push, measured with HIP events on the context's stream:
- * [0] range filter ms, [1] ICET solve ms, [2] map-queue kernel ms (0 if no map).  ICET_ERR_BAD_ARG when the push recorded none: the first cloud, a burst, and the
+ * [0] range filter ms, [1] ICET solve ms, [2] map-queue kernel ms (0 if no map).  ICET_ERR_BAD_ARG when the push recorded none: the first cloud and the
  * one-launch odometry frame (range filter on, no map, no aligned cloud / snail trail, pipelined) unless the node has ICET_NODE_TIME_PHASES. */
 icet_status icet_node_last_timing(icet_node* node, float out_ms[3]);
 

@@ -59,7 +59,7 @@ public:
         if (status != ICET_OK) { error = std::string("icet_node_push failed: ") + icet_node_last_error(node_); return false; }
         return last.solved != 0;
     }
-    // A burst of frames that already live in HBM (icet_node_push_many_device): chained on the device, one copy of all results at the end; results[k] belongs to
+    // A burst of frames that already live in HBM (icet_node_push_many_device): pushed one after the other by the library; results[k] belongs to
     // frames[k] (`last` = the burst's last frame).  Returns the number of frames that were solved (a first-ever frame is only stored).
     int pointCloudBurst(const icet_dev_scan* frames, int n_frames, std::vector<icet_node_result>& results) {
         results.assign(n_frames > 0 ? (size_t)n_frames : 0, icet_node_result{});

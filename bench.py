@@ -178,9 +178,6 @@ def run_nodes(args):
     for k in range(args.warmup + 1, n_frames):
         r = push(k)
         per_frame_X.append(r["X"].copy())
-        if kw["map_capacity"]:                       # (the one-launch odometry frame records no timing events: phases from a second node below)
-            t = node.last_timing()
-            for key in tim: tim[key] += t[key]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -188,8 +185,8 @@ def run_nodes(args):
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
     for key in tim: tim[key] /= max(args.steps, 1)
-    if not kw["map_capacity"] and world == 1:
-        # the pipelined odometry frame is one graph launch (filter + loop together): the phases are timed on a second node that keeps them apart (ICET_NODE_TIME_PHASES)
+    if world == 1:
+        # a pipelined frame is one graph launch (filter + loop together, no timing events): the phases are timed on a second node that keeps them apart (ICET_NODE_TIME_PHASES)
         node_t = api.Node(ctx, **dict(kw, flags=kw.get("flags", 0) | api.NODE_TIME_PHASES))
         for k in range(args.warmup + 1):
             node_t.push_device(bufs[k].data_ptr(), frames[k].shape[1], bufs[k].shape[1])

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kFB) void k_range_scan(const int32_t* __restrict__ 
     for (int i = lo; i < hi; i++) s += counts[i];
     part[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int t = 0; t < kFB; t++) { const int v = part[t]; part[t] = run; run += v; } *n_kept = run; if (n_kept_copy) *n_kept_copy = run; }
+    if (threadIdx.x == 0) { int run = 0; for (int t = 0; t < kFB; t++) { const int v = part[t]; part[t] = run; run += v; } *n_kept = run; if (n_kept_copy) { *n_kept_copy = run; __threadfence_system(); } }      // (the copy lives in pinned host memory: a host thread may be watching it)
     __syncthreads();
     int run = part[threadIdx.x];
     for (int i = lo; i < hi; i++) { bases[i] = run; run += counts[i]; }
@@ -430,7 +430,11 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
     // ... and since round 6 such a frame is ONE launch on the critical path: the loop's context captures the filter in front of its loop (one graph: the loop's first kernel
     // used to start 30-40 us after the filter's last one), and the keyframe build of this scan, on the other stream, filters the raw frame once more for itself instead of
     // waiting for this stream's filter (a dependency between two streams costs more than 20 us of duplicated filter).  ICET_NODE_TIME_PHASES keeps the phases apart.
-    const bool fused = fast && loop_on_filter_stream && nd->p.solve.runlen > 0 && !(nd->p.flags & ICET_NODE_TIME_PHASES);
+    // The map maker's frame takes the same shape (round 6): its loop does not need the kept-row count on the host either -- only the down-sample shuffle does, and the
+    // host gets the count by watching the pinned word the filter's kernel stores it into, a few microseconds into the frame, while the loop runs.
+    const bool map_ok = nd->pipelined && nd->p.map_capacity > 0 && n > 0 && !(nd->p.flags & (ICET_NODE_NO_RANGE_FILTER | ICET_NODE_ALIGNED_CLOUD | ICET_NODE_SNAIL_TRAIL));
+    const bool fused = (fast || map_ok) && loop_on_filter_stream && nd->p.solve.runlen > 0 && !(nd->p.flags & ICET_NODE_TIME_PHASES);
+    const bool dev_count = fast || fused;                         // the solve's halves read the row count on the device
     const int n_blocks = fused ? (int)((lcur + kFB * kFRows - 1) / (kFB * kFRows)) : (int)((n + kFB * kFRows - 1) / (kFB * kFRows));      // fused: by CAPACITY (the launch does not change with n)
     if (n_blocks > nd->cap_blocks) {
         NCHK(nd, hipDeviceSynchronize());
@@ -449,6 +453,7 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         *nd->h_nkept = (int32_t)n;
     } else if (fused) {
         nd->h_frame[cur] = FrameDesc{d_scan, (int32_t)n, (int32_t)ld};                          // what both filters of this frame read
+        *static_cast<volatile int32_t*>(nd->h_nkept) = -1;                                      // ("not yet": the map maker's host side watches this word)
         nd->fl[cur] = FilterLaunch{nd->h_frame + cur, nd->p.min_range, nd->d_counts, nd->d_bases, n_blocks, d_cnt, nd->h_nkept, nd->d_scan[cur], lcur};
     } else if (n > 0) {
         const float *x = d_scan, *y = d_scan + ld, *z = d_scan + 2 * ld;
@@ -459,15 +464,15 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         k_range_scan<<<1, kFB, 0, st>>>(nd->d_counts, nd->d_bases, n_blocks, d_cnt, nd->h_nkept);
         k_range_scatter<<<n_blocks, kFB, 0, st>>>(x, y, z, (int)n, nd->p.min_range, nd->d_bases, o, o + lcur, o + 2 * lcur);
         NCHK(nd, hipGetLastError());
-        if (fast) NCHK(nd, hipEventRecord(nd->ev[1], st));        // what the solve streams wait for: the filtered scan
+        if (dev_count) NCHK(nd, hipEventRecord(nd->ev[1], st));   // what the solve streams wait for: the filtered scan
     } else {
         *nd->h_nkept = 0;
     }
-    if (!fast) NCHK(nd, hipEventRecord(nd->ev[1], st));
-    if (!fast) NCHK(nd, hipStreamSynchronize(st));                // the solve's launch geometry needs the row count
+    if (!dev_count) NCHK(nd, hipEventRecord(nd->ev[1], st));
+    if (!dev_count) NCHK(nd, hipStreamSynchronize(st));           // the solve's launch geometry needs the row count
     // fast: an upper bound until the end-of-frame synchronisation -- the buffer's CAPACITY, which does not change from frame to frame, so that the
     // two halves of the solve see the same launch key every frame and replay their captured graphs (one hipGraphLaunch each instead of ~35 launches)
-    int64_t nk = fast ? lcur : (int64_t)*nd->h_nkept;
+    int64_t nk = dev_count ? lcur : (int64_t)*nd->h_nkept;
     nd->n_scan[cur] = nk; nd->ld_scan[cur] = lcur;
     // ---- ICET it(prev, cur, runlen, X0, bins_phi, bins_theta, n, thresh, buff)  (odometry.cpp:76) ----
     // The down-sample indices of this frame (simpleMapMaker.cpp:147-158) depend only on the row count and on the node's RNG stream,
@@ -476,7 +481,7 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
     int m_map = 0;
     bool flip_owner = false;
     std::future<int> shuffle;
-    if (nd->p.map_capacity > 0) {
+    if (nd->p.map_capacity > 0 && !fused) {
         shuffle = std::async(std::launch::async, [nd, nk]() {
             nd->indices.resize((size_t)nk);
             std::iota(nd->indices.begin(), nd->indices.end(), (std::size_t)0);
@@ -502,9 +507,9 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         if (loop_on_filter_stream) {
             // (the build is done, as a rule, by the time the next frame arrives: asking costs the host a microsecond, a wait command in the stream five to ten)
             if (nd->kf_built[nd->owner] && hipEventQuery(nd->ev_kfdone[nd->owner]) != hipSuccess) { (void)hipGetLastError(); NCHK(nd, hipStreamWaitEvent(st, nd->ev_kfdone[nd->owner], 0)); }
-            if (fast && !fused) NCHK(nd, hipStreamWaitEvent(s_oth, nd->ev[1], 0));
+            if (dev_count && !fused) NCHK(nd, hipStreamWaitEvent(s_oth, nd->ev[1], 0));
             icet_ctx_set_stream(own, st);
-        } else if (fast) {                                        // nobody waited for the filter: both solve streams do
+        } else if (dev_count) {                                   // nobody waited for the filter: both solve streams do
             NCHK(nd, hipStreamWaitEvent(so, nd->ev[1], 0));
             NCHK(nd, hipStreamWaitEvent(s_oth, nd->ev[1], 0));
         }
@@ -528,7 +533,7 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         float* out_dev = sp.runlen > 0 ? nd->h_out : nd->d_out;
         ICET_TR(1);
         if (fused) icet_ctx_set_prologue(own, filter_prologue, &nd->fl[cur], filter_key(nd->fl[cur]));        // filter + loop: one graph, one launch
-        s = icet_register_device_n(own, &sp, 1, &b, fast ? d_cnt : nullptr, nd->h_x0, out_dev);
+        s = icet_register_device_n(own, &sp, 1, &b, dev_count ? d_cnt : nullptr, nd->h_x0, out_dev);
         if (fused) icet_ctx_set_prologue(own, nullptr, nullptr, 0);
         ICET_TR(2);
         icet_ctx_set_stream(own, s_own);
@@ -543,7 +548,7 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
                 icet_dev_scan bk{nd->d_scan_kf[cur], lkf, lkf};
                 s = icet_keyframe_device_n(oth, &sp, 1, &bk, nd->d_nkept_kf + cur);
             } else {
-                s = icet_keyframe_device_n(oth, &sp, 1, &b, fast ? d_cnt : nullptr);
+                s = icet_keyframe_device_n(oth, &sp, 1, &b, dev_count ? d_cnt : nullptr);
             }
             if (s != ICET_OK) { nd->err = icet_last_error(oth); return s; }
             NCHK(nd, hipEventRecord(nd->ev_kfdone[nd->owner ^ 1], s_oth)); nd->kf_built[nd->owner ^ 1] = true;
@@ -555,6 +560,22 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         if (s != ICET_OK) { nd->err = icet_last_error(nd->ctx); return s; }
         if (out_dev != nd->h_out) NCHK(nd, hipMemcpyAsync(nd->h_out, nd->d_out, sizeof(float) * 48, hipMemcpyDeviceToHost, st));
         NCHK(nd, hipEventRecord(nd->ev[2], st));
+    }
+    if (fused && nd->p.map_capacity > 0) {
+        // the frame is in flight; its filter's count lands in pinned memory ~25 us in (k_range_scan's own store), the loop runs for another ~230: the down-sample
+        // shuffle (simpleMapMaker.cpp:147-158: std::shuffle over exactly that many indices with the node's RNG stream) runs here, on this thread, beside it
+        volatile int32_t* hc = nd->h_nkept;
+        for (long spins = 1; *hc < 0; spins++)
+            if ((spins & 4095) == 0 && hipStreamQuery(st) != hipErrorNotReady) break;             // (finished or failed without a count: decided below)
+        (void)hipGetLastError();
+        if (*hc < 0) NCHK(nd, hipStreamSynchronize(st));
+        if (*hc < 0) { nd->err = "the range filter's row count did not arrive"; if (nd->kw) (void)kf_wait_idle(nd); return ICET_ERR_HIP; }
+        const int64_t nkh = *hc;
+        nd->indices.resize((size_t)nkh);
+        std::iota(nd->indices.begin(), nd->indices.end(), (std::size_t)0);
+        std::shuffle(nd->indices.begin(), nd->indices.end(), nd->gen);
+        m_map = (int)std::min<int64_t>(nd->p.map_downsample, nkh);
+        for (int i = 0; i < m_map; i++) nd->h_idx[i] = (int32_t)nd->indices[i];                  // pinned: the map kernel reads it in place (no copy command)
     }
     if (shuffle.valid()) {
         m_map = shuffle.get();
@@ -568,7 +589,7 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         const icet_status hs = kf_wait_idle(nd); if (hs != ICET_OK) return hs;      // (the helper has recorded the event)
         NCHK(nd, hipEventSynchronize(nd->ev_f2));
     }
-    if (fast) { nk = *nd->h_nkept; nd->n_scan[cur] = nk; }        // the filter's count has arrived with everything else
+    if (dev_count) { nk = *nd->h_nkept; nd->n_scan[cur] = nk; }   // the filter's count has arrived with everything else
     float X[6];
     std::memcpy(X, nd->h_out, sizeof(X)); std::memcpy(res->pred_stds, nd->h_out + 6, sizeof(float) * 6);
     // seed for the next frame (odometry.cpp:82 / simpleMapMaker.cpp:124), then the guard (simpleMapMaker.cpp:129-137)
@@ -592,14 +613,14 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         const int cap = nd->p.map_capacity;
         float* q = nd->d_map; const float* sc = nd->d_scan[cur];
         const int blocks = std::min((cap + 255) / 256, 256 * 8);
-        NCHK(nd, hipEventRecord(nd->ev[4], st));
-        k_map_add_scan<<<blocks, 256, 0, st>>>(q, q + cap, q + 2 * (size_t)cap, cap, (int)nd->map_pos, m, sc, sc + lcur, sc + 2 * lcur, nd->d_idx,
+        if (!fused) NCHK(nd, hipEventRecord(nd->ev[4], st));
+        k_map_add_scan<<<blocks, 256, 0, st>>>(q, q + cap, q + 2 * (size_t)cap, cap, (int)nd->map_pos, m, sc, sc + lcur, sc + 2 * lcur, fused ? nd->h_idx : nd->d_idx,
                                                X[0], X[1], X[2], Ri[0], Ri[1], Ri[2], Ri[3], Ri[4], Ri[5], Ri[6], Ri[7], Ri[8]);
         NCHK(nd, hipGetLastError());
-        NCHK(nd, hipEventRecord(nd->ev[3], st));                  // not waited for: the next push (or icet_node_map) synchronises the stream
+        if (!fused) NCHK(nd, hipEventRecord(nd->ev[3], st));      // not waited for: the next push (or icet_node_map) synchronises the stream
         if (nd->map_pos + m >= cap) nd->map_filled = true;
         nd->map_pos = (nd->map_pos + m) % cap;
-        nd->timed_map = true;
+        nd->timed_map = !fused;
     }
     if (nd->p.flags & (ICET_NODE_ALIGNED_CLOUD | ICET_NODE_SNAIL_TRAIL)) {
         float Ri[9]; inverse3_lu(R, Ri);
@@ -679,7 +700,7 @@ icet_status icet_node_create(icet_ctx* ctx, const icet_node_params* p, icet_node
     nd->ctx = ctx; nd->p = *p; nd->stream = reinterpret_cast<hipStream_t>(icet_stream(ctx)); nd->device = icet_device(ctx);
     auto fail = [&](icet_status s) { icet_node_destroy(nd); return s; };
     if (hipSetDevice(nd->device) != hipSuccess) return fail(ICET_ERR_NO_DEVICE);
-    if (hipMalloc(reinterpret_cast<void**>(&nd->d_nkept), 2 * sizeof(int32_t)) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_nkept), sizeof(int32_t)) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void**>(&nd->d_nkept), 2 * sizeof(int32_t)) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_nkept), sizeof(int32_t), hipHostMallocCoherent) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&nd->d_x0), sizeof(float) * 6) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&nd->d_out), sizeof(float) * 48) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&nd->h_out), sizeof(float) * 48) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_x0), sizeof(float) * 6) != hipSuccess)
         return fail(ICET_ERR_NOMEM);

@@ -218,6 +218,16 @@ def test_gpu_one_launch_frame_equals_phased_frame(gpu_ctx, seq64):
         with pytest.raises(Exception):                                                      # the one-launch frame records no timing events
             one.last_timing()
         one.close(); ph.close()
+    # the map maker's frame is one launch too (its host side watches the filter's row count arrive in pinned memory and shuffles beside the loop): results, ring
+    # contents and the stored scan, a ring that wraps
+    kw = dict(api.MAP_MAKER_NODE); kw.update(map_capacity=7000, runlen=5)
+    one, ph = api.Node(gpu_ctx, **kw), api.Node(gpu_ctx, **dict(kw, flags=api.NODE_TIME_PHASES))
+    for k, f in enumerate(fr[:8]):
+        ra, rb = one.push_device(*f), ph.push_device(*f)
+        assert same(ra, rb) and ra["map_rows"] == rb["map_rows"], k
+        assert np.array_equal(one.map(), ph.map()) and np.array_equal(one.prev_scan(), ph.prev_scan())
+    assert ph.last_timing()["map_ms"] > 0
+    one.close(); ph.close()
 
 
 @pytest.mark.gpu

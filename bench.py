@@ -581,13 +581,33 @@ def main(argv=None):
                 t = ctx.last_timing()
                 s_acc += t["accumulate_ms"]; s_kf += t["keyframe_ms"]; s_gn += t["gn_loop_ms"]; s_l += t["accumulate_launches"]
         pts_real = float(np.mean(m1) + np.mean(m2)) / 2; pts_syn = float(np.mean(n1) + np.mean(n2)) / 2
+        # The real batch alternates 65 536-row and 131 072-row scans (mean 98 k rows against the synthetic batch's 116 k), and a sixth of a step is spent in kernels that run
+        # one block per PAIR whatever its size: part of "slower per point" is the size mix, not the data.  The synthetic points cut to the same mix (every even pair's scans
+        # truncated to the real even pairs' share of the odd pairs' rows) separate the two.
+        cut = [min(n, int(round(n * (m1[0] / m1[1])))) if k % 2 == 0 and len(m1) > 1 else n for k, n in enumerate(n1)]
+        cut2 = [min(n, int(round(n * (m2[0] / m2[1])))) if k % 2 == 0 and len(m2) > 1 else n for k, n in enumerate(n2)]
+        g1 = [(b.data_ptr(), n, b.shape[1]) for b, n in zip(bufs1, cut)]; g2 = [(b.data_ptr(), n, b.shape[1]) for b, n in zip(bufs2, cut2)]
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                ctx.solve_batch_device(g1, g2, p_plain, out_r.data_ptr())
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(nrep_r):
+                ctx.solve_batch_device(g1, g2, p_plain, out_r.data_ptr())
+            ctx.sync()
+            mix_ms = (time.perf_counter() - t0) / nrep_r * 1e3
+            ctx.solve_batch_device(f1, f2, p_plain, out_r.data_ptr()); ctx.sync()      # (out_r holds the real batch's results again)
+        pts_mix = float(np.mean(cut) + np.mean(cut2)) / 2
         real_res = out_r.cpu().numpy()
         sample_batch = {"workload": "%d pairs from the reference's REAL sample scans (even k: frame_804/805, 65 536 rows of which ~5 k exact zeros; odd k: sample_pc_1/2, 131 072 rows), "
                                     "pair k turned by its own small rotation, zero rows kept; one icet_solve_batch_device call per step" % len(ids), "data": "real",
                         "pairs_per_s": round(len(ids) / (r_ms * 1e-3), 1), "ms_per_step": round(r_ms, 4), "points_per_scan_mean": int(pts_real),
                         "keyframe_ms_per_step": round(s_kf / 3, 4), "gn_loop_ms_per_step": round(s_gn / 3, 4), "accumulate_avg_launch_ms": round(s_acc / max(s_l, 1), 5),
                         "ns_per_point": round(r_ms * 1e6 / (len(ids) * pts_real), 3), "synthetic_ns_per_point": round(ms_per_step * 1e6 / (len(ids) * pts_syn), 3),
-                        "slowdown_vs_synthetic_at_equal_point_count": round((r_ms / pts_real) / (ms_per_step / pts_syn), 3), "all_finite": bool(np.isfinite(real_res).all())}
+                        "slowdown_vs_synthetic_at_equal_point_count": round((r_ms / pts_real) / (ms_per_step / pts_syn), 3),
+                        "synthetic_same_size_mix": {"points_per_scan_mean": int(pts_mix), "ms_per_step": round(mix_ms, 4), "ns_per_point": round(mix_ms * 1e6 / (len(ids) * pts_mix), 3),
+                                                    "note": "the synthetic pairs with every even pair's scans cut to the real batch's small-to-large row ratio: what the size mix alone costs per point"},
+                        "slowdown_vs_synthetic_of_the_same_size_mix": round((r_ms / pts_real) / (mix_ms / pts_mix), 3), "all_finite": bool(np.isfinite(real_res).all())}
         real_host = [(rp[k][0].T.cpu().numpy(), rp[k][1].T.cpu().numpy()) for k in (0, 1, 2, 3)]      # for the oracle cross-check in the cpu_baseline leg
         real_X = real_res[:4, :6].copy()
         del r1, r2, rp

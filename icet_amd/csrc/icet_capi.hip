@@ -77,6 +77,8 @@ struct icet_ctx {
     // sequence -- enqueued on the context's stream right before the loop's first kernel, captured into the same graph: the range filter and the loop of a frame
     // are then ONE hipGraphLaunch (round 6: the loop's graph used to start 30-40 us after the filter's last kernel).  `prologue_key` names what the hook's
     // launches depend on (buffers, grid): it is part of the graph key.  Cleared by the caller after the call (icet_ctx_set_prologue).
+    // A ragged throughput batch is laid out XCD-balanced (solve_device_part): slot s of the internal tables holds the caller's pair h_seg[n_pairs + 1 + s]
+    bool perm_active = false; int32_t perm_pairs = 0;
     hipError_t (*prologue)(void*, hipStream_t) = nullptr; void* prologue_user = nullptr; int64_t prologue_key = 0;
 };
 
@@ -113,7 +115,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         const size_t pv = (size_t)np * VV;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, dev_realloc(w.desc, np));
-        HIPCHK(c, dev_realloc(w.seg_off, (size_t)np + 1));
+        HIPCHK(c, dev_realloc(w.seg_off, 2 * (size_t)np + 1));              // segment offsets, then (ragged throughput batches) the caller's pair of every slot
         HIPCHK(c, dev_realloc(w.bin_count, pv));
         HIPCHK(c, dev_realloc(w.bin_start, (size_t)np * (VV + 1)));
         HIPCHK(c, dev_realloc(w.live_bins, pv * 4)); HIPCHK(c, dev_realloc(w.n_live, np));
@@ -134,7 +136,7 @@ icet_status ensure_workspace(icet_ctx* c, const icet_params* p, int32_t n_pairs,
         if (c->h_seg) { HIPCHK(c, hipHostFree(c->h_seg)); c->h_seg = nullptr; }
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_desc), sizeof(PairDesc) * np));
         std::memset(c->h_desc, 0, sizeof(PairDesc) * np); c->desc_kf_valid = c->desc_reg_valid = false;
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_seg), sizeof(int32_t) * ((size_t)np + 1)));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_seg), sizeof(int32_t) * (2 * (size_t)np + 1)));
         c->h_cap_pairs = np;
         w.cap_pairs = np; w.cap_V = VV;
     }
@@ -398,6 +400,7 @@ LaunchCfg make_cfg(icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     cfg.lds_slots = c->tune.lds_slots; cfg.acc_min_pts_per_thread = c->tune.acc_pts; cfg.acc_target_blocks = c->tune.acc_blocks;
     cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds; cfg.exec_pairwise = c->tune.exec_pairwise; cfg.fuse_solve = c->tune.fuse_solve != 0 ? 1 : 0; cfg.lds_rank = (c->tune.lds_rank != 0 && c->lds_rank_ok) ? 1 : 0;
     cfg.gn_cond_bound2 = (float)(c->tune.gn_cond_bound * c->tune.gn_cond_bound);
+    cfg.pair_user = (c->perm_active && c->perm_pairs == n_pairs) ? c->w.seg_off + n_pairs + 1 : nullptr;
     // the keep list of the point pass (KeepState, icet_internal.h): throughput batches only -- a small batch's point pass is a few microseconds of launch floor --,
     // never with the scan-2 round trip (a kernel of its own) nor when fewer than two passes could walk a list; same bits either way
     cfg.keep_from = c->tune.keep_from < 0 ? 0 : c->tune.keep_from; cfg.keep_bt = (float)c->tune.keep_budget_t; cfg.keep_br = (float)c->tune.keep_budget_r; cfg.keep_check_scale = (float)c->tune.keep_check_scale;
@@ -434,7 +437,7 @@ icet_status upload_desc(icet_ctx* c, int32_t n_pairs, bool by_next_kernel = fals
         HIPCHK(c, launch_upload_desc(w, c->h_desc, c->h_seg, n_pairs, c->stream));       // small batch: a kernel reads the pinned words (no copy command, no memcpy node)
     } else {
         HIPCHK(c, hipMemcpyAsync(w.desc, c->h_desc, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(w.seg_off, c->h_seg, sizeof(int32_t) * (n_pairs + 1), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(w.seg_off, c->h_seg, sizeof(int32_t) * (n_pairs + 1 + (c->perm_active ? n_pairs : 0)), hipMemcpyHostToDevice, c->stream));
     }
     if (!c->ev_desc) HIPCHK(c, hipEventCreateWithFlags(&c->ev_desc, hipEventDisableTiming));
     if (!c->capturing) { HIPCHK(c, hipEventRecord(c->ev_desc, c->stream)); c->desc_in_flight = true; }     // (a captured event cannot be waited for on the host: the replay path orders the staging itself)
@@ -847,8 +850,32 @@ static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t 
     if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
     if (c->graph_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_graph)); c->graph_in_flight = false; }     // a replay re-reads the pinned descriptor staging when it RUNS
     c->desc_kf_valid = c->desc_reg_valid = false;
-    for (int k = 0; k < n_pairs; k++) {
-        PairDesc& d = c->h_desc[k];
+    // A RAGGED throughput batch is laid out XCD-balanced (round 6).  decode_block gives every block of a pair the XCD `slot % 8`, so that a pair's tables stay in one L2;
+    // with pairs of very different sizes in caller order the XCDs' shares differ -- the reference's sample scans alternate 65 536 and 131 072 rows, all small pairs on the
+    // even XCDs, all large ones on the odd ones: a step took what the odd XCDs took.  Pairs sorted by size and dealt to the slots of each group of eight in snake order
+    // give every XCD the same share to a few per cent.  The caller's order comes back in k_init_state (X0) and k_gn_solve (results): LaunchCfg::pair_user.  Same bits: a
+    // pair's result does not depend on its slot (section 6 of DESIGN.md).
+    c->perm_active = false; c->perm_pairs = n_pairs;
+    if (n_pairs > kUploadDescMaxPairs && p->runlen > 0) {
+        int64_t mn = INT64_MAX, mx = 0;
+        for (int k = 0; k < n_pairs; k++) { const int64_t z = scan1[k].n + scan2[k].n; mn = std::min(mn, z); mx = std::max(mx, z); }
+        c->perm_active = mx > mn + mn / 4;
+    }
+    std::vector<int32_t> order((size_t)n_pairs);
+    for (int k = 0; k < n_pairs; k++) order[(size_t)k] = k;
+    if (c->perm_active) {
+        std::vector<int32_t> by_size(order);
+        std::stable_sort(by_size.begin(), by_size.end(), [&](int32_t a, int32_t b) { return scan1[a].n + scan2[a].n > scan1[b].n + scan2[b].n; });
+        for (int i = 0; i < n_pairs; i++) {
+            const int g = i / 8, r = i % 8, in_group = std::min(8, n_pairs - 8 * g);
+            const int pos = (g & 1) ? in_group - 1 - r : r;                      // snake: the group's largest goes where the previous group put its smallest
+            order[(size_t)(8 * g + pos)] = by_size[(size_t)i];
+        }
+        for (int s = 0; s < n_pairs; s++) c->h_seg[n_pairs + 1 + s] = order[(size_t)s];
+    }
+    for (int s = 0; s < n_pairs; s++) {
+        const int k = order[(size_t)s];
+        PairDesc& d = c->h_desc[s];
         d.s1 = scan1[k].ptr; d.s2 = scan2[k].ptr;
         d.n1 = (int32_t)scan1[k].n; d.ld1 = (int32_t)scan1[k].ld; d.n2 = (int32_t)scan2[k].n; d.ld2 = (int32_t)scan2[k].ld;
         d.off1 = 0; d.off2 = 0;
@@ -876,7 +903,7 @@ icet_status icet_keyframe_device_n(icet_ctx* c, const icet_params* p, int32_t n_
         tot1 += a.n;
     }
     HIPCHK(c, hipSetDevice(c->device));
-    c->kf_pairs = 0;
+    c->kf_pairs = 0; c->perm_active = false;
     icet_status s = ensure_workspace(c, p, n_pairs, tot1, 0);
     if (s != ICET_OK) return s;
     // A sequential caller hands the SAME buffers to this half frame after frame (include/icet_nodes.h): the pinned descriptor staging then already holds
@@ -989,7 +1016,7 @@ icet_status icet_solve_batch(icet_ctx* c, const icet_params* p, int32_t n_pairs,
     };
     if (p->runlen == 0) s = write_runlen0(c, n_pairs, dx0, c->d_out);
     else {
-        c->kf_pairs = 0;
+        c->kf_pairs = 0; c->perm_active = false;
         s = enqueue_keyframe(c, p, n_pairs, nullptr);
         if (s == ICET_OK) {
             const hipError_t e = upload_scan2s();
@@ -1090,7 +1117,7 @@ icet_status icet_solve_begin(icet_ctx* c, const icet_params* p, const float* sca
             q.scan2 = scan2; q.ld2 = ld2;
             if (!want_pts2 && !want_side2) ad.xf_last = nullptr;
         }
-        c->kf_pairs = 0;
+        c->kf_pairs = 0; c->perm_active = false;
         st = enqueue_keyframe(c, p, 1, aux ? &ad : nullptr);
         if (st == ICET_OK && want_side1) {                                     // points1Spherical / pointIndices1 from the tables the keyframe build has just left
             const LaunchCfg scfg = make_cfg(c, p, 1);
@@ -1327,7 +1354,10 @@ icet_status icet_keep_stats(icet_ctx* c, int32_t n_pairs, int32_t* out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<KeepState> h((size_t)n_pairs);
     HIPCHK(c, hipMemcpy(h.data(), c->w.keep_state, sizeof(KeepState) * (size_t)n_pairs, hipMemcpyDeviceToHost));
-    for (int k = 0; k < n_pairs; k++) { out[4 * k] = h[k].mode; out[4 * k + 1] = h[k].n_keep; out[4 * k + 2] = h[k].list_passes; out[4 * k + 3] = h[k].builds; }
+    for (int s = 0; s < n_pairs; s++) {
+        const int k = (c->perm_active && c->perm_pairs == n_pairs) ? c->h_seg[n_pairs + 1 + s] : s;      // (a ragged batch sits XCD-balanced in the tables: back to the caller's order)
+        out[4 * k] = h[s].mode; out[4 * k + 1] = h[s].n_keep; out[4 * k + 2] = h[s].list_passes; out[4 * k + 3] = h[s].builds;
+    }
     return ICET_OK;
 }
 

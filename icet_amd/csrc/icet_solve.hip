@@ -18,7 +18,7 @@ namespace {
 // less in front of a sequential caller's first iteration)
 __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X, float* __restrict__ xf, int n_pairs, float* __restrict__ xf_last,
                              PairDesc* __restrict__ desc, const int32_t* __restrict__ n2, uint32_t* __restrict__ done, KeepState* __restrict__ keep, int32_t* __restrict__ keep_modes,
-                             const PairDesc* __restrict__ h_desc, const int32_t* __restrict__ h_seg, int32_t* __restrict__ seg) {
+                             const PairDesc* __restrict__ h_desc, const int32_t* __restrict__ h_seg, int32_t* __restrict__ seg, const int32_t* __restrict__ pair_user) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     // (h_desc: k_upload_desc's job as well, when this is the first kernel that reads the descriptors -- the register half of a sequential caller: one launch less)
@@ -30,7 +30,8 @@ __global__ void k_init_state(const float* __restrict__ x0, float* __restrict__ X
     }
     if (n2) desc[p].n2 = max(0, min(n2[p], desc[p].n2));
     float x[6];
-    for (int k = 0; k < 6; k++) { x[k] = x0 ? x0[p * 6 + k] : 0.f; X[p * 6 + k] = x[k]; }
+    const int pu = pair_user ? pair_user[p] : p;                 // (a ragged throughput batch sits XCD-balanced in the tables: the caller's X0 of this slot's pair)
+    for (int k = 0; k < 6; k++) { x[k] = x0 ? x0[pu * 6 + k] : 0.f; X[p * 6 + k] = x[k]; }
     write_xf(xf + p * kXf, x);
     if (xf_last) for (int k = 0; k < kXf; k++) xf_last[p * kXf + k] = xf[p * kXf + k];      // a one-iteration solve transforms scan 2 by X0 (`points2`)
 }
@@ -119,7 +120,7 @@ hipError_t launch_upload_desc(const Workspace& w, const PairDesc* h_desc, const 
 }
 
 hipError_t launch_init_state(const Workspace& w, const LaunchCfg& c, const float* d_x0, hipStream_t st, float* xf_last, const int32_t* d_n2, const PairDesc* h_desc, const int32_t* h_seg) {
-    k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs, xf_last, w.desc, d_n2, w.gn_done(), c.keep ? w.keep_state : nullptr, w.keep_modes, h_desc, h_seg, w.seg_off);
+    k_init_state<<<(c.n_pairs + 63) / 64, 64, 0, st>>>(d_x0, w.X, w.xf, c.n_pairs, xf_last, w.desc, d_n2, w.gn_done(), c.keep ? w.keep_state : nullptr, w.keep_modes, h_desc, h_seg, w.seg_off, c.pair_user);
     ICET_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -150,6 +151,7 @@ hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* x
 
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* auxp, hipStream_t st, int keep_pass) {
     AuxDev aux{}; if (auxp) aux = *auxp;
+    aux.pair_user = c.pair_user;
     const KeepArgs keep{w.desc, w.keep_mask, w.keep_list, w.keep_state, c.keep_bt * c.keep_bt * c.keep_check_scale * c.keep_check_scale, c.keep_br * c.keep_br * c.keep_check_scale * c.keep_check_scale, w.keep_state ? keep_pass : 0,      // 1: build / check; 2: behind the last pass (statistics only)
                         w.keep_modes ? w.keep_modes + (size_t)((iter + 1) & 1) * c.n_pairs : nullptr, c.n_pairs};
     NearOverflow over{w.desc, w.slot_of_voxel, w.hotS, w.thr, w.near_over, w.near_over_count, c.T, c.P, c.rt2};

@@ -456,7 +456,7 @@ __device__ __forceinline__ void gn_solve_body(const int32_t* n_slots, const Slot
     if constexpr (kStage != 1 && kBlockT == kT) { if (keep.on == 1) keep_budget_check(keep, pair, stage, s_keep_ref, lane, keep_n); }
     if (lane < kXf) xf_all[pair * kXf + lane] = stage[lane];
     if (aux.xf_last && iter == runlen - 2 && lane < kXf) aux.xf_last[pair * kXf + lane] = stage[lane];      // what the last point pass will use (`points2`)
-    if (lane < 48) out[(size_t)pair * 48 + lane] = stage[kXf + lane];
+    if (lane < 48) out[(size_t)(aux.pair_user ? aux.pair_user[pair] : pair) * 48 + lane] = stage[kXf + lane];      // (the caller's pair of this slot: ragged throughput batches)
     if (lane < 6) X[lane] = stage[kXf + lane];
     if (lane == 0) {
         if (aux.x_hist) for (int k = 0; k < 6; k++) aux.x_hist[((size_t)pair * runlen + iter) * 6 + k] = Xn[k];

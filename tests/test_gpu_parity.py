@@ -436,6 +436,49 @@ def test_fast_classification_equals_literal_evaluation(gpu_ctx, frames, sample_p
             gpu_ctx.set_option("force_exact", 0)
 
 
+def test_ragged_batch_is_laid_out_xcd_balanced_with_the_callers_order_kept(gpu_ctx):
+    """Round 6: a throughput batch (> 64 pairs) whose pairs differ in size by more than a quarter is sorted by size and dealt to the slots of every group of eight
+    in snake order (every XCD the same share; icet_capi.hip solve_device_part) -- the caller's order comes back in k_init_state (X0) and k_gn_solve (results).  A pair's
+    bits do not depend on its slot: every pair of a 100-pair batch of four sizes (alternating halves and fulls, as the reference's sample scans do, a few quarter-size
+    and tiny ones), each with an X0 of its own, must give the bits of that pair solved alone; with batch parts (each part laid out by itself) as well."""
+    from icet_amd import lidar_sim as ls, api
+    import icet_amd
+    dev = torch.device("cuda", 0)
+    base = [ls.make_batch_pair(k, device=dev) for k in range(3)]
+    n_pairs = 100
+    def rows(j, full):
+        return full if j % 2 else (full // 2 if j % 10 else (full // 4 if j % 20 else 5000))
+    sel = [base[j % 3][:2] for j in range(n_pairs)]
+    d1 = [(a.data_ptr(), rows(j, a.shape[1]), a.shape[1]) for j, (a, b) in enumerate(sel)]
+    d2 = [(b.data_ptr(), rows(j, b.shape[1]), b.shape[1]) for j, (a, b) in enumerate(sel)]
+    x0 = torch.zeros((n_pairs, 6), dtype=torch.float32, device=dev)
+    x0[:, 0] = 0.004 * (torch.arange(n_pairs, device=dev) % 11).float(); x0[:, 5] = 0.0007 * (torch.arange(n_pairs, device=dev) % 5).float()
+    ctx = icet_amd.Context(0)
+    p = api.Params(5, 24, 75, 25, 0.1, 0.1, 0)
+    outs = {}
+    for parts in (0, 2):
+        ctx.set_option("batch_parts", parts)
+        o = torch.full((n_pairs, 48), float("nan"), dtype=torch.float32, device=dev)
+        ctx.solve_batch_device(d1, d2, p, o.data_ptr(), x0.data_ptr()); ctx.sync()
+        outs[parts] = o.cpu().numpy()
+    ctx.set_option("batch_parts", 0)
+    assert np.array_equal(outs[0], outs[2], equal_nan=True) and np.isfinite(outs[0]).all()
+    for j in list(range(0, 24)) + [n_pairs - 1, n_pairs - 2, 40, 60, 61]:
+        a, b = sel[j]
+        single = gpu_ctx.solve(a[:, :d1[j][1]].T.cpu().numpy(), b[:, :d2[j][1]].T.cpu().numpy(), 5, x0[j].cpu().numpy(), 24, 75)
+        assert np.array_equal(outs[0][j, :6], single["X"]) and np.array_equal(outs[0][j, 6:12], single["pred_stds"]), j
+    # a uniform batch behind a ragged one on the same context (the layout is decided per call), and a ragged one again
+    du1 = [(a.data_ptr(), a.shape[1], a.shape[1]) for a, b in sel]; du2 = [(b.data_ptr(), b.shape[1], b.shape[1]) for a, b in sel]
+    o = torch.zeros((n_pairs, 48), dtype=torch.float32, device=dev)
+    ctx.solve_batch_device(du1, du2, p, o.data_ptr(), x0.data_ptr()); ctx.sync()
+    single = gpu_ctx.solve(sel[7][0].T.cpu().numpy(), sel[7][1].T.cpu().numpy(), 5, x0[7].cpu().numpy(), 24, 75)
+    assert np.array_equal(o.cpu().numpy()[7, :6], single["X"])
+    o2 = torch.zeros_like(o)
+    ctx.solve_batch_device(d1, d2, p, o2.data_ptr(), x0.data_ptr()); ctx.sync()
+    assert np.array_equal(o2.cpu().numpy(), outs[0])
+    ctx.close()
+
+
 def test_device_resident_batch_full_size(gpu_ctx):
     """icet_solve_batch_device with inputs resident in HBM (the bench path) at config-3 size with 4 distinct
     pairs cycled 64 x: every replica of a pair must give that pair's single-solve answer."""

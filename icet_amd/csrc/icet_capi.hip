@@ -68,7 +68,7 @@ struct icet_ctx {
     hipEvent_t ev_desc = nullptr; bool desc_in_flight = false;   // completion of the last copy out of the pinned descriptor staging
     // Small device batches whose launch geometry repeats call after call are replayed from a captured hipGraph (option "graph"): the ~33
     // launches of a single-pair solve then cost one hipGraphLaunch on the host, and the command processor runs them back to back.
-    struct GraphKey { int64_t v[44]; };                        // every LaunchCfg field + the pointers the launches take + the prologue's key (graph_key_of)
+    struct GraphKey { int64_t v[45]; };                        // every LaunchCfg field + the pointers the launches take + the prologue's key (graph_key_of)
     struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; GraphKey key{}, seen{}; bool have_seen = false, have_graph = false; };
     bool capturing = false; int graph_mode = -1;               // -1: replay batches of <= 8 pairs whose launch key repeats; 0 never; 1 same as -1
     GraphSlot g_solve, g_keyframe, g_loop;                     // the whole solve (icet_solve_batch_device) and its two halves (icet_keyframe_device_n / icet_register_device_n)
@@ -80,6 +80,9 @@ struct icet_ctx {
     // A ragged throughput batch is laid out XCD-balanced (solve_device_part): slot s of the internal tables holds the caller's pair h_seg[n_pairs + 1 + s]
     bool perm_active = false; int32_t perm_pairs = 0;
     hipError_t (*prologue)(void*, hipStream_t) = nullptr; void* prologue_user = nullptr; int64_t prologue_key = 0;
+    // ... and have the LAST solve of the next icet_register_device_n call store 1 into a word of (coherent) pinned host memory once the results are written: the caller
+    // watches that word instead of synchronising the stream (icet_ctx_set_done_flag; part of the graph key)
+    int32_t* done_flag = nullptr;
 };
 
 namespace {
@@ -401,6 +404,7 @@ LaunchCfg make_cfg(icet_ctx* c, const icet_params* p, int32_t n_pairs) {
     cfg.force_exact = c->tune.force_exact; cfg.use_library_sort = c->tune.library_sort; cfg.kf_pts_per_thread = c->tune.kf_pts; cfg.rs_cap = c->tune.rs_cap; cfg.rs_max_cell = c->tune.rs_max_cell; cfg.exec_bits_lds = c->tune.exec_bits_lds; cfg.exec_pairwise = c->tune.exec_pairwise; cfg.fuse_solve = c->tune.fuse_solve != 0 ? 1 : 0; cfg.lds_rank = (c->tune.lds_rank != 0 && c->lds_rank_ok) ? 1 : 0;
     cfg.gn_cond_bound2 = (float)(c->tune.gn_cond_bound * c->tune.gn_cond_bound);
     cfg.pair_user = (c->perm_active && c->perm_pairs == n_pairs) ? c->w.seg_off + n_pairs + 1 : nullptr;
+    cfg.done_flag = c->done_flag;
     // the keep list of the point pass (KeepState, icet_internal.h): throughput batches only -- a small batch's point pass is a few microseconds of launch floor --,
     // never with the scan-2 round trip (a kernel of its own) nor when fewer than two passes could walk a list; same bits either way
     cfg.keep_from = c->tune.keep_from < 0 ? 0 : c->tune.keep_from; cfg.keep_bt = (float)c->tune.keep_budget_t; cfg.keep_br = (float)c->tune.keep_budget_r; cfg.keep_check_scale = (float)c->tune.keep_check_scale;
@@ -788,7 +792,7 @@ static icet_ctx::GraphKey graph_key_of(icet_ctx* c, const icet_params* p, int32_
                             k.exec_bits_lds, k.exec_pairwise, k.lds_rank, k.reject_moving, k.half_gap, k.rt2 + 2 * k.ref_w, p->flags, (int64_t)(intptr_t)a0, (int64_t)(intptr_t)a1, (int64_t)(intptr_t)a2, (int64_t)(intptr_t)a3,
                             (int64_t)(intptr_t)c->w.desc, (int64_t)(intptr_t)c->w.thr, (int64_t)(intptr_t)c->w.lut, (int64_t)(intptr_t)c->w.r1, (int64_t)(intptr_t)c->w.counts,
                             (int64_t)(intptr_t)c->w.near_over, (int64_t)(intptr_t)c->w.acc, (int64_t)(intptr_t)c->w.fit_items, (int64_t)(intptr_t)c->w.sort_tmp, (int64_t)(intptr_t)c->w.tile_vr,
-                            c->prologue ? c->prologue_key : 0};
+                            c->prologue ? c->prologue_key : 0, (int64_t)(intptr_t)c->done_flag};
     static_assert(sizeof(vals) == sizeof(key.v), "GraphKey size");
     std::memcpy(key.v, vals, sizeof(vals));
     return key;
@@ -1329,6 +1333,7 @@ icet_status icet_set_option(icet_ctx* c, const char* name, double value) {
 
 } // extern "C" (reopened below)
 void icet_ctx_set_stream(icet_ctx* c, hipStream_t s) { if (c) c->stream = s; }
+void icet_ctx_set_done_flag(icet_ctx* c, int32_t* pinned_word) { if (c) c->done_flag = pinned_word; }
 void icet_ctx_set_prologue(icet_ctx* c, hipError_t (*fn)(void*, hipStream_t), void* user, int64_t key) { if (c) { c->prologue = fn; c->prologue_user = user; c->prologue_key = key; } }
 extern "C" {
 void* icet_stream(icet_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }

@@ -106,6 +106,7 @@ struct AuxDev {
     float* bounds; int32_t* n1_raw; int32_t* has_fit; float* mu1; float* sigma1; float* evecs1; float* l_diag;
     float* x_hist; float* htwh; float* htwdz; float* cond; int32_t* n2_raw; int32_t* n2_in; float* test_points;
     const int32_t* pair_user;   // LaunchCfg::pair_user (set by launch_gn_solve, not by callers)
+    int32_t* done_flag;         // LaunchCfg::done_flag, in the last iteration's launch only (set by launch_gn_solve)
     float* xf_last;      // 48 floats: the transform record the LAST iteration's point pass uses (written by k_init_state / the solve of iteration runlen - 2), for `points2`
 };
 
@@ -217,6 +218,7 @@ struct LaunchCfg {
     int keep = 0, keep_from = 1;      // Tuning::keep resolved for this launch (batch size, flags), Tuning::keep_from
     float keep_bt = 0.f, keep_br = 0.f, keep_check_scale = 1.f;   // Tuning::keep_budget_t / _r / keep_check_scale
     float gn_cond_bound2 = 6.25e10f;     // Tuning::gn_cond_bound squared: k_gn_solve's Cholesky route needs |A|_F |A^-1|_F <= the bound (icet_solve.hip gn_tail)
+    int32_t* done_flag = nullptr;          // set: the solve of the last iteration stores 1 there (pinned host memory) behind its results (icet_ctx_set_done_flag)
     const int32_t* pair_user = nullptr;    // set (ragged throughput batches, icet_capi.hip solve_device_part): slot s of the tables holds the caller's pair pair_user[s] -- X0 is read and the results are written there
     const PairDesc* h_desc_up = nullptr; const int32_t* h_seg_up = nullptr;      // set: the keyframe's first kernel (k_rs_splitters) copies the descriptors / segment offsets from this pinned staging itself (small batches: launch_upload_desc's job)
 };

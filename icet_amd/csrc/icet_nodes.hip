@@ -219,6 +219,7 @@ void quat_of(const float* P /* 4x4 row-major */, float q[4]) {
 
 void icet_ctx_set_stream(icet_ctx* c, hipStream_t s);      // icet_capi.hip (internal)
 void icet_ctx_set_prologue(icet_ctx* c, hipError_t (*fn)(void*, hipStream_t), void* user, int64_t key);      // icet_capi.hip (internal)
+void icet_ctx_set_done_flag(icet_ctx* c, int32_t* pinned_word);      // icet_capi.hip (internal)
 
 // The helper thread of a pipelined node: it ENQUEUES the keyframe builds (icet_keyframe_device_n on the context the build goes into, then the event that says it is
 // done) while the calling thread enqueues the frame's loop.  A build is ~20 launches or one graph launch of 20 nodes -- 35 to 140 us of host time that used to sit between
@@ -271,6 +272,7 @@ struct icet_node {
     float* d_scan_kf[2] = {nullptr, nullptr}; int64_t cap_scan_kf[2] = {0, 0};
     int32_t* d_counts_kf = nullptr; int32_t* d_bases_kf = nullptr; int cap_blocks_kf = 0; int32_t* d_nkept_kf = nullptr;
     hipEvent_t ev_f2 = nullptr;                                   // the keyframe side's filter has read the caller's frame
+    int32_t* h_done = nullptr;                                    // pinned, coherent: the frame's last solve stores 1 here behind its results (the host watches it instead of synchronising the stream)
 #ifdef ICET_DIAG_ENV
     double tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long tr_n = 0, tr_seen = 0;       // ICET_NODE_TRACE: host microseconds of push_frame by section, summed (printed by icet_node_destroy)
 #endif
@@ -357,6 +359,7 @@ icet_status ensure_kf_side(icet_node* nd, int which, int64_t n) {
     if (!nd->h_frame) { NCHK(nd, hipHostMalloc(reinterpret_cast<void**>(&nd->h_frame), 2 * sizeof(FrameDesc))); std::memset(nd->h_frame, 0, 2 * sizeof(FrameDesc)); }
     if (!nd->d_nkept_kf) NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_nkept_kf), 2 * sizeof(int32_t)));
     if (!nd->ev_f2) NCHK(nd, hipEventCreateWithFlags(&nd->ev_f2, hipEventDisableTiming));
+    if (!nd->h_done) { NCHK(nd, hipHostMalloc(reinterpret_cast<void**>(&nd->h_done), sizeof(int32_t), hipHostMallocCoherent)); *nd->h_done = 0; }
     if (n > nd->cap_scan_kf[which]) {
         NCHK(nd, hipDeviceSynchronize());
         if (nd->d_scan_kf[which]) { NCHK(nd, hipFree(nd->d_scan_kf[which])); nd->d_scan_kf[which] = nullptr; }
@@ -532,9 +535,10 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         // device buffer and its copy.)
         float* out_dev = sp.runlen > 0 ? nd->h_out : nd->d_out;
         ICET_TR(1);
+        if (fused) { *static_cast<volatile int32_t*>(nd->h_done) = 0; icet_ctx_set_done_flag(own, nd->h_done); }
         if (fused) icet_ctx_set_prologue(own, filter_prologue, &nd->fl[cur], filter_key(nd->fl[cur]));        // filter + loop: one graph, one launch
         s = icet_register_device_n(own, &sp, 1, &b, dev_count ? d_cnt : nullptr, nd->h_x0, out_dev);
-        if (fused) icet_ctx_set_prologue(own, nullptr, nullptr, 0);
+        if (fused) { icet_ctx_set_prologue(own, nullptr, nullptr, 0); icet_ctx_set_done_flag(own, nullptr); }
         ICET_TR(2);
         icet_ctx_set_stream(own, s_own);
         if (s != ICET_OK) { nd->err = icet_last_error(own); if (via_helper) (void)kf_wait_idle(nd); return s; }
@@ -583,7 +587,17 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
     }
     ICET_TR(3);
     if (so != st) NCHK(nd, hipStreamSynchronize(so));
-    NCHK(nd, hipStreamSynchronize(st));
+    if (fused) {
+        // the frame's last kernel stores its 48 result floats and then a 1 into pinned host memory: this thread watches that word -- hipStreamSynchronize answers
+        // several microseconds after the queue has drained -- and asks the stream only now and then (a frame that failed never writes the word)
+        volatile int32_t* hd = nd->h_done;
+        for (long spins = 1; *hd == 0; spins++)
+            if ((spins & 8191) == 0 && hipStreamQuery(st) != hipErrorNotReady) break;
+        (void)hipGetLastError();
+        if (*hd == 0) NCHK(nd, hipStreamSynchronize(st));
+        if (*hd == 0) { nd->err = "the frame's result did not arrive"; if (nd->kw) (void)kf_wait_idle(nd); return ICET_ERR_HIP; }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else NCHK(nd, hipStreamSynchronize(st));
     ICET_TR(4);
     if (fused) {                                                  // the caller's frame may be released when this returns: the other stream's filter has read it (long done: it started beside this stream's)
         const icet_status hs = kf_wait_idle(nd); if (hs != ICET_OK) return hs;      // (the helper has recorded the event)
@@ -702,7 +716,7 @@ icet_status icet_node_create(icet_ctx* ctx, const icet_node_params* p, icet_node
     if (hipSetDevice(nd->device) != hipSuccess) return fail(ICET_ERR_NO_DEVICE);
     if (hipMalloc(reinterpret_cast<void**>(&nd->d_nkept), 2 * sizeof(int32_t)) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_nkept), sizeof(int32_t), hipHostMallocCoherent) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&nd->d_x0), sizeof(float) * 6) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&nd->d_out), sizeof(float) * 48) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&nd->h_out), sizeof(float) * 48) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_x0), sizeof(float) * 6) != hipSuccess)
+        hipHostMalloc(reinterpret_cast<void**>(&nd->h_out), sizeof(float) * 48, hipHostMallocCoherent) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_x0), sizeof(float) * 6) != hipSuccess)
         return fail(ICET_ERR_NOMEM);
     for (hipEvent_t& e : nd->ev) if (hipEventCreate(&e) != hipSuccess) return fail(ICET_ERR_HIP);
     for (hipEvent_t& e : nd->ev_kfdone) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(ICET_ERR_HIP);
@@ -734,7 +748,7 @@ icet_status icet_node_destroy(icet_node* nd) {
     void* dp[] = {nd->d_scan[0], nd->d_scan[1], nd->d_stage, nd->d_counts, nd->d_bases, nd->d_nkept, nd->d_x0, nd->d_out, nd->d_map, nd->d_idx, nd->d_aligned,
                   nd->d_scan_kf[0], nd->d_scan_kf[1], nd->d_counts_kf, nd->d_bases_kf, nd->d_nkept_kf};
     for (void* q : dp) if (q) (void)hipFree(q);
-    void* hp[] = {nd->h_nkept, nd->h_out, nd->h_x0, nd->h_idx, nd->h_frame};
+    void* hp[] = {nd->h_nkept, nd->h_out, nd->h_x0, nd->h_idx, nd->h_frame, nd->h_done};
     for (void* q : hp) if (q) (void)hipHostFree(q);
     for (hipEvent_t e : nd->ev) if (e) (void)hipEventDestroy(e);
     if (nd->ev_f2) (void)hipEventDestroy(nd->ev_f2);

@@ -152,6 +152,7 @@ hipError_t launch_points2(const Workspace& w, const LaunchCfg& c, const float* x
 hipError_t launch_gn_solve(const Workspace& w, const LaunchCfg& c, int iter, float* d_out, const AuxDev* auxp, hipStream_t st, int keep_pass) {
     AuxDev aux{}; if (auxp) aux = *auxp;
     aux.pair_user = c.pair_user;
+    aux.done_flag = (iter == c.runlen - 1) ? c.done_flag : nullptr;
     const KeepArgs keep{w.desc, w.keep_mask, w.keep_list, w.keep_state, c.keep_bt * c.keep_bt * c.keep_check_scale * c.keep_check_scale, c.keep_br * c.keep_br * c.keep_check_scale * c.keep_check_scale, w.keep_state ? keep_pass : 0,      // 1: build / check; 2: behind the last pass (statistics only)
                         w.keep_modes ? w.keep_modes + (size_t)((iter + 1) & 1) * c.n_pairs : nullptr, c.n_pairs};
     NearOverflow over{w.desc, w.slot_of_voxel, w.hotS, w.thr, w.near_over, w.near_over_count, c.T, c.P, c.rt2};

@@ -458,6 +458,10 @@ __device__ __forceinline__ void gn_solve_body(const int32_t* n_slots, const Slot
     if (aux.xf_last && iter == runlen - 2 && lane < kXf) aux.xf_last[pair * kXf + lane] = stage[lane];      // what the last point pass will use (`points2`)
     if (lane < 48) out[(size_t)(aux.pair_user ? aux.pair_user[pair] : pair) * 48 + lane] = stage[kXf + lane];      // (the caller's pair of this slot: ragged throughput batches)
     if (lane < 6) X[lane] = stage[kXf + lane];
+    if (aux.done_flag) {                                          // a sequential caller watches this word of pinned host memory instead of synchronising the stream: results first, then the word
+        __threadfence_system();
+        if (lane == 0) *reinterpret_cast<volatile int32_t*>(aux.done_flag) = 1;
+    }
     if (lane == 0) {
         if (aux.x_hist) for (int k = 0; k < 6; k++) aux.x_hist[((size_t)pair * runlen + iter) * 6 + k] = Xn[k];
         if (aux.htwh) for (int k = 0; k < 36; k++) aux.htwh[((size_t)pair * runlen + iter) * 36 + k] = Hm[k];

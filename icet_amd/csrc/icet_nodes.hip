@@ -13,6 +13,7 @@
 // host as in the reference: it is O(1) or inherently sequential (Fisher-Yates with one RNG stream).
 // No CPU implementation of the solve lives here; without a device every entry point fails with an error status.
 #include "../../include/icet_nodes.h"
+#include "icet_shuffle.h"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -256,6 +257,7 @@ struct icet_node {
     float X0[6] = {0, 0, 0, 0, 0, 0};
     float pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     std::mt19937 gen;                                              // default seed: simpleMapMaker.cpp:258
+    icet_shuffle::FastMt fgen; bool fast_shuffle = false;         // the same stream written out (icet_shuffle.h); used when it reproduced std::shuffle on this C++ library at creation
     std::vector<std::size_t> indices;
     float* d_map = nullptr; int64_t map_pos = 0; bool map_filled = false;
     int32_t* d_idx = nullptr; int32_t* h_idx = nullptr;
@@ -337,6 +339,16 @@ icet_status ensure_scan(icet_node* nd, int which, int64_t n) {
     NCHK(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_scan[which]), sizeof(float) * 3 * (size_t)cap));
     nd->cap_scan[which] = cap;
     return ICET_OK;
+}
+
+// The frame's down-sample indices into pinned h_idx (simpleMapMaker.cpp:147-158: iota, std::shuffle with the node's generator, the first map_downsample entries): returns
+// how many.  Only the first entries of the shuffled vector are ever used, so only they are tracked while the generator makes its n - 1 draws (icet_shuffle.h).
+int draw_downsample(icet_node* nd, int64_t nk) {
+    if (nd->fast_shuffle) icet_shuffle::head_of_shuffled_iota((std::size_t)nk, (std::size_t)nd->p.map_downsample, nd->fgen, nd->indices);
+    else icet_shuffle::head_of_shuffled_iota((std::size_t)nk, (std::size_t)nd->p.map_downsample, nd->gen, nd->indices);
+    const int m = (int)nd->indices.size();
+    for (int i = 0; i < m; i++) nd->h_idx[i] = (int32_t)nd->indices[i];
+    return m;
 }
 
 // ---- the one-launch frame (round 6) ----
@@ -485,14 +497,7 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
     bool flip_owner = false;
     std::future<int> shuffle;
     if (nd->p.map_capacity > 0 && !fused) {
-        shuffle = std::async(std::launch::async, [nd, nk]() {
-            nd->indices.resize((size_t)nk);
-            std::iota(nd->indices.begin(), nd->indices.end(), (std::size_t)0);
-            std::shuffle(nd->indices.begin(), nd->indices.end(), nd->gen);
-            const int m = (int)std::min<int64_t>(nd->p.map_downsample, nk);
-            for (int i = 0; i < m; i++) nd->h_idx[i] = (int32_t)nd->indices[i];
-            return m;
-        });
+        shuffle = std::async(std::launch::async, [nd, nk]() { return draw_downsample(nd, nk); });
     }
     std::memcpy(nd->h_x0, nd->X0, sizeof(nd->X0));
     icet_dev_scan a{nd->d_scan[nd->prev], nd->n_scan[nd->prev], nd->ld_scan[nd->prev]}, b{nd->d_scan[cur], nk, lcur};
@@ -574,12 +579,7 @@ icet_status push_frame(icet_node* nd, const float* d_scan, int64_t n, int64_t ld
         (void)hipGetLastError();
         if (*hc < 0) NCHK(nd, hipStreamSynchronize(st));
         if (*hc < 0) { nd->err = "the range filter's row count did not arrive"; if (nd->kw) (void)kf_wait_idle(nd); return ICET_ERR_HIP; }
-        const int64_t nkh = *hc;
-        nd->indices.resize((size_t)nkh);
-        std::iota(nd->indices.begin(), nd->indices.end(), (std::size_t)0);
-        std::shuffle(nd->indices.begin(), nd->indices.end(), nd->gen);
-        m_map = (int)std::min<int64_t>(nd->p.map_downsample, nkh);
-        for (int i = 0; i < m_map; i++) nd->h_idx[i] = (int32_t)nd->indices[i];                  // pinned: the map kernel reads it in place (no copy command)
+        m_map = draw_downsample(nd, (int64_t)*hc);                                                // into pinned h_idx: the map kernel reads it in place (no copy command)
     }
     if (shuffle.valid()) {
         m_map = shuffle.get();
@@ -718,6 +718,10 @@ icet_status icet_node_create(icet_ctx* ctx, const icet_node_params* p, icet_node
         hipMalloc(reinterpret_cast<void**>(&nd->d_x0), sizeof(float) * 6) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&nd->d_out), sizeof(float) * 48) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&nd->h_out), sizeof(float) * 48, hipHostMallocCoherent) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&nd->h_x0), sizeof(float) * 6) != hipSuccess)
         return fail(ICET_ERR_NOMEM);
+    if (p->map_capacity > 0) {                                    // (a few milliseconds, once per process: the written-out generator against this C++ library's std::shuffle)
+        static const bool fast_ok = icet_shuffle::matches_std_shuffle() && icet_shuffle::fast_matches_std_shuffle();
+        nd->fast_shuffle = fast_ok;
+    }
     for (hipEvent_t& e : nd->ev) if (hipEventCreate(&e) != hipSuccess) return fail(ICET_ERR_HIP);
     for (hipEvent_t& e : nd->ev_kfdone) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(ICET_ERR_HIP);
     if (!(p->flags & ICET_NODE_NO_PIPELINE)) {

@@ -238,6 +238,19 @@ def test_gather_single_process_identity():
         gather_results(x, 4, rank=0, world=1)
 
 
+def test_downsample_shuffle_head_equals_std_shuffle(tmp_path):
+    """The map maker's down-sample indices (icet_amd/csrc/icet_shuffle.h): the first entries of iota + std::shuffle and the generator's state afterwards, tracked
+    without the n-entry vector, with the library's distribution objects and with the generator and the bounded draw written out -- against std::shuffle itself, both of
+    libstdc++'s branches, 60 chained frames of random sizes (tests/cpp/test_shuffle.cpp).  The node runs the same comparison when it is created and falls back to the
+    plain form if it fails."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "cpp", "test_shuffle.cpp")
+    exe = str(tmp_path / "test_shuffle")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", src, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), (r.returncode, r.stdout, r.stderr)
+
+
 def test_multi_gpu_scheduler_with_fake_devices(tmp_path):
     """The host-side scheduler of icet_multi_* (icet_amd/csrc/icet_multi_sched.h: one thread per device, the two-phase protocol around a collective gather) driven
     on the CPU with 8 fake devices and a gather that blocks until every rank has entered it: a failure injected on one rank BEFORE the collective (by status and by

@@ -753,6 +753,7 @@ hipError_t launch_gn_accumulate(const Workspace& w, const LaunchCfg& c, hipStrea
                                                      w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count)
     if (fuse_it) {
         AuxDev aux{}; if (fuse->aux) aux = *fuse->aux;
+        aux.pair_user = c.pair_user; aux.done_flag = (fuse->iter == c.runlen - 1) ? c.done_flag : nullptr;      // (as launch_gn_solve sets them)
         const SolveFuse sf{w.fitS, w.X, fuse->d_out, aux, c.n, fuse->iter, c.runlen, c.reject_moving, c.gn_cond_bound2, w.gn_done()};
         if (c.vec4_ok) k_gn_accumulate_solve<true><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp, w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count, sf);
         else k_gn_accumulate_solve<false><<<grid, blk, lds, st>>>(w.desc, w.xf, w.slot_of_voxel, w.n_slots, w.hotS, w.acc, w.thr, lut, c.T, c.P, w.lut_Mt, w.lut_Mp, w.guard_t, w.guard_p, lds_slots, chunks, c.n_pairs, c.force_exact, w.near_over, w.near_over_count, sf);

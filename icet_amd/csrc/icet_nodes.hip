@@ -91,9 +91,15 @@ __global__ __launch_bounds__(kFB) void k_range_scan(const int32_t* __restrict__ 
 // row is: kept rows in earlier k-slices + kept rows of lower threads in its own slice.
 __global__ __launch_bounds__(kFB) void k_range_scatter(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
                                                       float min_range, const int32_t* __restrict__ bases,
-                                                      float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, const FrameDesc* __restrict__ fd = nullptr) {
+                                                      float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz, const FrameDesc* __restrict__ fd = nullptr,
+                                                      const int32_t* __restrict__ counts = nullptr, int n_blocks = 0, int32_t* __restrict__ n_kept = nullptr, int32_t* __restrict__ n_kept_copy = nullptr) {
     __shared__ int wcnt[kFRows][kFB / 64];
+    __shared__ int s_part[kFB / 64], s_tot[kFB / 64];
     if (fd) { const FrameDesc d = *fd; x = d.x; y = d.x + d.ld; z = d.x + 2 * (size_t)d.ld; n = d.n; }
+    // counts: pass 2 folded in (a one-launch frame, at most a few hundred blocks): every block adds up the counts of the blocks in front of it itself, block 0 also the
+    // total -- k_range_scan's 4.6 us launch is what the frame saves
+    int part = 0, tot = 0;
+    if (counts) for (int i = threadIdx.x; i < n_blocks; i += kFB) { const int c = counts[i]; tot += c; part += (i < (int)blockIdx.x) ? c : 0; }
     const int base = blockIdx.x * kFB * kFRows;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float vx[kFRows], vy[kFRows], vz[kFRows];
@@ -108,8 +114,18 @@ __global__ __launch_bounds__(kFB) void k_range_scatter(const float* __restrict__
         below[k] = __popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0) wcnt[k][wave] = __popcll(m);
     }
+    if (counts) {
+        for (int o = 32; o > 0; o >>= 1) { part += __shfl_down(part, o); tot += __shfl_down(tot, o); }
+        if (lane == 0) { s_part[wave] = part; s_tot[wave] = tot; }
+    }
     __syncthreads();
-    int run = bases[blockIdx.x];
+    int run;
+    if (counts) {
+        run = 0; int t = 0;
+#pragma unroll
+        for (int w = 0; w < kFB / 64; w++) { run += s_part[w]; t += s_tot[w]; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { *n_kept = t; if (n_kept_copy) { *n_kept_copy = t; __threadfence_system(); } }
+    } else run = bases[blockIdx.x];
 #pragma unroll
     for (int k = 0; k < kFRows; k++) {
         int before = 0, total = 0;
@@ -355,6 +371,10 @@ int draw_downsample(icet_node* nd, int64_t nk) {
 hipError_t filter_prologue(void* user, hipStream_t st) {          // the hook icet_register_device_n runs in front of its loop (icet_ctx_set_prologue)
     const FilterLaunch& f = *static_cast<const FilterLaunch*>(user);
     k_range_count<<<f.n_blocks, kFB, 0, st>>>(nullptr, nullptr, nullptr, 0, f.min_range, f.counts, f.fd);
+    if (f.n_blocks <= 1024) {                                     // the scan folded into the scatter (every block reads at most 4 KB of counts)
+        k_range_scatter<<<f.n_blocks, kFB, 0, st>>>(nullptr, nullptr, nullptr, 0, f.min_range, nullptr, f.o, f.o + f.ld_o, f.o + 2 * f.ld_o, f.fd, f.counts, f.n_blocks, f.d_cnt, f.h_cnt);
+        return hipGetLastError();
+    }
     k_range_scan<<<1, kFB, 0, st>>>(f.counts, f.bases, f.n_blocks, f.d_cnt, f.h_cnt);
     k_range_scatter<<<f.n_blocks, kFB, 0, st>>>(nullptr, nullptr, nullptr, 0, f.min_range, f.bases, f.o, f.o + f.ld_o, f.o + 2 * f.ld_o, f.fd);
     return hipGetLastError();

@@ -7,6 +7,7 @@
 #include "../../include/icet_hip.h"
 #include "../../include/icet_nodes.h"
 #include "icet_internal.h"
+#include "icet_layout.h"
 
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -854,37 +855,19 @@ static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t 
     if (c->desc_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_desc)); c->desc_in_flight = false; }
     if (c->graph_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_graph)); c->graph_in_flight = false; }     // a replay re-reads the pinned descriptor staging when it RUNS
     c->desc_kf_valid = c->desc_reg_valid = false;
-    // A RAGGED throughput batch is laid out XCD-balanced (round 6).  decode_block gives every block of a pair the XCD `slot % 8`, so that a pair's tables stay in one L2;
-    // with pairs of very different sizes in caller order the XCDs' shares differ -- the reference's sample scans alternate 65 536 and 131 072 rows, all small pairs on the
-    // even XCDs, all large ones on the odd ones: a step took what the odd XCDs took.  Pairs sorted by size and dealt to the slots of each group of eight in snake order
-    // give every XCD the same share to a few per cent.  The caller's order comes back in k_init_state (X0) and k_gn_solve (results): LaunchCfg::pair_user.  Same bits: a
-    // pair's result does not depend on its slot (section 6 of DESIGN.md).
+    // A RAGGED throughput batch is laid out XCD-balanced (round 6; icet_layout.h says why and how).  The caller's order comes back in k_init_state (X0) and
+    // k_gn_solve (results): LaunchCfg::pair_user.  Same bits: a pair's result does not depend on its slot (section 6 of DESIGN.md).
     c->perm_active = false; c->perm_pairs = n_pairs;
-    if (n_pairs > kUploadDescMaxPairs && p->runlen > 0) {
-        int64_t mn = INT64_MAX, mx = 0;
-        for (int k = 0; k < n_pairs; k++) { const int64_t z = scan1[k].n + scan2[k].n; mn = std::min(mn, z); mx = std::max(mx, z); }
-        c->perm_active = mx > mn + mn / 4;
-    }
     std::vector<int32_t> order((size_t)n_pairs);
     for (int k = 0; k < n_pairs; k++) order[(size_t)k] = k;
-    if (c->perm_active) {
-        std::vector<int32_t> by_size(order);
-        std::stable_sort(by_size.begin(), by_size.end(), [&](int32_t a, int32_t b) { return scan1[a].n + scan2[a].n > scan1[b].n + scan2[b].n; });
-        for (int i = 0; i < n_pairs; i++) {
-            const int g = i / 8, r = i % 8, in_group = std::min(8, n_pairs - 8 * g);
-            const int pos = (g & 1) ? in_group - 1 - r : r;                      // snake: the group's largest goes where the previous group put its smallest
-            order[(size_t)(8 * g + pos)] = by_size[(size_t)i];
+    if (n_pairs > kUploadDescMaxPairs && p->runlen > 0) {
+        std::vector<int64_t> size((size_t)n_pairs);
+        for (int k = 0; k < n_pairs; k++) size[(size_t)k] = scan1[k].n + scan2[k].n;
+        if (icet_layout::is_ragged(size)) {
+            order = icet_layout::balanced_slot_order(size);
+            for (int s = 0; s < n_pairs; s++) c->h_seg[n_pairs + 1 + s] = order[(size_t)s];
+            c->perm_active = true;
         }
-        // ... and inside an XCD's column of slots (slot % 8) large and small pairs alternate -- largest, smallest, second largest, ... -- instead of running from large to
-        // small: with all the large pairs' blocks dispatched first the point pass was 8 % slower on the reference's sample scans than with sizes mixed (blocks are dealt in slot order)
-        for (int x = 0; x < 8 && x < n_pairs; x++) {
-            std::vector<int32_t> col;
-            for (int s = x; s < n_pairs; s += 8) col.push_back(order[(size_t)s]);
-            std::stable_sort(col.begin(), col.end(), [&](int32_t a, int32_t b) { return scan1[a].n + scan2[a].n > scan1[b].n + scan2[b].n; });
-            size_t lo = 0, hi = col.size();
-            for (int s = x, t = 0; s < n_pairs; s += 8, t++) order[(size_t)s] = (t & 1) ? col[--hi] : col[lo++];
-        }
-        for (int s = 0; s < n_pairs; s++) c->h_seg[n_pairs + 1 + s] = order[(size_t)s];
     }
     for (int s = 0; s < n_pairs; s++) {
         const int k = order[(size_t)s];

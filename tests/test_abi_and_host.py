@@ -238,6 +238,18 @@ def test_gather_single_process_identity():
         gather_results(x, 4, rank=0, world=1)
 
 
+def test_ragged_batch_slot_order(tmp_path):
+    """The slot order of a ragged throughput batch (icet_amd/csrc/icet_layout.h): a permutation, every XCD's share of the rows within a few per cent of the mean where
+    the caller's order gives some XCDs twice the others', large and small pairs alternating down each XCD's column of slots (tests/cpp/test_layout.cpp; the GPU side --
+    same bits per pair, the caller's order of X0 and results -- is tests/test_gpu_parity.py::test_ragged_batch_is_laid_out_xcd_balanced_with_the_callers_order_kept)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "cpp", "test_layout.cpp")
+    exe = str(tmp_path / "test_layout")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", src, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), (r.returncode, r.stdout, r.stderr)
+
+
 def test_downsample_shuffle_head_equals_std_shuffle(tmp_path):
     """The map maker's down-sample indices (icet_amd/csrc/icet_shuffle.h): the first entries of iota + std::shuffle and the generator's state afterwards, tracked
     without the n-entry vector, with the library's distribution objects and with the generator and the bounded draw written out -- against std::shuffle itself, both of

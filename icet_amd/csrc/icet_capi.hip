@@ -84,6 +84,10 @@ struct icet_ctx {
     // ... and have the LAST solve of the next icet_register_device_n call store 1 into a word of (coherent) pinned host memory once the results are written: the caller
     // watches that word instead of synchronising the stream (icet_ctx_set_done_flag; part of the graph key)
     int32_t* done_flag = nullptr;
+    // icet_sync after ONE small device-resident solve (icet_solve_batch_device, replayed graph) watches a word of its own the same way: h_sync_word, raised by that solve's
+    // last kernel.  armed_calls counts such solves since the last icet_sync; anything else enqueued on the context (or a second solve, whose reset of the word races with the
+    // first one's store) makes it 2 or more and icet_sync synchronises the stream as before.
+    int32_t* h_sync_word = nullptr; int armed_calls = 2;
 };
 
 namespace {
@@ -627,6 +631,8 @@ icet_status icet_create(icet_ctx** out, int device_id, void* hip_stream) {
         if (hipMalloc(reinterpret_cast<void**>(&d_t), sizeof(int32_t)) == hipSuccess) { if (lds_rank_selftest(d_t, c->stream, &ok) != hipSuccess) { ok = 0; (void)hipGetLastError(); } (void)hipFree(d_t); }
         c->lds_rank_ok = ok;
     }
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_sync_word), sizeof(int32_t), hipHostMallocCoherent) == hipSuccess) *c->h_sync_word = 0;      // (without it icet_sync synchronises the stream)
+    else { c->h_sync_word = nullptr; (void)hipGetLastError(); }
     *out = c;
     return ICET_OK;
 }
@@ -646,6 +652,7 @@ icet_status icet_destroy(icet_ctx* c) {
     if (c->d_pts2) (void)hipFree(c->d_pts2);
     for (void* q : {(void*)c->d_sph1, (void*)c->d_idx1, (void*)c->d_sph2, (void*)c->d_vox2}) if (q) (void)hipFree(q);
     if (c->h_x0) (void)hipHostFree(c->h_x0);
+    if (c->h_sync_word) (void)hipHostFree(c->h_sync_word);
     for (hipEvent_t e : {c->ev_s2, c->ev_kf, c->ev_kfd, c->ev_prev, c->ev_pts2}) if (e) (void)hipEventDestroy(e);
     if (c->st_copy) (void)hipStreamDestroy(c->st_copy);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
@@ -670,7 +677,17 @@ icet_status icet_destroy(icet_ctx* c) {
 
 icet_status icet_sync(icet_ctx* c) {
     if (!c) return ICET_ERR_BAD_ARG;
+    if (c->armed_calls == 1 && c->h_sync_word) {
+        // exactly one small solve is in flight and its last kernel raises h_sync_word behind its results: watch the word (hipStreamSynchronize answers several
+        // microseconds after the queue has drained), asking the stream only now and then so that a failed launch still ends the wait
+        volatile int32_t* w = c->h_sync_word;
+        for (long spins = 1; *w == 0; spins++)
+            if ((spins & 8191) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) break;
+        (void)hipGetLastError();
+        if (*w != 0) { __atomic_thread_fence(__ATOMIC_ACQUIRE); c->armed_calls = 0; return ICET_OK; }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->armed_calls = 0;
     return ICET_OK;
 }
 
@@ -741,6 +758,7 @@ icet_status icet_solve_batch_device(icet_ctx* c, const icet_params* p, int32_t n
     const int parts = (p->runlen == 0) ? 1 : batch_parts(c, p, n_pairs);
     auto range_tot = [&](int b, int e) { int64_t t = 0; for (int k = b; k < e; k++) t += scan1[k].n; return t; };
     if (parts == 1) return solve_device_part(c, p, n_pairs, scan1, scan2, d_x0, d_out, range_tot(0, n_pairs));
+    c->armed_calls = 2;
     { icet_status s = ensure_helpers(c, parts); if (s != ICET_OK) return s; }
     // fork: helpers start after whatever the caller queued on this context's stream (e.g. the writes of the scans)
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -876,12 +894,18 @@ static icet_status solve_device_part(icet_ctx* c, const icet_params* p, int32_t 
         d.n1 = (int32_t)scan1[k].n; d.ld1 = (int32_t)scan1[k].ld; d.n2 = (int32_t)scan2[k].n; d.ld2 = (int32_t)scan2[k].ld;
         d.off1 = 0; d.off2 = 0;
     }
-    if (p->runlen == 0) return write_runlen0(c, n_pairs, d_x0, d_out);
+    if (p->runlen == 0) { c->armed_calls = 2; return write_runlen0(c, n_pairs, d_x0, d_out); }
     if (graph_eligible(c, p, n_pairs)) {
         icet_status ts = ensure_thresholds(c, p->bins_theta, p->bins_phi);
         if (ts != ICET_OK) return ts;
-        return run_or_replay(c, c->g_solve, graph_key_of(c, p, n_pairs, d_x0, d_out, nullptr, nullptr), [&]() { return enqueue(c, p, n_pairs, d_x0, d_out, nullptr); });
+        // (the solve's last kernel raises the context's sync word: icet_sync)
+        const bool own_word = !c->done_flag && c->h_sync_word;
+        if (own_word) { if (c->armed_calls == 0) *static_cast<volatile int32_t*>(c->h_sync_word) = 0; c->done_flag = c->h_sync_word; }
+        const icet_status rs = run_or_replay(c, c->g_solve, graph_key_of(c, p, n_pairs, d_x0, d_out, nullptr, nullptr), [&]() { return enqueue(c, p, n_pairs, d_x0, d_out, nullptr); });
+        if (own_word) { c->done_flag = nullptr; c->armed_calls = (rs == ICET_OK && c->g_solve.have_graph) ? c->armed_calls + 1 : 2; }
+        return rs;
     }
+    c->armed_calls = 2;
     return enqueue(c, p, n_pairs, d_x0, d_out, nullptr);
 }
 
@@ -899,7 +923,7 @@ icet_status icet_keyframe_device_n(icet_ctx* c, const icet_params* p, int32_t n_
         tot1 += a.n;
     }
     HIPCHK(c, hipSetDevice(c->device));
-    c->kf_pairs = 0; c->perm_active = false;
+    c->kf_pairs = 0; c->perm_active = false; c->armed_calls = 2;
     icet_status s = ensure_workspace(c, p, n_pairs, tot1, 0);
     if (s != ICET_OK) return s;
     // A sequential caller hands the SAME buffers to this half frame after frame (include/icet_nodes.h): the pinned descriptor staging then already holds
@@ -947,6 +971,7 @@ icet_status icet_register_device_n(icet_ctx* c, const icet_params* p, int32_t n_
         tot2 += b.n;
     }
     HIPCHK(c, hipSetDevice(c->device));
+    c->armed_calls = 2;
     if (p->runlen == 0) return write_runlen0(c, n_pairs, d_x0, d_out);
     icet_status s = ensure_workspace(c, p, n_pairs, 0, tot2);              // only the scan-2 overflow list can grow here: the keyframe tables stay
     if (s != ICET_OK) return s;
@@ -1012,7 +1037,7 @@ icet_status icet_solve_batch(icet_ctx* c, const icet_params* p, int32_t n_pairs,
     };
     if (p->runlen == 0) s = write_runlen0(c, n_pairs, dx0, c->d_out);
     else {
-        c->kf_pairs = 0; c->perm_active = false;
+        c->kf_pairs = 0; c->perm_active = false; c->armed_calls = 2;
         s = enqueue_keyframe(c, p, n_pairs, nullptr);
         if (s == ICET_OK) {
             const hipError_t e = upload_scan2s();
@@ -1113,7 +1138,7 @@ icet_status icet_solve_begin(icet_ctx* c, const icet_params* p, const float* sca
             q.scan2 = scan2; q.ld2 = ld2;
             if (!want_pts2 && !want_side2) ad.xf_last = nullptr;
         }
-        c->kf_pairs = 0; c->perm_active = false;
+        c->kf_pairs = 0; c->perm_active = false; c->armed_calls = 2;
         st = enqueue_keyframe(c, p, 1, aux ? &ad : nullptr);
         if (st == ICET_OK && want_side1) {                                     // points1Spherical / pointIndices1 from the tables the keyframe build has just left
             const LaunchCfg scfg = make_cfg(c, p, 1);

@@ -173,6 +173,8 @@ icet_status icet_solve_batch(icet_ctx* ctx, const icet_params* p, int32_t n_pair
 icet_status icet_solve_batch_device(icet_ctx* ctx, const icet_params* p, int32_t n_pairs,
                                     const icet_dev_scan* scan1, const icet_dev_scan* scan2,
                                     const float* d_x0, float* d_out);
+/* Waits until everything this context has enqueued is done.  Behind exactly one small icet_solve_batch_device call (<= 8 pairs: a replayed graph) it watches a word of
+ * pinned memory that the solve's last kernel raises behind its results instead of synchronising the stream (10 us sooner on this part); otherwise hipStreamSynchronize. */
 icet_status icet_sync(icet_ctx* ctx);
 
 /* --- the same solve in two halves, for the sequential callers (src/odometry.cpp:73-88: scan 2 of one frame is scan 1 of the next) ---

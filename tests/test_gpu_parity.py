@@ -436,6 +436,43 @@ def test_fast_classification_equals_literal_evaluation(gpu_ctx, frames, sample_p
             gpu_ctx.set_option("force_exact", 0)
 
 
+def test_sync_after_small_device_solves(gpu_ctx):
+    """Round 6: icet_sync behind exactly ONE small icet_solve_batch_device call watches a word of pinned memory that the solve's last kernel raises behind its results
+    (icet_capi.hip: armed_calls) instead of synchronising the stream; two calls in flight, or any other entry on the context in between, take the stream synchronisation.
+    Whatever the path, the results behind an icet_sync must be complete: alternating one / two / three solves per sync on different pairs and X0s, with a keyframe / register
+    pair of calls and a large batch in between, every output compared with the pair solved alone."""
+    from icet_amd import lidar_sim as ls, api
+    import icet_amd
+    dev = torch.device("cuda", 0)
+    pairs = [ls.make_batch_pair(k, device=dev)[:2] for k in range(3)]
+    desc = [([(a.data_ptr(), a.shape[1], a.shape[1])], [(b.data_ptr(), b.shape[1], b.shape[1])]) for a, b in pairs]
+    p = api.Params(4, 24, 75, 25, 0.1, 0.1, 0)
+    ref = [gpu_ctx.solve(a.T.cpu().numpy(), b.T.cpu().numpy(), 4, np.zeros(6), 24, 75) for a, b in pairs]
+    ctx = icet_amd.Context(0)
+    outs = [torch.full((1, 48), float("nan"), dtype=torch.float32, device=dev) for _ in range(3)]
+    pattern = [1, 1, 2, 1, 3, 1, 1, 2, 1]
+    k = 0
+    for rep, m in enumerate(pattern):
+        used = []
+        for _ in range(m):
+            j = k % 3; k += 1
+            outs[j].fill_(float("nan")); torch.cuda.synchronize()
+            ctx.solve_batch_device(desc[j][0], desc[j][1], p, outs[j].data_ptr()); used.append(j)
+        ctx.sync()
+        for j in used:
+            got = outs[j].cpu().numpy()[0]
+            assert np.array_equal(got[:6], ref[j]["X"]) and np.array_equal(got[6:12], ref[j]["pred_stds"]), (rep, j)
+        if rep == 3:                                                   # the two halves on the same context, then a batch too large for the graph path
+            o = torch.zeros((1, 48), dtype=torch.float32, device=dev)
+            ctx.keyframe_device(desc[0][0], p); ctx.register_device(desc[0][1], p, o.data_ptr()); ctx.sync()
+            assert np.array_equal(o.cpu().numpy()[0, :6], ref[0]["X"])
+            big1 = desc[1][0] * 12; big2 = desc[1][1] * 12
+            ob = torch.zeros((12, 48), dtype=torch.float32, device=dev)
+            ctx.solve_batch_device(big1, big2, p, ob.data_ptr()); ctx.sync()
+            assert np.array_equal(ob.cpu().numpy()[7, :6], ref[1]["X"])
+    ctx.close()
+
+
 def test_ragged_batch_is_laid_out_xcd_balanced_with_the_callers_order_kept(gpu_ctx):
     """Round 6: a throughput batch (> 64 pairs) whose pairs differ in size by more than a quarter is sorted by size and dealt to the slots of every group of eight
     in snake order (every XCD the same share; icet_capi.hip solve_device_part) -- the caller's order comes back in k_init_state (X0) and k_gn_solve (results).  A pair's

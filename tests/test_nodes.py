@@ -201,6 +201,11 @@ def test_gpu_one_launch_frame_equals_phased_frame(gpu_ctx, seq64):
     fr = [(b.data_ptr(), b.shape[1], b.shape[1]) for b in bufs]
     def same(a, b):
         return all(np.array_equal(a[k], b[k]) for k in ("X", "pred_stds", "pose", "quat")) and a["solved"] == b["solved"] and a["n_kept"] == b["n_kept"] and a["diverged"] == b["diverged"]
+    # (the keyframe side of a one-launch frame enqueued by the calling thread instead of the helper: ICET_NODE_SERIAL_ENQUEUE)
+    ser, ref = api.Node(gpu_ctx, **dict(api.ODOMETRY_NODE, flags=api.NODE_SERIAL_ENQUEUE)), api.Node(gpu_ctx, **api.ODOMETRY_NODE)
+    for k, f in enumerate(fr[:6]):
+        assert same(ser.push_device(*f), ref.push_device(*f)), k
+    ser.close(); ref.close()
     for extra in (dict(), dict(seed_x0=0), dict(min_range=6.0, runlen=3)):
         kw = dict(api.ODOMETRY_NODE); kw.update(extra)
         one, ph = api.Node(gpu_ctx, **kw), api.Node(gpu_ctx, **dict(kw, flags=api.NODE_TIME_PHASES))

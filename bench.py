@@ -273,9 +273,13 @@ def main(argv=None):
         for ln in child.stdout.splitlines():
             if not ln.startswith("{\"metric\""):
                 print(ln, file=sys.stderr)
+        if lines: print(lines[-1], flush=True)                 # (also from a run that ends non-zero: the gloo fallback prints its line, then its ranks exit 3)
         if child.returncode != 0 or not lines:
-            raise SystemExit(child.returncode or 1)
-        print(lines[-1], flush=True)
+            rc = child.returncode or 1
+            try:
+                if lines and json.loads(lines[-1])["config"].get("rccl_ranks") == 0: rc = 3      # the launcher reports 1 for ranks that exited 3
+            except (ValueError, KeyError): pass
+            raise SystemExit(rc)
         return 0
     if args.workload in ("odometry", "mapmaker"):
         if not torch.cuda.is_available():

@@ -147,12 +147,15 @@ def run_nodes(args):
     A step is ONE lidar frame pushed from HBM: range filter -> ICET(prev, cur) -> pose chain (-> 600k-row map update).
     Sequential by construction (frame k+1 needs frame k's X): N > 1 runs independent replicas."""
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("ICET_BENCH_SHARE_DEVICE"): local_rank = int(os.environ["ICET_BENCH_SHARE_DEVICE"])      # rehearsal hook (several ranks on one card), as in main()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("ICET_BENCH_BACKEND", "nccl")
+        if backend == "nccl": dist.init_process_group(backend="nccl", device_id=dev)
+        else: dist.init_process_group(backend=backend)
     import icet_amd
     from icet_amd import lidar_sim, api
     kw = dict(api.ODOMETRY_NODE if args.workload == "odometry" else api.MAP_MAKER_NODE)
@@ -183,7 +186,7 @@ def run_nodes(args):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+        tt = torch.tensor([dt], dtype=torch.float64, device=(dev if dist.get_backend() == "nccl" else "cpu")); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
     for key in tim: tim[key] /= max(args.steps, 1)
     if world == 1:
         # a pipelined frame is one graph launch (filter + loop together, no timing events): the phases are timed on a second node that keeps them apart (ICET_NODE_TIME_PHASES)

@@ -379,13 +379,14 @@ def test_gpu_scan_registration_node_matches_oracle(gpu_ctx, seq64):
 
 
 @pytest.mark.gpu
-def test_gpu_nodes_random_settings_and_hostile_frames(gpu_ctx):
-    """15 seeded draws (tests/param_sweep.draw_node_case; 60 more by hand, scripts/fuzz_nodes.py -> profiles/r05_fuzz_nodes.txt): odometry / map-maker / registration
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_gpu_nodes_random_settings_and_hostile_frames(gpu_ctx, seed):
+    """(Three seeds in the suite since round 6 rewrote the frame path.)  15 seeded draws (tests/param_sweep.draw_node_case; 60 more by hand, scripts/fuzz_nodes.py -> profiles/r05_fuzz_nodes.txt, 330 in profiles/r06_fuzz_final_pass.txt): odometry / map-maker / registration
     settings with random runlen, min_range, minimum points, guard thresholds and queue sizes, over short drives in which frames are replaced by hostile ones -- an empty
     cloud, a cloud entirely inside min_range, a cloud of a few rows, zero and NaN rows, the same cloud twice.  Frame by frame the device node takes the oracle node's
     decisions (solved, diverged, kept rows, map rows; finite X where the oracle's is); and the same frames as ONE device burst give the bits of the frame-by-frame pushes."""
     from tests.param_sweep import draw_node_case, run_node_case
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(seed)
     for c in range(15):
         kw, frames = draw_node_case(rng)
         bad = run_node_case(gpu_ctx, kw, frames)

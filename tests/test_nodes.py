@@ -236,6 +236,37 @@ def test_gpu_one_launch_frame_equals_phased_frame(gpu_ctx, seq64):
 
 
 @pytest.mark.gpu
+def test_gpu_one_launch_frame_soak(gpu_ctx):
+    """A thousand frames through the one-launch path (helper thread, pinned done word, folded filter, ragged row counts) against the phased node, bit for bit, and two
+    nodes driven from two host threads at once against one node alone (scripts/node_soak.py runs thousands more; profiles/r06_node_soak.txt)."""
+    import threading
+    import icet_amd
+    from icet_amd import api, lidar_sim as ls
+    dev = torch.device("cuda", 0)
+    frames = ls.make_sequence(24, motion=(0.25, 0.02, 0.005, 0.001, -0.001, 0.006), rings=32, steps=1024, device=dev)
+    frames = [f if k % 5 else f[:, : f.shape[1] - 97 * (k % 7)].contiguous() for k, f in enumerate(frames)]
+    a, b = api.Node(gpu_ctx, **api.ODOMETRY_NODE), api.Node(gpu_ctx, **dict(api.ODOMETRY_NODE, flags=api.NODE_TIME_PHASES))
+    ref = []
+    for k in range(1000):
+        f = frames[(k * 7) % len(frames)]
+        ra, rb = a.push_device(f.data_ptr(), f.shape[1], f.shape[1]), b.push_device(f.data_ptr(), f.shape[1], f.shape[1])
+        assert np.array_equal(ra["X"], rb["X"]) and np.array_equal(ra["pred_stds"], rb["pred_stds"]) and ra["n_kept"] == rb["n_kept"], k
+        ref.append(ra["X"].copy())
+    a.close(); b.close()
+    bad = [0, 0]
+    def drive(i):
+        c = icet_amd.Context(0); nd = api.Node(c, **api.ODOMETRY_NODE)
+        for k in range(400):
+            f = frames[(k * 7) % len(frames)]
+            if not np.array_equal(nd.push_device(f.data_ptr(), f.shape[1], f.shape[1])["X"], ref[k]): bad[i] += 1
+        nd.close(); c.close()
+    ts = [threading.Thread(target=drive, args=(i,)) for i in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert bad == [0, 0]
+
+
+@pytest.mark.gpu
 def test_gpu_map_maker_node_matches_oracle(gpu_ctx, seq64):
     from oracle import pyoracle as po
     from icet_amd import api

@@ -470,6 +470,12 @@ def test_sync_after_small_device_solves(gpu_ctx):
             ob = torch.zeros((12, 48), dtype=torch.float32, device=dev)
             ctx.solve_batch_device(big1, big2, p, ob.data_ptr()); ctx.sync()
             assert np.array_equal(ob.cpu().numpy()[7, :6], ref[1]["X"])
+    # six hundred solve / sync cycles in a row (the watched word is reset and raised every time), the output cleared in between
+    for k in range(600):
+        j = k % 3
+        outs[j].zero_(); torch.cuda.synchronize()
+        ctx.solve_batch_device(desc[j][0], desc[j][1], p, outs[j].data_ptr()); ctx.sync()
+        assert np.array_equal(outs[j].cpu().numpy()[0, :6], ref[j]["X"]), k
     ctx.close()
 
 

@@ -609,6 +609,7 @@ struct GnTailWs {
     float H[36], g[6];                                            // in
     float cov[36], ps[6], dx[6], ev[6]; int pruned, rank;         // out
     float U2[36], L2[36], lam[36], U2t[36], T1[36], innards[36], inv[36], T2[36], lhs[36];
+    float H1[36]; int rank1;                                       // the helper wave's copy of H and the rank it found (gn_tail_literal<true>)
 #ifdef ICET_TAIL_TIMING
     unsigned long long ts[8];                                     // diagnostic build: wall_clock64 at the phase boundaries of gn_tail_literal
 #endif
@@ -832,12 +833,15 @@ __device__ inline int cod_pinv_c6_wave(const float* Ain, int rows_in, float* pin
 
 // src/icet.cpp:410-430 for the (H, g) in the workspace: cov = noise_mat, ps = pred_stds (after checkCondition's additions), dx, ev = eigenvalues
 // ascending, pruned = number of pruned axes, rank = the COD rank of HTWH.  Call from a WHOLE wave (wave-uniform control flow).
-__device__ __noinline__ void gn_tail_literal(GnTailWs& w) {
+// kHelper: a SECOND wave of the block takes pinv(HTWH) (gn_tail_literal_helper) while this one runs the eigen-decomposition -- the two do not depend on each other --
+// and raises *pinv_done when cov and the rank are in the workspace (round 6: 6.5 us of the route's 32 per evaluation).
+template <bool kHelper = false>
+__device__ __noinline__ void gn_tail_literal(GnTailWs& w, volatile int* pinv_done = nullptr) {
 #pragma clang fp contract(off)
     const int lane = (int)(threadIdx.x & 63u);
     ICET_TS(0);
-    const int rank = cod_pinv_c6_wave(w.H, 6, w.cov, lane);
-    ICET_WSYNC();
+    int rank = 0;
+    if (!kHelper) { rank = cod_pinv_c6_wave(w.H, 6, w.cov, lane); ICET_WSYNC(); }
     ICET_TS(1);
     float* U2 = w.U2;
     float ev[6], Qrow[6];
@@ -848,6 +852,11 @@ __device__ __noinline__ void gn_tail_literal(GnTailWs& w) {
         eig6_sym_wave(Hr, ev, Qrow, lane);                            // every lane: the eigenvalues; lane r < 6: row r of the eigenvectors
     }
     ICET_TS(2);
+    if (kHelper) {                                                // cov (and the rank) come from the helper wave
+        while (*pinv_done == 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        rank = w.rank1;
+    }
     int k0 = 0;
     {
         // checkCondition (src/icet.cpp:443-492), one lane per entry of pred_stds: the pruning loop runs on the eigenvalues every lane holds
@@ -887,6 +896,21 @@ __device__ __noinline__ void gn_tail_literal(GnTailWs& w) {
     mm_seq(w.T2, 6, 6, w.U2t, 6, w.lhs, lane);
     mm_seq(w.lhs, 6, 6, w.g, 1, w.dx, lane);                                                 // src/icet.cpp:430
     ICET_TS(6);
+}
+// The helper wave's share (every lane holds the same Hm): noise_mat = pinv(HTWH) into the workspace, then the flag.
+__device__ __noinline__ void gn_tail_literal_helper(const float* Hm, GnTailWs& w, volatile int* pinv_done) {
+#pragma clang fp contract(off)
+    const int lane = (int)(threadIdx.x & 63u);
+    if (lane < 36) { float v = Hm[0];
+#pragma unroll
+        for (int k = 1; k < 36; k++) v = (lane == k) ? Hm[k] : v;
+        w.H1[lane] = v; }
+    ICET_WSYNC();
+    const int rank = cod_pinv_c6_wave(w.H1, 6, w.cov, lane);
+    if (lane == 0) w.rank1 = rank;
+    ICET_WSYNC();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) *pinv_done = 1;
 }
 #undef ICET_TS
 #undef ICET_WSYNC

@@ -55,14 +55,20 @@ __device__ __forceinline__ void write_xf(float* xf, const float X[6]) {
 // gn_tail_literal), which decides rank, pruning and eigenvector signs exactly as the reference's algorithms do on the same bits.
 // `ws`: the literal route's workspace in LDS; `leader`: the one lane of the wave that fills in the matrix (the whole wave then walks the workspace and
 // reads the results, so that the outputs are wave-uniform on either route).  Must be called by a whole wave, every lane with the same matrix.
-__device__ __forceinline__ void gn_tail(const float* Hm, const float* g, float bound2, float* cov, float* ps, float* dx, float* ev, int& route, int& pruned,
-                                        icetdev::GnTailWs& ws, bool leader) {
+// (is the Cholesky route enough?  `cov` = the inverse when it is)
+__device__ __forceinline__ bool gn_tail_plain(const float* Hm, float bound2, float* cov) {
     bool plain = icetdev::chol6_inverse(Hm, cov);
     if (plain) {
         float fa = 0.f, fi = 0.f;
         for (int k = 0; k < 36; k++) { fa += Hm[k] * Hm[k]; fi += cov[k] * cov[k]; }
         plain = fa * fi <= bound2;                                  // (false for NaN)
     }
+    return plain;
+}
+// pinv_done != nullptr: a second wave of the block runs gn_tail_helper on the same matrix beside this call (gn_solve_body)
+__device__ __forceinline__ void gn_tail(const float* Hm, const float* g, float bound2, float* cov, float* ps, float* dx, float* ev, int& route, int& pruned,
+                                        icetdev::GnTailWs& ws, bool leader, volatile int* pinv_done = nullptr) {
+    bool plain = gn_tail_plain(Hm, bound2, cov);
     if (plain) {
         for (int k = 0; k < 6; k++) ps[k] = sqrtf(fabsf(cov[k * 6 + k]));         // src/icet.cpp:412-417
         for (int a = 0; a < 6; a++) { float t = 0.f; for (int b = 0; b < 6; b++) t += cov[a * 6 + b] * g[b]; dx[a] = t; }
@@ -74,13 +80,20 @@ __device__ __forceinline__ void gn_tail(const float* Hm, const float* g, float b
             for (int k = 0; k < 6; k++) ws.g[k] = g[k];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-        icetdev::gn_tail_literal(ws);                                // the whole wave walks the workspace (`plain` is wave-uniform: every lane holds the same matrix)
+        if (pinv_done) icetdev::gn_tail_literal<true>(ws, pinv_done); else icetdev::gn_tail_literal<false>(ws);      // the whole wave works (`plain` is wave-uniform: every lane holds the same matrix)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         for (int k = 0; k < 36; k++) cov[k] = ws.cov[k];
         for (int k = 0; k < 6; k++) { ps[k] = ws.ps[k]; dx[k] = ws.dx[k]; ev[k] = ws.ev[k]; }
         pruned = ws.pruned;
         route = 2;
     }
+}
+
+// The second wave's share of the 6 x 6 tail: the same decision on the same matrix; on the literal route pinv(HTWH) while the first wave runs the eigen-decomposition.
+__device__ __forceinline__ void gn_tail_helper(const float* Hm, float bound2, icetdev::GnTailWs& ws, volatile int* pinv_done) {
+    float cov[36];
+    if (gn_tail_plain(Hm, bound2, cov)) return;                     // the first wave takes the Cholesky route and waits for nobody
+    icetdev::gn_tail_literal_helper(Hm, ws, pinv_done);
 }
 
 // Undecided scan-2 points that did not fit a block's LDS queue in k_gn_accumulate (see there): literal classification, each a
@@ -406,15 +419,35 @@ __device__ __forceinline__ void gn_solve_body(const int32_t* n_slots, const Slot
     }
     if (ICET_SOLVE_PHASE == 2) { float t = 0.f; for (int k = 0; k < 27; k++) t += S[k]; if (t == 1.2345e-30f) out[0] = t; return; }
     if (kStage == 1) return;
+    // Two waves stay for the 6 x 6 part: the first does what it always did; the second waits for the matrix and, on the literal route, takes pinv(HTWH) beside the first
+    // wave's eigen-decomposition (two words in LDS hand over: the matrix is staged / the pseudo-inverse is in the workspace).
+    __shared__ int s_tail_flag[3];                                  // [0] the sums are staged, [1] the pseudo-inverse is in the workspace, [2] the second wave has read the sums
+    if (threadIdx.x == 0) { s_tail_flag[0] = 0; s_tail_flag[1] = 0; s_tail_flag[2] = 0; }
     if (!kCanon) {
 #pragma unroll
         for (int k = 0; k < 27; k++) { float t = wave_total(S[k]); if (lane == 0 && wave < kT / 64) red[wave][k] = t; }      // DPP scan, not 6 x 27 trips through the LDS crossbar
-        __syncthreads();
     }
-    if (wave != 0) return;
+    __syncthreads();
+    if (wave > 1) return;
+    volatile int* tail_flag = s_tail_flag;
     // The 6 x 6 part runs on lane 0 of the first wave; its lanes assemble the input and write the results out (one lane doing the
     // 27 four-way sums and ~100 scalar stores was a quarter of the tail).
     __shared__ float stage[kXf + 48];                               // transform record | X, pred_stds, covariance
+    __shared__ icetdev::GnTailWs tail_ws;
+    if (wave == 1) {
+        while (tail_flag[0] == 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        float Hh[36];
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) { const float t = stage[q]; Hh[a * 6 + b] = t; Hh[b * 6 + a] = t; q++; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (lane == 0) tail_flag[2] = 1;                            // (the first wave reuses `stage` for its results)
+        gn_tail_helper(Hh, cond_bound2, tail_ws, tail_flag + 1);
+        return;
+    }
     if (lane < 27) {
         float t = 0.f;
         if (kCanon) {                                               // the virtual blocks in index order, from wherever they were reduced
@@ -425,6 +458,8 @@ __device__ __forceinline__ void gn_solve_body(const int32_t* n_slots, const Slot
         stage[lane] = t;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) tail_flag[0] = 1;                                // the second wave may read the sums
     float Hm[36], g[6];
     {
         int q = 0;
@@ -439,13 +474,13 @@ __device__ __forceinline__ void gn_solve_body(const int32_t* n_slots, const Slot
     if (ICET_SOLVE_PHASE == 3) { float t = 0.f; for (int k = 0; k < 36; k++) t += Hm[k]; if (t == 1.2345e-30f) out[0] = t; return; }
     float ev[6], cov[36], ps[6], dx[6];
     int route, pruned;
-    __shared__ icetdev::GnTailWs tail_ws;
-    gn_tail(Hm, g, cond_bound2, cov, ps, dx, ev, route, pruned, tail_ws, lane == 0);
+    gn_tail(Hm, g, cond_bound2, cov, ps, dx, ev, route, pruned, tail_ws, lane == 0, tail_flag + 1);
     // (every lane of the wave ran the scalar algebra above on the same inputs -- a wave costs what a lane costs -- so the results are
     // wave-uniform; lane 0 stages them and the lanes store them)
     if (ICET_SOLVE_PHASE == 4) { float t = 0.f; for (int k = 0; k < 36; k++) t += cov[k]; for (int k = 0; k < 6; k++) t += dx[k] + ps[k]; if (t == 1.2345e-30f) out[0] = t; return; }
     float Xn[6];
     for (int k = 0; k < 6; k++) Xn[k] = X[k] + dx[k];
+    while (tail_flag[2] == 0) __builtin_amdgcn_s_sleep(1);          // (long since: the second wave read the sums before this wave's Cholesky attempt was over)
     if (lane == 0) {
         write_xf(stage, Xn);
         float* r = stage + kXf;

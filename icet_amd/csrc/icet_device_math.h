@@ -601,7 +601,8 @@ __device__ inline void cod_pinv3_lane(const float Ain[9], float pinv[9]) {
 // (|lambda_k| > 6 eps lambda_max) for the rank here; scripts/rank_rule_study.py finds it disagreeing with the pivot rule on 35 of 8400
 // matrices around cond = 1.4e6 = 1 / (6 eps), right above checkCondition's cutoff.
 // Rare by construction (a tunnel, a single wall, open ground).  Rounds 4-5 wrote it for fidelity with generic small matrices in an LDS workspace (67 us per
-// evaluation); round 6 moved the two decompositions into registers (eig6_sym_wave, cod_pinv_c6_wave: 32 us, the same bits).
+// evaluation); round 6 moved the two decompositions into registers (eig6_sym_wave, cod_pinv_c6_wave: 32 us, the same bits) and the first pseudo-inverse onto a second
+// wave beside the eigen-decomposition (gn_tail_literal<true> / gn_tail_literal_helper: 26 us).
 
 // What the phases of the literal tail hand to each other lives in ONE workspace the caller places in LDS: input, results, and the operands of the small products
 // (no scratch memory in the kernels that hold this rarely taken branch).

@@ -491,7 +491,8 @@ __device__ __forceinline__ void gn_solve_body(const int32_t* n_slots, const Slot
     if constexpr (kStage != 1 && kBlockT == kT) { if (keep.on == 1) keep_budget_check(keep, pair, stage, s_keep_ref, lane, keep_n); }
     if (lane < kXf) xf_all[pair * kXf + lane] = stage[lane];
     if (aux.xf_last && iter == runlen - 2 && lane < kXf) aux.xf_last[pair * kXf + lane] = stage[lane];      // what the last point pass will use (`points2`)
-    if (lane < 48) out[(size_t)(aux.pair_user ? aux.pair_user[pair] : pair) * 48 + lane] = stage[kXf + lane];      // (the caller's pair of this slot: ragged throughput batches)
+    // (the results of the LAST iteration are what a caller reads; a sequential caller's `out` is pinned host memory, where every iteration's 48 stores cross PCIe before the kernel can end)
+    if (lane < 48 && iter == runlen - 1) out[(size_t)(aux.pair_user ? aux.pair_user[pair] : pair) * 48 + lane] = stage[kXf + lane];      // (the caller's pair of this slot: ragged throughput batches)
     if (lane < 6) X[lane] = stage[kXf + lane];
     if (aux.done_flag) {                                          // a sequential caller watches this word of pinned host memory instead of synchronising the stream: results first, then the word
         __threadfence_system();
